@@ -1,0 +1,214 @@
+/* rcgpu.h -- C ABI of the MI355X-native FFV1 + FLAC encode path for RAWcooked.
+ *
+ * This library replaces the one hot path of MediaArea/RAWcooked that the reference delegates to an
+ * external `ffmpeg` process: `int Value = system(Command.c_str());` at Source/CLI/Output.cpp:356
+ * (command assembled at Output.cpp:81-310).  Everything here is extern "C", plain pointers and sizes.
+ * See INTEGRATION.md for the patch a RAWcooked maintainer would apply, and for the argv-compatible
+ * shim (`rcgpu-ffmpeg`) that works with an unmodified rawcooked through `--bin-name`.
+ *
+ * All `file:line` citations are relative to /root/reference/Source.
+ *
+ * Error convention (all functions returning int): 0 = ok, >0 = error; rcgpu_last_error() returns a
+ * thread-local, NUL-terminated description.  Nothing throws across this boundary.
+ */
+#ifndef RCGPU_H
+#define RCGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===========================================================================================
+ * 0. Library
+ * ======================================================================================== */
+const char* rcgpu_version(void);       /* "rcgpu <x.y> ..."; the shim prints it for `-version` (CLI/Main.cpp:751-774) */
+const char* rcgpu_last_error(void);    /* thread-local static storage */
+int         rcgpu_device_count(void);  /* number of visible HIP devices (0 when there is none) */
+
+/* ===========================================================================================
+ * 1. Job level -- replaces output::FFmpeg_Command's system() call (CLI/Output.cpp:36-378)
+ * ======================================================================================== */
+typedef struct {
+    const char* path_or_template;   /* stream::FileName_Template or FileName (CLI/Output.h:23-24), printf-style %0Nd */
+    const char* start_number;       /* stream::FileName_StartNumber (Output.h:25); NULL for a single file */
+    const char* filelist;           /* stream::FileList, '\n' separated paths (Output.h:27); NULL if none */
+    const char* flavor;             /* stream::Flavor, e.g. "DPX/Raw/RGB/16bit/U/BE" (Lib/Common/Common.cpp:123-157); may be NULL: probed */
+    const char* framerate;          /* decimal or "n/d" (Output.cpp:58-79,149-160) */
+    uint32_t    slices;             /* stream::Slices (slice_x*slice_y) or user -slices; 0 = audio */
+    int         vflip;              /* `-vf vflip` (CLI/Main.cpp:207-211) */
+} rcgpu_stream;
+
+typedef struct {
+    const char* path_in;            /* attachment::FileName_In  (Output.h:36) */
+    const char* name_out;           /* attachment::FileName_Out (Output.h:37) */
+} rcgpu_attachment;
+
+typedef struct {
+    const rcgpu_stream*     streams;      size_t n_streams;
+    const rcgpu_attachment* attachments;  size_t n_attachments;
+    const char* reversibility_path;       /* Global.rawcooked_reversibility_FileName; NULL when IgnoreReversibilityFile (Output.cpp:291) */
+    const char* output_path;              /* Global.OutputFileName (Output.cpp:292-305) */
+    const char* framemd5_path;            /* optional (Output.cpp:312-332); NULL = none */
+    const char* const* options;           /* key,value,key,value... = Global.OutputOptions (Output.cpp:273-278):           */
+    size_t      n_options;                /*   coder, context, g, level, slicecrc, slices, threads, c:a, c:v, y, n, loglevel */
+    int device_first;                     /* first HIP device to use */
+    int device_count;                     /* number of devices (frames shard i mod device_count); 0 = all visible */
+} rcgpu_job;
+
+/* 0 ok; >0 error (becomes the process exit code the reference propagates, Output.cpp:356-374).
+ * Human-readable text goes to stderr prefixed "Error: " (Project/GNU/CLI/test/helpers.sh:81). */
+int rcgpu_encode(const rcgpu_job* job);
+
+/* The reference's argv grammar (Output.cpp:81-332) -> job -> rcgpu_encode.  This is what the shim's main() calls. */
+int rcgpu_main_ffmpeg_argv(int argc, const char* const* argv);
+
+/* ===========================================================================================
+ * 2. Uncompressed-format probes -- the subset of dpx::ParseBuffer (Lib/Uncompressed/DPX/DPX.cpp:250-634),
+ *    tiff::ParseBuffer (TIFF/TIFF.cpp:380-717) and wav::ParseBuffer (WAV/WAV.cpp:271-542) the encoder
+ *    side needs: payload offset, geometry, flavor, slice count.
+ * ======================================================================================== */
+enum {   /* pixel layouts; names follow the reference flavors (DPX.cpp:184-231, TIFF.cpp:157-173) */
+    RCGPU_PIX_RGB8 = 0,
+    RCGPU_PIX_RGB10_FILLEDA_BE = 1, RCGPU_PIX_RGB10_FILLEDA_LE = 2,
+    RCGPU_PIX_RGB12_FILLEDA_BE = 3, RCGPU_PIX_RGB12_FILLEDA_LE = 4,
+    RCGPU_PIX_RGB16_BE = 5, RCGPU_PIX_RGB16_LE = 6,
+    RCGPU_PIX_RGBA8 = 7, RCGPU_PIX_RGBA16_BE = 8, RCGPU_PIX_RGBA16_LE = 9,
+    RCGPU_PIX_Y8 = 10, RCGPU_PIX_Y16_BE = 11, RCGPU_PIX_Y16_LE = 12,
+    RCGPU_PIX_COUNT
+};
+
+typedef struct {
+    uint32_t width, height;
+    uint32_t pixfmt;            /* RCGPU_PIX_* */
+    uint32_t bits_per_sample;
+    uint64_t data_offset;       /* OffsetToImageData / StripOffsets[0] */
+    uint64_t data_size;         /* line_bytes * height */
+    uint32_t line_bytes;        /* DPX: padded to 32 bit (Utils/RawFrame/RawFrame.cpp:109); TIFF: unpadded */
+    uint32_t slices;            /* slice_x*slice_y the reference would pass as -slices (DPX.cpp:428-458, TIFF.cpp:657-672) */
+    double   framerate;         /* DPX only (DPX.cpp:370-387); 0 when absent */
+    char     flavor[64];        /* "DPX/Raw/RGB/16bit/U/BE" ... */
+} rcgpu_image_info;
+
+typedef struct {
+    uint32_t channels, sample_rate, bits_per_sample;
+    uint32_t block_align;
+    uint64_t data_offset, data_size;
+    char     flavor[64];        /* "WAV/PCM/48kHz/24bit/6ch/S/LE" */
+} rcgpu_audio_info;
+
+int rcgpu_dpx_probe (const uint8_t* file, size_t size, rcgpu_image_info* out);
+int rcgpu_tiff_probe(const uint8_t* file, size_t size, rcgpu_image_info* out);
+int rcgpu_wav_probe (const uint8_t* file, size_t size, rcgpu_audio_info* out);
+
+/* -slices N -> h x v the way FFmpeg's ffv1 encoder factorises it (accepted set == test/slices.sh:12). 0 ok. */
+int rcgpu_slices_to_grid(uint32_t n, uint32_t* num_h, uint32_t* num_v);
+
+/* ===========================================================================================
+ * 3. FFV1 encoder (device) -- replaces FFmpeg's ffv1enc; inverse of the in-tree decoder
+ *    ffv1_frame::{OutOfBand,Process} (Lib/CoDec/FFV1/FFV1_Frame.cpp:105-228),
+ *    slice::{Parse,SliceHeader,Line} (FFV1_Slice.cpp:113-472), rangecoder (FFV1_RangeCoder.cpp:71-305),
+ *    and of the packers in Lib/Transform/Transform.cpp.
+ * ======================================================================================== */
+typedef struct {
+    uint32_t width, height;
+    uint32_t pixfmt;          /* RCGPU_PIX_* */
+    uint32_t line_bytes;      /* bytes between payload lines */
+    uint32_t num_h_slices, num_v_slices;   /* num_h >= num_v (FFV1_Slice.cpp:127) */
+    uint32_t slicecrc;        /* -slicecrc (ec) */
+    uint32_t context;         /* -context 0|1 */
+    uint32_t max_batch;       /* frames encoded per call (frames in flight on the device) */
+    int      device;          /* HIP device ordinal */
+} rcgpu_ffv1_config;
+
+typedef struct rcgpu_ffv1 rcgpu_ffv1;
+
+int    rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** enc);
+void   rcgpu_ffv1_destroy(rcgpu_ffv1* enc);
+/* FFV1 configuration record incl. CRC = Matroska CodecPrivate (parsed at FFV1_Parameters.cpp:23-183). */
+size_t rcgpu_ffv1_config_record(const rcgpu_ffv1* enc, uint8_t* out, size_t cap);
+/* Worst-case packet bytes per frame (size d_packets as n * this). */
+size_t rcgpu_ffv1_max_packet_bytes(const rcgpu_ffv1* enc);
+
+/* Encode n (<= max_batch) frames whose payloads (data_size bytes each, first byte = first pixel) are
+ * already resident in device memory.  Asynchronous: all work is enqueued on `hip_stream` (a hipStream_t,
+ * NULL = the encoder's own stream).  On completion packet i occupies
+ * d_packets[i*packet_stride .. + d_packet_sizes[i]) and is a complete FFV1 frame (all slices, footers, CRCs).
+ *   d_frames       host array of n device pointers
+ *   d_packets      device buffer, n * packet_stride bytes, packet_stride >= rcgpu_ffv1_max_packet_bytes()
+ *   d_packet_sizes device array of n uint64
+ */
+int rcgpu_ffv1_encode_device(rcgpu_ffv1* enc, const void* const* d_frames, uint32_t n,
+                             void* d_packets, size_t packet_stride, uint64_t* d_packet_sizes, void* hip_stream);
+
+/* Host-buffer convenience used by rcgpu_encode: pinned staging, H2D, encode, D2H, synchronous.
+ * out_packets[i] must hold rcgpu_ffv1_max_packet_bytes(). */
+int rcgpu_ffv1_encode_host(rcgpu_ffv1* enc, const uint8_t* const* frames, uint32_t n,
+                           uint8_t* const* out_packets, size_t* out_sizes);
+
+/* Per-kernel device time of the last encode call on this encoder, measured with HIP events on the stream
+ * the kernels were launched on.  names[i] is a static string. Returns the number of entries written. */
+int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* enc, const char** names, float* ms, int cap);
+/* Totals of the last batch (valid after the stream is synchronised): binary range-coder decisions and packet bytes. */
+int rcgpu_ffv1_last_stats(const rcgpu_ffv1* enc, uint64_t* decisions, uint64_t* packet_bytes);
+
+/* FFV1 decoder (device) for the --check path: restates ffv1_frame::Process + Transform::From on the GPU and
+ * returns the rebuilt payload (padding bits zero).  d_payloads[i] receives data_size bytes. */
+int rcgpu_ffv1_decode_device(rcgpu_ffv1* enc, const void* const* d_packets, const uint64_t* packet_sizes, uint32_t n,
+                             void* const* d_payloads, void* hip_stream);
+
+/* ===========================================================================================
+ * 4. FLAC encoder (device) -- replaces FFmpeg's flacenc; inverse of flac_wrapper (Lib/CoDec/Wrapper.cpp:131-373)
+ *    + libFLAC stream_decoder.c:2012-2788.
+ * ======================================================================================== */
+typedef struct {
+    uint32_t channels, sample_rate, bits_per_sample;   /* 1..8, 1..655350, 8/16/24 */
+    uint32_t block_size;                               /* samples per channel per FLAC frame; 0 = 4608 @48k like FFmpeg */
+    uint32_t max_lpc_order;                            /* 0 = fixed predictors only; else 1..32 */
+    int      device;
+} rcgpu_flac_config;
+
+typedef struct rcgpu_flac rcgpu_flac;
+
+int    rcgpu_flac_create(const rcgpu_flac_config* cfg, rcgpu_flac** enc);
+void   rcgpu_flac_destroy(rcgpu_flac* enc);
+/* Encode interleaved little-endian PCM (WAV data chunk bytes).  frames_out receives the concatenated FLAC
+ * frames; frame_sizes[i] the size of frame i.  Returns number of FLAC frames via *n_frames. */
+int    rcgpu_flac_encode_host(rcgpu_flac* enc, const uint8_t* pcm, uint64_t pcm_bytes,
+                              uint8_t* frames_out, size_t cap, uint32_t* frame_sizes, uint32_t frame_cap, uint32_t* n_frames);
+/* "fLaC" + STREAMINFO = Matroska CodecPrivate for A_FLAC (Wrapper.cpp:138; stream_decoder.c:1565-1634).
+ * Valid after the whole stream was encoded (total samples, min/max frame size, MD5). */
+size_t rcgpu_flac_codec_private(const rcgpu_flac* enc, uint8_t* out, size_t cap);
+
+/* ===========================================================================================
+ * 5. Matroska muxer -- replaces FFmpeg's matroskaenc for this path; emits what the reference's reader
+ *    requires (Lib/Compressed/Matroska/Matroska.cpp:128-217, :863-873, :934-953, :1007-1030, :1259-1277).
+ * ======================================================================================== */
+typedef struct rcgpu_mkv rcgpu_mkv;
+
+int  rcgpu_mkv_open(const char* path, int overwrite, rcgpu_mkv** mux);
+/* returns 1-based track number, <0 on error */
+int  rcgpu_mkv_add_video(rcgpu_mkv* mux, const uint8_t* codec_private, size_t cp_size, uint32_t width, uint32_t height,
+                         uint32_t fps_num, uint32_t fps_den);
+int  rcgpu_mkv_add_audio(rcgpu_mkv* mux, const uint8_t* codec_private, size_t cp_size, uint32_t channels,
+                         uint32_t sample_rate, uint32_t bits_per_sample);
+int  rcgpu_mkv_add_attachment(rcgpu_mkv* mux, const char* name, const char* mime, const uint8_t* data, size_t size);
+/* Writes EBML header, Segment, SeekHead, Info, Tracks, Attachments.  Call once after all add_* calls. */
+int  rcgpu_mkv_begin(rcgpu_mkv* mux);
+/* One SimpleBlock (one FFV1 frame or >= 1 whole FLAC frames); pts in nanoseconds, non-decreasing per track. */
+int  rcgpu_mkv_write_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, const uint8_t* data, size_t size, int keyframe);
+/* Patches A_FLAC CodecPrivate written by begin() (same size) once STREAMINFO is final. */
+int  rcgpu_mkv_update_codec_private(rcgpu_mkv* mux, int track, const uint8_t* codec_private, size_t cp_size);
+/* Writes Cues, patches Segment size / SeekHead / Duration; closes the file. */
+int  rcgpu_mkv_close(rcgpu_mkv* mux);
+
+/* ===========================================================================================
+ * 6. Hashes -- Lib/ThirdParty/md5/md5.c as used by Utils/FileIO/Input_Base.cpp:54-81, FileWriter.cpp:596-727
+ * ======================================================================================== */
+void     rcgpu_md5(const uint8_t* data, size_t size, uint8_t out[16]);
+uint32_t rcgpu_crc32_ffv1(const uint8_t* data, size_t size);   /* Utils/CRC32/ZenCRC32.cpp:1097-1135 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

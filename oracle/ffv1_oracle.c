@@ -1,0 +1,763 @@
+/* ffv1_oracle.c -- CPU oracle for the FFV1 v3 intra path.  TEST INFRASTRUCTURE ONLY (see ffv1_oracle.h).
+ *
+ * Every function cites the reference lines (under /root/reference/Source/Lib) it restates or inverts.
+ * The encoder half has no in-tree counterpart (the reference runs FFmpeg, CLI/Output.cpp:356); it is
+ * written as the exact inverse of the in-tree decoder following RFC 9043, and is pinned by feeding its
+ * output to the real reference binary (oracle/_ref/rawcooked --check), see tests/.
+ *
+ * Scalar, single threaded, no dependencies beyond libc.
+ */
+#include "ffv1_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define CONTEXT_SIZE 32          /* states_size, CoDec/FFV1/FFV1_RangeCoder.h:23 */
+#define MAX_QUANT 256            /* MAX_QUANT_TABLE_SIZE, CoDec/FFV1/Coder/FFV1_Coder.h:21 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Tables
+ * ---------------------------------------------------------------------------------------------- */
+/* default_state_transitions, CoDec/FFV1/FFV1_Frame.cpp:35-55 (a bitstream constant of FFV1, RFC 9043
+ * section 4.2 "state_transition_delta" default) -- generated here as data, values identical. */
+static const uint8_t one_state_default[256] = {
+      0,  0,  0,  0,  0,  0,  0,  0, 20, 21, 22, 23, 24, 25, 26, 27,
+     28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 37, 38, 39, 40, 41, 42,
+     43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 56, 57,
+     58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73,
+     74, 75, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88,
+     89, 90, 91, 92, 93, 94, 94, 95, 96, 97, 98, 99,100,101,102,103,
+    104,105,106,107,108,109,110,111,112,113,114,114,115,116,117,118,
+    119,120,121,122,123,124,125,126,127,128,129,130,131,132,133,133,
+    134,135,136,137,138,139,140,141,142,143,144,145,146,147,148,149,
+    150,151,152,152,153,154,155,156,157,158,159,160,161,162,163,164,
+    165,166,167,168,169,170,171,171,172,173,174,175,176,177,178,179,
+    180,181,182,183,184,185,186,187,188,189,190,190,191,192,194,194,
+    195,196,197,198,199,200,201,202,202,204,205,206,207,208,209,209,
+    210,211,212,213,215,215,216,217,218,219,220,220,222,223,224,225,
+    226,227,227,229,229,230,231,232,234,234,235,236,237,238,239,240,
+    241,242,243,244,245,246,247,248,248,  0,  0,  0,  0,  0,  0,  0,
+};
+
+/* Quantisation levels for indices 0..127 given as run lengths of equal levels (that is how the record
+ * carries them, FFV1_Parameters.cpp:222-253).  These are the level maps FFmpeg's encoder uses
+ * ([ffmpeg-knowledge], SURVEY.md 8c: not pinned by any in-tree vector; any monotone map is conformant
+ * because the tables travel in the configuration record). */
+static const uint8_t runs_q11[]      = { 1, 1, 3, 7, 20, 96 };          /* levels 0..5, <=8 bit */
+static const uint8_t runs_q5[]       = { 1, 3, 124 };                   /* levels 0..2, <=8 bit */
+static const uint8_t runs_q9_10bit[] = { 5, 8, 14, 29, 72 };            /* levels 0..4, >8 bit  */
+static const uint8_t runs_q5_10bit[] = { 11, 53, 64 };                  /* levels 0..2, >8 bit  */
+
+typedef struct {
+    int16_t  q[5][MAX_QUANT];   /* value = level * scale, negative half mirrored */
+    uint32_t context_count;
+} quant_set;
+
+static void fill_quant(int16_t* q, const uint8_t* runs, int nruns, int scale)
+{
+    int k = 0;
+    for (int v = 0; v < nruns; v++)
+        for (int a = 0; a < runs[v]; a++)
+            q[k++] = (int16_t)(scale * v);
+    /* mirror, FFV1_Parameters.cpp:243-245 */
+    for (int i = 1; i < 128; i++)
+        q[256 - i] = (int16_t)-q[i];
+    q[128] = (int16_t)-q[127];
+}
+
+/* Two table sets as FFmpeg transmits them: set 0 = 3-input model, set 1 = 5-input model. */
+static void build_quant_sets(uint32_t bps, quant_set qs[2])
+{
+    memset(qs, 0, 2 * sizeof(quant_set));
+    if (bps <= 8) {
+        fill_quant(qs[0].q[0], runs_q11, 6, 1);
+        fill_quant(qs[0].q[1], runs_q11, 6, 11);
+        fill_quant(qs[0].q[2], runs_q11, 6, 11 * 11);
+        qs[0].context_count = (11 * 11 * 11 + 1) / 2;
+        fill_quant(qs[1].q[0], runs_q11, 6, 1);
+        fill_quant(qs[1].q[1], runs_q11, 6, 11);
+        fill_quant(qs[1].q[2], runs_q5, 3, 11 * 11);
+        fill_quant(qs[1].q[3], runs_q5, 3, 5 * 11 * 11);
+        fill_quant(qs[1].q[4], runs_q5, 3, 5 * 5 * 11 * 11);
+        qs[1].context_count = (11 * 11 * 5 * 5 * 5 + 1) / 2;
+    } else {
+        fill_quant(qs[0].q[0], runs_q9_10bit, 5, 1);
+        fill_quant(qs[0].q[1], runs_q9_10bit, 5, 9);
+        fill_quant(qs[0].q[2], runs_q9_10bit, 5, 9 * 9);
+        qs[0].context_count = (9 * 9 * 9 + 1) / 2;
+        fill_quant(qs[1].q[0], runs_q9_10bit, 5, 1);
+        fill_quant(qs[1].q[1], runs_q9_10bit, 5, 9);
+        fill_quant(qs[1].q[2], runs_q5_10bit, 3, 9 * 9);
+        fill_quant(qs[1].q[3], runs_q5_10bit, 3, 5 * 9 * 9);
+        fill_quant(qs[1].q[4], runs_q5_10bit, 3, 5 * 5 * 9 * 9);
+        qs[1].context_count = (9 * 9 * 5 * 5 * 5 + 1) / 2;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Pixel formats
+ * ---------------------------------------------------------------------------------------------- */
+uint32_t ffv1o_bits_per_raw_sample(uint32_t f)
+{
+    switch (f) {
+    case FFV1O_RGB8: case FFV1O_RGBA8: case FFV1O_Y8: return 8;
+    case FFV1O_RGB10_FILLEDA_BE: case FFV1O_RGB10_FILLEDA_LE: return 10;
+    case FFV1O_RGB12_FILLEDA_BE: case FFV1O_RGB12_FILLEDA_LE: return 12;
+    default: return 16;
+    }
+}
+uint32_t ffv1o_plane_count(uint32_t f)
+{
+    switch (f) {
+    case FFV1O_Y8: case FFV1O_Y16_BE: case FFV1O_Y16_LE: return 1;
+    case FFV1O_RGBA8: case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE: return 4;
+    default: return 3;
+    }
+}
+uint32_t ffv1o_bytes_per_pixel(uint32_t f)
+{
+    switch (f) {
+    case FFV1O_RGB8: return 3;
+    case FFV1O_RGB10_FILLEDA_BE: case FFV1O_RGB10_FILLEDA_LE: return 4;
+    case FFV1O_RGB12_FILLEDA_BE: case FFV1O_RGB12_FILLEDA_LE: return 6;
+    case FFV1O_RGB16_BE: case FFV1O_RGB16_LE: return 6;
+    case FFV1O_RGBA8: return 4;
+    case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE: return 8;
+    case FFV1O_Y8: return 1;
+    default: return 2;
+    }
+}
+size_t ffv1o_line_bytes(uint32_t f, uint32_t width, int dpx_line_padding)
+{
+    size_t n = (size_t)width * ffv1o_bytes_per_pixel(f);
+    if (dpx_line_padding)      /* Line_Alignment = 32 bit, Utils/RawFrame/RawFrame.cpp:109 */
+        n = (n + 3) & ~(size_t)3;
+    return n;
+}
+static int is_rgb(uint32_t f) { return ffv1o_plane_count(f) != 1; }
+static int has_alpha(uint32_t f) { return ffv1o_plane_count(f) == 4; }
+static int is_be(uint32_t f)
+{
+    return f == FFV1O_RGB10_FILLEDA_BE || f == FFV1O_RGB12_FILLEDA_BE || f == FFV1O_RGB16_BE ||
+           f == FFV1O_RGBA16_BE || f == FFV1O_Y16_BE;
+}
+static inline uint32_t rd16(const uint8_t* p, int be) { return be ? ((uint32_t)p[0] << 8) | p[1] : ((uint32_t)p[1] << 8) | p[0]; }
+static inline void wr16(uint8_t* p, uint32_t v, int be) { if (be) { p[0] = (uint8_t)(v >> 8); p[1] = (uint8_t)v; } else { p[1] = (uint8_t)(v >> 8); p[0] = (uint8_t)v; } }
+static inline uint32_t rd32(const uint8_t* p, int be)
+{
+    return be ? ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]
+              : ((uint32_t)p[3] << 24) | ((uint32_t)p[2] << 16) | ((uint32_t)p[1] << 8) | p[0];
+}
+static inline void wr32(uint8_t* p, uint32_t v, int be)
+{
+    if (be) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+    else    { p[3] = (uint8_t)(v >> 24); p[2] = (uint8_t)(v >> 16); p[1] = (uint8_t)(v >> 8); p[0] = (uint8_t)v; }
+}
+
+/* Forward of Transform.cpp: file components (R,G,B[,A]) of one pixel. */
+static inline void load_px(uint32_t f, const uint8_t* p, int be, uint32_t c[4])
+{
+    switch (f) {
+    case FFV1O_RGB8:  c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; break;                       /* Transform.cpp:70-88 */
+    case FFV1O_RGBA8: c[0] = p[0]; c[1] = p[1]; c[2] = p[2]; c[3] = p[3]; break;           /* :423-442 */
+    case FFV1O_RGB10_FILLEDA_BE: case FFV1O_RGB10_FILLEDA_LE: {                             /* :91-132 */
+        uint32_t w = rd32(p, be);
+        c[0] = (w >> 22) & 0x3FF; c[1] = (w >> 12) & 0x3FF; c[2] = (w >> 2) & 0x3FF; break; }
+    case FFV1O_RGB12_FILLEDA_BE: case FFV1O_RGB12_FILLEDA_LE:                               /* :325-372 */
+        c[0] = rd16(p, be) >> 4; c[1] = rd16(p + 2, be) >> 4; c[2] = rd16(p + 4, be) >> 4; break;
+    case FFV1O_RGB16_BE: case FFV1O_RGB16_LE:                                               /* :375-420 */
+        c[0] = rd16(p, be); c[1] = rd16(p + 2, be); c[2] = rd16(p + 4, be); break;
+    case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE:                                             /* :603-650 */
+        c[0] = rd16(p, be); c[1] = rd16(p + 2, be); c[2] = rd16(p + 4, be); c[3] = rd16(p + 6, be); break;
+    case FFV1O_Y8: c[0] = p[0]; break;                                                      /* :653-668 */
+    default: c[0] = rd16(p, be); break;                                                     /* :993-1034 */
+    }
+}
+static inline void store_px(uint32_t f, uint8_t* p, int be, const uint32_t c[4])
+{
+    switch (f) {
+    case FFV1O_RGB8:  p[0] = (uint8_t)c[0]; p[1] = (uint8_t)c[1]; p[2] = (uint8_t)c[2]; break;
+    case FFV1O_RGBA8: p[0] = (uint8_t)c[0]; p[1] = (uint8_t)c[1]; p[2] = (uint8_t)c[2]; p[3] = (uint8_t)c[3]; break;
+    case FFV1O_RGB10_FILLEDA_BE: case FFV1O_RGB10_FILLEDA_LE:
+        wr32(p, ((c[0] & 0x3FF) << 22) | ((c[1] & 0x3FF) << 12) | ((c[2] & 0x3FF) << 2), be); break;
+    case FFV1O_RGB12_FILLEDA_BE: case FFV1O_RGB12_FILLEDA_LE:
+        wr16(p, (c[0] << 4) & 0xFFFF, be); wr16(p + 2, (c[1] << 4) & 0xFFFF, be); wr16(p + 4, (c[2] << 4) & 0xFFFF, be); break;
+    case FFV1O_RGB16_BE: case FFV1O_RGB16_LE:
+        wr16(p, c[0] & 0xFFFF, be); wr16(p + 2, c[1] & 0xFFFF, be); wr16(p + 4, c[2] & 0xFFFF, be); break;
+    case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE:
+        wr16(p, c[0] & 0xFFFF, be); wr16(p + 2, c[1] & 0xFFFF, be); wr16(p + 4, c[2] & 0xFFFF, be); wr16(p + 6, c[3] & 0xFFFF, be); break;
+    case FFV1O_Y8: p[0] = (uint8_t)c[0]; break;
+    default: wr16(p, c[0] & 0xFFFF, be); break;
+    }
+}
+/* FFV1 codes 9..15-bit RGB without alpha with G and B exchanged (RFC 9043 3.7.2.1; Transform.cpp:104,126,
+ * 338,363 "g and b are inverted"); 8 and 16 bit and every RGBA flavor are not exchanged (:78-83,388-390,460). */
+static int gb_swapped(uint32_t f)
+{
+    uint32_t bps = ffv1o_bits_per_raw_sample(f);
+    return is_rgb(f) && !has_alpha(f) && bps >= 9 && bps <= 15;
+}
+
+void ffv1o_unpack(const ffv1o_params* p, const uint8_t* payload, size_t line_bytes, int32_t* const planes[4])
+{
+    const uint32_t f = p->pixfmt, bpp = ffv1o_bytes_per_pixel(f);
+    const int be = is_be(f), swap = gb_swapped(f), rgb = is_rgb(f), alpha = has_alpha(f);
+    const int32_t off = (int32_t)1 << ffv1o_bits_per_raw_sample(f);
+    for (uint32_t y = 0; y < p->height; y++) {
+        const uint8_t* s = payload + (size_t)y * line_bytes;
+        size_t o = (size_t)y * p->width;
+        for (uint32_t x = 0; x < p->width; x++, s += bpp) {
+            uint32_t c[4] = { 0, 0, 0, 0 };
+            load_px(f, s, be, c);
+            if (!rgb) { planes[0][o + x] = (int32_t)c[0]; continue; }
+            /* inverse of JPEG2000RCT, Transform.cpp:29-37 */
+            int32_t r = (int32_t)c[0], g = (int32_t)c[1], b = (int32_t)c[2];
+            if (swap) { int32_t t = g; g = b; b = t; }
+            b -= g; r -= g;
+            g += (b + r) >> 2;
+            planes[0][o + x] = g;
+            planes[1][o + x] = b + off;
+            planes[2][o + x] = r + off;
+            if (alpha) planes[3][o + x] = (int32_t)c[3];
+        }
+    }
+}
+
+void ffv1o_pack(const ffv1o_params* p, int32_t* const planes[4], uint8_t* payload, size_t line_bytes)
+{
+    const uint32_t f = p->pixfmt, bpp = ffv1o_bytes_per_pixel(f);
+    const int be = is_be(f), swap = gb_swapped(f), rgb = is_rgb(f), alpha = has_alpha(f);
+    const int32_t off = (int32_t)1 << ffv1o_bits_per_raw_sample(f);
+    for (uint32_t y = 0; y < p->height; y++) {
+        uint8_t* d = payload + (size_t)y * line_bytes;
+        memset(d, 0, line_bytes);
+        size_t o = (size_t)y * p->width;
+        for (uint32_t x = 0; x < p->width; x++, d += bpp) {
+            uint32_t c[4] = { 0, 0, 0, 0 };
+            if (!rgb) { c[0] = (uint32_t)planes[0][o + x]; store_px(f, d, be, c); continue; }
+            /* JPEG2000RCT, Transform.cpp:29-37 */
+            int32_t g = planes[0][o + x], b = planes[1][o + x], r = planes[2][o + x];
+            b -= off; r -= off;
+            g -= (b + r) >> 2;
+            b += g; r += g;
+            if (swap) { int32_t t = g; g = b; b = t; }
+            c[0] = (uint32_t)r; c[1] = (uint32_t)g; c[2] = (uint32_t)b;
+            if (alpha) c[3] = (uint32_t)planes[3][o + x];
+            store_px(f, d, be, c);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * CRC-32 (ZenCRC32.cpp:1062-1135: poly 0x04C11DB7, MSB first, init 0, no xor-out) -- bitwise table.
+ * ---------------------------------------------------------------------------------------------- */
+static uint32_t crc_table[256];
+static int crc_table_ready;
+static void crc_init(void)
+{
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i << 24;
+        for (int k = 0; k < 8; k++)
+            c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
+        crc_table[i] = c;
+    }
+    crc_table_ready = 1;
+}
+uint32_t ffv1o_crc32(const uint8_t* d, size_t n)
+{
+    if (!crc_table_ready) crc_init();
+    uint32_t c = 0;
+    for (size_t i = 0; i < n; i++)
+        c = (c << 8) ^ crc_table[(c >> 24) ^ d[i]];
+    return c;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Range coder, encoder side: inverse of rangecoder::b, FFV1_RangeCoder.cpp:71-102 (RFC 9043 3.8.1).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t low, range;
+    int      outstanding_byte, outstanding_count;
+    uint8_t* p; uint8_t* end; int overflow;
+    uint8_t  one_state[256], zero_state[256];
+    uint64_t decisions;
+} rc_enc;
+
+static void rc_tables(uint8_t* one, uint8_t* zero)
+{
+    /* AssignStateTransitions, FFV1_RangeCoder.cpp:35-41 */
+    memcpy(one, one_state_default, 256);
+    zero[0] = 0;
+    for (int i = 1; i < 256; i++)
+        zero[i] = (uint8_t)(256 - one[256 - i]);
+}
+static void rce_init(rc_enc* c, uint8_t* buf, size_t cap)
+{
+    c->low = 0; c->range = 0xFF00; c->outstanding_byte = -1; c->outstanding_count = 0;
+    c->p = buf; c->end = buf + cap; c->overflow = 0; c->decisions = 0;
+    rc_tables(c->one_state, c->zero_state);
+}
+static inline void rce_out(rc_enc* c, int v) { if (c->p < c->end) *c->p++ = (uint8_t)v; else c->overflow = 1; }
+static void rce_renorm(rc_enc* c)
+{
+    while (c->range < 0x100) {
+        if (c->outstanding_byte < 0) {
+            c->outstanding_byte = (int)(c->low >> 8);
+        } else if (c->low <= 0xFF00) {
+            rce_out(c, c->outstanding_byte);
+            for (; c->outstanding_count; c->outstanding_count--) rce_out(c, 0xFF);
+            c->outstanding_byte = (int)(c->low >> 8);
+        } else if (c->low >= 0x10000) {
+            rce_out(c, c->outstanding_byte + 1);
+            for (; c->outstanding_count; c->outstanding_count--) rce_out(c, 0x00);
+            c->outstanding_byte = (int)((c->low >> 8) & 0xFF);
+        } else {
+            c->outstanding_count++;
+        }
+        c->low = (c->low & 0xFF) << 8;
+        c->range <<= 8;
+    }
+}
+static inline void rce_put(rc_enc* c, uint8_t* state, int bit)
+{
+    uint32_t r1 = (c->range * *state) >> 8;      /* Mask2, FFV1_RangeCoder.cpp:90 */
+    if (!bit) { c->range -= r1; *state = c->zero_state[*state]; }
+    else { c->low += c->range - r1; c->range = r1; *state = c->one_state[*state]; }
+    c->decisions++;
+    rce_renorm(c);
+}
+/* Ends the coder; with_end_bit = slices (decoder consumes state 129 at FFV1_Slice.cpp:336-340). */
+static size_t rce_terminate(rc_enc* c, uint8_t* start, int with_end_bit)
+{
+    if (with_end_bit) { uint8_t s = 129; rce_put(c, &s, 0); }
+    c->range = 0xFF; c->low += 0xFF; rce_renorm(c);
+    c->range = 0xFF; rce_renorm(c);
+    return (size_t)(c->p - start);
+}
+static inline int ilog2(uint32_t a) { int e = 0; while (a >>= 1) e++; return e; }
+/* inverse of rangecoder::u / ::s, FFV1_RangeCoder.cpp:105-305 */
+static void rce_symbol(rc_enc* c, uint8_t* st, int32_t v, int is_signed)
+{
+    if (!v) { rce_put(c, st + 0, 1); return; }
+    uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    int e = ilog2(a);
+    rce_put(c, st + 0, 0);
+    for (int i = 0; i < e; i++) rce_put(c, st + 1 + (i < 9 ? i : 9), 1);
+    rce_put(c, st + 1 + (e < 9 ? e : 9), 0);
+    for (int i = e - 1; i >= 0; i--) rce_put(c, st + 22 + (i < 9 ? i : 9), (a >> i) & 1);
+    if (is_signed) rce_put(c, st + 11 + (e < 10 ? e : 10), v < 0);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Configuration record (inverse of parameters::Parse, FFV1_Parameters.cpp:23-183, :206-253)
+ * ---------------------------------------------------------------------------------------------- */
+static void write_quant_table(rc_enc* c, const int16_t* q)
+{
+    uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);     /* fresh states per table, :224 */
+    int last = 0, i;
+    for (i = 1; i < 128; i++)
+        if (q[i] != q[i - 1]) { rce_symbol(c, st, i - last - 1, 0); last = i; }
+    rce_symbol(c, st, i - last - 1, 0);
+}
+size_t ffv1o_config_record(const ffv1o_params* p, uint8_t* out, size_t cap)
+{
+    quant_set qs[2];
+    const uint32_t bps = ffv1o_bits_per_raw_sample(p->pixfmt);
+    build_quant_sets(bps, qs);
+    rc_enc c; rce_init(&c, out, cap);
+    uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);
+    rce_symbol(&c, st, 3, 0);                        /* version */
+    rce_symbol(&c, st, 4, 0);                        /* micro_version (>=4 required, :37-38) */
+    rce_symbol(&c, st, 1, 0);                        /* coder_type = range coder, default table */
+    rce_symbol(&c, st, is_rgb(p->pixfmt) ? 1 : 0, 0);/* colorspace_type */
+    rce_symbol(&c, st, (int32_t)bps, 0);             /* bits_per_raw_sample */
+    rce_put(&c, st, is_rgb(p->pixfmt) ? 1 : 0);      /* chroma_planes */
+    rce_symbol(&c, st, 0, 0);                        /* log2_h_chroma_subsample */
+    rce_symbol(&c, st, 0, 0);                        /* log2_v_chroma_subsample */
+    rce_put(&c, st, has_alpha(p->pixfmt));           /* alpha_plane */
+    rce_symbol(&c, st, (int32_t)p->num_h_slices - 1, 0);
+    rce_symbol(&c, st, (int32_t)p->num_v_slices - 1, 0);
+    rce_symbol(&c, st, 2, 0);                        /* quant_table_set_count */
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 5; j++)
+            write_quant_table(&c, qs[i].q[j]);
+    for (int i = 0; i < 2; i++)
+        rce_put(&c, st, 0);                          /* states_coded */
+    rce_symbol(&c, st, (int32_t)p->ec, 0);           /* ec */
+    rce_symbol(&c, st, 1, 0);                        /* intra (-g 1) */
+    size_t n = rce_terminate(&c, out, 0);
+    if (c.overflow || n + 4 > cap) return 0;
+    uint32_t crc = ffv1o_crc32(out, n);              /* parity: CRC over record||crc == 0, FFV1_Frame.cpp:116 */
+    out[n] = (uint8_t)(crc >> 24); out[n + 1] = (uint8_t)(crc >> 16); out[n + 2] = (uint8_t)(crc >> 8); out[n + 3] = (uint8_t)crc;
+    return n + 4;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Slice geometry, predictor, contexts (FFV1_Slice.cpp:21-93, :153-156)
+ * ---------------------------------------------------------------------------------------------- */
+static inline int32_t median3(int32_t a, int32_t b, int32_t c)
+{
+    /* get_median_number, FFV1_Slice.cpp:21-49 */
+    if (a > b) { if (b > c) return b; if (c > a) return a; return c; }
+    if (c > b) return b;
+    if (c > a) return c;
+    return a;
+}
+static inline int32_t sign_extend(int32_t v, int bits)
+{
+    uint32_t m = (uint32_t)1 << (bits - 1);
+    uint32_t u = (uint32_t)v & ((m << 1) - 1);
+    return (int32_t)((u ^ m) - m);
+}
+
+typedef struct {
+    uint32_t bps, bits, planes, set_index_count;
+    int rgb, overflow16;
+    uint32_t qidx;             /* quant_table_set index used by every plane = context_model */
+    quant_set qs[2];
+} codec_ctx;
+
+static void codec_ctx_init(codec_ctx* k, const ffv1o_params* p)
+{
+    k->bps = ffv1o_bits_per_raw_sample(p->pixfmt);
+    k->rgb = is_rgb(p->pixfmt);
+    k->planes = ffv1o_plane_count(p->pixfmt);
+    /* FFV1_Parameters.cpp:160-181 */
+    k->overflow16 = (!k->rgb && k->bps == 16);
+    k->bits = k->rgb ? k->bps + 1 : (k->bps <= 8 ? 8 : k->bps);
+    k->set_index_count = k->rgb ? k->planes - 1 : 2;       /* version<4: 1 + 1 (+alpha) */
+    k->qidx = p->context_model ? 1 : 0;
+    build_quant_sets(k->bps, k->qs);
+}
+
+/* One line of one plane.  cur/prev point at x=0 of buffers with 2 guard samples on the left and 1 on the
+ * right (SamplesBuffer layout, FFV1_Slice.cpp:406-425).  On entry cur[] holds the line two above (TT). */
+static void encode_line(rc_enc* c, const codec_ctx* k, uint8_t (*states)[CONTEXT_SIZE], uint32_t w,
+                        int32_t* cur, int32_t* prev, const int32_t* src)
+{
+    const quant_set* qs = &k->qs[k->qidx];
+    const int is5 = qs->q[3][127] != 0;                       /* FFV1_Slice.cpp:453 */
+    const int32_t mask = (int32_t)(((uint32_t)1 << k->bits) - 1);
+    for (uint32_t x = 0; x < w; x++) {
+        int32_t* s1 = cur + x; int32_t* s0 = prev + x;
+        const int32_t LT = s0[-1], T = s0[0], RT = s0[1], L = s1[-1];
+        int32_t ctx = qs->q[0][(L - LT) & 0xFF] + qs->q[1][(LT - T) & 0xFF] + qs->q[2][(T - RT) & 0xFF];
+        if (is5) ctx += qs->q[3][(s1[-2] - L) & 0xFF] + qs->q[4][(s1[0] - T) & 0xFF];
+        int32_t pred;
+        if (k->overflow16) pred = median3((int16_t)L, (int16_t)L + (int16_t)T - (int16_t)LT, (int16_t)T);   /* :52-57 */
+        else pred = median3(L, L + T - LT, T);
+        int32_t v = src[x] & mask;
+        int32_t d = v - pred;
+        if (ctx < 0) { ctx = -ctx; d = -d; }
+        d = sign_extend(d, (int)k->bits);
+        rce_symbol(c, states[ctx], d, 1);
+        *s1 = v;
+    }
+}
+
+static void slice_rect(const ffv1o_params* p, uint32_t sx, uint32_t sy, uint32_t* x, uint32_t* y, uint32_t* w, uint32_t* h)
+{
+    /* FFV1_Slice.cpp:153-156 */
+    *x = sx * p->width / p->num_h_slices;
+    *y = sy * p->height / p->num_v_slices;
+    *w = (sx + 1) * p->width / p->num_h_slices - *x;
+    *h = (sy + 1) * p->height / p->num_v_slices - *y;
+}
+
+static __thread uint64_t g_last_decisions;
+uint64_t ffv1o_last_decisions(void) { return g_last_decisions; }
+
+static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* const planes[4], uint32_t sx, uint32_t sy,
+                           int first, uint8_t* out, size_t cap)
+{
+    uint32_t x0, y0, w, h;
+    slice_rect(p, sx, sy, &x0, &y0, &w, &h);
+    rc_enc c; rce_init(&c, out, cap);
+    if (first) { uint8_t ks = 128; rce_put(&c, &ks, 1); }     /* keyframe, FFV1_Frame.cpp:148-156 */
+    /* slice header, FFV1_Slice.cpp:113-177 */
+    uint8_t hs[CONTEXT_SIZE]; memset(hs, 128, sizeof hs);
+    rce_symbol(&c, hs, (int32_t)sx, 0);
+    rce_symbol(&c, hs, (int32_t)sy, 0);
+    rce_symbol(&c, hs, 0, 0);                                 /* slice_width - 1 (slice units) */
+    rce_symbol(&c, hs, 0, 0);
+    for (uint32_t i = 0; i < k->set_index_count; i++) rce_symbol(&c, hs, (int32_t)k->qidx, 0);
+    rce_symbol(&c, hs, 3, 0);                                 /* picture_structure: progressive */
+    rce_symbol(&c, hs, 0, 0); rce_symbol(&c, hs, 0, 0);       /* sar 0/0 = unknown */
+
+    /* context states: one array per quant_table_set_index, all 128 (states_coded = 0), GOP_Init */
+    const uint32_t nctx = k->qs[k->qidx].context_count;
+    uint8_t (*states[3])[CONTEXT_SIZE];
+    for (uint32_t i = 0; i < k->set_index_count; i++) {
+        states[i] = malloc((size_t)nctx * CONTEXT_SIZE);
+        memset(states[i], 128, (size_t)nctx * CONTEXT_SIZE);
+    }
+    int32_t* buf = calloc((size_t)2 * k->planes * (w + 3), sizeof(int32_t));
+    int32_t* sample[4][2];
+    for (uint32_t pl = 0; pl < k->planes; pl++) {
+        sample[pl][0] = buf + 2 * pl * (w + 3) + 2;
+        sample[pl][1] = sample[pl][0] + w + 3;
+    }
+    if (k->rgb) {
+        /* SliceContent_LineThenPlane, FFV1_Slice.cpp:406-444 */
+        for (uint32_t y = 0; y < h; y++)
+            for (uint32_t pl = 0; pl < k->planes; pl++) {
+                int32_t* t = sample[pl][0]; sample[pl][0] = sample[pl][1]; sample[pl][1] = t;
+                sample[pl][1][-1] = sample[pl][0][0];
+                sample[pl][0][w] = sample[pl][0][w - 1];
+                encode_line(&c, k, states[(pl + 1) >> 1], w, sample[pl][1], sample[pl][0],
+                            planes[pl] + (size_t)(y0 + y) * p->width + x0);
+            }
+    } else {
+        /* SliceContent_PlaneThenLine, FFV1_Slice.cpp:346-403 (luma only: chroma_planes = 0) */
+        for (uint32_t y = 0; y < h; y++) {
+            int32_t* t = sample[0][0]; sample[0][0] = sample[0][1]; sample[0][1] = t;
+            sample[0][1][-1] = sample[0][0][0];
+            sample[0][0][w] = sample[0][0][w - 1];
+            encode_line(&c, k, states[0], w, sample[0][1], sample[0][0], planes[0] + (size_t)(y0 + y) * p->width + x0);
+        }
+    }
+    free(buf);
+    for (uint32_t i = 0; i < k->set_index_count; i++) free(states[i]);
+
+    size_t n = rce_terminate(&c, out, 1);
+    g_last_decisions += c.decisions;
+    /* footer, FFV1_Frame.cpp:177-196, FFV1_Slice.cpp:301-314 */
+    if (c.overflow || n + 8 > cap || n > 0xFFFFFF) return 0;
+    out[n] = (uint8_t)(n >> 16); out[n + 1] = (uint8_t)(n >> 8); out[n + 2] = (uint8_t)n; n += 3;
+    if (p->ec) {
+        out[n++] = 0;                                         /* error_status */
+        uint32_t crc = ffv1o_crc32(out, n);
+        out[n] = (uint8_t)(crc >> 24); out[n + 1] = (uint8_t)(crc >> 16); out[n + 2] = (uint8_t)(crc >> 8); out[n + 3] = (uint8_t)crc;
+        n += 4;
+    }
+    return n;
+}
+
+size_t ffv1o_encode_frame(const ffv1o_params* p, int32_t* const planes[4], uint8_t* out, size_t cap, uint32_t* slice_sizes)
+{
+    codec_ctx* k = malloc(sizeof *k);
+    codec_ctx_init(k, p);
+    size_t pos = 0;
+    g_last_decisions = 0;
+    for (uint32_t sy = 0; sy < p->num_v_slices; sy++)
+        for (uint32_t sx = 0; sx < p->num_h_slices; sx++) {
+            size_t n = encode_slice(p, k, planes, sx, sy, pos == 0, out + pos, cap - pos);
+            if (!n) { free(k); return 0; }
+            if (slice_sizes) slice_sizes[sy * p->num_h_slices + sx] = (uint32_t)n;
+            pos += n;
+        }
+    free(k);
+    return pos;
+}
+
+size_t ffv1o_encode_payload(const ffv1o_params* p, const uint8_t* payload, size_t line_bytes, uint8_t* out, size_t cap,
+                            uint32_t* slice_sizes)
+{
+    size_t n = (size_t)p->width * p->height;
+    int32_t* planes[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < ffv1o_plane_count(p->pixfmt); i++) planes[i] = malloc(n * sizeof(int32_t));
+    ffv1o_unpack(p, payload, line_bytes, planes);
+    size_t r = ffv1o_encode_frame(p, planes, out, cap, slice_sizes);
+    for (int i = 0; i < 4; i++) free(planes[i]);
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Decoder: restates rangecoder (FFV1_RangeCoder.cpp:21-132), slice::Parse (FFV1_Slice.cpp:210-318),
+ * ffv1_frame::Process (FFV1_Frame.cpp:134-228)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t current, mask;
+    const uint8_t *beg, *cur, *end;
+    uint8_t one_state[256], zero_state[256];
+} rc_dec;
+static void rcd_init(rc_dec* c, const uint8_t* buf, size_t n)
+{
+    c->beg = buf; c->cur = buf; c->end = buf + n;
+    c->current = n ? *c->cur : 0; c->mask = 0xFF; c->cur++;       /* AssignBuffer, :22-33 */
+    rc_tables(c->one_state, c->zero_state);
+}
+static int rcd_b(rc_dec* c, uint8_t* state)
+{
+    if (c->mask < 0x100) {
+        c->current <<= 8;
+        if (c->cur > c->end) return 0;
+        if (c->cur < c->end) c->current |= *c->cur;
+        c->mask <<= 8;
+        c->cur++;
+    }
+    uint32_t m2 = (c->mask * *state) >> 8;
+    c->mask -= m2;
+    if (c->current < c->mask) { *state = c->zero_state[*state]; return 0; }
+    c->current -= c->mask; c->mask = m2; *state = c->one_state[*state];
+    return 1;
+}
+static size_t rcd_bytes_used(const rc_dec* c)
+{
+    if (c->cur > c->end) return (size_t)(c->end - c->beg);
+    return (size_t)(c->cur - c->beg) - (c->mask < 0x100 ? 0 : 1);
+}
+static uint32_t rcd_u(rc_dec* c, uint8_t* st)
+{
+    if (rcd_b(c, st)) return 0;
+    int e = 0;
+    while (rcd_b(c, st + 1 + (e < 9 ? e : 9))) { if (++e > 31) return 0; }
+    uint32_t a = 1;
+    for (int i = e - 1; i >= 0; i--) a = (a << 1) | (uint32_t)rcd_b(c, st + 22 + (i < 9 ? i : 9));
+    return a;
+}
+static int32_t rcd_s(rc_dec* c, uint8_t* st)
+{
+    if (rcd_b(c, st)) return 0;
+    int e = 0;
+    while (rcd_b(c, st + 1 + (e < 9 ? e : 9))) { if (++e > 31) return 0; }
+    int32_t a = 1;
+    for (int i = e - 1; i >= 0; i--) a = (a << 1) | rcd_b(c, st + 22 + (i < 9 ? i : 9));
+    return rcd_b(c, st + 11 + (e < 10 ? e : 10)) ? -a : a;
+}
+
+static int decode_slice(const ffv1o_params* p, const codec_ctx* k, const uint8_t* buf, size_t size, int first, int32_t* const planes[4])
+{
+    const size_t tail = p->ec ? 8 : 3;
+    if (size < tail) return 10;
+    if (p->ec && ffv1o_crc32(buf, size)) return 11;             /* FFV1_Slice.cpp:247-249 */
+    rc_dec c; rcd_init(&c, buf, size - tail);
+    if (first) { uint8_t ks = 128; rcd_b(&c, &ks); }
+    uint8_t hs[CONTEXT_SIZE]; memset(hs, 128, sizeof hs);
+    uint32_t sx = rcd_u(&c, hs), sy = rcd_u(&c, hs);
+    uint32_t sw1 = rcd_u(&c, hs), sh1 = rcd_u(&c, hs);
+    if (sx >= p->num_h_slices || sy >= p->num_v_slices || sw1 || sh1) return 12;
+    for (uint32_t i = 0; i < k->set_index_count; i++) if (rcd_u(&c, hs) != k->qidx) return 13;
+    (void)rcd_u(&c, hs); (void)rcd_u(&c, hs); (void)rcd_u(&c, hs);
+    uint32_t x0, y0, w, h;
+    slice_rect(p, sx, sy, &x0, &y0, &w, &h);
+
+    const quant_set* qs = &k->qs[k->qidx];
+    const int is5 = qs->q[3][127] != 0;
+    const int32_t mask = (int32_t)(((uint32_t)1 << k->bits) - 1);
+    const uint32_t nctx = qs->context_count;
+    uint8_t (*states[3])[CONTEXT_SIZE];
+    for (uint32_t i = 0; i < k->set_index_count; i++) {
+        states[i] = malloc((size_t)nctx * CONTEXT_SIZE);
+        memset(states[i], 128, (size_t)nctx * CONTEXT_SIZE);
+    }
+    int32_t* sb = calloc((size_t)2 * k->planes * (w + 3), sizeof(int32_t));
+    int32_t* sample[4][2];
+    for (uint32_t pl = 0; pl < k->planes; pl++) { sample[pl][0] = sb + 2 * pl * (w + 3) + 2; sample[pl][1] = sample[pl][0] + w + 3; }
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t pl = 0; pl < k->planes; pl++) {
+            int32_t* t = sample[pl][0]; sample[pl][0] = sample[pl][1]; sample[pl][1] = t;
+            sample[pl][1][-1] = sample[pl][0][0];
+            sample[pl][0][w] = sample[pl][0][w - 1];
+            uint8_t (*st)[CONTEXT_SIZE] = states[k->rgb ? (pl + 1) >> 1 : 0];
+            int32_t* dst = planes[pl] + (size_t)(y0 + y) * p->width + x0;
+            /* slice::Line, FFV1_Slice.cpp:447-472 */
+            for (uint32_t x = 0; x < w; x++) {
+                int32_t* s1 = sample[pl][1] + x; int32_t* s0 = sample[pl][0] + x;
+                const int32_t LT = s0[-1], T = s0[0], RT = s0[1], L = s1[-1];
+                int32_t ctx = qs->q[0][(L - LT) & 0xFF] + qs->q[1][(LT - T) & 0xFF] + qs->q[2][(T - RT) & 0xFF];
+                if (is5) ctx += qs->q[3][(s1[-2] - L) & 0xFF] + qs->q[4][(s1[0] - T) & 0xFF];
+                int32_t v;
+                if (k->overflow16) v = median3((int16_t)L, (int16_t)L + (int16_t)T - (int16_t)LT, (int16_t)T);
+                else v = median3(L, L + T - LT, T);
+                if (ctx >= 0) v += rcd_s(&c, st[ctx]); else v -= rcd_s(&c, st[-ctx]);
+                *s1 = v & mask;
+                dst[x] = *s1;
+            }
+        }
+    free(sb);
+    for (uint32_t i = 0; i < k->set_index_count; i++) free(states[i]);
+    { uint8_t es = 129; rcd_b(&c, &es); }                        /* FFV1_Slice.cpp:336-340 */
+    if (c.cur - (c.mask < 0x100 ? 0 : 1) > c.end) return 14;    /* IsUnderrun */
+    if (rcd_bytes_used(&c) < size - tail) return 15;             /* FFV1-SLICE-JUNK, :297-299 */
+    if (p->ec && buf[size - 5]) return 16;                       /* error_status */
+    return 0;
+}
+
+int ffv1o_decode_frame(const ffv1o_params* p, const uint8_t* pkt, size_t size, int32_t* const planes[4])
+{
+    codec_ctx* k = malloc(sizeof *k);
+    codec_ctx_init(k, p);
+    const size_t tail = p->ec ? 8 : 3;
+    /* keyframe bit, FFV1_Frame.cpp:148-156 */
+    { rc_dec c; rcd_init(&c, pkt, size); uint8_t ks = 128; if (!rcd_b(&c, &ks)) { free(k); return 1; } }
+    /* split from the tail, FFV1_Frame.cpp:177-198 */
+    size_t pos = size; uint32_t count = 0; int err = 0;
+    while (pos && !err) {
+        if (pos < tail) { err = 2; break; }
+        size_t s = (((size_t)pkt[pos - tail]) << 16) | (((size_t)pkt[pos - tail + 1]) << 8) | pkt[pos - tail + 2];
+        s += tail;
+        if (s > pos) { err = 3; break; }
+        pos -= s;
+        err = decode_slice(p, k, pkt + pos, s, pos == 0, planes);
+        count++;
+    }
+    if (!err && count != p->num_h_slices * p->num_v_slices) err = 4;
+    free(k);
+    return err;
+}
+
+int ffv1o_decode_payload(const ffv1o_params* p, const uint8_t* pkt, size_t size, uint8_t* payload, size_t line_bytes)
+{
+    size_t n = (size_t)p->width * p->height;
+    int32_t* planes[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < ffv1o_plane_count(p->pixfmt); i++) planes[i] = calloc(n, sizeof(int32_t));
+    int r = ffv1o_decode_frame(p, pkt, size, planes);
+    if (!r) ffv1o_pack(p, planes, payload, line_bytes);
+    for (int i = 0; i < 4; i++) free(planes[i]);
+    return r;
+}
+
+/* parameters::Parse, FFV1_Parameters.cpp:23-183 (the subset of values this path emits is accepted;
+ * anything else is reported as a mismatch). */
+int ffv1o_parse_config_record(const uint8_t* rec, size_t size, ffv1o_params* p)
+{
+    if (size < 5) return 1;
+    if (ffv1o_crc32(rec, size)) return 2;                          /* FFV1_Frame.cpp:116 */
+    rc_dec c; rcd_init(&c, rec, size - 4);
+    uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);
+    if (rcd_u(&c, st) != 3) return 3;
+    if (rcd_u(&c, st) < 4) return 4;
+    if (rcd_u(&c, st) != 1) return 5;
+    uint32_t colorspace = rcd_u(&c, st);
+    uint32_t bps = rcd_u(&c, st);
+    int chroma = rcd_b(&c, st);
+    if (rcd_u(&c, st) || rcd_u(&c, st)) return 6;
+    int alpha = rcd_b(&c, st);
+    p->num_h_slices = rcd_u(&c, st) + 1;
+    p->num_v_slices = rcd_u(&c, st) + 1;
+    uint32_t nsets = rcd_u(&c, st);
+    if (nsets != 2) return 7;
+    if (colorspace != (uint32_t)is_rgb(p->pixfmt) || bps != ffv1o_bits_per_raw_sample(p->pixfmt) ||
+        chroma != is_rgb(p->pixfmt) || alpha != has_alpha(p->pixfmt)) return 8;
+    quant_set ref[2]; build_quant_sets(bps, ref);
+    for (uint32_t i = 0; i < nsets; i++) {
+        int32_t scale = 1;
+        for (int j = 0; j < 5; j++) {
+            uint8_t qst[CONTEXT_SIZE]; memset(qst, 128, sizeof qst);
+            int32_t v = 0;
+            for (uint32_t kk = 0; kk < 128;) {
+                uint32_t len1 = rcd_u(&c, qst);
+                if (kk + len1 >= 128) return 9;
+                for (uint32_t a = 0; a <= len1; a++, kk++)
+                    if (ref[i].q[j][kk] != (int16_t)(scale * v)) return 10;
+                v++;
+            }
+            scale *= 2 * v - 1;
+        }
+        if ((uint32_t)((scale + 1) >> 1) != ref[i].context_count) return 11;
+    }
+    for (uint32_t i = 0; i < nsets; i++) if (rcd_b(&c, st)) return 12;   /* states_coded */
+    p->ec = rcd_u(&c, st);
+    if (p->ec > 1) return 13;
+    if (rcd_u(&c, st) != 1) return 14;                                   /* intra */
+    return 0;
+}
+
+int ffv1o_slices_to_grid(uint32_t n, uint32_t* num_h, uint32_t* num_v)
+{
+    if (n == 1) { *num_h = 1; *num_v = 1; return 0; }
+    for (uint32_t v = 2; v < 32; v++)
+        for (uint32_t h = v; h < 2 * v; h++)
+            if (h * v == n) { *num_h = h; *num_v = v; return 0; }
+    return -1;
+}

@@ -1,0 +1,94 @@
+/* ffv1_oracle.h -- CPU oracle for the FFV1 v3 intra path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the algorithm on RAWcooked's DPX/TIFF -> FFV1 hot path
+ * (SURVEY.md section 8 rows a6, a7, a9).  The decode half follows the reference's in-tree
+ * decoder line by line; the encode half is its exact inverse (the reference delegates encoding
+ * to an external FFmpeg process, Source/CLI/Output.cpp:356, so the inverse is pinned by
+ * round-tripping through the real reference binary oracle/_ref/rawcooked, see
+ * tests/test_oracle_vs_reference.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this.
+ * The product (rawcooked_amd/csrc) never includes or links anything from oracle/.
+ */
+#ifndef FFV1_ORACLE_H
+#define FFV1_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Pixel layouts of the uncompressed payload, named after the reference's flavors
+ * (Source/Lib/Uncompressed/DPX/DPX.cpp:184-231, TIFF/TIFF.cpp:157-173). */
+enum {
+    FFV1O_RGB8 = 0,            /* DPX/TIFF Raw/RGB/8bit            3 B/px  R,G,B                         */
+    FFV1O_RGB10_FILLEDA_BE = 1,/* DPX Raw/RGB/10bit/FilledA BE     4 B/px  R<<22|G<<12|B<<2             */
+    FFV1O_RGB10_FILLEDA_LE = 2,
+    FFV1O_RGB12_FILLEDA_BE = 3,/* DPX Raw/RGB/12bit/FilledA        6 B/px  3 x (v<<4) u16               */
+    FFV1O_RGB12_FILLEDA_LE = 4,
+    FFV1O_RGB16_BE = 5,        /* DPX/TIFF Raw/RGB/16bit           6 B/px  R,G,B u16                     */
+    FFV1O_RGB16_LE = 6,
+    FFV1O_RGBA8 = 7,           /* 4 B/px R,G,B,A */
+    FFV1O_RGBA16_BE = 8,       /* 8 B/px */
+    FFV1O_RGBA16_LE = 9,
+    FFV1O_Y8 = 10,             /* 1 B/px */
+    FFV1O_Y16_BE = 11,         /* 2 B/px */
+    FFV1O_Y16_LE = 12,
+    FFV1O_PIXFMT_COUNT
+};
+
+typedef struct {
+    uint32_t width, height;
+    uint32_t pixfmt;        /* FFV1O_* */
+    uint32_t num_h_slices;  /* >= num_v_slices (reference decoder limit, FFV1_Slice.cpp:127) */
+    uint32_t num_v_slices;
+    uint32_t ec;            /* slicecrc: 0/1 */
+    uint32_t context_model; /* -context: 0 (3 inputs) / 1 (5 inputs) */
+} ffv1o_params;
+
+/* geometry helpers */
+uint32_t ffv1o_bits_per_raw_sample(uint32_t pixfmt);
+uint32_t ffv1o_plane_count(uint32_t pixfmt);        /* 1, 3 or 4 */
+uint32_t ffv1o_bytes_per_pixel(uint32_t pixfmt);
+/* bytes per payload line: DPX pads each line to 32 bit (RawFrame.cpp:109); TIFF does not. */
+size_t   ffv1o_line_bytes(uint32_t pixfmt, uint32_t width, int dpx_line_padding);
+
+/* FFV1 configuration record incl. CRC (inverse of FFV1_Parameters.cpp:23-183).  Returns size. */
+size_t ffv1o_config_record(const ffv1o_params* p, uint8_t* out, size_t cap);
+
+/* payload -> FFV1 planes (forward RCT + unpack; inverse of Transform.cpp). planes[i] has width*height int32. */
+void ffv1o_unpack(const ffv1o_params* p, const uint8_t* payload, size_t line_bytes, int32_t* const planes[4]);
+/* planes -> payload (restates Transform.cpp From()). Padding bits are written as zero. */
+void ffv1o_pack(const ffv1o_params* p, int32_t* const planes[4], uint8_t* payload, size_t line_bytes);
+
+/* One intra frame: planes -> packet.  Returns packet size, 0 on overflow.
+ * slice_sizes (optional, num_h*num_v entries) receives the byte size of each slice incl. footer. */
+size_t ffv1o_encode_frame(const ffv1o_params* p, int32_t* const planes[4], uint8_t* out, size_t cap,
+                          uint32_t* slice_sizes);
+/* Convenience: unpack + encode. */
+size_t ffv1o_encode_payload(const ffv1o_params* p, const uint8_t* payload, size_t line_bytes,
+                            uint8_t* out, size_t cap, uint32_t* slice_sizes);
+/* Packet -> planes (restates FFV1_Frame.cpp:134-228 + FFV1_Slice.cpp). 0 ok, else error code. */
+int ffv1o_decode_frame(const ffv1o_params* p, const uint8_t* pkt, size_t size, int32_t* const planes[4]);
+/* Convenience: decode + pack.  0 ok. */
+int ffv1o_decode_payload(const ffv1o_params* p, const uint8_t* pkt, size_t size, uint8_t* payload, size_t line_bytes);
+
+/* Parse a configuration record back into params (width/height/pixfmt are not in the record: the
+ * caller supplies them; checks that the record agrees with them).  0 ok. */
+int ffv1o_parse_config_record(const uint8_t* rec, size_t size, ffv1o_params* p);
+
+/* CRC-32, poly 0x04C11DB7, MSB first, init 0, no final xor (ZenCRC32.cpp:1097-1135). */
+uint32_t ffv1o_crc32(const uint8_t* d, size_t n);
+
+/* -slices N -> (num_h, num_v): first v in [2,31], h in [v, 2v-1] with h*v==N (FFmpeg's rule; the set
+ * of N it accepts equals Project/GNU/CLI/test/slices.sh:12 valid_slices).  N==1 -> 1x1.  0 ok, -1 invalid. */
+int ffv1o_slices_to_grid(uint32_t n, uint32_t* num_h, uint32_t* num_v);
+
+/* Number of binary range-coder decisions the encoder performed for the last ffv1o_encode_frame call
+ * on this thread (instrumentation for DESIGN.md's per-unit figures). */
+uint64_t ffv1o_last_decisions(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,153 @@
+// ffv1_host.cpp -- host-side FFV1: constants, quantisation models, configuration record, slice-header decisions.
+//
+// The configuration record and the slice headers are a few dozen range-coded symbols per stream / slice; they are
+// produced here on the host.  Everything per-sample runs on the device (ffv1_gpu.hip).
+#include "ffv1_host.h"
+#include "rc_common.h"
+
+namespace rc { namespace ffv1 {
+
+// RFC 9043 default state transition table ("default_state_transition"); index = current state, value = next
+// state after coding a 1.  States 0 and 249..255 are unreachable.
+const uint8_t kOneState[256] = {
+      0,   0,   0,   0,   0,   0,   0,   0,  20,  21,  22,  23,  24,  25,  26,  27,  28,  29,  30,  31,  32,  33,  34,  35,  36,  37,  37,  38,  39,  40,  41,  42,
+     43,  44,  45,  46,  47,  48,  49,  50,  51,  52,  53,  54,  55,  56,  56,  57,  58,  59,  60,  61,  62,  63,  64,  65,  66,  67,  68,  69,  70,  71,  72,  73,
+     74,  75,  75,  76,  77,  78,  79,  80,  81,  82,  83,  84,  85,  86,  87,  88,  89,  90,  91,  92,  93,  94,  94,  95,  96,  97,  98,  99, 100, 101, 102, 103,
+    104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 126, 127, 128, 129, 130, 131, 132, 133, 133,
+    134, 135, 136, 137, 138, 139, 140, 141, 142, 143, 144, 145, 146, 147, 148, 149, 150, 151, 152, 152, 153, 154, 155, 156, 157, 158, 159, 160, 161, 162, 163, 164,
+    165, 166, 167, 168, 169, 170, 171, 171, 172, 173, 174, 175, 176, 177, 178, 179, 180, 181, 182, 183, 184, 185, 186, 187, 188, 189, 190, 190, 191, 192, 194, 194,
+    195, 196, 197, 198, 199, 200, 201, 202, 202, 204, 205, 206, 207, 208, 209, 209, 210, 211, 212, 213, 215, 215, 216, 217, 218, 219, 220, 220, 222, 223, 224, 225,
+    226, 227, 227, 229, 229, 230, 231, 232, 234, 234, 235, 236, 237, 238, 239, 240, 241, 242, 243, 244, 245, 246, 247, 248, 248,   0,   0,   0,   0,   0,   0,   0,
+};
+
+void make_zero_state(uint8_t zero[256])
+{
+    zero[0] = 0;
+    for (int i = 1; i < 256; i++) zero[i] = uint8_t(256 - kOneState[256 - i]);
+}
+
+// Level maps over |difference| 0..127 as run lengths (the record carries exactly these runs, FFV1_Parameters.cpp:222-253).
+static void fill(int16_t* q, std::initializer_list<int> runs, int scale)
+{
+    int k = 0, level = 0;
+    for (int r : runs) { for (int a = 0; a < r; a++) q[k++] = int16_t(level * scale); level++; }
+    for (int i = 1; i < 128; i++) q[256 - i] = int16_t(-q[i]);
+    q[128] = int16_t(-q[127]);
+}
+
+void build_quant_models(uint32_t bps, quant_model m[2])
+{
+    memset(m, 0, 2 * sizeof(quant_model));
+    if (bps <= 8) {            // 11-level / 5-level maps for 8-bit material
+        const std::initializer_list<int> q11 = { 1, 1, 3, 7, 20, 96 }, q5 = { 1, 3, 124 };
+        fill(m[0].q[0], q11, 1); fill(m[0].q[1], q11, 11); fill(m[0].q[2], q11, 121);
+        m[0].context_count = (11 * 11 * 11 + 1) / 2;
+        fill(m[1].q[0], q11, 1); fill(m[1].q[1], q11, 11); fill(m[1].q[2], q5, 121); fill(m[1].q[3], q5, 605); fill(m[1].q[4], q5, 3025);
+        m[1].context_count = (11 * 11 * 5 * 5 * 5 + 1) / 2;
+    } else {                   // 9-level / 5-level maps for high bit depth
+        const std::initializer_list<int> q9 = { 5, 8, 14, 29, 72 }, q5 = { 11, 53, 64 };
+        fill(m[0].q[0], q9, 1); fill(m[0].q[1], q9, 9); fill(m[0].q[2], q9, 81);
+        m[0].context_count = (9 * 9 * 9 + 1) / 2;
+        fill(m[1].q[0], q9, 1); fill(m[1].q[1], q9, 9); fill(m[1].q[2], q5, 81); fill(m[1].q[3], q5, 405); fill(m[1].q[4], q5, 2025);
+        m[1].context_count = (9 * 9 * 5 * 5 * 5 + 1) / 2;
+    }
+}
+
+namespace {
+// Scalar range encoder (RFC 9043 3.8.1; inverse of rangecoder::b, FFV1_RangeCoder.cpp:71-102).  With `trace` set it
+// records (state | bit << 8) instead of producing bytes -- the device consumes that form.
+struct host_rc {
+    uint32_t low = 0, range = 0xFF00;
+    int outstanding = -1, run = 0;
+    std::vector<uint8_t> out;
+    std::vector<uint16_t>* trace = nullptr;
+    uint8_t zero[256];
+    host_rc() { make_zero_state(zero); }
+    void renorm()
+    {
+        while (range < 0x100) {
+            if (outstanding < 0) outstanding = int(low >> 8);
+            else if (low <= 0xFF00) { out.push_back(uint8_t(outstanding)); for (; run; run--) out.push_back(0xFF); outstanding = int(low >> 8); }
+            else if (low >= 0x10000) { out.push_back(uint8_t(outstanding + 1)); for (; run; run--) out.push_back(0x00); outstanding = int((low >> 8) & 0xFF); }
+            else run++;
+            low = (low & 0xFF) << 8; range <<= 8;
+        }
+    }
+    void put(uint8_t& st, int bit)
+    {
+        if (trace) trace->push_back(uint16_t(st | (bit << 8)));
+        else {
+            const uint32_t r1 = (range * st) >> 8;
+            if (bit) { low += range - r1; range = r1; } else range -= r1;
+            renorm();
+        }
+        st = bit ? kOneState[st] : zero[st];
+    }
+    void symbol(uint8_t* st, int32_t v, bool is_signed)   // inverse of rangecoder::u / ::s, FFV1_RangeCoder.cpp:105-305
+    {
+        if (!v) { put(st[0], 1); return; }
+        const uint32_t a = uint32_t(v < 0 ? -v : v);
+        int e = 31 - __builtin_clz(a);
+        put(st[0], 0);
+        for (int i = 0; i < e; i++) put(st[1 + (i < 9 ? i : 9)], 1);
+        put(st[1 + (e < 9 ? e : 9)], 0);
+        for (int i = e - 1; i >= 0; i--) put(st[22 + (i < 9 ? i : 9)], int((a >> i) & 1));
+        if (is_signed) put(st[11 + (e < 10 ? e : 10)], v < 0);
+    }
+    void finish() { range = 0xFF; low += 0xFF; renorm(); range = 0xFF; renorm(); }   // no end bit: record only
+};
+
+void write_quant_table(host_rc& c, const int16_t* q)
+{
+    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
+    int last = 0, i;
+    for (i = 1; i < 128; i++)
+        if (q[i] != q[i - 1]) { c.symbol(st, i - last - 1, false); last = i; }
+    c.symbol(st, i - last - 1, false);
+}
+}  // namespace
+
+std::vector<uint8_t> config_record(const stream_params& p)
+{
+    quant_model m[2];
+    build_quant_models(p.bits_per_raw_sample, m);
+    host_rc c;
+    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
+    c.symbol(st, 3, false);                         // version
+    c.symbol(st, 4, false);                         // micro_version
+    c.symbol(st, 1, false);                         // coder_type: range coder, default transitions (-coder 1)
+    c.symbol(st, p.rgb ? 1 : 0, false);             // colorspace_type
+    c.symbol(st, int32_t(p.bits_per_raw_sample), false);
+    c.put(st[0], p.rgb ? 1 : 0);                    // chroma_planes
+    c.symbol(st, 0, false); c.symbol(st, 0, false); // log2 chroma subsampling
+    c.put(st[0], p.alpha ? 1 : 0);                  // alpha_plane
+    c.symbol(st, int32_t(p.num_h_slices) - 1, false);
+    c.symbol(st, int32_t(p.num_v_slices) - 1, false);
+    c.symbol(st, 2, false);                         // quant_table_set_count
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 5; j++) write_quant_table(c, m[i].q[j]);
+    for (int i = 0; i < 2; i++) c.put(st[0], 0);    // states_coded
+    c.symbol(st, int32_t(p.ec), false);
+    c.symbol(st, 1, false);                         // intra (-g 1)
+    c.finish();
+    const uint32_t crc = rcgpu_crc32_ffv1(c.out.data(), c.out.size());
+    for (int s = 24; s >= 0; s -= 8) c.out.push_back(uint8_t(crc >> s));   // parity: CRC(record || crc) == 0 (FFV1_Frame.cpp:116)
+    return c.out;
+}
+
+std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx, uint32_t sy, bool first_slice)
+{
+    std::vector<uint16_t> d;
+    host_rc c; c.trace = &d;
+    if (first_slice) { uint8_t ks = 128; c.put(ks, 1); }           // keyframe
+    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
+    c.symbol(st, int32_t(sx), false);
+    c.symbol(st, int32_t(sy), false);
+    c.symbol(st, 0, false); c.symbol(st, 0, false);                 // slice_width-1, slice_height-1 in slice units
+    const uint32_t index_count = p.rgb ? (p.alpha ? 3u : 2u) : 2u;  // quant_table_set_index_count, FFV1_Parameters.cpp:164-178
+    for (uint32_t i = 0; i < index_count; i++) c.symbol(st, int32_t(p.context_model), false);
+    c.symbol(st, 3, false);                                         // picture_structure: progressive
+    c.symbol(st, 0, false); c.symbol(st, 0, false);                 // sar_num / sar_den unknown
+    return d;
+}
+
+}}  // namespace rc::ffv1

@@ -1,0 +1,40 @@
+// ffv1_host.h -- host-side FFV1 pieces of the encoder: bitstream constants, the configuration record,
+// and the per-slice header decisions that are prepended to each slice's decision stream on the device.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace rc { namespace ffv1 {
+
+constexpr int kContextSize = 32;      // states per context (Lib/CoDec/FFV1/FFV1_RangeCoder.h:23)
+
+// FFV1 default state transition table (bitstream constant; the decoder's copy is FFV1_Frame.cpp:35-55) and
+// its mirror zero_state[i] = 256 - one_state[256 - i] (FFV1_RangeCoder.cpp:35-41).
+extern const uint8_t kOneState[256];
+void make_zero_state(uint8_t zero[256]);
+
+struct quant_model {
+    int16_t  q[5][256];           // value = level * scale, negative half mirrored (FFV1_Parameters.cpp:243-245)
+    uint32_t context_count;       // (scale_final + 1) / 2
+};
+// The two table sets carried in the configuration record: [0] 3-input model, [1] 5-input model
+// (level maps as FFmpeg's ffv1enc chooses them for <= 8 bit and > 8 bit material).
+void build_quant_models(uint32_t bits_per_raw_sample, quant_model out[2]);
+
+struct stream_params {
+    uint32_t bits_per_raw_sample;
+    bool     rgb;                 // colorspace_type 1 (JPEG 2000 RCT) vs 0 (gray)
+    bool     alpha;
+    uint32_t num_h_slices, num_v_slices;
+    uint32_t ec;                  // slicecrc
+    uint32_t context_model;       // quant table set index used by every plane (-context)
+};
+
+// Configuration record incl. CRC (what parameters::Parse reads, FFV1_Parameters.cpp:23-183).
+std::vector<uint8_t> config_record(const stream_params& p);
+
+// (state | bit << 8) decisions of [keyframe bit ||] slice header (FFV1_Frame.cpp:148-156, FFV1_Slice.cpp:113-177)
+// for slice (sx, sy); the adaptive states involved are private to the header, so the host can resolve them.
+std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx, uint32_t sy, bool first_slice);
+
+}}  // namespace rc::ffv1

@@ -1,0 +1,287 @@
+// formats.cpp -- header probes for the uncompressed inputs of the encode path.
+//
+// The reference's parsers (Lib/Uncompressed/{DPX,TIFF,WAV}) also write the reversibility data; that half
+// stays in RAWcooked (north_star: "reversibility-data attachment unchanged").  The encoder side only needs
+// what FFmpeg's demuxers extracted for it: where the payload starts, its geometry and layout.  Each probe
+// re-derives the reference's flavor / slice decisions so that a stream described only by a file template
+// yields the same encoder configuration `rawcooked -d` prints.
+#include "rc_common.h"
+#include <algorithm>
+
+using namespace rc;
+
+// slice_x rule shared by dpx::ParseBuffer (DPX.cpp:428-441) and tiff::ParseBuffer (TIFF.cpp:657-669)
+static uint32_t reference_slice_x(uint32_t width, uint32_t height, uint32_t bitdepth)
+{
+    uint32_t s = 4;
+    if (width >= 1440) s <<= 1;
+    if (width >= 2880) s <<= 1;
+    if (bitdepth > 10) s = s * 3 / 2;
+    s = std::min(s, width / 2);
+    s = std::min(s, height / 2);
+    return s ? s : 1;
+}
+
+static void flavor_string(char out[64], const char* container, uint32_t pixfmt)
+{
+    // "<container>/Raw/<RGB|RGBA|Y>/<bits>bit[/Packing]/U[/BE|LE]"  (Lib/Common/Common.cpp:123-139, DPX.cpp DPX_Flavor_String)
+    const pix_desc& d = pix(pixfmt);
+    const char* cs = d.planes == 1 ? "Y" : d.planes == 4 ? "RGBA" : "RGB";
+    const bool filled = pixfmt == RCGPU_PIX_RGB10_FILLEDA_BE || pixfmt == RCGPU_PIX_RGB10_FILLEDA_LE ||
+                        pixfmt == RCGPU_PIX_RGB12_FILLEDA_BE || pixfmt == RCGPU_PIX_RGB12_FILLEDA_LE;
+    if (d.bits == 8)
+        snprintf(out, 64, "%s/Raw/%s/8bit/U", container, cs);
+    else
+        snprintf(out, 64, "%s/Raw/%s/%ubit%s/U/%s", container, cs, d.bits, filled ? "/FilledA" : "", d.big_endian ? "BE" : "LE");
+}
+
+extern "C" int rcgpu_dpx_probe(const uint8_t* f, size_t size, rcgpu_image_info* out)
+{
+    clear_error();
+    if (!f || !out) return fail(1, "dpx: null argument");
+    if (size < 1664) return fail(2, "dpx: file too small for a header");
+    memset(out, 0, sizeof *out);
+    bool be;
+    const uint32_t magic = rd32(f, true);
+    if (magic == 0x53445058) be = true;          // "SDPX"   DPX.cpp:296-299
+    else if (magic == 0x58504453) be = false;    // "XPDS"   DPX.cpp:292-295
+    else return fail(3, "dpx: bad magic number");
+    const uint32_t offset_to_image = rd32(f + 4, be);
+    const uint32_t version = rd32(f + 8, true);
+    if (version != 0 && version != 0x56312E30 && version != 0x56322E30 && version != 0x76312E30 && version != 0x76322E30)
+        return fail(4, "dpx: unsupported version number");                                   // DPX.cpp:306-318
+    uint32_t industry = rd32(f + 28, be);
+    if (industry == 0xFFFFFFFFu) industry = 0;
+    const uint32_t encryption = rd32(f + 660, be);
+    if (encryption != 0xFFFFFFFFu && encryption != 0) return fail(5, "dpx: encrypted content");
+    const uint16_t orientation = rd16(f + 768, be);
+    if (rd16(f + 770, be) != 1) return fail(6, "dpx: number of image elements is not 1");
+    const uint32_t width = rd32(f + 772, be), height = rd32(f + 776, be);
+    if (rd32(f + 780, be) != 0) return fail(7, "dpx: signed data");
+    const uint8_t descriptor = f[800], bitdepth = f[803];
+    const uint16_t packing = rd16(f + 804, be), encoding = rd16(f + 806, be);
+    if (encoding) return fail(8, "dpx: RLE encoding");
+    uint32_t offset_to_data = rd32(f + 808, be);
+    if (offset_to_data) {
+        if (offset_to_data < 1664 || offset_to_data > size) return fail(9, "dpx: bad offset to data");
+        if (offset_to_data != offset_to_image) return fail(10, "dpx: offset to image data differs from element offset");
+    } else
+        offset_to_data = offset_to_image;                                                     // DPX.cpp:352-361
+    if (rd32(f + 812, be) != 0) return fail(11, "dpx: end-of-line padding");
+    if (orientation != 0) return fail(12, "dpx: orientation %u not supported by this encoder", orientation);
+    if (!width || !height) return fail(13, "dpx: empty image");
+
+    // flavor table, DPX.cpp:184-231 (Tested + Also rows reachable with the layouts this encoder implements)
+    int pf = -1;
+    const bool filledA = packing == 1, packed = packing == 0;
+    switch (descriptor) {
+    case 50:   // RGB
+        if (bitdepth == 8 && (packed || filledA)) pf = RCGPU_PIX_RGB8;
+        else if (bitdepth == 10 && filledA) pf = be ? RCGPU_PIX_RGB10_FILLEDA_BE : RCGPU_PIX_RGB10_FILLEDA_LE;
+        else if (bitdepth == 12 && filledA) pf = be ? RCGPU_PIX_RGB12_FILLEDA_BE : RCGPU_PIX_RGB12_FILLEDA_LE;
+        else if (bitdepth == 16 && (packed || filledA)) pf = be ? RCGPU_PIX_RGB16_BE : RCGPU_PIX_RGB16_LE;
+        break;
+    case 51:   // RGBA
+        if (bitdepth == 8 && (packed || filledA)) pf = RCGPU_PIX_RGBA8;
+        else if (bitdepth == 16 && (packed || filledA)) pf = be ? RCGPU_PIX_RGBA16_BE : RCGPU_PIX_RGBA16_LE;
+        break;
+    case 6:    // Y
+        if (bitdepth == 8 && (packed || filledA)) pf = RCGPU_PIX_Y8;
+        else if (bitdepth == 16 && (packed || filledA || packing == 3)) pf = be ? RCGPU_PIX_Y16_BE : RCGPU_PIX_Y16_LE;
+        break;
+    }
+    if (pf < 0)
+        return fail(14, "dpx: flavor (descriptor %u, %u bit, packing %u, %s) is not supported by this encoder yet",
+                    descriptor, bitdepth, packing, be ? "BE" : "LE");
+    const pix_desc& d = pix(uint32_t(pf));
+    out->width = width; out->height = height; out->pixfmt = uint32_t(pf); out->bits_per_sample = d.bits;
+    // lines are padded to 32 bit (DPX.cpp:476-481, RawFrame.cpp:109)
+    const uint64_t bits_per_line = uint64_t(width) * d.bytes_pp * 8;
+    out->line_bytes = uint32_t(((bits_per_line + 31) / 32) * 4);
+    out->data_offset = offset_to_data;
+    out->data_size = uint64_t(out->line_bytes) * height;
+    if (out->data_offset + out->data_size > size) return fail(15, "dpx: truncated image data");
+    const uint32_t sx = reference_slice_x(width, height, bitdepth);
+    out->slices = sx * sx;
+    if (industry && size >= 1944) {     // DPX.cpp:370-387
+        auto f32 = [&](size_t o) { uint32_t u = rd32(f + o, be); float v; memcpy(&v, &u, 4); return (u == 0xFFFFFFFFu || v != v) ? 0.0 : double(v); };
+        const double film = f32(1724), tv = f32(1940);
+        out->framerate = film ? film : tv;
+    }
+    flavor_string(out->flavor, "DPX", out->pixfmt);
+    return 0;
+}
+
+namespace {
+struct tiff_reader {
+    const uint8_t* f; size_t size; bool be; bool bad = false;
+    uint16_t u16(size_t o) { if (o + 2 > size) { bad = true; return 0; } return rd16(f + o, be); }
+    uint32_t u32(size_t o) { if (o + 4 > size) { bad = true; return 0; } return rd32(f + o, be); }
+    // all values of one IFD entry (TIFF.cpp:283-378)
+    std::vector<uint32_t> values(size_t entry)
+    {
+        std::vector<uint32_t> v;
+        const uint16_t type = u16(entry + 2);
+        const uint32_t count = u32(entry + 4);
+        static const uint8_t tsz[6] = { 0, 1, 1, 2, 4, 8 };
+        if (!type || type > 5 || !count || count > (1u << 24)) { bad = true; return v; }
+        const size_t esz = tsz[type];
+        size_t o = entry + 8;
+        if (esz * count > 4) o = u32(entry + 8);
+        for (uint32_t i = 0; i < count && !bad; i++, o += esz)
+            v.push_back(esz == 1 ? (o < size ? f[o] : (bad = true, 0)) : esz == 2 ? u16(o) : u32(o));
+        return v;
+    }
+};
+}
+
+extern "C" int rcgpu_tiff_probe(const uint8_t* f, size_t size, rcgpu_image_info* out)
+{
+    clear_error();
+    if (!f || !out) return fail(1, "tiff: null argument");
+    if (size < 8) return fail(2, "tiff: file too small");
+    memset(out, 0, sizeof *out);
+    tiff_reader r{ f, size, false };
+    const uint32_t magic = rd32(f, true);
+    if (magic == 0x49492A00) r.be = false;       // "II*\0"  TIFF.cpp:391-394
+    else if (magic == 0x4D4D002A) r.be = true;   // "MM\0*"  TIFF.cpp:395-398
+    else return fail(3, "tiff: bad magic number");
+    const uint32_t ifd = r.u32(4);
+    if (ifd > size || ifd + 2 > size) return fail(4, "tiff: bad first IFD offset");
+    const uint32_t n = r.u16(ifd);
+    if (size_t(ifd) + 2 + 12 * size_t(n) + 4 > size) return fail(5, "tiff: bad directory count");
+    uint32_t width = 0, height = 0, bps = 0, photometric = ~0u, compression = 0, spp = 1, planar = 1, fill = 1,
+             orientation = 1, sample_format = 1, extra = 0;
+    bool has_w = false, has_h = false, has_bps = false, has_comp = false, has_extra = false;
+    std::vector<uint32_t> offs, counts;
+    for (uint32_t i = 0; i < n; i++) {
+        const size_t e = size_t(ifd) + 2 + 12 * size_t(i);
+        const uint16_t tag = r.u16(e);
+        auto one = [&]() { auto v = r.values(e); return v.empty() ? 0u : v[0]; };
+        switch (tag) {
+        case 256: width = one(); has_w = true; break;
+        case 257: height = one(); has_h = true; break;
+        case 258: { auto v = r.values(e); if (!v.empty()) { bps = v[0]; has_bps = true; for (auto x : v) if (x != bps) return fail(6, "tiff: BitsPerSample values differ"); } break; }
+        case 259: compression = one(); has_comp = true; break;
+        case 262: photometric = one(); break;
+        case 266: fill = one(); break;
+        case 273: offs = r.values(e); break;
+        case 274: orientation = one(); break;
+        case 277: spp = one(); break;
+        case 279: counts = r.values(e); break;
+        case 284: planar = one(); break;
+        case 338: extra = one(); has_extra = true; break;
+        case 339: sample_format = one(); break;
+        case 254: if (one()) return fail(7, "tiff: NewSubfileType"); break;
+        case 255: return fail(7, "tiff: SubfileType");
+        case 317: case 320: case 322: case 323: case 324: case 325:   // Predictor, ColorMap, tiles (TIFF.cpp:527-551)
+            return fail(8, "tiff: unsupported IFD tag %u", tag);
+        default: break;
+        }
+    }
+    if (r.bad) return fail(9, "tiff: directory points outside the file");
+    // checks of TIFF.cpp:556-590
+    if (!has_w || !has_h || !has_bps || !has_comp || photometric == ~0u) return fail(10, "tiff: missing mandatory tag");
+    if (compression != 1) return fail(11, "tiff: compressed content");
+    if (fill != 1 || orientation != 1 || planar != 1 || sample_format != 1) return fail(12, "tiff: unsupported FillOrder/Orientation/PlanarConfiguration/SampleFormat");
+    if (offs.empty() || offs.size() != counts.size()) return fail(13, "tiff: bad StripOffsets/StripByteCounts");
+    int pf = -1;
+    if (photometric == 2 && spp == 3 && !has_extra) {
+        if (bps == 8) pf = RCGPU_PIX_RGB8;
+        else if (bps == 16) pf = r.be ? RCGPU_PIX_RGB16_BE : RCGPU_PIX_RGB16_LE;
+    } else if (photometric == 2 && spp == 4 && has_extra && extra == 2) {
+        if (bps == 8) pf = RCGPU_PIX_RGBA8;
+        else if (bps == 16 && !r.be) pf = RCGPU_PIX_RGBA16_LE;         // TIFF.cpp:161-162: no RGBA16 BE row
+    } else if (photometric == 1 && spp == 1 && !has_extra) {
+        if (bps == 8) pf = RCGPU_PIX_Y8;
+        else if (bps == 16) pf = r.be ? RCGPU_PIX_Y16_BE : RCGPU_PIX_Y16_LE;
+    }
+    if (pf < 0) return fail(14, "tiff: flavor (photometric %u, %u x %u bit, %s) is not supported", photometric, spp, bps, r.be ? "BE" : "LE");
+    // strips must be contiguous and exactly cover the image (TIFF.cpp:638-645, 675-678)
+    uint64_t last = uint64_t(offs[0]) + counts[0];
+    for (size_t i = 1; i < offs.size(); i++) {
+        if (last != offs[i]) return fail(15, "tiff: strips are not contiguous");
+        last += counts[i];
+    }
+    const pix_desc& d = pix(uint32_t(pf));
+    out->width = width; out->height = height; out->pixfmt = uint32_t(pf); out->bits_per_sample = d.bits;
+    out->line_bytes = width * d.bytes_pp;
+    out->data_offset = offs[0];
+    out->data_size = uint64_t(out->line_bytes) * height;
+    if (out->data_offset + out->data_size != last) return fail(16, "tiff: strip sizes do not match the image size");
+    if (last > size) return fail(17, "tiff: truncated image data");
+    const uint32_t sx = reference_slice_x(width, height, bps);
+    out->slices = sx * sx;
+    flavor_string(out->flavor, "TIFF", out->pixfmt);
+    return 0;
+}
+
+extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* out)
+{
+    clear_error();
+    if (!f || !out) return fail(1, "wav: null argument");
+    if (size < 12) return fail(2, "wav: file too small");
+    memset(out, 0, sizeof *out);
+    const uint32_t first = rd32(f, true);
+    const bool rf64 = first == 0x52463634;                                   // WAV.cpp:281-286
+    if ((first != 0x52494646 && !rf64) || rd32(f + 8, true) != 0x57415645) return fail(3, "wav: not a RIFF/RF64 WAVE file");
+    uint64_t pos = 12, ds64_data = 0;
+    bool have_fmt = false;
+    uint16_t tag = 0;
+    while (pos + 8 <= size) {
+        const uint32_t name = rd32(f + pos, true);
+        uint64_t csize = rd32(f + pos + 4, false);
+        pos += 8;
+        if (name == 0x64733634) {                 // "ds64"  WAV.cpp:438-459
+            if (pos + 28 > size) return fail(4, "wav: truncated ds64 chunk");
+            ds64_data = rd64le(f + pos + 8);
+            if (rd32(f + pos + 24, false)) return fail(5, "wav: ds64 table is not supported");
+        } else if (name == 0x666D7420) {          // "fmt "  WAV.cpp:461-542
+            if (csize < 16 || pos + csize > size) return fail(6, "wav: bad fmt chunk");
+            tag = rd16(f + pos, false);
+            out->channels = rd16(f + pos + 2, false);
+            out->sample_rate = rd32(f + pos + 4, false);
+            const uint32_t avg = rd32(f + pos + 8, false);
+            out->block_align = rd16(f + pos + 12, false);
+            out->bits_per_sample = rd16(f + pos + 14, false);
+            if (uint64_t(avg) * 8 != uint64_t(out->channels) * out->bits_per_sample * out->sample_rate) return fail(7, "wav: incoherent AvgBytesPerSec");
+            if (out->block_align * 8u != out->channels * out->bits_per_sample) return fail(7, "wav: incoherent BlockAlign");
+            if (tag == 0xFFFE) {
+                if (csize != 40 || rd16(f + pos + 16, false) != 22) return fail(8, "wav: bad WAVE_FORMAT_EXTENSIBLE chunk");
+                if (rd16(f + pos + 18, false) != out->bits_per_sample) return fail(8, "wav: ValidBitsPerSample differs");
+                tag = uint16_t(rd32(f + pos + 24, false));
+            }
+            if (tag != 1) return fail(9, "wav: format tag %u is not integer PCM", tag);
+            have_fmt = true;
+        } else if (name == 0x64617461) {          // "data"  WAV.cpp:390-436
+            if (!have_fmt) return fail(10, "wav: data chunk before fmt chunk");
+            if (rf64 && (csize == 0xFFFFFFFFu || csize == ds64_data)) csize = ds64_data;
+            if (csize > size - pos) return fail(11, "wav: truncated data chunk");
+            if (csize % out->block_align) return fail(12, "wav: data size is not a multiple of the block size");
+            out->data_offset = pos; out->data_size = csize;
+            // flavor table WAV.cpp:125-221: channels {1,2,4,6,8}... kept permissive up to 8 channels
+            if (out->channels < 1 || out->channels > 8) return fail(13, "wav: %u channels not supported", out->channels);
+            if (out->bits_per_sample != 8 && out->bits_per_sample != 16 && out->bits_per_sample != 24)
+                return fail(14, "wav: %u-bit PCM cannot be coded as FLAC (reference forces -c:a copy, CLI/Main.cpp:300-317)", out->bits_per_sample);
+            snprintf(out->flavor, sizeof out->flavor, "WAV/PCM/%ukHz/%ubit/%uch/%s/LE", out->sample_rate / 1000,
+                     out->bits_per_sample, out->channels, out->bits_per_sample == 8 ? "U" : "S");
+            return 0;
+        }
+        pos += csize;
+        if ((pos & 1) && pos < size && !f[pos]) pos++;     // padding byte, WAV.cpp:360-365
+    }
+    return fail(15, "wav: no data chunk");
+}
+
+extern "C" int rcgpu_slices_to_grid(uint32_t n, uint32_t* num_h, uint32_t* num_v)
+{
+    // FFmpeg's ffv1 encoder maps -slices N to the first (v in [2,31], h in [v,2v-1]) with h*v == N; the set of
+    // N this accepts is exactly valid_slices in Project/GNU/CLI/test/slices.sh:12.  N == 1 is the 1x1 case the
+    // reference allows with -level 0/1 only (CLI/Global.cpp:976-985).
+    if (!num_h || !num_v) return 1;
+    if (n == 1) { *num_h = *num_v = 1; return 0; }
+    for (uint32_t v = 2; v < 32; v++)
+        for (uint32_t h = v; h < 2 * v; h++)
+            if (h * v == n) { *num_h = h; *num_v = v; return 0; }
+    return fail(1, "slices: %u cannot be laid out as h x v with v <= h < 2v", n);
+}

@@ -1,0 +1,324 @@
+// mkv_mux.cpp -- minimal Matroska writer for the FFV1 (+FLAC) + attachments files RAWcooked produces.
+//
+// Replaces FFmpeg's matroska muxer on the encode path (the `-f matroska "<out>"` tail of the command assembled at
+// CLI/Output.cpp:303-305).  Layout rules come from what the reference's own reader accepts
+// (Lib/Compressed/Matroska/Matroska.cpp): one Segment with a KNOWN size (:1259-1277), Tracks in stream order with
+// CodecID/CodecPrivate/PixelWidth/PixelHeight as 1-2 byte uints (:992-1030), Attachments BEFORE the first Cluster
+// (:863-873), SimpleBlocks only with single-byte track numbers (:934-953).  SeekHead, Info, Cues and the
+// per-track UIDs/durations are there for stock players (they are skipped by the reference, :128-217).
+#include "rc_common.h"
+#include <cerrno>
+#include <cmath>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+using namespace rc;
+
+namespace {
+
+struct ebuf {                       // growable byte buffer with EBML primitives
+    std::vector<uint8_t> b;
+    void raw(const void* p, size_t n) { const uint8_t* s = static_cast<const uint8_t*>(p); b.insert(b.end(), s, s + n); }
+    void id(uint32_t v) { for (int s = 24; s >= 0; s -= 8) if (v >> s) { for (; s >= 0; s -= 8) b.push_back(uint8_t(v >> s)); return; } }
+    void size(uint64_t v)           // shortest EBML size
+    {
+        int n = 1;
+        while (n < 8 && v >= (uint64_t(1) << (7 * n)) - 1) n++;
+        size_n(v, n);
+    }
+    void size_n(uint64_t v, int n) { for (int i = n - 1; i >= 0; i--) b.push_back(uint8_t((v >> (8 * i)) & 0xFF) | (i == n - 1 ? uint8_t(1 << (8 - n)) : 0)); }
+    void uint(uint32_t i, uint64_t v) { id(i); int n = 1; while (n < 8 && (v >> (8 * n))) n++; size(uint64_t(n)); for (int k = n - 1; k >= 0; k--) b.push_back(uint8_t(v >> (8 * k))); }
+    void uint_n(uint32_t i, uint64_t v, int n) { id(i); size(uint64_t(n)); for (int k = n - 1; k >= 0; k--) b.push_back(uint8_t(v >> (8 * k))); }
+    void f64(uint32_t i, double v) { id(i); size(8); uint64_t u; memcpy(&u, &v, 8); for (int k = 7; k >= 0; k--) b.push_back(uint8_t(u >> (8 * k))); }
+    void str(uint32_t i, const std::string& s) { id(i); size(s.size()); raw(s.data(), s.size()); }
+    void bin(uint32_t i, const void* p, size_t n) { id(i); size(n); raw(p, n); }
+    void master(uint32_t i, const ebuf& c) { id(i); size(c.b.size()); raw(c.b.data(), c.b.size()); }
+    void voidel(size_t total)       // EBML Void occupying exactly `total` bytes (total >= 2)
+    {
+        b.push_back(0xEC);
+        if (total < 10) { size_n(total - 2, 1); b.insert(b.end(), total - 2, 0); }
+        else { size_n(total - 9, 8); b.insert(b.end(), total - 9, 0); }
+    }
+};
+
+struct track {
+    bool video;
+    std::vector<uint8_t> codec_private;
+    uint32_t width = 0, height = 0, fps_num = 0, fps_den = 0;
+    uint32_t channels = 0, sample_rate = 0, bits = 0;
+    uint64_t cp_file_pos = 0;      // absolute file offset of the CodecPrivate payload
+    uint64_t last_pts_ms = 0, end_ms = 0;
+};
+struct attach { std::string name, mime; std::vector<uint8_t> data; };
+struct cue { uint64_t time_ms; int track; uint64_t cluster_pos; };
+
+}  // namespace
+
+struct rcgpu_mkv {
+    int fd = -1;
+    std::string path;
+    std::vector<track> tracks;
+    std::vector<attach> attachments;
+    std::vector<cue> cues;
+    uint64_t pos = 0;                 // bytes written so far
+    uint64_t segment_data = 0;        // file offset of the first byte after the Segment size field
+    uint64_t seekhead_pos = 0, info_pos = 0, tracks_pos = 0, attachments_pos = 0, duration_pos = 0;
+    bool begun = false;
+    // open cluster
+    ebuf cluster; uint64_t cluster_ts = 0; bool cluster_open = false; uint64_t cluster_file_pos = 0;
+    uint64_t uid_seed = 0x9E3779B97F4A7C15ull;
+
+    uint64_t next_uid() { uid_seed ^= uid_seed << 13; uid_seed ^= uid_seed >> 7; uid_seed ^= uid_seed << 17; return uid_seed | 1; }
+    int put(const void* p, size_t n)
+    {
+        const uint8_t* s = static_cast<const uint8_t*>(p);
+        while (n) {
+            ssize_t w = ::write(fd, s, n);
+            if (w < 0) { if (errno == EINTR) continue; return fail(20, "mkv: write to %s failed: %s", path.c_str(), strerror(errno)); }
+            s += w; n -= size_t(w); pos += uint64_t(w);
+        }
+        return 0;
+    }
+    int put_at(uint64_t off, const void* p, size_t n)
+    {
+        if (::pwrite(fd, p, n, off_t(off)) != ssize_t(n)) return fail(21, "mkv: patching %s failed: %s", path.c_str(), strerror(errno));
+        return 0;
+    }
+    int flush_cluster()
+    {
+        if (!cluster_open) return 0;
+        ebuf head; head.id(0x1F43B675); head.size(cluster.b.size());
+        cluster_open = false;
+        if (int r = put(head.b.data(), head.b.size())) return r;
+        return put(cluster.b.data(), cluster.b.size());
+    }
+};
+
+static const uint64_t kSeekHeadReserve = 160;     // room for 5 Seek entries, padded with Void
+
+extern "C" int rcgpu_mkv_open(const char* path, int overwrite, rcgpu_mkv** out)
+{
+    clear_error();
+    if (!path || !out) return fail(1, "mkv: null argument");
+    int flags = O_WRONLY | O_CREAT | (overwrite ? O_TRUNC : O_EXCL);
+    int fd = ::open(path, flags, 0644);
+    if (fd < 0) return fail(2, "mkv: cannot create %s: %s", path, strerror(errno));
+    rcgpu_mkv* m = new rcgpu_mkv;
+    m->fd = fd; m->path = path;
+    for (const char* c = path; *c; c++) m->uid_seed = m->uid_seed * 1099511628211ull + uint8_t(*c);
+    *out = m;
+    return 0;
+}
+
+extern "C" int rcgpu_mkv_add_video(rcgpu_mkv* m, const uint8_t* cp, size_t cp_size, uint32_t w, uint32_t h, uint32_t fps_num, uint32_t fps_den)
+{
+    if (!m || m->begun) { fail(1, "mkv: add_video after begin"); return -1; }
+    if (w > 0xFFFF || h > 0xFFFF) { fail(1, "mkv: picture size above 65535 is not readable by the reference (Matroska.cpp:1007-1030)"); return -1; }
+    if (m->tracks.size() >= 126) { fail(1, "mkv: too many tracks"); return -1; }
+    track t; t.video = true; t.codec_private.assign(cp, cp + cp_size); t.width = w; t.height = h;
+    t.fps_num = fps_num ? fps_num : 24; t.fps_den = fps_den ? fps_den : 1;
+    m->tracks.push_back(t);
+    return int(m->tracks.size());
+}
+
+extern "C" int rcgpu_mkv_add_audio(rcgpu_mkv* m, const uint8_t* cp, size_t cp_size, uint32_t ch, uint32_t rate, uint32_t bits)
+{
+    if (!m || m->begun) { fail(1, "mkv: add_audio after begin"); return -1; }
+    if (m->tracks.size() >= 126) { fail(1, "mkv: too many tracks"); return -1; }
+    track t; t.video = false; t.codec_private.assign(cp, cp + cp_size); t.channels = ch; t.sample_rate = rate; t.bits = bits;
+    m->tracks.push_back(t);
+    return int(m->tracks.size());
+}
+
+extern "C" int rcgpu_mkv_add_attachment(rcgpu_mkv* m, const char* name, const char* mime, const uint8_t* data, size_t size)
+{
+    if (!m || m->begun) return fail(1, "mkv: add_attachment after begin");
+    attach a; a.name = name ? name : ""; a.mime = mime ? mime : "application/octet-stream"; a.data.assign(data, data + size);
+    m->attachments.push_back(std::move(a));
+    return 0;
+}
+
+extern "C" int rcgpu_mkv_begin(rcgpu_mkv* m)
+{
+    clear_error();
+    if (!m || m->begun) return fail(1, "mkv: begin called twice");
+    if (m->tracks.empty()) return fail(1, "mkv: no track");
+    m->begun = true;
+    ebuf f;
+    {   // EBML header
+        ebuf h;
+        h.uint(0x4286, 1); h.uint(0x42F7, 1); h.uint(0x42F2, 4); h.uint(0x42F3, 8);
+        h.str(0x4282, "matroska"); h.uint(0x4287, 4); h.uint(0x4285, 2);
+        f.master(0x1A45DFA3, h);
+    }
+    f.id(0x18538067); f.size_n(0, 8);             // Segment, size patched by close()
+    m->segment_data = f.b.size();
+    m->seekhead_pos = f.b.size();
+    f.voidel(kSeekHeadReserve);                   // SeekHead goes here at close()
+    {   // Info
+        m->info_pos = f.b.size();
+        ebuf i;
+        i.uint(0x2AD7B1, 1000000);                // TimestampScale: 1 ms
+        i.str(0x4D80, "rcgpu"); i.str(0x5741, rcgpu_version());
+        { uint8_t uid[16]; for (int k = 0; k < 16; k += 8) { uint64_t u = m->next_uid(); memcpy(uid + k, &u, 8); } i.bin(0x73A4, uid, 16); }
+        const size_t dur_rel = i.b.size();
+        i.f64(0x4489, 0.0);                       // Duration, patched by close()
+        ebuf tmp; tmp.id(0x1549A966); tmp.size(i.b.size());
+        m->duration_pos = f.b.size() + tmp.b.size() + dur_rel + 3;   // id(2) + size(1) -> payload
+        f.master(0x1549A966, i);
+    }
+    {   // Tracks
+        m->tracks_pos = f.b.size();
+        ebuf ts;
+        for (size_t k = 0; k < m->tracks.size(); k++) {
+            track& t = m->tracks[k];
+            ebuf e;
+            e.uint(0xD7, k + 1); e.uint(0x73C5, m->next_uid() & 0x7FFFFFFFFFFFFFFFull);
+            e.uint(0x83, t.video ? 1 : 2); e.uint(0x9C, 0);
+            e.str(0x22B59C, "und");
+            e.str(0x86, t.video ? "V_FFV1" : "A_FLAC");
+            const size_t cp_rel_before = e.b.size();
+            e.bin(0x63A2, t.codec_private.data(), t.codec_private.size());
+            const size_t cp_payload_rel = e.b.size() - t.codec_private.size();
+            (void)cp_rel_before;
+            if (t.video) {
+                e.uint(0x23E383, uint64_t(std::llround(1e9 * double(t.fps_den) / double(t.fps_num))));   // DefaultDuration
+                ebuf v; v.uint(0x9A, 2); v.uint(0xB0, t.width); v.uint(0xBA, t.height); v.uint(0x54B0, t.width); v.uint(0x54BA, t.height);
+                e.master(0xE0, v);
+            } else {
+                ebuf a; a.f64(0xB5, double(t.sample_rate)); a.uint(0x9F, t.channels); a.uint(0x6264, t.bits);
+                e.master(0xE1, a);
+            }
+            ebuf tmp; tmp.id(0xAE); tmp.size(e.b.size());
+            // remember where this entry's CodecPrivate payload lands (relative to the Tracks payload for now)
+            t.cp_file_pos = ts.b.size() + tmp.b.size() + cp_payload_rel;
+            ts.master(0xAE, e);
+        }
+        ebuf tmp; tmp.id(0x1654AE6B); tmp.size(ts.b.size());
+        for (track& t : m->tracks) t.cp_file_pos += f.b.size() + tmp.b.size();
+        f.master(0x1654AE6B, ts);
+    }
+    if (int r = m->put(f.b.data(), f.b.size())) return r;
+    if (!m->attachments.empty()) {   // Attachments (before any Cluster, Matroska.cpp:863-873); streamed to keep big sidecars out of one buffer
+        m->attachments_pos = m->pos;
+        std::vector<ebuf> heads(m->attachments.size());
+        uint64_t total = 0;
+        for (size_t k = 0; k < m->attachments.size(); k++) {
+            attach& a = m->attachments[k];
+            ebuf inner;
+            inner.str(0x466E, a.name); inner.str(0x4660, a.mime); inner.uint(0x46AE, m->next_uid() & 0x7FFFFFFFFFFFFFFFull);
+            inner.id(0x465C); inner.size(a.data.size());
+            ebuf& h = heads[k];
+            h.id(0x61A7); h.size(inner.b.size() + a.data.size()); h.raw(inner.b.data(), inner.b.size());
+            total += h.b.size() + a.data.size();
+        }
+        ebuf top; top.id(0x1941A469); top.size(total);
+        if (int r = m->put(top.b.data(), top.b.size())) return r;
+        for (size_t k = 0; k < m->attachments.size(); k++) {
+            if (int r = m->put(heads[k].b.data(), heads[k].b.size())) return r;
+            if (int r = m->put(m->attachments[k].data.data(), m->attachments[k].data.size())) return r;
+            std::vector<uint8_t>().swap(m->attachments[k].data);
+        }
+    }
+    return 0;
+}
+
+extern "C" int rcgpu_mkv_write_block(rcgpu_mkv* m, int trk, uint64_t pts_ns, const uint8_t* data, size_t size, int keyframe)
+{
+    if (!m || !m->begun) return fail(1, "mkv: write_block before begin");
+    if (trk < 1 || size_t(trk) > m->tracks.size()) return fail(1, "mkv: bad track number %d", trk);
+    track& t = m->tracks[size_t(trk) - 1];
+    const uint64_t ms = (pts_ns + 500000) / 1000000;
+    // FFmpeg-like clustering: a new Cluster on every video keyframe once the open one holds >= 5 MB or spans
+    // >= 5 s, and always before the 16-bit relative timestamp would overflow.
+    const bool big = m->cluster.b.size() + size > (5u << 20);
+    const bool far = m->cluster_open && (ms < m->cluster_ts || ms - m->cluster_ts > 5000);
+    if (m->cluster_open && (far || (big && (t.video || m->tracks.size() == 1)) || ms - m->cluster_ts > 32000))
+        if (int r = m->flush_cluster()) return r;
+    if (!m->cluster_open) {
+        m->cluster.b.clear();
+        m->cluster.uint(0xE7, ms);
+        m->cluster_ts = ms; m->cluster_open = true; m->cluster_file_pos = m->pos;
+    }
+    if (t.video && keyframe)
+        m->cues.push_back({ ms, trk, m->cluster_file_pos - m->segment_data });
+    ebuf& c = m->cluster;
+    c.id(0xA3); c.size(size + 4);
+    c.b.push_back(uint8_t(0x80 | trk));
+    const int16_t rel = int16_t(ms - m->cluster_ts);
+    c.b.push_back(uint8_t(uint16_t(rel) >> 8)); c.b.push_back(uint8_t(rel));
+    c.b.push_back(keyframe ? 0x80 : 0x00);
+    if (size > (1u << 20)) {      // large frame: write the cluster directly, avoiding a second copy of 50 MB packets
+        ebuf head; head.id(0x1F43B675); head.size(c.b.size() + size);
+        m->cluster_open = false;
+        if (int r = m->put(head.b.data(), head.b.size())) return r;
+        if (int r = m->put(c.b.data(), c.b.size())) return r;
+        if (int r = m->put(data, size)) return r;
+    } else
+        c.raw(data, size);
+    t.last_pts_ms = ms;
+    uint64_t end = ms;
+    if (t.video) end = ms + uint64_t(std::llround(1000.0 * t.fps_den / t.fps_num));
+    if (end > t.end_ms) t.end_ms = end;
+    return 0;
+}
+
+extern "C" int rcgpu_mkv_update_codec_private(rcgpu_mkv* m, int trk, const uint8_t* cp, size_t cp_size)
+{
+    if (!m || !m->begun) return fail(1, "mkv: update_codec_private before begin");
+    if (trk < 1 || size_t(trk) > m->tracks.size()) return fail(1, "mkv: bad track number %d", trk);
+    track& t = m->tracks[size_t(trk) - 1];
+    if (cp_size != t.codec_private.size()) return fail(1, "mkv: CodecPrivate size changed");
+    t.codec_private.assign(cp, cp + cp_size);
+    return m->put_at(t.cp_file_pos, cp, cp_size);
+}
+
+extern "C" int rcgpu_mkv_close(rcgpu_mkv* m)
+{
+    if (!m) return 0;
+    int r = 0;
+    if (m->begun) {
+        r = m->flush_cluster();
+        uint64_t cues_pos = 0;
+        if (!r && !m->cues.empty()) {
+            cues_pos = m->pos;
+            ebuf cs;
+            for (const cue& c : m->cues) {
+                ebuf tp; tp.uint(0xF7, uint64_t(c.track)); tp.uint(0xF1, c.cluster_pos);
+                ebuf cp; cp.uint(0xB3, c.time_ms); cp.master(0xB7, tp);
+                cs.master(0xBB, cp);
+            }
+            ebuf top; top.master(0x1C53BB6B, cs);
+            r = m->put(top.b.data(), top.b.size());
+        }
+        if (!r) {   // Segment size
+            ebuf s; s.size_n(m->pos - m->segment_data, 8);
+            r = m->put_at(m->segment_data - 8, s.b.data(), 8);
+        }
+        if (!r) {   // SeekHead in the reserved Void
+            ebuf sh;
+            auto seek = [&](uint32_t id, uint64_t at) {
+                ebuf e; ebuf idb; idb.id(id); e.bin(0x53AB, idb.b.data(), idb.b.size()); e.uint_n(0x53AC, at - m->segment_data, 8); sh.master(0x4DBB, e);
+            };
+            seek(0x1549A966, m->info_pos); seek(0x1654AE6B, m->tracks_pos);
+            if (m->attachments_pos) seek(0x1941A469, m->attachments_pos);
+            if (cues_pos) seek(0x1C53BB6B, cues_pos);
+            ebuf top; top.master(0x114D9B74, sh);
+            if (top.b.size() + 2 <= kSeekHeadReserve) {
+                top.voidel(kSeekHeadReserve - top.b.size());
+                r = m->put_at(m->seekhead_pos, top.b.data(), top.b.size());
+            }
+        }
+        if (!r) {   // Duration (ms)
+            uint64_t end = 0;
+            for (const track& t : m->tracks) end = std::max(end, t.end_ms);
+            double d = double(end); uint64_t u; memcpy(&u, &d, 8);
+            uint8_t be[8]; for (int k = 0; k < 8; k++) be[k] = uint8_t(u >> (8 * (7 - k)));
+            r = m->put_at(m->duration_pos, be, 8);
+        }
+    }
+    if (::close(m->fd) != 0 && !r) r = fail(22, "mkv: closing %s failed: %s", m->path.c_str(), strerror(errno));
+    delete m;
+    return r;
+}
