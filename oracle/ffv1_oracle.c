@@ -282,6 +282,11 @@ typedef struct {
     uint64_t decisions;
 } rc_enc;
 
+/* Optional per-thread trace of one slice (ffv1o_trace_slice): every decision as state | bit << 8, and every
+ * sample as set << 30 | |ctx| << 17 | (residual & 0x1FFFF) -- the intermediates of the device pipeline. */
+static __thread uint16_t* t_dec; static __thread size_t t_dec_cap, t_dec_n;
+static __thread uint32_t* t_sym; static __thread size_t t_sym_n;
+
 static void rc_tables(uint8_t* one, uint8_t* zero)
 {
     /* AssignStateTransitions, FFV1_RangeCoder.cpp:35-41 */
@@ -320,6 +325,7 @@ static void rce_renorm(rc_enc* c)
 static inline void rce_put(rc_enc* c, uint8_t* state, int bit)
 {
     uint32_t r1 = (c->range * *state) >> 8;      /* Mask2, FFV1_RangeCoder.cpp:90 */
+    if (t_dec) { if (t_dec_n < t_dec_cap) t_dec[t_dec_n] = (uint16_t)(*state | (bit ? 0x100 : 0)); t_dec_n++; }
     if (!bit) { c->range -= r1; *state = c->zero_state[*state]; }
     else { c->low += c->range - r1; c->range = r1; *state = c->one_state[*state]; }
     c->decisions++;
@@ -432,7 +438,7 @@ static void codec_ctx_init(codec_ctx* k, const ffv1o_params* p)
 /* One line of one plane.  cur/prev point at x=0 of buffers with 2 guard samples on the left and 1 on the
  * right (SamplesBuffer layout, FFV1_Slice.cpp:406-425).  On entry cur[] holds the line two above (TT). */
 static void encode_line(rc_enc* c, const codec_ctx* k, uint8_t (*states)[CONTEXT_SIZE], uint32_t w,
-                        int32_t* cur, int32_t* prev, const int32_t* src)
+                        int32_t* cur, int32_t* prev, const int32_t* src, uint32_t set)
 {
     const quant_set* qs = &k->qs[k->qidx];
     const int is5 = qs->q[3][127] != 0;                       /* FFV1_Slice.cpp:453 */
@@ -449,6 +455,7 @@ static void encode_line(rc_enc* c, const codec_ctx* k, uint8_t (*states)[CONTEXT
         int32_t d = v - pred;
         if (ctx < 0) { ctx = -ctx; d = -d; }
         d = sign_extend(d, (int)k->bits);
+        if (t_sym) t_sym[t_sym_n++] = (set << 30) | ((uint32_t)ctx << 17) | ((uint32_t)d & 0x1FFFFu);
         rce_symbol(c, states[ctx], d, 1);
         *s1 = v;
     }
@@ -504,7 +511,7 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
                 sample[pl][1][-1] = sample[pl][0][0];
                 sample[pl][0][w] = sample[pl][0][w - 1];
                 encode_line(&c, k, states[(pl + 1) >> 1], w, sample[pl][1], sample[pl][0],
-                            planes[pl] + (size_t)(y0 + y) * p->width + x0);
+                            planes[pl] + (size_t)(y0 + y) * p->width + x0, (pl + 1) >> 1);
             }
     } else {
         /* SliceContent_PlaneThenLine, FFV1_Slice.cpp:346-403 (luma only: chroma_planes = 0) */
@@ -512,7 +519,7 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
             int32_t* t = sample[0][0]; sample[0][0] = sample[0][1]; sample[0][1] = t;
             sample[0][1][-1] = sample[0][0][0];
             sample[0][0][w] = sample[0][0][w - 1];
-            encode_line(&c, k, states[0], w, sample[0][1], sample[0][0], planes[0] + (size_t)(y0 + y) * p->width + x0);
+            encode_line(&c, k, states[0], w, sample[0][1], sample[0][0], planes[0] + (size_t)(y0 + y) * p->width + x0, 0);
         }
     }
     free(buf);
@@ -547,6 +554,19 @@ size_t ffv1o_encode_frame(const ffv1o_params* p, int32_t* const planes[4], uint8
         }
     free(k);
     return pos;
+}
+
+size_t ffv1o_trace_slice(const ffv1o_params* p, int32_t* const planes[4], uint32_t sx, uint32_t sy,
+                         uint32_t* sym_out, uint16_t* dec_out, size_t dec_cap, size_t* ndec, uint8_t* raw_out, size_t raw_cap)
+{
+    codec_ctx* k = malloc(sizeof *k);
+    codec_ctx_init(k, p);
+    t_sym = sym_out; t_sym_n = 0; t_dec = dec_out; t_dec_cap = dec_cap; t_dec_n = 0;
+    size_t n = encode_slice(p, k, planes, sx, sy, sx == 0 && sy == 0, raw_out, raw_cap);
+    if (ndec) *ndec = t_dec_n;
+    t_sym = NULL; t_dec = NULL;
+    free(k);
+    return n;
 }
 
 size_t ffv1o_encode_payload(const ffv1o_params* p, const uint8_t* payload, size_t line_bytes, uint8_t* out, size_t cap,

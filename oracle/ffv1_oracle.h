@@ -65,6 +65,12 @@ void ffv1o_pack(const ffv1o_params* p, int32_t* const planes[4], uint8_t* payloa
  * slice_sizes (optional, num_h*num_v entries) receives the byte size of each slice incl. footer. */
 size_t ffv1o_encode_frame(const ffv1o_params* p, int32_t* const planes[4], uint8_t* out, size_t cap,
                           uint32_t* slice_sizes);
+/* One slice with its intermediates, for stage-by-stage parity tests of the device pipeline: sym_out receives one
+ * word per sample in coding order (set << 30 | |ctx| << 17 | residual & 0x1FFFF), dec_out every binary decision
+ * (state | bit << 8, incl. keyframe bit, slice header and the state-129 end bit), raw_out the slice bytes incl. footer.
+ * Returns the slice size; *ndec the number of decisions. */
+size_t ffv1o_trace_slice(const ffv1o_params* p, int32_t* const planes[4], uint32_t sx, uint32_t sy,
+                         uint32_t* sym_out, uint16_t* dec_out, size_t dec_cap, size_t* ndec, uint8_t* raw_out, size_t raw_cap);
 /* Convenience: unpack + encode. */
 size_t ffv1o_encode_payload(const ffv1o_params* p, const uint8_t* payload, size_t line_bytes,
                             uint8_t* out, size_t cap, uint32_t* slice_sizes);

@@ -1,0 +1,325 @@
+"""ctypes binding of librcgpu.so (include/rcgpu.h).
+
+Python is only the harness language here (tests, bench.py, __graft_entry__): the product is the C-ABI library.
+The names mirror the reference's interface for this path -- `output.Process()` (Source/CLI/Output.cpp:22) hands a
+list of `stream`s and `attachment`s (Output.h:21-39) to the encoder; `Output` below does the same through
+`rcgpu_encode`.  Nothing in this module imports the oracle, and there is no CPU fallback: when the HIP library is
+missing or no device is visible, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librcgpu.so")
+
+
+class RcgpuError(RuntimeError):
+    pass
+
+
+class ImageInfo(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("pixfmt", C.c_uint32), ("bits_per_sample", C.c_uint32),
+                ("data_offset", C.c_uint64), ("data_size", C.c_uint64), ("line_bytes", C.c_uint32), ("slices", C.c_uint32),
+                ("framerate", C.c_double), ("flavor", C.c_char * 64)]
+
+
+class AudioInfo(C.Structure):
+    _fields_ = [("channels", C.c_uint32), ("sample_rate", C.c_uint32), ("bits_per_sample", C.c_uint32), ("block_align", C.c_uint32),
+                ("data_offset", C.c_uint64), ("data_size", C.c_uint64), ("flavor", C.c_char * 64)]
+
+
+class Ffv1Config(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("pixfmt", C.c_uint32), ("line_bytes", C.c_uint32),
+                ("num_h_slices", C.c_uint32), ("num_v_slices", C.c_uint32), ("slicecrc", C.c_uint32), ("context", C.c_uint32),
+                ("max_batch", C.c_uint32), ("device", C.c_int)]
+
+
+class FlacConfig(C.Structure):
+    _fields_ = [("channels", C.c_uint32), ("sample_rate", C.c_uint32), ("bits_per_sample", C.c_uint32), ("block_size", C.c_uint32),
+                ("max_lpc_order", C.c_uint32), ("device", C.c_int)]
+
+
+class _Stream(C.Structure):
+    _fields_ = [("path_or_template", C.c_char_p), ("start_number", C.c_char_p), ("filelist", C.c_char_p), ("flavor", C.c_char_p),
+                ("framerate", C.c_char_p), ("slices", C.c_uint32), ("vflip", C.c_int)]
+
+
+class _Attachment(C.Structure):
+    _fields_ = [("path_in", C.c_char_p), ("name_out", C.c_char_p)]
+
+
+class _Job(C.Structure):
+    _fields_ = [("streams", C.POINTER(_Stream)), ("n_streams", C.c_size_t), ("attachments", C.POINTER(_Attachment)), ("n_attachments", C.c_size_t),
+                ("reversibility_path", C.c_char_p), ("output_path", C.c_char_p), ("framemd5_path", C.c_char_p),
+                ("options", C.POINTER(C.c_char_p)), ("n_options", C.c_size_t), ("device_first", C.c_int), ("device_count", C.c_int)]
+
+
+# every symbol include/rcgpu.h declares: name -> (restype, argtypes)
+_VP, _SZ, _U8P = C.c_void_p, C.c_size_t, C.c_char_p
+SYMBOLS = {
+    "rcgpu_version": (C.c_char_p, []),
+    "rcgpu_last_error": (C.c_char_p, []),
+    "rcgpu_device_count": (C.c_int, []),
+    "rcgpu_encode": (C.c_int, [C.POINTER(_Job)]),
+    "rcgpu_main_ffmpeg_argv": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
+    "rcgpu_dpx_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
+    "rcgpu_tiff_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
+    "rcgpu_wav_probe": (C.c_int, [_U8P, _SZ, C.POINTER(AudioInfo)]),
+    "rcgpu_slices_to_grid": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rcgpu_ffv1_create": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP)]),
+    "rcgpu_ffv1_destroy": (None, [_VP]),
+    "rcgpu_ffv1_config_record": (_SZ, [_VP, _VP, _SZ]),
+    "rcgpu_ffv1_max_packet_bytes": (_SZ, [_VP]),
+    "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
+    "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
+    "rcgpu_ffv1_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
+    "rcgpu_ffv1_last_stats": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rcgpu_ffv1_decode_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP), _VP]),
+    "rcgpu_flac_create": (C.c_int, [C.POINTER(FlacConfig), C.POINTER(_VP)]),
+    "rcgpu_flac_destroy": (None, [_VP]),
+    "rcgpu_flac_encode_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rcgpu_flac_codec_private": (_SZ, [_VP, _VP, _SZ]),
+    "rcgpu_mkv_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_VP)]),
+    "rcgpu_mkv_add_video": (C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rcgpu_mkv_add_audio": (C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rcgpu_mkv_add_attachment": (C.c_int, [_VP, C.c_char_p, C.c_char_p, _VP, _SZ]),
+    "rcgpu_mkv_begin": (C.c_int, [_VP]),
+    "rcgpu_mkv_write_block": (C.c_int, [_VP, C.c_int, C.c_uint64, _VP, _SZ, C.c_int]),
+    "rcgpu_mkv_update_codec_private": (C.c_int, [_VP, C.c_int, _VP, _SZ]),
+    "rcgpu_mkv_close": (C.c_int, [_VP]),
+    "rcgpu_md5": (None, [_VP, _SZ, _VP]),
+    "rcgpu_crc32_ffv1": (C.c_uint32, [_VP, _SZ]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load librcgpu.so (built in-tree by `make -C rawcooked_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RcgpuError(f"{LIB_PATH} is missing -- run __graft_entry__.build() (hipcc, gfx950); there is no fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        dbg = L.rcgpu_ffv1_debug_fetch
+        dbg.restype, dbg.argtypes = C.c_longlong, [_VP, C.c_int, C.c_uint32, _VP, _SZ]
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().rcgpu_last_error().decode(errors="replace")
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RcgpuError(f"{what} failed ({rc}): {last_error()}")
+
+
+def dpx_probe(data: bytes) -> ImageInfo:
+    info = ImageInfo()
+    _check(lib().rcgpu_dpx_probe(data, len(data), C.byref(info)), "rcgpu_dpx_probe")
+    return info
+
+
+def tiff_probe(data: bytes) -> ImageInfo:
+    info = ImageInfo()
+    _check(lib().rcgpu_tiff_probe(data, len(data), C.byref(info)), "rcgpu_tiff_probe")
+    return info
+
+
+def wav_probe(data: bytes) -> AudioInfo:
+    info = AudioInfo()
+    _check(lib().rcgpu_wav_probe(data, len(data), C.byref(info)), "rcgpu_wav_probe")
+    return info
+
+
+def slices_to_grid(n: int) -> tuple[int, int]:
+    h, v = C.c_uint32(), C.c_uint32()
+    _check(lib().rcgpu_slices_to_grid(n, C.byref(h), C.byref(v)), "rcgpu_slices_to_grid")
+    return h.value, v.value
+
+
+def md5(data: bytes) -> bytes:
+    out = C.create_string_buffer(16)
+    lib().rcgpu_md5(data, len(data), out)
+    return out.raw
+
+
+class Ffv1Encoder:
+    """Device FFV1 encoder (rcgpu_ffv1_*).  Raises when no HIP device is visible."""
+
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device)
+        self.h = _VP()
+        _check(lib().rcgpu_ffv1_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_create")
+        self.max_packet = lib().rcgpu_ffv1_max_packet_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().rcgpu_ffv1_destroy(self.h)
+            self.h = _VP()
+
+    __del__ = close
+
+    def config_record(self) -> bytes:
+        buf = C.create_string_buffer(8192)
+        n = lib().rcgpu_ffv1_config_record(self.h, buf, 8192)
+        return buf.raw[:n]
+
+    def encode_host(self, payloads: list[bytes]) -> list[bytes]:
+        n = len(payloads)
+        keep = [C.create_string_buffer(p, len(p)) for p in payloads]
+        ptrs = (_VP * n)(*[C.cast(k, _VP) for k in keep])
+        outs = [C.create_string_buffer(self.max_packet) for _ in range(n)]
+        optrs = (_VP * n)(*[C.cast(o, _VP) for o in outs])
+        sizes = (_SZ * n)()
+        _check(lib().rcgpu_ffv1_encode_host(self.h, ptrs, n, optrs, sizes), "rcgpu_ffv1_encode_host")
+        return [outs[i].raw[:sizes[i]] for i in range(n)]
+
+    def encode_device(self, frame_ptrs: list[int], d_packets: int, packet_stride: int, d_sizes: int, stream: int = 0) -> None:
+        n = len(frame_ptrs)
+        ptrs = (_VP * n)(*frame_ptrs)
+        _check(lib().rcgpu_ffv1_encode_device(self.h, ptrs, n, d_packets, packet_stride, d_sizes, stream), "rcgpu_ffv1_encode_device")
+
+    def kernel_times(self) -> dict[str, float]:
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        k = lib().rcgpu_ffv1_last_kernel_times(self.h, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+    def stats(self) -> tuple[int, int]:
+        d, b = C.c_uint64(), C.c_uint64()
+        lib().rcgpu_ffv1_last_stats(self.h, C.byref(d), C.byref(b))
+        return d.value, b.value
+
+    def debug_fetch(self, what: int, chain: int, cap: int) -> bytes:
+        buf = C.create_string_buffer(cap)
+        n = lib().rcgpu_ffv1_debug_fetch(self.h, what, chain, buf, cap)
+        if n < 0:
+            raise RcgpuError(f"rcgpu_ffv1_debug_fetch({what}) -> {n}")
+        return buf.raw[:n]
+
+
+class FlacEncoder:
+    def __init__(self, channels, sample_rate, bits_per_sample, block_size=0, max_lpc_order=8, device=0):
+        self.cfg = FlacConfig(channels, sample_rate, bits_per_sample, block_size, max_lpc_order, device)
+        self.h = _VP()
+        _check(lib().rcgpu_flac_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_flac_create")
+
+    def close(self):
+        if self.h:
+            lib().rcgpu_flac_destroy(self.h)
+            self.h = _VP()
+
+    __del__ = close
+
+    def encode(self, pcm: bytes) -> tuple[list[bytes], bytes]:
+        """Returns (FLAC frames, CodecPrivate = 'fLaC' + STREAMINFO)."""
+        cap = len(pcm) + len(pcm) // 4 + 65536
+        out = C.create_string_buffer(cap)
+        fcap = len(pcm) // 64 + 64
+        sizes = (C.c_uint32 * fcap)()
+        n = C.c_uint32()
+        keep = C.create_string_buffer(pcm, len(pcm))
+        _check(lib().rcgpu_flac_encode_host(self.h, keep, len(pcm), out, cap, sizes, fcap, C.byref(n)), "rcgpu_flac_encode_host")
+        frames, off = [], 0
+        for i in range(n.value):
+            frames.append(out.raw[off:off + sizes[i]])
+            off += sizes[i]
+        cp = C.create_string_buffer(256)
+        k = lib().rcgpu_flac_codec_private(self.h, cp, 256)
+        return frames, cp.raw[:k]
+
+
+class MkvMuxer:
+    def __init__(self, path: str, overwrite: bool = True):
+        self.h = _VP()
+        _check(lib().rcgpu_mkv_open(path.encode(), 1 if overwrite else 0, C.byref(self.h)), "rcgpu_mkv_open")
+
+    def add_video(self, codec_private: bytes, width, height, fps_num=24, fps_den=1) -> int:
+        t = lib().rcgpu_mkv_add_video(self.h, codec_private, len(codec_private), width, height, fps_num, fps_den)
+        if t < 0:
+            raise RcgpuError("rcgpu_mkv_add_video: " + last_error())
+        return t
+
+    def add_audio(self, codec_private: bytes, channels, sample_rate, bits) -> int:
+        t = lib().rcgpu_mkv_add_audio(self.h, codec_private, len(codec_private), channels, sample_rate, bits)
+        if t < 0:
+            raise RcgpuError("rcgpu_mkv_add_audio: " + last_error())
+        return t
+
+    def add_attachment(self, name: str, data: bytes, mime: str = "application/octet-stream"):
+        _check(lib().rcgpu_mkv_add_attachment(self.h, name.encode(), mime.encode(), data, len(data)), "rcgpu_mkv_add_attachment")
+
+    def begin(self):
+        _check(lib().rcgpu_mkv_begin(self.h), "rcgpu_mkv_begin")
+
+    def write_block(self, track: int, pts_ns: int, data: bytes, keyframe: bool = True):
+        _check(lib().rcgpu_mkv_write_block(self.h, track, pts_ns, data, len(data), 1 if keyframe else 0), "rcgpu_mkv_write_block")
+
+    def close(self):
+        if self.h:
+            h, self.h = self.h, _VP()
+            _check(lib().rcgpu_mkv_close(h), "rcgpu_mkv_close")
+
+
+# --- the reference's job vocabulary (Source/CLI/Output.h:21-53) -------------------------------------------------
+@dataclass
+class Stream:
+    """`stream` of Output.h:21-33."""
+    FileName: str = ""
+    FileName_Template: str = ""
+    FileName_StartNumber: str = ""
+    FileList: str = ""
+    Flavor: str = ""
+    Slices: str = ""
+    FrameRate: str = ""
+
+
+@dataclass
+class Attachment:
+    """`attachment` of Output.h:34-38."""
+    FileName_In: str = ""
+    FileName_Out: str = ""
+
+
+@dataclass
+class Output:
+    """`output` of Output.h:41-53: fill Streams/Attachments, call Process()."""
+    Streams: list = field(default_factory=list)
+    Attachments: list = field(default_factory=list)
+
+    def Process(self, OutputFileName: str, rawcooked_reversibility_FileName: str | None = None, OutputOptions: dict | None = None,
+                device_first: int = 0, device_count: int = 0) -> int:
+        opts = {"c:v": "ffv1", "c:a": "flac", "coder": "1", "context": "1", "g": "1", "level": "3", "slicecrc": "1", "y": ""}   # Global.cpp:938-989
+        opts.update(OutputOptions or {})
+        keep = []
+
+        def s(x):
+            if not x:
+                return None
+            b = x.encode()
+            keep.append(b)
+            return b
+
+        streams = (_Stream * len(self.Streams))()
+        for i, st in enumerate(self.Streams):
+            streams[i] = _Stream(s(st.FileName_Template or st.FileName), s(st.FileName_StartNumber), s(st.FileList), s(st.Flavor),
+                                 s(st.FrameRate), int(st.Slices) if st.Slices else (0 if st.Flavor.startswith("WAV/") else 0xFFFFFFFF), 0)
+        atts = (_Attachment * max(1, len(self.Attachments)))()
+        for i, a in enumerate(self.Attachments):
+            atts[i] = _Attachment(s(a.FileName_In), s(a.FileName_Out))
+        flat = []
+        for k, v in sorted(opts.items()):
+            flat += [k.encode(), str(v).encode()]
+        arr = (C.c_char_p * len(flat))(*flat)
+        job = _Job(streams, len(self.Streams), atts, len(self.Attachments), s(rawcooked_reversibility_FileName), s(OutputFileName), None,
+                   arr, len(flat), device_first, device_count)
+        return lib().rcgpu_encode(C.byref(job))

@@ -1,0 +1,919 @@
+// ffv1_gpu.hip -- FFV1 v3 intra encoder for MI355X (gfx950, wave64).  No CPU fallback: without a HIP device
+// rcgpu_ffv1_create() fails.
+//
+// What it replaces: FFmpeg's ffv1enc inside the subprocess RAWcooked launches (CLI/Output.cpp:356).  What it mirrors:
+// the in-tree decoder -- ffv1_frame::Process (Lib/CoDec/FFV1/FFV1_Frame.cpp:134-228), slice::Line
+// (FFV1_Slice.cpp:447-472), rangecoder::b/s (FFV1_RangeCoder.cpp:71-305) and the packers of
+// Lib/Transform/Transform.cpp, all inverted.
+//
+// Pipeline for a batch of F frames x S slices ("chains" = F*S independent range-coder chains):
+//   K1 k_unpack     thread / pixel      payload bytes -> planar Y,Cb,Cr(,A) int32       (inverse of Transform.cpp From())
+//   K2 k_model      thread / sample     neighbours -> context, folded residual, #decisions; symbols in coding order
+//   K3 k_resolve    wave   / slice      adaptive-state resolution: walks the symbols 64 at a time, applies the state
+//                                       transitions in coding order (same-context lanes serialised through LDS) and
+//                                       emits (state, bit) decisions, interleaved [piece][lane of chain][32 x u16]
+//   K4 k_rangecode  LANE   / slice      the serial low/range recurrence + carry-resolved byte emission; 64 slices per
+//                                       wave advance in lock-step over the interleaved decision stream
+//   K5 k_footer     wave   / slice      slice size, error_status, parallel CRC-32 (segment CRCs + GF(2) combine)
+//   K6 k_scan       block  / frame      exclusive scan of slice sizes -> packet layout
+//   K7 k_gather     blocks / slice      compaction into one contiguous FFV1 packet per frame
+// The only serial recurrences are per-context state updates (K3) and low/range (K4); DESIGN.md explains why the
+// second one is mapped lane-per-slice rather than wave-per-slice.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "ffv1_host.h"
+#include "rc_common.h"
+
+using namespace rc;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-visible configuration
+// ---------------------------------------------------------------------------------------------------------
+struct enc_const {
+    uint32_t W, H, line_bytes, pixfmt;
+    uint32_t planes, bps, bits, rgb, gb_swap, big_endian, bytes_pp, overflow16;
+    uint32_t num_h, num_v, S, nctx, nsets, ec, is5;
+    uint32_t samples_per_frame;            // W*H*planes
+    int16_t  q[5][256];
+    uint8_t  one_state[256], zero_state[256];
+};
+
+struct slice_geom {
+    uint32_t x0, y0, w, h;
+    uint32_t sym_off;     // first symbol of this slice inside a frame's symbol area
+    uint32_t nsamp;       // w*h*planes
+    uint32_t hdr_off, hdr_n;   // header decisions in d_hdr
+    uint32_t cbuf_off_lo, cbuf_off_hi;   // byte offset of this slice's raw-byte buffer inside a frame's cbuf area
+    uint32_t cbuf_cap;
+    uint32_t pad;
+};
+
+constexpr int kPieceEntries = 32;                 // decisions per 64-byte piece
+constexpr int kPieceBytes = 64;
+constexpr int kGroupPieceBytes = 64 * kPieceBytes; // one piece of each of the 64 chains of a group
+constexpr int kMaxDecPerSample = 35;              // 2*16+3 for 17-bit residuals
+constexpr int kStageEntries = kPieceEntries + 64 * kMaxDecPerSample + 32;   // carry + one chunk (+ slack)
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: unpack + forward RCT.  One thread per pixel; 10-bit words and 8/16-bit triplets are read with the widest
+// naturally aligned loads the layout allows.  Inverse of JPEG2000RCT (Transform.cpp:29-37) and of the packers.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld16(const uint8_t* p, bool be)
+{
+    const uint32_t v = *reinterpret_cast<const uint16_t*>(p);
+    return be ? ((v >> 8) | ((v & 0xFF) << 8)) : v;
+}
+
+__global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C, const uint8_t* const* __restrict__ frames,
+                                                int32_t* __restrict__ planes)
+{
+    const uint32_t W = C->W, H = C->H;
+    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= W * H) return;
+    const uint32_t f = blockIdx.y;
+    const uint32_t y = pix / W, x = pix - y * W;
+    const uint8_t* p = frames[f] + size_t(y) * C->line_bytes + size_t(x) * C->bytes_pp;
+    const bool be = C->big_endian;
+    uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
+    switch (C->pixfmt) {
+    case RCGPU_PIX_RGB8:  c0 = p[0]; c1 = p[1]; c2 = p[2]; break;
+    case RCGPU_PIX_RGBA8: { const uint32_t w = *reinterpret_cast<const uint32_t*>(p); c0 = w & 0xFF; c1 = (w >> 8) & 0xFF; c2 = (w >> 16) & 0xFF; c3 = w >> 24; break; }
+    case RCGPU_PIX_RGB10_FILLEDA_BE: case RCGPU_PIX_RGB10_FILLEDA_LE: {
+        uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+        if (be) w = __builtin_bswap32(w);
+        c0 = (w >> 22) & 0x3FF; c1 = (w >> 12) & 0x3FF; c2 = (w >> 2) & 0x3FF; break; }
+    case RCGPU_PIX_RGB12_FILLEDA_BE: case RCGPU_PIX_RGB12_FILLEDA_LE:
+        c0 = ld16(p, be) >> 4; c1 = ld16(p + 2, be) >> 4; c2 = ld16(p + 4, be) >> 4; break;
+    case RCGPU_PIX_RGB16_BE: case RCGPU_PIX_RGB16_LE:
+        c0 = ld16(p, be); c1 = ld16(p + 2, be); c2 = ld16(p + 4, be); break;
+    case RCGPU_PIX_RGBA16_BE: case RCGPU_PIX_RGBA16_LE:
+        c0 = ld16(p, be); c1 = ld16(p + 2, be); c2 = ld16(p + 4, be); c3 = ld16(p + 6, be); break;
+    case RCGPU_PIX_Y8: c0 = p[0]; break;
+    default: c0 = ld16(p, be); break;
+    }
+    const size_t plane_sz = size_t(W) * H;
+    int32_t* dst = planes + size_t(f) * C->planes * plane_sz + pix;
+    if (!C->rgb) { dst[0] = int32_t(c0); return; }
+    int32_t r = int32_t(c0), g = int32_t(c1), b = int32_t(c2);
+    if (C->gb_swap) { const int32_t t = g; g = b; b = t; }
+    b -= g; r -= g;
+    g += (b + r) >> 2;
+    const int32_t off = int32_t(1) << C->bps;
+    dst[0] = g; dst[plane_sz] = b + off; dst[2 * plane_sz] = r + off;
+    if (C->planes == 4) dst[3 * plane_sz] = int32_t(c3);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: context model.  For every sample: 5-tap context (get_context_5, FFV1_Slice.cpp:80-93), median prediction
+// (:21-66), residual folded to `bits` (:469 inverse), and the number of binary decisions its symbol will take.
+// Output symbol = set << 30 | |ctx| << 17 | (residual & 0x1FFFF), stored in CODING order of the slice
+// (line-interleaved planes, SliceContent_LineThenPlane :427-441).
+// grid = (ceil(lines / 8), chains); a block walks 8 slice-plane-lines.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t median3(int32_t a, int32_t b, int32_t c)
+{
+    return max(min(a, b), min(max(a, b), c));
+}
+
+__global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+                                               const int32_t* __restrict__ planes, uint32_t* __restrict__ sym,
+                                               unsigned long long* __restrict__ chain_ndec)
+{
+    __shared__ int16_t q[5][256];
+    __shared__ unsigned long long red[4];
+    for (uint32_t i = threadIdx.x; i < 5 * 256; i += 256) (&q[0][0])[i] = (&C->q[0][0])[i];
+    __syncthreads();
+    const uint32_t chain = blockIdx.y;
+    const uint32_t S = C->S, f = chain / S, s = chain - f * S;
+    const slice_geom G = geom[s];
+    const uint32_t W = C->W, np = C->planes;
+    const size_t plane_sz = size_t(W) * C->H;
+    const int32_t* fp = planes + size_t(f) * np * plane_sz;
+    uint32_t* out = sym + size_t(f) * C->samples_per_frame + G.sym_off;
+    const uint32_t nlines = G.h * np;
+    const int bits = int(C->bits);
+    const bool is5 = C->is5, ov16 = C->overflow16, rgb = C->rgb;
+    unsigned long long local = 0;
+    const uint32_t line_end = min(nlines, (blockIdx.x + 1) * 8);
+    for (uint32_t line = blockIdx.x * 8; line < line_end; line++) {
+        const uint32_t y = line / np, p = line - y * np;
+        const int32_t* pl = fp + p * plane_sz + size_t(G.y0) * W + G.x0;     // slice origin in plane p
+        const uint32_t set = rgb ? (p + 1) >> 1 : 0;
+        for (uint32_t x = threadIdx.x; x < G.w; x += 256) {
+            // neighbours with the decoder's edge rules (FFV1_Slice.cpp:386-387 of SURVEY appendix A; :432-433)
+            auto at = [&](int yy, int xx) -> int32_t { return yy < 0 ? 0 : pl[size_t(yy) * W + xx]; };
+            const int yi = int(y), xi = int(x), wl = int(G.w) - 1;
+            const int32_t cur = at(yi, xi);
+            const int32_t T  = at(yi - 1, xi);
+            const int32_t L  = xi > 0 ? at(yi, xi - 1) : at(yi - 1, 0);
+            const int32_t LT = xi > 0 ? at(yi - 1, xi - 1) : at(yi - 2, 0);
+            const int32_t RT = xi < wl ? at(yi - 1, xi + 1) : T;
+            int32_t ctx = q[0][(L - LT) & 0xFF] + q[1][(LT - T) & 0xFF] + q[2][(T - RT) & 0xFF];
+            if (is5) {
+                const int32_t LL = xi > 1 ? at(yi, xi - 2) : (xi == 1 ? at(yi - 1, 0) : 0);
+                const int32_t TT = at(yi - 2, xi);
+                ctx += q[3][(LL - L) & 0xFF] + q[4][(TT - T) & 0xFF];
+            }
+            int32_t pred;
+            if (ov16) pred = median3(int16_t(L), int16_t(L) + int16_t(T) - int16_t(LT), int16_t(T));   // FFV1_Slice.cpp:52-57
+            else pred = median3(L, L + T - LT, T);
+            int32_t d = cur - pred;
+            if (ctx < 0) { ctx = -ctx; d = -d; }
+            d = int32_t(uint32_t(d) << (32 - bits)) >> (32 - bits);                  // fold: sign-extend to `bits`
+            const uint32_t a = uint32_t(d < 0 ? -d : d);
+            local += a ? uint32_t(2 * (31 - __clz(int(a))) + 3) : 1u;
+            out[size_t(line) * G.w + x] = (set << 30) | (uint32_t(ctx) << 17) | (uint32_t(d) & 0x1FFFFu);
+        }
+    }
+    // block reduction -> one atomic per block
+    for (int o = 32; o; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&chain_ndec[chain], red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: adaptive-state resolution, one wavefront per slice.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+                                                const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
+                                                uint8_t* __restrict__ states, const unsigned long long* __restrict__ group_off,
+                                                uint8_t* __restrict__ stream, uint32_t nkeys)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t* stage = reinterpret_cast<uint16_t*>(smem);                           // kStageEntries u16
+    uint8_t*  slot = smem + ((kStageEntries * 2 + 15) & ~15);                      // 64 x 32
+    uint8_t*  trans = slot + 64 * 32;                                               // [bit][state]
+    uint32_t* touched = reinterpret_cast<uint32_t*>(trans + 512);                   // nkeys bits
+    uint8_t*  Hk = reinterpret_cast<uint8_t*>(touched + ((nkeys + 31) / 32 + 3) / 4 * 4);   // nkeys u8
+
+    const int lane = threadIdx.x;
+    const uint32_t chain = blockIdx.x;
+    const uint32_t S = C->S, f = chain / S, s = chain - f * S;
+    const slice_geom G = geom[s];
+    const uint32_t nctx = C->nctx;
+    const uint32_t* in = sym + size_t(f) * C->samples_per_frame + G.sym_off;
+    uint8_t* st_base = states + size_t(chain) * nkeys * 32;
+    // interleaved decision stream: piece k of this chain lives at group base + (k*64 + lane_of_chain)*64
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(stream + group_off[chain >> 6]) + (chain & 63) * 16;
+
+    for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; }
+    for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = 0;
+    for (uint32_t i = lane; i < G.hdr_n; i += 64) stage[i] = hdr[G.hdr_off + i];
+    uint32_t stage_count = G.hdr_n;
+    uint32_t piece_base = 0;
+    __syncthreads();
+
+    auto flush_full = [&]() {
+        __syncthreads();
+        const uint32_t np = stage_count / kPieceEntries;
+        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
+        for (uint32_t idx = lane; idx < np * 16; idx += 64) {
+            const uint32_t pc = idx >> 4, dw = idx & 15;
+            out32[size_t(piece_base + pc) * (kGroupPieceBytes / 4) + dw] = s32[idx];
+        }
+        const uint32_t rem = stage_count - np * kPieceEntries;
+        uint32_t keep = 0;
+        if (lane < 16) keep = s32[np * 16 + lane];
+        __syncthreads();
+        if (lane < 16 && np) reinterpret_cast<uint32_t*>(stage)[lane] = keep;
+        piece_base += np;
+        stage_count = rem;
+        __syncthreads();
+    };
+    flush_full();
+
+    const unsigned long long lane_bit = 1ull << lane;
+    for (uint32_t base = 0; base < G.nsamp; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < G.nsamp;
+        const uint32_t sv = valid ? in[i] : 0;
+        const int32_t d = int32_t(sv << 15) >> 15;                    // 17-bit signed residual
+        const uint32_t key = (sv >> 30) * nctx + ((sv >> 17) & 0x1FFF);
+        const uint32_t a = uint32_t(d < 0 ? -d : d);
+        const int e = a ? 31 - __clz(int(a)) : 0;
+        const uint32_t ndec = valid ? (a ? uint32_t(2 * e + 3) : 1u) : 0u;
+        const uint32_t incl = wave_incl_scan(ndec, lane);
+        const uint32_t excl = incl - ndec;
+        const uint32_t total = __shfl(incl, 63);
+
+        // --- which lanes share a context?  One LDS write/read finds the colliding lanes; a scalar loop over the
+        // distinct colliding keys gives every lane its predecessor, its group leader and whether it is the last.
+        if (valid) Hk[key] = uint8_t(lane);
+        __syncthreads();
+        const uint32_t seen = valid ? Hk[key] : uint32_t(lane);
+        int leader = lane, pred = -1;
+        bool last = true;
+        unsigned long long lm = __ballot(valid && seen != uint32_t(lane));
+        while (lm) {
+            const int src = __ffsll((long long)lm) - 1;
+            const uint32_t k = __shfl(key, src);
+            const bool mine = valid && key == k;
+            const unsigned long long m = __ballot(mine);
+            if (mine) {
+                leader = __ffsll((long long)m) - 1;
+                const unsigned long long lower = m & (lane_bit - 1);
+                pred = lower ? 63 - __clzll((long long)lower) : -1;
+                last = ((m >> lane) >> 1) == 0;
+            }
+            lm &= ~m;
+        }
+
+        // --- group leaders fetch the context's 32 states: all 128 on first use in this slice (states_coded = 0),
+        // else from the slice's state array in HBM.
+        const bool first = valid && pred < 0;
+        uint4 s0 = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u), s1 = s0;
+        if (first) {
+            const bool was = (touched[key >> 5] >> (key & 31)) & 1;
+            if (was) {
+                const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(key) * 32);
+                s0 = gp[0]; s1 = gp[1];
+            }
+            uint4* sp = reinterpret_cast<uint4*>(slot + lane * 32);
+            sp[0] = s0; sp[1] = s1;
+        }
+        __syncthreads();
+        if (first) atomicOr(&touched[key >> 5], 1u << (key & 31));
+
+        // --- rounds: a lane runs once its predecessor (same context, earlier in coding order) is done.
+        unsigned long long done = 0;
+        bool pending = valid;
+        uint8_t* sl = slot + leader * 32;
+        uint16_t* op = stage + stage_count + excl;
+        while (__ballot(pending)) {
+            const bool ready = pending && (pred < 0 || ((done >> pred) & 1));
+            if (ready) {
+                // symbol binarisation, inverse of rangecoder::s (FFV1_RangeCoder.cpp:135-305)
+                uint32_t j = 0;
+                if (a == 0) {
+                    const uint32_t st = sl[0]; op[0] = uint16_t(st | 0x100); sl[0] = trans[256 + st];
+                } else {
+                    { const uint32_t st = sl[0]; op[j++] = uint16_t(st); sl[0] = trans[st]; }
+                    for (int t = 0; t < e; t++) {
+                        const int k = 1 + (t < 9 ? t : 9);
+                        const uint32_t st = sl[k]; op[j++] = uint16_t(st | 0x100); sl[k] = trans[256 + st];
+                    }
+                    { const int k = 1 + (e < 9 ? e : 9); const uint32_t st = sl[k]; op[j++] = uint16_t(st); sl[k] = trans[st]; }
+                    for (int t = e - 1; t >= 0; t--) {
+                        const int k = 22 + (t < 9 ? t : 9);
+                        const uint32_t b = (a >> t) & 1;
+                        const uint32_t st = sl[k]; op[j++] = uint16_t(st | (b << 8)); sl[k] = trans[b * 256 + st];
+                    }
+                    { const int k = 11 + (e < 10 ? e : 10); const uint32_t b = d < 0;
+                      const uint32_t st = sl[k]; op[j++] = uint16_t(st | (b << 8)); sl[k] = trans[b * 256 + st]; }
+                }
+            }
+            done |= __ballot(ready);
+            pending = pending && !ready;
+            __syncthreads();
+        }
+
+        // --- last lane of each group writes the states back
+        if (valid && last) {
+            const uint4* sp = reinterpret_cast<const uint4*>(sl);
+            uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
+            gp[0] = sp[0]; gp[1] = sp[1];
+        }
+        stage_count += total;
+        flush_full();      // contains the workgroup-scope fences that order the state write-back before the next gather
+    }
+    // end-of-slice bit (state 129, FFV1_Slice.cpp:336-340), then pad the last piece
+    if (lane == 0) stage[stage_count] = 129;
+    stage_count += 1;
+    __syncthreads();
+    const uint32_t padded = (stage_count + kPieceEntries - 1) / kPieceEntries * kPieceEntries;
+    for (uint32_t i = stage_count + lane; i < padded; i += 64) stage[i] = 128;
+    stage_count = padded;
+    flush_full();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K4: range coder, one LANE per slice (chain).  The 64 chains of a wavefront read the same piece index of their
+// interleaved streams each iteration and run the low/range recurrence of RFC 9043 3.8.1 in lock-step:
+//     r1 = range*state >> 8;  bit ? (low += range - r1, range = r1) : (range -= r1);  renormalise by bytes.
+// `low` is kept as a 64-bit big number (16 live bits + up to 5 finished bytes + carry), so carries ripple by plain
+// integer addition; finished bytes leave through `pd`, a 4-byte second stage that absorbs late carries.  A carry out
+// of `pd` (probability ~2^-32 per flush) walks back through bytes already in HBM.
+// ---------------------------------------------------------------------------------------------------------
+struct rc_lane {
+    uint32_t range; unsigned long long low; int nb; uint32_t pd; bool have_pd; uint32_t pos; uint8_t* out; uint32_t cap; bool overflow;
+};
+
+__device__ __forceinline__ void rc_carry_into_memory(rc_lane& r)
+{
+    // pd wrapped from 0xFFFFFFFF: propagate +1 into the bytes already stored
+    uint32_t p = r.pos;
+    while (p) { p--; const uint8_t b = uint8_t(r.out[p] + 1); r.out[p] = b; if (b) break; }
+}
+
+__device__ __forceinline__ void rc_store_pd(rc_lane& r, uint32_t carry)
+{
+    if (!r.have_pd) return;
+    if (carry) { r.pd += carry; if (r.pd < carry) rc_carry_into_memory(r); }
+    if (r.pos + 4 <= r.cap) *reinterpret_cast<uint32_t*>(r.out + r.pos) = __builtin_bswap32(r.pd);
+    else r.overflow = true;
+    r.pos += 4;
+}
+
+__device__ __forceinline__ void rc_flush4(rc_lane& r)
+{
+    // nb == 5: bits [16,56) hold five finished bytes, bit 56.. a pending carry
+    rc_store_pd(r, uint32_t(r.low >> 56));
+    r.pd = uint32_t(r.low >> 24);
+    r.have_pd = true;
+    r.low &= 0xFFFFFFull;
+    r.nb = 1;
+}
+
+__device__ __forceinline__ void rc_step(rc_lane& r, uint32_t state, uint32_t bit)
+{
+    const uint32_t r1 = (r.range * state) >> 8;
+    const uint32_t rr = r.range - r1;
+    r.low += bit ? rr : 0u;
+    r.range = bit ? r1 : rr;
+    if (r.range < 0x100) {
+        r.range <<= 8; r.low <<= 8;
+        if (++r.nb == 5) rc_flush4(r);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+                                                  const unsigned long long* __restrict__ chain_ndec,
+                                                  const unsigned long long* __restrict__ group_off,
+                                                  const uint8_t* __restrict__ stream, uint8_t* __restrict__ cbuf,
+                                                  unsigned long long cbuf_frame_stride, uint32_t nchains,
+                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ err)
+{
+    const int lane = threadIdx.x;
+    const uint32_t chain = blockIdx.x * 64 + lane;
+    const bool active = chain < nchains;
+    const uint32_t S = C->S;
+    const uint32_t cc = active ? chain : nchains - 1;
+    const uint32_t f = cc / S, s = cc - f * S;
+    const slice_geom G = geom[s];
+    const unsigned long long n = active ? G.hdr_n + chain_ndec[cc] + 1 : 0;
+    const uint4* src = reinterpret_cast<const uint4*>(stream + group_off[blockIdx.x]) + lane * 4;
+
+    rc_lane r;
+    r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.have_pd = false; r.pos = 0; r.overflow = false;
+    r.out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
+    r.cap = G.cbuf_cap;
+
+    const unsigned long long npieces = (n + kPieceEntries - 1) / kPieceEntries;
+    unsigned long long maxp = npieces;
+    for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_xor(maxp, o); maxp = t > maxp ? t : maxp; }
+
+    for (unsigned long long pc = 0; pc < maxp; pc++) {
+        if (pc < npieces) {
+            const uint4* p = src + pc * (kGroupPieceBytes / 16);
+            const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
+            const uint32_t w[16] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w };
+            const unsigned long long left = n - pc * kPieceEntries;
+            const uint32_t cnt = left < kPieceEntries ? uint32_t(left) : kPieceEntries;
+#pragma unroll
+            for (int j = 0; j < kPieceEntries; j++) {
+                if (uint32_t(j) < cnt) {
+                    const uint32_t ent = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
+                    rc_step(r, ent & 0xFF, (ent >> 8) & 1);
+                }
+            }
+        }
+    }
+    if (active) {
+        // terminate (the state-129 end bit is already the last decision): two forced renormalisations; the last
+        // latched byte is not emitted -- the decoder reads bytes past the end as zero (FFV1_RangeCoder.cpp:79-85).
+        r.low += 0xFF;
+        r.low <<= 8; if (++r.nb == 5) rc_flush4(r);
+        r.low <<= 8; ++r.nb;
+        const int top = 16 + 8 * r.nb;
+        rc_store_pd(r, uint32_t(r.low >> top));
+        for (int t = r.nb - 1; t >= 1; t--) {
+            if (r.pos < r.cap) r.out[r.pos] = uint8_t(r.low >> (16 + 8 * t)); else r.overflow = true;
+            r.pos++;
+        }
+        out_len[chain] = r.pos;
+        if (r.overflow) atomicOr(err, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5: slice footer (size24, error_status, CRC-32), one wavefront per slice.
+// CRC: poly 0x04C11DB7, MSB first, init 0, no final xor (ZenCRC32.cpp:1097-1135).  Each lane takes one contiguous
+// segment; crc(A||B) = crc(A) * x^(8|B|) + crc(B) in GF(2)[x]/P combines them.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r >> 31) ? 0x04C11DB7u : 0u);
+        if ((b >> i) & 1) r ^= a;
+    }
+    return r;
+}
+__device__ uint32_t gf_xpow8(unsigned long long nbytes)      // x^(8*nbytes) mod P
+{
+    uint32_t result = 1, base = 0x100;
+    while (nbytes) {
+        if (nbytes & 1) result = gf_mulmod(result, base);
+        base = gf_mulmod(base, base);
+        nbytes >>= 1;
+    }
+    return result;
+}
+
+__global__ __launch_bounds__(64) void k_footer(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+                                               uint8_t* __restrict__ cbuf, unsigned long long cbuf_frame_stride,
+                                               const uint32_t* __restrict__ out_len, uint32_t* __restrict__ tot_len,
+                                               uint32_t* __restrict__ err)
+{
+    __shared__ uint32_t T[256];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = uint32_t(i) << 24;
+        for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
+        T[i] = c;
+    }
+    const uint32_t chain = blockIdx.x;
+    const uint32_t S = C->S, f = chain / S, s = chain - f * S;
+    const slice_geom G = geom[s];
+    uint8_t* out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
+    const uint32_t len = out_len[chain];
+    const uint32_t tail = C->ec ? 8 : 3;
+    if (len + tail > G.cbuf_cap || len > 0xFFFFFF) { if (lane == 0) { atomicOr(err, 2u); tot_len[chain] = 0; } return; }
+    if (lane == 0) {
+        out[len] = uint8_t(len >> 16); out[len + 1] = uint8_t(len >> 8); out[len + 2] = uint8_t(len);
+        if (C->ec) out[len + 3] = 0;                      // error_status
+    }
+    __syncthreads();
+    if (!C->ec) { if (lane == 0) tot_len[chain] = len + 3; return; }
+    const uint32_t total = len + 4;
+    const uint32_t seg = ((total + 63) / 64 + 3) & ~3u;   // bytes per lane, multiple of 4
+    const uint32_t beg = min(total, uint32_t(lane) * seg), end = min(total, beg + seg);
+    uint32_t c = 0;
+    for (uint32_t i = beg; i < end; i++) c = (c << 8) ^ T[(c >> 24) ^ out[i]];
+    // shift by the bytes that follow this lane's segment, then xor-reduce
+    c = gf_mulmod(c, gf_xpow8(total - end));
+    for (int o = 32; o; o >>= 1) c ^= __shfl_xor(c, o);
+    if (lane == 0) {
+        out[len + 4] = uint8_t(c >> 24); out[len + 5] = uint8_t(c >> 16); out[len + 6] = uint8_t(c >> 8); out[len + 7] = uint8_t(c);
+        tot_len[chain] = len + 8;
+    }
+}
+
+// K6: per-frame exclusive scan of slice sizes (slices are stored in raster order sy*num_h + sx, the order FFmpeg
+// emits them; the decoder walks them from the tail, FFV1_Frame.cpp:177-198).
+__global__ __launch_bounds__(64) void k_scan(const enc_const* __restrict__ C, const uint32_t* __restrict__ tot_len,
+                                             unsigned long long* __restrict__ slice_dst, unsigned long long* __restrict__ packet_sizes)
+{
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x, S = C->S;
+    unsigned long long run = 0;
+    for (uint32_t base = 0; base < S; base += 64) {
+        const uint32_t s = base + lane;
+        const uint32_t v = s < S ? tot_len[f * S + s] : 0;
+        const uint32_t incl = wave_incl_scan(v, lane);
+        if (s < S) slice_dst[f * S + s] = run + incl - v;
+        run += __shfl(incl, 63);
+    }
+    if (lane == 0) packet_sizes[f] = run;
+}
+
+// K7: gather slices into the packet.  Destination dwords are written aligned; the source is re-aligned with a
+// funnel shift.  grid = (8, chains).
+__global__ __launch_bounds__(256) void k_gather(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+                                                const uint8_t* __restrict__ cbuf, unsigned long long cbuf_frame_stride,
+                                                const uint32_t* __restrict__ tot_len, const unsigned long long* __restrict__ slice_dst,
+                                                uint8_t* __restrict__ packets, unsigned long long packet_stride)
+{
+    const uint32_t chain = blockIdx.y;
+    const uint32_t S = C->S, f = chain / S, s = chain - f * S;
+    const slice_geom G = geom[s];
+    const uint8_t* src = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
+    uint8_t* dst = packets + size_t(f) * packet_stride + slice_dst[chain];
+    const uint32_t len = tot_len[chain];
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+    const uint32_t head = min(len, uint32_t((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3));
+    if (tid < head) dst[tid] = src[tid];
+    const uint32_t ndw = (len - head) / 4;
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);      // src is 16-byte aligned
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+    const uint32_t sh = head * 8;                                        // source byte offset of dst dword 0 is `head` (0..3)
+    for (uint32_t t = tid; t < ndw; t += nthreads) {
+        const uint32_t lo = s32[t], hi = s32[t + 1];
+        d32[t] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    }
+    const uint32_t done = head + ndw * 4;
+    if (tid < len - done) dst[done + tid] = src[done + tid];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------------------
+struct rcgpu_ffv1 {
+    rcgpu_ffv1_config cfg{};
+    ffv1::stream_params sp{};
+    enc_const hc{};
+    std::vector<slice_geom> geom;
+    std::vector<uint8_t> record;
+    uint32_t nkeys = 0;
+    size_t resolve_lds = 0;
+    size_t frame_payload = 0, cbuf_frame_stride = 0, max_packet = 0;
+    hipStream_t own_stream = nullptr;
+    // device buffers
+    enc_const* d_const = nullptr; slice_geom* d_geom = nullptr; uint16_t* d_hdr = nullptr;
+    const uint8_t** d_frame_ptrs = nullptr;
+    int32_t* d_planes = nullptr; uint32_t* d_sym = nullptr; uint8_t* d_states = nullptr;
+    unsigned long long* d_ndec = nullptr; unsigned long long* d_group_off = nullptr;
+    uint8_t* d_stream = nullptr; size_t stream_cap = 0;
+    uint8_t* d_cbuf = nullptr; uint32_t* d_out_len = nullptr; uint32_t* d_tot_len = nullptr;
+    unsigned long long* d_slice_dst = nullptr; uint32_t* d_err = nullptr;
+    // host staging for the convenience path
+    uint8_t* h_pinned_in = nullptr; uint8_t* d_in = nullptr; uint8_t* d_packets = nullptr; unsigned long long* d_psizes = nullptr;
+    uint8_t* h_pinned_out = nullptr; unsigned long long* h_psizes = nullptr;
+    unsigned long long* h_ndec_pinned = nullptr;
+    // instrumentation
+    static constexpr int kNumK = 7;
+    hipEvent_t ev[2 * kNumK]{};            // start/stop pair per kernel, recorded on the launch stream
+    const void** h_frame_ptrs = nullptr;  // pinned copies of small host->device tables
+    unsigned long long* h_group_off_pinned = nullptr;
+    bool ev_valid = false;
+    uint64_t last_decisions = 0, last_packet_bytes = 0;
+    uint32_t last_n = 0;
+    std::vector<unsigned long long> h_last_psizes;
+};
+
+static const char* const kKernelNames[rcgpu_ffv1::kNumK] = { "k_unpack", "k_model", "k_resolve", "k_rangecode", "k_footer", "k_scan", "k_gather" };
+
+extern "C" int rcgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    void* bufs[] = { e->d_const, e->d_geom, e->d_hdr, e->d_frame_ptrs, e->d_planes, e->d_sym, e->d_states, e->d_ndec, e->d_group_off,
+                     e->d_stream, e->d_cbuf, e->d_out_len, e->d_tot_len, e->d_slice_dst, e->d_err, e->d_in, e->d_packets, e->d_psizes };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (e->h_pinned_in) (void)hipHostFree(e->h_pinned_in);
+    if (e->h_pinned_out) (void)hipHostFree(e->h_pinned_out);
+    if (e->h_psizes) (void)hipHostFree(e->h_psizes);
+    if (e->h_ndec_pinned) (void)hipHostFree(e->h_ndec_pinned);
+    if (e->h_frame_ptrs) (void)hipHostFree(e->h_frame_ptrs);
+    if (e->h_group_off_pinned) (void)hipHostFree(e->h_group_off_pinned);
+    for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
+{
+    clear_error();
+    if (!cfg || !out) return fail(1, "ffv1: null argument");
+    *out = nullptr;
+    if (cfg->pixfmt >= RCGPU_PIX_COUNT) return fail(2, "ffv1: unknown pixel format %u", cfg->pixfmt);
+    if (!cfg->width || !cfg->height) return fail(2, "ffv1: empty picture");
+    if (!cfg->num_h_slices || !cfg->num_v_slices || cfg->num_h_slices < cfg->num_v_slices)
+        return fail(2, "ffv1: slice grid %ux%u needs num_h >= num_v >= 1 (reference decoder limit, FFV1_Slice.cpp:127)", cfg->num_h_slices, cfg->num_v_slices);
+    const uint32_t S = cfg->num_h_slices * cfg->num_v_slices;
+    if (S > 1 && (cfg->num_h_slices >= cfg->width || cfg->num_v_slices >= cfg->height))
+        return fail(2, "ffv1: more slices than pixels (FFV1_Frame.cpp:161-164)");
+    if (!cfg->max_batch) return fail(2, "ffv1: max_batch is 0");
+    const pix_desc& d = pix(cfg->pixfmt);
+    if (cfg->line_bytes < cfg->width * d.bytes_pp) return fail(2, "ffv1: line_bytes smaller than a line");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(3, "ffv1: no HIP device available -- this encoder has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(3, "ffv1: device %d out of range (%d visible)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    rcgpu_ffv1* e = new rcgpu_ffv1;
+    e->cfg = *cfg;
+    e->sp.bits_per_raw_sample = d.bits; e->sp.rgb = d.planes != 1; e->sp.alpha = d.planes == 4;
+    e->sp.num_h_slices = cfg->num_h_slices; e->sp.num_v_slices = cfg->num_v_slices;
+    e->sp.ec = cfg->slicecrc ? 1 : 0; e->sp.context_model = cfg->context ? 1 : 0;
+    e->record = ffv1::config_record(e->sp);
+
+    ffv1::quant_model qm[2];
+    ffv1::build_quant_models(d.bits, qm);
+    const ffv1::quant_model& Q = qm[e->sp.context_model];
+    enc_const& c = e->hc;
+    c.W = cfg->width; c.H = cfg->height; c.line_bytes = cfg->line_bytes; c.pixfmt = cfg->pixfmt;
+    c.planes = d.planes; c.bps = d.bits; c.rgb = d.planes != 1; c.gb_swap = d.gb_swap; c.big_endian = d.big_endian; c.bytes_pp = d.bytes_pp;
+    c.bits = c.rgb ? d.bits + 1 : (d.bits <= 8 ? 8 : d.bits);                  // FFV1_Parameters.cpp:164-181
+    c.overflow16 = (!c.rgb && d.bits == 16);                                   // FFV1_Parameters.cpp:160
+    c.num_h = cfg->num_h_slices; c.num_v = cfg->num_v_slices; c.S = S; c.nctx = Q.context_count;
+    c.nsets = c.rgb ? (d.planes == 4 ? 3 : 2) : 1; c.ec = e->sp.ec; c.is5 = Q.q[3][127] != 0;
+    c.samples_per_frame = cfg->width * cfg->height * d.planes;
+    memcpy(c.q, Q.q, sizeof c.q);
+    memcpy(c.one_state, ffv1::kOneState, 256);
+    ffv1::make_zero_state(c.zero_state);
+    if (c.nctx > 8191) { delete e; return fail(2, "ffv1: context count %u does not fit the symbol format", c.nctx); }
+    e->nkeys = c.nsets * c.nctx;
+    e->resolve_lds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);
+    e->frame_payload = size_t(cfg->line_bytes) * cfg->height;
+
+    // slice geometry (FFV1_Slice.cpp:153-156), header decisions, raw-byte buffers
+    std::vector<uint16_t> hdr;
+    uint32_t sym_off = 0; size_t cb = 0;
+    for (uint32_t sy = 0; sy < c.num_v; sy++)
+        for (uint32_t sx = 0; sx < c.num_h; sx++) {
+            slice_geom g{};
+            g.x0 = uint32_t(uint64_t(sx) * c.W / c.num_h); g.y0 = uint32_t(uint64_t(sy) * c.H / c.num_v);
+            g.w = uint32_t(uint64_t(sx + 1) * c.W / c.num_h) - g.x0; g.h = uint32_t(uint64_t(sy + 1) * c.H / c.num_v) - g.y0;
+            g.sym_off = sym_off; g.nsamp = g.w * g.h * c.planes; sym_off += g.nsamp;
+            const auto hd = ffv1::slice_header_decisions(e->sp, sx, sy, e->geom.empty());
+            g.hdr_off = uint32_t(hdr.size()); g.hdr_n = uint32_t(hd.size());
+            hdr.insert(hdr.end(), hd.begin(), hd.end());
+            // worst realistic size: twice the raw payload of the slice, plus header/footer room
+            size_t cap = (size_t(g.w) * g.h * d.bytes_pp * 2 + 4096 + 15) & ~size_t(15);
+            if (cap > 0xFFFFFF + 64) cap = 0xFFFFFF + 64;          // slice size field is 24 bit
+            g.cbuf_off_lo = uint32_t(cb); g.cbuf_off_hi = uint32_t(uint64_t(cb) >> 32); g.cbuf_cap = uint32_t(cap);
+            cb += cap;
+            e->geom.push_back(g);
+        }
+    e->cbuf_frame_stride = cb;
+    e->max_packet = (cb + 15) & ~size_t(15);
+
+    const uint32_t F = cfg->max_batch;
+    const size_t nchains = size_t(F) * S, ngroups = (nchains + 63) / 64;
+    auto dmalloc = [&](auto** p, size_t bytes) -> hipError_t { return hipMalloc(reinterpret_cast<void**>(p), bytes ? bytes : 16); };
+    hipError_t he = hipSuccess;
+#define DM(p, b) if (he == hipSuccess) he = dmalloc(&(p), (b))
+    DM(e->d_const, sizeof(enc_const)); DM(e->d_geom, sizeof(slice_geom) * S); DM(e->d_hdr, hdr.size() * 2 + 16);
+    DM(e->d_frame_ptrs, sizeof(void*) * F);
+    DM(e->d_planes, size_t(F) * c.samples_per_frame * 4); DM(e->d_sym, size_t(F) * c.samples_per_frame * 4);
+    DM(e->d_states, nchains * e->nkeys * 32);
+    DM(e->d_ndec, nchains * 8); DM(e->d_group_off, ngroups * 8);
+    DM(e->d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
+    DM(e->d_out_len, nchains * 4); DM(e->d_tot_len, nchains * 4); DM(e->d_slice_dst, nchains * 8); DM(e->d_err, 16);
+#undef DM
+    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&e->h_ndec_pinned), nchains * 8);
+    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&e->h_frame_ptrs), sizeof(void*) * F);
+    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&e->h_group_off_pinned), ngroups * 8);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    for (auto& ev : e->ev) if (he == hipSuccess) he = hipEventCreate(&ev);
+    if (he == hipSuccess) he = hipMemcpy(e->d_const, &e->hc, sizeof(enc_const), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(e->d_geom, e->geom.data(), sizeof(slice_geom) * S, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(e->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void*>(k_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, int(e->resolve_lds));
+    if (he != hipSuccess) {
+        const int r = fail(100, "ffv1: device setup failed: %s", hipGetErrorString(he));
+        rcgpu_ffv1_destroy(e);
+        return r;
+    }
+    *out = e;
+    return 0;
+}
+
+extern "C" size_t rcgpu_ffv1_config_record(const rcgpu_ffv1* e, uint8_t* out, size_t cap)
+{
+    if (!e) return 0;
+    if (out && cap >= e->record.size()) memcpy(out, e->record.data(), e->record.size());
+    return e->record.size();
+}
+
+extern "C" size_t rcgpu_ffv1_max_packet_bytes(const rcgpu_ffv1* e) { return e ? e->max_packet : 0; }
+
+extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_frames, uint32_t n, void* d_packets, size_t packet_stride,
+                                        uint64_t* d_packet_sizes, void* hip_stream)
+{
+    clear_error();
+    if (!e || !d_frames || !d_packets || !d_packet_sizes) return fail(1, "ffv1: null argument");
+    if (!n || n > e->cfg.max_batch) return fail(2, "ffv1: batch of %u frames (max_batch %u)", n, e->cfg.max_batch);
+    if (packet_stride < e->max_packet || (packet_stride & 3)) return fail(2, "ffv1: packet_stride must be a multiple of 4 and >= %zu", e->max_packet);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    const enc_const& c = e->hc;
+    const uint32_t S = c.S, nchains = n * S, ngroups = (nchains + 63) / 64;
+
+    for (uint32_t i = 0; i < n; i++) e->h_frame_ptrs[i] = d_frames[i];
+    HIP_TRY(hipMemcpyAsync(e->d_frame_ptrs, e->h_frame_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(e->d_ndec, 0, size_t(nchains) * 8, st));
+    HIP_TRY(hipMemsetAsync(e->d_err, 0, 16, st));
+    HIP_TRY(hipEventRecord(e->ev[0], st));
+    hipLaunchKernelGGL(k_unpack, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, e->d_const, e->d_frame_ptrs, e->d_planes);
+    HIP_TRY(hipEventRecord(e->ev[1], st));
+    uint32_t max_lines = 0;
+    for (const slice_geom& g : e->geom) max_lines = std::max(max_lines, g.h * c.planes);
+    HIP_TRY(hipEventRecord(e->ev[2], st));
+    hipLaunchKernelGGL(k_model, dim3((max_lines + 7) / 8, nchains), dim3(256), 0, st, e->d_const, e->d_geom, e->d_planes, e->d_sym, e->d_ndec);
+    HIP_TRY(hipEventRecord(e->ev[3], st));
+    // The exact decision counts size the interleaved stream: one host round trip per batch.
+    HIP_TRY(hipMemcpyAsync(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    uint64_t total_dec = 0; unsigned long long off = 0;
+    for (uint32_t g = 0; g < ngroups; g++) {
+        unsigned long long pieces = 0;
+        for (uint32_t l = 0; l < 64 && g * 64 + l < nchains; l++) {
+            const uint32_t chain = g * 64 + l;
+            const unsigned long long nd = e->geom[chain % S].hdr_n + e->h_ndec_pinned[chain] + 1;
+            total_dec += nd;
+            pieces = std::max(pieces, (nd + kPieceEntries - 1) / kPieceEntries);
+        }
+        e->h_group_off_pinned[g] = off;
+        off += pieces * kGroupPieceBytes;
+    }
+    e->last_decisions = total_dec;
+    if (off > e->stream_cap) {
+        if (e->d_stream) HIP_TRY(hipFree(e->d_stream));
+        e->d_stream = nullptr; e->stream_cap = 0;
+        const size_t want = size_t(off) + size_t(off) / 8 + (1u << 20);
+        hipError_t he = hipMalloc(reinterpret_cast<void**>(&e->d_stream), want);
+        if (he != hipSuccess) return fail(101, "ffv1: cannot allocate %zu bytes for the decision stream of %u frames: %s -- lower max_batch", want, n, hipGetErrorString(he));
+        e->stream_cap = want;
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_group_off, e->h_group_off_pinned, size_t(ngroups) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(e->ev[4], st));
+    hipLaunchKernelGGL(k_resolve, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
+                       e->d_group_off, e->d_stream, e->nkeys);
+    HIP_TRY(hipEventRecord(e->ev[5], st));
+    HIP_TRY(hipEventRecord(e->ev[6], st));
+    hipLaunchKernelGGL(k_rangecode, dim3(ngroups), dim3(64), 0, st, e->d_const, e->d_geom, e->d_ndec, e->d_group_off, e->d_stream, e->d_cbuf,
+                       (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err);
+    HIP_TRY(hipEventRecord(e->ev[7], st));
+    HIP_TRY(hipEventRecord(e->ev[8], st));
+    hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(64), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+                       e->d_out_len, e->d_tot_len, e->d_err);
+    HIP_TRY(hipEventRecord(e->ev[9], st));
+    HIP_TRY(hipEventRecord(e->ev[10], st));
+    hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, st, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes));
+    HIP_TRY(hipEventRecord(e->ev[11], st));
+    HIP_TRY(hipEventRecord(e->ev[12], st));
+    hipLaunchKernelGGL(k_gather, dim3(8, nchains), dim3(256), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+                       e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride);
+    HIP_TRY(hipEventRecord(e->ev[13], st));
+    HIP_TRY(hipGetLastError());
+    e->ev_valid = true; e->last_n = n;
+    return 0;
+}
+
+extern "C" int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap)
+{
+    if (!e || !e->ev_valid) return 0;
+    if (hipEventSynchronize(e->ev[2 * rcgpu_ffv1::kNumK - 1]) != hipSuccess) return 0;
+    int k = 0;
+    for (; k < rcgpu_ffv1::kNumK && k < cap; k++) {
+        names[k] = kKernelNames[k];
+        float t = 0;
+        (void)hipEventElapsedTime(&t, e->ev[2 * k], e->ev[2 * k + 1]);
+        ms[k] = t;
+    }
+    return k;
+}
+
+extern "C" int rcgpu_ffv1_last_stats(const rcgpu_ffv1* e, uint64_t* decisions, uint64_t* packet_bytes)
+{
+    if (!e) return 1;
+    if (decisions) *decisions = e->last_decisions;
+    if (packet_bytes) *packet_bytes = e->last_packet_bytes;
+    return 0;
+}
+
+extern "C" int rcgpu_ffv1_encode_host(rcgpu_ffv1* e, const uint8_t* const* frames, uint32_t n, uint8_t* const* out_packets, size_t* out_sizes)
+{
+    clear_error();
+    if (!e || !frames || !out_packets || !out_sizes) return fail(1, "ffv1: null argument");
+    if (!n || n > e->cfg.max_batch) return fail(2, "ffv1: batch of %u frames (max_batch %u)", n, e->cfg.max_batch);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const uint32_t F = e->cfg.max_batch;
+    const size_t in_stride = (e->frame_payload + 255) & ~size_t(255);
+    if (!e->d_in) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_in), in_stride * F));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_packets), e->max_packet * F));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_psizes), 8 * F));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned_in), in_stride * F));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_psizes), 8 * F));
+    }
+    hipStream_t st = e->own_stream;
+    std::vector<const void*> ptrs(n);
+    for (uint32_t i = 0; i < n; i++) {
+        memcpy(e->h_pinned_in + i * in_stride, frames[i], e->frame_payload);
+        HIP_TRY(hipMemcpyAsync(e->d_in + i * in_stride, e->h_pinned_in + i * in_stride, e->frame_payload, hipMemcpyHostToDevice, st));
+        ptrs[i] = e->d_in + i * in_stride;
+    }
+    if (int r = rcgpu_ffv1_encode_device(e, ptrs.data(), n, e->d_packets, e->max_packet, reinterpret_cast<uint64_t*>(e->d_psizes), st)) return r;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(e->h_psizes, e->d_psizes, 8 * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&err, e->d_err, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (err) return fail(102, "ffv1: a slice outgrew its buffer (flags %u) -- content expands beyond 2x raw size", err);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        out_sizes[i] = size_t(e->h_psizes[i]);
+        total += e->h_psizes[i];
+        HIP_TRY(hipMemcpyAsync(out_packets[i], e->d_packets + i * e->max_packet, out_sizes[i], hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    e->last_packet_bytes = total;
+    return 0;
+}
+
+// Debug taps for the stage-by-stage parity tests (tests/test_gpu_stages.py): copies an intermediate of the LAST
+// batch to the host.  what: 0 planes (int32), 1 symbols (u32), 2 per-chain decision counts (u64),
+// 3 decision stream of `chain` de-interleaved (u16), 4 raw slice bytes of `chain` before the footer.
+extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t chain, void* dst, size_t cap)
+{
+    if (!e || !e->ev_valid) return -1;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    const enc_const& c = e->hc;
+    const uint32_t S = c.S;
+    auto d2h = [&](const void* src, size_t bytes) -> long long {
+        if (bytes > cap) return -2;
+        return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? (long long)bytes : -3;
+    };
+    switch (what) {
+    case 0: return d2h(e->d_planes, size_t(e->last_n) * c.samples_per_frame * 4);
+    case 1: return d2h(e->d_sym, size_t(e->last_n) * c.samples_per_frame * 4);
+    case 2: return d2h(e->d_ndec, size_t(e->last_n) * S * 8);
+    case 3: {
+        if (chain >= e->last_n * S) return -4;
+        const unsigned long long nd = e->geom[chain % S].hdr_n + e->h_ndec_pinned[chain] + 1;
+        const size_t pieces = (nd + kPieceEntries - 1) / kPieceEntries;
+        if (nd * 2 > cap) return -2;
+        std::vector<uint8_t> tmp(pieces * kPieceBytes);
+        const uint8_t* base = e->d_stream + e->h_group_off_pinned[chain >> 6] + (chain & 63) * kPieceBytes;
+        if (hipMemcpy2D(tmp.data(), kPieceBytes, base, kGroupPieceBytes, kPieceBytes, pieces, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+        memcpy(dst, tmp.data(), nd * 2);
+        return (long long)(nd * 2);
+    }
+    case 4: {
+        if (chain >= e->last_n * S) return -4;
+        uint32_t len = 0;
+        if (hipMemcpy(&len, e->d_out_len + chain, 4, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+        const slice_geom& g = e->geom[chain % S];
+        const uint8_t* src = e->d_cbuf + size_t(chain / S) * e->cbuf_frame_stride + (size_t(g.cbuf_off_hi) << 32 | g.cbuf_off_lo);
+        return d2h(src, len);
+    }
+    default: return -5;
+    }
+}
+
+extern "C" int rcgpu_ffv1_decode_device(rcgpu_ffv1*, const void* const*, const uint64_t*, uint32_t, void* const*, void*)
+{
+    return fail(200, "ffv1: device decoder (--check path) is not built yet");
+}

@@ -1,0 +1,433 @@
+// job.cpp -- the drop-in boundary: one encode job = what RAWcooked hands to `ffmpeg` today.
+//
+// rcgpu_encode() replaces `system(Command)` at CLI/Output.cpp:356; rcgpu_main_ffmpeg_argv() accepts the argv
+// grammar that output::FFmpeg_Command assembles (CLI/Output.cpp:81-332), so an UNMODIFIED rawcooked can run this
+// encoder through `--bin-name` (CLI/Global.cpp:543-550).  Files are read on the host, frames are sharded
+// round-robin over the selected devices in batches, packets come back over each device's own PCIe link and one
+// muxer writes them in frame order.  No collective is involved: every frame is a key frame (-g 1).
+#include "rc_common.h"
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <condition_variable>
+#include <fcntl.h>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+
+using namespace rc;
+
+namespace {
+
+struct mapped_file {
+    const uint8_t* data = nullptr; size_t size = 0;
+    mapped_file() = default;
+    mapped_file(const mapped_file&) = delete;
+    ~mapped_file() { if (data) munmap(const_cast<uint8_t*>(data), size); }
+    bool open(const std::string& path)
+    {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return false; }
+        void* p = mmap(nullptr, size_t(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);   // the reference's default reader, Lib/Utils/FileIO/FileIO.cpp:274
+        ::close(fd);
+        if (p == MAP_FAILED) return false;
+        data = static_cast<const uint8_t*>(p); size = size_t(st.st_size);
+        return true;
+    }
+};
+
+bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+
+std::string lower_ext(const std::string& p)
+{
+    const size_t d = p.rfind('.');
+    std::string e = d == std::string::npos ? "" : p.substr(d + 1);
+    for (char& c : e) c = char(tolower(c));
+    return e;
+}
+
+// "%06d"-style template expansion (the only conversion input::DetectSequence emits, CLI/Input.cpp:305-306)
+bool expand_template(const std::string& tpl, unsigned long long n, std::string& out)
+{
+    const size_t pc = tpl.find('%');
+    if (pc == std::string::npos) return false;
+    size_t i = pc + 1; int width = 0; bool zero = false;
+    if (i < tpl.size() && tpl[i] == '0') { zero = true; i++; }
+    while (i < tpl.size() && isdigit(uint8_t(tpl[i]))) width = width * 10 + (tpl[i++] - '0');
+    if (i >= tpl.size() || tpl[i] != 'd') return false;
+    char num[32];
+    snprintf(num, sizeof num, zero ? "%0*llu" : "%*llu", width, n);
+    out = tpl.substr(0, pc) + num + tpl.substr(i + 1);
+    return true;
+}
+
+struct rational { uint32_t num = 24, den = 1; };
+rational parse_framerate(const char* s)
+{
+    rational r;
+    if (!s || !*s) return r;
+    char* end = nullptr;
+    const double a = strtod(s, &end);
+    if (end && *end == '/') {
+        const double b = strtod(end + 1, nullptr);
+        if (a > 0 && b > 0) { r.num = uint32_t(std::llround(a)); r.den = uint32_t(std::llround(b)); }
+        return r;
+    }
+    if (!(a > 0)) return r;
+    // decimal: NTSC-style rates are n*1000/1001
+    const double n1001 = a * 1001.0 / 1000.0;
+    if (std::fabs(a - std::round(a)) < 1e-6) { r.num = uint32_t(std::llround(a)); r.den = 1; }
+    else if (std::fabs(n1001 - std::round(n1001)) < 2e-3) { r.num = uint32_t(std::llround(n1001)) * 1000; r.den = 1001; }
+    else { r.num = uint32_t(std::llround(a * 1000.0)); r.den = 1000; }
+    return r;
+}
+
+struct options {
+    std::map<std::string, std::string> kv;
+    const char* get(const char* k) const { auto i = kv.find(k); return i == kv.end() ? nullptr : i->second.c_str(); }
+    long num(const char* k, long def) const { const char* v = get(k); return v && *v ? strtol(v, nullptr, 10) : def; }
+    bool has(const char* k) const { return kv.count(k) != 0; }
+};
+
+struct video_plan {
+    std::vector<std::string> files;
+    rcgpu_image_info info{};
+    bool tiff = false;
+    rational fps;
+    uint32_t num_h = 1, num_v = 1;
+    int track = 0;
+};
+struct audio_plan {
+    std::string file;
+    rcgpu_audio_info info{};
+    std::vector<uint8_t> frames;              // concatenated FLAC frames
+    std::vector<uint32_t> frame_sizes;
+    uint32_t block_size = 0;
+    std::vector<uint8_t> codec_private;
+    int track = 0;
+};
+
+int probe_image(const std::string& path, bool& tiff, rcgpu_image_info& info)
+{
+    mapped_file f;
+    if (!f.open(path)) return fail(30, "cannot open %s: %s", path.c_str(), strerror(errno));
+    const std::string ext = lower_ext(path);
+    const bool looks_tiff = f.size >= 4 && ((f.data[0] == 'I' && f.data[1] == 'I') || (f.data[0] == 'M' && f.data[1] == 'M'));
+    tiff = looks_tiff || ext == "tif" || ext == "tiff";
+    return tiff ? rcgpu_tiff_probe(f.data, f.size, &info) : rcgpu_dpx_probe(f.data, f.size, &info);
+}
+
+// Ordered, single-writer hand-over of encoded batches to the muxer.
+struct turnstile {
+    std::mutex m; std::condition_variable cv; size_t next = 0; int error = 0;
+    void wait_turn(size_t idx) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return next == idx || error; }); }
+    void done(size_t idx, int err) { { std::lock_guard<std::mutex> l(m); if (err && !error) error = err; next = idx + 1; } cv.notify_all(); }
+};
+
+}  // namespace
+
+extern "C" int rcgpu_encode(const rcgpu_job* job)
+{
+    clear_error();
+    auto bail = [](int code) { fprintf(stderr, "Error: %s\n", rcgpu_last_error()); return code ? code : 1; };
+    if (!job || !job->streams || !job->n_streams || !job->output_path) return bail(fail(1, "job: missing streams or output path"));
+    options opt;
+    for (size_t i = 0; i + 1 < job->n_options; i += 2)
+        if (job->options[i]) opt.kv[job->options[i]] = job->options[i + 1] ? job->options[i + 1] : "";
+    // What this encoder implements of the option surface (defaults: CLI/Global.cpp:938-989)
+    if (const char* cv = opt.get("c:v")) if (strcmp(cv, "ffv1") != 0) return bail(fail(2, "video codec %s is not supported by rcgpu (only ffv1)", cv));
+    if (const char* ca = opt.get("c:a")) if (strcmp(ca, "flac") != 0) return bail(fail(2, "audio codec %s is not supported by rcgpu (only flac)", ca));
+    if (opt.num("coder", 1) != 1) return bail(fail(2, "-coder %ld is not supported by rcgpu (only 1, range coder with default table)", opt.num("coder", 1)));
+    if (opt.num("level", 3) != 3) return bail(fail(2, "-level %ld is not supported by rcgpu (only 3)", opt.num("level", 3)));
+    if (opt.num("g", 1) != 1) return bail(fail(2, "-g %ld is not supported by rcgpu (intra only)", opt.num("g", 1)));
+    if (job->framemd5_path) return bail(fail(2, "-f framemd5 is not supported by rcgpu"));
+    const uint32_t context = uint32_t(opt.num("context", 0)), slicecrc = uint32_t(opt.num("slicecrc", 1));
+    const bool overwrite = opt.has("y") && !opt.has("n");
+    if (!overwrite && file_exists(job->output_path)) return bail(fail(3, "output file %s already exists (use -y)", job->output_path));
+
+    int ndev_visible = rcgpu_device_count();
+    if (ndev_visible <= 0) return bail(fail(4, "no HIP device available -- rcgpu has no CPU encode path"));
+    const int dev0 = std::max(0, job->device_first);
+    int ndev = job->device_count > 0 ? job->device_count : ndev_visible - dev0;
+    if (dev0 >= ndev_visible || ndev <= 0) return bail(fail(4, "device selection %d+%d is outside the %d visible devices", dev0, job->device_count, ndev_visible));
+    ndev = std::min(ndev, ndev_visible - dev0);
+
+    // ---- analyse the streams
+    std::vector<video_plan> videos; std::vector<audio_plan> audios;
+    std::vector<std::pair<bool, size_t>> order;        // stream order -> (is_video, index)
+    for (size_t si = 0; si < job->n_streams; si++) {
+        const rcgpu_stream& s = job->streams[si];
+        if (!s.path_or_template && !s.filelist) return bail(fail(5, "stream %zu has no input", si));
+        if (s.vflip) return bail(fail(5, "-vf vflip (DPX orientation 2) is not supported by rcgpu yet"));
+        std::vector<std::string> files;
+        if (s.filelist && *s.filelist) {
+            const char* p = s.filelist;
+            while (*p) { const char* e = strchr(p, '\n'); std::string one = e ? std::string(p, e) : std::string(p); if (!one.empty()) files.push_back(one); if (!e) break; p = e + 1; }
+        } else if (s.start_number && strchr(s.path_or_template, '%')) {
+            unsigned long long n = strtoull(s.start_number, nullptr, 10);
+            for (;; n++) { std::string f; if (!expand_template(s.path_or_template, n, f) || !file_exists(f)) break; files.push_back(f); }   // stop at the first gap, like image2
+        } else
+            files.push_back(s.path_or_template);
+        if (files.empty()) return bail(fail(5, "stream %zu: no input file matches %s", si, s.path_or_template ? s.path_or_template : "(list)"));
+        const std::string ext = lower_ext(files[0]);
+        const bool is_audio = s.slices == 0 && (ext == "wav" || (s.flavor && !strncmp(s.flavor, "WAV/", 4)));
+        if (is_audio) {
+            audio_plan a; a.file = files[0];
+            mapped_file f;
+            if (!f.open(a.file)) return bail(fail(30, "cannot open %s: %s", a.file.c_str(), strerror(errno)));
+            if (int r = rcgpu_wav_probe(f.data, f.size, &a.info)) return bail(r);
+            audios.push_back(std::move(a)); order.push_back({ false, audios.size() - 1 });
+        } else {
+            video_plan v; v.files = std::move(files);
+            if (int r = probe_image(v.files[0], v.tiff, v.info)) return bail(r);
+            if (s.flavor && *s.flavor && strcmp(s.flavor, v.info.flavor) != 0)
+                return bail(fail(6, "stream %zu: caller says flavor %s, file is %s", si, s.flavor, v.info.flavor));
+            uint32_t slices = uint32_t(opt.num("slices", 0));
+            if (!slices && s.slices && s.slices != 0xFFFFFFFFu) slices = s.slices;    // 0xFFFFFFFF: video, count left to the probe
+            if (!slices) slices = v.info.slices;
+            if (int r = rcgpu_slices_to_grid(slices, &v.num_h, &v.num_v)) return bail(r);
+            v.fps = parse_framerate(s.framerate && *s.framerate ? s.framerate : nullptr);
+            if ((!s.framerate || !*s.framerate) && v.info.framerate > 0) { char t[32]; snprintf(t, sizeof t, "%.6f", v.info.framerate); v.fps = parse_framerate(t); }
+            videos.push_back(std::move(v)); order.push_back({ true, videos.size() - 1 });
+        }
+    }
+    if (videos.size() > 1) return bail(fail(7, "more than one video stream per file is not supported by rcgpu yet"));
+
+    // ---- audio first: A_FLAC CodecPrivate (STREAMINFO) must be final before the header is written
+    for (audio_plan& a : audios) {
+        mapped_file f;
+        if (!f.open(a.file)) return bail(fail(30, "cannot open %s", a.file.c_str()));
+        rcgpu_flac_config fc{}; fc.channels = a.info.channels; fc.sample_rate = a.info.sample_rate; fc.bits_per_sample = a.info.bits_per_sample;
+        fc.block_size = 0; fc.max_lpc_order = 8; fc.device = dev0;
+        rcgpu_flac* fe = nullptr;
+        if (int r = rcgpu_flac_create(&fc, &fe)) return bail(r);
+        const uint64_t nsamples = a.info.data_size / a.info.block_align;
+        a.frames.resize(size_t(a.info.data_size + a.info.data_size / 4 + (1 << 16)));
+        a.frame_sizes.resize(size_t(nsamples / 192 + 16));
+        uint32_t nframes = 0;
+        int r = rcgpu_flac_encode_host(fe, f.data + a.info.data_offset, a.info.data_size, a.frames.data(), a.frames.size(), a.frame_sizes.data(),
+                                       uint32_t(a.frame_sizes.size()), &nframes);
+        if (!r) {
+            a.frame_sizes.resize(nframes);
+            a.codec_private.resize(64);
+            a.codec_private.resize(rcgpu_flac_codec_private(fe, a.codec_private.data(), a.codec_private.size()));
+            a.block_size = a.codec_private.size() >= 12 ? (uint32_t(a.codec_private[10]) << 8 | a.codec_private[11]) : 4608;   // STREAMINFO max blocksize
+        }
+        rcgpu_flac_destroy(fe);
+        if (r) return bail(r);
+    }
+
+    // ---- container header
+    rcgpu_mkv* mux = nullptr;
+    if (int r = rcgpu_mkv_open(job->output_path, 1, &mux)) return bail(r);
+    struct mux_guard { rcgpu_mkv*& m; const char* path; bool ok = false; ~mux_guard() { if (m) { rcgpu_mkv_close(m); if (!ok) unlink(path); } } } guard{ mux, job->output_path };
+
+    std::vector<std::unique_ptr<rcgpu_ffv1, void (*)(rcgpu_ffv1*)>> encoders;
+    const uint32_t batch = uint32_t(std::max(1L, opt.num("rcgpu_batch", 0)));
+    uint32_t F = 1;
+    for (auto& o : order) {
+        if (o.first) {
+            video_plan& v = videos[o.second];
+            // frames in flight per device: bounded by HBM (intermediates ~1.3 GB per 4K frame) and by the sequence length
+            const uint64_t px = uint64_t(v.info.width) * v.info.height;
+            F = batch ? batch : uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (uint64_t(96) << 30) / (px * 160 + 1))));
+            F = uint32_t(std::min<uint64_t>(F, (v.files.size() + ndev - 1) / ndev));
+            rcgpu_ffv1_config c{}; c.width = v.info.width; c.height = v.info.height; c.pixfmt = v.info.pixfmt; c.line_bytes = v.info.line_bytes;
+            c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.max_batch = F;
+            for (int d = 0; d < ndev; d++) {
+                c.device = dev0 + d;
+                rcgpu_ffv1* e = nullptr;
+                if (int r = rcgpu_ffv1_create(&c, &e)) return bail(r);
+                encoders.emplace_back(e, rcgpu_ffv1_destroy);
+            }
+            uint8_t rec[4096];
+            const size_t n = rcgpu_ffv1_config_record(encoders[0].get(), rec, sizeof rec);
+            v.track = rcgpu_mkv_add_video(mux, rec, n, v.info.width, v.info.height, v.fps.num, v.fps.den);
+            if (v.track < 0) return bail(8);
+        } else {
+            audio_plan& a = audios[o.second];
+            a.track = rcgpu_mkv_add_audio(mux, a.codec_private.data(), a.codec_private.size(), a.info.channels, a.info.sample_rate, a.info.bits_per_sample);
+            if (a.track < 0) return bail(8);
+        }
+    }
+    auto attach = [&](const char* path, const char* name) -> int {
+        mapped_file f;
+        if (!f.open(path)) return fail(30, "cannot open attachment %s: %s", path, strerror(errno));
+        return rcgpu_mkv_add_attachment(mux, name, "application/octet-stream", f.data, f.size);
+    };
+    for (size_t i = 0; i < job->n_attachments; i++)
+        if (int r = attach(job->attachments[i].path_in, job->attachments[i].name_out ? job->attachments[i].name_out : job->attachments[i].path_in)) return bail(r);
+    if (job->reversibility_path)
+        if (int r = attach(job->reversibility_path, "RAWcooked reversibility data")) return bail(r);
+    if (int r = rcgpu_mkv_begin(mux)) return bail(r);
+
+    // ---- blocks, in timestamp order: audio frames are interleaved in front of the video frame they precede
+    std::vector<size_t> audio_pos(audios.size(), 0), audio_off(audios.size(), 0);
+    auto write_audio_until = [&](uint64_t pts_ns_limit) -> int {
+        for (size_t ai = 0; ai < audios.size(); ai++) {
+            audio_plan& a = audios[ai];
+            while (audio_pos[ai] < a.frame_sizes.size()) {
+                const uint64_t pts = uint64_t(audio_pos[ai]) * a.block_size * 1000000000ull / a.info.sample_rate;
+                if (pts > pts_ns_limit) break;
+                if (int r = rcgpu_mkv_write_block(mux, a.track, pts, a.frames.data() + audio_off[ai], a.frame_sizes[audio_pos[ai]], 1)) return r;
+                audio_off[ai] += a.frame_sizes[audio_pos[ai]++];
+            }
+        }
+        return 0;
+    };
+
+    if (!videos.empty()) {
+        video_plan& v = videos[0];
+        const size_t nframes = v.files.size(), nbatches = (nframes + F - 1) / F;
+        turnstile ts;
+        auto worker = [&](int d) {
+            rcgpu_ffv1* enc = encoders[size_t(d)].get();
+            const size_t cap = rcgpu_ffv1_max_packet_bytes(enc);
+            std::vector<std::vector<uint8_t>> packets;
+            for (size_t b = size_t(d); b < nbatches; b += size_t(ndev)) {
+                const size_t first = b * F, n = std::min<size_t>(F, nframes - first);
+                int err = 0;
+                std::vector<std::unique_ptr<mapped_file>> maps(n);
+                std::vector<const uint8_t*> ptrs(n); std::vector<uint8_t*> outs(n); std::vector<size_t> sizes(n);
+                if (packets.size() < n) packets.resize(n);
+                for (size_t i = 0; i < n && !err; i++) {
+                    maps[i].reset(new mapped_file);
+                    if (!maps[i]->open(v.files[first + i])) { err = fail(30, "cannot open %s: %s", v.files[first + i].c_str(), strerror(errno)); break; }
+                    rcgpu_image_info fi{};
+                    const int r = v.tiff ? rcgpu_tiff_probe(maps[i]->data, maps[i]->size, &fi) : rcgpu_dpx_probe(maps[i]->data, maps[i]->size, &fi);
+                    if (r) { err = r; break; }
+                    if (fi.width != v.info.width || fi.height != v.info.height || fi.pixfmt != v.info.pixfmt || fi.line_bytes != v.info.line_bytes)
+                        { err = fail(31, "%s differs in geometry/flavor from the first frame of the sequence", v.files[first + i].c_str()); break; }
+                    ptrs[i] = maps[i]->data + fi.data_offset;
+                    if (packets[i].size() < cap) packets[i].resize(cap);
+                    outs[i] = packets[i].data();
+                }
+                if (!err) err = rcgpu_ffv1_encode_host(enc, ptrs.data(), uint32_t(n), outs.data(), sizes.data());
+                std::string msg = err ? rcgpu_last_error() : "";
+                ts.wait_turn(b);
+                if (!err && !ts.error) {
+                    for (size_t i = 0; i < n && !err; i++) {
+                        const uint64_t pts = uint64_t(first + i) * v.fps.den * 1000000000ull / v.fps.num;
+                        err = write_audio_until(pts);
+                        if (!err) err = rcgpu_mkv_write_block(mux, v.track, pts, outs[i], sizes[i], 1);
+                    }
+                    if (err) msg = rcgpu_last_error();
+                }
+                if (err) { std::lock_guard<std::mutex> l(ts.m); if (!ts.error) fail(err, "%s", msg.c_str()); }
+                ts.done(b, err);
+                if (err || ts.error) break;
+            }
+        };
+        std::vector<std::thread> threads;
+        for (int d = 1; d < ndev; d++) threads.emplace_back(worker, d);
+        worker(0);
+        for (auto& t : threads) t.join();
+        if (ts.error) { if (!*rcgpu_last_error()) fail(ts.error, "encode failed on a worker thread"); return bail(ts.error); }
+    }
+    if (int r = write_audio_until(~0ull)) return bail(r);
+    rcgpu_mkv* m = mux; mux = nullptr;
+    if (int r = rcgpu_mkv_close(m)) { unlink(job->output_path); return bail(r); }
+    guard.ok = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// argv front end: the grammar of output::FFmpeg_Command (CLI/Output.cpp:81-332)
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int rcgpu_main_ffmpeg_argv(int argc, const char* const* argv)
+{
+    clear_error();
+    struct in_stream { std::string path, start, framerate, filelist, fmt; bool is_video_hint = false; };
+    std::vector<in_stream> ins; in_stream cur;
+    std::vector<std::pair<std::string, std::string>> attach_files;   // path, display name
+    std::map<std::string, std::string> out_opts;
+    std::string output, rev_path, framemd5;
+    std::string pending_f;
+    auto need = [&](int i) { return i + 1 < argc; };
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-version" || a == "--version") { printf("%s\n", rcgpu_version()); return 0; }
+        if (a == "-xerror" || a == "-nostdin" || a == "-hide_banner") continue;
+        if (a == "-y" || a == "-n") { out_opts[a.substr(1)] = ""; continue; }
+        if (a == "-i" && need(i)) {
+            cur.path = argv[++i]; cur.fmt = pending_f; pending_f.clear();
+            if (cur.fmt == "concat") {     // ffconcat list written at Output.cpp:236-246: file '<path>' / duration x
+                mapped_file f;
+                if (!f.open(cur.path)) { fprintf(stderr, "Error: cannot open file list %s\n", cur.path.c_str()); return 1; }
+                std::string text(reinterpret_cast<const char*>(f.data), f.size), list;
+                size_t p = 0;
+                while (p < text.size()) {
+                    size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
+                    std::string line = text.substr(p, e - p); p = e + 1;
+                    if (line.compare(0, 6, "file '") == 0 && line.size() > 7 && line.back() == '\'') { if (!list.empty()) list += '\n'; list += line.substr(6, line.size() - 7); }
+                }
+                cur.filelist = list; cur.path.clear();
+            }
+            ins.push_back(cur); cur = in_stream(); continue;
+        }
+        if (a == "-f" && need(i)) {
+            const std::string v = argv[++i];
+            if (v == "matroska") { if (need(i) && argv[i + 1][0] != '-') output = argv[++i]; continue; }
+            if (v == "framemd5") { if (need(i)) framemd5 = argv[++i]; continue; }
+            pending_f = v; continue;
+        }
+        if (a == "-attach" && need(i)) { attach_files.push_back({ argv[++i], "" }); continue; }
+        if (a.compare(0, 12, "-metadata:s:") == 0 && need(i)) {
+            const std::string kv = argv[++i];
+            if (kv.compare(0, 9, "filename=") == 0 && !attach_files.empty()) attach_files.back().second = kv.substr(9);
+            continue;
+        }
+        if (a == "-map" && need(i)) { i++; continue; }
+        if (a == "-an") continue;
+        if (a[0] == '-' && need(i)) {
+            const std::string k = a.substr(1), v = argv[++i];
+            // options in front of an -i belong to that input (Output.cpp:111-131); the rest are output options
+            if (k == "framerate") { cur.framerate = v; cur.is_video_hint = true; continue; }
+            if (k == "r") { if (cur.framerate.empty()) cur.framerate = v; continue; }
+            if (k == "start_number") { cur.start = v; continue; }
+            if (k == "safe" || k == "consider_float16_as_uint16") continue;
+            if (k == "c:v" && (v == "dpx" || v == "tiff" || v == "exr")) { cur.is_video_hint = true; if (v == "exr") { fprintf(stderr, "Error: EXR input is not supported by rcgpu yet\n"); return 1; } continue; }
+            out_opts[k] = v;
+            continue;
+        }
+        if (a[0] != '-') { output = a; continue; }
+        fprintf(stderr, "Error: rcgpu-ffmpeg does not understand argument %s\n", a.c_str());
+        return 1;
+    }
+    if (ins.empty() || output.empty()) { fprintf(stderr, "Error: rcgpu-ffmpeg needs at least one -i and an output (-f matroska <file>)\n"); return 1; }
+    // the reversibility file is the attachment displayed as "RAWcooked reversibility data" (Output.cpp:289-291)
+    std::vector<rcgpu_attachment> atts;
+    for (auto& af : attach_files) {
+        if (af.second == "RAWcooked reversibility data") rev_path = af.first;
+        else atts.push_back({ af.first.c_str(), af.second.empty() ? af.first.c_str() : af.second.c_str() });
+    }
+    std::vector<rcgpu_stream> streams;
+    for (in_stream& s : ins) {
+        rcgpu_stream r{};
+        r.path_or_template = s.path.empty() ? nullptr : s.path.c_str();
+        r.start_number = s.start.empty() ? nullptr : s.start.c_str();
+        r.filelist = s.filelist.empty() ? nullptr : s.filelist.c_str();
+        r.framerate = s.framerate.empty() ? nullptr : s.framerate.c_str();
+        const std::string ext = lower_ext(s.path);
+        r.slices = (ext == "wav") ? 0 : 0xFFFFFFFFu;      // 0 = audio; 0xFFFFFFFF = video, count from -slices or the probe
+        streams.push_back(r);
+    }
+    std::vector<const char*> kv;
+    for (auto& o : out_opts) { kv.push_back(o.first.c_str()); kv.push_back(o.second.c_str()); }
+    rcgpu_job job{};
+    job.streams = streams.data(); job.n_streams = streams.size();
+    job.attachments = atts.data(); job.n_attachments = atts.size();
+    job.reversibility_path = rev_path.empty() ? nullptr : rev_path.c_str();
+    job.output_path = output.c_str();
+    job.framemd5_path = framemd5.empty() ? nullptr : framemd5.c_str();
+    job.options = kv.data(); job.n_options = kv.size();
+    const char* dv = getenv("RCGPU_DEVICES");     // "first,count"; default: all visible
+    if (dv) { int a = 0, b = 0; if (sscanf(dv, "%d,%d", &a, &b) >= 1) { job.device_first = a; job.device_count = b; } }
+    return rcgpu_encode(&job);
+}

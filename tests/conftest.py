@@ -1,0 +1,34 @@
+"""pytest configuration: `gpu` marker, locations of the oracle and of the reference binary."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure librcgpu.so and liboracle.so exist (builds them when the toolchain is here)."""
+    lib = os.path.join(ROOT, "rawcooked_amd", "librcgpu.so")
+    ora = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(ora)):
+        import __graft_entry__
+        __graft_entry__.build()
+    return lib, ora
+
+
+@pytest.fixture(scope="session")
+def refbin():
+    """oracle/_ref/rawcooked: the real reference, built by oracle/Makefile.ref where /root/reference exists."""
+    p = os.path.join(ROOT, "oracle", "_ref", "rawcooked")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref/rawcooked not built (needs /root/reference)")
+    return p

@@ -1,0 +1,72 @@
+"""ctypes binding of oracle/liboracle.so -- the CPU checker.  Imported by tests only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "pixfmt", "num_h_slices", "num_v_slices", "ec", "context_model")]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+        L.ffv1o_config_record.restype = C.c_size_t
+        L.ffv1o_encode_payload.restype = C.c_size_t
+        L.ffv1o_encode_frame.restype = C.c_size_t
+        L.ffv1o_trace_slice.restype = C.c_size_t
+        L.ffv1o_line_bytes.restype = C.c_size_t
+        L.ffv1o_last_decisions.restype = C.c_uint64
+        L.ffv1o_crc32.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def config_record(p: Params) -> bytes:
+    buf = C.create_string_buffer(8192)
+    n = lib().ffv1o_config_record(C.byref(p), buf, C.c_size_t(8192))
+    return buf.raw[:n]
+
+
+def encode_payload(p: Params, payload: bytes, line_bytes: int) -> bytes:
+    cap = len(payload) * 2 + (1 << 16)
+    out = C.create_string_buffer(cap)
+    n = lib().ffv1o_encode_payload(C.byref(p), payload, C.c_size_t(line_bytes), out, C.c_size_t(cap), None)
+    assert n > 0, "oracle encoder overflow"
+    return out.raw[:n]
+
+
+def decode_payload(p: Params, packet: bytes, line_bytes: int) -> bytes:
+    out = C.create_string_buffer(line_bytes * p.height)
+    r = lib().ffv1o_decode_payload(C.byref(p), packet, C.c_size_t(len(packet)), out, C.c_size_t(line_bytes))
+    assert r == 0, f"oracle decoder error {r}"
+    return out.raw
+
+
+def unpack(p: Params, payload: bytes, line_bytes: int, nplanes: int) -> np.ndarray:
+    planes = np.zeros((4, p.height, p.width), dtype=np.int32)
+    ptrs = (C.c_void_p * 4)(*[planes[i].ctypes.data for i in range(4)])
+    lib().ffv1o_unpack(C.byref(p), payload, C.c_size_t(line_bytes), ptrs)
+    return planes[:nplanes]
+
+
+def trace_slice(p: Params, planes: np.ndarray, sx: int, sy: int, nsamp: int):
+    """-> (symbols u32[nsamp], decisions u16[], slice bytes incl. footer)"""
+    full = np.zeros((4, p.height, p.width), dtype=np.int32)
+    full[:planes.shape[0]] = planes
+    ptrs = (C.c_void_p * 4)(*[full[i].ctypes.data for i in range(4)])
+    sym = np.zeros(nsamp, dtype=np.uint32)
+    dcap = nsamp * 36 + 256
+    dec = np.zeros(dcap, dtype=np.uint16)
+    ndec = C.c_size_t()
+    rcap = nsamp * 8 + 4096
+    raw = C.create_string_buffer(rcap)
+    n = lib().ffv1o_trace_slice(C.byref(p), ptrs, sx, sy, sym.ctypes.data_as(C.c_void_p), dec.ctypes.data_as(C.c_void_p), C.c_size_t(dcap),
+                                C.byref(ndec), raw, C.c_size_t(rcap))
+    assert n > 0
+    return sym, dec[:ndec.value].copy(), raw.raw[:n]
