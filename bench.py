@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- 4K-DCI 16-bit DPX -> FFV1 frames/s on MI355X (BASELINE.json metric, configs[1]).
+
+One "step" = one pass of the whole device hot path (unpack+RCT, context model, state resolution, range coder,
+footer/CRC, packet gather) over one batch of synthetic 4096x2160 RGB 16-bit big-endian DPX payloads that are
+already resident in HBM, -slices 64 (8x8), -coder 1 -context 1 -slicecrc 1 -g 1 -level 3 -- the options RAWcooked
+passes (Source/CLI/Global.cpp:938-989).  Frames shard across ranks with no collective: every rank
+encodes its own batch; torch.distributed (RCCL) is used only for the barriers and the max-over-ranks timing.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch F] [--kind film|flat|noise]
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W4K, H4K = 4096, 2160
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_frames(torch, n, width, height, kind, seed, device):
+    """n synthetic RGB16-BE payloads on the device, uint8 [n, height*width*6]."""
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + seed)
+    maxv = 65535.0
+    if kind == "flat":
+        base = torch.randint(0, 65536, (n, 1, 1, 3), generator=g, device=device, dtype=torch.int32)
+        v = base.expand(n, height, width, 3).contiguous()
+    elif kind == "noise":
+        v = torch.randint(0, 65536, (n, height, width, 3), generator=g, device=device, dtype=torch.int32)
+    else:
+        y = torch.linspace(0, 1, height, device=device).view(1, height, 1, 1)
+        x = torch.linspace(0, 1, width, device=device).view(1, 1, width, 1)
+        ph = torch.rand((n, 1, 1, 3), generator=g, device=device) * 6.28
+        c = torch.arange(3, device=device).view(1, 1, 1, 3).float()
+        sig = 0.45 + 0.25 * torch.sin(3.1 * x + ph) * torch.cos(2.3 * y + ph * 0.7) + 0.15 * (x * (c + 1) / 3 + y * 0.5) \
+            + 0.05 * torch.sin(40 * x + 31 * y + ph * 1.3)
+        out = torch.empty((n, height, width, 3), device=device, dtype=torch.int32)
+        for i in range(n):      # grain per frame (sigma = 1/64 of full scale: the low ~10 bits are noise, like scanned film)
+            grain = torch.randn((height, width, 3), generator=g, device=device) / 64.0
+            out[i] = torch.clamp((sig[i] + grain) * maxv * 0.8, 0, maxv).to(torch.int32)
+        v = out
+    hi = (v >> 8).to(torch.uint8)
+    lo = (v & 0xFF).to(torch.uint8)
+    return torch.stack((hi, lo), dim=-1).reshape(n, height * width * 6).contiguous()
+
+
+def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int, frames_done_per_thread: int = 1):
+    """The oracle (scalar C restatement, kind 'port') on the host cores: one frame per thread, all cores."""
+    import oracle_binding as ob
+    from rawcooked_amd import synth
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    p = ob.Params(width, height, synth.PIX_RGB16_BE, 8, 8, 1, 1)
+    ob.lib()
+    out = [None] * cores
+
+    def work(i):
+        for _ in range(frames_done_per_thread):
+            out[i] = len(ob.encode_payload(p, payload_host, line_bytes))
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    nfr = cores * frames_done_per_thread
+    return {"value": round(nfr / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{nfr} frames of the same {width}x{height} RGB16 workload, one frame per thread, oracle/ffv1_oracle.c (scalar C, not FFmpeg)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "48")), help="frames in flight per GPU per step")
+    ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
+    ap.add_argument("--width", type=int, default=W4K)
+    ap.add_argument("--height", type=int, default=H4K)
+    ap.add_argument("--slices", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from rawcooked_amd import api, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    width, height, F = args.width, args.height, args.batch
+    pixfmt = synth.PIX_RGB16_BE
+    line_bytes = width * 6
+    nh, nv = api.slices_to_grid(args.slices)
+    frames = make_frames(torch, F, width, height, args.kind, rank, dev)
+    enc = api.Ffv1Encoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=F, device=local_rank)
+    stride = (enc.max_packet + 255) & ~255
+    d_packets = torch.empty(F * stride, dtype=torch.uint8, device=dev)
+    d_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
+    ptrs = [frames[i].data_ptr() for i in range(F)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(max(0, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    # per-kernel device time of one (untimed) step, HIP events recorded on the launch stream
+    ktimes = enc.kernel_times()
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    ksum = {k: 0.0 for k in ktimes}
+    kt = enc.kernel_times()          # events of the last timed step
+    for k in kt:
+        ksum[k] = kt[k]
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    sizes = d_sizes.cpu().tolist()
+    decisions, _ = enc.stats()
+    total_frames = world * F * args.steps
+    fps = total_frames / dt
+    payload_bytes = line_bytes * height
+    packet_avg = sum(sizes) / len(sizes)
+
+    verified = None
+    if rank == 0 and not args.no_verify:
+        # parity spot check outside the timed region: packet 0 of the last step == the oracle's bytes and decodes to the source
+        import oracle_binding as ob
+        p = ob.Params(width, height, pixfmt, nh, nv, 1, 1)
+        pk = bytes(d_packets[:sizes[0]].cpu().numpy())
+        src = bytes(frames[0].cpu().numpy())
+        verified = ob.decode_payload(p, pk, line_bytes) == src
+        if not verified:
+            print("bench: GPU packet does not decode to the source payload", file=sys.stderr)
+            sys.exit(2)
+
+    if rank == 0:
+        dom = max(kt, key=lambda k: kt[k]) if kt else None
+        alg_bytes_launch = F * (payload_bytes + packet_avg)
+        roof = None
+        if dom:
+            achieved = alg_bytes_launch / (kt[dom] * 1e-3) / 1e9
+            traffic = None
+            tj = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tj):
+                try:
+                    traffic = json.load(open(tj)).get(dom, {}).get(str(F))
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(alg_bytes_launch), "launch_ms": round(kt[dom], 3),
+                    "kernel_ms": {k: round(v, 3) for k, v in kt.items()}}
+        result = {
+            "metric": "4K-DCI 16-bit DPX->FFV1 frames/sec", "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": f"{width}x{height} RGB 16-bit BE DPX payload -> FFV1 v3 intra, slices={args.slices} ({nh}x{nv}), "
+                                   f"coder=1 context=1 slicecrc=1, content={args.kind}",
+                       "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective",
+                       "packet_bytes_avg": int(packet_avg), "compression_ratio": round(packet_avg / payload_bytes, 4),
+                       "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(bytes(frames[0].cpu().numpy()), line_bytes, width, height)
+        print(json.dumps(result))
+    enc.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -304,21 +304,21 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
                 // symbol binarisation, inverse of rangecoder::s (FFV1_RangeCoder.cpp:135-305)
                 uint32_t j = 0;
                 if (a == 0) {
-                    const uint32_t st = sl[0]; op[0] = uint16_t(st | 0x100); sl[0] = trans[256 + st];
+                    const uint32_t st = sl[0]; op[0] = uint16_t(st); sl[0] = trans[256 + st];
                 } else {
-                    { const uint32_t st = sl[0]; op[j++] = uint16_t(st); sl[0] = trans[st]; }
+                    { const uint32_t st = sl[0]; op[j++] = uint16_t(0xFF00u | (256 - st)); sl[0] = trans[st]; }
                     for (int t = 0; t < e; t++) {
                         const int k = 1 + (t < 9 ? t : 9);
-                        const uint32_t st = sl[k]; op[j++] = uint16_t(st | 0x100); sl[k] = trans[256 + st];
+                        const uint32_t st = sl[k]; op[j++] = uint16_t(st); sl[k] = trans[256 + st];
                     }
-                    { const int k = 1 + (e < 9 ? e : 9); const uint32_t st = sl[k]; op[j++] = uint16_t(st); sl[k] = trans[st]; }
+                    { const int k = 1 + (e < 9 ? e : 9); const uint32_t st = sl[k]; op[j++] = uint16_t(0xFF00u | (256 - st)); sl[k] = trans[st]; }
                     for (int t = e - 1; t >= 0; t--) {
                         const int k = 22 + (t < 9 ? t : 9);
                         const uint32_t b = (a >> t) & 1;
-                        const uint32_t st = sl[k]; op[j++] = uint16_t(st | (b << 8)); sl[k] = trans[b * 256 + st];
+                        const uint32_t st = sl[k]; op[j++] = uint16_t(b ? st : (0xFF00u | (256 - st))); sl[k] = trans[b * 256 + st];
                     }
                     { const int k = 11 + (e < 10 ? e : 10); const uint32_t b = d < 0;
-                      const uint32_t st = sl[k]; op[j++] = uint16_t(st | (b << 8)); sl[k] = trans[b * 256 + st]; }
+                      const uint32_t st = sl[k]; op[j++] = uint16_t(b ? st : (0xFF00u | (256 - st))); sl[k] = trans[b * 256 + st]; }
                 }
             }
             done |= __ballot(ready);
@@ -336,62 +336,116 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         flush_full();      // contains the workgroup-scope fences that order the state write-back before the next gather
     }
     // end-of-slice bit (state 129, FFV1_Slice.cpp:336-340), then pad the last piece
-    if (lane == 0) stage[stage_count] = 129;
+    if (lane == 0) stage[stage_count] = uint16_t(0xFF00u | (256 - 129));     // state 129, bit 0
     stage_count += 1;
     __syncthreads();
     const uint32_t padded = (stage_count + kPieceEntries - 1) / kPieceEntries * kPieceEntries;
-    for (uint32_t i = stage_count + lane; i < padded; i += 64) stage[i] = 128;
+    for (uint32_t i = stage_count + lane; i < padded; i += 64) stage[i] = 0x0080;
     stage_count = padded;
     flush_full();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // K4: range coder, one LANE per slice (chain).  The 64 chains of a wavefront read the same piece index of their
-// interleaved streams each iteration and run the low/range recurrence of RFC 9043 3.8.1 in lock-step:
-//     r1 = range*state >> 8;  bit ? (low += range - r1, range = r1) : (range -= r1);  renormalise by bytes.
-// `low` is kept as a 64-bit big number (16 live bits + up to 5 finished bytes + carry), so carries ripple by plain
-// integer addition; finished bytes leave through `pd`, a 4-byte second stage that absorbs late carries.  A carry out
-// of `pd` (probability ~2^-32 per flush) walks back through bytes already in HBM.
+// interleaved streams each iteration and run the low/range recurrence of RFC 9043 3.8.1 in lock-step.
+//
+// Decision entries arrive pre-digested by k_resolve as (t, c): t = bit ? state : 256 - state, c = bit ? 0 : 255, so
+//     new_range = (range * t + c) >> 8          [ == bit ? range*state>>8 : range - (range*state>>8) ]
+//     low      += bit ? range - new_range : 0
+// and the dependent chain per decision is mad -> shift -> (compare || shift) -> select.  A single wavefront issues
+// in order, so the length of that chain -- not the instruction count -- sets the time per decision; everything else
+// (low, byte bookkeeping) is independent work that fills the gaps.  There is no branch in the steady state:
+//   * `low` is a 64-bit big number: 16 live bits, up to five finished bytes above them, carry above those; carries
+//     ripple by plain integer addition;
+//   * every second decision a predicated flush moves four finished bytes to `pd`, a one-dword second stage that
+//     absorbs late carries, and parks the previous `pd` in LDS;
+//   * parked dwords leave for HBM at the next piece boundary, before the next prefetch is issued, so the loads the
+//     loop waits on are always younger than every store;
+//   * a carry out of `pd` (probability ~2^-32 per flush) is flagged per parked dword and handed to k_footer as an
+//     event, which ripples it through the bytes already in HBM.
 // ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kMaxCarryEvents = 4096;
+constexpr int kOutRows = 9;           // 32 decisions renormalise at most 32 times: 8 flushes (+1 carried in)
+
 struct rc_lane {
-    uint32_t range; unsigned long long low; int nb; uint32_t pd; bool have_pd; uint32_t pos; uint8_t* out; uint32_t cap; bool overflow;
+    uint32_t range; unsigned long long low; uint32_t nb; uint32_t pd;
+    uint32_t ocnt, ovf;               // dwords parked during this piece, and which of them overflowed
+    uint32_t* obuf;                   // LDS [kOutRows + 1][64], this lane's column; the last row is a dump for non-flushes
+    int pos; uint8_t* out; int cap; uint32_t chain;
 };
 
-__device__ __forceinline__ void rc_carry_into_memory(rc_lane& r)
+__device__ __forceinline__ void rc_step(rc_lane& r, uint32_t t, uint32_t c)
 {
-    // pd wrapped from 0xFFFFFFFF: propagate +1 into the bytes already stored
-    uint32_t p = r.pos;
-    while (p) { p--; const uint8_t b = uint8_t(r.out[p] + 1); r.out[p] = b; if (b) break; }
+    const uint32_t nr = (__umul24(r.range, t) + c) >> 8;
+    const uint32_t inc = (r.range - nr) & uint32_t(int32_t(c - 1) >> 8);      // c == 0 (bit 1): all ones
+    const bool need = nr < 0x100;
+    r.range = need ? nr << 8 : nr;
+    unsigned long long low = r.low + inc;
+    r.low = need ? low << 8 : low;
+    r.nb += need ? 1u : 0u;
 }
 
-__device__ __forceinline__ void rc_store_pd(rc_lane& r, uint32_t carry)
+// Predicated flush: when >= 4 finished bytes are pending, the four oldest move to pd and the old pd is parked.
+__device__ __forceinline__ void rc_check(rc_lane& r)
 {
-    if (!r.have_pd) return;
-    if (carry) { r.pd += carry; if (r.pd < carry) rc_carry_into_memory(r); }
-    if (r.pos + 4 <= r.cap) *reinterpret_cast<uint32_t*>(r.out + r.pos) = __builtin_bswap32(r.pd);
-    else r.overflow = true;
-    r.pos += 4;
+    const bool f = r.nb >= 4;
+    const uint32_t k8 = (r.nb - 4) * 8;                       // 0 or 8 when f
+    const uint32_t hi = uint32_t(r.low >> 32), lo = uint32_t(r.low);
+    const uint32_t carry = hi >> ((16 + k8) & 31);            // bit 16+8nb of low = bit 8nb-16 of hi
+    const uint32_t four = uint32_t(r.low >> ((16 + k8) & 63));
+    const uint32_t npd = r.pd + carry;
+    const uint32_t ov = (npd < carry) ? 1u : 0u;
+    r.obuf[(f ? r.ocnt : uint32_t(kOutRows)) * 64] = __builtin_bswap32(npd);
+    r.ovf |= f ? ov << r.ocnt : 0u;
+    r.ocnt += f ? 1u : 0u;
+    r.pd = f ? four : r.pd;
+    const uint32_t keep = lo & ((0x10000u << k8) - 1);
+    r.low = f ? (unsigned long long)keep : r.low;
+    r.nb = f ? r.nb - 4 : r.nb;
 }
 
-__device__ __forceinline__ void rc_flush4(rc_lane& r)
+__device__ __forceinline__ void rc_drain(rc_lane& r, uint32_t* ev_count, uint2* ev)
 {
-    // nb == 5: bits [16,56) hold five finished bytes, bit 56.. a pending carry
-    rc_store_pd(r, uint32_t(r.low >> 56));
-    r.pd = uint32_t(r.low >> 24);
-    r.have_pd = true;
-    r.low &= 0xFFFFFFull;
-    r.nb = 1;
+    if (r.ovf) {                                              // ~never: pd wrapped, +1 belongs to the bytes below that dword
+        for (uint32_t k = 0; k < r.ocnt; k++)
+            if ((r.ovf >> k) & 1) {
+                const uint32_t slot = atomicAdd(ev_count, 1u);
+                if (slot < kMaxCarryEvents) ev[slot] = make_uint2(r.chain, uint32_t(r.pos + 4 * int(k)));
+            }
+        r.ovf = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kOutRows; k++) {
+        if (uint32_t(k) < r.ocnt) {
+            const int at = r.pos + 4 <= r.cap ? r.pos : r.cap - 4;     // r.pos == -4 the first time: lands in the slack in front
+            *reinterpret_cast<uint32_t*>(r.out + at) = r.obuf[k * 64];
+            r.pos += 4;
+        }
+    }
+    r.ocnt = 0;
 }
 
-__device__ __forceinline__ void rc_step(rc_lane& r, uint32_t state, uint32_t bit)
+__device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32_t cnt)
 {
-    const uint32_t r1 = (r.range * state) >> 8;
-    const uint32_t rr = r.range - r1;
-    r.low += bit ? rr : 0u;
-    r.range = bit ? r1 : rr;
-    if (r.range < 0x100) {
-        r.range <<= 8; r.low <<= 8;
-        if (++r.nb == 5) rc_flush4(r);
+    const uint32_t w[16] = { q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
+                             q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w };
+    if (cnt == kPieceEntries) {
+#pragma unroll
+        for (int j = 0; j < kPieceEntries; j++) {
+            const uint32_t word = w[j >> 1];
+            rc_step(r, (j & 1) ? (word >> 16) & 0xFF : word & 0xFF, (j & 1) ? word >> 24 : (word >> 8) & 0xFF);
+            if (j & 1) rc_check(r);
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t j = 0; j < cnt; j++) {      // last (partial) piece only: pick dword j/2 without indexing registers dynamically
+            uint32_t ww = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) ww = (j >> 1) == uint32_t(k) ? w[k] : ww;
+            const uint32_t ent = (ww >> (16 * (j & 1))) & 0xFFFF;
+            rc_step(r, ent & 0xFF, ent >> 8);
+            rc_check(r);
+        }
     }
 }
 
@@ -400,8 +454,9 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
                                                   const unsigned long long* __restrict__ group_off,
                                                   const uint8_t* __restrict__ stream, uint8_t* __restrict__ cbuf,
                                                   unsigned long long cbuf_frame_stride, uint32_t nchains,
-                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ err)
+                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ err, uint2* __restrict__ events)
 {
+    __shared__ uint32_t obuf[(kOutRows + 1) * 64];
     const int lane = threadIdx.x;
     const uint32_t chain = blockIdx.x * 64 + lane;
     const bool active = chain < nchains;
@@ -413,44 +468,51 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
     const uint4* src = reinterpret_cast<const uint4*>(stream + group_off[blockIdx.x]) + lane * 4;
 
     rc_lane r;
-    r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.have_pd = false; r.pos = 0; r.overflow = false;
+    r.obuf = obuf + lane; r.ocnt = 0; r.ovf = 0;
+    r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.pos = -4; r.chain = cc;
     r.out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
-    r.cap = G.cbuf_cap;
+    r.cap = int(G.cbuf_cap);
 
     const unsigned long long npieces = (n + kPieceEntries - 1) / kPieceEntries;
     unsigned long long maxp = npieces;
     for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_xor(maxp, o); maxp = t > maxp ? t : maxp; }
 
-    for (unsigned long long pc = 0; pc < maxp; pc++) {
-        if (pc < npieces) {
-            const uint4* p = src + pc * (kGroupPieceBytes / 16);
-            const uint4 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];
-            const uint32_t w[16] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w };
-            const unsigned long long left = n - pc * kPieceEntries;
-            const uint32_t cnt = left < kPieceEntries ? uint32_t(left) : kPieceEntries;
+    uint4 cur[4], nxt[4];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < kPieceEntries; j++) {
-                if (uint32_t(j) < cnt) {
-                    const uint32_t ent = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFF;
-                    rc_step(r, ent & 0xFF, (ent >> 8) & 1);
-                }
-            }
+    for (int k = 0; k < 4; k++) cur[k] = npieces ? src[k] : zero4;
+    for (unsigned long long pc = 0; pc < maxp; pc++) {
+        rc_drain(r, err + 1, events);
+        const bool more = pc + 1 < npieces;
+        const uint4* p = src + (pc + 1) * (kGroupPieceBytes / 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) nxt[k] = more ? p[k] : zero4;      // prefetch: in flight while this piece is coded
+        if (pc < npieces) {
+            const unsigned long long left = n - pc * kPieceEntries;
+            rc_piece(r, cur, left < kPieceEntries ? uint32_t(left) : uint32_t(kPieceEntries));
         }
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
+    rc_drain(r, err + 1, events);
     if (active) {
         // terminate (the state-129 end bit is already the last decision): two forced renormalisations; the last
         // latched byte is not emitted -- the decoder reads bytes past the end as zero (FFV1_RangeCoder.cpp:79-85).
-        r.low += 0xFF;
-        r.low <<= 8; if (++r.nb == 5) rc_flush4(r);
-        r.low <<= 8; ++r.nb;
-        const int top = 16 + 8 * r.nb;
-        rc_store_pd(r, uint32_t(r.low >> top));
-        for (int t = r.nb - 1; t >= 1; t--) {
-            if (r.pos < r.cap) r.out[r.pos] = uint8_t(r.low >> (16 + 8 * t)); else r.overflow = true;
+        r.low += 0xFF;                         // nb <= 3 here
+        r.low <<= 8; r.nb++;
+        r.low <<= 8; r.nb++;                   // nb <= 5: 16 + 40 + carry bits still fit
+        const uint32_t carry = uint32_t(r.low >> (16 + 8 * r.nb));
+        const uint32_t npd = r.pd + carry;
+        if (npd < carry) { const uint32_t slot = atomicAdd(err + 1, 1u); if (slot < kMaxCarryEvents) events[slot] = make_uint2(r.chain, uint32_t(r.pos)); }
+        bool overflow = false;
+        if (r.pos + 4 <= r.cap) *reinterpret_cast<uint32_t*>(r.out + r.pos) = __builtin_bswap32(npd); else overflow = true;
+        r.pos += 4;
+        for (int t = int(r.nb) - 1; t >= 1; t--) {
+            if (r.pos < r.cap) r.out[r.pos] = uint8_t(r.low >> (16 + 8 * t)); else overflow = true;
             r.pos++;
         }
-        out_len[chain] = r.pos;
-        if (r.overflow) atomicOr(err, 1u);
+        out_len[chain] = uint32_t(r.pos);
+        if (overflow) atomicOr(err, 1u);
     }
 }
 
@@ -482,7 +544,7 @@ __device__ uint32_t gf_xpow8(unsigned long long nbytes)      // x^(8*nbytes) mod
 __global__ __launch_bounds__(64) void k_footer(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                uint8_t* __restrict__ cbuf, unsigned long long cbuf_frame_stride,
                                                const uint32_t* __restrict__ out_len, uint32_t* __restrict__ tot_len,
-                                               uint32_t* __restrict__ err)
+                                               uint32_t* __restrict__ err, const uint2* __restrict__ events)
 {
     __shared__ uint32_t T[256];
     const int lane = threadIdx.x;
@@ -499,6 +561,11 @@ __global__ __launch_bounds__(64) void k_footer(const enc_const* __restrict__ C, 
     const uint32_t tail = C->ec ? 8 : 3;
     if (len + tail > G.cbuf_cap || len > 0xFFFFFF) { if (lane == 0) { atomicOr(err, 2u); tot_len[chain] = 0; } return; }
     if (lane == 0) {
+        // carries that left k_rangecode's second stage after the bytes below them were already stored
+        const uint32_t nev = err[1];
+        if (nev > kMaxCarryEvents) atomicOr(err, 4u);
+        for (uint32_t i = 0; i < nev && i < kMaxCarryEvents; i++)
+            if (events[i].x == chain) { uint32_t p = events[i].y; while (p) { p--; const uint8_t b = uint8_t(out[p] + 1); out[p] = b; if (b) break; } }
         out[len] = uint8_t(len >> 16); out[len + 1] = uint8_t(len >> 8); out[len + 2] = uint8_t(len);
         if (C->ec) out[len + 3] = 0;                      // error_status
     }
@@ -586,7 +653,7 @@ struct rcgpu_ffv1 {
     unsigned long long* d_ndec = nullptr; unsigned long long* d_group_off = nullptr;
     uint8_t* d_stream = nullptr; size_t stream_cap = 0;
     uint8_t* d_cbuf = nullptr; uint32_t* d_out_len = nullptr; uint32_t* d_tot_len = nullptr;
-    unsigned long long* d_slice_dst = nullptr; uint32_t* d_err = nullptr;
+    unsigned long long* d_slice_dst = nullptr; uint32_t* d_err = nullptr; uint2* d_events = nullptr;
     // host staging for the convenience path
     uint8_t* h_pinned_in = nullptr; uint8_t* d_in = nullptr; uint8_t* d_packets = nullptr; unsigned long long* d_psizes = nullptr;
     uint8_t* h_pinned_out = nullptr; unsigned long long* h_psizes = nullptr;
@@ -616,7 +683,7 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     void* bufs[] = { e->d_const, e->d_geom, e->d_hdr, e->d_frame_ptrs, e->d_planes, e->d_sym, e->d_states, e->d_ndec, e->d_group_off,
-                     e->d_stream, e->d_cbuf, e->d_out_len, e->d_tot_len, e->d_slice_dst, e->d_err, e->d_in, e->d_packets, e->d_psizes };
+                     e->d_stream, e->d_cbuf, e->d_out_len, e->d_tot_len, e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (e->h_pinned_in) (void)hipHostFree(e->h_pinned_in);
     if (e->h_pinned_out) (void)hipHostFree(e->h_pinned_out);
@@ -687,10 +754,11 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             g.sym_off = sym_off; g.nsamp = g.w * g.h * c.planes; sym_off += g.nsamp;
             const auto hd = ffv1::slice_header_decisions(e->sp, sx, sy, e->geom.empty());
             g.hdr_off = uint32_t(hdr.size()); g.hdr_n = uint32_t(hd.size());
-            hdr.insert(hdr.end(), hd.begin(), hd.end());
+            for (uint16_t d16 : hd) hdr.push_back((d16 & 0x100) ? uint16_t(d16 & 0xFF) : uint16_t(0xFF00u | (256 - (d16 & 0xFF))));   // (state, bit) -> (t, c)
             // worst realistic size: twice the raw payload of the slice, plus header/footer room
             size_t cap = (size_t(g.w) * g.h * d.bytes_pp * 2 + 4096 + 15) & ~size_t(15);
             if (cap > 0xFFFFFF + 64) cap = 0xFFFFFF + 64;          // slice size field is 24 bit
+            cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here
             g.cbuf_off_lo = uint32_t(cb); g.cbuf_off_hi = uint32_t(uint64_t(cb) >> 32); g.cbuf_cap = uint32_t(cap);
             cb += cap;
             e->geom.push_back(g);
@@ -709,7 +777,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     DM(e->d_states, nchains * e->nkeys * 32);
     DM(e->d_ndec, nchains * 8); DM(e->d_group_off, ngroups * 8);
     DM(e->d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
-    DM(e->d_out_len, nchains * 4); DM(e->d_tot_len, nchains * 4); DM(e->d_slice_dst, nchains * 8); DM(e->d_err, 16);
+    DM(e->d_out_len, nchains * 4); DM(e->d_tot_len, nchains * 4); DM(e->d_slice_dst, nchains * 8); DM(e->d_err, 16); DM(e->d_events, sizeof(uint2) * kMaxCarryEvents);
 #undef DM
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&e->h_ndec_pinned), nchains * 8);
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&e->h_frame_ptrs), sizeof(void*) * F);
@@ -793,11 +861,11 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(hipEventRecord(e->ev[5], st));
     HIP_TRY(hipEventRecord(e->ev[6], st));
     hipLaunchKernelGGL(k_rangecode, dim3(ngroups), dim3(64), 0, st, e->d_const, e->d_geom, e->d_ndec, e->d_group_off, e->d_stream, e->d_cbuf,
-                       (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err);
+                       (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events);
     HIP_TRY(hipEventRecord(e->ev[7], st));
     HIP_TRY(hipEventRecord(e->ev[8], st));
     hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(64), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
-                       e->d_out_len, e->d_tot_len, e->d_err);
+                       e->d_out_len, e->d_tot_len, e->d_err, e->d_events);
     HIP_TRY(hipEventRecord(e->ev[9], st));
     HIP_TRY(hipEventRecord(e->ev[10], st));
     hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, st, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes));
@@ -898,7 +966,10 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
         std::vector<uint8_t> tmp(pieces * kPieceBytes);
         const uint8_t* base = e->d_stream + e->h_group_off_pinned[chain >> 6] + (chain & 63) * kPieceBytes;
         if (hipMemcpy2D(tmp.data(), kPieceBytes, base, kGroupPieceBytes, kPieceBytes, pieces, hipMemcpyDeviceToHost) != hipSuccess) return -3;
-        memcpy(dst, tmp.data(), nd * 2);
+        const uint16_t* ent = reinterpret_cast<const uint16_t*>(tmp.data());
+        uint16_t* o = static_cast<uint16_t*>(dst);
+        for (unsigned long long i = 0; i < nd; i++)          // (t, c) -> state | bit << 8, the oracle's trace form
+            o[i] = (ent[i] >> 8) ? uint16_t(256 - (ent[i] & 0xFF)) : uint16_t((ent[i] & 0xFF) | 0x100);
         return (long long)(nd * 2);
     }
     case 4: {
