@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "48")), help="frames in flight per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "96")), help="frames in flight per GPU per step")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
@@ -181,7 +181,8 @@ def main():
             tj = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tj):
                 try:
-                    traffic = json.load(open(tj)).get(dom, {}).get(str(F))
+                    per_frame = json.load(open(tj)).get(dom, {}).get("per_frame_bytes")
+                    traffic = int(per_frame * F) if per_frame else None      # PMC-measured HBM bytes per launch (scales with the batch)
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
