@@ -70,3 +70,44 @@ def trace_slice(p: Params, planes: np.ndarray, sx: int, sy: int, nsamp: int):
                                 C.byref(ndec), raw, C.c_size_t(rcap))
     assert n > 0
     return sym, dec[:ndec.value].copy(), raw.raw[:n]
+
+
+class FlacParams(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("channels", "sample_rate", "bits_per_sample", "block_size", "max_lpc_order")]
+
+
+def flac_encode(ch, rate, bits, pcm: bytes, block_size=0, max_order=8):
+    """-> (list of frames, CodecPrivate) from the scalar oracle."""
+    L = lib()
+    L.flaco_encode.restype = C.c_long
+    L.flaco_codec_private.restype = C.c_size_t
+    L.flaco_default_block_size.restype = C.c_uint32
+    p = FlacParams(ch, rate, bits, block_size, max_order)
+    n = len(pcm) // (ch * bits // 8)
+    out = C.create_string_buffer(len(pcm) * 2 + 65536)
+    fs = (C.c_uint32 * (n // 16 + 16))()
+    nf = L.flaco_encode(C.byref(p), pcm, C.c_uint64(len(pcm)), out, C.c_size_t(len(out)), fs, C.c_size_t(len(fs)))
+    assert nf >= 0, nf
+    frames, off = [], 0
+    for i in range(nf):
+        frames.append(out.raw[off:off + fs[i]])
+        off += fs[i]
+    md5 = C.create_string_buffer(16)
+    spcm = pcm[:n * ch * (bits // 8)]
+    if bits == 8:
+        spcm = (np.frombuffer(spcm, dtype=np.uint8).astype(np.int16) - 128).astype(np.int8).tobytes()
+    L.flaco_md5(spcm, C.c_size_t(len(spcm)), md5)
+    cp = C.create_string_buffer(64)
+    sizes = [fs[i] for i in range(nf)] or [0]
+    k = L.flaco_codec_private(C.byref(p), C.c_uint64(n), min(sizes), max(sizes), md5, cp)
+    return frames, cp.raw[:k]
+
+
+def flac_decode(ch, rate, bits, data: bytes, pcm_len: int) -> bytes:
+    L = lib()
+    L.flaco_decode.restype = C.c_longlong
+    p = FlacParams(ch, rate, bits, 0, 8)
+    out = C.create_string_buffer(pcm_len + 64)
+    r = L.flaco_decode(C.byref(p), data, C.c_size_t(len(data)), out, C.c_size_t(len(out)))
+    assert r >= 0, f"oracle FLAC decoder error {r}"
+    return out.raw[:r]
