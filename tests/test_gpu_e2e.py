@@ -1,0 +1,102 @@
+"""End to end on the GPU box, judged by the REAL reference: rawcooked (oracle/_ref) analyses the sources and prints the
+encoder command; our ffmpeg-argv shim (rcgpu-ffmpeg -> librcgpu.so -> MI355X) executes it; `rawcooked --check` must then
+rebuild every source file bit-exactly (this mirrors Project/GNU/CLI/test/test1.sh:22-67 and vulkan.sh:48-80 of the
+reference, with the encoder swapped)."""
+import os
+import shlex
+import shutil
+import subprocess
+
+import pytest
+
+from rawcooked_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+OK_LINE = "Reversibility was checked, no issue detected."      # test2.sh:37,69
+
+
+def make_package(work, w, h, pixfmt, nframes, kind, tiff=False, audio=None, start=0):
+    os.makedirs(os.path.join(work, "pkg", "img"))
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    for i in range(nframes):
+        comp = synth.components(w, h, nc, bits, kind, seed=7 * i + 1)
+        data = synth.tiff_file(comp, pixfmt, trailer=b"tail123") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i)
+        with open(os.path.join(work, "pkg", "img", "f_%06d.%s" % (start + i, "tif" if tiff else "dpx")), "wb") as f:
+            f.write(data)
+    if audio:
+        ch, abits, rate, n = audio
+        with open(os.path.join(work, "pkg", "snd.wav"), "wb") as f:
+            f.write(synth.wav_file(synth.pcm_samples(n, ch, abits, rate), abits, rate))
+
+
+def run(cmd, cwd):
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+CASES = [
+    dict(w=64, h=48, pixfmt=synth.PIX_RGB16_BE, nframes=3, kind="film"),
+    dict(w=50, h=38, pixfmt=synth.PIX_RGB10_FILLEDA_BE, nframes=2, kind="film"),
+    dict(w=61, h=35, pixfmt=synth.PIX_RGB10_FILLEDA_LE, nframes=2, kind="noise"),
+    dict(w=40, h=30, pixfmt=synth.PIX_RGB16_LE, nframes=2, kind="film", tiff=True),
+    dict(w=48, h=32, pixfmt=synth.PIX_RGB8, nframes=2, kind="film"),
+    dict(w=34, h=17, pixfmt=synth.PIX_RGB12_FILLEDA_BE, nframes=2, kind="film"),   # even width: the reference itself mis-sizes odd-width 12-bit FilledA (DPX.cpp:470-474 vs RawFrame.cpp:109)
+    dict(w=46, h=21, pixfmt=synth.PIX_RGB12_FILLEDA_LE, nframes=2, kind="noise"),
+    dict(w=32, h=24, pixfmt=synth.PIX_RGBA16_BE, nframes=2, kind="film"),
+    dict(w=40, h=24, pixfmt=synth.PIX_Y16_BE, nframes=2, kind="film"),
+    dict(w=40, h=24, pixfmt=synth.PIX_Y8, nframes=2, kind="film"),
+    dict(w=64, h=48, pixfmt=synth.PIX_RGB16_BE, nframes=4, kind="film", audio=(6, 24, 48000, 9000)),   # config 3 shape
+    dict(w=2048, h=1556, pixfmt=synth.PIX_RGB10_FILLEDA_BE, nframes=2, kind="film"),                    # config 1 shape
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-%d%s%s" % (c["w"], c["h"], c["pixfmt"], "-tiff" if c.get("tiff") else "", "-wav" if c.get("audio") else ""))
+def test_reference_accepts_gpu_mkv(built, refbin, tmp_path, case):
+    work = str(tmp_path)
+    make_package(work, case["w"], case["h"], case["pixfmt"], case["nframes"], case["kind"], case.get("tiff", False), case.get("audio"))
+    # 1. the reference analyses the package, writes the reversibility data and prints the ffmpeg command (-d)
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    argv = shlex.split(r.stdout.strip())
+    assert argv[0] == "ffmpeg"
+    # 2. our shim executes exactly that command line on the GPU
+    r = run([SHIM] + argv[1:], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert os.path.exists(os.path.join(work, "pkg.mkv"))
+    # 3. the reference decodes the MKV and compares every rebuilt file with the hashes it stored
+    r = run([refbin, "--check", "pkg.mkv"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+    # 4. full decode, byte compare
+    r = run([refbin, "-y", "pkg.mkv"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for dirpath, _, files in os.walk(os.path.join(work, "pkg")):
+        for fn in files:
+            src = os.path.join(dirpath, fn)
+            dst = os.path.join(work, "pkg.mkv.RAWcooked", os.path.relpath(src, work))
+            assert open(src, "rb").read() == open(dst, "rb").read(), fn
+
+
+def test_unmodified_rawcooked_drives_the_shim(built, refbin, tmp_path):
+    """rawcooked --bin-name <shim>: the reference itself launches our encoder through system() (Output.cpp:356)
+    and then runs its own post-encode check."""
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB16_BE, 3, "film", audio=(2, 16, 48000, 6000))
+    r = run([refbin, "--bin-name", SHIM, "--check", "--hash", "-y", "pkg"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    assert os.path.exists(os.path.join(work, "pkg.mkv"))
+
+
+def test_flipped_byte_is_detected(built, refbin, tmp_path):
+    """Negative control (paddingbits.sh / check.sh style): corrupt one slice byte -> the reference must object."""
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB16_BE, 2, "film")
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    argv = shlex.split(r.stdout.strip())
+    assert run([SHIM] + argv[1:], work).returncode == 0
+    p = os.path.join(work, "pkg.mkv")
+    data = bytearray(open(p, "rb").read())
+    data[len(data) - 2000] ^= 0x40
+    open(p, "wb").write(data)
+    r = run([refbin, "--check", "pkg.mkv"], work)
+    assert r.returncode != 0 or "Error" in (r.stdout + r.stderr) or OK_LINE not in r.stdout
