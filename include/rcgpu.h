@@ -101,6 +101,9 @@ int rcgpu_dpx_probe (const uint8_t* file, size_t size, rcgpu_image_info* out);
 int rcgpu_tiff_probe(const uint8_t* file, size_t size, rcgpu_image_info* out);
 int rcgpu_wav_probe (const uint8_t* file, size_t size, rcgpu_audio_info* out);
 
+/* slice_x*slice_y the reference computes for a DPX/TIFF picture (DPX.cpp:428-458, TIFF.cpp:657-672): pixels_per_block > 1
+ * models the flavors whose slices must start on a block boundary (e.g. 3 for DPX RGBA 10-bit FilledA); 0 = unsupported. */
+uint32_t rcgpu_reference_slices(uint32_t width, uint32_t height, uint32_t bitdepth, uint32_t pixels_per_block);
 /* -slices N -> h x v the way FFmpeg's ffv1 encoder factorises it (accepted set == test/slices.sh:12). 0 ok. */
 int rcgpu_slices_to_grid(uint32_t n, uint32_t* num_h, uint32_t* num_v);
 

@@ -68,6 +68,7 @@ SYMBOLS = {
     "rcgpu_dpx_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
     "rcgpu_tiff_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
     "rcgpu_wav_probe": (C.c_int, [_U8P, _SZ, C.POINTER(AudioInfo)]),
+    "rcgpu_reference_slices": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rcgpu_slices_to_grid": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rcgpu_ffv1_create": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP)]),
     "rcgpu_ffv1_destroy": (None, [_VP]),

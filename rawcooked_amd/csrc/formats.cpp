@@ -273,6 +273,14 @@ extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* 
     return fail(15, "wav: no data chunk");
 }
 
+extern "C" uint32_t rcgpu_reference_slices(uint32_t width, uint32_t height, uint32_t bitdepth, uint32_t pixels_per_block)
+{
+    uint32_t sx = reference_slice_x(width, height, bitdepth);
+    if (pixels_per_block > 1)                       // DPX.cpp:443-456: no slice may start inside a block
+        for (; sx; sx--) if (width % (sx * pixels_per_block) == 0) break;
+    return sx * sx;
+}
+
 extern "C" int rcgpu_slices_to_grid(uint32_t n, uint32_t* num_h, uint32_t* num_v)
 {
     // FFmpeg's ffv1 encoder maps -slices N to the first (v in [2,31], h in [v,2v-1]) with h*v == N; the set of

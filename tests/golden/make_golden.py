@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/{vectors.json,*.bin}: small seeded inputs, the oracle's outputs, and the real reference's verdict.
+
+Run in the build container (needs oracle/_ref/rawcooked, i.e. /root/reference):  python tests/golden/make_golden.py
+Each FFV1 vector: payload (file layout bytes) -> packet(s) from oracle/ffv1_oracle.c; an MKV with those packets + the
+reference's own reversibility data is then checked by `rawcooked --check` and decoded by `rawcooked -y` (byte compare).
+Each FLAC vector: PCM -> frames from oracle/flac_oracle.c, checked the same way.
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_binding as ob          # noqa: E402
+from rawcooked_amd import api, synth  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref", "rawcooked")
+OK = "Reversibility was checked, no issue detected."
+
+FFV1 = [  # name, w, h, pixfmt, frames, kind, tiff
+    ("dpx_rgb16be_64x48", 64, 48, synth.PIX_RGB16_BE, 2, "film", False),
+    ("dpx_rgb10be_50x38", 50, 38, synth.PIX_RGB10_FILLEDA_BE, 2, "film", False),
+    ("dpx_rgb10le_61x35", 61, 35, synth.PIX_RGB10_FILLEDA_LE, 1, "noise", False),
+    ("dpx_rgb12be_34x17", 34, 17, synth.PIX_RGB12_FILLEDA_BE, 1, "film", False),
+    ("dpx_rgb8_48x32", 48, 32, synth.PIX_RGB8, 1, "film", False),
+    ("dpx_rgba16be_32x24", 32, 24, synth.PIX_RGBA16_BE, 1, "film", False),
+    ("dpx_y16be_40x24", 40, 24, synth.PIX_Y16_BE, 1, "noise", False),
+    ("dpx_y8_40x24", 40, 24, synth.PIX_Y8, 1, "film", False),
+    ("tiff_rgb16le_40x30", 40, 30, synth.PIX_RGB16_LE, 2, "film", True),
+    ("dpx_rgb16be_flat_96x64", 96, 64, synth.PIX_RGB16_BE, 1, "flat", False),
+]
+FLAC = [  # name, ch, bits, rate, samples, kind
+    ("wav_2ch16_48k", 2, 16, 48000, 10000, "music"),
+    ("wav_6ch24_48k", 6, 24, 48000, 6000, "music"),
+    ("wav_1ch8_44k", 1, 8, 44100, 5000, "music"),
+    ("wav_2ch24_noise", 2, 24, 96000, 9000, "noise"),
+]
+
+
+def run(cmd, cwd):
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
+
+
+def main():
+    vectors = {"ffv1": [], "flac": []}
+    for name, w, h, pixfmt, nframes, kind, tiff in FFV1:
+        work = tempfile.mkdtemp()
+        os.makedirs(work + "/seq")
+        bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+        files = []
+        for i in range(nframes):
+            comp = synth.components(w, h, nc, bits, kind, seed=31 * i + 5)
+            data = synth.tiff_file(comp, pixfmt, trailer=b"xyz") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i)
+            fn = work + "/seq/f_%06d.%s" % (i, "tif" if tiff else "dpx")
+            open(fn, "wb").write(data)
+            files.append(fn)
+        r = run([REF, "--hash", "--no-check-padding", "-d", "-y", "seq"], work)
+        assert r.returncode == 0, r.stderr
+        first = open(files[0], "rb").read()
+        info = api.tiff_probe(first) if tiff else api.dpx_probe(first)
+        slices = int(r.stdout.split("-slices ")[1].split()[0])
+        assert slices == info.slices
+        nh, nv = api.slices_to_grid(slices)
+        p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+        rec = ob.config_record(p)
+        mux = api.MkvMuxer(work + "/seq.mkv")
+        t = mux.add_video(rec, w, h, 24, 1)
+        mux.add_attachment("RAWcooked reversibility data", open(work + "/seq.rawcooked_reversibility_data", "rb").read())
+        mux.begin()
+        entry = {"name": name, "width": w, "height": h, "pixfmt": pixfmt, "num_h": nh, "num_v": nv, "line_bytes": info.line_bytes,
+                 "config_record": rec.hex(), "frames": []}
+        for i, fn in enumerate(files):
+            b = open(fn, "rb").read()
+            payload = b[info.data_offset:info.data_offset + info.data_size]
+            pkt = ob.encode_payload(p, payload, info.line_bytes)
+            mux.write_block(t, i * 1000000000 // 24, pkt)
+            open(os.path.join(HERE, f"ffv1_{name}_{i}.payload.bin"), "wb").write(payload)
+            open(os.path.join(HERE, f"ffv1_{name}_{i}.packet.bin"), "wb").write(pkt)
+            entry["frames"].append({"payload": f"ffv1_{name}_{i}.payload.bin", "packet": f"ffv1_{name}_{i}.packet.bin",
+                                    "payload_sha256": hashlib.sha256(payload).hexdigest(), "packet_sha256": hashlib.sha256(pkt).hexdigest()})
+        mux.close()
+        r = run([REF, "--check", "seq.mkv"], work)
+        ok = r.returncode == 0 and OK in r.stdout
+        r2 = run([REF, "-y", "seq.mkv"], work)
+        same = all(open(f, "rb").read() == open(work + "/seq.mkv.RAWcooked/seq/" + os.path.basename(f), "rb").read() for f in files)
+        entry["reference_check"] = bool(ok and r2.returncode == 0 and same)
+        assert entry["reference_check"], (name, r.stdout, r.stderr)
+        vectors["ffv1"].append(entry)
+        shutil.rmtree(work)
+        print("ffv1", name, "reference ok")
+    for name, ch, bits, rate, n, kind in FLAC:
+        work = tempfile.mkdtemp()
+        os.makedirs(work + "/aud")
+        wav = synth.wav_file(synth.pcm_samples(n, ch, bits, rate, kind), bits, rate)
+        open(work + "/aud/a.wav", "wb").write(wav)
+        info = api.wav_probe(wav)
+        pcm = wav[info.data_offset:info.data_offset + info.data_size]
+        frames, cp = ob.flac_encode(ch, rate, bits, pcm, 0, 8)
+        r = run([REF, "--hash", "-d", "-y", "aud"], work)
+        assert r.returncode == 0, r.stderr
+        mux = api.MkvMuxer(work + "/aud.mkv")
+        t = mux.add_audio(cp, ch, rate, bits)
+        mux.add_attachment("RAWcooked reversibility data", open(work + "/aud.rawcooked_reversibility_data", "rb").read())
+        mux.begin()
+        B = int.from_bytes(cp[8:10], "big")
+        for i, f in enumerate(frames):
+            mux.write_block(t, i * B * 1000000000 // rate, f)
+        mux.close()
+        r = run([REF, "--check", "aud.mkv"], work)
+        ok = r.returncode == 0 and OK in r.stdout
+        assert ok, (name, r.stdout, r.stderr)
+        open(os.path.join(HERE, f"flac_{name}.pcm.bin"), "wb").write(pcm)
+        open(os.path.join(HERE, f"flac_{name}.frames.bin"), "wb").write(b"".join(frames))
+        vectors["flac"].append({"name": name, "channels": ch, "bits": bits, "rate": rate, "pcm": f"flac_{name}.pcm.bin",
+                                "frames": f"flac_{name}.frames.bin", "frame_sizes": [len(f) for f in frames], "codec_private": cp.hex(),
+                                "frames_sha256": hashlib.sha256(b"".join(frames)).hexdigest(), "reference_check": True})
+        shutil.rmtree(work)
+        print("flac", name, "reference ok")
+    json.dump(vectors, open(os.path.join(HERE, "vectors.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

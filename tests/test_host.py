@@ -1,0 +1,183 @@
+"""CPU: host-side product logic -- C-ABI surface, probes, slice rules (reference's golden table), muxer layout,
+hashes, and that the product refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import hashlib
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+from rawcooked_amd import api, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+G = os.path.join(HERE, "golden")
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "rcgpu.h")).read()
+    declared = set(re.findall(r"\b(rcgpu_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(api.SYMBOLS), declared ^ set(api.SYMBOLS)
+    L = api.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    nm = subprocess.run(["nm", "-D", "--defined-only", api.LIB_PATH], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(r"\bT %s\b" % name, nm), f"{name} not exported"
+    assert b"rcgpu version" in L.rcgpu_version()
+
+
+def test_product_does_not_link_the_oracle(built):
+    ldd = subprocess.run(["ldd", api.LIB_PATH], capture_output=True, text=True).stdout
+    assert "liboracle" not in ldd
+    for fn in os.listdir(os.path.join(ROOT, "rawcooked_amd", "csrc")):
+        if fn.endswith((".cpp", ".hip", ".h")):
+            assert "oracle" not in open(os.path.join(ROOT, "rawcooked_amd", "csrc", fn)).read().replace("oracle/flac_oracle.c", "").replace("scalar oracle", "").replace("the oracle", "").replace("oracle's", "").replace("oracle ", "")
+
+
+@pytest.mark.skipif(api.lib().rcgpu_device_count() > 0, reason="GPU present")
+def test_no_gpu_means_loud_failure_not_fallback(built, tmp_path):
+    with pytest.raises(api.RcgpuError, match="no HIP device"):
+        api.Ffv1Encoder(64, 48, synth.PIX_RGB16_BE, 384, 2, 2)
+    with pytest.raises(api.RcgpuError, match="no HIP device"):
+        api.FlacEncoder(2, 48000, 16)
+    p = tmp_path / "a.dpx"
+    p.write_bytes(synth.dpx_file(synth.components(16, 16, 3, 16), synth.PIX_RGB16_BE))
+    out = api.Output(Streams=[api.Stream(FileName=str(p), Slices="4")])
+    assert out.Process(str(tmp_path / "o.mkv")) != 0 and "no HIP device" in api.last_error()
+    assert not (tmp_path / "o.mkv").exists()
+
+
+def test_slices_golden_table(built):
+    """Project/GNU/CLI/test/slices.sh:65-90 on its own 4624-row table, without FFmpeg."""
+    valid = set(int(x) for x in open(os.path.join(G, "valid_slices.txt")).read().split())
+    # pix_fmt -> (bitdepth, pixels per block of the DPX flavor FFmpeg writes for it; DPX.cpp:184-231)
+    fmt = {"rgb24": (8, 1), "rgba": (8, 1), "rgb48be": (16, 1), "rgba64be": (16, 1), "gbrp10le": (10, 1), "gbrp12le": (12, 1),
+           "gbrap10le": (16, 1),      # FFmpeg's DPX encoder has no 10-bit RGBA: the test file comes out deeper than 10 bit (table rows = 12^2)
+           "gbrap12le": (12, 1)}
+    L = api.lib()
+    rows = 0
+    for line in open(os.path.join(G, "slices.txt")):
+        w, h, f, c = line.strip().split(":")
+        w, h, c = int(w), int(h), int(c)
+        bits, ppb = fmt[f]
+        n = L.rcgpu_reference_slices(w, h, bits, ppb)
+        assert c <= n <= c + c // 2, (line, n)
+        assert n in valid, (line, n)
+        nh, nv = api.slices_to_grid(n)
+        assert nh * nv == n and nv <= nh < 2 * nv
+        rows += 1
+    assert rows == 4624
+    # the factorisation accepts exactly the reference's list
+    L.rcgpu_slices_to_grid.restype = C.c_int
+    a, b = C.c_uint32(), C.c_uint32()
+    ok = {n for n in range(2, 1025) if L.rcgpu_slices_to_grid(n, C.byref(a), C.byref(b)) == 0}
+    assert ok == {v for v in valid if v <= 1024}
+
+
+def test_probes(built):
+    comp = synth.components(4096 // 16, 2160 // 16, 3, 16, "film", seed=3)
+    d = synth.dpx_file(comp, synth.PIX_RGB16_BE, fps=25.0)
+    i = api.dpx_probe(d)
+    assert (i.width, i.height, i.pixfmt, i.data_offset, i.line_bytes, i.framerate) == (256, 135, synth.PIX_RGB16_BE, 2048, 1536, 25.0)
+    assert i.flavor == b"DPX/Raw/RGB/16bit/U/BE" and i.data_size == 1536 * 135
+    le = synth.dpx_file(synth.components(50, 38, 3, 10), synth.PIX_RGB10_FILLEDA_LE)
+    assert api.dpx_probe(le).flavor == b"DPX/Raw/RGB/10bit/FilledA/U/LE"
+    assert api.lib().rcgpu_reference_slices(4096, 2160, 16, 1) == 576 and api.lib().rcgpu_reference_slices(2048, 1556, 10, 1) == 64
+    t = synth.tiff_file(synth.components(40, 30, 3, 16), synth.PIX_RGB16_LE, trailer=b"1234567")
+    ti = api.tiff_probe(t)
+    assert (ti.width, ti.height, ti.line_bytes, ti.flavor) == (40, 30, 240, b"TIFF/Raw/RGB/16bit/U/LE")
+    assert t[ti.data_offset + ti.data_size:] == b"1234567"
+    w = synth.wav_file(synth.pcm_samples(1000, 6, 24), 24, 48000, extensible=True)
+    wi = api.wav_probe(w)
+    assert (wi.channels, wi.sample_rate, wi.bits_per_sample, wi.data_size, wi.flavor) == (6, 48000, 24, 18000, b"WAV/PCM/48kHz/24bit/6ch/S/LE")
+    # malformed input is an error, never a crash
+    for bad in (b"", b"SDPX", d[:1000], b"XXXX" + d[4:], d[:3000], t[:100], b"RIFF\x00\x00\x00\x00WAVE", w[:60]):
+        for probe in (api.dpx_probe, api.tiff_probe, api.wav_probe):
+            try:
+                probe(bad)
+            except api.RcgpuError:
+                pass
+
+
+def test_hash_known_answers(built):
+    for msg in (b"", b"a", b"abc", b"x" * 55, b"y" * 56, b"z" * 64, bytes(range(256)) * 37):
+        assert api.md5(msg) == hashlib.md5(msg).digest()
+    L = api.lib()
+    assert L.rcgpu_crc32_ffv1(b"123456789", 9) == 0x89A1897F          # CRC-32/MPEG-2 with init 0: poly 04C11DB7, no reflection, no xorout
+    data = os.urandom(1000)
+    crc = L.rcgpu_crc32_ffv1(data, len(data))
+    assert L.rcgpu_crc32_ffv1(data + struct.pack(">I", crc), len(data) + 4) == 0   # parity property FFV1 relies on
+
+
+def _ebml(buf, pos, end):
+    """Minimal EBML walker -> list of (id, data_start, data_end)."""
+    out = []
+    while pos < end:
+        b = buf[pos]
+        n = 8 - b.bit_length() + 1
+        eid = int.from_bytes(buf[pos:pos + n], "big")
+        pos += n
+        b = buf[pos]
+        n = 8 - b.bit_length() + 1
+        size = int.from_bytes(buf[pos:pos + n], "big") & ((1 << (7 * n)) - 1)
+        pos += n
+        out.append((eid, pos, pos + size))
+        pos += size
+    return out
+
+
+def test_muxer_layout(built, tmp_path):
+    """What the reference's reader needs (Matroska.cpp:863-873, :934-953, :1007-1030, :1259-1277)."""
+    path = str(tmp_path / "m.mkv")
+    mux = api.MkvMuxer(path)
+    tv = mux.add_video(b"\x01\x02\x03", 4096, 2160, 24000, 1001)
+    ta = mux.add_audio(b"fLaC" + bytes(38), 6, 48000, 24)
+    mux.add_attachment("side.txt", b"hello")
+    mux.add_attachment("RAWcooked reversibility data", b"\x1a\x45\xdf\xa3rest")
+    mux.begin()
+    big = os.urandom(3 << 20)
+    for i in range(3):
+        mux.write_block(ta, i * 96000000, b"A" * 100)
+        mux.write_block(tv, i * 1001 * 10 ** 9 // 24000, big if i == 1 else b"V" * 500)
+    mux.close()
+    buf = open(path, "rb").read()
+    top = _ebml(buf, 0, len(buf))
+    assert [e[0] for e in top] == [0x1A45DFA3, 0x18538067] and top[1][2] == len(buf)      # Segment size known and exact
+    seg = _ebml(buf, top[1][1], top[1][2])
+    ids = [e[0] for e in seg]
+    assert ids.index(0x1654AE6B) < ids.index(0x1941A469) < ids.index(0x1F43B675)           # Tracks < Attachments < first Cluster
+    assert ids[-1] == 0x1C53BB6B                                                           # Cues last
+    tracks = _ebml(buf, *[e for e in seg if e[0] == 0x1654AE6B][0][1:])
+    assert len(tracks) == 2
+    ent = {e[0]: buf[e[1]:e[2]] for e in _ebml(buf, tracks[0][1], tracks[0][2])}
+    assert ent[0x86] == b"V_FFV1" and ent[0x63A2] == b"\x01\x02\x03" and ent[0xD7] == b"\x01"
+    vid = {e[0]: buf[e[1]:e[2]] for e in _ebml(buf, *[e for e in _ebml(buf, tracks[0][1], tracks[0][2]) if e[0] == 0xE0][0][1:])}
+    assert vid[0xB0] == b"\x10\x00" and vid[0xBA] == b"\x08\x70"                           # 2-byte uints
+    blocks = []
+    for e in seg:
+        if e[0] == 0x1F43B675:
+            for c in _ebml(buf, e[1], e[2]):
+                assert c[0] in (0xE7, 0xA3)                                                # Timestamp + SimpleBlocks only
+                if c[0] == 0xA3:
+                    blocks.append((buf[c[1]] & 0x7F, c[2] - c[1] - 4))
+    assert blocks == [(2, 100), (1, 500), (2, 100), (1, 3 << 20), (2, 100), (1, 500)]
+    att = _ebml(buf, *[e for e in seg if e[0] == 0x1941A469][0][1:])
+    datas = [{x[0]: buf[x[1]:x[2]] for x in _ebml(buf, a[1], a[2])} for a in att]
+    assert datas[1][0x465C].startswith(b"\x1a\x45\xdf\xa3") and datas[0][0x466E] == b"side.txt"
+    with pytest.raises(api.RcgpuError):
+        api.MkvMuxer(path, overwrite=False)
+
+
+def test_argv_front_end_rejects_what_it_cannot_do(built, tmp_path):
+    shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+    r = subprocess.run([shim, "-version"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("rcgpu version")                       # Main.cpp:751-774 parses "<name> version <x>"
+    p = tmp_path / "a.dpx"
+    p.write_bytes(synth.dpx_file(synth.components(16, 16, 3, 16), synth.PIX_RGB16_BE))
+    for extra in (["-coder", "0"], ["-level", "1"], ["-c:v", "ffv1_vulkan"], ["-g", "2"]):
+        r = subprocess.run([shim, "-i", str(p), "-c:v", "ffv1", "-coder", "1", "-level", "3", "-g", "1"] + extra + ["-f", "matroska", str(tmp_path / "o.mkv")],
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "Error: " in r.stderr                                  # helpers.sh:81 greps for "Error:"

@@ -1,0 +1,107 @@
+"""CPU: the oracle against the committed golden vectors (blessed by the real reference, see golden/README.md),
+against its own decoder, and -- where oracle/_ref exists -- against the real reference binary."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from rawcooked_amd import api, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+VEC = json.load(open(os.path.join(G, "vectors.json")))
+
+
+@pytest.mark.parametrize("v", VEC["ffv1"], ids=lambda v: v["name"])
+def test_ffv1_golden(built, v):
+    assert v["reference_check"]
+    p = ob.Params(v["width"], v["height"], v["pixfmt"], v["num_h"], v["num_v"], 1, 1)
+    assert ob.config_record(p).hex() == v["config_record"]
+    for fr in v["frames"]:
+        payload = open(os.path.join(G, fr["payload"]), "rb").read()
+        packet = open(os.path.join(G, fr["packet"]), "rb").read()
+        assert hashlib.sha256(payload).hexdigest() == fr["payload_sha256"]
+        assert ob.encode_payload(p, payload, v["line_bytes"]) == packet          # encoder restatement
+        assert ob.decode_payload(p, packet, v["line_bytes"]) == payload          # decoder restatement (FFV1_Frame/Slice.cpp)
+
+
+@pytest.mark.parametrize("v", VEC["flac"], ids=lambda v: v["name"])
+def test_flac_golden(built, v):
+    pcm = open(os.path.join(G, v["pcm"]), "rb").read()
+    frames = open(os.path.join(G, v["frames"]), "rb").read()
+    got, cp = ob.flac_encode(v["channels"], v["rate"], v["bits"], pcm, 0, 8)
+    assert b"".join(got) == frames and [len(f) for f in got] == v["frame_sizes"] and cp.hex() == v["codec_private"]
+    assert ob.flac_decode(v["channels"], v["rate"], v["bits"], frames, len(pcm)) == pcm
+
+
+def test_config_record_parses_and_crc_is_zero(built):
+    for pixfmt in range(13):
+        p = ob.Params(64, 48, pixfmt, 3, 2, 1, 1)
+        rec = ob.config_record(p)
+        assert ob.lib().ffv1o_crc32(rec, len(rec)) == 0                          # FFV1_Frame.cpp:116
+        q = ob.Params(64, 48, pixfmt, 0, 0, 0, 1)
+        assert ob.lib().ffv1o_parse_config_record(rec, len(rec), __import__("ctypes").byref(q)) == 0
+        assert (q.num_h_slices, q.num_v_slices, q.ec) == (3, 2, 1)
+
+
+EDGE = [  # w, h, pixfmt, nh, nv, kind  -- ragged slices, 1x1 grid, single-column slices, every layout
+    (7, 5, synth.PIX_RGB16_BE, 1, 1, "noise"), (65, 33, synth.PIX_RGB10_FILLEDA_LE, 4, 3, "film"), (9, 9, synth.PIX_RGB8, 4, 4, "noise"),
+    (31, 8, synth.PIX_RGBA8, 5, 3, "film"), (20, 20, synth.PIX_RGBA16_LE, 3, 3, "noise"), (40, 13, synth.PIX_Y16_LE, 4, 2, "noise"),
+    (40, 13, synth.PIX_Y8, 2, 2, "flat"), (16, 16, synth.PIX_RGB12_FILLEDA_LE, 2, 2, "film"), (128, 4, synth.PIX_RGB16_LE, 3, 2, "flat"),
+]
+
+
+@pytest.mark.parametrize("w,h,pixfmt,nh,nv,kind", EDGE)
+def test_roundtrip_edges(built, w, h, pixfmt, nh, nv, kind):
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    payload, lb = synth.pack_payload(synth.components(w, h, nc, bits, kind, seed=w * 131 + h), pixfmt, True)
+    for ec in (0, 1):
+        for ctx in (0, 1):
+            p = ob.Params(w, h, pixfmt, nh, nv, ec, ctx)
+            pkt = ob.encode_payload(p, payload, lb)
+            assert ob.decode_payload(p, pkt, lb) == payload
+    bad = bytearray(pkt)
+    bad[len(bad) // 2] ^= 1
+    out = __import__("ctypes").create_string_buffer(lb * h)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    assert ob.lib().ffv1o_decode_payload(__import__("ctypes").byref(p), bytes(bad), len(bad), out, lb) != 0   # slice CRC catches it
+
+
+def test_oracle_packets_pass_the_real_reference(built, refbin, tmp_path):
+    """Re-pins the oracle here and now (not only through the committed vectors): DPX 16-bit + WAV package."""
+    work = str(tmp_path)
+    os.makedirs(work + "/pkg/img")
+    w, h, pixfmt = 72, 40, synth.PIX_RGB16_BE
+    files = []
+    for i in range(2):
+        fn = work + "/pkg/img/f_%06d.dpx" % i
+        open(fn, "wb").write(synth.dpx_file(synth.components(w, h, 3, 16, "film", seed=i), pixfmt, frame_index=i))
+        files.append(fn)
+    wav = synth.wav_file(synth.pcm_samples(5000, 2, 16, 48000), 16, 48000)
+    open(work + "/pkg/snd.wav", "wb").write(wav)
+    r = subprocess.run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], cwd=work, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    info = api.dpx_probe(open(files[0], "rb").read())
+    nh, nv = api.slices_to_grid(info.slices)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    ai = api.wav_probe(wav)
+    pcm = wav[ai.data_offset:ai.data_offset + ai.data_size]
+    frames, cp = ob.flac_encode(2, 48000, 16, pcm, 0, 8)
+    mux = api.MkvMuxer(work + "/pkg.mkv")
+    tv = mux.add_video(ob.config_record(p), w, h, 24, 1)
+    ta = mux.add_audio(cp, 2, 48000, 16)
+    mux.add_attachment("RAWcooked reversibility data", open(work + "/pkg.rawcooked_reversibility_data", "rb").read())
+    mux.begin()
+    B = int.from_bytes(cp[8:10], "big")
+    for i, f in enumerate(frames):
+        mux.write_block(ta, i * B * 10 ** 9 // 48000, f)
+    for i, fn in enumerate(files):
+        b = open(fn, "rb").read()
+        mux.write_block(tv, i * 10 ** 9 // 24, ob.encode_payload(p, b[info.data_offset:info.data_offset + info.data_size], info.line_bytes))
+    mux.close()
+    r = subprocess.run([refbin, "--check", "pkg.mkv"], cwd=work, capture_output=True, text=True)
+    assert r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout, r.stdout + r.stderr
