@@ -122,6 +122,8 @@ typedef struct {
     uint32_t context;         /* -context 0|1 */
     uint32_t max_batch;       /* frames encoded per call (frames in flight on the device) */
     int      device;          /* HIP device ordinal */
+    uint32_t segments;        /* hand-over granularity between state resolution and range coding: each slice's decision
+                                 stream is produced/consumed in this many windows (0 = automatic, 1 = whole slice) */
 } rcgpu_ffv1_config;
 
 typedef struct rcgpu_ffv1 rcgpu_ffv1;
@@ -149,9 +151,10 @@ int rcgpu_ffv1_encode_device(rcgpu_ffv1* enc, const void* const* d_frames, uint3
 int rcgpu_ffv1_encode_host(rcgpu_ffv1* enc, const uint8_t* const* frames, uint32_t n,
                            uint8_t* const* out_packets, size_t* out_sizes);
 
-/* Per-kernel device time of the last encode call on this encoder, measured with HIP events on the stream
- * the kernels were launched on.  names[i] is a static string. Returns the number of entries written. */
+/* Per-kernel device time (summed over its launches) of the last encode call on this encoder, measured with HIP events
+ * on the stream the kernels were launched on.  names[i] is a static string. Returns the number of entries written. */
 int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* enc, const char** names, float* ms, int cap);
+int rcgpu_ffv1_last_kernel_launches(const rcgpu_ffv1* enc, int index);   /* launches of kernel `index` in the last call */
 /* Totals of the last batch (valid after the stream is synchronised): binary range-coder decisions and packet bytes. */
 int rcgpu_ffv1_last_stats(const rcgpu_ffv1* enc, uint64_t* decisions, uint64_t* packet_bytes);
 

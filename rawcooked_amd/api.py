@@ -34,7 +34,7 @@ class AudioInfo(C.Structure):
 class Ffv1Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("pixfmt", C.c_uint32), ("line_bytes", C.c_uint32),
                 ("num_h_slices", C.c_uint32), ("num_v_slices", C.c_uint32), ("slicecrc", C.c_uint32), ("context", C.c_uint32),
-                ("max_batch", C.c_uint32), ("device", C.c_int)]
+                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32)]
 
 
 class FlacConfig(C.Structure):
@@ -77,6 +77,7 @@ SYMBOLS = {
     "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rcgpu_ffv1_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
+    "rcgpu_ffv1_last_kernel_launches": (C.c_int, [_VP, C.c_int]),
     "rcgpu_ffv1_last_stats": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rcgpu_ffv1_decode_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP), _VP]),
     "rcgpu_flac_create": (C.c_int, [C.POINTER(FlacConfig), C.POINTER(_VP)]),
@@ -156,8 +157,8 @@ def md5(data: bytes) -> bytes:
 class Ffv1Encoder:
     """Device FFV1 encoder (rcgpu_ffv1_*).  Raises when no HIP device is visible."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0):
-        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device)
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments)
         self.h = _VP()
         _check(lib().rcgpu_ffv1_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_create")
         self.max_packet = lib().rcgpu_ffv1_max_packet_bytes(self.h)
@@ -194,6 +195,10 @@ class Ffv1Encoder:
         ms = (C.c_float * 16)()
         k = lib().rcgpu_ffv1_last_kernel_times(self.h, names, ms, 16)
         return {names[i].decode(): float(ms[i]) for i in range(k)}
+
+    def kernel_launches(self) -> dict[str, int]:
+        names = ["k_unpack", "k_model", "k_resolve", "k_rangecode", "k_footer", "k_scan", "k_gather"]
+        return {n: lib().rcgpu_ffv1_last_kernel_launches(self.h, i) for i, n in enumerate(names)}
 
     def stats(self) -> tuple[int, int]:
         d, b = C.c_uint64(), C.c_uint64()

@@ -40,6 +40,7 @@ struct enc_const {
     uint32_t planes, bps, bits, rgb, gb_swap, big_endian, bytes_pp, overflow16;
     uint32_t num_h, num_v, S, nctx, nsets, ec, is5;
     uint32_t samples_per_frame;            // W*H*planes
+    uint32_t nseg;                         // segments a slice is cut into for the k_resolve -> k_rangecode hand-over
     int16_t  q[5][256];
     uint8_t  one_state[256], zero_state[256];
 };
@@ -51,7 +52,7 @@ struct slice_geom {
     uint32_t hdr_off, hdr_n;   // header decisions in d_hdr
     uint32_t cbuf_off_lo, cbuf_off_hi;   // byte offset of this slice's raw-byte buffer inside a frame's cbuf area
     uint32_t cbuf_cap;
-    uint32_t pad;
+    uint32_t seg_q;       // symbols per segment (multiple of 64)
 };
 
 constexpr int kPieceEntries = 32;                 // decisions per 64-byte piece
@@ -73,14 +74,14 @@ __device__ __forceinline__ uint32_t ld16(const uint8_t* p, bool be)
 }
 
 __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C, const uint8_t* const* __restrict__ frames,
-                                                int32_t* __restrict__ planes)
+                                                int32_t* __restrict__ planes, uint32_t frame0)
 {
     const uint32_t W = C->W, H = C->H;
     const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= W * H) return;
-    const uint32_t f = blockIdx.y;
+    const uint32_t f = blockIdx.y;           // frame inside this sub-batch; planes hold one sub-batch
     const uint32_t y = pix / W, x = pix - y * W;
-    const uint8_t* p = frames[f] + size_t(y) * C->line_bytes + size_t(x) * C->bytes_pp;
+    const uint8_t* p = frames[frame0 + f] + size_t(y) * C->line_bytes + size_t(x) * C->bytes_pp;
     const bool be = C->big_endian;
     uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
     switch (C->pixfmt) {
@@ -125,23 +126,25 @@ __device__ __forceinline__ int32_t median3(int32_t a, int32_t b, int32_t c)
 
 __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                const int32_t* __restrict__ planes, uint32_t* __restrict__ sym,
-                                               unsigned long long* __restrict__ chain_ndec)
+                                               unsigned long long* __restrict__ chain_ndec, uint32_t frame0)
 {
     __shared__ int16_t q[5][256];
-    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long segsum[64];
     for (uint32_t i = threadIdx.x; i < 5 * 256; i += 256) (&q[0][0])[i] = (&C->q[0][0])[i];
+    if (threadIdx.x < 64) segsum[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t chain = blockIdx.y;
-    const uint32_t S = C->S, f = chain / S, s = chain - f * S;
+    const uint32_t S = C->S, fl = blockIdx.y / S, s = blockIdx.y - fl * S;     // fl: frame inside the sub-batch (planes)
+    const uint32_t f = frame0 + fl, chain = f * S + s;
     const slice_geom G = geom[s];
     const uint32_t W = C->W, np = C->planes;
     const size_t plane_sz = size_t(W) * C->H;
-    const int32_t* fp = planes + size_t(f) * np * plane_sz;
+    const int32_t* fp = planes + size_t(fl) * np * plane_sz;
     uint32_t* out = sym + size_t(f) * C->samples_per_frame + G.sym_off;
     const uint32_t nlines = G.h * np;
     const int bits = int(C->bits);
     const bool is5 = C->is5, ov16 = C->overflow16, rgb = C->rgb;
     unsigned long long local = 0;
+    uint32_t cur_seg = 0xFFFFFFFFu;
     const uint32_t line_end = min(nlines, (blockIdx.x + 1) * 8);
     for (uint32_t line = blockIdx.x * 8; line < line_end; line++) {
         const uint32_t y = line / np, p = line - y * np;
@@ -169,15 +172,16 @@ __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, 
             if (ctx < 0) { ctx = -ctx; d = -d; }
             d = int32_t(uint32_t(d) << (32 - bits)) >> (32 - bits);                  // fold: sign-extend to `bits`
             const uint32_t a = uint32_t(d < 0 ? -d : d);
+            const uint32_t idx = line * G.w + x, seg = idx / G.seg_q;
+            if (seg != cur_seg) { if (local) atomicAdd(&segsum[cur_seg], local); local = 0; cur_seg = seg; }
             local += a ? uint32_t(2 * (31 - __clz(int(a))) + 3) : 1u;
-            out[size_t(line) * G.w + x] = (set << 30) | (uint32_t(ctx) << 17) | (uint32_t(d) & 0x1FFFFu);
+            out[size_t(idx)] = (set << 30) | (uint32_t(ctx) << 17) | (uint32_t(d) & 0x1FFFFu);
         }
     }
-    // block reduction -> one atomic per block
-    for (int o = 32; o; o >>= 1) local += __shfl_down(local, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    // per-segment decision counts: LDS first, then at most nseg global atomics per block
+    if (local) atomicAdd(&segsum[cur_seg], local);
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&chain_ndec[chain], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x < C->nseg && segsum[threadIdx.x]) atomicAdd(&chain_ndec[size_t(chain) * C->nseg + threadIdx.x], segsum[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -196,8 +200,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
                                                 uint8_t* __restrict__ states, const unsigned long long* __restrict__ group_off,
-                                                uint8_t* __restrict__ stream, uint32_t nkeys)
+                                                uint8_t* __restrict__ stream, uint32_t nkeys, uint32_t seg,
+                                                uint8_t* __restrict__ resume, uint32_t resume_stride)
 {
+    // One launch handles segment `seg` of every slice.  What must survive between launches -- the < 32 decisions that
+    // did not fill a piece and the first-touch bitmap -- lives in `resume` (per chain: count, 32 entries, bitmap).
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint16_t* stage = reinterpret_cast<uint16_t*>(smem);                           // kStageEntries u16
     uint8_t*  slot = smem + ((kStageEntries * 2 + 15) & ~15);                      // 64 x 32
@@ -216,10 +223,21 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     uint32_t* out32 = reinterpret_cast<uint32_t*>(stream + group_off[chain >> 6]) + (chain & 63) * 16;
 
     for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; }
-    for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = 0;
-    for (uint32_t i = lane; i < G.hdr_n; i += 64) stage[i] = hdr[G.hdr_off + i];
-    uint32_t stage_count = G.hdr_n;
-    uint32_t piece_base = 0;
+    uint8_t* rs = resume + size_t(chain) * resume_stride;
+    uint32_t* rs_touched = reinterpret_cast<uint32_t*>(rs + 80);
+    uint32_t stage_count;
+    if (seg == 0) {
+        for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = 0;
+        for (uint32_t i = lane; i < G.hdr_n; i += 64) stage[i] = hdr[G.hdr_off + i];
+        stage_count = G.hdr_n;
+    } else {
+        for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = rs_touched[i];
+        if (lane < 16) reinterpret_cast<uint32_t*>(stage)[lane] = reinterpret_cast<const uint32_t*>(rs + 16)[lane];
+        stage_count = *reinterpret_cast<const uint32_t*>(rs);
+    }
+    uint32_t piece_base = 0;              // piece index inside this segment's window
+    const uint32_t sym_begin = min(G.nsamp, seg * G.seg_q), sym_end = min(G.nsamp, (seg + 1) * G.seg_q);
+    const bool last_seg = seg + 1 == C->nseg;
     __syncthreads();
 
     auto flush_full = [&]() {
@@ -242,9 +260,9 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     flush_full();
 
     const unsigned long long lane_bit = 1ull << lane;
-    for (uint32_t base = 0; base < G.nsamp; base += 64) {
+    for (uint32_t base = sym_begin; base < sym_end; base += 64) {
         const uint32_t i = base + lane;
-        const bool valid = i < G.nsamp;
+        const bool valid = i < sym_end;
         const uint32_t sv = valid ? in[i] : 0;
         const int32_t d = int32_t(sv << 15) >> 15;                    // 17-bit signed residual
         const uint32_t key = (sv >> 30) * nctx + ((sv >> 17) & 0x1FFF);
@@ -335,6 +353,12 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         stage_count += total;
         flush_full();      // contains the workgroup-scope fences that order the state write-back before the next gather
     }
+    if (!last_seg) {      // park the unfinished piece and the bitmap for the next segment
+        for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) rs_touched[i] = touched[i];
+        if (lane < 16) reinterpret_cast<uint32_t*>(rs + 16)[lane] = reinterpret_cast<const uint32_t*>(stage)[lane];
+        if (lane == 0) *reinterpret_cast<uint32_t*>(rs) = stage_count;
+        return;
+    }
     // end-of-slice bit (state 129, FFV1_Slice.cpp:336-340), then pad the last piece
     if (lane == 0) stage[stage_count] = uint16_t(0xFF00u | (256 - 129));     // state 129, bit 0
     stage_count += 1;
@@ -366,6 +390,8 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kMaxCarryEvents = 4096;
 constexpr int kOutRows = 9;           // 32 decisions renormalise at most 32 times: 8 flushes (+1 carried in)
+
+struct rc_resume { uint32_t range, nb, pd; int pos; unsigned long long low; unsigned long long pad; };   // per chain, between segments
 
 struct rc_lane {
     uint32_t range; unsigned long long low; uint32_t nb; uint32_t pd;
@@ -450,7 +476,8 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
 }
 
 __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
-                                                  const unsigned long long* __restrict__ chain_ndec,
+                                                  const unsigned long long* __restrict__ total_n, const uint32_t* __restrict__ seg_pieces,
+                                                  uint32_t seg, rc_resume* __restrict__ resume,
                                                   const unsigned long long* __restrict__ group_off,
                                                   const uint8_t* __restrict__ stream, uint8_t* __restrict__ cbuf,
                                                   unsigned long long cbuf_frame_stride, uint32_t nchains,
@@ -464,16 +491,20 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
     const uint32_t cc = active ? chain : nchains - 1;
     const uint32_t f = cc / S, s = cc - f * S;
     const slice_geom G = geom[s];
-    const unsigned long long n = active ? G.hdr_n + chain_ndec[cc] + 1 : 0;
+    // this launch codes the pieces k_resolve produced for segment `seg`; only the last piece of the last segment is partial
+    const bool last_seg = seg + 1 == C->nseg;
+    const unsigned long long npieces = active ? seg_pieces[cc] : 0;
+    unsigned long long n = npieces * kPieceEntries;
+    if (active && last_seg && npieces) n -= (kPieceEntries - 1) - ((total_n[cc] - 1) % kPieceEntries);
     const uint4* src = reinterpret_cast<const uint4*>(stream + group_off[blockIdx.x]) + lane * 4;
 
     rc_lane r;
     r.obuf = obuf + lane; r.ocnt = 0; r.ovf = 0;
     r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.pos = -4; r.chain = cc;
+    if (seg) { const rc_resume v = resume[cc]; r.range = v.range; r.low = v.low; r.nb = v.nb; r.pd = v.pd; r.pos = v.pos; }
     r.out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
     r.cap = int(G.cbuf_cap);
 
-    const unsigned long long npieces = (n + kPieceEntries - 1) / kPieceEntries;
     unsigned long long maxp = npieces;
     for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_xor(maxp, o); maxp = t > maxp ? t : maxp; }
 
@@ -495,7 +526,8 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
         for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
     rc_drain(r, err + 1, events);
-    if (active) {
+    if (active && !last_seg) { rc_resume v; v.range = r.range; v.low = r.low; v.nb = r.nb; v.pd = r.pd; v.pos = r.pos; v.pad = 0; resume[cc] = v; }
+    if (active && last_seg) {
         // terminate (the state-129 end bit is already the last decision): two forced renormalisations; the last
         // latched byte is not emitted -- the decoder reads bytes past the end as zero (FFV1_RangeCoder.cpp:79-85).
         r.low += 0xFF;                         // nb <= 3 here
@@ -636,37 +668,45 @@ __global__ __launch_bounds__(256) void k_gather(const enc_const* __restrict__ C,
 // ---------------------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kMaxSeg = 64;
+constexpr uint32_t kSubBatch = 16;           // frames whose int32 planes are resident at once (k_unpack -> k_model)
+
 struct rcgpu_ffv1 {
     rcgpu_ffv1_config cfg{};
     ffv1::stream_params sp{};
     enc_const hc{};
     std::vector<slice_geom> geom;
     std::vector<uint8_t> record;
-    uint32_t nkeys = 0;
+    uint32_t nkeys = 0, nseg = 1, resume_stride = 0;
     size_t resolve_lds = 0;
     size_t frame_payload = 0, cbuf_frame_stride = 0, max_packet = 0;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr, rc_stream = nullptr;      // rc_stream: k_rangecode runs beside k_resolve
     // device buffers
     enc_const* d_const = nullptr; slice_geom* d_geom = nullptr; uint16_t* d_hdr = nullptr;
     const uint8_t** d_frame_ptrs = nullptr;
     int32_t* d_planes = nullptr; uint32_t* d_sym = nullptr; uint8_t* d_states = nullptr;
-    unsigned long long* d_ndec = nullptr; unsigned long long* d_group_off = nullptr;
-    uint8_t* d_stream = nullptr; size_t stream_cap = 0;
+    unsigned long long* d_ndec = nullptr;          // [chain][seg] decisions coded by the samples of a segment
+    unsigned long long* d_total_n = nullptr;       // [chain] all decisions incl. header and end bit
+    uint32_t* d_seg_pieces = nullptr;              // [seg][chain] 64-byte pieces produced in a segment
+    unsigned long long* d_group_off = nullptr;     // [seg][group] byte offset inside the segment's window
+    uint8_t* d_k3_resume = nullptr; rc_resume* d_k4_resume = nullptr;
+    uint8_t* d_window[2] = { nullptr, nullptr }; size_t window_cap = 0;
     uint8_t* d_cbuf = nullptr; uint32_t* d_out_len = nullptr; uint32_t* d_tot_len = nullptr;
     unsigned long long* d_slice_dst = nullptr; uint32_t* d_err = nullptr; uint2* d_events = nullptr;
     // host staging for the convenience path
     uint8_t* h_pinned_in = nullptr; uint8_t* d_in = nullptr; uint8_t* d_packets = nullptr; unsigned long long* d_psizes = nullptr;
-    uint8_t* h_pinned_out = nullptr; unsigned long long* h_psizes = nullptr;
-    unsigned long long* h_ndec_pinned = nullptr;
-    // instrumentation
+    unsigned long long* h_psizes = nullptr;
+    unsigned long long* h_ndec_pinned = nullptr; const void** h_frame_ptrs = nullptr;
+    unsigned long long* h_total_n = nullptr; uint32_t* h_seg_pieces = nullptr; unsigned long long* h_group_off = nullptr;
+    // instrumentation: start/stop event pairs on the stream each kernel is launched on
     static constexpr int kNumK = 7;
-    hipEvent_t ev[2 * kNumK]{};            // start/stop pair per kernel, recorded on the launch stream
-    const void** h_frame_ptrs = nullptr;  // pinned copies of small host->device tables
-    unsigned long long* h_group_off_pinned = nullptr;
+    std::vector<hipEvent_t> ev;                    // pairs, in launch order
+    std::vector<int> ev_kernel;                    // kernel index of each pair
+    size_t ev_used = 0;
+    hipEvent_t ev_k3[kMaxSeg]{}, ev_k4[kMaxSeg]{}, ev_fork = nullptr;
     bool ev_valid = false;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
     uint32_t last_n = 0;
-    std::vector<unsigned long long> h_last_psizes;
 };
 
 static const char* const kKernelNames[rcgpu_ffv1::kNumK] = { "k_unpack", "k_model", "k_resolve", "k_rangecode", "k_footer", "k_scan", "k_gather" };
@@ -682,17 +722,18 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
 {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
-    void* bufs[] = { e->d_const, e->d_geom, e->d_hdr, e->d_frame_ptrs, e->d_planes, e->d_sym, e->d_states, e->d_ndec, e->d_group_off,
-                     e->d_stream, e->d_cbuf, e->d_out_len, e->d_tot_len, e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes };
+    void* bufs[] = { e->d_const, e->d_geom, e->d_hdr, e->d_frame_ptrs, e->d_planes, e->d_sym, e->d_states, e->d_ndec, e->d_total_n, e->d_seg_pieces,
+                     e->d_group_off, e->d_k3_resume, e->d_k4_resume, e->d_window[0], e->d_window[1], e->d_cbuf, e->d_out_len, e->d_tot_len,
+                     e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes };
     for (void* b : bufs) if (b) (void)hipFree(b);
-    if (e->h_pinned_in) (void)hipHostFree(e->h_pinned_in);
-    if (e->h_pinned_out) (void)hipHostFree(e->h_pinned_out);
-    if (e->h_psizes) (void)hipHostFree(e->h_psizes);
-    if (e->h_ndec_pinned) (void)hipHostFree(e->h_ndec_pinned);
-    if (e->h_frame_ptrs) (void)hipHostFree(e->h_frame_ptrs);
-    if (e->h_group_off_pinned) (void)hipHostFree(e->h_group_off_pinned);
+    void* hosts[] = { e->h_pinned_in, e->h_psizes, e->h_ndec_pinned, e->h_frame_ptrs, e->h_total_n, e->h_seg_pieces, e->h_group_off };
+    for (void* h : hosts) if (h) (void)hipHostFree(h);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_k3) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_k4) if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->rc_stream) (void)hipStreamDestroy(e->rc_stream);
     delete e;
 }
 
@@ -709,6 +750,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (S > 1 && (cfg->num_h_slices >= cfg->width || cfg->num_v_slices >= cfg->height))
         return fail(2, "ffv1: more slices than pixels (FFV1_Frame.cpp:161-164)");
     if (!cfg->max_batch) return fail(2, "ffv1: max_batch is 0");
+    if (cfg->segments > kMaxSeg) return fail(2, "ffv1: at most %u segments", kMaxSeg);
     const pix_desc& d = pix(cfg->pixfmt);
     if (cfg->line_bytes < cfg->width * d.bytes_pp) return fail(2, "ffv1: line_bytes smaller than a line");
     int ndev = 0;
@@ -741,7 +783,20 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (c.nctx > 8191) { delete e; return fail(2, "ffv1: context count %u does not fit the symbol format", c.nctx); }
     e->nkeys = c.nsets * c.nctx;
     e->resolve_lds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);
+    e->resume_stride = uint32_t((80 + ((e->nkeys + 31) / 32) * 4 + 15) & ~15u);
     e->frame_payload = size_t(cfg->line_bytes) * cfg->height;
+
+    // segments: the decision stream of a slice is produced and consumed in nseg windows (double buffered) instead of
+    // being resident as a whole; auto = enough symbols per segment to keep launch overheads invisible
+    uint32_t min_nsamp = ~0u;
+    for (uint32_t sy = 0; sy < c.num_v; sy++)
+        for (uint32_t sx = 0; sx < c.num_h; sx++) {
+            const uint32_t w = uint32_t(uint64_t(sx + 1) * c.W / c.num_h) - uint32_t(uint64_t(sx) * c.W / c.num_h);
+            const uint32_t h = uint32_t(uint64_t(sy + 1) * c.H / c.num_v) - uint32_t(uint64_t(sy) * c.H / c.num_v);
+            min_nsamp = std::min(min_nsamp, w * h * c.planes);
+        }
+    e->nseg = cfg->segments ? cfg->segments : std::max(1u, std::min(16u, min_nsamp / 8192));
+    c.nseg = e->nseg;
 
     // slice geometry (FFV1_Slice.cpp:153-156), header decisions, raw-byte buffers
     std::vector<uint16_t> hdr;
@@ -752,11 +807,14 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             g.x0 = uint32_t(uint64_t(sx) * c.W / c.num_h); g.y0 = uint32_t(uint64_t(sy) * c.H / c.num_v);
             g.w = uint32_t(uint64_t(sx + 1) * c.W / c.num_h) - g.x0; g.h = uint32_t(uint64_t(sy + 1) * c.H / c.num_v) - g.y0;
             g.sym_off = sym_off; g.nsamp = g.w * g.h * c.planes; sym_off += g.nsamp;
+            g.seg_q = ((g.nsamp + e->nseg - 1) / e->nseg + 63) & ~63u;
             const auto hd = ffv1::slice_header_decisions(e->sp, sx, sy, e->geom.empty());
             g.hdr_off = uint32_t(hdr.size()); g.hdr_n = uint32_t(hd.size());
             for (uint16_t d16 : hd) hdr.push_back((d16 & 0x100) ? uint16_t(d16 & 0xFF) : uint16_t(0xFF00u | (256 - (d16 & 0xFF))));   // (state, bit) -> (t, c)
-            // worst realistic size: twice the raw payload of the slice, plus header/footer room
-            size_t cap = (size_t(g.w) * g.h * d.bytes_pp * 2 + 4096 + 15) & ~size_t(15);
+            // room for 1.5x the raw payload of the slice (incompressible 16-bit noise codes to ~1.1x once the contexts have
+            // adapted) + what ~10^4 contexts x 32 states can cost before they have (tiny slices reach 1.7x), + header/footer
+            const size_t raw15 = size_t(g.w) * g.h * d.bytes_pp * 3 / 2;
+            size_t cap = (raw15 + std::min<size_t>(raw15, 256u << 10) + 4096 + 15) & ~size_t(15);
             if (cap > 0xFFFFFF + 64) cap = 0xFFFFFF + 64;          // slice size field is 24 bit
             cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here
             g.cbuf_off_lo = uint32_t(cb); g.cbuf_off_hi = uint32_t(uint64_t(cb) >> 32); g.cbuf_cap = uint32_t(cap);
@@ -768,22 +826,32 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
 
     const uint32_t F = cfg->max_batch;
     const size_t nchains = size_t(F) * S, ngroups = (nchains + 63) / 64;
+    const uint32_t nseg = e->nseg;
     auto dmalloc = [&](auto** p, size_t bytes) -> hipError_t { return hipMalloc(reinterpret_cast<void**>(p), bytes ? bytes : 16); };
     hipError_t he = hipSuccess;
 #define DM(p, b) if (he == hipSuccess) he = dmalloc(&(p), (b))
+#define HM(p, b) if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&(p)), (b))
     DM(e->d_const, sizeof(enc_const)); DM(e->d_geom, sizeof(slice_geom) * S); DM(e->d_hdr, hdr.size() * 2 + 16);
     DM(e->d_frame_ptrs, sizeof(void*) * F);
-    DM(e->d_planes, size_t(F) * c.samples_per_frame * 4); DM(e->d_sym, size_t(F) * c.samples_per_frame * 4);
+    DM(e->d_planes, size_t(std::min(F, kSubBatch)) * c.samples_per_frame * 4); DM(e->d_sym, size_t(F) * c.samples_per_frame * 4);
     DM(e->d_states, nchains * e->nkeys * 32);
-    DM(e->d_ndec, nchains * 8); DM(e->d_group_off, ngroups * 8);
+    DM(e->d_ndec, nchains * nseg * 8); DM(e->d_total_n, nchains * 8); DM(e->d_seg_pieces, nchains * nseg * 4); DM(e->d_group_off, ngroups * nseg * 8);
+    DM(e->d_k3_resume, nchains * e->resume_stride); DM(e->d_k4_resume, nchains * sizeof(rc_resume));
     DM(e->d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
     DM(e->d_out_len, nchains * 4); DM(e->d_tot_len, nchains * 4); DM(e->d_slice_dst, nchains * 8); DM(e->d_err, 16); DM(e->d_events, sizeof(uint2) * kMaxCarryEvents);
+    HM(e->h_ndec_pinned, nchains * nseg * 8); HM(e->h_frame_ptrs, sizeof(void*) * F); HM(e->h_total_n, nchains * 8);
+    HM(e->h_seg_pieces, nchains * nseg * 4); HM(e->h_group_off, ngroups * nseg * 8);
 #undef DM
-    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&e->h_ndec_pinned), nchains * 8);
-    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&e->h_frame_ptrs), sizeof(void*) * F);
-    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&e->h_group_off_pinned), ngroups * 8);
+#undef HM
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->rc_stream, hipStreamNonBlocking);
+    e->ev.resize(2 * (5 + 2 * nseg + (F + kSubBatch - 1) / kSubBatch * 2));
     for (auto& ev : e->ev) if (he == hipSuccess) he = hipEventCreate(&ev);
+    for (uint32_t j = 0; j < nseg; j++) {
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k3[j], hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k4[j], hipEventDisableTiming);
+    }
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
     if (he == hipSuccess) he = hipMemcpy(e->d_const, &e->hc, sizeof(enc_const), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(e->d_geom, e->geom.data(), sizeof(slice_geom) * S, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(e->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
@@ -815,82 +883,120 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     if (packet_stride < e->max_packet || (packet_stride & 3)) return fail(2, "ffv1: packet_stride must be a multiple of 4 and >= %zu", e->max_packet);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    hipStream_t s2 = e->rc_stream;
     const enc_const& c = e->hc;
-    const uint32_t S = c.S, nchains = n * S, ngroups = (nchains + 63) / 64;
+    const uint32_t S = c.S, nchains = n * S, ngroups = (nchains + 63) / 64, nseg = e->nseg;
+    e->ev_used = 0; e->ev_kernel.clear();
+    auto timed = [&](int kernel, hipStream_t stream, auto&& launch) -> hipError_t {
+        if (e->ev_used + 2 > e->ev.size()) { launch(); return hipGetLastError(); }
+        hipError_t r = hipEventRecord(e->ev[e->ev_used], stream);
+        launch();
+        if (r == hipSuccess) r = hipEventRecord(e->ev[e->ev_used + 1], stream);
+        e->ev_used += 2; e->ev_kernel.push_back(kernel);
+        return r;
+    };
 
     for (uint32_t i = 0; i < n; i++) e->h_frame_ptrs[i] = d_frames[i];
     HIP_TRY(hipMemcpyAsync(e->d_frame_ptrs, e->h_frame_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(e->d_ndec, 0, size_t(nchains) * 8, st));
+    HIP_TRY(hipMemsetAsync(e->d_ndec, 0, size_t(nchains) * nseg * 8, st));
     HIP_TRY(hipMemsetAsync(e->d_err, 0, 16, st));
-    HIP_TRY(hipEventRecord(e->ev[0], st));
-    hipLaunchKernelGGL(k_unpack, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, e->d_const, e->d_frame_ptrs, e->d_planes);
-    HIP_TRY(hipEventRecord(e->ev[1], st));
     uint32_t max_lines = 0;
     for (const slice_geom& g : e->geom) max_lines = std::max(max_lines, g.h * c.planes);
-    HIP_TRY(hipEventRecord(e->ev[2], st));
-    hipLaunchKernelGGL(k_model, dim3((max_lines + 7) / 8, nchains), dim3(256), 0, st, e->d_const, e->d_geom, e->d_planes, e->d_sym, e->d_ndec);
-    HIP_TRY(hipEventRecord(e->ev[3], st));
-    // The exact decision counts size the interleaved stream: one host round trip per batch.
-    HIP_TRY(hipMemcpyAsync(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * 8, hipMemcpyDeviceToHost, st));
+    for (uint32_t f0 = 0; f0 < n; f0 += kSubBatch) {          // planes are transient: one sub-batch at a time
+        const uint32_t nf = std::min(kSubBatch, n - f0);
+        HIP_TRY(timed(0, st, [&] { hipLaunchKernelGGL(k_unpack, dim3((c.W * c.H + 255) / 256, nf), dim3(256), 0, st, e->d_const, e->d_frame_ptrs, e->d_planes, f0); }));
+        HIP_TRY(timed(1, st, [&] { hipLaunchKernelGGL(k_model, dim3((max_lines + 7) / 8, nf * S), dim3(256), 0, st, e->d_const, e->d_geom, e->d_planes, e->d_sym, e->d_ndec, f0); }));
+    }
+    // The exact decision counts size the stream windows: one host round trip per batch.
+    HIP_TRY(hipMemcpyAsync(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * nseg * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    uint64_t total_dec = 0; unsigned long long off = 0;
-    for (uint32_t g = 0; g < ngroups; g++) {
-        unsigned long long pieces = 0;
-        for (uint32_t l = 0; l < 64 && g * 64 + l < nchains; l++) {
-            const uint32_t chain = g * 64 + l;
-            const unsigned long long nd = e->geom[chain % S].hdr_n + e->h_ndec_pinned[chain] + 1;
-            total_dec += nd;
-            pieces = std::max(pieces, (nd + kPieceEntries - 1) / kPieceEntries);
+    uint64_t total_dec = 0;
+    for (uint32_t chain = 0; chain < nchains; chain++) {
+        unsigned long long D = e->geom[chain % S].hdr_n, done = 0;
+        for (uint32_t j = 0; j < nseg; j++) {
+            D += e->h_ndec_pinned[size_t(chain) * nseg + j];
+            if (j + 1 == nseg) D += 1;                                                   // end-of-slice bit
+            const unsigned long long pieces = j + 1 == nseg ? (D + kPieceEntries - 1) / kPieceEntries : D / kPieceEntries;
+            e->h_seg_pieces[size_t(j) * nchains + chain] = uint32_t(pieces - done);
+            done = pieces;
         }
-        e->h_group_off_pinned[g] = off;
-        off += pieces * kGroupPieceBytes;
+        e->h_total_n[chain] = D;
+        total_dec += D;
+    }
+    size_t window_need = 0;
+    for (uint32_t j = 0; j < nseg; j++) {
+        unsigned long long off = 0;
+        for (uint32_t g = 0; g < ngroups; g++) {
+            uint32_t mx = 0;
+            for (uint32_t l = 0; l < 64 && g * 64 + l < nchains; l++) mx = std::max(mx, e->h_seg_pieces[size_t(j) * nchains + g * 64 + l]);
+            e->h_group_off[size_t(j) * ngroups + g] = off;
+            off += (unsigned long long)mx * kGroupPieceBytes;
+        }
+        window_need = std::max<size_t>(window_need, off);
     }
     e->last_decisions = total_dec;
-    if (off > e->stream_cap) {
-        if (e->d_stream) HIP_TRY(hipFree(e->d_stream));
-        e->d_stream = nullptr; e->stream_cap = 0;
-        const size_t want = size_t(off) + size_t(off) / 8 + (1u << 20);
-        hipError_t he = hipMalloc(reinterpret_cast<void**>(&e->d_stream), want);
-        if (he != hipSuccess) return fail(101, "ffv1: cannot allocate %zu bytes for the decision stream of %u frames: %s -- lower max_batch", want, n, hipGetErrorString(he));
-        e->stream_cap = want;
+    if (window_need > e->window_cap) {
+        for (auto& w : e->d_window) { if (w) HIP_TRY(hipFree(w)); w = nullptr; }
+        e->window_cap = 0;
+        const size_t want = window_need + window_need / 8 + (1u << 20);
+        for (int k = 0; k < (nseg > 1 ? 2 : 1); k++) {
+            hipError_t he = hipMalloc(reinterpret_cast<void**>(&e->d_window[k]), want);
+            if (he != hipSuccess) return fail(101, "ffv1: cannot allocate %zu bytes for a decision-stream window of %u frames: %s -- lower max_batch", want, n, hipGetErrorString(he));
+        }
+        e->window_cap = want;
     }
-    HIP_TRY(hipMemcpyAsync(e->d_group_off, e->h_group_off_pinned, size_t(ngroups) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(e->ev[4], st));
-    hipLaunchKernelGGL(k_resolve, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
-                       e->d_group_off, e->d_stream, e->nkeys);
-    HIP_TRY(hipEventRecord(e->ev[5], st));
-    HIP_TRY(hipEventRecord(e->ev[6], st));
-    hipLaunchKernelGGL(k_rangecode, dim3(ngroups), dim3(64), 0, st, e->d_const, e->d_geom, e->d_ndec, e->d_group_off, e->d_stream, e->d_cbuf,
-                       (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events);
-    HIP_TRY(hipEventRecord(e->ev[7], st));
-    HIP_TRY(hipEventRecord(e->ev[8], st));
-    hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(64), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
-                       e->d_out_len, e->d_tot_len, e->d_err, e->d_events);
-    HIP_TRY(hipEventRecord(e->ev[9], st));
-    HIP_TRY(hipEventRecord(e->ev[10], st));
-    hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, st, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes));
-    HIP_TRY(hipEventRecord(e->ev[11], st));
-    HIP_TRY(hipEventRecord(e->ev[12], st));
-    hipLaunchKernelGGL(k_gather, dim3(8, nchains), dim3(256), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
-                       e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride);
-    HIP_TRY(hipEventRecord(e->ev[13], st));
+    HIP_TRY(hipMemcpyAsync(e->d_total_n, e->h_total_n, size_t(nchains) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(e->d_seg_pieces, e->h_seg_pieces, size_t(nchains) * nseg * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(e->d_group_off, e->h_group_off, size_t(ngroups) * nseg * 8, hipMemcpyHostToDevice, st));
+    // k_resolve(seg j) on the caller's stream, k_rangecode(seg j) on rc_stream; window j&1 is reused once k_rangecode(j-2) is done
+    HIP_TRY(hipEventRecord(e->ev_fork, st));
+    HIP_TRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
+    for (uint32_t j = 0; j < nseg; j++) {
+        uint8_t* win = e->d_window[j & 1];
+        if (j >= 2) HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[j - 2], 0));
+        HIP_TRY(timed(2, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
+                                                      e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride); }));
+        HIP_TRY(hipEventRecord(e->ev_k3[j], st));
+        HIP_TRY(hipStreamWaitEvent(s2, e->ev_k3[j], 0));
+        HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
+                                                      j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
+                                                      (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events); }));
+        HIP_TRY(hipEventRecord(e->ev_k4[j], s2));
+    }
+    HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[nseg - 1], 0));
+    HIP_TRY(timed(4, st, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(64), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+                                                  e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));
+    HIP_TRY(timed(5, st, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, st, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
+    HIP_TRY(timed(6, st, [&] { hipLaunchKernelGGL(k_gather, dim3(8, nchains), dim3(256), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+                                                  e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
     HIP_TRY(hipGetLastError());
     e->ev_valid = true; e->last_n = n;
     return 0;
 }
 
+// Sum of the device time of every launch of each kernel in the last encode call (HIP events on the launch stream).
 extern "C" int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap)
 {
-    if (!e || !e->ev_valid) return 0;
-    if (hipEventSynchronize(e->ev[2 * rcgpu_ffv1::kNumK - 1]) != hipSuccess) return 0;
+    if (!e || !e->ev_valid || !e->ev_used) return 0;
+    if (hipEventSynchronize(e->ev[e->ev_used - 1]) != hipSuccess) return 0;
     int k = 0;
-    for (; k < rcgpu_ffv1::kNumK && k < cap; k++) {
-        names[k] = kKernelNames[k];
+    for (; k < rcgpu_ffv1::kNumK && k < cap; k++) { names[k] = kKernelNames[k]; ms[k] = 0; }
+    for (size_t i = 0; i < e->ev_kernel.size(); i++) {
         float t = 0;
-        (void)hipEventElapsedTime(&t, e->ev[2 * k], e->ev[2 * k + 1]);
-        ms[k] = t;
+        if (hipEventSynchronize(e->ev[2 * i + 1]) != hipSuccess) continue;
+        (void)hipEventElapsedTime(&t, e->ev[2 * i], e->ev[2 * i + 1]);
+        if (e->ev_kernel[i] < k) ms[e->ev_kernel[i]] += t;
     }
     return k;
+}
+
+// launches of kernel `index` in the last encode call (k_resolve / k_rangecode run once per segment)
+extern "C" int rcgpu_ffv1_last_kernel_launches(const rcgpu_ffv1* e, int index)
+{
+    if (!e) return 0;
+    int n = 0;
+    for (int k : e->ev_kernel) n += k == index;
+    return n;
 }
 
 extern "C" int rcgpu_ffv1_last_stats(const rcgpu_ffv1* e, uint64_t* decisions, uint64_t* packet_bytes)
@@ -928,7 +1034,7 @@ extern "C" int rcgpu_ffv1_encode_host(rcgpu_ffv1* e, const uint8_t* const* frame
     HIP_TRY(hipMemcpyAsync(e->h_psizes, e->d_psizes, 8 * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&err, e->d_err, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (err) return fail(102, "ffv1: a slice outgrew its buffer (flags %u) -- content expands beyond 2x raw size", err);
+    if (err) return fail(102, "ffv1: a slice outgrew its buffer (flags %u) -- content expands beyond the slice buffer", err);
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; i++) {
         out_sizes[i] = size_t(e->h_psizes[i]);
@@ -941,8 +1047,8 @@ extern "C" int rcgpu_ffv1_encode_host(rcgpu_ffv1* e, const uint8_t* const* frame
 }
 
 // Debug taps for the stage-by-stage parity tests (tests/test_gpu_stages.py): copies an intermediate of the LAST
-// batch to the host.  what: 0 planes (int32), 1 symbols (u32), 2 per-chain decision counts (u64),
-// 3 decision stream of `chain` de-interleaved (u16), 4 raw slice bytes of `chain` before the footer.
+// batch to the host.  what: 0 planes (int32, first sub-batch only), 1 symbols (u32), 2 per-chain decision counts (u64),
+// 3 decision stream of `chain` de-interleaved (u16; needs segments == 1), 4 raw slice bytes of `chain` before the footer.
 extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t chain, void* dst, size_t cap)
 {
     if (!e || !e->ev_valid) return -1;
@@ -955,16 +1061,19 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
         return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? (long long)bytes : -3;
     };
     switch (what) {
-    case 0: return d2h(e->d_planes, size_t(e->last_n) * c.samples_per_frame * 4);
+    case 0: return d2h(e->d_planes, size_t(std::min(e->last_n, kSubBatch)) * c.samples_per_frame * 4);
     case 1: return d2h(e->d_sym, size_t(e->last_n) * c.samples_per_frame * 4);
-    case 2: return d2h(e->d_ndec, size_t(e->last_n) * S * 8);
+    case 2: return d2h(e->d_total_n, size_t(e->last_n) * S * 8);
     case 3: {
         if (chain >= e->last_n * S) return -4;
-        const unsigned long long nd = e->geom[chain % S].hdr_n + e->h_ndec_pinned[chain] + 1;
-        const size_t pieces = (nd + kPieceEntries - 1) / kPieceEntries;
+        if (e->nseg != 1) return -6;
+        const uint32_t nchains = e->last_n * S;
+        const unsigned long long nd = e->h_total_n[chain];
+        const size_t pieces = e->h_seg_pieces[chain];
         if (nd * 2 > cap) return -2;
         std::vector<uint8_t> tmp(pieces * kPieceBytes);
-        const uint8_t* base = e->d_stream + e->h_group_off_pinned[chain >> 6] + (chain & 63) * kPieceBytes;
+        const uint8_t* base = e->d_window[0] + e->h_group_off[chain >> 6] + (chain & 63) * kPieceBytes;
+        (void)nchains;
         if (hipMemcpy2D(tmp.data(), kPieceBytes, base, kGroupPieceBytes, kPieceBytes, pieces, hipMemcpyDeviceToHost) != hipSuccess) return -3;
         const uint16_t* ent = reinterpret_cast<const uint16_t*>(tmp.data());
         uint16_t* o = static_cast<uint16_t*>(dst);

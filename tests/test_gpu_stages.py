@@ -27,7 +27,7 @@ def test_stages_match_oracle(built, w, h, pixfmt, slices, kind, nframes):
         comp = synth.components(w, h, nc, bits, kind, seed=100 + i)
         pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
         payloads.append(pl)
-    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=1)   # whole decision stream stays resident: every stage can be fetched
     p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
     assert enc.config_record() == ob.config_record(p)
     packets = enc.encode_host(payloads)
@@ -55,4 +55,36 @@ def test_stages_match_oracle(built, w, h, pixfmt, slices, kind, nframes):
                 sym_off += nsamp
         assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}: packet differs"
         assert ob.decode_payload(p, packets[f], line_bytes) == payloads[f]
+    enc.close()
+
+
+@pytest.mark.parametrize("segments", [0, 2, 5, 16, 64])
+def test_segmented_handover_is_bit_exact(built, segments):
+    """The k_resolve -> k_rangecode hand-over in windows (resumable kernels, two streams) must not change a byte."""
+    w, h, pixfmt, nh, nv, nframes = 200, 120, synth.PIX_RGB16_BE, 3, 2, 3
+    payloads = []
+    for i in range(nframes):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 16, "film" if i else "noise", seed=50 + i), pixfmt, True)
+        payloads.append(pl)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=segments)
+    for rep in range(2):          # second call reuses every buffer and resume record
+        packets = enc.encode_host(payloads)
+        for f in range(nframes):
+            assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"segments={segments} call {rep} frame {f}"
+    enc.close()
+
+
+def test_many_frames_cross_sub_batches(built):
+    """More frames than one k_unpack/k_model sub-batch (16) and more than one wavefront of chains."""
+    w, h, pixfmt, nh, nv, nframes = 96, 64, synth.PIX_RGB10_FILLEDA_BE, 2, 2, 37
+    payloads = []
+    for i in range(nframes):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 10, "film", seed=i), pixfmt, True)
+        payloads.append(pl)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes)
+    packets = enc.encode_host(payloads)
+    for f in range(nframes):
+        assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
     enc.close()
