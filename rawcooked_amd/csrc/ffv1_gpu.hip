@@ -484,6 +484,8 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
                                                   uint32_t* __restrict__ out_len, uint32_t* __restrict__ err, uint2* __restrict__ events)
 {
     __shared__ uint32_t obuf[(kOutRows + 1) * 64];
+    // This kernel is latency-bound and shares SIMDs with throughput-bound k_resolve wavefronts: take issue priority.
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const uint32_t chain = blockIdx.x * 64 + lane;
     const bool active = chain < nchains;
@@ -573,26 +575,30 @@ __device__ uint32_t gf_xpow8(unsigned long long nbytes)      // x^(8*nbytes) mod
     return result;
 }
 
-__global__ __launch_bounds__(64) void k_footer(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
-                                               uint8_t* __restrict__ cbuf, unsigned long long cbuf_frame_stride,
-                                               const uint32_t* __restrict__ out_len, uint32_t* __restrict__ tot_len,
-                                               uint32_t* __restrict__ err, const uint2* __restrict__ events)
+__global__ __launch_bounds__(256) void k_footer(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+                                                uint8_t* __restrict__ cbuf, unsigned long long cbuf_frame_stride,
+                                                const uint32_t* __restrict__ out_len, uint32_t* __restrict__ tot_len,
+                                                uint32_t* __restrict__ err, const uint2* __restrict__ events)
 {
-    __shared__ uint32_t T[256];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) {
-        uint32_t c = uint32_t(i) << 24;
+    // slicing-by-4 tables: T[k][b] = crc of byte b followed by k zero bytes
+    __shared__ uint32_t T[4][256];
+    __shared__ uint32_t part[256];
+    const int tid = threadIdx.x;
+    {
+        uint32_t c = uint32_t(tid) << 24;
         for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
-        T[i] = c;
+        T[0][tid] = c;
     }
+    __syncthreads();
+    for (int k = 1; k < 4; k++) { const uint32_t p = T[k - 1][tid]; T[k][tid] = (p << 8) ^ T[0][p >> 24]; __syncthreads(); }
     const uint32_t chain = blockIdx.x;
     const uint32_t S = C->S, f = chain / S, s = chain - f * S;
     const slice_geom G = geom[s];
     uint8_t* out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
     const uint32_t len = out_len[chain];
     const uint32_t tail = C->ec ? 8 : 3;
-    if (len + tail > G.cbuf_cap || len > 0xFFFFFF) { if (lane == 0) { atomicOr(err, 2u); tot_len[chain] = 0; } return; }
-    if (lane == 0) {
+    if (len + tail > G.cbuf_cap || len > 0xFFFFFF) { if (tid == 0) { atomicOr(err, 2u); tot_len[chain] = 0; } return; }
+    if (tid == 0) {
         // carries that left k_rangecode's second stage after the bytes below them were already stored
         const uint32_t nev = err[1];
         if (nev > kMaxCarryEvents) atomicOr(err, 4u);
@@ -602,16 +608,47 @@ __global__ __launch_bounds__(64) void k_footer(const enc_const* __restrict__ C, 
         if (C->ec) out[len + 3] = 0;                      // error_status
     }
     __syncthreads();
-    if (!C->ec) { if (lane == 0) tot_len[chain] = len + 3; return; }
+    if (!C->ec) { if (tid == 0) tot_len[chain] = len + 3; return; }
+    // Bulk: 16 KB tiles read fully coalesced -- thread t owns the 64-byte chunk t of every tile.  Its chunks are 16 KB
+    // apart, so a Horner recurrence with the constant M = x^(8*16384) accumulates them:  acc = acc*M + crc(chunk);
+    // multiplication by M is four table look-ups (TM, built once per block).  The sub-tile remainder is done with
+    // contiguous per-thread segments.  crc(A||B) = crc(A) * x^(8|B|) + crc(B) glues everything together.
+    constexpr uint32_t kTile = 16384, kChunk = kTile / 256;
+    __shared__ uint32_t TM[4][256];
     const uint32_t total = len + 4;
-    const uint32_t seg = ((total + 63) / 64 + 3) & ~3u;   // bytes per lane, multiple of 4
-    const uint32_t beg = min(total, uint32_t(lane) * seg), end = min(total, beg + seg);
+    const uint32_t ntiles = total / kTile, rem = total - ntiles * kTile;
+    const uint32_t M = gf_xpow8(kTile);
+    for (int k = 0; k < 4; k++) TM[k][tid] = gf_mulmod(uint32_t(tid) << (8 * k), M);
+    __syncthreads();
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        const uint4* p4 = reinterpret_cast<const uint4*>(out + size_t(t) * kTile + size_t(tid) * kChunk);
+        uint32_t cc = 0;
+#pragma unroll
+        for (int q = 0; q < int(kChunk / 16); q++) {
+            const uint4 v = p4[q];
+            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cc ^= __builtin_bswap32(w[j]);
+                cc = T[3][cc >> 24] ^ T[2][(cc >> 16) & 0xFF] ^ T[1][(cc >> 8) & 0xFF] ^ T[0][cc & 0xFF];
+            }
+        }
+        acc = TM[3][acc >> 24] ^ TM[2][(acc >> 16) & 0xFF] ^ TM[1][(acc >> 8) & 0xFF] ^ TM[0][acc & 0xFF] ^ cc;
+    }
+    if (ntiles) acc = gf_mulmod(acc, gf_xpow8((unsigned long long)kChunk * (255 - tid) + rem));
+    const uint8_t* rp = out + size_t(ntiles) * kTile;
+    const uint32_t seg = ((rem + 255) / 256 + 3) & ~3u;
+    const uint32_t beg = min(rem, uint32_t(tid) * seg), end = min(rem, beg + seg);
     uint32_t c = 0;
-    for (uint32_t i = beg; i < end; i++) c = (c << 8) ^ T[(c >> 24) ^ out[i]];
-    // shift by the bytes that follow this lane's segment, then xor-reduce
-    c = gf_mulmod(c, gf_xpow8(total - end));
+    for (uint32_t i = beg; i < end; i++) c = (c << 8) ^ T[0][(c >> 24) ^ rp[i]];
+    c = gf_mulmod(c, gf_xpow8(rem - end)) ^ acc;
+    // xor-reduce over the block
     for (int o = 32; o; o >>= 1) c ^= __shfl_xor(c, o);
-    if (lane == 0) {
+    if ((tid & 63) == 0) part[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) {
+        c = part[0] ^ part[1] ^ part[2] ^ part[3];
         out[len + 4] = uint8_t(c >> 24); out[len + 5] = uint8_t(c >> 16); out[len + 6] = uint8_t(c >> 8); out[len + 7] = uint8_t(c);
         tot_len[chain] = len + 8;
     }
@@ -963,12 +1000,14 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
                                                       (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events); }));
         HIP_TRY(hipEventRecord(e->ev_k4[j], s2));
     }
-    HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[nseg - 1], 0));
-    HIP_TRY(timed(4, st, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(64), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+    // footer / scan / gather follow the last range-coder segment on its stream; the caller's stream then joins
+    HIP_TRY(timed(4, s2, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));
-    HIP_TRY(timed(5, st, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, st, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
-    HIP_TRY(timed(6, st, [&] { hipLaunchKernelGGL(k_gather, dim3(8, nchains), dim3(256), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+    HIP_TRY(timed(5, s2, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, s2, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
+    HIP_TRY(timed(6, s2, [&] { hipLaunchKernelGGL(k_gather, dim3(8, nchains), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
+    HIP_TRY(hipEventRecord(e->ev_fork, s2));
+    HIP_TRY(hipStreamWaitEvent(st, e->ev_fork, 0));
     HIP_TRY(hipGetLastError());
     e->ev_valid = true; e->last_n = n;
     return 0;
@@ -978,7 +1017,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
 extern "C" int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap)
 {
     if (!e || !e->ev_valid || !e->ev_used) return 0;
-    if (hipEventSynchronize(e->ev[e->ev_used - 1]) != hipSuccess) return 0;
+    for (size_t i = 0; i < e->ev_used; i++) if (hipEventSynchronize(e->ev[i]) != hipSuccess) return 0;
     int k = 0;
     for (; k < rcgpu_ffv1::kNumK && k < cap; k++) { names[k] = kKernelNames[k]; ms[k] = 0; }
     for (size_t i = 0; i < e->ev_kernel.size(); i++) {
