@@ -158,10 +158,25 @@ int rcgpu_ffv1_last_kernel_launches(const rcgpu_ffv1* enc, int index);   /* laun
 /* Totals of the last batch (valid after the stream is synchronised): binary range-coder decisions and packet bytes. */
 int rcgpu_ffv1_last_stats(const rcgpu_ffv1* enc, uint64_t* decisions, uint64_t* packet_bytes);
 
-/* FFV1 decoder (device) for the --check path: restates ffv1_frame::Process + Transform::From on the GPU and
- * returns the rebuilt payload (padding bits zero).  d_payloads[i] receives data_size bytes. */
-int rcgpu_ffv1_decode_device(rcgpu_ffv1* enc, const void* const* d_packets, const uint64_t* packet_sizes, uint32_t n,
-                             void* const* d_payloads, void* hip_stream);
+/* ---- FFV1 decoder + verification (device): the `--check` half (BASELINE config 5).  Restates ffv1_frame::Process
+ * (FFV1_Frame.cpp:134-228), slice::Parse/Line (FFV1_Slice.cpp:210-472), rangecoder (FFV1_RangeCoder.cpp:71-305) and
+ * Transform::From (Lib/Transform/Transform.cpp) on the GPU; the comparison semantics are frame_writer's
+ * (Lib/Utils/FileIO/FileWriter.cpp:448-463 byte compare, :596-727 MD5).  The configuration is the encoder's
+ * (same struct; `segments` ignored): it must describe the stream being decoded. */
+typedef struct rcgpu_ffv1_decoder rcgpu_ffv1_decoder;
+int  rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1_decoder** dec);
+void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* dec);
+/* Decode n (<= max_batch) packets resident in device memory into n payload buffers in device memory (data_size bytes
+ * each, padding bits zero -- the caller XORs the reversibility `InData`, RawFrame.cpp:184-206).  When h_err_flags is
+ * not NULL the call synchronises and returns an error if any slice failed (bad split 1|2, CRC 4, header 32, underrun 64,
+ * junk 128, error_status 256); with NULL it is asynchronous on `hip_stream`. */
+int  rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* dec, const void* const* d_packets, const uint64_t* packet_sizes, uint32_t n,
+                                      void* const* d_payloads, uint32_t* h_err_flags, void* hip_stream);
+int  rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* dec, float ms[3]);   /* split+crc, slices, pack */
+/* First differing byte of two device buffers; *first_diff = UINT64_MAX when they are equal (FileWriter.cpp:448-463). */
+int  rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t* first_diff, void* hip_stream);
+/* MD5 of n device buffers, one lane per buffer; out_md5 = n x 16 bytes on the host (FileWriter.cpp:596-727). */
+int  rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, void* hip_stream);
 
 /* ===========================================================================================
  * 4. FLAC encoder (device) -- replaces FFmpeg's flacenc; inverse of flac_wrapper (Lib/CoDec/Wrapper.cpp:131-373)

@@ -79,7 +79,12 @@ SYMBOLS = {
     "rcgpu_ffv1_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "rcgpu_ffv1_last_kernel_launches": (C.c_int, [_VP, C.c_int]),
     "rcgpu_ffv1_last_stats": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "rcgpu_ffv1_decode_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP), _VP]),
+    "rcgpu_ffv1_decoder_create": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP)]),
+    "rcgpu_ffv1_decoder_destroy": (None, [_VP]),
+    "rcgpu_ffv1_decoder_decode_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP), C.POINTER(C.c_uint32), _VP]),
+    "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
+    "rcgpu_compare_device": (C.c_int, [_VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
+    "rcgpu_md5_device": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _VP, _VP]),
     "rcgpu_flac_create": (C.c_int, [C.POINTER(FlacConfig), C.POINTER(_VP)]),
     "rcgpu_flac_destroy": (None, [_VP]),
     "rcgpu_flac_encode_host": (C.c_int, [_VP, _VP, C.c_uint64, _VP, _SZ, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -211,6 +216,50 @@ class Ffv1Encoder:
         if n < 0:
             raise RcgpuError(f"rcgpu_ffv1_debug_fetch({what}) -> {n}")
         return buf.raw[:n]
+
+
+class Ffv1Decoder:
+    """Device FFV1 decoder + pack (the --check half).  Buffers are device pointers (ints)."""
+
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, 0)
+        self.h = _VP()
+        _check(lib().rcgpu_ffv1_decoder_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_decoder_create")
+
+    def close(self):
+        if self.h:
+            lib().rcgpu_ffv1_decoder_destroy(self.h)
+            self.h = _VP()
+
+    __del__ = close
+
+    def decode_device(self, packet_ptrs: list[int], packet_sizes: list[int], payload_ptrs: list[int], stream: int = 0, check: bool = True) -> int:
+        n = len(packet_ptrs)
+        pk = (_VP * n)(*packet_ptrs)
+        sz = (C.c_uint64 * n)(*packet_sizes)
+        out = (_VP * n)(*payload_ptrs)
+        flags = C.c_uint32(0)
+        _check(lib().rcgpu_ffv1_decoder_decode_device(self.h, pk, sz, n, out, C.byref(flags) if check else None, stream), "rcgpu_ffv1_decoder_decode_device")
+        return flags.value
+
+    def kernel_times(self) -> dict[str, float]:
+        ms = (C.c_float * 3)()
+        lib().rcgpu_ffv1_decoder_last_kernel_times(self.h, ms)
+        return {"k_dec_split+k_dec_crc": float(ms[0]), "k_dec_slices": float(ms[1]), "k_pack": float(ms[2])}
+
+
+def compare_device(a: int, b: int, n: int, stream: int = 0) -> int:
+    """-> index of the first differing byte, or -1."""
+    r = C.c_uint64()
+    _check(lib().rcgpu_compare_device(a, b, n, C.byref(r), stream), "rcgpu_compare_device")
+    return -1 if r.value == 0xFFFFFFFFFFFFFFFF else r.value
+
+
+def md5_device(ptrs: list[int], sizes: list[int], stream: int = 0) -> list[bytes]:
+    n = len(ptrs)
+    out = C.create_string_buffer(16 * n)
+    _check(lib().rcgpu_md5_device((_VP * n)(*ptrs), (C.c_uint64 * n)(*sizes), n, out, stream), "rcgpu_md5_device")
+    return [out.raw[16 * i:16 * i + 16] for i in range(n)]
 
 
 class FlacEncoder:

@@ -1,0 +1,473 @@
+// ffv1_check.hip -- the `--check` half on the device (BASELINE config 5): FFV1 packets -> rebuilt payload bytes,
+// byte comparison with the source and MD5, for MI355X (gfx950).
+//
+// What it restates: ffv1_frame::Process (Lib/CoDec/FFV1/FFV1_Frame.cpp:134-228: slice split from the tail sizes),
+// slice::Parse / SliceHeader / Line (FFV1_Slice.cpp:113-177,210-318,447-472), rangecoder::b/u/s
+// (FFV1_RangeCoder.cpp:71-305), the slice CRC (FFV1_Slice.cpp:247-249), Transform::From (Lib/Transform/Transform.cpp:
+// inverse RCT + packers) and the compare / MD5 of frame_writer (Lib/Utils/FileIO/FileWriter.cpp:448-463,596-727).
+//
+// Decoding is serial per slice in both recurrences AND in the context model (the context of a sample depends on the
+// sample decoded just before it), so there is nothing for a wavefront to share: the mapping is one LANE per slice,
+// 64 slices per wavefront, thousands of slices in flight.  Context states live in HBM (32 bytes per context, one
+// gather + one write-back per sample through a per-lane LDS slot); previous lines are read back from the output planes.
+//   k_dec_split   thread / frame    walk the 24-bit slice sizes from the packet tail
+//   k_dec_crc     block  / slice    CRC-32 over the whole slice must be 0 (ec = 1)
+//   k_dec_slices  LANE   / slice    range decoder + median predictor + contexts -> planar int32
+//   k_pack        thread / pixel    inverse RCT + pack into the file layout (padding bits zero)
+//   k_compare     grid-stride       byte compare of two buffers -> first mismatch
+//   k_md5         LANE   / buffer   RFC 1321, one buffer per lane
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
+#include "ffv1_host.h"
+#include "rc_common.h"
+
+using namespace rc;
+
+namespace {
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+struct dec_const {
+    uint32_t W, H, line_bytes, pixfmt;
+    uint32_t planes, bps, bits, rgb, gb_swap, big_endian, bytes_pp, overflow16;
+    uint32_t num_h, num_v, S, nctx, nsets, ec, is5, index_count, qidx;
+    int16_t  q[5][256];
+    uint8_t  one_state[256], zero_state[256];
+};
+
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_dec_split(const dec_const* __restrict__ C, const uint8_t* const* __restrict__ packets,
+                            const unsigned long long* __restrict__ sizes, uint32_t n,
+                            unsigned long long* __restrict__ slice_start, uint32_t* __restrict__ slice_len, uint32_t* __restrict__ err)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    const uint8_t* p = packets[f];
+    const uint32_t tail = C->ec ? 8 : 3, S = C->S;
+    unsigned long long pos = sizes[f];
+    uint32_t count = 0;
+    while (pos && count < S) {                               // FFV1_Frame.cpp:177-198
+        if (pos < tail) { atomicOr(err, 1u); break; }
+        const unsigned long long sz = ((unsigned long long)p[pos - tail] << 16 | (unsigned long long)p[pos - tail + 1] << 8 | p[pos - tail + 2]) + tail;
+        if (sz > pos) { atomicOr(err, 1u); break; }
+        pos -= sz;
+        slice_start[f * S + count] = pos; slice_len[f * S + count] = uint32_t(sz);
+        count++;
+    }
+    if (pos || count != S) atomicOr(err, 2u);
+    for (; count < S; count++) { slice_start[f * S + count] = 0; slice_len[f * S + count] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_dec_crc(const dec_const* __restrict__ C, const uint8_t* const* __restrict__ packets,
+                                                 const unsigned long long* __restrict__ slice_start, const uint32_t* __restrict__ slice_len,
+                                                 uint32_t* __restrict__ err)
+{
+    __shared__ uint32_t T[256]; __shared__ uint32_t part[4];
+    const int tid = threadIdx.x;
+    { uint32_t c = uint32_t(tid) << 24; for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1); T[tid] = c; }
+    __syncthreads();
+    const uint32_t chain = blockIdx.x, f = chain / C->S;
+    const uint8_t* p = packets[f] + slice_start[chain];
+    const uint32_t total = slice_len[chain];
+    const uint32_t seg = (total + 255) / 256;
+    const uint32_t beg = min(total, uint32_t(tid) * seg), end = min(total, beg + seg);
+    uint32_t c = 0;
+    for (uint32_t i = beg; i < end; i++) c = (c << 8) ^ T[(c >> 24) ^ p[i]];
+    // crc(A||B) = crc(A) * x^(8|B|) + crc(B)
+    unsigned long long nb = total - end; uint32_t result = 1, base = 0x100;
+    auto mulmod = [](uint32_t a, uint32_t b) { uint32_t r = 0; for (int i = 31; i >= 0; i--) { r = (r << 1) ^ ((r >> 31) ? 0x04C11DB7u : 0u); if ((b >> i) & 1) r ^= a; } return r; };
+    while (nb) { if (nb & 1) result = mulmod(result, base); base = mulmod(base, base); nb >>= 1; }
+    c = mulmod(c, result);
+    for (int o = 32; o; o >>= 1) c ^= __shfl_xor(c, o);
+    if ((tid & 63) == 0) part[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0 && (part[0] ^ part[1] ^ part[2] ^ part[3])) atomicOr(err, 4u);       // FFV1-SLICE-slice_crc_parity
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Range decoder state of one lane (rangecoder, FFV1_RangeCoder.cpp:21-102)
+struct rd_lane { uint32_t current, mask; const uint8_t* cur; const uint8_t* end; };
+
+__device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* st, const uint8_t* trans)
+{
+    if (r.mask < 0x100) {
+        r.current <<= 8;
+        if (r.cur > r.end) return 0;                        // underrun: zeros
+        if (r.cur < r.end) r.current |= *r.cur;
+        r.mask <<= 8;
+        r.cur++;
+    }
+    const uint32_t s = *st;
+    const uint32_t m2 = (r.mask * s) >> 8;
+    r.mask -= m2;
+    if (r.current < r.mask) { *st = trans[s]; return 0; }
+    r.current -= r.mask; r.mask = m2; *st = trans[256 + s];
+    return 1;
+}
+__device__ uint32_t rd_u(rd_lane& r, uint8_t* st, const uint8_t* trans)
+{
+    if (rd_bit(r, st, trans)) return 0;
+    int e = 0;
+    while (rd_bit(r, st + 1 + (e < 9 ? e : 9), trans)) { if (++e > 31) return 0; }
+    uint32_t a = 1;
+    for (int i = e - 1; i >= 0; i--) a = (a << 1) | rd_bit(r, st + 22 + (i < 9 ? i : 9), trans);
+    return a;
+}
+__device__ int32_t rd_s(rd_lane& r, uint8_t* st, const uint8_t* trans)
+{
+    if (rd_bit(r, st, trans)) return 0;
+    int e = 0;
+    while (rd_bit(r, st + 1 + (e < 9 ? e : 9), trans)) { if (++e > 31) return 0; }
+    int32_t a = 1;
+    for (int i = e - 1; i >= 0; i--) a = (a << 1) | int32_t(rd_bit(r, st + 22 + (i < 9 ? i : 9), trans));
+    return rd_bit(r, st + 11 + (e < 10 ? e : 10), trans) ? -a : a;
+}
+__device__ __forceinline__ int32_t med3(int32_t a, int32_t b, int32_t c) { return max(min(a, b), min(max(a, b), c)); }
+
+__global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__ C, const uint8_t* const* __restrict__ packets,
+                                                   const unsigned long long* __restrict__ slice_start, const uint32_t* __restrict__ slice_len,
+                                                   uint32_t nchains, uint8_t* __restrict__ states, uint32_t nkeys,
+                                                   int32_t* __restrict__ planes, uint32_t* __restrict__ err)
+{
+    __shared__ uint8_t trans[512];
+    __shared__ int16_t q[5][256];
+    __shared__ __attribute__((aligned(16))) uint8_t slot[64 * 32];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; }
+    for (int i = lane; i < 5 * 256; i += 64) (&q[0][0])[i] = (&C->q[0][0])[i];
+    __syncthreads();
+    const uint32_t chain = blockIdx.x * 64 + lane;
+    if (chain >= nchains) return;
+    const uint32_t S = C->S, f = chain / S;
+    const uint32_t tail = C->ec ? 8 : 3;
+    const uint32_t len = slice_len[chain];
+    if (len < tail) { atomicOr(err, 8u); return; }
+    const uint8_t* buf = packets[f] + slice_start[chain];
+    rd_lane r;
+    r.cur = buf; r.end = buf + (len - tail);
+    r.current = len - tail ? *r.cur : 0; r.mask = 0xFF; r.cur++;                   // AssignBuffer, FFV1_RangeCoder.cpp:22-33
+    uint8_t* my = slot + lane * 32;
+    auto fresh = [&]() { uint4* p = reinterpret_cast<uint4*>(my); p[0] = p[1] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u); };
+    if (slice_start[chain] == 0) { fresh(); if (!rd_bit(r, my, trans)) atomicOr(err, 16u); }     // keyframe bit of the first slice in the packet
+    // slice header, FFV1_Slice.cpp:113-177
+    fresh();
+    const uint32_t sx = rd_u(r, my, trans), sy = rd_u(r, my, trans);
+    const uint32_t sw1 = rd_u(r, my, trans), sh1 = rd_u(r, my, trans);
+    bool bad = sx >= C->num_h || sy >= C->num_v || sw1 || sh1;
+    for (uint32_t i = 0; i < C->index_count; i++) bad |= rd_u(r, my, trans) != C->qidx;
+    (void)rd_u(r, my, trans); (void)rd_u(r, my, trans); (void)rd_u(r, my, trans);
+    if (bad) { atomicOr(err, 32u); return; }
+    const uint32_t W = C->W, H = C->H, np = C->planes;
+    const uint32_t x0 = uint32_t((unsigned long long)sx * W / C->num_h), y0 = uint32_t((unsigned long long)sy * H / C->num_v);
+    const uint32_t w = uint32_t((unsigned long long)(sx + 1) * W / C->num_h) - x0, h = uint32_t((unsigned long long)(sy + 1) * H / C->num_v) - y0;
+    const size_t plane_sz = size_t(W) * H;
+    int32_t* fp = planes + size_t(f) * np * plane_sz + size_t(y0) * W + x0;
+    uint8_t* st_base = states + size_t(chain) * nkeys * 32;          // pre-set to 128 by the host (states_coded = 0)
+    const bool is5 = C->is5, ov16 = C->overflow16, rgb = C->rgb;
+    const int32_t bitmask = int32_t((1u << C->bits) - 1);
+    const uint32_t nctx = C->nctx;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t p = 0; p < np; p++) {
+            int32_t* cur = fp + p * plane_sz + size_t(y) * W;
+            const int32_t* prev = cur - W;                            // valid when y >= 1
+            const int32_t* pp = cur - 2 * size_t(W);                  // valid when y >= 2
+            const uint32_t set = rgb ? (p + 1) >> 1 : 0;
+            // edge rules of SliceContent_LineThenPlane (FFV1_Slice.cpp:427-441): cur[-1] = prev[0], prev[w] = prev[w-1],
+            // everything above the slice is 0, cur[-2] is 0
+            int32_t L = y ? prev[0] : 0, LL = 0;
+            int32_t LT = y >= 2 ? pp[0] : 0;
+            int32_t T = y ? prev[0] : 0;
+            for (uint32_t x = 0; x < w; x++) {
+                const int32_t RT = y ? (x + 1 < w ? prev[x + 1] : T) : 0;
+                const int32_t TT = y >= 2 ? pp[x] : 0;
+                int32_t ctx = q[0][(L - LT) & 0xFF] + q[1][(LT - T) & 0xFF] + q[2][(T - RT) & 0xFF];
+                if (is5) ctx += q[3][(LL - L) & 0xFF] + q[4][(TT - T) & 0xFF];
+                int32_t v = ov16 ? med3(int16_t(L), int16_t(L) + int16_t(T) - int16_t(LT), int16_t(T)) : med3(L, L + T - LT, T);
+                const uint32_t key = set * nctx + uint32_t(ctx < 0 ? -ctx : ctx);
+                uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
+                uint4* sp = reinterpret_cast<uint4*>(my);
+                sp[0] = gp[0]; sp[1] = gp[1];
+                const int32_t delta = rd_s(r, my, trans);
+                gp[0] = sp[0]; gp[1] = sp[1];
+                v = (ctx >= 0 ? v + delta : v - delta) & bitmask;
+                cur[x] = v;
+                LL = L; L = v; LT = T; T = RT;
+            }
+        }
+    // end-of-slice bit, underrun and junk checks (FFV1_Slice.cpp:286-299,336-340)
+    my[0] = 129; rd_bit(r, my, trans);
+    const bool underrun = r.cur - (r.mask < 0x100 ? 0 : 1) > r.end;
+    const size_t used = r.cur > r.end ? size_t(r.end - buf) : size_t(r.cur - buf) - (r.mask < 0x100 ? 0 : 1);
+    if (underrun) atomicOr(err, 64u);
+    if (used < len - tail) atomicOr(err, 128u);
+    if (C->ec && buf[len - 5]) atomicOr(err, 256u);                  // error_status
+}
+
+// inverse of k_unpack: JPEG2000RCT (Transform.cpp:29-37) + packers; whole lines incl. DPX padding are written
+__device__ __forceinline__ void st16(uint8_t* p, uint32_t v, bool be) { if (be) { p[0] = uint8_t(v >> 8); p[1] = uint8_t(v); } else { p[0] = uint8_t(v); p[1] = uint8_t(v >> 8); } }
+
+__global__ __launch_bounds__(256) void k_pack(const dec_const* __restrict__ C, const int32_t* __restrict__ planes, uint8_t* const* __restrict__ payloads)
+{
+    const uint32_t W = C->W, H = C->H;
+    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= W * H) return;
+    const uint32_t f = blockIdx.y, y = pix / W, x = pix - y * W;
+    const size_t plane_sz = size_t(W) * H;
+    const int32_t* src = planes + size_t(f) * C->planes * plane_sz + pix;
+    uint8_t* line = payloads[f] + size_t(y) * C->line_bytes;
+    uint8_t* p = line + size_t(x) * C->bytes_pp;
+    const bool be = C->big_endian;
+    uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
+    if (!C->rgb) c0 = uint32_t(src[0]);
+    else {
+        int32_t g = src[0], b = src[plane_sz], r = src[2 * plane_sz];
+        const int32_t off = int32_t(1) << C->bps;
+        b -= off; r -= off; g -= (b + r) >> 2; b += g; r += g;
+        if (C->gb_swap) { const int32_t t = g; g = b; b = t; }
+        c0 = uint32_t(r); c1 = uint32_t(g); c2 = uint32_t(b);
+        if (C->planes == 4) c3 = uint32_t(src[3 * plane_sz]);
+    }
+    switch (C->pixfmt) {
+    case RCGPU_PIX_RGB8: p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2); break;
+    case RCGPU_PIX_RGBA8: p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2); p[3] = uint8_t(c3); break;
+    case RCGPU_PIX_RGB10_FILLEDA_BE: case RCGPU_PIX_RGB10_FILLEDA_LE: {
+        uint32_t w = ((c0 & 0x3FF) << 22) | ((c1 & 0x3FF) << 12) | ((c2 & 0x3FF) << 2);
+        if (be) w = __builtin_bswap32(w);
+        *reinterpret_cast<uint32_t*>(p) = w; break; }
+    case RCGPU_PIX_RGB12_FILLEDA_BE: case RCGPU_PIX_RGB12_FILLEDA_LE:
+        st16(p, (c0 << 4) & 0xFFFF, be); st16(p + 2, (c1 << 4) & 0xFFFF, be); st16(p + 4, (c2 << 4) & 0xFFFF, be); break;
+    case RCGPU_PIX_RGB16_BE: case RCGPU_PIX_RGB16_LE:
+        st16(p, c0 & 0xFFFF, be); st16(p + 2, c1 & 0xFFFF, be); st16(p + 4, c2 & 0xFFFF, be); break;
+    case RCGPU_PIX_RGBA16_BE: case RCGPU_PIX_RGBA16_LE:
+        st16(p, c0 & 0xFFFF, be); st16(p + 2, c1 & 0xFFFF, be); st16(p + 4, c2 & 0xFFFF, be); st16(p + 6, c3 & 0xFFFF, be); break;
+    case RCGPU_PIX_Y8: p[0] = uint8_t(c0); break;
+    default: st16(p, c0 & 0xFFFF, be); break;
+    }
+    if (x == W - 1)                                   // DPX lines are padded to 32 bit (RawFrame.cpp:109): zero the padding
+        for (uint32_t i = W * C->bytes_pp; i < C->line_bytes; i++) line[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_compare(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, unsigned long long n,
+                                                 unsigned long long* __restrict__ first_diff)
+{
+    unsigned long long best = ~0ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256)
+        if (a[i] != b[i]) { best = i; break; }
+    if (best != ~0ull) atomicMin(first_diff, best);
+}
+
+// RFC 1321, one buffer per lane (the hash is serial per buffer; many buffers are in flight)
+__device__ __forceinline__ uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+__global__ __launch_bounds__(64) void k_md5(const uint8_t* const* __restrict__ bufs, const unsigned long long* __restrict__ sizes, uint32_t n,
+                                            uint8_t* __restrict__ out)
+{
+    const uint32_t K[64] = {
+        0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,0x698098d8,0x8b44f7af,0xffff5bb1,0x895cd7be,0x6b901122,0xfd987193,0xa679438e,0x49b40821,
+        0xf61e2562,0xc040b340,0x265e5a51,0xe9b6c7aa,0xd62f105d,0x02441453,0xd8a1e681,0xe7d3fbc8,0x21e1cde6,0xc33707d6,0xf4d50d87,0x455a14ed,0xa9e3e905,0xfcefa3f8,0x676f02d9,0x8d2a4c8a,
+        0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
+        0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391 };
+    const int S[16] = { 7, 12, 17, 22, 5, 9, 14, 20, 4, 11, 16, 23, 6, 10, 15, 21 };
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = bufs[i];
+    const unsigned long long size = sizes[i];
+    uint32_t h0 = 0x67452301, h1 = 0xefcdab89, h2 = 0x98badcfe, h3 = 0x10325476;
+    const unsigned long long total = ((size + 8) / 64 + 1) * 64;
+    for (unsigned long long off = 0; off < total; off += 64) {
+        uint32_t m[16];
+        if (off + 64 <= size && !(reinterpret_cast<uintptr_t>(p) & 3)) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(p + off);
+#pragma unroll
+            for (int k = 0; k < 16; k++) m[k] = w[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint32_t v = 0;
+                for (int b = 0; b < 4; b++) {
+                    const unsigned long long q = off + 4 * k + b;
+                    uint32_t byte = q < size ? p[q] : (q == size ? 0x80u : 0u);
+                    if (off + 64 == total && 4 * k + b >= 56) byte = uint32_t(((size * 8) >> (8 * (4 * k + b - 56))) & 0xFF);
+                    v |= byte << (8 * b);
+                }
+                m[k] = v;
+            }
+        }
+        uint32_t a = h0, b = h1, c = h2, d = h3;
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            uint32_t fn; int g;
+            if (r < 16) { fn = (b & c) | (~b & d); g = r; }
+            else if (r < 32) { fn = (d & b) | (~d & c); g = (5 * r + 1) & 15; }
+            else if (r < 48) { fn = b ^ c ^ d; g = (3 * r + 5) & 15; }
+            else { fn = c ^ (b | ~d); g = (7 * r) & 15; }
+            const uint32_t t = d; d = c; c = b; b = b + rol(a + fn + K[r] + m[g], S[(r >> 4) * 4 + (r & 3)]); a = t;
+        }
+        h0 += a; h1 += b; h2 += c; h3 += d;
+    }
+    const uint32_t hh[4] = { h0, h1, h2, h3 };
+    for (int k = 0; k < 16; k++) out[size_t(i) * 16 + k] = uint8_t(hh[k / 4] >> (8 * (k % 4)));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+struct rcgpu_ffv1_decoder {
+    rcgpu_ffv1_config cfg{};
+    dec_const hc{};
+    uint32_t nkeys = 0;
+    size_t payload_bytes = 0;
+    dec_const* d_const = nullptr;
+    const uint8_t** d_pkt_ptrs = nullptr; uint8_t** d_out_ptrs = nullptr; unsigned long long* d_sizes = nullptr;
+    unsigned long long* d_slice_start = nullptr; uint32_t* d_slice_len = nullptr;
+    uint8_t* d_states = nullptr; int32_t* d_planes = nullptr; uint32_t* d_err = nullptr;
+    void** h_ptrs = nullptr; unsigned long long* h_sizes = nullptr;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev[8]{};
+    bool ev_valid = false;
+};
+
+extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->cfg.device);
+    void* bufs[] = { d->d_const, d->d_pkt_ptrs, d->d_out_ptrs, d->d_sizes, d->d_slice_start, d->d_slice_len, d->d_states, d->d_planes, d->d_err };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (d->h_ptrs) (void)hipHostFree(d->h_ptrs);
+    if (d->h_sizes) (void)hipHostFree(d->h_sizes);
+    for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
+    if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+    delete d;
+}
+
+extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1_decoder** out)
+{
+    clear_error();
+    if (!cfg || !out) return fail(1, "ffv1 decoder: null argument");
+    *out = nullptr;
+    if (cfg->pixfmt >= RCGPU_PIX_COUNT || !cfg->width || !cfg->height || !cfg->num_h_slices || !cfg->num_v_slices || !cfg->max_batch)
+        return fail(2, "ffv1 decoder: bad configuration");
+    const pix_desc& px = pix(cfg->pixfmt);
+    if (cfg->line_bytes < cfg->width * px.bytes_pp) return fail(2, "ffv1 decoder: line_bytes smaller than a line");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(3, "ffv1 decoder: no HIP device available -- there is no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(3, "ffv1 decoder: device %d out of range", cfg->device);
+    HIP_TRY(hipSetDevice(cfg->device));
+    rcgpu_ffv1_decoder* d = new rcgpu_ffv1_decoder;
+    d->cfg = *cfg;
+    ffv1::quant_model qm[2];
+    ffv1::build_quant_models(px.bits, qm);
+    const uint32_t qidx = cfg->context ? 1 : 0;
+    const ffv1::quant_model& Q = qm[qidx];
+    dec_const& c = d->hc;
+    c.W = cfg->width; c.H = cfg->height; c.line_bytes = cfg->line_bytes; c.pixfmt = cfg->pixfmt;
+    c.planes = px.planes; c.bps = px.bits; c.rgb = px.planes != 1; c.gb_swap = px.gb_swap; c.big_endian = px.big_endian; c.bytes_pp = px.bytes_pp;
+    c.bits = c.rgb ? px.bits + 1 : (px.bits <= 8 ? 8 : px.bits);
+    c.overflow16 = (!c.rgb && px.bits == 16);
+    c.num_h = cfg->num_h_slices; c.num_v = cfg->num_v_slices; c.S = c.num_h * c.num_v; c.nctx = Q.context_count;
+    c.nsets = c.rgb ? (px.planes == 4 ? 3 : 2) : 1; c.ec = cfg->slicecrc ? 1 : 0; c.is5 = Q.q[3][127] != 0;
+    c.index_count = c.rgb ? (px.planes == 4 ? 3u : 2u) : 2u; c.qidx = qidx;
+    memcpy(c.q, Q.q, sizeof c.q);
+    memcpy(c.one_state, ffv1::kOneState, 256);
+    ffv1::make_zero_state(c.zero_state);
+    d->nkeys = c.nsets * c.nctx;
+    d->payload_bytes = size_t(cfg->line_bytes) * cfg->height;
+    const uint32_t F = cfg->max_batch; const size_t nchains = size_t(F) * c.S;
+    hipError_t he = hipSuccess;
+#define DM(p, b) if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&(p)), (b))
+    DM(d->d_const, sizeof c); DM(d->d_pkt_ptrs, sizeof(void*) * F); DM(d->d_out_ptrs, sizeof(void*) * F); DM(d->d_sizes, 8 * F);
+    DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32);
+    DM(d->d_planes, size_t(F) * c.planes * c.W * c.H * 4); DM(d->d_err, 16);
+#undef DM
+    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_ptrs), sizeof(void*) * F * 2);
+    if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_sizes), 8 * F);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking);
+    for (auto& e : d->ev) if (he == hipSuccess) he = hipEventCreate(&e);
+    if (he == hipSuccess) he = hipMemcpy(d->d_const, &c, sizeof c, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { const int r = fail(100, "ffv1 decoder: device setup failed: %s", hipGetErrorString(he)); rcgpu_ffv1_decoder_destroy(d); return r; }
+    *out = d;
+    return 0;
+}
+
+// Decode n packets (device memory) into n payload buffers (device memory, data_size bytes each).  Asynchronous on the
+// stream; *d_err_out (device, optional) receives the error flags -- 0 means every slice parsed, CRCs matched, no junk.
+extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const void* const* d_packets, const uint64_t* packet_sizes, uint32_t n,
+                                                void* const* d_payloads, uint32_t* h_err_flags, void* hip_stream)
+{
+    clear_error();
+    if (!d || !d_packets || !packet_sizes || !d_payloads) return fail(1, "ffv1 decoder: null argument");
+    if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : d->own_stream;
+    const dec_const& c = d->hc;
+    const uint32_t nchains = n * c.S;
+    for (uint32_t i = 0; i < n; i++) { d->h_ptrs[i] = const_cast<void*>(d_packets[i]); d->h_ptrs[d->cfg.max_batch + i] = d_payloads[i]; d->h_sizes[i] = packet_sizes[i]; }
+    HIP_TRY(hipMemcpyAsync(d->d_pkt_ptrs, d->h_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d->d_out_ptrs, d->h_ptrs + d->cfg.max_batch, sizeof(void*) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d->d_sizes, d->h_sizes, 8 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d->d_err, 0, 16, st));
+    HIP_TRY(hipMemsetAsync(d->d_states, 128, size_t(nchains) * d->nkeys * 32, st));          // states_coded = 0: every state starts at 128
+    HIP_TRY(hipEventRecord(d->ev[0], st));
+    hipLaunchKernelGGL(k_dec_split, dim3((n + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_sizes, n, d->d_slice_start, d->d_slice_len, d->d_err);
+    if (c.ec) hipLaunchKernelGGL(k_dec_crc, dim3(nchains), dim3(256), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, d->d_err);
+    HIP_TRY(hipEventRecord(d->ev[1], st));
+    hipLaunchKernelGGL(k_dec_slices, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
+                       d->d_states, d->nkeys, d->d_planes, d->d_err);
+    HIP_TRY(hipEventRecord(d->ev[2], st));
+    hipLaunchKernelGGL(k_pack, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, d->d_const, d->d_planes, d->d_out_ptrs);
+    HIP_TRY(hipEventRecord(d->ev[3], st));
+    HIP_TRY(hipGetLastError());
+    d->ev_valid = true;
+    if (h_err_flags) {
+        HIP_TRY(hipMemcpyAsync(h_err_flags, d->d_err, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (*h_err_flags) return fail(210, "ffv1 decoder: undecodable frame in the batch (flags 0x%x)", *h_err_flags);
+    }
+    return 0;
+}
+
+extern "C" int rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* d, float ms[3])
+{
+    if (!d || !d->ev_valid || hipEventSynchronize(d->ev[3]) != hipSuccess) return 1;
+    for (int k = 0; k < 3; k++) (void)hipEventElapsedTime(&ms[k], d->ev[k], d->ev[k + 1]);
+    return 0;
+}
+
+// First differing byte of two device buffers (frame_writer::CheckFile, FileWriter.cpp:448-463); *first_diff = ~0 when equal.
+extern "C" int rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t* first_diff, void* hip_stream)
+{
+    clear_error();
+    if (!d_a || !d_b || !first_diff) return fail(1, "compare: null argument");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    unsigned long long* d_res = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_res), 8));
+    hipError_t he = hipMemsetAsync(d_res, 0xFF, 8, st);
+    if (he == hipSuccess) { hipLaunchKernelGGL(k_compare, dim3(2048), dim3(256), 0, st, static_cast<const uint8_t*>(d_a), static_cast<const uint8_t*>(d_b), (unsigned long long)n, d_res); he = hipGetLastError(); }
+    unsigned long long r = 0;
+    if (he == hipSuccess) he = hipMemcpyAsync(&r, d_res, 8, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    (void)hipFree(d_res);
+    if (he != hipSuccess) return fail(100, "compare: %s", hipGetErrorString(he));
+    *first_diff = r;
+    return 0;
+}
+
+// MD5 of n device buffers, one lane each (frame_writer::CheckMD5, FileWriter.cpp:596-727; Input_Base.cpp:54-81).
+extern "C" int rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5 /* n x 16, host */, void* hip_stream)
+{
+    clear_error();
+    if (!d_bufs || !sizes || !out_md5 || !n) return fail(1, "md5: null argument");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const uint8_t** d_p = nullptr; unsigned long long* d_s = nullptr; uint8_t* d_o = nullptr;
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_p), sizeof(void*) * n);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_s), 8 * n);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_o), 16 * n);
+    if (he == hipSuccess) he = hipMemcpy(d_p, d_bufs, sizeof(void*) * n, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(d_s, sizes, 8 * n, hipMemcpyHostToDevice);
+    if (he == hipSuccess) { hipLaunchKernelGGL(k_md5, dim3((n + 63) / 64), dim3(64), 0, st, d_p, d_s, n, d_o); he = hipGetLastError(); }
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he == hipSuccess) he = hipMemcpy(out_md5, d_o, 16 * n, hipMemcpyDeviceToHost);
+    for (void* p : { (void*)d_p, (void*)d_s, (void*)d_o }) if (p) (void)hipFree(p);
+    if (he != hipSuccess) return fail(100, "md5: %s", hipGetErrorString(he));
+    return 0;
+}

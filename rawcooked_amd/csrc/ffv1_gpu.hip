@@ -1131,8 +1131,3 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
     default: return -5;
     }
 }
-
-extern "C" int rcgpu_ffv1_decode_device(rcgpu_ffv1*, const void* const*, const uint64_t*, uint32_t, void* const*, void*)
-{
-    return fail(200, "ffv1: device decoder (--check path) is not built yet");
-}
