@@ -79,6 +79,52 @@ def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int, 
             "sample": f"{nfr} frames of the same {width}x{height} RGB16 workload, one frame per thread, oracle/ffv1_oracle.c (scalar C, not FFmpeg)"}
 
 
+def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device):
+    """Config 5: decode the MKV payloads back and verify them -- everything resident in HBM (single GPU)."""
+    enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
+    torch.cuda.synchronize()
+    sizes = d_sizes.cpu().tolist()
+    dec = api.Ffv1Decoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=F, device=device)
+    outs = torch.empty((F, line_bytes * height), dtype=torch.uint8, device=frames.device)
+    pk = [d_packets.data_ptr() + i * stride for i in range(F)]
+    op = [outs[i].data_ptr() for i in range(F)]
+
+    def step():
+        dec.decode_device(pk, sizes, op, stream, check=False)
+
+    for _ in range(max(0, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = dec.kernel_times()
+    t1 = time.perf_counter()
+    same = all(api.compare_device(op[i], ptrs[i], line_bytes * height, stream) == -1 for i in range(F))
+    md5 = api.md5_device(op[:min(F, 64)], [line_bytes * height] * min(F, 64), stream)
+    t_verify = time.perf_counter() - t1
+    import hashlib
+    ok_md5 = md5[0] == hashlib.md5(bytes(frames[0].cpu().numpy())).digest()
+    payload = line_bytes * height
+    packet_avg = sum(sizes) / len(sizes)
+    dom = "k_dec_slices"
+    achieved = F * (packet_avg + payload) / (kt[dom] * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "4K-DCI 16-bit FFV1->DPX check frames/sec", "value": round(F * args.steps / dt, 3), "unit": "frames/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": f"{width}x{height} RGB16 FFV1 packets (slices={args.slices}) -> payload, byte compare + MD5 on device", "frames_per_step_per_gpu": F,
+                   "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "verify_seconds_all_frames": round(t_verify, 3)},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                     "traffic": None, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}}}))
+    dec.close()
+    enc.close()
+    if not (same and ok_md5):
+        sys.exit(2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +137,8 @@ def main():
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--mode", default="encode", choices=["encode", "check"],
+                    help="check: BASELINE config 5 -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
 
     import torch
@@ -128,6 +176,9 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    if args.mode == "check":
+        return check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, local_rank)
 
     for _ in range(max(0, args.warmup)):
         step()
