@@ -510,16 +510,21 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
     unsigned long long maxp = npieces;
     for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_xor(maxp, o); maxp = t > maxp ? t : maxp; }
 
+    // Loads are unconditional (the index is clamped to a valid piece) so that they stay plain global_load_dwordx4
+    // (a select against a zero constant turns them into flat loads of an unknown address space).
     uint4 cur[4], nxt[4];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int k = 0; k < 4; k++) cur[k] = npieces ? src[k] : zero4;
+    for (int k = 0; k < 4; k++) cur[k] = src[k];
     for (unsigned long long pc = 0; pc < maxp; pc++) {
-        rc_drain(r, err + 1, events);
-        const bool more = pc + 1 < npieces;
-        const uint4* p = src + (pc + 1) * (kGroupPieceBytes / 16);
+        // Pin the current piece in VGPRs *before* anything new is issued: the compiler's s_waitcnt for these registers then
+        // sits here (covering only loads issued a whole piece ago), not behind the next prefetch.
 #pragma unroll
-        for (int k = 0; k < 4; k++) nxt[k] = more ? p[k] : zero4;      // prefetch: in flight while this piece is coded
+        for (int k = 0; k < 4; k++) { asm volatile("" : "+v"(cur[k].x), "+v"(cur[k].y), "+v"(cur[k].z), "+v"(cur[k].w)); }
+        rc_drain(r, err + 1, events);
+        const unsigned long long pn = pc + 1 < npieces ? pc + 1 : (npieces ? npieces - 1 : 0);
+        const uint4* p = src + pn * (kGroupPieceBytes / 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) nxt[k] = p[k];                      // prefetch: in flight while this piece is coded
         if (pc < npieces) {
             const unsigned long long left = n - pc * kPieceEntries;
             rc_piece(r, cur, left < kPieceEntries ? uint32_t(left) : uint32_t(kPieceEntries));
