@@ -28,30 +28,31 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def make_frames(torch, n, width, height, kind, seed, device):
-    """n synthetic RGB16-BE payloads on the device, uint8 [n, height*width*6]."""
+    """n synthetic RGB16-BE payloads on the device, uint8 [n, height*width*6]; generated 8 frames at a time."""
     g = torch.Generator(device=device)
     g.manual_seed(1000 + seed)
     maxv = 65535.0
-    if kind == "flat":
-        base = torch.randint(0, 65536, (n, 1, 1, 3), generator=g, device=device, dtype=torch.int32)
-        v = base.expand(n, height, width, 3).contiguous()
-    elif kind == "noise":
-        v = torch.randint(0, 65536, (n, height, width, 3), generator=g, device=device, dtype=torch.int32)
-    else:
-        y = torch.linspace(0, 1, height, device=device).view(1, height, 1, 1)
-        x = torch.linspace(0, 1, width, device=device).view(1, 1, width, 1)
-        ph = torch.rand((n, 1, 1, 3), generator=g, device=device) * 6.28
-        c = torch.arange(3, device=device).view(1, 1, 1, 3).float()
-        sig = 0.45 + 0.25 * torch.sin(3.1 * x + ph) * torch.cos(2.3 * y + ph * 0.7) + 0.15 * (x * (c + 1) / 3 + y * 0.5) \
-            + 0.05 * torch.sin(40 * x + 31 * y + ph * 1.3)
-        out = torch.empty((n, height, width, 3), device=device, dtype=torch.int32)
-        for i in range(n):      # grain per frame (sigma = 1/64 of full scale: the low ~10 bits are noise, like scanned film)
-            grain = torch.randn((height, width, 3), generator=g, device=device) / 64.0
-            out[i] = torch.clamp((sig[i] + grain) * maxv * 0.8, 0, maxv).to(torch.int32)
-        v = out
-    hi = (v >> 8).to(torch.uint8)
-    lo = (v & 0xFF).to(torch.uint8)
-    return torch.stack((hi, lo), dim=-1).reshape(n, height * width * 6).contiguous()
+    out = torch.empty((n, height * width * 6), dtype=torch.uint8, device=device)
+    y = torch.linspace(0, 1, height, device=device).view(1, height, 1, 1)
+    x = torch.linspace(0, 1, width, device=device).view(1, 1, width, 1)
+    c = torch.arange(3, device=device).view(1, 1, 1, 3).float()
+    for i0 in range(0, n, 8):
+        m = min(8, n - i0)
+        if kind == "flat":
+            v = torch.randint(0, 65536, (m, 1, 1, 3), generator=g, device=device, dtype=torch.int32).expand(m, height, width, 3)
+        elif kind == "noise":
+            v = torch.randint(0, 65536, (m, height, width, 3), generator=g, device=device, dtype=torch.int32)
+        else:
+            # smooth picture + grain with sigma = 1/64 of full scale: the low ~10 bits are noise, like scanned film
+            ph = torch.rand((m, 1, 1, 3), generator=g, device=device) * 6.28
+            sig = 0.45 + 0.25 * torch.sin(3.1 * x + ph) * torch.cos(2.3 * y + ph * 0.7) + 0.15 * (x * (c + 1) / 3 + y * 0.5) \
+                + 0.05 * torch.sin(40 * x + 31 * y + ph * 1.3)
+            grain = torch.randn((m, height, width, 3), generator=g, device=device) / 64.0
+            v = torch.clamp((sig + grain) * maxv * 0.8, 0, maxv).to(torch.int32)
+        out[i0:i0 + m] = torch.stack(((v >> 8).to(torch.uint8), (v & 0xFF).to(torch.uint8)), dim=-1).reshape(m, height * width * 6)
+        del v
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int, frames_done_per_thread: int = 1):
@@ -130,7 +131,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "96")), help="frames in flight per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "320")), help="frames in flight per GPU per step")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
@@ -252,7 +253,8 @@ def main():
                                    f"coder=1 context=1 slicecrc=1, content={args.kind}",
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective",
                        "packet_bytes_avg": int(packet_avg), "compression_ratio": round(packet_avg / payload_bytes, 4),
-                       "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified},
+                       "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified,
+                       "hbm_in_use_gb": round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 1e9, 1)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
