@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--context-model", default="ffmpeg", choices=["ffmpeg", "compact"],
+                    help="level maps of the 5-input context model: FFmpeg's (5063 contexts, states in HBM) or compact (338 contexts, states in LDS)")
     ap.add_argument("--mode", default="encode", choices=["encode", "check"],
                     help="check: BASELINE config 5 -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
@@ -164,7 +166,8 @@ def main():
     line_bytes = width * 6
     nh, nv = api.slices_to_grid(args.slices)
     frames = make_frames(torch, F, width, height, args.kind, rank, dev)
-    enc = api.Ffv1Encoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=F, device=local_rank)
+    ctx = 2 if args.context_model == "compact" else 1
+    enc = api.Ffv1Encoder(width, height, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=F, device=local_rank)
     stride = (enc.max_packet + 255) & ~255
     d_packets = torch.empty(F * stride, dtype=torch.uint8, device=dev)
     d_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
@@ -215,7 +218,7 @@ def main():
     if rank == 0 and not args.no_verify:
         # parity spot check outside the timed region: packet 0 of the last step == the oracle's bytes and decodes to the source
         import oracle_binding as ob
-        p = ob.Params(width, height, pixfmt, nh, nv, 1, 1)
+        p = ob.Params(width, height, pixfmt, nh, nv, 1, ctx)
         pk = bytes(d_packets[:sizes[0]].cpu().numpy())
         src = bytes(frames[0].cpu().numpy())
         verified = ob.decode_payload(p, pk, line_bytes) == src
@@ -250,7 +253,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": f"{width}x{height} RGB 16-bit BE DPX payload -> FFV1 v3 intra, slices={args.slices} ({nh}x{nv}), "
-                                   f"coder=1 context=1 slicecrc=1, content={args.kind}",
+                                   f"coder=1 context=1 ({args.context_model} level maps) slicecrc=1, content={args.kind}",
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective",
                        "packet_bytes_avg": int(packet_avg), "compression_ratio": round(packet_avg / payload_bytes, 4),
                        "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified,

@@ -119,7 +119,8 @@ typedef struct {
     uint32_t line_bytes;      /* bytes between payload lines */
     uint32_t num_h_slices, num_v_slices;   /* num_h >= num_v (FFV1_Slice.cpp:127) */
     uint32_t slicecrc;        /* -slicecrc (ec) */
-    uint32_t context;         /* -context 0|1 */
+    uint32_t context;         /* -context 0|1 with FFmpeg's level maps (365 / 5063 contexts for > 8 bit); 2 = 5-input model with
+                                 compact level maps (338 contexts): adaptive states stay in LDS */
     uint32_t max_batch;       /* frames encoded per call (frames in flight on the device) */
     int      device;          /* HIP device ordinal */
     uint32_t segments;        /* hand-over granularity between state resolution and range coding: each slice's decision

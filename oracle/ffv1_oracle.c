@@ -65,7 +65,10 @@ static void fill_quant(int16_t* q, const uint8_t* runs, int nruns, int scale)
 }
 
 /* Two table sets as FFmpeg transmits them: set 0 = 3-input model, set 1 = 5-input model. */
-static void build_quant_sets(uint32_t bps, quant_set qs[2])
+static const uint8_t runs_q3[]       = { 4, 124 };                      /* compact model, <=8 bit */
+static const uint8_t runs_q3_10bit[] = { 24, 104 };                     /* compact model, >8 bit  */
+
+static void build_quant_sets_c(uint32_t bps, quant_set qs[2], int compact)
 {
     memset(qs, 0, 2 * sizeof(quant_set));
     if (bps <= 8) {
@@ -90,6 +93,14 @@ static void build_quant_sets(uint32_t bps, quant_set qs[2])
         fill_quant(qs[1].q[3], runs_q5_10bit, 3, 5 * 9 * 9);
         fill_quant(qs[1].q[4], runs_q5_10bit, 3, 5 * 5 * 9 * 9);
         qs[1].context_count = (9 * 9 * 5 * 5 * 5 + 1) / 2;
+    }
+    if (compact) {   /* context_model 2: the device's LDS-sized 5-input model, 5,5,3,3,3 levels = 338 contexts (same rule as ffv1_host.cpp) */
+        const uint8_t* q5 = bps <= 8 ? runs_q5 : runs_q5_10bit;
+        const uint8_t* q3 = bps <= 8 ? runs_q3 : runs_q3_10bit;
+        memset(&qs[1], 0, sizeof(quant_set));
+        fill_quant(qs[1].q[0], q5, 3, 1); fill_quant(qs[1].q[1], q5, 3, 5); fill_quant(qs[1].q[2], q3, 2, 25);
+        fill_quant(qs[1].q[3], q3, 2, 75); fill_quant(qs[1].q[4], q3, 2, 225);
+        qs[1].context_count = (5 * 5 * 3 * 3 * 3 + 1) / 2;
     }
 }
 
@@ -368,7 +379,7 @@ size_t ffv1o_config_record(const ffv1o_params* p, uint8_t* out, size_t cap)
 {
     quant_set qs[2];
     const uint32_t bps = ffv1o_bits_per_raw_sample(p->pixfmt);
-    build_quant_sets(bps, qs);
+    build_quant_sets_c(bps, qs, p->context_model == 2);
     rc_enc c; rce_init(&c, out, cap);
     uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);
     rce_symbol(&c, st, 3, 0);                        /* version */
@@ -432,7 +443,7 @@ static void codec_ctx_init(codec_ctx* k, const ffv1o_params* p)
     k->bits = k->rgb ? k->bps + 1 : (k->bps <= 8 ? 8 : k->bps);
     k->set_index_count = k->rgb ? k->planes - 1 : 2;       /* version<4: 1 + 1 (+alpha) */
     k->qidx = p->context_model ? 1 : 0;
-    build_quant_sets(k->bps, k->qs);
+    build_quant_sets_c(k->bps, k->qs, p->context_model == 2);
 }
 
 /* One line of one plane.  cur/prev point at x=0 of buffers with 2 guard samples on the left and 1 on the
@@ -749,7 +760,7 @@ int ffv1o_parse_config_record(const uint8_t* rec, size_t size, ffv1o_params* p)
     if (nsets != 2) return 7;
     if (colorspace != (uint32_t)is_rgb(p->pixfmt) || bps != ffv1o_bits_per_raw_sample(p->pixfmt) ||
         chroma != is_rgb(p->pixfmt) || alpha != has_alpha(p->pixfmt)) return 8;
-    quant_set ref[2]; build_quant_sets(bps, ref);
+    quant_set ref[2]; build_quant_sets_c(bps, ref, p->context_model == 2);
     for (uint32_t i = 0; i < nsets; i++) {
         int32_t scale = 1;
         for (int j = 0; j < 5; j++) {

@@ -43,7 +43,7 @@ typedef struct {
     uint32_t num_h_slices;  /* >= num_v_slices (reference decoder limit, FFV1_Slice.cpp:127) */
     uint32_t num_v_slices;
     uint32_t ec;            /* slicecrc: 0/1 */
-    uint32_t context_model; /* -context: 0 (3 inputs) / 1 (5 inputs) */
+    uint32_t context_model; /* -context: 0 (3 inputs) / 1 (5 inputs, FFmpeg's level maps) / 2 (5 inputs, compact 5,5,3,3,3 maps) */
 } ffv1o_params;
 
 /* geometry helpers */

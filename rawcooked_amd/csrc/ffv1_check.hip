@@ -356,7 +356,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     rcgpu_ffv1_decoder* d = new rcgpu_ffv1_decoder;
     d->cfg = *cfg;
     ffv1::quant_model qm[2];
-    ffv1::build_quant_models(px.bits, qm);
+    ffv1::build_quant_models(px.bits, qm, cfg->context == 2);
     const uint32_t qidx = cfg->context ? 1 : 0;
     const ffv1::quant_model& Q = qm[qidx];
     dec_const& c = d->hc;

@@ -197,6 +197,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
+template <bool LDS_STATES>
 __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
                                                 uint8_t* __restrict__ states, const unsigned long long* __restrict__ group_off,
@@ -211,6 +212,8 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     uint8_t*  trans = slot + 64 * 32;                                               // [bit][state]
     uint32_t* touched = reinterpret_cast<uint32_t*>(trans + 512);                   // nkeys bits
     uint8_t*  Hk = reinterpret_cast<uint8_t*>(touched + ((nkeys + 31) / 32 + 3) / 4 * 4);   // nkeys u8
+    // LDS_STATES (compact context model): every context's 32 states live here for the whole slice -- no HBM traffic per sample
+    uint8_t*  lstates = Hk + ((nkeys + 15) & ~15u);                                          // nkeys x 32
 
     const int lane = threadIdx.x;
     const uint32_t chain = blockIdx.x;
@@ -225,13 +228,16 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; }
     uint8_t* rs = resume + size_t(chain) * resume_stride;
     uint32_t* rs_touched = reinterpret_cast<uint32_t*>(rs + 80);
+    uint4* rs_states = reinterpret_cast<uint4*>(rs + 80);             // LDS_STATES: the state table itself is parked here
     uint32_t stage_count;
     if (seg == 0) {
-        for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = 0;
+        if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) reinterpret_cast<uint4*>(lstates)[i] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+        else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = 0;
         for (uint32_t i = lane; i < G.hdr_n; i += 64) stage[i] = hdr[G.hdr_off + i];
         stage_count = G.hdr_n;
     } else {
-        for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = rs_touched[i];
+        if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) reinterpret_cast<uint4*>(lstates)[i] = rs_states[i];
+        else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = rs_touched[i];
         if (lane < 16) reinterpret_cast<uint32_t*>(stage)[lane] = reinterpret_cast<const uint32_t*>(rs + 16)[lane];
         stage_count = *reinterpret_cast<const uint32_t*>(rs);
     }
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
 
         // --- group leaders fetch the context's 32 states: all 128 on first use in this slice (states_coded = 0),
         // else from the slice's state array in HBM.
-        const bool first = valid && pred < 0;
+        const bool first = !LDS_STATES && valid && pred < 0;
         uint4 s0 = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u), s1 = s0;
         if (first) {
             const bool was = (touched[key >> 5] >> (key & 31)) & 1;
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         // --- rounds: a lane runs once its predecessor (same context, earlier in coding order) is done.
         unsigned long long done = 0;
         bool pending = valid;
-        uint8_t* sl = slot + leader * 32;
+        uint8_t* sl = LDS_STATES ? lstates + size_t(key) * 32 : slot + leader * 32;
         uint16_t* op = stage + stage_count + excl;
         while (__ballot(pending)) {
             const bool ready = pending && (pred < 0 || ((done >> pred) & 1));
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         }
 
         // --- last lane of each group writes the states back
-        if (valid && last) {
+        if (!LDS_STATES && valid && last) {
             const uint4* sp = reinterpret_cast<const uint4*>(sl);
             uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
             gp[0] = sp[0]; gp[1] = sp[1];
@@ -353,8 +359,9 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         stage_count += total;
         flush_full();      // contains the workgroup-scope fences that order the state write-back before the next gather
     }
-    if (!last_seg) {      // park the unfinished piece and the bitmap for the next segment
-        for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) rs_touched[i] = touched[i];
+    if (!last_seg) {      // park the unfinished piece and the bitmap (or the state table) for the next segment
+        if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) rs_states[i] = reinterpret_cast<const uint4*>(lstates)[i];
+        else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) rs_touched[i] = touched[i];
         if (lane < 16) reinterpret_cast<uint32_t*>(rs + 16)[lane] = reinterpret_cast<const uint32_t*>(stage)[lane];
         if (lane == 0) *reinterpret_cast<uint32_t*>(rs) = stage_count;
         return;
@@ -720,6 +727,7 @@ struct rcgpu_ffv1 {
     std::vector<slice_geom> geom;
     std::vector<uint8_t> record;
     uint32_t nkeys = 0, nseg = 1, resume_stride = 0;
+    bool lds_states = false;            // compact context model: k_resolve keeps the slice's states in LDS
     size_t resolve_lds = 0;
     size_t frame_payload = 0, cbuf_frame_stride = 0, max_packet = 0;
     hipStream_t own_stream = nullptr, rc_stream = nullptr;      // rc_stream: k_rangecode runs beside k_resolve
@@ -805,11 +813,11 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     e->cfg = *cfg;
     e->sp.bits_per_raw_sample = d.bits; e->sp.rgb = d.planes != 1; e->sp.alpha = d.planes == 4;
     e->sp.num_h_slices = cfg->num_h_slices; e->sp.num_v_slices = cfg->num_v_slices;
-    e->sp.ec = cfg->slicecrc ? 1 : 0; e->sp.context_model = cfg->context ? 1 : 0;
+    e->sp.ec = cfg->slicecrc ? 1 : 0; e->sp.context_model = cfg->context ? 1 : 0; e->sp.compact = cfg->context == 2;
     e->record = ffv1::config_record(e->sp);
 
     ffv1::quant_model qm[2];
-    ffv1::build_quant_models(d.bits, qm);
+    ffv1::build_quant_models(d.bits, qm, e->sp.compact);
     const ffv1::quant_model& Q = qm[e->sp.context_model];
     enc_const& c = e->hc;
     c.W = cfg->width; c.H = cfg->height; c.line_bytes = cfg->line_bytes; c.pixfmt = cfg->pixfmt;
@@ -826,6 +834,8 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     e->nkeys = c.nsets * c.nctx;
     e->resolve_lds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);
     e->resume_stride = uint32_t((80 + ((e->nkeys + 31) / 32) * 4 + 15) & ~15u);
+    e->lds_states = size_t(e->nkeys) * 32 <= (48u << 10);                        // 338 contexts x 2 (3) sets x 32 B = 21.6 (32.4) KB
+    if (e->lds_states) { e->resolve_lds += size_t(e->nkeys) * 32; e->resume_stride = uint32_t(80 + e->nkeys * 32); }
     e->frame_payload = size_t(cfg->line_bytes) * cfg->height;
 
     // segments: the decision stream of a slice is produced and consumed in nseg windows (double buffered) instead of
@@ -876,7 +886,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     DM(e->d_const, sizeof(enc_const)); DM(e->d_geom, sizeof(slice_geom) * S); DM(e->d_hdr, hdr.size() * 2 + 16);
     DM(e->d_frame_ptrs, sizeof(void*) * F);
     DM(e->d_planes, size_t(std::min(F, kSubBatch)) * c.samples_per_frame * 4); DM(e->d_sym, size_t(F) * c.samples_per_frame * 4);
-    DM(e->d_states, nchains * e->nkeys * 32);
+    DM(e->d_states, e->lds_states ? 16 : nchains * e->nkeys * 32);
     DM(e->d_ndec, nchains * nseg * 8); DM(e->d_total_n, nchains * 8); DM(e->d_seg_pieces, nchains * nseg * 4); DM(e->d_group_off, ngroups * nseg * 8);
     DM(e->d_k3_resume, nchains * e->resume_stride); DM(e->d_k4_resume, nchains * sizeof(rc_resume));
     DM(e->d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
@@ -897,7 +907,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (he == hipSuccess) he = hipMemcpy(e->d_const, &e->hc, sizeof(enc_const), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(e->d_geom, e->geom.data(), sizeof(slice_geom) * S, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(e->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
-    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void*>(k_resolve), hipFuncAttributeMaxDynamicSharedMemorySize, int(e->resolve_lds));
+    if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void*>(e->lds_states ? k_resolve<true> : k_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(e->resolve_lds));
     if (he != hipSuccess) {
         const int r = fail(100, "ffv1: device setup failed: %s", hipGetErrorString(he));
         rcgpu_ffv1_destroy(e);
@@ -996,8 +1006,11 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     for (uint32_t j = 0; j < nseg; j++) {
         uint8_t* win = e->d_window[j & 1];
         if (j >= 2) HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[j - 2], 0));
-        HIP_TRY(timed(2, st, [&] { hipLaunchKernelGGL(k_resolve, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
-                                                      e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride); }));
+        HIP_TRY(timed(2, st, [&] {
+            if (e->lds_states) hipLaunchKernelGGL(k_resolve<true>, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
+                                                  e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride);
+            else hipLaunchKernelGGL(k_resolve<false>, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
+                                    e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride); }));
         HIP_TRY(hipEventRecord(e->ev_k3[j], st));
         HIP_TRY(hipStreamWaitEvent(s2, e->ev_k3[j], 0));
         HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,

@@ -35,7 +35,7 @@ static void fill(int16_t* q, std::initializer_list<int> runs, int scale)
     q[128] = int16_t(-q[127]);
 }
 
-void build_quant_models(uint32_t bps, quant_model m[2])
+void build_quant_models(uint32_t bps, quant_model m[2], bool compact)
 {
     memset(m, 0, 2 * sizeof(quant_model));
     if (bps <= 8) {            // 11-level / 5-level maps for 8-bit material
@@ -50,6 +50,17 @@ void build_quant_models(uint32_t bps, quant_model m[2])
         m[0].context_count = (9 * 9 * 9 + 1) / 2;
         fill(m[1].q[0], q9, 1); fill(m[1].q[1], q9, 9); fill(m[1].q[2], q5, 81); fill(m[1].q[3], q5, 405); fill(m[1].q[4], q5, 2025);
         m[1].context_count = (9 * 9 * 5 * 5 * 5 + 1) / 2;
+    }
+    if (compact) {             // 5,5,3,3,3 levels: thresholds of the 5-level map above, and one threshold for the 3-level inputs
+        memset(&m[1], 0, sizeof(quant_model));
+        if (bps <= 8) {
+            const std::initializer_list<int> q5 = { 1, 3, 124 }, q3 = { 4, 124 };
+            fill(m[1].q[0], q5, 1); fill(m[1].q[1], q5, 5); fill(m[1].q[2], q3, 25); fill(m[1].q[3], q3, 75); fill(m[1].q[4], q3, 225);
+        } else {
+            const std::initializer_list<int> q5 = { 11, 53, 64 }, q3 = { 24, 104 };
+            fill(m[1].q[0], q5, 1); fill(m[1].q[1], q5, 5); fill(m[1].q[2], q3, 25); fill(m[1].q[3], q3, 75); fill(m[1].q[4], q3, 225);
+        }
+        m[1].context_count = (5 * 5 * 3 * 3 * 3 + 1) / 2;
     }
 }
 
@@ -110,7 +121,7 @@ void write_quant_table(host_rc& c, const int16_t* q)
 std::vector<uint8_t> config_record(const stream_params& p)
 {
     quant_model m[2];
-    build_quant_models(p.bits_per_raw_sample, m);
+    build_quant_models(p.bits_per_raw_sample, m, p.compact);
     host_rc c;
     uint8_t st[kContextSize]; memset(st, 128, sizeof st);
     c.symbol(st, 3, false);                         // version

@@ -19,7 +19,9 @@ struct quant_model {
 };
 // The two table sets carried in the configuration record: [0] 3-input model, [1] 5-input model
 // (level maps as FFmpeg's ffv1enc chooses them for <= 8 bit and > 8 bit material).
-void build_quant_models(uint32_t bits_per_raw_sample, quant_model out[2]);
+// compact = true replaces [1] by a 5-input model with 5,5,3,3,3 levels (338 contexts): small enough for a slice's adaptive
+// states to live in LDS, and -- on the 10^5-sample planes of a 64..576-slice 4K frame -- a better fit than 5063 contexts.
+void build_quant_models(uint32_t bits_per_raw_sample, quant_model out[2], bool compact = false);
 
 struct stream_params {
     uint32_t bits_per_raw_sample;
@@ -28,6 +30,7 @@ struct stream_params {
     uint32_t num_h_slices, num_v_slices;
     uint32_t ec;                  // slicecrc
     uint32_t context_model;       // quant table set index used by every plane (-context)
+    bool     compact = false;     // table set 1 is the compact 5-input model
 };
 
 // Configuration record incl. CRC (what parameters::Parse reads, FFV1_Parameters.cpp:23-183).

@@ -147,7 +147,13 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     if (opt.num("level", 3) != 3) return bail(fail(2, "-level %ld is not supported by rcgpu (only 3)", opt.num("level", 3)));
     if (opt.num("g", 1) != 1) return bail(fail(2, "-g %ld is not supported by rcgpu (intra only)", opt.num("g", 1)));
     if (job->framemd5_path) return bail(fail(2, "-f framemd5 is not supported by rcgpu"));
-    const uint32_t context = uint32_t(opt.num("context", 0)), slicecrc = uint32_t(opt.num("slicecrc", 1));
+    uint32_t context = uint32_t(opt.num("context", 0));
+    const uint32_t slicecrc = uint32_t(opt.num("slicecrc", 1));
+    // -context 1 uses FFmpeg's level maps unless the compact 5-input model is asked for (RCGPU_CONTEXT_MODEL=compact or
+    // the option rcgpu_context_model=compact): same bitstream syntax, tables in the configuration record, states in LDS
+    const char* model = opt.get("rcgpu_context_model");
+    if (!model) model = getenv("RCGPU_CONTEXT_MODEL");
+    if (context == 1 && model && !strcmp(model, "compact")) context = 2;
     const bool overwrite = opt.has("y") && !opt.has("n");
     if (!overwrite && file_exists(job->output_path)) return bail(fail(3, "output file %s already exists (use -y)", job->output_path));
 

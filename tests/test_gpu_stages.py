@@ -88,3 +88,31 @@ def test_many_frames_cross_sub_batches(built):
     for f in range(nframes):
         assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
     enc.close()
+
+
+@pytest.mark.parametrize("pixfmt,w,h,slices", [(synth.PIX_RGB16_BE, 200, 120, 6), (synth.PIX_RGB10_FILLEDA_LE, 96, 64, 4), (synth.PIX_RGBA16_BE, 64, 48, 4),
+                                                (synth.PIX_Y16_LE, 80, 40, 4), (synth.PIX_RGB8, 90, 50, 4)])
+@pytest.mark.parametrize("segments", [1, 3])
+def test_compact_context_model(built, pixfmt, w, h, slices, segments):
+    """context = 2: 5-input model with compact level maps, adaptive states resident in LDS -- same bytes as the oracle, and the
+    device decoder (states in HBM) rebuilds the payload."""
+    import torch
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    nh, nv = api.slices_to_grid(slices)
+    payloads = []
+    for i in range(3):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, ["film", "noise", "flat"][i], seed=70 + i), pixfmt, True)
+        payloads.append(pl)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 2)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 2, max_batch=3, segments=segments)
+    assert enc.config_record() == ob.config_record(p)
+    packets = enc.encode_host(payloads)
+    for f in range(3):
+        assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 2, max_batch=3)
+    dpk = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in packets]
+    dout = [torch.empty(len(x), dtype=torch.uint8, device="cuda") for x in payloads]
+    assert dec.decode_device([t.data_ptr() for t in dpk], [len(x) for x in packets], [t.data_ptr() for t in dout]) == 0
+    for f in range(3):
+        assert bytes(dout[f].cpu().numpy()) == payloads[f]
+    enc.close(); dec.close()
