@@ -137,8 +137,9 @@ size_t rcgpu_ffv1_config_record(const rcgpu_ffv1* enc, uint8_t* out, size_t cap)
 size_t rcgpu_ffv1_max_packet_bytes(const rcgpu_ffv1* enc);
 
 /* Encode n (<= max_batch) frames whose payloads (data_size bytes each, first byte = first pixel) are
- * already resident in device memory.  Asynchronous: all work is enqueued on `hip_stream` (a hipStream_t,
- * NULL = the encoder's own stream).  On completion packet i occupies
+ * already resident in device memory.  All work is ordered on `hip_stream` (a hipStream_t, NULL = the default
+ * stream); the call itself blocks once (exact decision counts come back to size the stream windows) and returns with the
+ * remaining kernels enqueued.  On completion packet i occupies
  * d_packets[i*packet_stride .. + d_packet_sizes[i]) and is a complete FFV1 frame (all slices, footers, CRCs).
  *   d_frames       host array of n device pointers
  *   d_packets      device buffer, n * packet_stride bytes, packet_stride >= rcgpu_ffv1_max_packet_bytes()

@@ -398,7 +398,7 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     if (!d || !d_packets || !packet_sizes || !d_payloads) return fail(1, "ffv1 decoder: null argument");
     if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
     HIP_TRY(hipSetDevice(d->cfg.device));
-    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : d->own_stream;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);      // NULL = the default stream: ordered after the caller's earlier work
     const dec_const& c = d->hc;
     const uint32_t nchains = n * c.S;
     for (uint32_t i = 0; i < n; i++) { d->h_ptrs[i] = const_cast<void*>(d_packets[i]); d->h_ptrs[d->cfg.max_batch + i] = d_payloads[i]; d->h_sizes[i] = packet_sizes[i]; }

@@ -325,25 +325,40 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         while (__ballot(pending)) {
             const bool ready = pending && (pred < 0 || ((done >> pred) & 1));
             if (ready) {
-                // symbol binarisation, inverse of rangecoder::s (FFV1_RangeCoder.cpp:135-305)
-                uint32_t j = 0;
+                // Symbol binarisation, inverse of rangecoder::s (FFV1_RangeCoder.cpp:135-305), fully unrolled: the context's 32
+                // states sit in 8 registers, every state index is a compile-time constant, and the only memory operations are
+                // the transition look-ups -- independent of each other except where an index repeats (k = 10 and k = 31 for
+                // exponents above 9), so they pipeline instead of forming a 20-deep chain of dependent LDS round trips.
+                uint32_t S[8];
+                { const uint4 v0 = reinterpret_cast<const uint4*>(sl)[0], v1 = reinterpret_cast<const uint4*>(sl)[1];
+                  S[0] = v0.x; S[1] = v0.y; S[2] = v0.z; S[3] = v0.w; S[4] = v1.x; S[5] = v1.y; S[6] = v1.z; S[7] = v1.w; }
+#define ST_GET(k) ((S[(k) >> 2] >> (8 * ((k) & 3))) & 0xFFu)
+#define ST_PUT(k, v) (S[(k) >> 2] = (S[(k) >> 2] & ~(0xFFu << (8 * ((k) & 3)))) | ((v) << (8 * ((k) & 3))))
+#define CODE(k, bit, pos) do { const uint32_t st_ = ST_GET(k); const uint32_t b_ = (bit); \
+                               op[pos] = uint16_t(b_ ? st_ : (0xFF00u | (256 - st_))); ST_PUT(k, uint32_t(trans[b_ * 256 + st_])); } while (0)
                 if (a == 0) {
-                    const uint32_t st = sl[0]; op[0] = uint16_t(st); sl[0] = trans[256 + st];
+                    CODE(0, 1u, 0);
                 } else {
-                    { const uint32_t st = sl[0]; op[j++] = uint16_t(0xFF00u | (256 - st)); sl[0] = trans[st]; }
-                    for (int t = 0; t < e; t++) {
-                        const int k = 1 + (t < 9 ? t : 9);
-                        const uint32_t st = sl[k]; op[j++] = uint16_t(st); sl[k] = trans[256 + st];
+                    CODE(0, 0u, 0);
+#pragma unroll
+                    for (int t = 0; t <= 16; t++) {                 // exponent in unary: ones for t < e, the zero at t == e
+                        if (t <= e) CODE(1 + (t < 9 ? t : 9), t < e ? 1u : 0u, 1 + t);
                     }
-                    { const int k = 1 + (e < 9 ? e : 9); const uint32_t st = sl[k]; op[j++] = uint16_t(0xFF00u | (256 - st)); sl[k] = trans[st]; }
-                    for (int t = e - 1; t >= 0; t--) {
-                        const int k = 22 + (t < 9 ? t : 9);
-                        const uint32_t b = (a >> t) & 1;
-                        const uint32_t st = sl[k]; op[j++] = uint16_t(b ? st : (0xFF00u | (256 - st))); sl[k] = trans[b * 256 + st];
+#pragma unroll
+                    for (int t = 15; t >= 0; t--) {                 // mantissa bits e-1 .. 0
+                        if (t < e) CODE(22 + (t < 9 ? t : 9), (a >> t) & 1u, 2 * e + 1 - t);
                     }
-                    { const int k = 11 + (e < 10 ? e : 10); const uint32_t b = d < 0;
-                      const uint32_t st = sl[k]; op[j++] = uint16_t(b ? st : (0xFF00u | (256 - st))); sl[k] = trans[b * 256 + st]; }
+                    const int ks = 11 + (e < 10 ? e : 10);
+#pragma unroll
+                    for (int k = 11; k <= 21; k++) {                // sign: the state index depends on e
+                        if (k == ks) CODE(k, d < 0 ? 1u : 0u, 2 * e + 2);
+                    }
                 }
+#undef ST_GET
+#undef ST_PUT
+#undef CODE
+                reinterpret_cast<uint4*>(sl)[0] = make_uint4(S[0], S[1], S[2], S[3]);
+                reinterpret_cast<uint4*>(sl)[1] = make_uint4(S[4], S[5], S[6], S[7]);
             }
             done |= __ballot(ready);
             pending = pending && !ready;
@@ -934,7 +949,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     if (!n || n > e->cfg.max_batch) return fail(2, "ffv1: batch of %u frames (max_batch %u)", n, e->cfg.max_batch);
     if (packet_stride < e->max_packet || (packet_stride & 3)) return fail(2, "ffv1: packet_stride must be a multiple of 4 and >= %zu", e->max_packet);
     HIP_TRY(hipSetDevice(e->cfg.device));
-    hipStream_t st = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);       // NULL = the default stream: ordered after the caller's earlier work
     hipStream_t s2 = e->rc_stream;
     const enc_const& c = e->hc;
     const uint32_t S = c.S, nchains = n * S, ngroups = (nchains + 63) / 64, nseg = e->nseg;
