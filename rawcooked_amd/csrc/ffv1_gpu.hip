@@ -700,19 +700,19 @@ __global__ __launch_bounds__(64) void k_scan(const enc_const* __restrict__ C, co
 }
 
 // K7: gather slices into the packet.  Destination dwords are written aligned; the source is re-aligned with a
-// funnel shift.  grid = (8, chains).
+// funnel shift.  grid = (chains, 8).
 __global__ __launch_bounds__(256) void k_gather(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 const uint8_t* __restrict__ cbuf, unsigned long long cbuf_frame_stride,
                                                 const uint32_t* __restrict__ tot_len, const unsigned long long* __restrict__ slice_dst,
                                                 uint8_t* __restrict__ packets, unsigned long long packet_stride)
 {
-    const uint32_t chain = blockIdx.y;
+    const uint32_t chain = blockIdx.x;           // chains on x: grid.y is limited to 65535
     const uint32_t S = C->S, f = chain / S, s = chain - f * S;
     const slice_geom G = geom[s];
     const uint8_t* src = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
     uint8_t* dst = packets + size_t(f) * packet_stride + slice_dst[chain];
     const uint32_t len = tot_len[chain];
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+    const uint32_t tid = blockIdx.y * 256 + threadIdx.x, nthreads = gridDim.y * 256;
     const uint32_t head = min(len, uint32_t((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3));
     if (tid < head) dst[tid] = src[tid];
     const uint32_t ndw = (len - head) / 4;
@@ -1037,7 +1037,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(timed(4, s2, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));
     HIP_TRY(timed(5, s2, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, s2, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
-    HIP_TRY(timed(6, s2, [&] { hipLaunchKernelGGL(k_gather, dim3(8, nchains), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+    HIP_TRY(timed(6, s2, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
     HIP_TRY(hipEventRecord(e->ev_fork, s2));
     HIP_TRY(hipStreamWaitEvent(st, e->ev_fork, 0));
