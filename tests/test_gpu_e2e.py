@@ -117,3 +117,59 @@ def test_reference_accepts_compact_context_model(built, refbin, tmp_path):
     assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
     assert run([SHIM] + argv[1:], work).returncode == 0          # FFmpeg's level maps, for the size comparison
     assert compact_size < os.path.getsize(os.path.join(work, "pkg.mkv"))
+
+
+def test_start_number_sidecar_and_no_overwrite(built, refbin, tmp_path):
+    """Non-zero -start_number (Input.cpp:305-306 template), an extra attachment (Output.cpp:279-287) and -n (Global.cpp:865-884)."""
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB16_BE, 3, "film", start=86400)
+    with open(os.path.join(work, "pkg", "notes.txt"), "w") as f:
+        f.write("sidecar kept as attachment\n")
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0 and "-start_number 086400" in r.stdout and "notes.txt" in r.stdout, r.stdout + r.stderr
+    argv = shlex.split(r.stdout.strip())
+    assert run([SHIM] + argv[1:], work).returncode == 0
+    r = run([refbin, "--check", "pkg.mkv"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    r = run([refbin, "-y", "pkg.mkv"], work)
+    assert open(os.path.join(work, "pkg.mkv.RAWcooked", "pkg", "notes.txt")).read() == "sidecar kept as attachment\n"
+    # -n: refuse to overwrite
+    argv_n = [a if a != "-y" else "-n" for a in argv[1:]]
+    r = run([SHIM] + argv_n, work)
+    assert r.returncode != 0 and "Error: " in r.stderr and "already exists" in r.stderr
+
+
+def test_gapped_sequence_uses_the_concat_list(built, refbin, tmp_path):
+    """--accept-gaps makes the reference write an ffconcat file list (Output.cpp:138-251); the shim must read it."""
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB16_BE, 5, "film")
+    os.remove(os.path.join(work, "pkg", "img", "f_000002.dpx"))
+    r = run([refbin, "--hash", "--no-check-padding", "--accept-gaps", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0 and "-f concat" in r.stdout, r.stdout + r.stderr
+    argv = shlex.split(r.stdout.strip())
+    r = run([SHIM] + argv[1:], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = run([refbin, "--check", "pkg.mkv"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+
+
+def test_ntsc_framerate_and_python_job_binding(built, refbin, tmp_path):
+    """The ctypes `Output.Process()` mirror of Output.h:41-53 with a 24000/1001 frame rate."""
+    from rawcooked_amd import api
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB10_FILLEDA_BE, 4, "film")
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        out = api.Output(Streams=[api.Stream(FileName_Template="pkg/img/f_%06d.dpx", FileName_StartNumber="000000",
+                                             Flavor="DPX/Raw/RGB/10bit/FilledA/U/BE", Slices="16", FrameRate="24000/1001")])
+        assert out.Process("pkg.mkv", rawcooked_reversibility_FileName="pkg.rawcooked_reversibility_data") == 0, api.last_error()
+    finally:
+        os.chdir(cwd)
+    r = run([refbin, "--check", "pkg.mkv"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    data = open(os.path.join(work, "pkg.mkv"), "rb").read()
+    i = data.index(bytes.fromhex("23E383"))                   # DefaultDuration
+    assert int.from_bytes(data[i + 4:i + 4 + (data[i + 3] & 0x7F)], "big") == 41708333
