@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:        # Load torch's bundled HIP runtime BEFORE librcgpu.so pulls in /opt/rocm's: with the opposite order torch's lazy
+    import torch  # noqa: F401   # device init later reports "No HIP GPUs are available" (two runtimes, one SONAME).
+except Exception:  # pragma: no cover - CPU-only environments without torch still run the host tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
