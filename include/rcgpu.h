@@ -75,8 +75,17 @@ enum {   /* pixel layouts; names follow the reference flavors (DPX.cpp:184-231, 
     RCGPU_PIX_RGB16_BE = 5, RCGPU_PIX_RGB16_LE = 6,
     RCGPU_PIX_RGBA8 = 7, RCGPU_PIX_RGBA16_BE = 8, RCGPU_PIX_RGBA16_LE = 9,
     RCGPU_PIX_Y8 = 10, RCGPU_PIX_Y16_BE = 11, RCGPU_PIX_Y16_LE = 12,
+    /* bit-packed DPX flavors (DPX.cpp:189,194-198,202-204; packers Transform.cpp:161-322,445-600,709-990) */
+    RCGPU_PIX_RGB12_PACKED_BE = 13,
+    RCGPU_PIX_RGBA10_FILLEDA_BE = 14, RCGPU_PIX_RGBA10_FILLEDA_LE = 15,
+    RCGPU_PIX_RGBA12_PACKED_BE = 16, RCGPU_PIX_RGBA12_FILLEDA_BE = 17, RCGPU_PIX_RGBA12_FILLEDA_LE = 18,
+    RCGPU_PIX_Y10_FILLEDA_BE = 19, RCGPU_PIX_Y10_FILLEDB_BE = 20, RCGPU_PIX_Y12_PACKED_BE = 21,
     RCGPU_PIX_COUNT
 };
+/* payload layout variants the DPX header announces; the FFV1 bitstream does not know about them */
+#define RCGPU_FLAG_VFLIP  1u   /* orientation 2: lines stored bottom to top; the reference then adds "-vf vflip" (Main.cpp:207-211),
+                                  picture line y = file line height-1-y (Transform.cpp:181-185).  12-bit Packed flavors only (DPX.cpp:189,204) */
+#define RCGPU_FLAG_ALTERN 2u   /* Y 10-bit from some scanners: words are filled across line ends, no line padding (DPX.cpp:363-368,465-469) */
 
 typedef struct {
     uint32_t width, height;
@@ -87,7 +96,8 @@ typedef struct {
     uint32_t line_bytes;        /* DPX: padded to 32 bit (Utils/RawFrame/RawFrame.cpp:109); TIFF: unpadded */
     uint32_t slices;            /* slice_x*slice_y the reference would pass as -slices (DPX.cpp:428-458, TIFF.cpp:657-672) */
     double   framerate;         /* DPX only (DPX.cpp:370-387); 0 when absent */
-    char     flavor[64];        /* "DPX/Raw/RGB/16bit/U/BE" ... */
+    char     flavor[64];        /* "DPX/Raw/RGB/16bit/U/BE", "DPX/Raw/RGB/10bit/U/BE/FilledA" ... (DPX.cpp:762-778, Common.cpp:123-139) */
+    uint32_t flags;             /* RCGPU_FLAG_* found in the header */
 } rcgpu_image_info;
 
 typedef struct {
@@ -125,6 +135,7 @@ typedef struct {
     int      device;          /* HIP device ordinal */
     uint32_t segments;        /* hand-over granularity between state resolution and range coding: each slice's decision
                                  stream is produced/consumed in this many windows (0 = automatic, 1 = whole slice) */
+    uint32_t flags;           /* RCGPU_FLAG_VFLIP | RCGPU_FLAG_ALTERN: how the payload is laid out (line_bytes is ignored for ALTERN) */
 } rcgpu_ffv1_config;
 
 typedef struct rcgpu_ffv1 rcgpu_ffv1;

@@ -112,15 +112,19 @@ uint32_t ffv1o_bits_per_raw_sample(uint32_t f)
     switch (f) {
     case FFV1O_RGB8: case FFV1O_RGBA8: case FFV1O_Y8: return 8;
     case FFV1O_RGB10_FILLEDA_BE: case FFV1O_RGB10_FILLEDA_LE: return 10;
+    case FFV1O_RGBA10_FILLEDA_BE: case FFV1O_RGBA10_FILLEDA_LE: case FFV1O_Y10_FILLEDA_BE: case FFV1O_Y10_FILLEDB_BE: return 10;
     case FFV1O_RGB12_FILLEDA_BE: case FFV1O_RGB12_FILLEDA_LE: return 12;
+    case FFV1O_RGB12_PACKED_BE: case FFV1O_RGBA12_PACKED_BE: case FFV1O_RGBA12_FILLEDA_BE: case FFV1O_RGBA12_FILLEDA_LE:
+    case FFV1O_Y12_PACKED_BE: return 12;
     default: return 16;
     }
 }
 uint32_t ffv1o_plane_count(uint32_t f)
 {
     switch (f) {
-    case FFV1O_Y8: case FFV1O_Y16_BE: case FFV1O_Y16_LE: return 1;
-    case FFV1O_RGBA8: case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE: return 4;
+    case FFV1O_Y8: case FFV1O_Y16_BE: case FFV1O_Y16_LE: case FFV1O_Y10_FILLEDA_BE: case FFV1O_Y10_FILLEDB_BE: case FFV1O_Y12_PACKED_BE: return 1;
+    case FFV1O_RGBA8: case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE: case FFV1O_RGBA10_FILLEDA_BE: case FFV1O_RGBA10_FILLEDA_LE:
+    case FFV1O_RGBA12_PACKED_BE: case FFV1O_RGBA12_FILLEDA_BE: case FFV1O_RGBA12_FILLEDA_LE: return 4;
     default: return 3;
     }
 }
@@ -132,24 +136,45 @@ uint32_t ffv1o_bytes_per_pixel(uint32_t f)
     case FFV1O_RGB12_FILLEDA_BE: case FFV1O_RGB12_FILLEDA_LE: return 6;
     case FFV1O_RGB16_BE: case FFV1O_RGB16_LE: return 6;
     case FFV1O_RGBA8: return 4;
-    case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE: return 8;
+    case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE: case FFV1O_RGBA12_FILLEDA_BE: case FFV1O_RGBA12_FILLEDA_LE: return 8;
     case FFV1O_Y8: return 1;
+    case FFV1O_RGB12_PACKED_BE: case FFV1O_RGBA12_PACKED_BE: case FFV1O_Y12_PACKED_BE:
+    case FFV1O_RGBA10_FILLEDA_BE: case FFV1O_RGBA10_FILLEDA_LE: case FFV1O_Y10_FILLEDA_BE: case FFV1O_Y10_FILLEDB_BE: return 0;   /* fields straddle bytes */
     default: return 2;
+    }
+}
+/* 0 = whole bytes per pixel; else fields per 32-bit word stream: 12 = packed 12-bit, 10 = three 10-bit fields per word */
+static int word_layout(uint32_t f)
+{
+    switch (f) {
+    case FFV1O_RGB12_PACKED_BE: case FFV1O_RGBA12_PACKED_BE: case FFV1O_Y12_PACKED_BE: return 12;
+    case FFV1O_RGBA10_FILLEDA_BE: case FFV1O_RGBA10_FILLEDA_LE: case FFV1O_Y10_FILLEDA_BE: case FFV1O_Y10_FILLEDB_BE: return 10;
+    default: return 0;
     }
 }
 size_t ffv1o_line_bytes(uint32_t f, uint32_t width, int dpx_line_padding)
 {
+    const size_t fields = (size_t)width * ffv1o_plane_count(f);
+    if (word_layout(f) == 12) return (fields * 12 + 31) / 32 * 4;    /* Transform.cpp:191-194, 881-884 */
+    if (word_layout(f) == 10) return (fields + 2) / 3 * 4;           /* Transform.cpp:751-753 */
     size_t n = (size_t)width * ffv1o_bytes_per_pixel(f);
     if (dpx_line_padding)      /* Line_Alignment = 32 bit, Utils/RawFrame/RawFrame.cpp:109 */
         n = (n + 3) & ~(size_t)3;
     return n;
+}
+size_t ffv1o_payload_bytes(const ffv1o_params* p, size_t line_bytes)
+{
+    if (p->flags & FFV1O_FLAG_ALTERN) return ((size_t)p->width * p->height + 2) / 3 * 4;   /* DPX.cpp:465-469 */
+    return line_bytes * p->height;
 }
 static int is_rgb(uint32_t f) { return ffv1o_plane_count(f) != 1; }
 static int has_alpha(uint32_t f) { return ffv1o_plane_count(f) == 4; }
 static int is_be(uint32_t f)
 {
     return f == FFV1O_RGB10_FILLEDA_BE || f == FFV1O_RGB12_FILLEDA_BE || f == FFV1O_RGB16_BE ||
-           f == FFV1O_RGBA16_BE || f == FFV1O_Y16_BE;
+           f == FFV1O_RGBA16_BE || f == FFV1O_Y16_BE || f == FFV1O_RGB12_PACKED_BE || f == FFV1O_RGBA10_FILLEDA_BE ||
+           f == FFV1O_RGBA12_PACKED_BE || f == FFV1O_RGBA12_FILLEDA_BE || f == FFV1O_Y10_FILLEDA_BE || f == FFV1O_Y10_FILLEDB_BE ||
+           f == FFV1O_Y12_PACKED_BE;
 }
 static inline uint32_t rd16(const uint8_t* p, int be) { return be ? ((uint32_t)p[0] << 8) | p[1] : ((uint32_t)p[1] << 8) | p[0]; }
 static inline void wr16(uint8_t* p, uint32_t v, int be) { if (be) { p[0] = (uint8_t)(v >> 8); p[1] = (uint8_t)v; } else { p[1] = (uint8_t)(v >> 8); p[0] = (uint8_t)v; } }
@@ -179,6 +204,8 @@ static inline void load_px(uint32_t f, const uint8_t* p, int be, uint32_t c[4])
         c[0] = rd16(p, be); c[1] = rd16(p + 2, be); c[2] = rd16(p + 4, be); break;
     case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE:                                             /* :603-650 */
         c[0] = rd16(p, be); c[1] = rd16(p + 2, be); c[2] = rd16(p + 4, be); c[3] = rd16(p + 6, be); break;
+    case FFV1O_RGBA12_FILLEDA_BE: case FFV1O_RGBA12_FILLEDA_LE:                             /* :553-600 */
+        c[0] = rd16(p, be) >> 4; c[1] = rd16(p + 2, be) >> 4; c[2] = rd16(p + 4, be) >> 4; c[3] = rd16(p + 6, be) >> 4; break;
     case FFV1O_Y8: c[0] = p[0]; break;                                                      /* :653-668 */
     default: c[0] = rd16(p, be); break;                                                     /* :993-1034 */
     }
@@ -196,6 +223,8 @@ static inline void store_px(uint32_t f, uint8_t* p, int be, const uint32_t c[4])
         wr16(p, c[0] & 0xFFFF, be); wr16(p + 2, c[1] & 0xFFFF, be); wr16(p + 4, c[2] & 0xFFFF, be); break;
     case FFV1O_RGBA16_BE: case FFV1O_RGBA16_LE:
         wr16(p, c[0] & 0xFFFF, be); wr16(p + 2, c[1] & 0xFFFF, be); wr16(p + 4, c[2] & 0xFFFF, be); wr16(p + 6, c[3] & 0xFFFF, be); break;
+    case FFV1O_RGBA12_FILLEDA_BE: case FFV1O_RGBA12_FILLEDA_LE:
+        wr16(p, (c[0] << 4) & 0xFFFF, be); wr16(p + 2, (c[1] << 4) & 0xFFFF, be); wr16(p + 4, (c[2] << 4) & 0xFFFF, be); wr16(p + 6, (c[3] << 4) & 0xFFFF, be); break;
     case FFV1O_Y8: p[0] = (uint8_t)c[0]; break;
     default: wr16(p, c[0] & 0xFFFF, be); break;
     }
@@ -208,17 +237,61 @@ static int gb_swapped(uint32_t f)
     return is_rgb(f) && !has_alpha(f) && bps >= 9 && bps <= 15;
 }
 
+/* Sequential reader / writer of the word-stream layouts, shaped like the reference's From() loops: fields are
+ * taken from / put into 32-bit words one after the other (Transform.cpp:214-322 for 12-bit packed, :451-480 for
+ * RGBA 10-bit, :781-796 for Y 10-bit). */
+typedef struct { const uint8_t* p; uint8_t* q; int be, kind, off; uint64_t acc; int nbits; int slot; } field_io;
+static void fio_start(field_io* s, uint32_t f, const uint8_t* rd, uint8_t* wr)
+{
+    s->p = rd; s->q = wr; s->be = is_be(f); s->kind = word_layout(f); s->acc = 0; s->nbits = 0; s->slot = 0;
+    s->off = f == FFV1O_Y10_FILLEDB_BE ? 0 : 2;
+    if (s->kind == 10 && ffv1o_plane_count(f) == 4) s->kind = 11;   /* RGBA 10-bit: first field in the top bits */
+}
+static uint32_t fio_get(field_io* s)
+{
+    if (s->kind == 12) {                                   /* LSB-first bit stream over big-endian words */
+        if (s->nbits < 12) { s->acc |= (uint64_t)rd32(s->p, 1) << s->nbits; s->p += 4; s->nbits += 32; }
+        uint32_t v = (uint32_t)(s->acc & 0xFFF); s->acc >>= 12; s->nbits -= 12; return v;
+    }
+    if (s->slot == 0) s->acc = rd32(s->p, s->be), s->p += 4;
+    uint32_t v = s->kind == 11 ? (uint32_t)(s->acc >> (22 - 10 * s->slot)) & 0x3FF : (uint32_t)(s->acc >> (10 * s->slot + s->off)) & 0x3FF;
+    s->slot = (s->slot + 1) % 3;
+    return v;
+}
+static void fio_put(field_io* s, uint32_t v)
+{
+    if (s->kind == 12) {
+        s->acc |= (uint64_t)(v & 0xFFF) << s->nbits; s->nbits += 12;
+        if (s->nbits >= 32) { wr32(s->q, (uint32_t)s->acc, 1); s->q += 4; s->acc >>= 32; s->nbits -= 32; }
+        return;
+    }
+    v &= 0x3FF;
+    s->acc |= s->kind == 11 ? (uint64_t)v << (22 - 10 * s->slot) : (uint64_t)v << (10 * s->slot + s->off);
+    if (++s->slot == 3) { wr32(s->q, (uint32_t)s->acc, s->be); s->q += 4; s->acc = 0; s->slot = 0; }
+}
+static void fio_flush(field_io* s)                         /* the last, partly filled word of a line; padding bits are zero */
+{
+    if (s->kind == 12) { if (s->nbits) { wr32(s->q, (uint32_t)s->acc, 1); s->q += 4; } s->acc = 0; s->nbits = 0; return; }
+    if (s->slot) { wr32(s->q, (uint32_t)s->acc, s->be); s->q += 4; s->acc = 0; s->slot = 0; }
+}
+
 void ffv1o_unpack(const ffv1o_params* p, const uint8_t* payload, size_t line_bytes, int32_t* const planes[4])
 {
     const uint32_t f = p->pixfmt, bpp = ffv1o_bytes_per_pixel(f);
-    const int be = is_be(f), swap = gb_swapped(f), rgb = is_rgb(f), alpha = has_alpha(f);
+    const int be = is_be(f), swap = gb_swapped(f), rgb = is_rgb(f), alpha = has_alpha(f), words = word_layout(f) != 0;
+    const int vflip = (p->flags & FFV1O_FLAG_VFLIP) != 0, altern = (p->flags & FFV1O_FLAG_ALTERN) != 0;
     const int32_t off = (int32_t)1 << ffv1o_bits_per_raw_sample(f);
-    for (uint32_t y = 0; y < p->height; y++) {
-        const uint8_t* s = payload + (size_t)y * line_bytes;
+    field_io io;
+    if (altern) fio_start(&io, f, payload, NULL);
+    for (uint32_t fy = 0; fy < p->height; fy++) {          /* fy: line in the file */
+        const uint32_t y = vflip ? p->height - 1 - fy : fy;
+        const uint8_t* s = payload + (size_t)fy * line_bytes;
+        if (words && !altern) fio_start(&io, f, s, NULL);
         size_t o = (size_t)y * p->width;
         for (uint32_t x = 0; x < p->width; x++, s += bpp) {
             uint32_t c[4] = { 0, 0, 0, 0 };
-            load_px(f, s, be, c);
+            if (words) for (uint32_t i = 0; i < ffv1o_plane_count(f); i++) c[i] = fio_get(&io);
+            else load_px(f, s, be, c);
             if (!rgb) { planes[0][o + x] = (int32_t)c[0]; continue; }
             /* inverse of JPEG2000RCT, Transform.cpp:29-37 */
             int32_t r = (int32_t)c[0], g = (int32_t)c[1], b = (int32_t)c[2];
@@ -236,26 +309,36 @@ void ffv1o_unpack(const ffv1o_params* p, const uint8_t* payload, size_t line_byt
 void ffv1o_pack(const ffv1o_params* p, int32_t* const planes[4], uint8_t* payload, size_t line_bytes)
 {
     const uint32_t f = p->pixfmt, bpp = ffv1o_bytes_per_pixel(f);
-    const int be = is_be(f), swap = gb_swapped(f), rgb = is_rgb(f), alpha = has_alpha(f);
+    const int be = is_be(f), swap = gb_swapped(f), rgb = is_rgb(f), alpha = has_alpha(f), words = word_layout(f) != 0;
+    const int vflip = (p->flags & FFV1O_FLAG_VFLIP) != 0, altern = (p->flags & FFV1O_FLAG_ALTERN) != 0;
     const int32_t off = (int32_t)1 << ffv1o_bits_per_raw_sample(f);
-    for (uint32_t y = 0; y < p->height; y++) {
-        uint8_t* d = payload + (size_t)y * line_bytes;
-        memset(d, 0, line_bytes);
+    field_io io;
+    if (altern) fio_start(&io, f, NULL, payload);
+    for (uint32_t fy = 0; fy < p->height; fy++) {
+        const uint32_t y = vflip ? p->height - 1 - fy : fy;
+        uint8_t* d = payload + (size_t)fy * line_bytes;
+        if (!altern) memset(d, 0, line_bytes);
+        if (words && !altern) fio_start(&io, f, NULL, d);
         size_t o = (size_t)y * p->width;
         for (uint32_t x = 0; x < p->width; x++, d += bpp) {
             uint32_t c[4] = { 0, 0, 0, 0 };
-            if (!rgb) { c[0] = (uint32_t)planes[0][o + x]; store_px(f, d, be, c); continue; }
-            /* JPEG2000RCT, Transform.cpp:29-37 */
-            int32_t g = planes[0][o + x], b = planes[1][o + x], r = planes[2][o + x];
-            b -= off; r -= off;
-            g -= (b + r) >> 2;
-            b += g; r += g;
-            if (swap) { int32_t t = g; g = b; b = t; }
-            c[0] = (uint32_t)r; c[1] = (uint32_t)g; c[2] = (uint32_t)b;
-            if (alpha) c[3] = (uint32_t)planes[3][o + x];
-            store_px(f, d, be, c);
+            if (!rgb) c[0] = (uint32_t)planes[0][o + x];
+            else {
+                /* JPEG2000RCT, Transform.cpp:29-37 */
+                int32_t g = planes[0][o + x], b = planes[1][o + x], r = planes[2][o + x];
+                b -= off; r -= off;
+                g -= (b + r) >> 2;
+                b += g; r += g;
+                if (swap) { int32_t t = g; g = b; b = t; }
+                c[0] = (uint32_t)r; c[1] = (uint32_t)g; c[2] = (uint32_t)b;
+                if (alpha) c[3] = (uint32_t)planes[3][o + x];
+            }
+            if (words) for (uint32_t i = 0; i < ffv1o_plane_count(f); i++) fio_put(&io, c[i]);
+            else store_px(f, d, be, c);
         }
+        if (words && !altern) fio_flush(&io);
     }
+    if (altern) fio_flush(&io);
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -34,8 +34,21 @@ enum {
     FFV1O_Y8 = 10,             /* 1 B/px */
     FFV1O_Y16_BE = 11,         /* 2 B/px */
     FFV1O_Y16_LE = 12,
+    /* bit-packed DPX flavors (DPX.cpp:184-207); "packed" = 12-bit fields filling big-endian 32-bit words from the LSB up,
+     * a line padded to a whole word (Transform.cpp:161-322, 521-550, 851-990) */
+    FFV1O_RGB12_PACKED_BE = 13,
+    FFV1O_RGBA10_FILLEDA_BE = 14, /* 3 fields per 32-bit word at <<22,<<12,<<2 running R,G,B,A,R,... (Transform.cpp:445-518) */
+    FFV1O_RGBA10_FILLEDA_LE = 15,
+    FFV1O_RGBA12_PACKED_BE = 16,
+    FFV1O_RGBA12_FILLEDA_BE = 17, /* 8 B/px 4 x (v<<4) u16 (Transform.cpp:553-600) */
+    FFV1O_RGBA12_FILLEDA_LE = 18,
+    FFV1O_Y10_FILLEDA_BE = 19,    /* 3 samples per big-endian word at <<2,<<12,<<22 (Transform.cpp:709-822, Offset 2) */
+    FFV1O_Y10_FILLEDB_BE = 20,    /* ... at <<0,<<10,<<20 (Offset 0) */
+    FFV1O_Y12_PACKED_BE = 21,
     FFV1O_PIXFMT_COUNT
 };
+#define FFV1O_FLAG_VFLIP  1u   /* picture line y is file line height-1-y (DPX orientation 2 + "-vf vflip", Main.cpp:207-211) */
+#define FFV1O_FLAG_ALTERN 2u   /* Y 10-bit only: words are filled across line ends, no line padding (DPX.cpp:363-368) */
 
 typedef struct {
     uint32_t width, height;
@@ -44,6 +57,7 @@ typedef struct {
     uint32_t num_v_slices;
     uint32_t ec;            /* slicecrc: 0/1 */
     uint32_t context_model; /* -context: 0 (3 inputs) / 1 (5 inputs, FFmpeg's level maps) / 2 (5 inputs, compact 5,5,3,3,3 maps) */
+    uint32_t flags;         /* FFV1O_FLAG_* (payload layout only; the bitstream does not know about them) */
 } ffv1o_params;
 
 /* geometry helpers */
@@ -52,6 +66,8 @@ uint32_t ffv1o_plane_count(uint32_t pixfmt);        /* 1, 3 or 4 */
 uint32_t ffv1o_bytes_per_pixel(uint32_t pixfmt);
 /* bytes per payload line: DPX pads each line to 32 bit (RawFrame.cpp:109); TIFF does not. */
 size_t   ffv1o_line_bytes(uint32_t pixfmt, uint32_t width, int dpx_line_padding);
+/* bytes of a whole payload: height * line_bytes, or the continuous word stream of the "altern" layout */
+size_t   ffv1o_payload_bytes(const ffv1o_params* p, size_t line_bytes);
 
 /* FFV1 configuration record incl. CRC (inverse of FFV1_Parameters.cpp:23-183).  Returns size. */
 size_t ffv1o_config_record(const ffv1o_params* p, uint8_t* out, size_t cap);

@@ -23,7 +23,7 @@ class RcgpuError(RuntimeError):
 class ImageInfo(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("pixfmt", C.c_uint32), ("bits_per_sample", C.c_uint32),
                 ("data_offset", C.c_uint64), ("data_size", C.c_uint64), ("line_bytes", C.c_uint32), ("slices", C.c_uint32),
-                ("framerate", C.c_double), ("flavor", C.c_char * 64)]
+                ("framerate", C.c_double), ("flavor", C.c_char * 64), ("flags", C.c_uint32)]
 
 
 class AudioInfo(C.Structure):
@@ -34,7 +34,7 @@ class AudioInfo(C.Structure):
 class Ffv1Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("pixfmt", C.c_uint32), ("line_bytes", C.c_uint32),
                 ("num_h_slices", C.c_uint32), ("num_v_slices", C.c_uint32), ("slicecrc", C.c_uint32), ("context", C.c_uint32),
-                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32)]
+                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class FlacConfig(C.Structure):
@@ -162,8 +162,8 @@ def md5(data: bytes) -> bytes:
 class Ffv1Encoder:
     """Device FFV1 encoder (rcgpu_ffv1_*).  Raises when no HIP device is visible."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0):
-        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments)
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0, flags=0):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments, flags)
         self.h = _VP()
         _check(lib().rcgpu_ffv1_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_create")
         self.max_packet = lib().rcgpu_ffv1_max_packet_bytes(self.h)
@@ -221,8 +221,8 @@ class Ffv1Encoder:
 class Ffv1Decoder:
     """Device FFV1 decoder + pack (the --check half).  Buffers are device pointers (ints)."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0):
-        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, 0)
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, flags=0):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, 0, flags)
         self.h = _VP()
         _check(lib().rcgpu_ffv1_decoder_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_decoder_create")
 

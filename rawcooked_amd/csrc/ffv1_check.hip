@@ -31,6 +31,7 @@ namespace {
 struct dec_const {
     uint32_t W, H, line_bytes, pixfmt;
     uint32_t planes, bps, bits, rgb, gb_swap, big_endian, bytes_pp, overflow16;
+    uint32_t fields, fill, vflip, altern;  // payload layout of the bit-packed DPX flavors (rc_common.h kFields*), RCGPU_FLAG_*
     uint32_t num_h, num_v, S, nctx, nsets, ec, is5, index_count, qidx;
     int16_t  q[5][256];
     uint8_t  one_state[256], zero_state[256];
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void k_pack(const dec_const* __restrict__ C, c
     const uint32_t f = blockIdx.y, y = pix / W, x = pix - y * W;
     const size_t plane_sz = size_t(W) * H;
     const int32_t* src = planes + size_t(f) * C->planes * plane_sz + pix;
-    uint8_t* line = payloads[f] + size_t(y) * C->line_bytes;
+    uint8_t* line = payloads[f] + size_t(C->vflip ? H - 1 - y : y) * C->line_bytes;
     uint8_t* p = line + size_t(x) * C->bytes_pp;
     const bool be = C->big_endian;
     uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
@@ -241,11 +242,59 @@ __global__ __launch_bounds__(256) void k_pack(const dec_const* __restrict__ C, c
         st16(p, c0 & 0xFFFF, be); st16(p + 2, c1 & 0xFFFF, be); st16(p + 4, c2 & 0xFFFF, be); break;
     case RCGPU_PIX_RGBA16_BE: case RCGPU_PIX_RGBA16_LE:
         st16(p, c0 & 0xFFFF, be); st16(p + 2, c1 & 0xFFFF, be); st16(p + 4, c2 & 0xFFFF, be); st16(p + 6, c3 & 0xFFFF, be); break;
+    case RCGPU_PIX_RGBA12_FILLEDA_BE: case RCGPU_PIX_RGBA12_FILLEDA_LE:
+        st16(p, (c0 << 4) & 0xFFFF, be); st16(p + 2, (c1 << 4) & 0xFFFF, be); st16(p + 4, (c2 << 4) & 0xFFFF, be); st16(p + 6, (c3 << 4) & 0xFFFF, be); break;
     case RCGPU_PIX_Y8: p[0] = uint8_t(c0); break;
     default: st16(p, c0 & 0xFFFF, be); break;
     }
     if (x == W - 1)                                   // DPX lines are padded to 32 bit (RawFrame.cpp:109): zero the padding
         for (uint32_t i = W * C->bytes_pp; i < C->line_bytes; i++) line[i] = 0;
+}
+
+// k_pack for the word-stream layouts (rc_common.h kFields*): one thread per 32-bit word of the payload assembles every field that
+// touches it, so no two threads write the same word.  Restates the From() loops of Transform.cpp:214-322 (RGB 12-bit packed),
+// :445-550 (RGBA 10/12-bit), :781-796 (Y 10-bit), :905-990 (Y 12-bit packed); padding bits are written as zero.
+__device__ __forceinline__ uint32_t field_value(const dec_const* C, const int32_t* fp, size_t plane_sz, uint32_t pix, uint32_t comp)
+{
+    if (!C->rgb) return uint32_t(fp[pix]);
+    if (comp == 3) return uint32_t(fp[3 * plane_sz + pix]);
+    int32_t g = fp[pix], b = fp[plane_sz + pix], r = fp[2 * plane_sz + pix];
+    const int32_t off = int32_t(1) << C->bps;
+    b -= off; r -= off; g -= (b + r) >> 2; b += g; r += g;
+    if (C->gb_swap) { const int32_t t = g; g = b; b = t; }
+    return uint32_t(comp == 0 ? r : comp == 1 ? g : b);
+}
+
+__global__ __launch_bounds__(256) void k_pack_words(const dec_const* __restrict__ C, const int32_t* __restrict__ planes, uint8_t* const* __restrict__ payloads)
+{
+    const uint32_t W = C->W, H = C->H, np = C->planes, fields = C->fields;
+    const uint32_t words_per_line = C->altern ? (W * H + 2) / 3 : C->line_bytes / 4, nlines = C->altern ? 1 : H;
+    const uint32_t widx = blockIdx.x * 256 + threadIdx.x;
+    if (widx >= words_per_line * nlines) return;
+    const uint32_t f = blockIdx.y, fy = widx / words_per_line, k = widx - fy * words_per_line;
+    const uint32_t y = C->vflip ? H - 1 - fy : fy;
+    const size_t plane_sz = size_t(W) * H;
+    const int32_t* fp = planes + size_t(f) * np * plane_sz;
+    const uint32_t nfields = C->altern ? W * H : W * np;             // fields in this line (altern: in the frame)
+    const uint32_t pix0 = C->altern ? 0 : y * W;
+    uint32_t word = 0;
+    if (fields == kFieldsPacked) {
+        const uint32_t lo = k * 32, first = lo / 12, last = min((lo + 31) / 12, nfields - 1);
+        for (uint32_t i = first; i <= last && i < nfields; i++) {
+            const uint32_t v = field_value(C, fp, plane_sz, pix0 + i / np, i % np) & 0xFFF, bit = i * 12;
+            word |= bit >= lo ? v << (bit - lo) : v >> (lo - bit);
+        }
+        word = __builtin_bswap32(word);
+    } else {
+        for (uint32_t slot = 0; slot < 3; slot++) {
+            const uint32_t i = k * 3 + slot;
+            if (i >= nfields) break;
+            const uint32_t v = field_value(C, fp, plane_sz, pix0 + i / np, i % np) & 0x3FF;
+            word |= v << (fields == kFieldsTop ? 22 - 10 * slot : 10 * slot + C->fill);
+        }
+        if (C->big_endian) word = __builtin_bswap32(word);
+    }
+    reinterpret_cast<uint32_t*>(payloads[f] + (C->altern ? size_t(0) : size_t(fy) * C->line_bytes))[k] = word;
 }
 
 __global__ __launch_bounds__(256) void k_compare(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, unsigned long long n,
@@ -348,7 +397,11 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     if (cfg->pixfmt >= RCGPU_PIX_COUNT || !cfg->width || !cfg->height || !cfg->num_h_slices || !cfg->num_v_slices || !cfg->max_batch)
         return fail(2, "ffv1 decoder: bad configuration");
     const pix_desc& px = pix(cfg->pixfmt);
-    if (cfg->line_bytes < cfg->width * px.bytes_pp) return fail(2, "ffv1 decoder: line_bytes smaller than a line");
+    const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
+    if (altern && px.fields != kFieldsLow) return fail(2, "ffv1 decoder: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only");
+    if ((cfg->flags & RCGPU_FLAG_VFLIP) && altern) return fail(2, "ffv1 decoder: RCGPU_FLAG_VFLIP and RCGPU_FLAG_ALTERN exclude each other");
+    if (!altern && cfg->line_bytes < payload_line_bytes(cfg->pixfmt, cfg->width, false)) return fail(2, "ffv1 decoder: line_bytes smaller than a line");
+    if (px.fields != kFieldsBytes && !altern && cfg->line_bytes % 4) return fail(2, "ffv1 decoder: line_bytes of a word-stream layout must be a multiple of 4");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(3, "ffv1 decoder: no HIP device available -- there is no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(3, "ffv1 decoder: device %d out of range", cfg->device);
@@ -362,6 +415,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     dec_const& c = d->hc;
     c.W = cfg->width; c.H = cfg->height; c.line_bytes = cfg->line_bytes; c.pixfmt = cfg->pixfmt;
     c.planes = px.planes; c.bps = px.bits; c.rgb = px.planes != 1; c.gb_swap = px.gb_swap; c.big_endian = px.big_endian; c.bytes_pp = px.bytes_pp;
+    c.fields = px.fields; c.fill = px.fill; c.vflip = (cfg->flags & RCGPU_FLAG_VFLIP) != 0; c.altern = altern;
     c.bits = c.rgb ? px.bits + 1 : (px.bits <= 8 ? 8 : px.bits);
     c.overflow16 = (!c.rgb && px.bits == 16);
     c.num_h = cfg->num_h_slices; c.num_v = cfg->num_v_slices; c.S = c.num_h * c.num_v; c.nctx = Q.context_count;
@@ -414,7 +468,12 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     hipLaunchKernelGGL(k_dec_slices, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
                        d->d_states, d->nkeys, d->d_planes, d->d_err);
     HIP_TRY(hipEventRecord(d->ev[2], st));
-    hipLaunchKernelGGL(k_pack, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, d->d_const, d->d_planes, d->d_out_ptrs);
+    if (c.fields == kFieldsBytes)
+        hipLaunchKernelGGL(k_pack, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, d->d_const, d->d_planes, d->d_out_ptrs);
+    else {
+        const uint32_t nwords = c.altern ? (c.W * c.H + 2) / 3 : c.H * (c.line_bytes / 4);
+        hipLaunchKernelGGL(k_pack_words, dim3((nwords + 255) / 256, n), dim3(256), 0, st, d->d_const, d->d_planes, d->d_out_ptrs);
+    }
     HIP_TRY(hipEventRecord(d->ev[3], st));
     HIP_TRY(hipGetLastError());
     d->ev_valid = true;

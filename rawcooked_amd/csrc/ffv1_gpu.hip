@@ -38,6 +38,7 @@ namespace {
 struct enc_const {
     uint32_t W, H, line_bytes, pixfmt;
     uint32_t planes, bps, bits, rgb, gb_swap, big_endian, bytes_pp, overflow16;
+    uint32_t fields, fill, vflip, altern;  // payload layout of the bit-packed DPX flavors (rc_common.h kFields*), RCGPU_FLAG_*
     uint32_t num_h, num_v, S, nctx, nsets, ec, is5;
     uint32_t samples_per_frame;            // W*H*planes
     uint32_t nseg;                         // segments a slice is cut into for the k_resolve -> k_rangecode hand-over
@@ -73,6 +74,23 @@ __device__ __forceinline__ uint32_t ld16(const uint8_t* p, bool be)
     return be ? ((v >> 8) | ((v & 0xFF) << 8)) : v;
 }
 
+// Field `idx` of a word-stream line (rc_common.h kFields*): 12-bit fields fill big-endian words from the LSB up and may
+// straddle two words; 10-bit fields sit three to a word.
+__device__ __forceinline__ uint32_t ld_field(const uint8_t* line, uint32_t idx, uint32_t fields, uint32_t fill, bool be)
+{
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(line);
+    if (fields == kFieldsPacked) {
+        const uint32_t bit = idx * 12, k = bit >> 5, sh = bit & 31;
+        uint32_t v = __builtin_bswap32(w[k]) >> sh;
+        if (sh > 20) v |= __builtin_bswap32(w[k + 1]) << (32 - sh);
+        return v & 0xFFF;
+    }
+    const uint32_t k = idx / 3, slot = idx - k * 3;
+    uint32_t v = w[k];
+    if (be) v = __builtin_bswap32(v);
+    return (v >> (fields == kFieldsTop ? 22 - 10 * slot : 10 * slot + fill)) & 0x3FF;
+}
+
 __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C, const uint8_t* const* __restrict__ frames,
                                                 int32_t* __restrict__ planes, uint32_t frame0)
 {
@@ -81,9 +99,18 @@ __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C,
     if (pix >= W * H) return;
     const uint32_t f = blockIdx.y;           // frame inside this sub-batch; planes hold one sub-batch
     const uint32_t y = pix / W, x = pix - y * W;
-    const uint8_t* p = frames[frame0 + f] + size_t(y) * C->line_bytes + size_t(x) * C->bytes_pp;
+    const uint32_t fy = C->vflip ? H - 1 - y : y;                    // line in the file (Transform.cpp:181-185)
+    const uint8_t* p = frames[frame0 + f] + size_t(fy) * C->line_bytes + size_t(x) * C->bytes_pp;
     const bool be = C->big_endian;
     uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
+    if (C->fields != kFieldsBytes) {
+        const uint32_t fields = C->fields, fill = C->fill, np = C->planes;
+        const uint8_t* line = frames[frame0 + f] + (C->altern ? size_t(0) : size_t(fy) * C->line_bytes);
+        const uint32_t i0 = C->altern ? fy * W + x : x * np;
+        c0 = ld_field(line, i0, fields, fill, be);
+        if (np > 1) { c1 = ld_field(line, i0 + 1, fields, fill, be); c2 = ld_field(line, i0 + 2, fields, fill, be); }
+        if (np > 3) c3 = ld_field(line, i0 + 3, fields, fill, be);
+    } else
     switch (C->pixfmt) {
     case RCGPU_PIX_RGB8:  c0 = p[0]; c1 = p[1]; c2 = p[2]; break;
     case RCGPU_PIX_RGBA8: { const uint32_t w = *reinterpret_cast<const uint32_t*>(p); c0 = w & 0xFF; c1 = (w >> 8) & 0xFF; c2 = (w >> 16) & 0xFF; c3 = w >> 24; break; }
@@ -97,6 +124,8 @@ __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C,
         c0 = ld16(p, be); c1 = ld16(p + 2, be); c2 = ld16(p + 4, be); break;
     case RCGPU_PIX_RGBA16_BE: case RCGPU_PIX_RGBA16_LE:
         c0 = ld16(p, be); c1 = ld16(p + 2, be); c2 = ld16(p + 4, be); c3 = ld16(p + 6, be); break;
+    case RCGPU_PIX_RGBA12_FILLEDA_BE: case RCGPU_PIX_RGBA12_FILLEDA_LE:
+        c0 = ld16(p, be) >> 4; c1 = ld16(p + 2, be) >> 4; c2 = ld16(p + 4, be) >> 4; c3 = ld16(p + 6, be) >> 4; break;
     case RCGPU_PIX_Y8: c0 = p[0]; break;
     default: c0 = ld16(p, be); break;
     }
@@ -817,7 +846,10 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (!cfg->max_batch) return fail(2, "ffv1: max_batch is 0");
     if (cfg->segments > kMaxSeg) return fail(2, "ffv1: at most %u segments", kMaxSeg);
     const pix_desc& d = pix(cfg->pixfmt);
-    if (cfg->line_bytes < cfg->width * d.bytes_pp) return fail(2, "ffv1: line_bytes smaller than a line");
+    const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
+    if (altern && d.fields != kFieldsLow) return fail(2, "ffv1: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only (DPX.cpp:363-368)");
+    if ((cfg->flags & RCGPU_FLAG_VFLIP) && altern) return fail(2, "ffv1: RCGPU_FLAG_VFLIP and RCGPU_FLAG_ALTERN exclude each other");
+    if (!altern && cfg->line_bytes < payload_line_bytes(cfg->pixfmt, cfg->width, false)) return fail(2, "ffv1: line_bytes smaller than a line");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(3, "ffv1: no HIP device available -- this encoder has no CPU path");
@@ -837,6 +869,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     enc_const& c = e->hc;
     c.W = cfg->width; c.H = cfg->height; c.line_bytes = cfg->line_bytes; c.pixfmt = cfg->pixfmt;
     c.planes = d.planes; c.bps = d.bits; c.rgb = d.planes != 1; c.gb_swap = d.gb_swap; c.big_endian = d.big_endian; c.bytes_pp = d.bytes_pp;
+    c.fields = d.fields; c.fill = d.fill; c.vflip = (cfg->flags & RCGPU_FLAG_VFLIP) != 0; c.altern = altern;
     c.bits = c.rgb ? d.bits + 1 : (d.bits <= 8 ? 8 : d.bits);                  // FFV1_Parameters.cpp:164-181
     c.overflow16 = (!c.rgb && d.bits == 16);                                   // FFV1_Parameters.cpp:160
     c.num_h = cfg->num_h_slices; c.num_v = cfg->num_v_slices; c.S = S; c.nctx = Q.context_count;
@@ -851,7 +884,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     e->resume_stride = uint32_t((80 + ((e->nkeys + 31) / 32) * 4 + 15) & ~15u);
     e->lds_states = size_t(e->nkeys) * 32 <= (48u << 10);                        // 338 contexts x 2 (3) sets x 32 B = 21.6 (32.4) KB
     if (e->lds_states) { e->resolve_lds += size_t(e->nkeys) * 32; e->resume_stride = uint32_t(80 + e->nkeys * 32); }
-    e->frame_payload = size_t(cfg->line_bytes) * cfg->height;
+    e->frame_payload = size_t(payload_bytes(cfg->pixfmt, cfg->width, cfg->height, cfg->line_bytes, cfg->flags));
 
     // segments: the decision stream of a slice is produced and consumed in nseg windows (double buffered) instead of
     // being resident as a whole; auto = enough symbols per segment to keep launch overheads invisible
@@ -880,7 +913,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             for (uint16_t d16 : hd) hdr.push_back((d16 & 0x100) ? uint16_t(d16 & 0xFF) : uint16_t(0xFF00u | (256 - (d16 & 0xFF))));   // (state, bit) -> (t, c)
             // room for 1.5x the raw payload of the slice (incompressible 16-bit noise codes to ~1.1x once the contexts have
             // adapted) + what ~10^4 contexts x 32 states can cost before they have (tiny slices reach 1.7x), + header/footer
-            const size_t raw15 = size_t(g.w) * g.h * d.bytes_pp * 3 / 2;
+            const size_t raw15 = size_t(g.w) * g.h * (d.bytes_pp ? d.bytes_pp : d.planes * 2u) * 3 / 2;
             size_t cap = (raw15 + std::min<size_t>(raw15, 256u << 10) + 4096 + 15) & ~size_t(15);
             if (cap > 0xFFFFFF + 64) cap = 0xFFFFFF + 64;          // slice size field is 24 bit
             cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here

@@ -22,17 +22,14 @@ static uint32_t reference_slice_x(uint32_t width, uint32_t height, uint32_t bitd
     return s ? s : 1;
 }
 
-static void flavor_string(char out[64], const char* container, uint32_t pixfmt)
+static void flavor_string(char out[64], const char* container, uint32_t pixfmt, const char* dpx_packing)
 {
-    // "<container>/Raw/<RGB|RGBA|Y>/<bits>bit[/Packing]/U[/BE|LE]"  (Lib/Common/Common.cpp:123-139, DPX.cpp DPX_Flavor_String)
+    // "<container>/Raw/<RGB|RGBA|Y>/<bits>bit/U/<BE|LE>[/<Packing>]": Raw_Flavor_String (Lib/Common/Common.cpp:123-139) and, for
+    // DPX bit depths that are not whole bytes, the packing name appended (DPX.cpp:762-778).  8-bit rows of both tables are "LE".
     const pix_desc& d = pix(pixfmt);
     const char* cs = d.planes == 1 ? "Y" : d.planes == 4 ? "RGBA" : "RGB";
-    const bool filled = pixfmt == RCGPU_PIX_RGB10_FILLEDA_BE || pixfmt == RCGPU_PIX_RGB10_FILLEDA_LE ||
-                        pixfmt == RCGPU_PIX_RGB12_FILLEDA_BE || pixfmt == RCGPU_PIX_RGB12_FILLEDA_LE;
-    if (d.bits == 8)
-        snprintf(out, 64, "%s/Raw/%s/8bit/U", container, cs);
-    else
-        snprintf(out, 64, "%s/Raw/%s/%ubit%s/U/%s", container, cs, d.bits, filled ? "/FilledA" : "", d.big_endian ? "BE" : "LE");
+    snprintf(out, 64, "%s/Raw/%s/%ubit/U/%s%s%s", container, cs, d.bits, d.bits > 8 && d.big_endian ? "BE" : "LE",
+             dpx_packing && d.bits % 8 ? "/" : "", dpx_packing && d.bits % 8 ? dpx_packing : "");
 }
 
 extern "C" int rcgpu_dpx_probe(const uint8_t* f, size_t size, rcgpu_image_info* out)
@@ -68,47 +65,58 @@ extern "C" int rcgpu_dpx_probe(const uint8_t* f, size_t size, rcgpu_image_info* 
     } else
         offset_to_data = offset_to_image;                                                     // DPX.cpp:352-361
     if (rd32(f + 812, be) != 0) return fail(11, "dpx: end-of-line padding");
-    if (orientation != 0) return fail(12, "dpx: orientation %u not supported by this encoder", orientation);
+    if (orientation != 0 && orientation != 2) return fail(12, "dpx: orientation %u is not supported", orientation);
     if (!width || !height) return fail(13, "dpx: empty image");
 
     // flavor table, DPX.cpp:184-231 (Tested + Also rows reachable with the layouts this encoder implements)
     int pf = -1;
-    const bool filledA = packing == 1, packed = packing == 0;
+    const bool filledA = packing == 1, filledB = packing == 2, packed = packing == 0;
     switch (descriptor) {
     case 50:   // RGB
         if (bitdepth == 8 && (packed || filledA)) pf = RCGPU_PIX_RGB8;
         else if (bitdepth == 10 && filledA) pf = be ? RCGPU_PIX_RGB10_FILLEDA_BE : RCGPU_PIX_RGB10_FILLEDA_LE;
         else if (bitdepth == 12 && filledA) pf = be ? RCGPU_PIX_RGB12_FILLEDA_BE : RCGPU_PIX_RGB12_FILLEDA_LE;
+        else if (bitdepth == 12 && packed && be) pf = RCGPU_PIX_RGB12_PACKED_BE;
         else if (bitdepth == 16 && (packed || filledA)) pf = be ? RCGPU_PIX_RGB16_BE : RCGPU_PIX_RGB16_LE;
         break;
     case 51:   // RGBA
         if (bitdepth == 8 && (packed || filledA)) pf = RCGPU_PIX_RGBA8;
+        else if (bitdepth == 10 && filledA) pf = be ? RCGPU_PIX_RGBA10_FILLEDA_BE : RCGPU_PIX_RGBA10_FILLEDA_LE;
+        else if (bitdepth == 12 && filledA) pf = be ? RCGPU_PIX_RGBA12_FILLEDA_BE : RCGPU_PIX_RGBA12_FILLEDA_LE;
+        else if (bitdepth == 12 && packed && be) pf = RCGPU_PIX_RGBA12_PACKED_BE;
         else if (bitdepth == 16 && (packed || filledA)) pf = be ? RCGPU_PIX_RGBA16_BE : RCGPU_PIX_RGBA16_LE;
         break;
     case 6:    // Y
         if (bitdepth == 8 && (packed || filledA)) pf = RCGPU_PIX_Y8;
+        else if (bitdepth == 10 && be && (filledA || filledB)) pf = filledA ? RCGPU_PIX_Y10_FILLEDA_BE : RCGPU_PIX_Y10_FILLEDB_BE;
+        else if (bitdepth == 12 && packed && be) pf = RCGPU_PIX_Y12_PACKED_BE;
         else if (bitdepth == 16 && (packed || filledA || packing == 3)) pf = be ? RCGPU_PIX_Y16_BE : RCGPU_PIX_Y16_LE;
         break;
     }
     if (pf < 0)
-        return fail(14, "dpx: flavor (descriptor %u, %u bit, packing %u, %s) is not supported by this encoder yet",
+        return fail(14, "dpx: flavor (descriptor %u, %u bit, packing %u, %s) is not supported",
                     descriptor, bitdepth, packing, be ? "BE" : "LE");
     const pix_desc& d = pix(uint32_t(pf));
+    // only the 12-bit Packed flavors may be stored bottom-up, only Y 10-bit may run words across lines (DPX.cpp:189,202-204,409-412)
+    const bool vflip_ok = pf == RCGPU_PIX_RGB12_PACKED_BE || pf == RCGPU_PIX_Y12_PACKED_BE;
+    if (orientation == 2 && !vflip_ok) return fail(12, "dpx: orientation 2 is not supported for this flavor");
+    const bool altern = bitdepth == 10 && descriptor != 50 && size >= 1563 &&
+                        (!memcmp(f + 160, "Lasergraphics Inc.", 18) || !memcmp(f + 160, "DIAMANT-Film", 12) || !memcmp(f + 1556, "Scanity", 7));   // DPX.cpp:363-368
+    if (altern && d.fields != kFieldsLow) return fail(12, "dpx: words running across lines are not supported for this flavor");
+    out->flags = (orientation == 2 ? RCGPU_FLAG_VFLIP : 0) | (altern ? RCGPU_FLAG_ALTERN : 0);
     out->width = width; out->height = height; out->pixfmt = uint32_t(pf); out->bits_per_sample = d.bits;
-    // lines are padded to 32 bit (DPX.cpp:476-481, RawFrame.cpp:109)
-    const uint64_t bits_per_line = uint64_t(width) * d.bytes_pp * 8;
-    out->line_bytes = uint32_t(((bits_per_line + 31) / 32) * 4);
+    out->line_bytes = altern ? 0 : payload_line_bytes(uint32_t(pf), width, true);
     out->data_offset = offset_to_data;
-    out->data_size = uint64_t(out->line_bytes) * height;
+    out->data_size = payload_bytes(uint32_t(pf), width, height, out->line_bytes, out->flags);
     if (out->data_offset + out->data_size > size) return fail(15, "dpx: truncated image data");
-    const uint32_t sx = reference_slice_x(width, height, bitdepth);
-    out->slices = sx * sx;
+    out->slices = rcgpu_reference_slices(width, height, bitdepth, d.px_per_block);
+    if (!out->slices) return fail(16, "dpx: no slice layout keeps %u-pixel blocks whole at width %u", d.px_per_block, width);   // DPX.cpp:443-456
     if (industry && size >= 1944) {     // DPX.cpp:370-387
         auto f32 = [&](size_t o) { uint32_t u = rd32(f + o, be); float v; memcpy(&v, &u, 4); return (u == 0xFFFFFFFFu || v != v) ? 0.0 : double(v); };
         const double film = f32(1724), tv = f32(1940);
         out->framerate = film ? film : tv;
     }
-    flavor_string(out->flavor, "DPX", out->pixfmt);
+    flavor_string(out->flavor, "DPX", out->pixfmt, packed ? "Packed" : filledA ? "FilledA" : filledB ? "FilledB" : nullptr);
     return 0;
 }
 
@@ -212,7 +220,7 @@ extern "C" int rcgpu_tiff_probe(const uint8_t* f, size_t size, rcgpu_image_info*
     if (last > size) return fail(17, "tiff: truncated image data");
     const uint32_t sx = reference_slice_x(width, height, bps);
     out->slices = sx * sx;
-    flavor_string(out->flavor, "TIFF", out->pixfmt);
+    flavor_string(out->flavor, "TIFF", out->pixfmt, nullptr);
     return 0;
 }
 

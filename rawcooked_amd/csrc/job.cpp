@@ -101,6 +101,7 @@ struct video_plan {
     bool tiff = false;
     rational fps;
     uint32_t num_h = 1, num_v = 1;
+    bool vflip = false;
     int track = 0;
 };
 struct audio_plan {
@@ -147,6 +148,9 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     if (opt.num("level", 3) != 3) return bail(fail(2, "-level %ld is not supported by rcgpu (only 3)", opt.num("level", 3)));
     if (opt.num("g", 1) != 1) return bail(fail(2, "-g %ld is not supported by rcgpu (intra only)", opt.num("g", 1)));
     if (job->framemd5_path) return bail(fail(2, "-f framemd5 is not supported by rcgpu"));
+    // the only filter the reference ever asks for is `-vf vflip`, for DPX stored bottom-up (CLI/Main.cpp:207-211)
+    if (const char* vf = opt.get("vf")) if (strcmp(vf, "vflip") != 0) return bail(fail(2, "-vf %s is not supported by rcgpu (only vflip)", vf));
+    const bool vflip_all = opt.has("vf");
     uint32_t context = uint32_t(opt.num("context", 0));
     const uint32_t slicecrc = uint32_t(opt.num("slicecrc", 1));
     // -context 1 uses FFmpeg's level maps unless the compact 5-input model is asked for (RCGPU_CONTEXT_MODEL=compact or
@@ -170,7 +174,6 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     for (size_t si = 0; si < job->n_streams; si++) {
         const rcgpu_stream& s = job->streams[si];
         if (!s.path_or_template && !s.filelist) return bail(fail(5, "stream %zu has no input", si));
-        if (s.vflip) return bail(fail(5, "-vf vflip (DPX orientation 2) is not supported by rcgpu yet"));
         std::vector<std::string> files;
         if (s.filelist && *s.filelist) {
             const char* p = s.filelist;
@@ -192,6 +195,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         } else {
             video_plan v; v.files = std::move(files);
             if (int r = probe_image(v.files[0], v.tiff, v.info)) return bail(r);
+            v.vflip = s.vflip || vflip_all;
             if (s.flavor && *s.flavor && strcmp(s.flavor, v.info.flavor) != 0)
                 return bail(fail(6, "stream %zu: caller says flavor %s, file is %s", si, s.flavor, v.info.flavor));
             uint32_t slices = uint32_t(opt.num("slices", 0));
@@ -245,6 +249,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             F = batch ? batch : uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (uint64_t(96) << 30) / (px * 160 + 1))));
             F = uint32_t(std::min<uint64_t>(F, (v.files.size() + ndev - 1) / ndev));
             rcgpu_ffv1_config c{}; c.width = v.info.width; c.height = v.info.height; c.pixfmt = v.info.pixfmt; c.line_bytes = v.info.line_bytes;
+            c.flags = (v.info.flags & RCGPU_FLAG_ALTERN) | (v.vflip ? RCGPU_FLAG_VFLIP : 0);
             c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.max_batch = F;
             for (int d = 0; d < ndev; d++) {
                 c.device = dev0 + d;
@@ -308,7 +313,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                     rcgpu_image_info fi{};
                     const int r = v.tiff ? rcgpu_tiff_probe(maps[i]->data, maps[i]->size, &fi) : rcgpu_dpx_probe(maps[i]->data, maps[i]->size, &fi);
                     if (r) { err = r; break; }
-                    if (fi.width != v.info.width || fi.height != v.info.height || fi.pixfmt != v.info.pixfmt || fi.line_bytes != v.info.line_bytes)
+                    if (fi.width != v.info.width || fi.height != v.info.height || fi.pixfmt != v.info.pixfmt || fi.line_bytes != v.info.line_bytes || fi.flags != v.info.flags)
                         { err = fail(31, "%s differs in geometry/flavor from the first frame of the sequence", v.files[first + i].c_str()); break; }
                     ptrs[i] = maps[i]->data + fi.data_offset;
                     if (packets[i].size() < cap) packets[i].resize(cap);

@@ -16,21 +16,46 @@ int fail(int code, const char* fmt, ...)
 void clear_error() { g_err[0] = 0; }
 
 static const pix_desc k_pix[RCGPU_PIX_COUNT] = {
-    /* RGB8            */ {  8, 3, 3, false, false },
-    /* RGB10_FILLEDA_BE*/ { 10, 3, 4, true,  true  },
-    /* RGB10_FILLEDA_LE*/ { 10, 3, 4, false, true  },
-    /* RGB12_FILLEDA_BE*/ { 12, 3, 6, true,  true  },
-    /* RGB12_FILLEDA_LE*/ { 12, 3, 6, false, true  },
-    /* RGB16_BE        */ { 16, 3, 6, true,  false },
-    /* RGB16_LE        */ { 16, 3, 6, false, false },
-    /* RGBA8           */ {  8, 4, 4, false, false },
-    /* RGBA16_BE       */ { 16, 4, 8, true,  false },
-    /* RGBA16_LE       */ { 16, 4, 8, false, false },
-    /* Y8              */ {  8, 1, 1, false, false },
-    /* Y16_BE          */ { 16, 1, 2, true,  false },
-    /* Y16_LE          */ { 16, 1, 2, false, false },
+    /* RGB8             */ {  8, 3, 3, false, false, kFieldsBytes,  0, 1 },
+    /* RGB10_FILLEDA_BE */ { 10, 3, 4, true,  true,  kFieldsBytes,  0, 1 },
+    /* RGB10_FILLEDA_LE */ { 10, 3, 4, false, true,  kFieldsBytes,  0, 1 },
+    /* RGB12_FILLEDA_BE */ { 12, 3, 6, true,  true,  kFieldsBytes,  0, 1 },
+    /* RGB12_FILLEDA_LE */ { 12, 3, 6, false, true,  kFieldsBytes,  0, 1 },
+    /* RGB16_BE         */ { 16, 3, 6, true,  false, kFieldsBytes,  0, 1 },
+    /* RGB16_LE         */ { 16, 3, 6, false, false, kFieldsBytes,  0, 1 },
+    /* RGBA8            */ {  8, 4, 4, false, false, kFieldsBytes,  0, 1 },
+    /* RGBA16_BE        */ { 16, 4, 8, true,  false, kFieldsBytes,  0, 1 },
+    /* RGBA16_LE        */ { 16, 4, 8, false, false, kFieldsBytes,  0, 1 },
+    /* Y8               */ {  8, 1, 1, false, false, kFieldsBytes,  0, 1 },
+    /* Y16_BE           */ { 16, 1, 2, true,  false, kFieldsBytes,  0, 1 },
+    /* Y16_LE           */ { 16, 1, 2, false, false, kFieldsBytes,  0, 1 },
+    /* RGB12_PACKED_BE  */ { 12, 3, 0, true,  true,  kFieldsPacked, 0, 1 },
+    /* RGBA10_FILLEDA_BE*/ { 10, 4, 0, true,  false, kFieldsTop,    0, 3 },
+    /* RGBA10_FILLEDA_LE*/ { 10, 4, 0, false, false, kFieldsTop,    0, 3 },
+    /* RGBA12_PACKED_BE */ { 12, 4, 0, true,  false, kFieldsPacked, 0, 2 },
+    /* RGBA12_FILLEDA_BE*/ { 12, 4, 8, true,  false, kFieldsBytes,  0, 1 },
+    /* RGBA12_FILLEDA_LE*/ { 12, 4, 8, false, false, kFieldsBytes,  0, 1 },
+    /* Y10_FILLEDA_BE   */ { 10, 1, 0, true,  false, kFieldsLow,    2, 1 },
+    /* Y10_FILLEDB_BE   */ { 10, 1, 0, true,  false, kFieldsLow,    0, 1 },
+    /* Y12_PACKED_BE    */ { 12, 1, 0, true,  false, kFieldsPacked, 0, 1 },
 };
 const pix_desc& pix(uint32_t pixfmt) { return k_pix[pixfmt < RCGPU_PIX_COUNT ? pixfmt : 0]; }
+
+uint32_t payload_line_bytes(uint32_t pixfmt, uint32_t width, bool dpx_padding)
+{
+    const pix_desc& d = pix(pixfmt);
+    const uint64_t nfields = uint64_t(width) * d.planes;
+    if (d.fields == kFieldsPacked) return uint32_t((nfields * 12 + 31) / 32 * 4);
+    if (d.fields != kFieldsBytes) return uint32_t((nfields + 2) / 3 * 4);
+    const uint64_t n = uint64_t(width) * d.bytes_pp;
+    return uint32_t(dpx_padding ? (n + 3) / 4 * 4 : n);
+}
+uint64_t payload_bytes(uint32_t pixfmt, uint32_t width, uint32_t height, uint32_t line_bytes, uint32_t flags)
+{
+    (void)pixfmt;
+    if (flags & RCGPU_FLAG_ALTERN) return (uint64_t(width) * height + 2) / 3 * 4;
+    return uint64_t(line_bytes) * height;
+}
 
 }  // namespace rc
 

@@ -26,10 +26,22 @@ inline uint64_t rd64le(const uint8_t* p) { return uint64_t(rd32(p, false)) | (ui
 struct pix_desc {
     uint8_t bits;        // bits_per_raw_sample
     uint8_t planes;      // 1 (Y), 3 (RGB) or 4 (RGBA)
-    uint8_t bytes_pp;    // bytes per pixel in the payload
+    uint8_t bytes_pp;    // bytes per pixel in the payload; 0 when fields straddle bytes (see fields)
     bool    big_endian;
     bool    gb_swap;     // FFV1 codes 9..15-bit RGB without alpha with G and B exchanged (Lib/Transform/Transform.cpp:104,126,338,363)
+    uint8_t fields;      // layout of the bit-packed DPX flavors, a stream of 32-bit words per line:
+                         //   kFieldsBytes   whole bytes per pixel
+                         //   kFieldsPacked  12-bit fields filling each big-endian word from the LSB up (Transform.cpp:214-322, 521-550, 905-990)
+                         //   kFieldsTop     three 10-bit fields per word at <<22, <<12, <<2 (RGBA 10-bit FilledA, Transform.cpp:445-518)
+                         //   kFieldsLow     three 10-bit fields per word at <<fill, <<10+fill, <<20+fill (Y 10-bit FilledA/B, Transform.cpp:781-796)
+    uint8_t fill;        // kFieldsLow: 2 = FilledA, 0 = FilledB
+    uint8_t px_per_block;// pixels per indivisible block when slices may NOT cut a block (DPX.cpp:184-207 without BlockSpan), else 1
 };
+enum { kFieldsBytes = 0, kFieldsPacked = 1, kFieldsTop = 2, kFieldsLow = 3 };
 const pix_desc& pix(uint32_t pixfmt);
+// bytes between payload lines: DPX pads every line to 32 bit (RawFrame.cpp:109, DPX.cpp:463-483), TIFF does not
+uint32_t payload_line_bytes(uint32_t pixfmt, uint32_t width, bool dpx_padding);
+// bytes of one payload; RCGPU_FLAG_ALTERN payloads are one word stream without line padding (DPX.cpp:465-469)
+uint64_t payload_bytes(uint32_t pixfmt, uint32_t width, uint32_t height, uint32_t line_bytes, uint32_t flags);
 
 }  // namespace rc

@@ -15,7 +15,10 @@ import numpy as np
 
 # pixel layouts, numbering shared with include/rcgpu.h (RCGPU_PIX_*)
 PIX_RGB8, PIX_RGB10_FILLEDA_BE, PIX_RGB10_FILLEDA_LE, PIX_RGB12_FILLEDA_BE, PIX_RGB12_FILLEDA_LE, \
-    PIX_RGB16_BE, PIX_RGB16_LE, PIX_RGBA8, PIX_RGBA16_BE, PIX_RGBA16_LE, PIX_Y8, PIX_Y16_BE, PIX_Y16_LE = range(13)
+    PIX_RGB16_BE, PIX_RGB16_LE, PIX_RGBA8, PIX_RGBA16_BE, PIX_RGBA16_LE, PIX_Y8, PIX_Y16_BE, PIX_Y16_LE, \
+    PIX_RGB12_PACKED_BE, PIX_RGBA10_FILLEDA_BE, PIX_RGBA10_FILLEDA_LE, PIX_RGBA12_PACKED_BE, PIX_RGBA12_FILLEDA_BE, \
+    PIX_RGBA12_FILLEDA_LE, PIX_Y10_FILLEDA_BE, PIX_Y10_FILLEDB_BE, PIX_Y12_PACKED_BE = range(22)
+FLAG_VFLIP, FLAG_ALTERN = 1, 2   # RCGPU_FLAG_*
 
 PIX_INFO = {  # pixfmt: (bits, components, bytes per pixel, big endian)
     PIX_RGB8: (8, 3, 3, False), PIX_RGB10_FILLEDA_BE: (10, 3, 4, True), PIX_RGB10_FILLEDA_LE: (10, 3, 4, False),
@@ -23,6 +26,13 @@ PIX_INFO = {  # pixfmt: (bits, components, bytes per pixel, big endian)
     PIX_RGB16_BE: (16, 3, 6, True), PIX_RGB16_LE: (16, 3, 6, False),
     PIX_RGBA8: (8, 4, 4, False), PIX_RGBA16_BE: (16, 4, 8, True), PIX_RGBA16_LE: (16, 4, 8, False),
     PIX_Y8: (8, 1, 1, False), PIX_Y16_BE: (16, 1, 2, True), PIX_Y16_LE: (16, 1, 2, False),
+    # bit-packed DPX flavors: fields straddle bytes (bytes per pixel 0)
+    PIX_RGB12_PACKED_BE: (12, 3, 0, True), PIX_RGBA10_FILLEDA_BE: (10, 4, 0, True), PIX_RGBA10_FILLEDA_LE: (10, 4, 0, False),
+    PIX_RGBA12_PACKED_BE: (12, 4, 0, True), PIX_RGBA12_FILLEDA_BE: (12, 4, 8, True), PIX_RGBA12_FILLEDA_LE: (12, 4, 8, False),
+    PIX_Y10_FILLEDA_BE: (10, 1, 0, True), PIX_Y10_FILLEDB_BE: (10, 1, 0, True), PIX_Y12_PACKED_BE: (12, 1, 0, True),
+}
+DPX_PACKING = {  # pixfmt: DPX "packing" field (0 packed, 1 filled method A, 2 filled method B)
+    PIX_RGB12_PACKED_BE: 0, PIX_RGBA12_PACKED_BE: 0, PIX_Y12_PACKED_BE: 0, PIX_Y10_FILLEDB_BE: 2,
 }
 
 
@@ -51,12 +61,39 @@ def components(width: int, height: int, ncomp: int, bits: int, kind: str = "film
     return out
 
 
-def pack_payload(comp: np.ndarray, pixfmt: int, dpx_line_padding: bool = True) -> tuple[bytes, int]:
+def _words_packed12(fields: np.ndarray) -> np.ndarray:
+    """[n, k] 12-bit fields per row -> [n, ceil(12k/32)] words: an LSB-first bit stream cut into 32-bit words."""
+    n, k = fields.shape
+    nw = (k * 12 + 31) // 32
+    bits = ((fields.astype(np.uint32)[:, :, None] >> np.arange(12, dtype=np.uint32)) & 1).astype(np.uint8).reshape(n, k * 12)
+    bits = np.concatenate([bits, np.zeros((n, nw * 32 - k * 12), dtype=np.uint8)], axis=1).reshape(n, nw, 32)
+    return (bits.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=2).astype(np.uint32)
+
+
+def _words_filled10(fields: np.ndarray, shifts) -> np.ndarray:
+    """[n, k] 10-bit fields per row -> [n, ceil(k/3)] words with three fields each at `shifts`."""
+    n, k = fields.shape
+    nw = (k + 2) // 3
+    f = np.concatenate([fields.astype(np.uint32), np.zeros((n, nw * 3 - k), dtype=np.uint32)], axis=1).reshape(n, nw, 3)
+    return (f[:, :, 0] << shifts[0]) | (f[:, :, 1] << shifts[1]) | (f[:, :, 2] << shifts[2])
+
+
+def pack_payload(comp: np.ndarray, pixfmt: int, dpx_line_padding: bool = True, flags: int = 0) -> tuple[bytes, int]:
     """Pack [h, w, ncomp] samples into the file layout of `pixfmt`.  Returns (payload, line_bytes)."""
     bits, ncomp, bpp, be = PIX_INFO[pixfmt]
     h, w, nc = comp.shape
     assert nc == ncomp
-    if pixfmt in (PIX_RGB10_FILLEDA_BE, PIX_RGB10_FILLEDA_LE):
+    if flags & FLAG_VFLIP:
+        comp = comp[::-1]
+    if pixfmt in (PIX_RGB12_PACKED_BE, PIX_RGBA12_PACKED_BE, PIX_Y12_PACKED_BE):
+        line = _words_packed12(comp.reshape(h, w * nc)).astype(">u4").view(np.uint8).reshape(h, -1)
+    elif pixfmt in (PIX_RGBA10_FILLEDA_BE, PIX_RGBA10_FILLEDA_LE):
+        line = _words_filled10(comp.reshape(h, w * nc), (22, 12, 2)).astype(">u4" if be else "<u4").view(np.uint8).reshape(h, -1)
+    elif pixfmt in (PIX_Y10_FILLEDA_BE, PIX_Y10_FILLEDB_BE):
+        sh = (2, 12, 22) if pixfmt == PIX_Y10_FILLEDA_BE else (0, 10, 20)
+        f = comp.reshape(1, h * w) if flags & FLAG_ALTERN else comp.reshape(h, w)
+        line = _words_filled10(f, sh).astype(">u4").view(np.uint8).reshape(f.shape[0], -1)
+    elif pixfmt in (PIX_RGB10_FILLEDA_BE, PIX_RGB10_FILLEDA_LE):
         c = comp.astype(np.uint32)
         words = (c[:, :, 0] << 22) | (c[:, :, 1] << 12) | (c[:, :, 2] << 2)
         line = words.astype(">u4" if be else "<u4").view(np.uint8).reshape(h, w * 4)
@@ -70,11 +107,11 @@ def pack_payload(comp: np.ndarray, pixfmt: int, dpx_line_padding: bool = True) -
         pad = 4 - line_bytes % 4
         line = np.concatenate([line, np.zeros((h, pad), dtype=np.uint8)], axis=1)
         line_bytes += pad
-    return line.tobytes(), line_bytes
+    return line.tobytes(), (0 if flags & FLAG_ALTERN else line_bytes)
 
 
 def dpx_file(comp: np.ndarray, pixfmt: int, fps: float = 24.0, frame_index: int = 0, big_endian_header: bool | None = None,
-             trailer: bytes = b"") -> bytes:
+             trailer: bytes = b"", flags: int = 0) -> bytes:
     """A DPX v2.0 file (2048-byte header) whose image element uses `pixfmt`."""
     bits, ncomp, bpp, be = PIX_INFO[pixfmt]
     if big_endian_header is None:
@@ -82,7 +119,7 @@ def dpx_file(comp: np.ndarray, pixfmt: int, fps: float = 24.0, frame_index: int 
     e = ">" if big_endian_header else "<"
     h, w, _ = comp.shape
     # 8-bit has no endianness in the payload; >8-bit payload endianness == header endianness in DPX
-    payload, _ = pack_payload(comp, pixfmt if bits == 8 else _with_endian(pixfmt, big_endian_header), True)
+    payload, _ = pack_payload(comp, pixfmt if bits == 8 else _with_endian(pixfmt, big_endian_header), True, flags)
     hdr = bytearray(b"\x00" * 2048)
     hdr[0:4] = b"SDPX" if big_endian_header else b"XPDS"
     struct.pack_into(e + "I", hdr, 4, 2048)
@@ -96,8 +133,10 @@ def dpx_file(comp: np.ndarray, pixfmt: int, fps: float = 24.0, frame_index: int 
     hdr[36:36 + len(name)] = name
     hdr[136:160] = b"2026:01:01:00:00:00:UTC\x00"
     hdr[160:160 + 5] = b"rcgpu"
+    if flags & FLAG_ALTERN:
+        hdr[160:160 + 18] = b"Lasergraphics Inc."        # creators whose 10-bit words run across line ends (DPX.cpp:363-368)
     struct.pack_into(e + "I", hdr, 660, 0xFFFFFFFF)   # encryption key: unencrypted
-    struct.pack_into(e + "H", hdr, 768, 0)            # orientation
+    struct.pack_into(e + "H", hdr, 768, 2 if flags & FLAG_VFLIP else 0)   # orientation: 2 = bottom to top
     struct.pack_into(e + "H", hdr, 770, 1)            # number of image elements
     struct.pack_into(e + "I", hdr, 772, w)
     struct.pack_into(e + "I", hdr, 776, h)
@@ -106,7 +145,7 @@ def dpx_file(comp: np.ndarray, pixfmt: int, fps: float = 24.0, frame_index: int 
     hdr[801] = 2
     hdr[802] = 2
     hdr[803] = bits
-    struct.pack_into(e + "H", hdr, 804, 1 if bits in (10, 12) else 0)   # packing: FilledA for 10/12 bit
+    struct.pack_into(e + "H", hdr, 804, DPX_PACKING.get(pixfmt, 1 if bits in (10, 12) else 0))   # packing
     struct.pack_into(e + "H", hdr, 806, 0)            # encoding: none
     struct.pack_into(e + "I", hdr, 808, 2048)         # offset to data
     struct.pack_into(e + "I", hdr, 812, 0)            # end-of-line padding
@@ -119,7 +158,8 @@ def dpx_file(comp: np.ndarray, pixfmt: int, fps: float = 24.0, frame_index: int 
 
 def _with_endian(pixfmt: int, be: bool) -> int:
     pairs = {PIX_RGB10_FILLEDA_BE: PIX_RGB10_FILLEDA_LE, PIX_RGB12_FILLEDA_BE: PIX_RGB12_FILLEDA_LE,
-             PIX_RGB16_BE: PIX_RGB16_LE, PIX_RGBA16_BE: PIX_RGBA16_LE, PIX_Y16_BE: PIX_Y16_LE}
+             PIX_RGB16_BE: PIX_RGB16_LE, PIX_RGBA16_BE: PIX_RGBA16_LE, PIX_Y16_BE: PIX_Y16_LE,
+             PIX_RGBA10_FILLEDA_BE: PIX_RGBA10_FILLEDA_LE, PIX_RGBA12_FILLEDA_BE: PIX_RGBA12_FILLEDA_LE}
     for b, l in pairs.items():
         if pixfmt in (b, l):
             return b if be else l

@@ -24,7 +24,7 @@ from rawcooked_amd import api, synth  # noqa: E402
 REF = os.path.join(ROOT, "oracle", "_ref", "rawcooked")
 OK = "Reversibility was checked, no issue detected."
 
-FFV1 = [  # name, w, h, pixfmt, frames, kind, tiff
+FFV1 = [  # name, w, h, pixfmt, frames, kind, tiff[, layout flags]
     ("dpx_rgb16be_64x48", 64, 48, synth.PIX_RGB16_BE, 2, "film", False),
     ("dpx_rgb10be_50x38", 50, 38, synth.PIX_RGB10_FILLEDA_BE, 2, "film", False),
     ("dpx_rgb10le_61x35", 61, 35, synth.PIX_RGB10_FILLEDA_LE, 1, "noise", False),
@@ -35,6 +35,22 @@ FFV1 = [  # name, w, h, pixfmt, frames, kind, tiff
     ("dpx_y8_40x24", 40, 24, synth.PIX_Y8, 1, "film", False),
     ("tiff_rgb16le_40x30", 40, 30, synth.PIX_RGB16_LE, 2, "film", True),
     ("dpx_rgb16be_flat_96x64", 96, 64, synth.PIX_RGB16_BE, 1, "flat", False),
+    # bit-packed flavors.  Widths: the reference only merges the words shared by two slices when slice (0,0) itself ends inside
+    # a word (Finalize is registered there, Transform.cpp:176-177,724-725,866-867), so 50..56-wide pictures with an aligned first
+    # slice fail in the reference itself; these geometries have either every or the first boundary unaligned.
+    ("dpx_rgb12packed_56x38", 56, 38, synth.PIX_RGB12_PACKED_BE, 1, "film", False),
+    ("dpx_rgb12packed_vflip_96x40", 96, 40, synth.PIX_RGB12_PACKED_BE, 1, "film", False, synth.FLAG_VFLIP),
+    ("dpx_rgba10be_96x40", 96, 40, synth.PIX_RGBA10_FILLEDA_BE, 1, "film", False),
+    ("dpx_rgba10le_51x38", 51, 38, synth.PIX_RGBA10_FILLEDA_LE, 1, "noise", False),
+    ("dpx_rgba12packed_50x38", 50, 38, synth.PIX_RGBA12_PACKED_BE, 1, "film", False),
+    ("dpx_rgba12be_50x38", 50, 38, synth.PIX_RGBA12_FILLEDA_BE, 1, "film", False),
+    ("dpx_rgba12le_50x38", 50, 38, synth.PIX_RGBA12_FILLEDA_LE, 1, "noise", False),
+    ("dpx_y10a_52x38", 52, 38, synth.PIX_Y10_FILLEDA_BE, 1, "film", False),
+    ("dpx_y10a_altern_50x38", 50, 38, synth.PIX_Y10_FILLEDA_BE, 1, "film", False, synth.FLAG_ALTERN),
+    ("dpx_y10b_100x38", 100, 38, synth.PIX_Y10_FILLEDB_BE, 1, "noise", False),
+    ("dpx_y10b_altern_52x38", 52, 38, synth.PIX_Y10_FILLEDB_BE, 1, "film", False, synth.FLAG_ALTERN),
+    ("dpx_y12packed_56x38", 56, 38, synth.PIX_Y12_PACKED_BE, 1, "film", False),
+    ("dpx_y12packed_vflip_96x40", 96, 40, synth.PIX_Y12_PACKED_BE, 1, "noise", False, synth.FLAG_VFLIP),
 ]
 FLAC = [  # name, ch, bits, rate, samples, kind
     ("wav_2ch16_48k", 2, 16, 48000, 10000, "music"),
@@ -45,37 +61,40 @@ FLAC = [  # name, ch, bits, rate, samples, kind
 
 
 def run(cmd, cwd):
-    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True)
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=120)
 
 
 def main():
     vectors = {"ffv1": [], "flac": []}
-    for name, w, h, pixfmt, nframes, kind, tiff in FFV1:
+    for name, w, h, pixfmt, nframes, kind, tiff, *rest in FFV1:
+        flags = rest[0] if rest else 0
         work = tempfile.mkdtemp()
         os.makedirs(work + "/seq")
         bits, nc, _, _ = synth.PIX_INFO[pixfmt]
         files = []
         for i in range(nframes):
             comp = synth.components(w, h, nc, bits, kind, seed=31 * i + 5)
-            data = synth.tiff_file(comp, pixfmt, trailer=b"xyz") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i)
+            data = synth.tiff_file(comp, pixfmt, trailer=b"xyz") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i, flags=flags)
             fn = work + "/seq/f_%06d.%s" % (i, "tif" if tiff else "dpx")
             open(fn, "wb").write(data)
             files.append(fn)
+        ri = run([REF, "--info", "--no-encode", "--no-check-padding", "-y", "seq"], work)      # prints the flavor string of every track
         r = run([REF, "--hash", "--no-check-padding", "-d", "-y", "seq"], work)
         assert r.returncode == 0, r.stderr
         first = open(files[0], "rb").read()
         info = api.tiff_probe(first) if tiff else api.dpx_probe(first)
         slices = int(r.stdout.split("-slices ")[1].split()[0])
-        assert slices == info.slices
+        assert slices == info.slices and info.flags == flags and ("-vf vflip" in r.stdout) == bool(flags & synth.FLAG_VFLIP)
+        assert (" " + info.flavor.decode() + "\n") in ri.stdout + ri.stderr, (info.flavor, ri.stdout, ri.stderr)
         nh, nv = api.slices_to_grid(slices)
-        p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+        p = ob.Params(w, h, pixfmt, nh, nv, 1, 1, flags)
         rec = ob.config_record(p)
         mux = api.MkvMuxer(work + "/seq.mkv")
         t = mux.add_video(rec, w, h, 24, 1)
         mux.add_attachment("RAWcooked reversibility data", open(work + "/seq.rawcooked_reversibility_data", "rb").read())
         mux.begin()
         entry = {"name": name, "width": w, "height": h, "pixfmt": pixfmt, "num_h": nh, "num_v": nv, "line_bytes": info.line_bytes,
-                 "config_record": rec.hex(), "frames": []}
+                 "flags": flags, "flavor": info.flavor.decode(), "slices": slices, "config_record": rec.hex(), "frames": []}
         for i, fn in enumerate(files):
             b = open(fn, "rb").read()
             payload = b[info.data_offset:info.data_offset + info.data_size]

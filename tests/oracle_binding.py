@@ -9,7 +9,7 @@ _lib = None
 
 
 class Params(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "pixfmt", "num_h_slices", "num_v_slices", "ec", "context_model")]
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "pixfmt", "num_h_slices", "num_v_slices", "ec", "context_model", "flags")]
 
 
 def lib():
@@ -21,6 +21,7 @@ def lib():
         L.ffv1o_encode_frame.restype = C.c_size_t
         L.ffv1o_trace_slice.restype = C.c_size_t
         L.ffv1o_line_bytes.restype = C.c_size_t
+        L.ffv1o_payload_bytes.restype = C.c_size_t
         L.ffv1o_last_decisions.restype = C.c_uint64
         L.ffv1o_crc32.restype = C.c_uint32
         _lib = L
@@ -42,7 +43,7 @@ def encode_payload(p: Params, payload: bytes, line_bytes: int) -> bytes:
 
 
 def decode_payload(p: Params, packet: bytes, line_bytes: int) -> bytes:
-    out = C.create_string_buffer(line_bytes * p.height)
+    out = C.create_string_buffer(lib().ffv1o_payload_bytes(C.byref(p), C.c_size_t(line_bytes)))
     r = lib().ffv1o_decode_payload(C.byref(p), packet, C.c_size_t(len(packet)), out, C.c_size_t(line_bytes))
     assert r == 0, f"oracle decoder error {r}"
     return out.raw

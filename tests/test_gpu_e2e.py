@@ -17,12 +17,12 @@ SHIM = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
 OK_LINE = "Reversibility was checked, no issue detected."      # test2.sh:37,69
 
 
-def make_package(work, w, h, pixfmt, nframes, kind, tiff=False, audio=None, start=0):
+def make_package(work, w, h, pixfmt, nframes, kind, tiff=False, audio=None, start=0, flags=0):
     os.makedirs(os.path.join(work, "pkg", "img"))
     bits, nc, _, _ = synth.PIX_INFO[pixfmt]
     for i in range(nframes):
         comp = synth.components(w, h, nc, bits, kind, seed=7 * i + 1)
-        data = synth.tiff_file(comp, pixfmt, trailer=b"tail123") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i)
+        data = synth.tiff_file(comp, pixfmt, trailer=b"tail123") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i, flags=flags)
         with open(os.path.join(work, "pkg", "img", "f_%06d.%s" % (start + i, "tif" if tiff else "dpx")), "wb") as f:
             f.write(data)
     if audio:
@@ -48,13 +48,24 @@ CASES = [
     dict(w=40, h=24, pixfmt=synth.PIX_Y8, nframes=2, kind="film"),
     dict(w=64, h=48, pixfmt=synth.PIX_RGB16_BE, nframes=4, kind="film", audio=(6, 24, 48000, 9000)),   # config 3 shape
     dict(w=2048, h=1556, pixfmt=synth.PIX_RGB10_FILLEDA_BE, nframes=2, kind="film"),                    # config 1 shape
+    # bit-packed flavors (geometries: see the note in tests/golden/make_golden.py about the reference's own word merge)
+    dict(w=56, h=38, pixfmt=synth.PIX_RGB12_PACKED_BE, nframes=2, kind="film"),
+    dict(w=96, h=40, pixfmt=synth.PIX_RGB12_PACKED_BE, nframes=2, kind="film", flags=synth.FLAG_VFLIP),    # DPX orientation 2 -> "-vf vflip"
+    dict(w=96, h=40, pixfmt=synth.PIX_RGBA10_FILLEDA_BE, nframes=2, kind="film"),
+    dict(w=51, h=38, pixfmt=synth.PIX_RGBA10_FILLEDA_LE, nframes=2, kind="noise"),
+    dict(w=50, h=38, pixfmt=synth.PIX_RGBA12_PACKED_BE, nframes=2, kind="film"),
+    dict(w=50, h=38, pixfmt=synth.PIX_RGBA12_FILLEDA_BE, nframes=2, kind="film"),
+    dict(w=52, h=38, pixfmt=synth.PIX_Y10_FILLEDA_BE, nframes=2, kind="film"),
+    dict(w=50, h=38, pixfmt=synth.PIX_Y10_FILLEDB_BE, nframes=2, kind="film", flags=synth.FLAG_ALTERN),     # words run across line ends
+    dict(w=56, h=38, pixfmt=synth.PIX_Y12_PACKED_BE, nframes=2, kind="film"),
+    dict(w=96, h=40, pixfmt=synth.PIX_Y12_PACKED_BE, nframes=2, kind="noise", flags=synth.FLAG_VFLIP),
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-%d%s%s" % (c["w"], c["h"], c["pixfmt"], "-tiff" if c.get("tiff") else "", "-wav" if c.get("audio") else ""))
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-%d%s%s%s" % (c["w"], c["h"], c["pixfmt"], "-tiff" if c.get("tiff") else "", "-wav" if c.get("audio") else "", "-f%d" % c["flags"] if c.get("flags") else ""))
 def test_reference_accepts_gpu_mkv(built, refbin, tmp_path, case):
     work = str(tmp_path)
-    make_package(work, case["w"], case["h"], case["pixfmt"], case["nframes"], case["kind"], case.get("tiff", False), case.get("audio"))
+    make_package(work, case["w"], case["h"], case["pixfmt"], case["nframes"], case["kind"], case.get("tiff", False), case.get("audio"), flags=case.get("flags", 0))
     # 1. the reference analyses the package, writes the reversibility data and prints the ffmpeg command (-d)
     r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -164,7 +175,7 @@ def test_ntsc_framerate_and_python_job_binding(built, refbin, tmp_path):
     os.chdir(work)
     try:
         out = api.Output(Streams=[api.Stream(FileName_Template="pkg/img/f_%06d.dpx", FileName_StartNumber="000000",
-                                             Flavor="DPX/Raw/RGB/10bit/FilledA/U/BE", Slices="16", FrameRate="24000/1001")])
+                                             Flavor="DPX/Raw/RGB/10bit/U/BE/FilledA", Slices="16", FrameRate="24000/1001")])
         assert out.Process("pkg.mkv", rawcooked_reversibility_FileName="pkg.rawcooked_reversibility_data") == 0, api.last_error()
     finally:
         os.chdir(cwd)

@@ -116,3 +116,55 @@ def test_compact_context_model(built, pixfmt, w, h, slices, segments):
     for f in range(3):
         assert bytes(dout[f].cpu().numpy()) == payloads[f]
     enc.close(); dec.close()
+
+
+import json as _json
+import os as _os
+_G = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+_VEC = _json.load(open(_os.path.join(_G, "vectors.json")))
+
+
+@pytest.mark.parametrize("v", _VEC["ffv1"], ids=lambda v: v["name"])
+def test_encode_golden_payloads(built, v):
+    """Every flavor: committed payload -> device encoder == the committed packet the REAL reference accepted and decoded
+    byte-identically (tests/golden/make_golden.py).  This check needs neither the oracle nor /root/reference at run time."""
+    payloads = [open(_os.path.join(_G, f["payload"]), "rb").read() for f in v["frames"]]
+    packets = [open(_os.path.join(_G, f["packet"]), "rb").read() for f in v["frames"]]
+    enc = api.Ffv1Encoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["num_h"], v["num_v"], 1, 1, max_batch=len(payloads), flags=v["flags"])
+    assert enc.config_record().hex() == v["config_record"]
+    assert enc.encode_host(payloads) == packets
+    enc.close()
+
+
+FLAVORS = [  # pixfmt, layout flags -- the bit-packed DPX flavors (DPX.cpp:184-207) at sizes where words straddle slices and lines
+    (synth.PIX_RGB12_PACKED_BE, 0), (synth.PIX_RGB12_PACKED_BE, synth.FLAG_VFLIP), (synth.PIX_RGBA10_FILLEDA_BE, 0), (synth.PIX_RGBA10_FILLEDA_LE, 0),
+    (synth.PIX_RGBA12_PACKED_BE, 0), (synth.PIX_RGBA12_FILLEDA_BE, 0), (synth.PIX_RGBA12_FILLEDA_LE, 0), (synth.PIX_Y10_FILLEDA_BE, 0),
+    (synth.PIX_Y10_FILLEDA_BE, synth.FLAG_ALTERN), (synth.PIX_Y10_FILLEDB_BE, 0), (synth.PIX_Y10_FILLEDB_BE, synth.FLAG_ALTERN),
+    (synth.PIX_Y12_PACKED_BE, 0), (synth.PIX_Y12_PACKED_BE, synth.FLAG_VFLIP),
+]
+
+
+@pytest.mark.parametrize("pixfmt,flags", FLAVORS)
+@pytest.mark.parametrize("w,h,slices", [(67, 29, 4), (130, 45, 9), (24, 10, 1)])
+def test_bit_packed_flavors(built, pixfmt, flags, w, h, slices):
+    """unpack kernel -> packet == oracle; device decoder + word-packing kernel -> the source bytes (padding bits zero)."""
+    import torch
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    nh, nv = api.slices_to_grid(slices)
+    payloads = []
+    for i, kind in enumerate(("film", "noise")):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, kind, seed=11 * pixfmt + i), pixfmt, True, flags)
+        payloads.append(pl)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1, flags)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=2, flags=flags)
+    assert enc.config_record() == ob.config_record(p)
+    packets = enc.encode_host(payloads)
+    for f in range(2):
+        assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=2, flags=flags)
+    dpk = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in packets]
+    dout = [torch.full((len(x),), 0xAA, dtype=torch.uint8, device="cuda") for x in payloads]
+    assert dec.decode_device([t.data_ptr() for t in dpk], [len(x) for x in packets], [t.data_ptr() for t in dout]) == 0
+    for f in range(2):
+        assert bytes(dout[f].cpu().numpy()) == payloads[f]
+    enc.close(); dec.close()

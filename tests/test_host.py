@@ -2,6 +2,7 @@
 hashes, and that the product refuses to run without a GPU (no CPU fallback)."""
 import ctypes as C
 import hashlib
+import json
 import os
 import re
 import struct
@@ -77,6 +78,19 @@ def test_slices_golden_table(built):
     assert ok == {v for v in valid if v <= 1024}
 
 
+@pytest.mark.parametrize("v", [v for v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["ffv1"]
+                               if v["name"].startswith("dpx")], ids=lambda v: v["name"])
+def test_dpx_probe_matches_what_the_reference_printed(built, v):
+    """vectors.json holds, per flavor, the flavor string, the -slices value and the vflip decision the REAL reference printed
+    (tests/golden/make_golden.py); the probe must re-derive them from the header alone."""
+    bits, nc, _, _ = synth.PIX_INFO[v["pixfmt"]]
+    d = synth.dpx_file(synth.components(v["width"], v["height"], nc, bits, "film", seed=1), v["pixfmt"], flags=v["flags"])
+    i = api.dpx_probe(d)
+    assert (i.width, i.height, i.pixfmt, i.flags, i.line_bytes, i.slices, i.flavor.decode()) == \
+           (v["width"], v["height"], v["pixfmt"], v["flags"], v["line_bytes"], v["slices"], v["flavor"])
+    assert i.data_offset + i.data_size == len(d)
+
+
 def test_probes(built):
     comp = synth.components(4096 // 16, 2160 // 16, 3, 16, "film", seed=3)
     d = synth.dpx_file(comp, synth.PIX_RGB16_BE, fps=25.0)
@@ -84,7 +98,8 @@ def test_probes(built):
     assert (i.width, i.height, i.pixfmt, i.data_offset, i.line_bytes, i.framerate) == (256, 135, synth.PIX_RGB16_BE, 2048, 1536, 25.0)
     assert i.flavor == b"DPX/Raw/RGB/16bit/U/BE" and i.data_size == 1536 * 135
     le = synth.dpx_file(synth.components(50, 38, 3, 10), synth.PIX_RGB10_FILLEDA_LE)
-    assert api.dpx_probe(le).flavor == b"DPX/Raw/RGB/10bit/FilledA/U/LE"
+    assert api.dpx_probe(le).flavor == b"DPX/Raw/RGB/10bit/U/LE/FilledA"                  # DPX.cpp:762-778
+    assert api.dpx_probe(synth.dpx_file(synth.components(16, 16, 3, 8), synth.PIX_RGB8)).flavor == b"DPX/Raw/RGB/8bit/U/LE"
     assert api.lib().rcgpu_reference_slices(4096, 2160, 16, 1) == 576 and api.lib().rcgpu_reference_slices(2048, 1556, 10, 1) == 64
     t = synth.tiff_file(synth.components(40, 30, 3, 16), synth.PIX_RGB16_LE, trailer=b"1234567")
     ti = api.tiff_probe(t)
