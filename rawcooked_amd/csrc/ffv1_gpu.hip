@@ -446,51 +446,46 @@ struct rc_resume { uint32_t range, nb, pd; int pos; unsigned long long low; unsi
 
 struct rc_lane {
     uint32_t range; unsigned long long low; uint32_t nb; uint32_t pd;
-    uint32_t ocnt, ovf;               // dwords parked during this piece, and which of them overflowed
-    uint32_t* obuf;                   // LDS [kOutRows + 1][64], this lane's column; the last row is a dump for non-flushes
+    uint32_t ocnt;                    // dwords parked during this piece
+    uint32_t* obuf;                   // LDS [kOutRows + 1][64], this lane's column
     int pos; uint8_t* out; int cap; uint32_t chain;
 };
 
 __device__ __forceinline__ void rc_step(rc_lane& r, uint32_t t, uint32_t c)
 {
     const uint32_t nr = (__umul24(r.range, t) + c) >> 8;
-    const uint32_t inc = (r.range - nr) & uint32_t(int32_t(c - 1) >> 8);      // c == 0 (bit 1): all ones
-    const bool need = nr < 0x100;
-    r.range = need ? nr << 8 : nr;
-    unsigned long long low = r.low + inc;
-    r.low = need ? low << 8 : low;
-    r.nb += need ? 1u : 0u;
+    const uint32_t inc = c ? 0u : r.range - nr;               // c == 0 <=> bit 1
+    const uint32_t sh = nr < 0x100 ? 8u : 0u;                 // renormalise: one byte at most, since t >= 1 keeps nr >= range >> 8
+    r.range = nr << sh;
+    r.low = (r.low + inc) << sh;
+    r.nb += sh >> 3;
 }
 
-// Predicated flush: when >= 4 finished bytes are pending, the four oldest move to pd and the old pd is parked.
-__device__ __forceinline__ void rc_check(rc_lane& r)
+// Predicated flush: when >= 4 finished bytes are pending, the four oldest move to pd and the old pd is parked.  The parked slot is
+// written unconditionally (a lane that does not flush rewrites it at its next real flush), and the ~2^-32 carry out of pd is the
+// only branch: taken by a whole wavefront almost never.
+__device__ __forceinline__ void rc_check(rc_lane& r, uint32_t* ev_count, uint2* ev)
 {
     const bool f = r.nb >= 4;
-    const uint32_t k8 = (r.nb - 4) * 8;                       // 0 or 8 when f
-    const uint32_t hi = uint32_t(r.low >> 32), lo = uint32_t(r.low);
-    const uint32_t carry = hi >> ((16 + k8) & 31);            // bit 16+8nb of low = bit 8nb-16 of hi
-    const uint32_t four = uint32_t(r.low >> ((16 + k8) & 63));
+    const uint32_t sh16 = r.nb * 8 - 16;                      // 16 or 24 when f: the four oldest bytes start at this bit
+    const uint32_t four = uint32_t(r.low >> (sh16 & 63));
+    const uint32_t carry = f ? uint32_t(r.low >> 32) >> (sh16 & 31) : 0u;   // whatever sits above those four bytes
     const uint32_t npd = r.pd + carry;
-    const uint32_t ov = (npd < carry) ? 1u : 0u;
-    r.obuf[(f ? r.ocnt : uint32_t(kOutRows)) * 64] = __builtin_bswap32(npd);
-    r.ovf |= f ? ov << r.ocnt : 0u;
+    r.obuf[r.ocnt * 64] = __builtin_bswap32(npd);
+    if (__builtin_expect(__ballot(npd < carry) != 0, 0)) {    // pd wrapped: +1 belongs to the bytes below that dword, already in HBM
+        if (npd < carry) {
+            const uint32_t slot = atomicAdd(ev_count, 1u);
+            if (slot < kMaxCarryEvents) ev[slot] = make_uint2(r.chain, uint32_t(r.pos + 4 * int(r.ocnt)));
+        }
+    }
     r.ocnt += f ? 1u : 0u;
     r.pd = f ? four : r.pd;
-    const uint32_t keep = lo & ((0x10000u << k8) - 1);
-    r.low = f ? (unsigned long long)keep : r.low;
+    r.low = f ? (unsigned long long)__builtin_amdgcn_ubfe(uint32_t(r.low), 0u, sh16) : r.low;
     r.nb = f ? r.nb - 4 : r.nb;
 }
 
-__device__ __forceinline__ void rc_drain(rc_lane& r, uint32_t* ev_count, uint2* ev)
+__device__ __forceinline__ void rc_drain(rc_lane& r)
 {
-    if (r.ovf) {                                              // ~never: pd wrapped, +1 belongs to the bytes below that dword
-        for (uint32_t k = 0; k < r.ocnt; k++)
-            if ((r.ovf >> k) & 1) {
-                const uint32_t slot = atomicAdd(ev_count, 1u);
-                if (slot < kMaxCarryEvents) ev[slot] = make_uint2(r.chain, uint32_t(r.pos + 4 * int(k)));
-            }
-        r.ovf = 0;
-    }
 #pragma unroll
     for (int k = 0; k < kOutRows; k++) {
         if (uint32_t(k) < r.ocnt) {
@@ -502,7 +497,7 @@ __device__ __forceinline__ void rc_drain(rc_lane& r, uint32_t* ev_count, uint2* 
     r.ocnt = 0;
 }
 
-__device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32_t cnt)
+__device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32_t cnt, uint32_t* ev_count, uint2* ev)
 {
     const uint32_t w[16] = { q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
                              q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w };
@@ -511,7 +506,7 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
         for (int j = 0; j < kPieceEntries; j++) {
             const uint32_t word = w[j >> 1];
             rc_step(r, (j & 1) ? (word >> 16) & 0xFF : word & 0xFF, (j & 1) ? word >> 24 : (word >> 8) & 0xFF);
-            if (j & 1) rc_check(r);
+            if (j & 1) rc_check(r, ev_count, ev);
         }
     } else {
 #pragma unroll 1
@@ -521,7 +516,7 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
             for (int k = 0; k < 16; k++) ww = (j >> 1) == uint32_t(k) ? w[k] : ww;
             const uint32_t ent = (ww >> (16 * (j & 1))) & 0xFFFF;
             rc_step(r, ent & 0xFF, ent >> 8);
-            rc_check(r);
+            rc_check(r, ev_count, ev);
         }
     }
 }
@@ -552,7 +547,7 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
     const uint4* src = reinterpret_cast<const uint4*>(stream + group_off[blockIdx.x]) + lane * 4;
 
     rc_lane r;
-    r.obuf = obuf + lane; r.ocnt = 0; r.ovf = 0;
+    r.obuf = obuf + lane; r.ocnt = 0;
     r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.pos = -4; r.chain = cc;
     if (seg) { const rc_resume v = resume[cc]; r.range = v.range; r.low = v.low; r.nb = v.nb; r.pd = v.pd; r.pos = v.pos; }
     r.out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
@@ -571,19 +566,19 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
         // sits here (covering only loads issued a whole piece ago), not behind the next prefetch.
 #pragma unroll
         for (int k = 0; k < 4; k++) { asm volatile("" : "+v"(cur[k].x), "+v"(cur[k].y), "+v"(cur[k].z), "+v"(cur[k].w)); }
-        rc_drain(r, err + 1, events);
+        rc_drain(r);
         const unsigned long long pn = pc + 1 < npieces ? pc + 1 : (npieces ? npieces - 1 : 0);
         const uint4* p = src + pn * (kGroupPieceBytes / 16);
 #pragma unroll
         for (int k = 0; k < 4; k++) nxt[k] = p[k];                      // prefetch: in flight while this piece is coded
         if (pc < npieces) {
             const unsigned long long left = n - pc * kPieceEntries;
-            rc_piece(r, cur, left < kPieceEntries ? uint32_t(left) : uint32_t(kPieceEntries));
+            rc_piece(r, cur, left < kPieceEntries ? uint32_t(left) : uint32_t(kPieceEntries), err + 1, events);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
-    rc_drain(r, err + 1, events);
+    rc_drain(r);
     if (active && !last_seg) { rc_resume v; v.range = r.range; v.low = r.low; v.nb = r.nb; v.pd = r.pd; v.pos = r.pos; v.pad = 0; resume[cc] = v; }
     if (active && last_seg) {
         // terminate (the state-129 end bit is already the last decision): two forced renormalisations; the last
