@@ -458,7 +458,7 @@ __device__ __forceinline__ void rc_step(rc_lane& r, uint32_t t, uint32_t c)
     const uint32_t sh = nr < 0x100 ? 8u : 0u;                 // renormalise: one byte at most, since t >= 1 keeps nr >= range >> 8
     r.range = nr << sh;
     r.low = (r.low + inc) << sh;
-    r.nb += sh >> 3;
+    r.nb += sh;                                               // nb counts finished BITS (8 per byte)
 }
 
 // Predicated flush: when >= 4 finished bytes are pending, the four oldest move to pd and the old pd is parked.  The parked slot is
@@ -466,8 +466,8 @@ __device__ __forceinline__ void rc_step(rc_lane& r, uint32_t t, uint32_t c)
 // only branch: taken by a whole wavefront almost never.
 __device__ __forceinline__ void rc_check(rc_lane& r, uint32_t* ev_count, uint2* ev)
 {
-    const bool f = r.nb >= 4;
-    const uint32_t sh16 = r.nb * 8 - 16;                      // 16 or 24 when f: the four oldest bytes start at this bit
+    const bool f = r.nb >= 32;                                // nb <= 40 here
+    const uint32_t sh16 = r.nb - 16;                          // 16 or 24 when f: the four oldest bytes start at this bit
     const uint32_t four = uint32_t(r.low >> (sh16 & 63));
     const uint32_t carry = f ? uint32_t(r.low >> 32) >> (sh16 & 31) : 0u;   // whatever sits above those four bytes
     const uint32_t npd = r.pd + carry;
@@ -478,10 +478,10 @@ __device__ __forceinline__ void rc_check(rc_lane& r, uint32_t* ev_count, uint2* 
             if (slot < kMaxCarryEvents) ev[slot] = make_uint2(r.chain, uint32_t(r.pos + 4 * int(r.ocnt)));
         }
     }
-    r.ocnt += f ? 1u : 0u;
+    r.ocnt += r.nb >> 5;                                      // bit 5 of nb <=> f
     r.pd = f ? four : r.pd;
     r.low = f ? (unsigned long long)__builtin_amdgcn_ubfe(uint32_t(r.low), 0u, sh16) : r.low;
-    r.nb = f ? r.nb - 4 : r.nb;
+    r.nb &= 31;                                               // -32 when f
 }
 
 __device__ __forceinline__ void rc_drain(rc_lane& r)
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
     rc_lane r;
     r.obuf = obuf + lane; r.ocnt = 0;
     r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.pos = -4; r.chain = cc;
-    if (seg) { const rc_resume v = resume[cc]; r.range = v.range; r.low = v.low; r.nb = v.nb; r.pd = v.pd; r.pos = v.pos; }
+    if (seg) { const rc_resume v = resume[cc]; r.range = v.range; r.low = v.low; r.nb = v.nb; r.pd = v.pd; r.pos = v.pos; }   // nb in bits
     r.out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
     r.cap = int(G.cbuf_cap);
 
@@ -583,6 +583,7 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
     if (active && last_seg) {
         // terminate (the state-129 end bit is already the last decision): two forced renormalisations; the last
         // latched byte is not emitted -- the decoder reads bytes past the end as zero (FFV1_RangeCoder.cpp:79-85).
+        r.nb >>= 3;                            // back to bytes for the tail
         r.low += 0xFF;                         // nb <= 3 here
         r.low <<= 8; r.nb++;
         r.low <<= 8; r.nb++;                   // nb <= 5: 16 + 40 + carry bits still fit
