@@ -226,6 +226,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
     return v;
 }
 
+// A k_resolve workgroup is ONE wavefront: its LDS operations execute in issue order, so phases that hand data from lane to lane
+// through LDS need no barrier and, above all, no s_waitcnt vmcnt(0) -- which __syncthreads() implies and which would put the HBM
+// latency of every prefetch and store on the critical path.  Only the compiler must keep the order.
+#define WAVE_SYNC() asm volatile("" ::: "memory")
 template <bool LDS_STATES>
 __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
@@ -273,10 +277,10 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     uint32_t piece_base = 0;              // piece index inside this segment's window
     const uint32_t sym_begin = min(G.nsamp, seg * G.seg_q), sym_end = min(G.nsamp, (seg + 1) * G.seg_q);
     const bool last_seg = seg + 1 == C->nseg;
-    __syncthreads();
+    WAVE_SYNC();
 
     auto flush_full = [&]() {
-        __syncthreads();
+        WAVE_SYNC();
         const uint32_t np = stage_count / kPieceEntries;
         const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
         for (uint32_t idx = lane; idx < np * 16; idx += 64) {
@@ -286,19 +290,34 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         const uint32_t rem = stage_count - np * kPieceEntries;
         uint32_t keep = 0;
         if (lane < 16) keep = s32[np * 16 + lane];
-        __syncthreads();
+        WAVE_SYNC();
         if (lane < 16 && np) reinterpret_cast<uint32_t*>(stage)[lane] = keep;
         piece_base += np;
         stage_count = rem;
-        __syncthreads();
+        WAVE_SYNC();
     };
     flush_full();
 
     const unsigned long long lane_bit = 1ull << lane;
+    // Software pipeline over chunks of 64 symbols.  While chunk k is binarised, the symbols of chunk k+2 and the context states of
+    // chunk k+1 are already on their way from HBM, so neither latency sits on the chunk's critical path:
+    //   sv_cur / sv_nxt   symbols of chunk k (in registers) and k+1 (loaded one chunk ago)
+    //   P0, P1            every lane's own context states for chunk k, loaded one chunk ago -- possibly stale if chunk k-1 updated
+    //                     that context, in which case the states are forwarded from chunk k-1's LDS slot instead
+    auto key_of = [&](uint32_t v) { return (v >> 30) * nctx + ((v >> 17) & 0x1FFF); };
+    uint32_t sv_cur = sym_begin + lane < sym_end ? in[sym_begin + lane] : 0;
+    uint32_t sv_nxt = sym_begin + 64 + lane < sym_end ? in[sym_begin + 64 + lane] : 0;
+    uint4 P0 = make_uint4(0, 0, 0, 0), P1 = P0;
+    if (!LDS_STATES && sym_begin + lane < sym_end) {
+        const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(key_of(sv_cur)) * 32);
+        P0 = gp[0]; P1 = gp[1];
+    }
+    uint32_t pkey = 0xFFFFFFFFu;          // previous chunk: this lane's key (none yet) and its group's slot
+    int pleader = 0;
     for (uint32_t base = sym_begin; base < sym_end; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < sym_end;
-        const uint32_t sv = valid ? in[i] : 0;
+        const uint32_t sv = sv_cur;
         const int32_t d = int32_t(sv << 15) >> 15;                    // 17-bit signed residual
         const uint32_t key = (sv >> 30) * nctx + ((sv >> 17) & 0x1FFF);
         const uint32_t a = uint32_t(d < 0 ? -d : d);
@@ -310,8 +329,14 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
 
         // --- which lanes share a context?  One LDS write/read finds the colliding lanes; a scalar loop over the
         // distinct colliding keys gives every lane its predecessor, its group leader and whether it is the last.
+        // did the previous chunk use this lane's context?  Its Hk entry still names one of the lanes that did.
+        const uint32_t hp = valid ? uint32_t(Hk[key]) & 63u : 0u;
+        const uint32_t hp_key = uint32_t(__shfl(int(pkey), int(hp)));      // all lanes take part: the source lane may be past the end of this chunk
+        const bool fwd = !LDS_STATES && valid && hp_key == key;
+        const int fwd_slot = __shfl(pleader, int(hp));
+        WAVE_SYNC();
         if (valid) Hk[key] = uint8_t(lane);
-        __syncthreads();
+        WAVE_SYNC();
         const uint32_t seen = valid ? Hk[key] : uint32_t(lane);
         int leader = lane, pred = -1;
         bool last = true;
@@ -330,21 +355,33 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
             lm &= ~m;
         }
 
-        // --- group leaders fetch the context's 32 states: all 128 on first use in this slice (states_coded = 0),
-        // else from the slice's state array in HBM.
+        // --- group leaders install the context's 32 states in their LDS slot: all 128 on first use in this slice (states_coded = 0),
+        // the previous chunk's result if it used the same context, else what was prefetched from the slice's state array in HBM.
+        // Everything this wavefront has in flight is at least most of a chunk old: the wait is (almost) free, and it also makes
+        // the write-backs of the previous chunk visible before the next prefetch is issued.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const bool first = !LDS_STATES && valid && pred < 0;
         uint4 s0 = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u), s1 = s0;
         if (first) {
             const bool was = (touched[key >> 5] >> (key & 31)) & 1;
-            if (was) {
-                const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(key) * 32);
-                s0 = gp[0]; s1 = gp[1];
-            }
+            if (fwd) { const uint4* fp = reinterpret_cast<const uint4*>(slot + fwd_slot * 32); s0 = fp[0]; s1 = fp[1]; }
+            else if (was) { s0 = P0; s1 = P1; }
+        }
+        WAVE_SYNC();                      // forwarded reads come before this chunk's leaders overwrite the slots
+        if (first) {
             uint4* sp = reinterpret_cast<uint4*>(slot + lane * 32);
             sp[0] = s0; sp[1] = s1;
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (first) atomicOr(&touched[key >> 5], 1u << (key & 31));
+        // --- next chunk's states and the symbols after it leave for HBM now
+        sv_cur = sv_nxt;
+        if (!LDS_STATES && i + 64 < sym_end) {
+            const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(key_of(sv_nxt)) * 32);
+            P0 = gp[0]; P1 = gp[1];
+        }
+        sv_nxt = i + 128 < sym_end ? in[i + 128] : 0;
+        WAVE_SYNC();
 
         // --- rounds: a lane runs once its predecessor (same context, earlier in coding order) is done.
         unsigned long long done = 0;
@@ -391,7 +428,7 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
             }
             done |= __ballot(ready);
             pending = pending && !ready;
-            __syncthreads();
+            WAVE_SYNC();
         }
 
         // --- last lane of each group writes the states back
@@ -401,7 +438,8 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
             gp[0] = sp[0]; gp[1] = sp[1];
         }
         stage_count += total;
-        flush_full();      // contains the workgroup-scope fences that order the state write-back before the next gather
+        flush_full();
+        pkey = valid ? key : 0xFFFFFFFFu; pleader = leader;
     }
     if (!last_seg) {      // park the unfinished piece and the bitmap (or the state table) for the next segment
         if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) rs_states[i] = reinterpret_cast<const uint4*>(lstates)[i];
@@ -413,7 +451,7 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     // end-of-slice bit (state 129, FFV1_Slice.cpp:336-340), then pad the last piece
     if (lane == 0) stage[stage_count] = uint16_t(0xFF00u | (256 - 129));     // state 129, bit 0
     stage_count += 1;
-    __syncthreads();
+    WAVE_SYNC();
     const uint32_t padded = (stage_count + kPieceEntries - 1) / kPieceEntries * kPieceEntries;
     for (uint32_t i = stage_count + lane; i < padded; i += 64) stage[i] = 0x0080;
     stage_count = padded;
@@ -421,6 +459,8 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
 }
 
 // ---------------------------------------------------------------------------------------------------------
+#undef WAVE_SYNC
+
 // K4: range coder, one LANE per slice (chain).  The 64 chains of a wavefront read the same piece index of their
 // interleaved streams each iteration and run the low/range recurrence of RFC 9043 3.8.1 in lock-step.
 //
