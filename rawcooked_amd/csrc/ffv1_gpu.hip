@@ -391,40 +391,79 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         while (__ballot(pending)) {
             const bool ready = pending && (pred < 0 || ((done >> pred) & 1));
             if (ready) {
-                // Symbol binarisation, inverse of rangecoder::s (FFV1_RangeCoder.cpp:135-305), fully unrolled: the context's 32
-                // states sit in 8 registers, every state index is a compile-time constant, and the only memory operations are
-                // the transition look-ups -- independent of each other except where an index repeats (k = 10 and k = 31 for
-                // exponents above 9), so they pipeline instead of forming a 20-deep chain of dependent LDS round trips.
+                // Symbol binarisation, inverse of rangecoder::s (FFV1_RangeCoder.cpp:135-305).  The context's 32 states sit in 8
+                // registers and every state index below is a compile-time constant.  A symbol touches each state at most once,
+                // except state 10 (exponent bits 9 and up) and state 31 (mantissa bits 9 and up): so the transition look-ups of
+                // all other decisions are independent.  Phase 1 issues them back to back (nothing waits on LDS), phase 2 applies
+                // them; only the two short chains are walked with dependent LDS round trips.
                 uint32_t S[8];
                 { const uint4 v0 = reinterpret_cast<const uint4*>(sl)[0], v1 = reinterpret_cast<const uint4*>(sl)[1];
                   S[0] = v0.x; S[1] = v0.y; S[2] = v0.z; S[3] = v0.w; S[4] = v1.x; S[5] = v1.y; S[6] = v1.z; S[7] = v1.w; }
 #define ST_GET(k) ((S[(k) >> 2] >> (8 * ((k) & 3))) & 0xFFu)
-#define ST_PUT(k, v) (S[(k) >> 2] = (S[(k) >> 2] & ~(0xFFu << (8 * ((k) & 3)))) | ((v) << (8 * ((k) & 3))))
-#define CODE(k, bit, pos) do { const uint32_t st_ = ST_GET(k); const uint32_t b_ = (bit); \
-                               op[pos] = uint16_t(b_ ? st_ : (0xFF00u | (256 - st_))); ST_PUT(k, uint32_t(trans[b_ * 256 + st_])); } while (0)
-                if (a == 0) {
-                    CODE(0, 1u, 0);
-                } else {
-                    CODE(0, 0u, 0);
+#define ST_PUT_IF(c, k, v) (S[(k) >> 2] = (c) ? ((S[(k) >> 2] & ~(0xFFu << (8 * ((k) & 3)))) | ((v) << (8 * ((k) & 3)))) : S[(k) >> 2])
+#define ENTRY(st, b) uint16_t((b) ? (st) : (0xFF00u | (256 - (st))))
+#define NEXT(st, b) uint32_t(trans[((b) << 8) + (st)])
+                const bool nz = a != 0;
+                const uint32_t neg = d < 0 ? 1u : 0u;
+                const int ks = 11 + (e < 10 ? e : 10);                  // sign state: the only index that depends on the symbol
+                // ---- phase 1: read states, emit decisions, issue the look-ups
+                const uint32_t st_z = ST_GET(0), b_z = nz ? 0u : 1u;
+                const uint32_t nx_z = NEXT(st_z, b_z);
+                op[0] = ENTRY(st_z, b_z);
+                const uint32_t st_s = nz ? uint32_t(sl[ks]) : 128u;     // sign states 11..21 are touched by nothing else: straight from LDS
+                uint32_t nxe[9], nxm[9];
 #pragma unroll
-                    for (int t = 0; t <= 16; t++) {                 // exponent in unary: ones for t < e, the zero at t == e
-                        if (t <= e) CODE(1 + (t < 9 ? t : 9), t < e ? 1u : 0u, 1 + t);
-                    }
-#pragma unroll
-                    for (int t = 15; t >= 0; t--) {                 // mantissa bits e-1 .. 0
-                        if (t < e) CODE(22 + (t < 9 ? t : 9), (a >> t) & 1u, 2 * e + 1 - t);
-                    }
-                    const int ks = 11 + (e < 10 ? e : 10);
-#pragma unroll
-                    for (int k = 11; k <= 21; k++) {                // sign: the state index depends on e
-                        if (k == ks) CODE(k, d < 0 ? 1u : 0u, 2 * e + 2);
+                for (int t = 0; t < 9; t++) {                           // exponent in unary: ones for t < e, the zero at t == e
+                    nxe[t] = 0;
+                    if (__ballot(nz && t <= e)) {
+                        const uint32_t st = ST_GET(1 + t), b = t < e ? 1u : 0u;
+                        nxe[t] = NEXT(st, b);
+                        if (nz && t <= e) op[1 + t] = ENTRY(st, b);
                     }
                 }
+#pragma unroll
+                for (int t = 0; t < 9; t++) {                           // mantissa bits 8 .. 0
+                    nxm[t] = 0;
+                    if (__ballot(nz && t < e)) {
+                        const uint32_t st = ST_GET(22 + t), b = (a >> t) & 1u;
+                        nxm[t] = NEXT(st, b);
+                        if (nz && t < e) op[2 * e + 1 - t] = ENTRY(st, b);
+                    }
+                }
+                const uint32_t nx_s = NEXT(st_s, neg);
+                if (nz) op[2 * e + 2] = ENTRY(st_s, neg);
+                // ---- the two chains: state 10 for exponent bits 9.., state 31 for mantissa bits e-1 .. 9
+#pragma unroll 1
+                for (int t = 9; t <= 16; t++) {
+                    const bool act = nz && t <= e;
+                    if (!__ballot(act)) break;
+                    const uint32_t st = ST_GET(10), b = t < e ? 1u : 0u;
+                    if (act) op[1 + t] = ENTRY(st, b);
+                    const uint32_t nx = NEXT(st, b);
+                    ST_PUT_IF(act, 10, nx);
+                }
+#pragma unroll 1
+                for (int t = 15; t >= 9; t--) {
+                    const bool act = nz && t < e;
+                    if (!__ballot(act)) continue;                       // no lane has mantissa bit t
+                    const uint32_t st = ST_GET(31), b = (a >> t) & 1u;
+                    if (act) op[2 * e + 1 - t] = ENTRY(st, b);
+                    const uint32_t nx = NEXT(st, b);
+                    ST_PUT_IF(act, 31, nx);
+                }
+                // ---- phase 2: apply the independent transitions
+                ST_PUT_IF(true, 0, nx_z);
+#pragma unroll
+                for (int t = 0; t < 9; t++) ST_PUT_IF(nz && t <= e, 1 + t, nxe[t]);
+#pragma unroll
+                for (int t = 0; t < 9; t++) ST_PUT_IF(nz && t < e, 22 + t, nxm[t]);
 #undef ST_GET
-#undef ST_PUT
-#undef CODE
+#undef ST_PUT_IF
+#undef ENTRY
+#undef NEXT
                 reinterpret_cast<uint4*>(sl)[0] = make_uint4(S[0], S[1], S[2], S[3]);
                 reinterpret_cast<uint4*>(sl)[1] = make_uint4(S[4], S[5], S[6], S[7]);
+                if (nz) sl[ks] = uint8_t(nx_s);                          // after the bulk write-back (LDS operations of a wave stay in order)
             }
             done |= __ballot(ready);
             pending = pending && !ready;
