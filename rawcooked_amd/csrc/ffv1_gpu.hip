@@ -216,14 +216,18 @@ __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, 
 // ---------------------------------------------------------------------------------------------------------
 // K3: adaptive-state resolution, one wavefront per slice.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+// Inclusive prefix sum over the 64 lanes with DPP moves (no LDS crossbar round trips): shifts inside each row of 16, then the
+// row totals are broadcast into the following rows (row_bcast:15 for rows 1 and 3, row_bcast:31 for rows 2 and 3).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+    int x = int(v);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return uint32_t(x);
 }
 
 // A k_resolve workgroup is ONE wavefront: its LDS operations execute in issue order, so phases that hand data from lane to lane
