@@ -247,7 +247,8 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     uint16_t* stage = reinterpret_cast<uint16_t*>(smem);                           // kStageEntries u16
     uint8_t*  slot = smem + ((kStageEntries * 2 + 15) & ~15);                      // 64 x 32
     uint8_t*  trans = slot + 64 * 32;                                               // [bit][state]
-    uint32_t* touched = reinterpret_cast<uint32_t*>(trans + 512);                   // nkeys bits
+    uint8_t*  pw = trans + 512;                                                     // [2][256]: one_state applied 4 and 16 times
+    uint32_t* touched = reinterpret_cast<uint32_t*>(pw + 2 * 256);                  // nkeys bits
     uint8_t*  Hk = reinterpret_cast<uint8_t*>(touched + ((nkeys + 31) / 32 + 3) / 4 * 4);   // nkeys u8
     // LDS_STATES (compact context model): every context's 32 states live here for the whole slice -- no HBM traffic per sample
     uint8_t*  lstates = Hk + ((nkeys + 15) & ~15u);                                          // nkeys x 32
@@ -263,6 +264,11 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     uint32_t* out32 = reinterpret_cast<uint32_t*>(stream + group_off[chain >> 6]) + (chain & 63) * 16;
 
     for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; }
+    // powers of the "coded a 1" transition, for runs of zero residuals in one context (see below)
+    WAVE_SYNC();
+    for (int i = lane; i < 256; i += 64) { const uint8_t* o = trans + 256; pw[i] = o[o[o[o[i]]]]; }
+    WAVE_SYNC();
+    for (int i = lane; i < 256; i += 64) pw[256 + i] = pw[pw[pw[pw[i]]]];
     uint8_t* rs = resume + size_t(chain) * resume_stride;
     uint32_t* rs_touched = reinterpret_cast<uint32_t*>(rs + 80);
     uint4* rs_states = reinterpret_cast<uint4*>(rs + 80);             // LDS_STATES: the state table itself is parked here
@@ -343,18 +349,22 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         WAVE_SYNC();
         const uint32_t seen = valid ? Hk[key] : uint32_t(lane);
         int leader = lane, pred = -1;
-        bool last = true;
+        bool last = true, zrun = false;
+        uint32_t rank = 0;
         unsigned long long lm = __ballot(valid && seen != uint32_t(lane));
         while (lm) {
             const int src = __ffsll((long long)lm) - 1;
             const uint32_t k = __shfl(key, src);
             const bool mine = valid && key == k;
             const unsigned long long m = __ballot(mine);
+            const bool allzero = __ballot(mine && a == 0) == m;        // a run of zero residuals: only state 0 moves, always by "coded a 1"
             if (mine) {
                 leader = __ffsll((long long)m) - 1;
                 const unsigned long long lower = m & (lane_bit - 1);
                 pred = lower ? 63 - __clzll((long long)lower) : -1;
                 last = ((m >> lane) >> 1) == 0;
+                zrun = allzero;
+                rank = uint32_t(__popcll(lower));
             }
             lm &= ~m;
         }
@@ -392,6 +402,21 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         bool pending = valid;
         uint8_t* sl = LDS_STATES ? lstates + size_t(key) * 32 : slot + leader * 32;
         uint16_t* op = stage + stage_count + excl;
+        // Lanes of one context that all carry a zero residual (flat picture areas, letterbox bars) need no rounds: the r-th of them
+        // sees state 0 after r "coded a 1" transitions, which the power tables give in a few look-ups.
+        if (__ballot(zrun)) {
+            if (zrun) {
+                uint32_t st = sl[0];
+                for (uint32_t r = rank & 3; r; r--) st = trans[256 + st];          // rank = 16 a + 4 b + c: at most 3 + 3 + 3 look-ups
+                for (uint32_t r = (rank >> 2) & 3; r; r--) st = pw[st];
+                for (uint32_t r = rank >> 4; r; r--) st = pw[256 + st];
+                op[0] = uint16_t(st);                                  // bit 1: (t, c) = (state, 0)
+                if (last) sl[0] = trans[256 + st];
+            }
+            done |= __ballot(zrun);
+            pending = pending && !zrun;
+            WAVE_SYNC();
+        }
         while (__ballot(pending)) {
             const bool ready = pending && (pred < 0 || ((done >> pred) & 1));
             if (ready) {
@@ -959,7 +984,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     ffv1::make_zero_state(c.zero_state);
     if (c.nctx > 8191) { delete e; return fail(2, "ffv1: context count %u does not fit the symbol format", c.nctx); }
     e->nkeys = c.nsets * c.nctx;
-    e->resolve_lds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);
+    e->resolve_lds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + 2 * 256 + ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);
     e->resume_stride = uint32_t((80 + ((e->nkeys + 31) / 32) * 4 + 15) & ~15u);
     e->lds_states = size_t(e->nkeys) * 32 <= (48u << 10);                        // 338 contexts x 2 (3) sets x 32 B = 21.6 (32.4) KB
     if (e->lds_states) { e->resolve_lds += size_t(e->nkeys) * 32; e->resume_stride = uint32_t(80 + e->nkeys * 32); }
