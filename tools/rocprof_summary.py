@@ -10,7 +10,10 @@ import sys
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "")
-    return name.split("(")[0].strip()
+    name = name.split("(")[0].strip()
+    if name.startswith("void "):            # template instantiations are reported with their return type
+        name = name[5:]
+    return name
 
 
 def main():
