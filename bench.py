@@ -85,10 +85,18 @@ def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, 
     enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
     torch.cuda.synchronize()
     sizes = d_sizes.cpu().tolist()
-    dec = api.Ffv1Decoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=F, device=device)
-    outs = torch.empty((F, line_bytes * height), dtype=torch.uint8, device=frames.device)
-    pk = [d_packets.data_ptr() + i * stride for i in range(F)]
-    op = [outs[i].data_ptr() for i in range(F)]
+    # the decoder is latency-bound per slice chain, so its rate is chains in flight / chain latency: free the encoder's buffers
+    # and decode D >= F frames per step (the F encoded packets, reused round-robin -- SURVEY.md 8d "ring reuse")
+    enc.close()
+    torch.cuda.empty_cache()
+    D = max(F, args.check_batch)
+    sizes = [sizes[i % F] for i in range(D)]
+    dec = api.Ffv1Decoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=D, device=device)
+    outs = torch.empty((D, line_bytes * height), dtype=torch.uint8, device=frames.device)
+    pk = [d_packets.data_ptr() + (i % F) * stride for i in range(D)]
+    op = [outs[i].data_ptr() for i in range(D)]
+    ptrs = [ptrs[i % F] for i in range(D)]
+    F = D
 
     def step():
         dec.decode_device(pk, sizes, op, stream, check=False)
@@ -121,7 +129,6 @@ def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, 
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                      "traffic": None, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}}}))
     dec.close()
-    enc.close()
     if not (same and ok_md5):
         sys.exit(2)
 
@@ -132,6 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "320")), help="frames in flight per GPU per step")
+    ap.add_argument("--check-batch", type=int, default=640, help="--mode check: frames decoded per step (>= --batch)")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)

@@ -21,6 +21,7 @@
 #include <vector>
 #include "ffv1_host.h"
 #include "rc_common.h"
+#include "crc_dev.h"
 
 using namespace rc;
 
@@ -64,22 +65,21 @@ __global__ __launch_bounds__(256) void k_dec_crc(const dec_const* __restrict__ C
                                                  const unsigned long long* __restrict__ slice_start, const uint32_t* __restrict__ slice_len,
                                                  uint32_t* __restrict__ err)
 {
-    __shared__ uint32_t T[256]; __shared__ uint32_t part[4];
+    // CRC over the whole slice incl. its stored CRC must be 0 (FFV1_Slice.cpp:248).  Slices start anywhere in the packet: the
+    // bytes in front of the first 16-byte boundary go to thread 0, the aligned body to the tiled block CRC of crc_dev.h.
+    __shared__ uint32_t T[4][256]; __shared__ uint32_t TM[4][256]; __shared__ uint32_t part[4];
     const int tid = threadIdx.x;
-    { uint32_t c = uint32_t(tid) << 24; for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1); T[tid] = c; }
-    __syncthreads();
+    crc_tables(T, tid);
     const uint32_t chain = blockIdx.x, f = chain / C->S;
     const uint8_t* p = packets[f] + slice_start[chain];
     const uint32_t total = slice_len[chain];
-    const uint32_t seg = (total + 255) / 256;
-    const uint32_t beg = min(total, uint32_t(tid) * seg), end = min(total, beg + seg);
-    uint32_t c = 0;
-    for (uint32_t i = beg; i < end; i++) c = (c << 8) ^ T[(c >> 24) ^ p[i]];
-    // crc(A||B) = crc(A) * x^(8|B|) + crc(B)
-    unsigned long long nb = total - end; uint32_t result = 1, base = 0x100;
-    auto mulmod = [](uint32_t a, uint32_t b) { uint32_t r = 0; for (int i = 31; i >= 0; i--) { r = (r << 1) ^ ((r >> 31) ? 0x04C11DB7u : 0u); if ((b >> i) & 1) r ^= a; } return r; };
-    while (nb) { if (nb & 1) result = mulmod(result, base); base = mulmod(base, base); nb >>= 1; }
-    c = mulmod(c, result);
+    const uint32_t head = min(total, uint32_t((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15));
+    uint32_t c = block_crc_share(p + head, total - head, T, TM, tid);
+    if (tid == 0 && head) {
+        uint32_t h = 0;
+        for (uint32_t i = 0; i < head; i++) h = (h << 8) ^ T[0][(h >> 24) ^ p[i]];
+        c ^= gf_mulmod(h, gf_xpow8(total - head));
+    }
     for (int o = 32; o; o >>= 1) c ^= __shfl_xor(c, o);
     if ((tid & 63) == 0) part[tid >> 6] = c;
     __syncthreads();
@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256) void k_dec_crc(const dec_const* __restrict__ C
 // Range decoder state of one lane (rangecoder, FFV1_RangeCoder.cpp:21-102)
 struct rd_lane { uint32_t current, mask; const uint8_t* cur; const uint8_t* end; };
 
-__device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* st, const uint8_t* trans)
+// A lane's 32 context states live in LDS as eight dwords of a [8][64] array (dword k of lane l at (k*64 + l)*4): for a state index
+// that is uniform over the wavefront every lane touches its own dword -- no bank conflicts, where a [lane][32] layout gives 16-way.
+#define ST_AT(base, k) ((base)[(uint32_t(k) >> 2) * 256 + (uint32_t(k) & 3)])
+
+__device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* base, int k, const uint8_t* trans)
 {
     if (r.mask < 0x100) {
         r.current <<= 8;
@@ -99,30 +103,30 @@ __device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* st, const uint8_
         r.mask <<= 8;
         r.cur++;
     }
-    const uint32_t s = *st;
+    const uint32_t s = ST_AT(base, k);
     const uint32_t m2 = (r.mask * s) >> 8;
     r.mask -= m2;
-    if (r.current < r.mask) { *st = trans[s]; return 0; }
-    r.current -= r.mask; r.mask = m2; *st = trans[256 + s];
+    if (r.current < r.mask) { ST_AT(base, k) = trans[s]; return 0; }
+    r.current -= r.mask; r.mask = m2; ST_AT(base, k) = trans[256 + s];
     return 1;
 }
 __device__ uint32_t rd_u(rd_lane& r, uint8_t* st, const uint8_t* trans)
 {
-    if (rd_bit(r, st, trans)) return 0;
+    if (rd_bit(r, st, 0, trans)) return 0;
     int e = 0;
-    while (rd_bit(r, st + 1 + (e < 9 ? e : 9), trans)) { if (++e > 31) return 0; }
+    while (rd_bit(r, st, 1 + (e < 9 ? e : 9), trans)) { if (++e > 31) return 0; }
     uint32_t a = 1;
-    for (int i = e - 1; i >= 0; i--) a = (a << 1) | rd_bit(r, st + 22 + (i < 9 ? i : 9), trans);
+    for (int i = e - 1; i >= 0; i--) a = (a << 1) | rd_bit(r, st, 22 + (i < 9 ? i : 9), trans);
     return a;
 }
 __device__ int32_t rd_s(rd_lane& r, uint8_t* st, const uint8_t* trans)
 {
-    if (rd_bit(r, st, trans)) return 0;
+    if (rd_bit(r, st, 0, trans)) return 0;
     int e = 0;
-    while (rd_bit(r, st + 1 + (e < 9 ? e : 9), trans)) { if (++e > 31) return 0; }
+    while (rd_bit(r, st, 1 + (e < 9 ? e : 9), trans)) { if (++e > 31) return 0; }
     int32_t a = 1;
-    for (int i = e - 1; i >= 0; i--) a = (a << 1) | int32_t(rd_bit(r, st + 22 + (i < 9 ? i : 9), trans));
-    return rd_bit(r, st + 11 + (e < 10 ? e : 10), trans) ? -a : a;
+    for (int i = e - 1; i >= 0; i--) a = (a << 1) | int32_t(rd_bit(r, st, 22 + (i < 9 ? i : 9), trans));
+    return rd_bit(r, st, 11 + (e < 10 ? e : 10), trans) ? -a : a;
 }
 __device__ __forceinline__ int32_t med3(int32_t a, int32_t b, int32_t c) { return max(min(a, b), min(max(a, b), c)); }
 
@@ -148,9 +152,10 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     rd_lane r;
     r.cur = buf; r.end = buf + (len - tail);
     r.current = len - tail ? *r.cur : 0; r.mask = 0xFF; r.cur++;                   // AssignBuffer, FFV1_RangeCoder.cpp:22-33
-    uint8_t* my = slot + lane * 32;
-    auto fresh = [&]() { uint4* p = reinterpret_cast<uint4*>(my); p[0] = p[1] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u); };
-    if (slice_start[chain] == 0) { fresh(); if (!rd_bit(r, my, trans)) atomicOr(err, 16u); }     // keyframe bit of the first slice in the packet
+    uint8_t* my = slot + lane * 4;
+    uint32_t* myw = reinterpret_cast<uint32_t*>(my);               // dword k of this lane's states: myw[k * 64]
+    auto fresh = [&]() { for (int k = 0; k < 8; k++) myw[k * 64] = 0x80808080u; };
+    if (slice_start[chain] == 0) { fresh(); if (!rd_bit(r, my, 0, trans)) atomicOr(err, 16u); }     // keyframe bit of the first slice in the packet
     // slice header, FFV1_Slice.cpp:113-177
     fresh();
     const uint32_t sx = rd_u(r, my, trans), sy = rd_u(r, my, trans);
@@ -187,17 +192,17 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                 int32_t v = ov16 ? med3(int16_t(L), int16_t(L) + int16_t(T) - int16_t(LT), int16_t(T)) : med3(L, L + T - LT, T);
                 const uint32_t key = set * nctx + uint32_t(ctx < 0 ? -ctx : ctx);
                 uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
-                uint4* sp = reinterpret_cast<uint4*>(my);
-                sp[0] = gp[0]; sp[1] = gp[1];
+                { const uint4 a0 = gp[0], a1 = gp[1];
+                  myw[0] = a0.x; myw[64] = a0.y; myw[128] = a0.z; myw[192] = a0.w; myw[256] = a1.x; myw[320] = a1.y; myw[384] = a1.z; myw[448] = a1.w; }
                 const int32_t delta = rd_s(r, my, trans);
-                gp[0] = sp[0]; gp[1] = sp[1];
+                gp[0] = make_uint4(myw[0], myw[64], myw[128], myw[192]); gp[1] = make_uint4(myw[256], myw[320], myw[384], myw[448]);
                 v = (ctx >= 0 ? v + delta : v - delta) & bitmask;
                 cur[x] = v;
                 LL = L; L = v; LT = T; T = RT;
             }
         }
     // end-of-slice bit, underrun and junk checks (FFV1_Slice.cpp:286-299,336-340)
-    my[0] = 129; rd_bit(r, my, trans);
+    my[0] = 129; rd_bit(r, my, 0, trans);
     const bool underrun = r.cur - (r.mask < 0x100 ? 0 : 1) > r.end;
     const size_t used = r.cur > r.end ? size_t(r.end - buf) : size_t(r.cur - buf) - (r.mask < 0x100 ? 0 : 1);
     if (underrun) atomicOr(err, 64u);

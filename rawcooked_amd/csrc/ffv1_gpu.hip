@@ -27,6 +27,7 @@
 #include <vector>
 #include "ffv1_host.h"
 #include "rc_common.h"
+#include "crc_dev.h"
 
 using namespace rc;
 
@@ -715,26 +716,6 @@ __global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ 
 // CRC: poly 0x04C11DB7, MSB first, init 0, no final xor (ZenCRC32.cpp:1097-1135).  Each lane takes one contiguous
 // segment; crc(A||B) = crc(A) * x^(8|B|) + crc(B) in GF(2)[x]/P combines them.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t gf_mulmod(uint32_t a, uint32_t b)
-{
-    uint32_t r = 0;
-    for (int i = 31; i >= 0; i--) {
-        r = (r << 1) ^ ((r >> 31) ? 0x04C11DB7u : 0u);
-        if ((b >> i) & 1) r ^= a;
-    }
-    return r;
-}
-__device__ uint32_t gf_xpow8(unsigned long long nbytes)      // x^(8*nbytes) mod P
-{
-    uint32_t result = 1, base = 0x100;
-    while (nbytes) {
-        if (nbytes & 1) result = gf_mulmod(result, base);
-        base = gf_mulmod(base, base);
-        nbytes >>= 1;
-    }
-    return result;
-}
-
 __global__ __launch_bounds__(256) void k_footer(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 uint8_t* __restrict__ cbuf, unsigned long long cbuf_frame_stride,
                                                 const uint32_t* __restrict__ out_len, uint32_t* __restrict__ tot_len,

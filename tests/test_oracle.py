@@ -71,6 +71,16 @@ def test_roundtrip_edges(built, w, h, pixfmt, nh, nv, kind):
     assert ob.lib().ffv1o_decode_payload(__import__("ctypes").byref(p), bytes(bad), len(bad), out, lb) != 0   # slice CRC catches it
 
 
+def _run_ref(cmd, cwd, timeout=120, attempts=3):
+    """The reference occasionally dead-locks in its own thread pool on many-core hosts: repeat a step that times out (idempotent, -y)."""
+    for attempt in range(attempts):
+        try:
+            return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, stdin=subprocess.DEVNULL)
+        except subprocess.TimeoutExpired:
+            if attempt + 1 == attempts:
+                raise
+
+
 def test_oracle_packets_pass_the_real_reference(built, refbin, tmp_path):
     """Re-pins the oracle here and now (not only through the committed vectors): DPX 16-bit + WAV package."""
     work = str(tmp_path)
@@ -83,7 +93,7 @@ def test_oracle_packets_pass_the_real_reference(built, refbin, tmp_path):
         files.append(fn)
     wav = synth.wav_file(synth.pcm_samples(5000, 2, 16, 48000), 16, 48000)
     open(work + "/pkg/snd.wav", "wb").write(wav)
-    r = subprocess.run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], cwd=work, capture_output=True, text=True)
+    r = _run_ref([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
     assert r.returncode == 0, r.stderr
     info = api.dpx_probe(open(files[0], "rb").read())
     nh, nv = api.slices_to_grid(info.slices)
@@ -103,5 +113,5 @@ def test_oracle_packets_pass_the_real_reference(built, refbin, tmp_path):
         b = open(fn, "rb").read()
         mux.write_block(tv, i * 10 ** 9 // 24, ob.encode_payload(p, b[info.data_offset:info.data_offset + info.data_size], info.line_bytes))
     mux.close()
-    r = subprocess.run([refbin, "--check", "pkg.mkv"], cwd=work, capture_output=True, text=True)
+    r = _run_ref([refbin, "--check", "pkg.mkv"], work)
     assert r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout, r.stdout + r.stderr
