@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "320")), help="frames in flight per GPU per step")
+    ap.add_argument("--segments", type=int, default=0, help="hand-over windows per slice between k_resolve and k_rangecode (0 = library default)")
     ap.add_argument("--check-batch", type=int, default=640, help="--mode check: frames decoded per step (>= --batch)")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
     ap.add_argument("--width", type=int, default=W4K)
@@ -175,7 +176,7 @@ def main():
     nh, nv = api.slices_to_grid(args.slices)
     frames = make_frames(torch, F, width, height, args.kind, rank, dev)
     ctx = 2 if args.context_model == "compact" else 1
-    enc = api.Ffv1Encoder(width, height, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=F, device=local_rank)
+    enc = api.Ffv1Encoder(width, height, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=F, device=local_rank, segments=args.segments)
     stride = (enc.max_packet + 255) & ~255
     d_packets = torch.empty(F * stride, dtype=torch.uint8, device=dev)
     d_sizes = torch.zeros(F, dtype=torch.int64, device=dev)

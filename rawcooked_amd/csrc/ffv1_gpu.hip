@@ -294,9 +294,11 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         WAVE_SYNC();
         const uint32_t np = stage_count / kPieceEntries;
         const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
-        for (uint32_t idx = lane; idx < np * 16; idx += 64) {
-            const uint32_t pc = idx >> 4, dw = idx & 15;
-            out32[size_t(piece_base + pc) * (kGroupPieceBytes / 4) + dw] = s32[idx];
+        const uint4* s128 = reinterpret_cast<const uint4*>(stage);
+        uint4* out128 = reinterpret_cast<uint4*>(out32);
+        for (uint32_t idx = lane; idx < np * 4; idx += 64) {          // 16 bytes per lane: four lanes cover one 64-byte piece
+            const uint32_t pc = idx >> 2, q = idx & 3;
+            out128[size_t(piece_base + pc) * (kGroupPieceBytes / 16) + q] = s128[idx];
         }
         const uint32_t rem = stage_count - np * kPieceEntries;
         uint32_t keep = 0;
@@ -980,7 +982,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             const uint32_t h = uint32_t(uint64_t(sy + 1) * c.H / c.num_v) - uint32_t(uint64_t(sy) * c.H / c.num_v);
             min_nsamp = std::min(min_nsamp, w * h * c.planes);
         }
-    e->nseg = cfg->segments ? cfg->segments : std::max(1u, std::min(16u, min_nsamp / 8192));
+    e->nseg = cfg->segments ? cfg->segments : std::max(1u, std::min(32u, min_nsamp / 8192));
     c.nseg = e->nseg;
 
     // slice geometry (FFV1_Slice.cpp:153-156), header decisions, raw-byte buffers
