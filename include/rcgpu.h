@@ -80,6 +80,10 @@ enum {   /* pixel layouts; names follow the reference flavors (DPX.cpp:184-231, 
     RCGPU_PIX_RGBA10_FILLEDA_BE = 14, RCGPU_PIX_RGBA10_FILLEDA_LE = 15,
     RCGPU_PIX_RGBA12_PACKED_BE = 16, RCGPU_PIX_RGBA12_FILLEDA_BE = 17, RCGPU_PIX_RGBA12_FILLEDA_LE = 18,
     RCGPU_PIX_Y10_FILLEDA_BE = 19, RCGPU_PIX_Y10_FILLEDB_BE = 20, RCGPU_PIX_Y12_PACKED_BE = 21,
+    /* OpenEXR scan lines, three HALF channels taken as uint16 (the reference runs FFmpeg with -consider_float16_as_uint16 1,
+     * Output.cpp:120-122): every line is [y:u32][bytes:u32][B x width][G x width][R x width], little endian
+     * (Transform.cpp:1062-1127, EXR.cpp:601-606) */
+    RCGPU_PIX_EXR_RGB16 = 22,
     RCGPU_PIX_COUNT
 };
 /* payload layout variants the DPX header announces; the FFV1 bitstream does not know about them */
@@ -109,6 +113,9 @@ typedef struct {
 
 int rcgpu_dpx_probe (const uint8_t* file, size_t size, rcgpu_image_info* out);
 int rcgpu_tiff_probe(const uint8_t* file, size_t size, rcgpu_image_info* out);
+/* exr::ParseBuffer (Lib/Uncompressed/EXR/EXR.cpp:199-633): version 2 single-part scan-line files, channels B,G,R of type HALF,
+ * no compression, increasing-Y line order, data window == display window at the origin. */
+int rcgpu_exr_probe (const uint8_t* file, size_t size, rcgpu_image_info* out);
 int rcgpu_wav_probe (const uint8_t* file, size_t size, rcgpu_audio_info* out);
 
 /* slice_x*slice_y the reference computes for a DPX/TIFF picture (DPX.cpp:428-458, TIFF.cpp:657-672): pixels_per_block > 1

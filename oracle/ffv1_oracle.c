@@ -140,6 +140,7 @@ uint32_t ffv1o_bytes_per_pixel(uint32_t f)
     case FFV1O_Y8: return 1;
     case FFV1O_RGB12_PACKED_BE: case FFV1O_RGBA12_PACKED_BE: case FFV1O_Y12_PACKED_BE:
     case FFV1O_RGBA10_FILLEDA_BE: case FFV1O_RGBA10_FILLEDA_LE: case FFV1O_Y10_FILLEDA_BE: case FFV1O_Y10_FILLEDB_BE: return 0;   /* fields straddle bytes */
+    case FFV1O_EXR_RGB16: return 0;                                                                                                   /* planar inside the line */
     default: return 2;
     }
 }
@@ -155,6 +156,7 @@ static int word_layout(uint32_t f)
 size_t ffv1o_line_bytes(uint32_t f, uint32_t width, int dpx_line_padding)
 {
     const size_t fields = (size_t)width * ffv1o_plane_count(f);
+    if (f == FFV1O_EXR_RGB16) return 8 + 6 * (size_t)width;         /* EXR.cpp:601-606 */
     if (word_layout(f) == 12) return (fields * 12 + 31) / 32 * 4;    /* Transform.cpp:191-194, 881-884 */
     if (word_layout(f) == 10) return (fields + 2) / 3 * 4;           /* Transform.cpp:751-753 */
     size_t n = (size_t)width * ffv1o_bytes_per_pixel(f);
@@ -290,7 +292,11 @@ void ffv1o_unpack(const ffv1o_params* p, const uint8_t* payload, size_t line_byt
         size_t o = (size_t)y * p->width;
         for (uint32_t x = 0; x < p->width; x++, s += bpp) {
             uint32_t c[4] = { 0, 0, 0, 0 };
-            if (words) for (uint32_t i = 0; i < ffv1o_plane_count(f); i++) c[i] = fio_get(&io);
+            if (f == FFV1O_EXR_RGB16) {                     /* inverse of transform_jpeg2000rct_exr_Raw_RGB_16::From, Transform.cpp:1105-1127 */
+                const uint8_t* l = payload + (size_t)fy * line_bytes + 8;
+                c[2] = rd16(l + 2 * (size_t)x, 0); c[1] = rd16(l + 2 * ((size_t)p->width + x), 0); c[0] = rd16(l + 2 * (2 * (size_t)p->width + x), 0);
+            }
+            else if (words) for (uint32_t i = 0; i < ffv1o_plane_count(f); i++) c[i] = fio_get(&io);
             else load_px(f, s, be, c);
             if (!rgb) { planes[0][o + x] = (int32_t)c[0]; continue; }
             /* inverse of JPEG2000RCT, Transform.cpp:29-37 */
@@ -333,8 +339,16 @@ void ffv1o_pack(const ffv1o_params* p, int32_t* const planes[4], uint8_t* payloa
                 c[0] = (uint32_t)r; c[1] = (uint32_t)g; c[2] = (uint32_t)b;
                 if (alpha) c[3] = (uint32_t)planes[3][o + x];
             }
-            if (words) for (uint32_t i = 0; i < ffv1o_plane_count(f); i++) fio_put(&io, c[i]);
+            if (f == FFV1O_EXR_RGB16) {
+                uint8_t* l = payload + (size_t)fy * line_bytes + 8;
+                wr16(l + 2 * (size_t)x, c[2] & 0xFFFF, 0); wr16(l + 2 * ((size_t)p->width + x), c[1] & 0xFFFF, 0); wr16(l + 2 * (2 * (size_t)p->width + x), c[0] & 0xFFFF, 0);
+            }
+            else if (words) for (uint32_t i = 0; i < ffv1o_plane_count(f); i++) fio_put(&io, c[i]);
             else store_px(f, d, be, c);
+        }
+        if (f == FFV1O_EXR_RGB16) {                         /* line header: y coordinate and byte count, Transform.cpp:1078-1085 */
+            uint8_t* l = payload + (size_t)fy * line_bytes;
+            wr32(l, fy, 0); wr32(l + 4, 6 * p->width, 0);
         }
         if (words && !altern) fio_flush(&io);
     }

@@ -45,6 +45,7 @@ enum {
     FFV1O_Y10_FILLEDA_BE = 19,    /* 3 samples per big-endian word at <<2,<<12,<<22 (Transform.cpp:709-822, Offset 2) */
     FFV1O_Y10_FILLEDB_BE = 20,    /* ... at <<0,<<10,<<20 (Offset 0) */
     FFV1O_Y12_PACKED_BE = 21,
+    FFV1O_EXR_RGB16 = 22,         /* OpenEXR scan line: [y:u32][bytes:u32][B x w][G x w][R x w] u16 LE (Transform.cpp:1062-1127) */
     FFV1O_PIXFMT_COUNT
 };
 #define FFV1O_FLAG_VFLIP  1u   /* picture line y is file line height-1-y (DPX orientation 2 + "-vf vflip", Main.cpp:207-211) */

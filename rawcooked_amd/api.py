@@ -67,6 +67,7 @@ SYMBOLS = {
     "rcgpu_main_ffmpeg_argv": (C.c_int, [C.c_int, C.POINTER(C.c_char_p)]),
     "rcgpu_dpx_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
     "rcgpu_tiff_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
+    "rcgpu_exr_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
     "rcgpu_wav_probe": (C.c_int, [_U8P, _SZ, C.POINTER(AudioInfo)]),
     "rcgpu_reference_slices": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rcgpu_slices_to_grid": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -132,6 +133,12 @@ def _check(rc: int, what: str) -> None:
 def dpx_probe(data: bytes) -> ImageInfo:
     info = ImageInfo()
     _check(lib().rcgpu_dpx_probe(data, len(data), C.byref(info)), "rcgpu_dpx_probe")
+    return info
+
+
+def exr_probe(data: bytes) -> ImageInfo:
+    info = ImageInfo()
+    _check(lib().rcgpu_exr_probe(data, len(data), C.byref(info)), "rcgpu_exr_probe")
     return info
 
 

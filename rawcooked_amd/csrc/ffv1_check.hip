@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256) void k_pack(const dec_const* __restrict__ C, c
         if (C->planes == 4) c3 = uint32_t(src[3 * plane_sz]);
     }
     switch (C->pixfmt) {
+    case RCGPU_PIX_EXR_RGB16: {                            // Transform.cpp:1062-1127: line header (y, byte count) then B, G, R runs
+        uint16_t* l16 = reinterpret_cast<uint16_t*>(line + 8);
+        l16[x] = uint16_t(c2); l16[W + x] = uint16_t(c1); l16[2 * W + x] = uint16_t(c0);
+        if (x == 0) { uint32_t* h32 = reinterpret_cast<uint32_t*>(line); h32[0] = y; h32[1] = 6 * W; }
+        return; }
     case RCGPU_PIX_RGB8: p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2); break;
     case RCGPU_PIX_RGBA8: p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2); p[3] = uint8_t(c3); break;
     case RCGPU_PIX_RGB10_FILLEDA_BE: case RCGPU_PIX_RGB10_FILLEDA_LE: {
@@ -406,7 +411,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     if (altern && px.fields != kFieldsLow) return fail(2, "ffv1 decoder: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only");
     if ((cfg->flags & RCGPU_FLAG_VFLIP) && altern) return fail(2, "ffv1 decoder: RCGPU_FLAG_VFLIP and RCGPU_FLAG_ALTERN exclude each other");
     if (!altern && cfg->line_bytes < payload_line_bytes(cfg->pixfmt, cfg->width, false)) return fail(2, "ffv1 decoder: line_bytes smaller than a line");
-    if (px.fields != kFieldsBytes && !altern && cfg->line_bytes % 4) return fail(2, "ffv1 decoder: line_bytes of a word-stream layout must be a multiple of 4");
+    if (px.fields != kFieldsBytes && px.fields != kFieldsExr && !altern && cfg->line_bytes % 4) return fail(2, "ffv1 decoder: line_bytes of a word-stream layout must be a multiple of 4");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(3, "ffv1 decoder: no HIP device available -- there is no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(3, "ffv1 decoder: device %d out of range", cfg->device);
@@ -473,7 +478,7 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     hipLaunchKernelGGL(k_dec_slices, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
                        d->d_states, d->nkeys, d->d_planes, d->d_err);
     HIP_TRY(hipEventRecord(d->ev[2], st));
-    if (c.fields == kFieldsBytes)
+    if (c.fields == kFieldsBytes || c.fields == kFieldsExr)
         hipLaunchKernelGGL(k_pack, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, d->d_const, d->d_planes, d->d_out_ptrs);
     else {
         const uint32_t nwords = c.altern ? (c.W * c.H + 2) / 3 : c.H * (c.line_bytes / 4);

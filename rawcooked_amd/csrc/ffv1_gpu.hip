@@ -104,7 +104,10 @@ __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C,
     const uint8_t* p = frames[frame0 + f] + size_t(fy) * C->line_bytes + size_t(x) * C->bytes_pp;
     const bool be = C->big_endian;
     uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
-    if (C->fields != kFieldsBytes) {
+    if (C->fields == kFieldsExr) {                                   // planar inside the line: B, G, R runs after an 8-byte line header
+        const uint16_t* l16 = reinterpret_cast<const uint16_t*>(frames[frame0 + f] + size_t(fy) * C->line_bytes + 8);
+        c2 = l16[x]; c1 = l16[W + x]; c0 = l16[2 * W + x];
+    } else if (C->fields != kFieldsBytes) {
         const uint32_t fields = C->fields, fill = C->fill, np = C->planes;
         const uint8_t* line = frames[frame0 + f] + (C->altern ? size_t(0) : size_t(fy) * C->line_bytes);
         const uint32_t i0 = C->altern ? fy * W + x : x * np;

@@ -224,6 +224,102 @@ extern "C" int rcgpu_tiff_probe(const uint8_t* f, size_t size, rcgpu_image_info*
     return 0;
 }
 
+extern "C" int rcgpu_exr_probe(const uint8_t* f, size_t size, rcgpu_image_info* out)
+{
+    clear_error();
+    if (!f || !out) return fail(1, "exr: null argument");
+    memset(out, 0, sizeof *out);
+    if (size < 8 || rd32(f, true) != 0x762F3101) return fail(3, "exr: bad magic number");                 // EXR.cpp:210-217
+    const uint32_t version = rd32(f + 4, true);
+    if ((version >> 24) != 2) return fail(4, "exr: unsupported version number");                          // EXR.cpp:220-227
+    if (version & 0xFFFFFF) return fail(4, "exr: version flags (tiles / long names / deep / multi-part) are not supported");
+    size_t o = 8;
+    uint32_t width = 0, height = 0, dw = 0, dh = 0;
+    bool have_display = false, rgb_half = false, have_channels = false;
+    double fps = 0;
+    auto cstr = [&](size_t at, size_t& len) -> const char* {      // NUL-terminated name of at most 31 characters
+        len = 0;
+        while (at + len < size && f[at + len] && len <= 31) len++;
+        if (at + len >= size || len > 31) return nullptr;
+        return reinterpret_cast<const char*>(f + at);
+    };
+    // names the reference knows and skips (EXR.cpp:310-520); anything else makes it refuse the file
+    static const char* const kSkipped[] = { "acesImageContainerFlag", "adoptedNeutral", "capDate", "chromaticities", "comments", "expTime", "focalLength", "focus",
+        "imageCounter", "isoSpeed", "lensMake", "lensSerialNumber", "originalImageFlag", "owner", "pixelAspectRatio", "reelName", "recorderFirmwareVersion",
+        "recorderMake", "recorderModel", "storageMediaSerialNumber", "timeCode", "timecodeRate" };
+    static const char* const kSkippedPrefix[] = { "arri.", "camera", "com.arri.", "interim." };
+    for (;;) {
+        size_t nlen, tlen;
+        const char* name = cstr(o, nlen);
+        if (!name) return fail(5, "exr: bad attribute name");
+        if (!nlen) { o++; break; }                                 // end of header
+        const char* type = cstr(o + nlen + 1, tlen);
+        if (!type || o + nlen + 1 + tlen + 1 + 4 > size) return fail(5, "exr: bad attribute type");
+        o += nlen + 1 + tlen + 1;
+        const uint32_t asz = rd32(f + o, false); o += 4;
+        if (asz > size - o) return fail(5, "exr: attribute larger than the file");
+        const uint8_t* v = f + o;
+        const std::string n(name), t(type);
+        if (n == "channels" && t == "chlist") {                    // EXR.cpp:331-398
+            size_t q = 0; uint32_t code = 0, count = 0; bool same_half = true;
+            while (q + 1 < asz) {
+                size_t cl = 0; while (q + cl < asz && v[q + cl]) cl++;
+                if (q + cl + 17 > asz) return fail(6, "exr: bad channel list");
+                if (count > 3 || cl != 1) code = 0xFFFFFFFFu; else code |= uint32_t(v[q]) << (8 * count);
+                q += cl + 1;
+                if (rd32(v + q, false) != 1) same_half = false;                                              // pixel type HALF
+                if (rd32(v + q + 4, false) != 0 || rd32(v + q + 8, false) != 1 || rd32(v + q + 12, false) != 1)
+                    return fail(6, "exr: channel list features (pLinear / sampling) are not supported");
+                q += 16; count++;
+            }
+            if (q + 1 != asz || v[q]) return fail(6, "exr: bad channel list");
+            rgb_half = code == 0x00524742 && same_half;           // "B","G","R"
+            have_channels = true;
+        } else if (n == "compression" && t == "compression") { if (asz != 1 || v[0]) return fail(7, "exr: compressed files are not supported"); }
+        else if (n == "dataWindow" && t == "box2i") {
+            if (asz != 16 || rd32(v, false) || rd32(v + 4, false)) return fail(8, "exr: dataWindow does not start at the origin");
+            width = rd32(v + 8, false); height = rd32(v + 12, false);
+            if (!width || !height) return fail(8, "exr: dataWindow");                                       // EXR.cpp:421-423 (sic: 1-pixel-wide pictures are refused)
+        } else if (n == "displayWindow" && t == "box2i") {
+            if (asz != 16 || rd32(v, false) || rd32(v + 4, false)) return fail(8, "exr: displayWindow does not start at the origin");
+            dw = rd32(v + 8, false); dh = rd32(v + 12, false); have_display = true;
+        } else if ((n == "framesPerSecond" || n == "captureRate") && t == "rational") {
+            if (asz != 8) return fail(9, "exr: %s", n.c_str());
+            const uint32_t num = rd32(v, false), den = rd32(v + 4, false);
+            if (n == "framesPerSecond") { if (!num || !den) return fail(9, "exr: framesPerSecond"); fps = double(num) / den; }
+            else if (num && den && fps == 0) fps = double(num) / den;
+        } else if (n == "imageRotation" && t == "float") { if (asz != 4 || rd32(v, false)) return fail(9, "exr: imageRotation"); }
+        else if (n == "lineOrder" && t == "lineOrder") { if (asz != 1 || v[0]) return fail(9, "exr: only increasing-Y line order is supported"); }
+        else if (n == "screenWindowCenter" && t == "v2f") { if (asz != 8 || rd32(v, false) || rd32(v + 4, false)) return fail(9, "exr: screenWindowCenter"); }
+        else if (n == "screenWindowWidth" && t == "float") { if (asz != 4 || rd32(v, false) != 0x3F800000u) return fail(9, "exr: screenWindowWidth"); }
+        else {
+            bool known = false;
+            for (const char* k : kSkipped) known |= n == k;
+            for (const char* k : kSkippedPrefix) known |= n.compare(0, strlen(k), k) == 0;
+            if (!known) return fail(10, "exr: header field %s is not supported", n.c_str());               // EXR.cpp:521-525,547-548
+        }
+        o += asz;
+    }
+    if (have_display && (width != dw || height != dh)) return fail(8, "exr: displayWindow differs from dataWindow");
+    if (!have_channels || !rgb_half) return fail(14, "exr: flavor (only B,G,R channels of type HALF) is not supported");
+    width++; height++;
+    out->width = width; out->height = height; out->pixfmt = RCGPU_PIX_EXR_RGB16; out->bits_per_sample = 16;
+    out->line_bytes = payload_line_bytes(RCGPU_PIX_EXR_RGB16, width, false);
+    out->data_offset = o + 8ull * height;                                                                   // line offset table, EXR.cpp:597-598
+    out->data_size = uint64_t(out->line_bytes) * height;
+    if (out->data_offset + out->data_size > size) return fail(15, "exr: truncated image data");
+    uint32_t sx = 4;                                                                                       // EXR.cpp:579-590: the 16-bit rule always
+    if (width >= 1440) sx <<= 1;
+    if (width >= 2880) sx <<= 1;
+    sx = sx * 3 / 2;
+    sx = std::min(sx, width / 2); sx = std::min(sx, height / 2);
+    if (!sx) sx = 1;
+    out->slices = sx * sx;
+    out->framerate = fps;
+    snprintf(out->flavor, sizeof out->flavor, "EXR/Raw/RGB/16bit/F/BE");                                   // EXR_Flavor_String, EXR.cpp:660-666
+    return 0;
+}
+
 extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* out)
 {
     clear_error();

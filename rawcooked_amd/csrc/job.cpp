@@ -121,6 +121,7 @@ int probe_image(const std::string& path, bool& tiff, rcgpu_image_info& info)
     const std::string ext = lower_ext(path);
     const bool looks_tiff = f.size >= 4 && ((f.data[0] == 'I' && f.data[1] == 'I') || (f.data[0] == 'M' && f.data[1] == 'M'));
     tiff = looks_tiff || ext == "tif" || ext == "tiff";
+    if (f.size >= 4 && f.data[0] == 0x76 && f.data[1] == 0x2F && f.data[2] == 0x31 && f.data[3] == 0x01) { tiff = false; return rcgpu_exr_probe(f.data, f.size, &info); }
     return tiff ? rcgpu_tiff_probe(f.data, f.size, &info) : rcgpu_dpx_probe(f.data, f.size, &info);
 }
 
@@ -311,7 +312,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                     maps[i].reset(new mapped_file);
                     if (!maps[i]->open(v.files[first + i])) { err = fail(30, "cannot open %s: %s", v.files[first + i].c_str(), strerror(errno)); break; }
                     rcgpu_image_info fi{};
-                    const int r = v.tiff ? rcgpu_tiff_probe(maps[i]->data, maps[i]->size, &fi) : rcgpu_dpx_probe(maps[i]->data, maps[i]->size, &fi);
+                    const int r = v.info.pixfmt == RCGPU_PIX_EXR_RGB16 ? rcgpu_exr_probe(maps[i]->data, maps[i]->size, &fi)
+                                : v.tiff ? rcgpu_tiff_probe(maps[i]->data, maps[i]->size, &fi) : rcgpu_dpx_probe(maps[i]->data, maps[i]->size, &fi);
                     if (r) { err = r; break; }
                     if (fi.width != v.info.width || fi.height != v.info.height || fi.pixfmt != v.info.pixfmt || fi.line_bytes != v.info.line_bytes || fi.flags != v.info.flags)
                         { err = fail(31, "%s differs in geometry/flavor from the first frame of the sequence", v.files[first + i].c_str()); break; }
@@ -403,7 +405,7 @@ extern "C" int rcgpu_main_ffmpeg_argv(int argc, const char* const* argv)
             if (k == "r") { if (cur.framerate.empty()) cur.framerate = v; continue; }
             if (k == "start_number") { cur.start = v; continue; }
             if (k == "safe" || k == "consider_float16_as_uint16") continue;
-            if (k == "c:v" && (v == "dpx" || v == "tiff" || v == "exr")) { cur.is_video_hint = true; if (v == "exr") { fprintf(stderr, "Error: EXR input is not supported by rcgpu yet\n"); return 1; } continue; }
+            if (k == "c:v" && (v == "dpx" || v == "tiff" || v == "exr")) { cur.is_video_hint = true; continue; }
             out_opts[k] = v;
             continue;
         }

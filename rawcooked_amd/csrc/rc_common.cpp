@@ -38,6 +38,7 @@ static const pix_desc k_pix[RCGPU_PIX_COUNT] = {
     /* Y10_FILLEDA_BE   */ { 10, 1, 0, true,  false, kFieldsLow,    2, 1 },
     /* Y10_FILLEDB_BE   */ { 10, 1, 0, true,  false, kFieldsLow,    0, 1 },
     /* Y12_PACKED_BE    */ { 12, 1, 0, true,  false, kFieldsPacked, 0, 1 },
+    /* EXR_RGB16        */ { 16, 3, 0, false, false, kFieldsExr,    0, 1 },
 };
 const pix_desc& pix(uint32_t pixfmt) { return k_pix[pixfmt < RCGPU_PIX_COUNT ? pixfmt : 0]; }
 
@@ -45,6 +46,7 @@ uint32_t payload_line_bytes(uint32_t pixfmt, uint32_t width, bool dpx_padding)
 {
     const pix_desc& d = pix(pixfmt);
     const uint64_t nfields = uint64_t(width) * d.planes;
+    if (d.fields == kFieldsExr) return uint32_t(8 + 6 * uint64_t(width));           // EXR.cpp:601-606
     if (d.fields == kFieldsPacked) return uint32_t((nfields * 12 + 31) / 32 * 4);
     if (d.fields != kFieldsBytes) return uint32_t((nfields + 2) / 3 * 4);
     const uint64_t n = uint64_t(width) * d.bytes_pp;

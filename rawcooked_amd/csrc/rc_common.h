@@ -37,7 +37,7 @@ struct pix_desc {
     uint8_t fill;        // kFieldsLow: 2 = FilledA, 0 = FilledB
     uint8_t px_per_block;// pixels per indivisible block when slices may NOT cut a block (DPX.cpp:184-207 without BlockSpan), else 1
 };
-enum { kFieldsBytes = 0, kFieldsPacked = 1, kFieldsTop = 2, kFieldsLow = 3 };
+enum { kFieldsBytes = 0, kFieldsPacked = 1, kFieldsTop = 2, kFieldsLow = 3, kFieldsExr = 4 };   // kFieldsExr: [y][size][B..][G..][R..] per line, u16 LE
 const pix_desc& pix(uint32_t pixfmt);
 // bytes between payload lines: DPX pads every line to 32 bit (RawFrame.cpp:109, DPX.cpp:463-483), TIFF does not
 uint32_t payload_line_bytes(uint32_t pixfmt, uint32_t width, bool dpx_padding);

@@ -17,7 +17,7 @@ import numpy as np
 PIX_RGB8, PIX_RGB10_FILLEDA_BE, PIX_RGB10_FILLEDA_LE, PIX_RGB12_FILLEDA_BE, PIX_RGB12_FILLEDA_LE, \
     PIX_RGB16_BE, PIX_RGB16_LE, PIX_RGBA8, PIX_RGBA16_BE, PIX_RGBA16_LE, PIX_Y8, PIX_Y16_BE, PIX_Y16_LE, \
     PIX_RGB12_PACKED_BE, PIX_RGBA10_FILLEDA_BE, PIX_RGBA10_FILLEDA_LE, PIX_RGBA12_PACKED_BE, PIX_RGBA12_FILLEDA_BE, \
-    PIX_RGBA12_FILLEDA_LE, PIX_Y10_FILLEDA_BE, PIX_Y10_FILLEDB_BE, PIX_Y12_PACKED_BE = range(22)
+    PIX_RGBA12_FILLEDA_LE, PIX_Y10_FILLEDA_BE, PIX_Y10_FILLEDB_BE, PIX_Y12_PACKED_BE, PIX_EXR_RGB16 = range(23)
 FLAG_VFLIP, FLAG_ALTERN = 1, 2   # RCGPU_FLAG_*
 
 PIX_INFO = {  # pixfmt: (bits, components, bytes per pixel, big endian)
@@ -30,6 +30,7 @@ PIX_INFO = {  # pixfmt: (bits, components, bytes per pixel, big endian)
     PIX_RGB12_PACKED_BE: (12, 3, 0, True), PIX_RGBA10_FILLEDA_BE: (10, 4, 0, True), PIX_RGBA10_FILLEDA_LE: (10, 4, 0, False),
     PIX_RGBA12_PACKED_BE: (12, 4, 0, True), PIX_RGBA12_FILLEDA_BE: (12, 4, 8, True), PIX_RGBA12_FILLEDA_LE: (12, 4, 8, False),
     PIX_Y10_FILLEDA_BE: (10, 1, 0, True), PIX_Y10_FILLEDB_BE: (10, 1, 0, True), PIX_Y12_PACKED_BE: (12, 1, 0, True),
+    PIX_EXR_RGB16: (16, 3, 0, False),     # OpenEXR scan lines: planar inside each line
 }
 DPX_PACKING = {  # pixfmt: DPX "packing" field (0 packed, 1 filled method A, 2 filled method B)
     PIX_RGB12_PACKED_BE: 0, PIX_RGBA12_PACKED_BE: 0, PIX_Y12_PACKED_BE: 0, PIX_Y10_FILLEDB_BE: 2,
@@ -85,6 +86,13 @@ def pack_payload(comp: np.ndarray, pixfmt: int, dpx_line_padding: bool = True, f
     assert nc == ncomp
     if flags & FLAG_VFLIP:
         comp = comp[::-1]
+    if pixfmt == PIX_EXR_RGB16:      # [y:u32][bytes:u32][B x w][G x w][R x w], little endian
+        hdr = np.zeros((h, 2), dtype="<u4")
+        hdr[:, 0] = np.arange(h)
+        hdr[:, 1] = 6 * w
+        planes = np.concatenate([comp[:, :, 2], comp[:, :, 1], comp[:, :, 0]], axis=1).astype("<u2")
+        line = np.concatenate([hdr.view(np.uint8).reshape(h, 8), planes.view(np.uint8).reshape(h, 6 * w)], axis=1)
+        return line.tobytes(), 8 + 6 * w
     if pixfmt in (PIX_RGB12_PACKED_BE, PIX_RGBA12_PACKED_BE, PIX_Y12_PACKED_BE):
         line = _words_packed12(comp.reshape(h, w * nc)).astype(">u4").view(np.uint8).reshape(h, -1)
     elif pixfmt in (PIX_RGBA10_FILLEDA_BE, PIX_RGBA10_FILLEDA_LE):
@@ -164,6 +172,27 @@ def _with_endian(pixfmt: int, be: bool) -> int:
         if pixfmt in (b, l):
             return b if be else l
     return pixfmt
+
+
+def exr_file(comp: np.ndarray, fps: tuple[int, int] | None = (24, 1), trailer: bytes = b"") -> bytes:
+    """An uncompressed single-part scan-line OpenEXR 2 file, channels B,G,R of type HALF (whose 16 bits are taken as they are)."""
+    h, w, _ = comp.shape
+
+    def attr(name, typ, value):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(value)) + value
+    ch = b"".join(c + b"\0" + struct.pack("<IIII", 1, 0, 1, 1) for c in (b"B", b"G", b"R")) + b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr = struct.pack(">I", 0x762F3101) + struct.pack("<I", 2)
+    hdr += attr("channels", "chlist", ch) + attr("compression", "compression", b"\0") + attr("dataWindow", "box2i", box)
+    hdr += attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+    hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+    if fps:
+        hdr += attr("framesPerSecond", "rational", struct.pack("<II", fps[0], fps[1]))
+    hdr += b"\0"
+    payload, lb = pack_payload(comp, PIX_EXR_RGB16, False)
+    first = len(hdr) + 8 * h
+    table = b"".join(struct.pack("<Q", first + y * lb) for y in range(h))
+    return hdr + table + payload + trailer
 
 
 def tiff_file(comp: np.ndarray, pixfmt: int, trailer: bytes = b"") -> bytes:

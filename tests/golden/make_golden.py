@@ -51,6 +51,7 @@ FFV1 = [  # name, w, h, pixfmt, frames, kind, tiff[, layout flags]
     ("dpx_y10b_altern_52x38", 52, 38, synth.PIX_Y10_FILLEDB_BE, 1, "film", False, synth.FLAG_ALTERN),
     ("dpx_y12packed_56x38", 56, 38, synth.PIX_Y12_PACKED_BE, 1, "film", False),
     ("dpx_y12packed_vflip_96x40", 96, 40, synth.PIX_Y12_PACKED_BE, 1, "noise", False, synth.FLAG_VFLIP),
+    ("exr_rgb16_72x40", 72, 40, synth.PIX_EXR_RGB16, 2, "film", "exr"),      # HALF channels taken as uint16 (Output.cpp:120-122)
 ]
 FLAC = [  # name, ch, bits, rate, samples, kind
     ("wav_2ch16_48k", 2, 16, 48000, 10000, "music"),
@@ -74,15 +75,15 @@ def main():
         files = []
         for i in range(nframes):
             comp = synth.components(w, h, nc, bits, kind, seed=31 * i + 5)
-            data = synth.tiff_file(comp, pixfmt, trailer=b"xyz") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i, flags=flags)
-            fn = work + "/seq/f_%06d.%s" % (i, "tif" if tiff else "dpx")
+            data = synth.exr_file(comp, trailer=b"xyz") if tiff == "exr" else synth.tiff_file(comp, pixfmt, trailer=b"xyz") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i, flags=flags)
+            fn = work + "/seq/f_%06d.%s" % (i, "exr" if tiff == "exr" else "tif" if tiff else "dpx")
             open(fn, "wb").write(data)
             files.append(fn)
-        ri = run([REF, "--info", "--no-encode", "--no-check-padding", "-y", "seq"], work)      # prints the flavor string of every track
-        r = run([REF, "--hash", "--no-check-padding", "-d", "-y", "seq"], work)
+        ri = run([REF, "--info", "--no-encode", "--no-check-padding", "--check", "-y", "seq"], work)      # prints the flavor string of every track
+        r = run([REF, "--hash", "--no-check-padding", "--check", "-d", "-y", "seq"], work)      # --check: the reference refuses EXR without it (Main.cpp:121-127)
         assert r.returncode == 0, r.stderr
         first = open(files[0], "rb").read()
-        info = api.tiff_probe(first) if tiff else api.dpx_probe(first)
+        info = api.exr_probe(first) if tiff == "exr" else api.tiff_probe(first) if tiff else api.dpx_probe(first)
         slices = int(r.stdout.split("-slices ")[1].split()[0])
         assert slices == info.slices and info.flags == flags and ("-vf vflip" in r.stdout) == bool(flags & synth.FLAG_VFLIP)
         assert (" " + info.flavor.decode() + "\n") in ri.stdout + ri.stderr, (info.flavor, ri.stdout, ri.stderr)

@@ -17,13 +17,13 @@ SHIM = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
 OK_LINE = "Reversibility was checked, no issue detected."      # test2.sh:37,69
 
 
-def make_package(work, w, h, pixfmt, nframes, kind, tiff=False, audio=None, start=0, flags=0):
+def make_package(work, w, h, pixfmt, nframes, kind, tiff=False, audio=None, start=0, flags=0, exr=False):
     os.makedirs(os.path.join(work, "pkg", "img"))
     bits, nc, _, _ = synth.PIX_INFO[pixfmt]
     for i in range(nframes):
         comp = synth.components(w, h, nc, bits, kind, seed=7 * i + 1)
-        data = synth.tiff_file(comp, pixfmt, trailer=b"tail123") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i, flags=flags)
-        with open(os.path.join(work, "pkg", "img", "f_%06d.%s" % (start + i, "tif" if tiff else "dpx")), "wb") as f:
+        data = synth.exr_file(comp) if exr else synth.tiff_file(comp, pixfmt, trailer=b"tail123") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i, flags=flags)
+        with open(os.path.join(work, "pkg", "img", "f_%06d.%s" % (start + i, "exr" if exr else "tif" if tiff else "dpx")), "wb") as f:
             f.write(data)
     if audio:
         ch, abits, rate, n = audio
@@ -67,15 +67,16 @@ CASES = [
     dict(w=50, h=38, pixfmt=synth.PIX_Y10_FILLEDB_BE, nframes=2, kind="film", flags=synth.FLAG_ALTERN),     # words run across line ends
     dict(w=56, h=38, pixfmt=synth.PIX_Y12_PACKED_BE, nframes=2, kind="film"),
     dict(w=96, h=40, pixfmt=synth.PIX_Y12_PACKED_BE, nframes=2, kind="noise", flags=synth.FLAG_VFLIP),
+    dict(w=72, h=40, pixfmt=synth.PIX_EXR_RGB16, nframes=3, kind="film", exr=True),                         # "-c:v exr -consider_float16_as_uint16 1"
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d-%d%s%s%s" % (c["w"], c["h"], c["pixfmt"], "-tiff" if c.get("tiff") else "", "-wav" if c.get("audio") else "", "-f%d" % c["flags"] if c.get("flags") else ""))
 def test_reference_accepts_gpu_mkv(built, refbin, tmp_path, case):
     work = str(tmp_path)
-    make_package(work, case["w"], case["h"], case["pixfmt"], case["nframes"], case["kind"], case.get("tiff", False), case.get("audio"), flags=case.get("flags", 0))
+    make_package(work, case["w"], case["h"], case["pixfmt"], case["nframes"], case["kind"], case.get("tiff", False), case.get("audio"), flags=case.get("flags", 0), exr=case.get("exr", False))
     # 1. the reference analyses the package, writes the reversibility data and prints the ffmpeg command (-d)
-    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"] + (["--check"] if case.get("exr") else []), work)   # EXR: Main.cpp:121-127
     assert r.returncode == 0, r.stdout + r.stderr
     argv = shlex.split(r.stdout.strip())
     assert argv[0] == "ffmpeg"

@@ -140,7 +140,7 @@ FLAVORS = [  # pixfmt, layout flags -- the bit-packed DPX flavors (DPX.cpp:184-2
     (synth.PIX_RGB12_PACKED_BE, 0), (synth.PIX_RGB12_PACKED_BE, synth.FLAG_VFLIP), (synth.PIX_RGBA10_FILLEDA_BE, 0), (synth.PIX_RGBA10_FILLEDA_LE, 0),
     (synth.PIX_RGBA12_PACKED_BE, 0), (synth.PIX_RGBA12_FILLEDA_BE, 0), (synth.PIX_RGBA12_FILLEDA_LE, 0), (synth.PIX_Y10_FILLEDA_BE, 0),
     (synth.PIX_Y10_FILLEDA_BE, synth.FLAG_ALTERN), (synth.PIX_Y10_FILLEDB_BE, 0), (synth.PIX_Y10_FILLEDB_BE, synth.FLAG_ALTERN),
-    (synth.PIX_Y12_PACKED_BE, 0), (synth.PIX_Y12_PACKED_BE, synth.FLAG_VFLIP),
+    (synth.PIX_Y12_PACKED_BE, 0), (synth.PIX_Y12_PACKED_BE, synth.FLAG_VFLIP), (synth.PIX_EXR_RGB16, 0),
 ]
 
 
@@ -153,7 +153,7 @@ def test_bit_packed_flavors(built, pixfmt, flags, w, h, slices):
     nh, nv = api.slices_to_grid(slices)
     payloads = []
     for i, kind in enumerate(("film", "noise")):
-        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, kind, seed=11 * pixfmt + i), pixfmt, True, flags)
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, kind, seed=11 * pixfmt + i), pixfmt, pixfmt != synth.PIX_EXR_RGB16, flags)
         payloads.append(pl)
     p = ob.Params(w, h, pixfmt, nh, nv, 1, 1, flags)
     enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=2, flags=flags)

@@ -91,6 +91,20 @@ def test_dpx_probe_matches_what_the_reference_printed(built, v):
     assert i.data_offset + i.data_size == len(d)
 
 
+def test_exr_probe(built):
+    v = [v for v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["ffv1"] if v["name"].startswith("exr")][0]
+    d = synth.exr_file(synth.components(v["width"], v["height"], 3, 16, "film", seed=1), trailer=b"tail")
+    i = api.exr_probe(d)
+    assert (i.width, i.height, i.pixfmt, i.line_bytes, i.slices, i.flavor.decode(), i.framerate) == \
+           (v["width"], v["height"], synth.PIX_EXR_RGB16, v["line_bytes"], v["slices"], v["flavor"], 24.0)      # flavor / slices as the reference printed them
+    assert d[i.data_offset + i.data_size:] == b"tail"
+    # what exr::ParseBuffer refuses (EXR.cpp:199-566) is refused here too, never a crash
+    for bad in (d[:100], d[:4] + b"\x02\x02\x00\x00" + d[8:], d.replace(b"compression\0compression\0\x01\0\0\0\0", b"compression\0compression\0\x01\0\0\0\x03"),
+                d.replace(b"lineOrder\0lineOrder\0\x01\0\0\0\0", b"lineOrder\0lineOrder\0\x01\0\0\0\x01"), d.replace(b"pixelAspectRatio", b"pixelAspectRatiX"), d[:-30000]):
+        with pytest.raises(RuntimeError):
+            api.exr_probe(bad)
+
+
 def test_probes(built):
     comp = synth.components(4096 // 16, 2160 // 16, 3, 16, "film", seed=3)
     d = synth.dpx_file(comp, synth.PIX_RGB16_BE, fps=25.0)
