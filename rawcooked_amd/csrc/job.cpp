@@ -103,6 +103,8 @@ struct video_plan {
     uint32_t num_h = 1, num_v = 1;
     bool vflip = false;
     int track = 0;
+    uint32_t F = 1;               // frames per batch (in flight per device)
+    size_t enc_first = 0;         // its encoders: encoders[enc_first + device]
 };
 struct audio_plan {
     std::string file;
@@ -208,7 +210,6 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             videos.push_back(std::move(v)); order.push_back({ true, videos.size() - 1 });
         }
     }
-    if (videos.size() > 1) return bail(fail(7, "more than one video stream per file is not supported by rcgpu yet"));
 
     // ---- audio first: A_FLAC CodecPrivate (STREAMINFO) must be final before the header is written
     for (audio_plan& a : audios) {
@@ -241,10 +242,11 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
 
     std::vector<std::unique_ptr<rcgpu_ffv1, void (*)(rcgpu_ffv1*)>> encoders;
     const uint32_t batch = uint32_t(std::max(1L, opt.num("rcgpu_batch", 0)));
-    uint32_t F = 1;
     for (auto& o : order) {
         if (o.first) {
             video_plan& v = videos[o.second];
+            uint32_t& F = v.F;
+            v.enc_first = encoders.size();
             // frames in flight per device: bounded by HBM (intermediates ~1.3 GB per 4K frame) and by the sequence length
             const uint64_t px = uint64_t(v.info.width) * v.info.height;
             F = batch ? batch : uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (uint64_t(96) << 30) / (px * 160 + 1))));
@@ -259,7 +261,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                 encoders.emplace_back(e, rcgpu_ffv1_destroy);
             }
             uint8_t rec[4096];
-            const size_t n = rcgpu_ffv1_config_record(encoders[0].get(), rec, sizeof rec);
+            const size_t n = rcgpu_ffv1_config_record(encoders[v.enc_first].get(), rec, sizeof rec);
             v.track = rcgpu_mkv_add_video(mux, rec, n, v.info.width, v.info.height, v.fps.num, v.fps.den);
             if (v.track < 0) return bail(8);
         } else {
@@ -295,15 +297,25 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     };
 
     if (!videos.empty()) {
-        video_plan& v = videos[0];
-        const size_t nframes = v.files.size(), nbatches = (nframes + F - 1) / F;
+        // work items = (video, batch), ordered by the timestamp of their first frame so that tracks interleave in the file;
+        // item g goes to device g % ndev, a turnstile hands finished items to the muxer in that order
+        struct item { size_t vi, first, n; uint64_t pts; };
+        std::vector<item> items;
+        for (size_t vi = 0; vi < videos.size(); vi++) {
+            const video_plan& v = videos[vi];
+            for (size_t first = 0; first < v.files.size(); first += v.F)
+                items.push_back({ vi, first, std::min<size_t>(v.F, v.files.size() - first), uint64_t(first) * v.fps.den * 1000000000ull / v.fps.num });
+        }
+        std::stable_sort(items.begin(), items.end(), [](const item& a, const item& b) { return a.pts < b.pts; });
         turnstile ts;
         auto worker = [&](int d) {
-            rcgpu_ffv1* enc = encoders[size_t(d)].get();
-            const size_t cap = rcgpu_ffv1_max_packet_bytes(enc);
             std::vector<std::vector<uint8_t>> packets;
-            for (size_t b = size_t(d); b < nbatches; b += size_t(ndev)) {
-                const size_t first = b * F, n = std::min<size_t>(F, nframes - first);
+            for (size_t g = size_t(d); g < items.size(); g += size_t(ndev)) {
+                const item& it = items[g];
+                video_plan& v = videos[it.vi];
+                rcgpu_ffv1* enc = encoders[v.enc_first + size_t(d)].get();
+                const size_t cap = rcgpu_ffv1_max_packet_bytes(enc);
+                const size_t first = it.first, n = it.n;
                 int err = 0;
                 std::vector<std::unique_ptr<mapped_file>> maps(n);
                 std::vector<const uint8_t*> ptrs(n); std::vector<uint8_t*> outs(n); std::vector<size_t> sizes(n);
@@ -323,7 +335,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                 }
                 if (!err) err = rcgpu_ffv1_encode_host(enc, ptrs.data(), uint32_t(n), outs.data(), sizes.data());
                 std::string msg = err ? rcgpu_last_error() : "";
-                ts.wait_turn(b);
+                ts.wait_turn(g);
                 if (!err && !ts.error) {
                     for (size_t i = 0; i < n && !err; i++) {
                         const uint64_t pts = uint64_t(first + i) * v.fps.den * 1000000000ull / v.fps.num;
@@ -333,7 +345,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                     if (err) msg = rcgpu_last_error();
                 }
                 if (err) { std::lock_guard<std::mutex> l(ts.m); if (!ts.error) fail(err, "%s", msg.c_str()); }
-                ts.done(b, err);
+                ts.done(g, err);
                 if (err || ts.error) break;
             }
         };

@@ -193,3 +193,37 @@ def test_ntsc_framerate_and_python_job_binding(built, refbin, tmp_path):
     data = open(os.path.join(work, "pkg.mkv"), "rb").read()
     i = data.index(bytes.fromhex("23E383"))                   # DefaultDuration
     assert int.from_bytes(data[i + 4:i + 4 + (data[i + 3] & 0x7F)], "big") == 41708333
+
+
+def test_package_with_two_video_tracks_and_two_audio_tracks(built, refbin, tmp_path):
+    """test2-style package: two image sequences of different flavors plus two WAV files -> four tracks in stream
+    order (Output.cpp:258-268 `-map`), every rebuilt file identical."""
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "pkg", "a_16bit"))
+    os.makedirs(os.path.join(work, "pkg", "b_12bit"))        # same slice count as the 16-bit track: the reference refuses mixed counts (one global -slices)
+    for i in range(3):
+        with open(os.path.join(work, "pkg", "a_16bit", "a_%04d.dpx" % i), "wb") as f:
+            f.write(synth.dpx_file(synth.components(64, 48, 3, 16, "film", seed=i), synth.PIX_RGB16_BE, frame_index=i))
+        with open(os.path.join(work, "pkg", "b_12bit", "b_%04d.dpx" % i), "wb") as f:
+            f.write(synth.dpx_file(synth.components(64, 48, 3, 12, "film", seed=10 + i), synth.PIX_RGB12_FILLEDA_LE, frame_index=i))
+    with open(os.path.join(work, "pkg", "c_stereo.wav"), "wb") as f:
+        f.write(synth.wav_file(synth.pcm_samples(6000, 2, 24, 48000), 24, 48000))
+    with open(os.path.join(work, "pkg", "d_mono.wav"), "wb") as f:
+        f.write(synth.wav_file(synth.pcm_samples(6000, 1, 16, 48000, seed=3), 16, 48000))
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0 and r.stdout.count(" -i ") == 4 and "-map 3" in r.stdout, r.stdout + r.stderr
+    argv = shlex.split(r.stdout.strip())
+    r = run([SHIM] + argv[1:], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = run([refbin, "--check", "pkg.mkv"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+    r = run([refbin, "-y", "pkg.mkv"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    n = 0
+    for dirpath, _, files in os.walk(os.path.join(work, "pkg")):
+        for fn in files:
+            src = os.path.join(dirpath, fn)
+            dst = os.path.join(work, "pkg.mkv.RAWcooked", os.path.relpath(src, work))
+            assert open(src, "rb").read() == open(dst, "rb").read(), fn
+            n += 1
+    assert n == 8
