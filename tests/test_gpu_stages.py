@@ -168,3 +168,44 @@ def test_bit_packed_flavors(built, pixfmt, flags, w, h, slices):
     for f in range(2):
         assert bytes(dout[f].cpu().numpy()) == payloads[f]
     enc.close(); dec.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_geometries_mixed_content(built, seed):
+    """Stress for k_resolve's chunk pipeline: pictures made of flat patches (runs of zero residuals in one context), smooth ramps
+    (many lanes per context -> rounds, forwarding between chunks) and noise, at random sizes / slice grids / segment counts, so that
+    slices end in partial chunks of every length."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    pixfmt = [synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGB8, synth.PIX_Y16_LE, synth.PIX_RGBA16_LE, synth.PIX_Y8][seed % 6]
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    w, h = int(rng.integers(24, 200)), int(rng.integers(10, 120))
+    slices = [1, 4, 6, 9, 12][int(rng.integers(0, 5))]
+    nh, nv = api.slices_to_grid(slices)
+    if nh >= w or nv >= h:
+        nh = nv = 1
+    segments = [0, 1, 3, 7][int(rng.integers(0, 4))]
+    maxv = (1 << bits) - 1
+    payloads = []
+    for f in range(3):
+        comp = np.zeros((h, w, nc), dtype=np.uint16)
+        for _ in range(12):                                   # random patches
+            y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+            y1, x1 = int(rng.integers(y0, h)) + 1, int(rng.integers(x0, w)) + 1
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                comp[y0:y1, x0:x1] = rng.integers(0, maxv + 1, size=nc)
+            elif kind == 1:
+                ramp = (np.arange(x1 - x0)[None, :, None] * int(rng.integers(1, 4)) + np.arange(y1 - y0)[:, None, None] + int(rng.integers(0, maxv // 2))) & maxv
+                comp[y0:y1, x0:x1] = ramp
+            else:
+                comp[y0:y1, x0:x1] = rng.integers(0, maxv + 1, size=(y1 - y0, x1 - x0, nc))
+        pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
+        payloads.append(pl)
+    for ctx in (1, 2):
+        p = ob.Params(w, h, pixfmt, nh, nv, 1, ctx)
+        enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=3, segments=segments)
+        packets = enc.encode_host(payloads)
+        for f in range(3):
+            assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"context model {ctx}, frame {f}, {w}x{h} {nh}x{nv} segments {segments}"
+        enc.close()
