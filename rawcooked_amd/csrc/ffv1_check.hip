@@ -88,7 +88,53 @@ __global__ __launch_bounds__(256) void k_dec_crc(const dec_const* __restrict__ C
 
 // ------------------------------------------------------------------------------------------------------------
 // Range decoder state of one lane (rangecoder, FFV1_RangeCoder.cpp:21-102)
-struct rd_lane { uint32_t current, mask; const uint8_t* cur; const uint8_t* end; };
+// The compressed bytes reach the decoder through a register window: `win` holds the next <= 8 bytes of the slice (left aligned),
+// `pend` a further load that was issued one sample earlier.  A renormalisation is then pure ALU work -- with 64 slices decoding in
+// lock-step some lane renormalises at almost every decision, and a global byte load there stalls the whole wavefront every time.
+struct rd_lane {
+    uint32_t current, mask;
+    uint32_t pos, n;                  // bytes consumed so far (Buffer_Cur - Buffer) and size of the slice's coded data
+    unsigned long long win, pend; uint32_t nwin, npend;
+    const uint8_t* next; const uint8_t* end;      // first byte not yet loaded, end of the coded data
+};
+
+__device__ __forceinline__ unsigned long long rd_load(const uint8_t* p, uint32_t avail, uint32_t& got)
+{
+    if (avail >= 8) {
+        const uint32_t lo = *reinterpret_cast<const uint32_t*>(p), hi = *reinterpret_cast<const uint32_t*>(p + 4);   // unaligned loads are fine in global memory
+        got = 8;
+        return (unsigned long long)__builtin_bswap32(lo) << 32 | __builtin_bswap32(hi);
+    }
+    unsigned long long v = 0;
+    for (uint32_t i = 0; i < avail; i++) v |= (unsigned long long)p[i] << (56 - 8 * i);     // last bytes of the slice: never read past them
+    got = avail;
+    return v;
+}
+// At a sample boundary (all lanes converged): move arrived bytes into the window, then put the next load in flight.
+__device__ __forceinline__ void rd_refill(rd_lane& r)
+{
+    if (r.npend && r.nwin < 8) {
+        const uint32_t k = min(r.npend, 8 - r.nwin);
+        r.win |= r.pend >> (8 * r.nwin);
+        r.pend = k < 8 ? r.pend << (8 * k) : 0ull;
+        r.npend -= k; r.nwin += k;
+    }
+    if (!r.npend && r.next < r.end) {
+        uint32_t got;
+        r.pend = rd_load(r.next, uint32_t(r.end - r.next), got);
+        r.npend = got; r.next += got;
+    }
+}
+__device__ __forceinline__ uint32_t rd_take(rd_lane& r)       // the byte at position r.pos (zero at and past the end of the data)
+{
+    uint32_t b = 0;
+    if (r.pos < r.n) {
+        if (!r.nwin) { rd_refill(r); rd_refill(r); }          // a sample used more than the window held: refill on the spot
+        b = uint32_t(r.win >> 56); r.win <<= 8; r.nwin--;
+    }
+    r.pos++;
+    return b;
+}
 
 // A lane's 32 context states live in LDS as eight dwords of a [8][64] array (dword k of lane l at (k*64 + l)*4): for a state index
 // that is uniform over the wavefront every lane touches its own dword -- no bank conflicts, where a [lane][32] layout gives 16-way.
@@ -98,10 +144,9 @@ __device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* base, int k, con
 {
     if (r.mask < 0x100) {
         r.current <<= 8;
-        if (r.cur > r.end) return 0;                        // underrun: zeros
-        if (r.cur < r.end) r.current |= *r.cur;
+        if (r.pos > r.n) return 0;                          // underrun: zeros
+        r.current |= rd_take(r);
         r.mask <<= 8;
-        r.cur++;
     }
     const uint32_t s = ST_AT(base, k);
     const uint32_t m2 = (r.mask * s) >> 8;
@@ -150,8 +195,9 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     if (len < tail) { atomicOr(err, 8u); return; }
     const uint8_t* buf = packets[f] + slice_start[chain];
     rd_lane r;
-    r.cur = buf; r.end = buf + (len - tail);
-    r.current = len - tail ? *r.cur : 0; r.mask = 0xFF; r.cur++;                   // AssignBuffer, FFV1_RangeCoder.cpp:22-33
+    r.n = len - tail; r.pos = 0; r.win = r.pend = 0; r.nwin = r.npend = 0; r.next = buf; r.end = buf + r.n;
+    rd_refill(r); rd_refill(r);
+    r.current = rd_take(r); r.mask = 0xFF;                                         // AssignBuffer, FFV1_RangeCoder.cpp:22-33
     uint8_t* my = slot + lane * 4;
     uint32_t* myw = reinterpret_cast<uint32_t*>(my);               // dword k of this lane's states: myw[k * 64]
     auto fresh = [&]() { for (int k = 0; k < 8; k++) myw[k * 64] = 0x80808080u; };
@@ -185,6 +231,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
             int32_t LT = y >= 2 ? pp[0] : 0;
             int32_t T = y ? prev[0] : 0;
             for (uint32_t x = 0; x < w; x++) {
+                rd_refill(r);
                 const int32_t RT = y ? (x + 1 < w ? prev[x + 1] : T) : 0;
                 const int32_t TT = y >= 2 ? pp[x] : 0;
                 int32_t ctx = q[0][(L - LT) & 0xFF] + q[1][(LT - T) & 0xFF] + q[2][(T - RT) & 0xFF];
@@ -203,8 +250,8 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
         }
     // end-of-slice bit, underrun and junk checks (FFV1_Slice.cpp:286-299,336-340)
     my[0] = 129; rd_bit(r, my, 0, trans);
-    const bool underrun = r.cur - (r.mask < 0x100 ? 0 : 1) > r.end;
-    const size_t used = r.cur > r.end ? size_t(r.end - buf) : size_t(r.cur - buf) - (r.mask < 0x100 ? 0 : 1);
+    const bool underrun = r.pos - (r.mask < 0x100 ? 0 : 1) > r.n;
+    const size_t used = r.pos > r.n ? size_t(r.n) : size_t(r.pos) - (r.mask < 0x100 ? 0 : 1);
     if (underrun) atomicOr(err, 64u);
     if (used < len - tail) atomicOr(err, 128u);
     if (C->ec && buf[len - 5]) atomicOr(err, 256u);                  // error_status
