@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_dec_crc(const dec_const* __restrict__ C
 struct rd_lane {
     uint32_t current, mask;
     uint32_t pos, n;                  // bytes consumed so far (Buffer_Cur - Buffer) and size of the slice's coded data
-    unsigned long long win, pend; uint32_t nwin, npend;
+    uint32_t win_hi, win_lo, nwin;    // window: the next nwin bytes, left aligned in win_hi:win_lo; zeros stand in once the data is used up
+    unsigned long long pend; uint32_t npend;
     const uint8_t* next; const uint8_t* end;      // first byte not yet loaded, end of the coded data
 };
 
@@ -107,7 +108,7 @@ __device__ __forceinline__ unsigned long long rd_load(const uint8_t* p, uint32_t
     }
     unsigned long long v = 0;
     for (uint32_t i = 0; i < avail; i++) v |= (unsigned long long)p[i] << (56 - 8 * i);     // last bytes of the slice: never read past them
-    got = avail;
+    got = 8;                                                                                 // ... and zeros after them (FFV1_RangeCoder.cpp:79-85)
     return v;
 }
 // At a sample boundary (all lanes converged): move arrived bytes into the window, then put the next load in flight.
@@ -115,45 +116,45 @@ __device__ __forceinline__ void rd_refill(rd_lane& r)
 {
     if (r.npend && r.nwin < 8) {
         const uint32_t k = min(r.npend, 8 - r.nwin);
-        r.win |= r.pend >> (8 * r.nwin);
+        const unsigned long long add = r.pend >> (8 * r.nwin);
+        r.win_hi |= uint32_t(add >> 32); r.win_lo |= uint32_t(add);
         r.pend = k < 8 ? r.pend << (8 * k) : 0ull;
         r.npend -= k; r.nwin += k;
     }
-    if (!r.npend && r.next < r.end) {
-        uint32_t got;
-        r.pend = rd_load(r.next, uint32_t(r.end - r.next), got);
-        r.npend = got; r.next += got;
+    if (!r.npend) {
+        uint32_t got = 8;
+        r.pend = r.next < r.end ? rd_load(r.next, uint32_t(r.end - r.next), got) : 0ull;       // past the end: zeros
+        r.npend = got; r.next += r.next < r.end ? min(got, uint32_t(r.end - r.next)) : 0u;
     }
-}
-__device__ __forceinline__ uint32_t rd_take(rd_lane& r)       // the byte at position r.pos (zero at and past the end of the data)
-{
-    uint32_t b = 0;
-    if (r.pos < r.n) {
-        if (!r.nwin) { rd_refill(r); rd_refill(r); }          // a sample used more than the window held: refill on the spot
-        b = uint32_t(r.win >> 56); r.win <<= 8; r.nwin--;
-    }
-    r.pos++;
-    return b;
 }
 
 // A lane's 32 context states live in LDS as eight dwords of a [8][64] array (dword k of lane l at (k*64 + l)*4): for a state index
 // that is uniform over the wavefront every lane touches its own dword -- no bank conflicts, where a [lane][32] layout gives 16-way.
 #define ST_AT(base, k) ((base)[(uint32_t(k) >> 2) * 256 + (uint32_t(k) & 3)])
 
+// rangecoder::b (FFV1_RangeCoder.cpp:71-102), without a branch in the common path: the renormalisation is a handful of selects.
 __device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* base, int k, const uint8_t* trans)
 {
-    if (r.mask < 0x100) {
-        r.current <<= 8;
-        if (r.pos > r.n) return 0;                          // underrun: zeros
-        r.current |= rd_take(r);
-        r.mask <<= 8;
+    const bool need = r.mask < 0x100;
+    if (__builtin_expect(__ballot(need && !r.nwin) != 0, 0)) {        // a sample used more than the window held: refill on the spot (rare)
+        if (need && !r.nwin) { rd_refill(r); rd_refill(r); }
     }
+    const uint32_t b = r.win_hi >> 24;
+    r.current = need ? (r.current << 8) | b : r.current;
+    r.mask = need ? r.mask << 8 : r.mask;
+    const uint32_t nhi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24);      // (hi:lo) << 8
+    r.win_hi = need ? nhi : r.win_hi;
+    r.win_lo = need ? r.win_lo << 8 : r.win_lo;
+    r.nwin -= need ? 1u : 0u;
+    r.pos += need ? 1u : 0u;
     const uint32_t s = ST_AT(base, k);
     const uint32_t m2 = (r.mask * s) >> 8;
-    r.mask -= m2;
-    if (r.current < r.mask) { ST_AT(base, k) = trans[s]; return 0; }
-    r.current -= r.mask; r.mask = m2; ST_AT(base, k) = trans[256 + s];
-    return 1;
+    const uint32_t nm = r.mask - m2;
+    const bool bit = r.current >= nm;
+    r.current -= bit ? nm : 0u;
+    r.mask = bit ? m2 : nm;
+    ST_AT(base, k) = trans[(bit ? 256u : 0u) + s];
+    return bit ? 1u : 0u;
 }
 __device__ uint32_t rd_u(rd_lane& r, uint8_t* st, const uint8_t* trans)
 {
@@ -195,9 +196,10 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     if (len < tail) { atomicOr(err, 8u); return; }
     const uint8_t* buf = packets[f] + slice_start[chain];
     rd_lane r;
-    r.n = len - tail; r.pos = 0; r.win = r.pend = 0; r.nwin = r.npend = 0; r.next = buf; r.end = buf + r.n;
+    r.n = len - tail; r.pos = 1; r.win_hi = r.win_lo = 0; r.pend = 0; r.nwin = r.npend = 0; r.next = buf; r.end = buf + r.n;
     rd_refill(r); rd_refill(r);
-    r.current = rd_take(r); r.mask = 0xFF;                                         // AssignBuffer, FFV1_RangeCoder.cpp:22-33
+    r.current = r.win_hi >> 24; r.win_hi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24); r.win_lo <<= 8; r.nwin--;   // AssignBuffer, FFV1_RangeCoder.cpp:22-33
+    r.mask = 0xFF;
     uint8_t* my = slot + lane * 4;
     uint32_t* myw = reinterpret_cast<uint32_t*>(my);               // dword k of this lane's states: myw[k * 64]
     auto fresh = [&]() { for (int k = 0; k < 8; k++) myw[k * 64] = 0x80808080u; };
