@@ -232,10 +232,13 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
             int32_t L = y ? prev[0] : 0, LL = 0;
             int32_t LT = y >= 2 ? pp[0] : 0;
             int32_t T = y ? prev[0] : 0;
+            // the two neighbours that come from memory are fetched one sample ahead
+            int32_t RTn = y ? (1 < w ? prev[1] : T) : 0, TTn = y >= 2 ? pp[0] : 0;
             for (uint32_t x = 0; x < w; x++) {
                 rd_refill(r);
-                const int32_t RT = y ? (x + 1 < w ? prev[x + 1] : T) : 0;
-                const int32_t TT = y >= 2 ? pp[x] : 0;
+                const int32_t RT = RTn, TT = TTn;
+                RTn = y ? (x + 2 < w ? prev[x + 2] : RT) : 0;
+                TTn = y >= 2 && x + 1 < w ? pp[x + 1] : 0;
                 int32_t ctx = q[0][(L - LT) & 0xFF] + q[1][(LT - T) & 0xFF] + q[2][(T - RT) & 0xFF];
                 if (is5) ctx += q[3][(LL - L) & 0xFF] + q[4][(TT - T) & 0xFF];
                 int32_t v = ov16 ? med3(int16_t(L), int16_t(L) + int16_t(T) - int16_t(LT), int16_t(T)) : med3(L, L + T - LT, T);
