@@ -51,7 +51,15 @@ FFV1 = [  # name, w, h, pixfmt, frames, kind, tiff[, layout flags]
     ("dpx_y10b_altern_52x38", 52, 38, synth.PIX_Y10_FILLEDB_BE, 1, "film", False, synth.FLAG_ALTERN),
     ("dpx_y12packed_56x38", 56, 38, synth.PIX_Y12_PACKED_BE, 1, "film", False),
     ("dpx_y12packed_vflip_96x40", 96, 40, synth.PIX_Y12_PACKED_BE, 1, "noise", False, synth.FLAG_VFLIP),
-    ("exr_rgb16_72x40", 72, 40, synth.PIX_EXR_RGB16, 2, "film", "exr"),      # HALF channels taken as uint16 (Output.cpp:120-122)
+    ("exr_rgb16_72x40", 72, 40, synth.PIX_EXR_RGB16, 2, "film", "exr"),
+    # the other TIFF flavors of TIFF.cpp:157-166
+    ("tiff_rgb8_40x30", 40, 30, synth.PIX_RGB8, 1, "film", True),
+    ("tiff_rgb16be_40x30", 40, 30, synth.PIX_RGB16_BE, 1, "film", True),
+    ("tiff_rgba8_40x30", 40, 30, synth.PIX_RGBA8, 1, "film", True),
+    ("tiff_rgba16le_40x30", 40, 30, synth.PIX_RGBA16_LE, 1, "film", True),
+    ("tiff_y8_40x30", 40, 30, synth.PIX_Y8, 1, "film", True),
+    ("tiff_y16le_40x30", 40, 30, synth.PIX_Y16_LE, 1, "film", True),
+    ("tiff_y16be_40x30", 40, 30, synth.PIX_Y16_BE, 1, "noise", True),      # HALF channels taken as uint16 (Output.cpp:120-122)
 ]
 FLAC = [  # name, ch, bits, rate, samples, kind
     ("wav_2ch16_48k", 2, 16, 48000, 10000, "music"),

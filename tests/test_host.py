@@ -79,13 +79,15 @@ def test_slices_golden_table(built):
 
 
 @pytest.mark.parametrize("v", [v for v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["ffv1"]
-                               if v["name"].startswith("dpx")], ids=lambda v: v["name"])
+                               if v["name"].startswith(("dpx", "tiff"))], ids=lambda v: v["name"])
 def test_dpx_probe_matches_what_the_reference_printed(built, v):
     """vectors.json holds, per flavor, the flavor string, the -slices value and the vflip decision the REAL reference printed
     (tests/golden/make_golden.py); the probe must re-derive them from the header alone."""
     bits, nc, _, _ = synth.PIX_INFO[v["pixfmt"]]
-    d = synth.dpx_file(synth.components(v["width"], v["height"], nc, bits, "film", seed=1), v["pixfmt"], flags=v["flags"])
-    i = api.dpx_probe(d)
+    comp = synth.components(v["width"], v["height"], nc, bits, "film", seed=1)
+    tiff = v["name"].startswith("tiff")
+    d = synth.tiff_file(comp, v["pixfmt"]) if tiff else synth.dpx_file(comp, v["pixfmt"], flags=v["flags"])
+    i = api.tiff_probe(d) if tiff else api.dpx_probe(d)
     assert (i.width, i.height, i.pixfmt, i.flags, i.line_bytes, i.slices, i.flavor.decode()) == \
            (v["width"], v["height"], v["pixfmt"], v["flags"], v["line_bytes"], v["slices"], v["flavor"])
     assert i.data_offset + i.data_size == len(d)
