@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "320")), help="frames in flight per GPU per step")
     ap.add_argument("--segments", type=int, default=0, help="hand-over windows per slice between k_resolve and k_rangecode (0 = library default)")
-    ap.add_argument("--check-batch", type=int, default=960, help="--mode check: frames decoded per step (>= --batch)")
+    ap.add_argument("--check-batch", type=int, default=1600, help="--mode check: frames decoded per step (>= --batch)")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)

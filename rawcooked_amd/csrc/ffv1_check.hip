@@ -12,8 +12,9 @@
 // gather + one write-back per sample through a per-lane LDS slot); previous lines are read back from the output planes.
 //   k_dec_split   thread / frame    walk the 24-bit slice sizes from the packet tail
 //   k_dec_crc     block  / slice    CRC-32 over the whole slice must be 0 (ec = 1)
-//   k_dec_slices  LANE   / slice    range decoder + median predictor + contexts -> planar int32
-//   k_pack        thread / pixel    inverse RCT + pack into the file layout (padding bits zero)
+//   k_dec_slices  LANE   / slice    range decoder + median predictor + contexts; whole-byte layouts: inverse RCT + pack of every
+//                                   finished line by the same lane (three-line rings, no planes); word-stream layouts: planar int32
+//   k_pack_words  thread / word     word-stream layouts only: inverse RCT + pack, one thread per 32-bit word of the payload
 //   k_compare     grid-stride       byte compare of two buffers -> first mismatch
 //   k_md5         LANE   / buffer   RFC 1321, one buffer per lane
 #include <hip/hip_runtime.h>
@@ -176,10 +177,59 @@ __device__ int32_t rd_s(rd_lane& r, uint8_t* st, const uint8_t* trans)
 }
 __device__ __forceinline__ int32_t med3(int32_t a, int32_t b, int32_t c) { return max(min(a, b), min(max(a, b), c)); }
 
+// inverse of k_unpack: JPEG2000RCT (Transform.cpp:29-37) + packers; whole lines incl. DPX padding are written
+__device__ __forceinline__ void st16(uint8_t* p, uint32_t v, bool be) { *reinterpret_cast<uint16_t*>(p) = uint16_t(be ? ((v >> 8) & 0xFF) | ((v & 0xFF) << 8) : v); }   // one store; global memory takes any alignment
+
+// One pixel: JPEG2000RCT (Transform.cpp:29-37) on the four plane values, then the packer of its flavor.  `line` is the start of
+// the payload line the pixel belongs to, `y` the picture line (EXR stores it in the line header).
+__device__ __forceinline__ void pack_px(const dec_const* C, int32_t v0, int32_t v1, int32_t v2, int32_t v3, uint8_t* line, uint32_t x, uint32_t y)
+{
+    const uint32_t W = C->W;
+    uint8_t* p = line + size_t(x) * C->bytes_pp;
+    const bool be = C->big_endian;
+    uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
+    if (!C->rgb) c0 = uint32_t(v0);
+    else {
+        int32_t g = v0, b = v1, r = v2;
+        const int32_t off = int32_t(1) << C->bps;
+        b -= off; r -= off; g -= (b + r) >> 2; b += g; r += g;
+        if (C->gb_swap) { const int32_t t = g; g = b; b = t; }
+        c0 = uint32_t(r); c1 = uint32_t(g); c2 = uint32_t(b);
+        if (C->planes == 4) c3 = uint32_t(v3);
+    }
+    switch (C->pixfmt) {
+    case RCGPU_PIX_EXR_RGB16: {                            // Transform.cpp:1062-1127: line header (y, byte count) then B, G, R runs
+        uint16_t* l16 = reinterpret_cast<uint16_t*>(line + 8);
+        l16[x] = uint16_t(c2); l16[W + x] = uint16_t(c1); l16[2 * W + x] = uint16_t(c0);
+        if (x == 0) { uint32_t* h32 = reinterpret_cast<uint32_t*>(line); h32[0] = y; h32[1] = 6 * W; }
+        return; }
+    case RCGPU_PIX_RGB8: p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2); break;
+    case RCGPU_PIX_RGBA8: p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2); p[3] = uint8_t(c3); break;
+    case RCGPU_PIX_RGB10_FILLEDA_BE: case RCGPU_PIX_RGB10_FILLEDA_LE: {
+        uint32_t w = ((c0 & 0x3FF) << 22) | ((c1 & 0x3FF) << 12) | ((c2 & 0x3FF) << 2);
+        if (be) w = __builtin_bswap32(w);
+        *reinterpret_cast<uint32_t*>(p) = w; break; }
+    case RCGPU_PIX_RGB12_FILLEDA_BE: case RCGPU_PIX_RGB12_FILLEDA_LE:
+        st16(p, (c0 << 4) & 0xFFFF, be); st16(p + 2, (c1 << 4) & 0xFFFF, be); st16(p + 4, (c2 << 4) & 0xFFFF, be); break;
+    case RCGPU_PIX_RGB16_BE: case RCGPU_PIX_RGB16_LE:
+        st16(p, c0 & 0xFFFF, be); st16(p + 2, c1 & 0xFFFF, be); st16(p + 4, c2 & 0xFFFF, be); break;
+    case RCGPU_PIX_RGBA16_BE: case RCGPU_PIX_RGBA16_LE:
+        st16(p, c0 & 0xFFFF, be); st16(p + 2, c1 & 0xFFFF, be); st16(p + 4, c2 & 0xFFFF, be); st16(p + 6, c3 & 0xFFFF, be); break;
+    case RCGPU_PIX_RGBA12_FILLEDA_BE: case RCGPU_PIX_RGBA12_FILLEDA_LE:
+        st16(p, (c0 << 4) & 0xFFFF, be); st16(p + 2, (c1 << 4) & 0xFFFF, be); st16(p + 4, (c2 << 4) & 0xFFFF, be); st16(p + 6, (c3 << 4) & 0xFFFF, be); break;
+    case RCGPU_PIX_Y8: p[0] = uint8_t(c0); break;
+    default: st16(p, c0 & 0xFFFF, be); break;
+    }
+    if (x == W - 1)                                   // DPX lines are padded to 32 bit (RawFrame.cpp:109): zero the padding
+        for (uint32_t i = W * C->bytes_pp; i < C->line_bytes; i++) line[i] = 0;
+}
+
+template <bool RING>
 __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__ C, const uint8_t* const* __restrict__ packets,
                                                    const unsigned long long* __restrict__ slice_start, const uint32_t* __restrict__ slice_len,
                                                    uint32_t nchains, uint8_t* __restrict__ states, uint32_t nkeys,
-                                                   int32_t* __restrict__ planes, uint32_t* __restrict__ err)
+                                                   int32_t* __restrict__ planes, uint8_t* const* __restrict__ payloads, uint32_t ring_w,
+                                                   uint32_t* __restrict__ err)
 {
     __shared__ uint8_t trans[512];
     __shared__ int16_t q[5][256];
@@ -215,17 +265,20 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     const uint32_t W = C->W, H = C->H, np = C->planes;
     const uint32_t x0 = uint32_t((unsigned long long)sx * W / C->num_h), y0 = uint32_t((unsigned long long)sy * H / C->num_v);
     const uint32_t w = uint32_t((unsigned long long)(sx + 1) * W / C->num_h) - x0, h = uint32_t((unsigned long long)(sy + 1) * H / C->num_v) - y0;
-    const size_t plane_sz = size_t(W) * H;
-    int32_t* fp = planes + size_t(f) * np * plane_sz + size_t(y0) * W + x0;
+    // RING: no picture-sized planes.  A lane keeps the last three lines of each plane of its slice ([plane][y % 3][ring_w]) and
+    // packs a picture line into the payload as soon as its last plane is decoded: 125 instead of 230 MB per frame in flight.
+    const size_t plane_sz = RING ? size_t(3) * ring_w : size_t(W) * H;
+    const uint32_t pitch = RING ? ring_w : W;
+    int32_t* fp = RING ? planes + size_t(chain) * np * plane_sz : planes + size_t(f) * np * plane_sz + size_t(y0) * W + x0;
     uint8_t* st_base = states + size_t(chain) * nkeys * 32;          // pre-set to 128 by the host (states_coded = 0)
     const bool is5 = C->is5, ov16 = C->overflow16, rgb = C->rgb;
     const int32_t bitmask = int32_t((1u << C->bits) - 1);
     const uint32_t nctx = C->nctx;
     for (uint32_t y = 0; y < h; y++)
         for (uint32_t p = 0; p < np; p++) {
-            int32_t* cur = fp + p * plane_sz + size_t(y) * W;
-            const int32_t* prev = cur - W;                            // valid when y >= 1
-            const int32_t* pp = cur - 2 * size_t(W);                  // valid when y >= 2
+            int32_t* cur = fp + p * plane_sz + size_t(RING ? y % 3 : y) * pitch;
+            const int32_t* prev = RING ? fp + p * plane_sz + size_t((y + 2) % 3) * pitch : cur - W;                  // valid when y >= 1
+            const int32_t* pp = RING ? fp + p * plane_sz + size_t((y + 1) % 3) * pitch : cur - 2 * size_t(W);        // valid when y >= 2
             const uint32_t set = rgb ? (p + 1) >> 1 : 0;
             // edge rules of SliceContent_LineThenPlane (FFV1_Slice.cpp:427-441): cur[-1] = prev[0], prev[w] = prev[w-1],
             // everything above the slice is 0, cur[-2] is 0
@@ -252,6 +305,22 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                 cur[x] = v;
                 LL = L; L = v; LT = T; T = RT;
             }
+            if (RING && p + 1 == np) {                                // the picture line is complete: inverse RCT + pack, Transform.cpp From()
+                const uint32_t gy = y0 + y;
+                uint8_t* line = payloads[f] + size_t(C->vflip ? H - 1 - gy : gy) * C->line_bytes;
+                const int32_t* r0 = fp + size_t(y % 3) * pitch;
+                for (uint32_t xb = 0; xb < w; xb += 8) {               // eight pixels' loads in flight together, then their stores
+                    int32_t a0[8], a1[8], a2[8], a3[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t x = min(xb + uint32_t(j), w - 1);
+                        a0[j] = r0[x]; a1[j] = np > 1 ? r0[plane_sz + x] : 0; a2[j] = np > 1 ? r0[2 * plane_sz + x] : 0; a3[j] = np > 3 ? r0[3 * plane_sz + x] : 0;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (xb + uint32_t(j) < w) pack_px(C, a0[j], a1[j], a2[j], a3[j], line, x0 + xb + uint32_t(j), gy);
+                }
+            }
         }
     // end-of-slice bit, underrun and junk checks (FFV1_Slice.cpp:286-299,336-340)
     my[0] = 129; rd_bit(r, my, 0, trans);
@@ -262,56 +331,6 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     if (C->ec && buf[len - 5]) atomicOr(err, 256u);                  // error_status
 }
 
-// inverse of k_unpack: JPEG2000RCT (Transform.cpp:29-37) + packers; whole lines incl. DPX padding are written
-__device__ __forceinline__ void st16(uint8_t* p, uint32_t v, bool be) { if (be) { p[0] = uint8_t(v >> 8); p[1] = uint8_t(v); } else { p[0] = uint8_t(v); p[1] = uint8_t(v >> 8); } }
-
-__global__ __launch_bounds__(256) void k_pack(const dec_const* __restrict__ C, const int32_t* __restrict__ planes, uint8_t* const* __restrict__ payloads)
-{
-    const uint32_t W = C->W, H = C->H;
-    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= W * H) return;
-    const uint32_t f = blockIdx.y, y = pix / W, x = pix - y * W;
-    const size_t plane_sz = size_t(W) * H;
-    const int32_t* src = planes + size_t(f) * C->planes * plane_sz + pix;
-    uint8_t* line = payloads[f] + size_t(C->vflip ? H - 1 - y : y) * C->line_bytes;
-    uint8_t* p = line + size_t(x) * C->bytes_pp;
-    const bool be = C->big_endian;
-    uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
-    if (!C->rgb) c0 = uint32_t(src[0]);
-    else {
-        int32_t g = src[0], b = src[plane_sz], r = src[2 * plane_sz];
-        const int32_t off = int32_t(1) << C->bps;
-        b -= off; r -= off; g -= (b + r) >> 2; b += g; r += g;
-        if (C->gb_swap) { const int32_t t = g; g = b; b = t; }
-        c0 = uint32_t(r); c1 = uint32_t(g); c2 = uint32_t(b);
-        if (C->planes == 4) c3 = uint32_t(src[3 * plane_sz]);
-    }
-    switch (C->pixfmt) {
-    case RCGPU_PIX_EXR_RGB16: {                            // Transform.cpp:1062-1127: line header (y, byte count) then B, G, R runs
-        uint16_t* l16 = reinterpret_cast<uint16_t*>(line + 8);
-        l16[x] = uint16_t(c2); l16[W + x] = uint16_t(c1); l16[2 * W + x] = uint16_t(c0);
-        if (x == 0) { uint32_t* h32 = reinterpret_cast<uint32_t*>(line); h32[0] = y; h32[1] = 6 * W; }
-        return; }
-    case RCGPU_PIX_RGB8: p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2); break;
-    case RCGPU_PIX_RGBA8: p[0] = uint8_t(c0); p[1] = uint8_t(c1); p[2] = uint8_t(c2); p[3] = uint8_t(c3); break;
-    case RCGPU_PIX_RGB10_FILLEDA_BE: case RCGPU_PIX_RGB10_FILLEDA_LE: {
-        uint32_t w = ((c0 & 0x3FF) << 22) | ((c1 & 0x3FF) << 12) | ((c2 & 0x3FF) << 2);
-        if (be) w = __builtin_bswap32(w);
-        *reinterpret_cast<uint32_t*>(p) = w; break; }
-    case RCGPU_PIX_RGB12_FILLEDA_BE: case RCGPU_PIX_RGB12_FILLEDA_LE:
-        st16(p, (c0 << 4) & 0xFFFF, be); st16(p + 2, (c1 << 4) & 0xFFFF, be); st16(p + 4, (c2 << 4) & 0xFFFF, be); break;
-    case RCGPU_PIX_RGB16_BE: case RCGPU_PIX_RGB16_LE:
-        st16(p, c0 & 0xFFFF, be); st16(p + 2, c1 & 0xFFFF, be); st16(p + 4, c2 & 0xFFFF, be); break;
-    case RCGPU_PIX_RGBA16_BE: case RCGPU_PIX_RGBA16_LE:
-        st16(p, c0 & 0xFFFF, be); st16(p + 2, c1 & 0xFFFF, be); st16(p + 4, c2 & 0xFFFF, be); st16(p + 6, c3 & 0xFFFF, be); break;
-    case RCGPU_PIX_RGBA12_FILLEDA_BE: case RCGPU_PIX_RGBA12_FILLEDA_LE:
-        st16(p, (c0 << 4) & 0xFFFF, be); st16(p + 2, (c1 << 4) & 0xFFFF, be); st16(p + 4, (c2 << 4) & 0xFFFF, be); st16(p + 6, (c3 << 4) & 0xFFFF, be); break;
-    case RCGPU_PIX_Y8: p[0] = uint8_t(c0); break;
-    default: st16(p, c0 & 0xFFFF, be); break;
-    }
-    if (x == W - 1)                                   // DPX lines are padded to 32 bit (RawFrame.cpp:109): zero the padding
-        for (uint32_t i = W * C->bytes_pp; i < C->line_bytes; i++) line[i] = 0;
-}
 
 // k_pack for the word-stream layouts (rc_common.h kFields*): one thread per 32-bit word of the payload assembles every field that
 // touches it, so no two threads write the same word.  Restates the From() loops of Transform.cpp:214-322 (RGB 12-bit packed),
@@ -427,6 +446,7 @@ struct rcgpu_ffv1_decoder {
     rcgpu_ffv1_config cfg{};
     dec_const hc{};
     uint32_t nkeys = 0;
+    bool ring = false; uint32_t ring_w = 0;       // line-ring mode: no picture-sized planes, lines are packed by the decoding lane
     size_t payload_bytes = 0;
     dec_const* d_const = nullptr;
     const uint8_t** d_pkt_ptrs = nullptr; uint8_t** d_out_ptrs = nullptr; unsigned long long* d_sizes = nullptr;
@@ -493,7 +513,11 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
 #define DM(p, b) if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&(p)), (b))
     DM(d->d_const, sizeof c); DM(d->d_pkt_ptrs, sizeof(void*) * F); DM(d->d_out_ptrs, sizeof(void*) * F); DM(d->d_sizes, 8 * F);
     DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32);
-    DM(d->d_planes, size_t(F) * c.planes * c.W * c.H * 4); DM(d->d_err, 16);
+    // whole-byte layouts (and EXR) are packed inline by the decoding lanes, which then only need three lines per plane and slice;
+    // the word-stream layouts share words between neighbouring slices and keep the planes + k_pack_words route
+    d->ring = c.fields == kFieldsBytes || c.fields == kFieldsExr;
+    d->ring_w = (c.W + c.num_h - 1) / c.num_h + 1;
+    DM(d->d_planes, d->ring ? nchains * c.planes * 3 * d->ring_w * 4 : size_t(F) * c.planes * c.W * c.H * 4); DM(d->d_err, 16);
 #undef DM
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_ptrs), sizeof(void*) * F * 2);
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_sizes), 8 * F);
@@ -527,11 +551,14 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     hipLaunchKernelGGL(k_dec_split, dim3((n + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_sizes, n, d->d_slice_start, d->d_slice_len, d->d_err);
     if (c.ec) hipLaunchKernelGGL(k_dec_crc, dim3(nchains), dim3(256), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, d->d_err);
     HIP_TRY(hipEventRecord(d->ev[1], st));
-    hipLaunchKernelGGL(k_dec_slices, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
-                       d->d_states, d->nkeys, d->d_planes, d->d_err);
+    if (d->ring)
+        hipLaunchKernelGGL(k_dec_slices<true>, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
+                           d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, d->ring_w, d->d_err);
+    else
+        hipLaunchKernelGGL(k_dec_slices<false>, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
+                           d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, 0u, d->d_err);
     HIP_TRY(hipEventRecord(d->ev[2], st));
-    if (c.fields == kFieldsBytes || c.fields == kFieldsExr)
-        hipLaunchKernelGGL(k_pack, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, d->d_const, d->d_planes, d->d_out_ptrs);
+    if (d->ring) { /* packed inline */ }
     else {
         const uint32_t nwords = c.altern ? (c.W * c.H + 2) / 3 : c.H * (c.line_bytes / 4);
         hipLaunchKernelGGL(k_pack_words, dim3((nwords + 255) / 256, n), dim3(256), 0, st, d->d_const, d->d_planes, d->d_out_ptrs);
