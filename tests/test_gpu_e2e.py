@@ -6,6 +6,7 @@ import os
 import shlex
 import shutil
 import subprocess
+import sys
 
 import pytest
 
@@ -31,7 +32,7 @@ def make_package(work, w, h, pixfmt, nframes, kind, tiff=False, audio=None, star
             f.write(synth.wav_file(synth.pcm_samples(n, ch, abits, rate), abits, rate))
 
 
-def run(cmd, cwd, timeout=90, attempts=3):
+def run(cmd, cwd, timeout=45, attempts=4):
     """Run one step of the round trip.  The reference binary occasionally dead-locks in its own analysis thread pool on many-core
     hosts (seen ~1 in 200 invocations of `rawcooked -d` on the GPU box, never with this repo's code involved), so a step that
     times out is repeated -- every step is idempotent (-y)."""
@@ -39,6 +40,10 @@ def run(cmd, cwd, timeout=90, attempts=3):
         try:
             return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, stdin=subprocess.DEVNULL)
         except subprocess.TimeoutExpired:
+            sys.stderr.write("e2e: step timed out after %d s (attempt %d): %s\n" % (timeout, attempt + 1, " ".join(cmd[:6])))
+            if os.environ.get("RCGPU_E2E_LOG"):
+                with open(os.environ["RCGPU_E2E_LOG"], "a") as f:
+                    f.write("timeout attempt %d: %s\n" % (attempt + 1, " ".join(cmd)))
             if attempt + 1 == attempts:
                 raise
 
