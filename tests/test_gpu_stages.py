@@ -209,3 +209,33 @@ def test_random_geometries_mixed_content(built, seed):
         for f in range(3):
             assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"context model {ctx}, frame {f}, {w}x{h} {nh}x{nv} segments {segments}"
         enc.close()
+
+
+@pytest.mark.parametrize("w,h,slices,pixfmt", [(2, 2, 1, synth.PIX_RGB16_BE), (3, 5, 1, synth.PIX_RGB10_FILLEDA_BE), (5, 4, 4, synth.PIX_RGB8), (64, 3, 1, synth.PIX_Y16_BE),
+                                               (3, 64, 1, synth.PIX_RGBA16_BE), (9, 9, 4, synth.PIX_RGB12_PACKED_BE), (7, 3, 1, synth.PIX_Y10_FILLEDA_BE),
+                                               (65, 2, 1, synth.PIX_EXR_RGB16), (6, 6, 4, synth.PIX_RGBA10_FILLEDA_BE)])
+def test_tiny_pictures_and_extreme_values(built, w, h, slices, pixfmt):
+    """Edge geometry: pictures smaller than one 64-symbol chunk, one-line slices, and the extreme sample values (all zero, all maximum,
+    alternating) that fold residuals at the boundaries of the coded range."""
+    import torch
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    nh, nv = api.slices_to_grid(slices)
+    maxv = (1 << bits) - 1
+    comps = [np.zeros((h, w, nc), dtype=np.uint16), np.full((h, w, nc), maxv, dtype=np.uint16),
+             ((np.add.outer(np.arange(h), np.arange(w)) & 1) * maxv).astype(np.uint16)[:, :, None].repeat(nc, axis=2),
+             synth.components(w, h, nc, bits, "noise", seed=w * 7 + h)]
+    payloads = []
+    for c in comps:
+        pl, line_bytes = synth.pack_payload(c, pixfmt, pixfmt != synth.PIX_EXR_RGB16)
+        payloads.append(pl)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=len(payloads))
+    packets = enc.encode_host(payloads)
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=len(payloads))
+    dpk = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in packets]
+    dout = [torch.full((len(x),), 0x55, dtype=torch.uint8, device="cuda") for x in payloads]
+    assert dec.decode_device([t.data_ptr() for t in dpk], [len(x) for x in packets], [t.data_ptr() for t in dout]) == 0
+    for f in range(len(payloads)):
+        assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
+        assert bytes(dout[f].cpu().numpy()) == payloads[f], f"frame {f}"
+    enc.close(); dec.close()
