@@ -59,7 +59,7 @@ def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int, 
     """The oracle (scalar C restatement, kind 'port') on the host cores: one frame per thread, all cores."""
     import oracle_binding as ob
     from rawcooked_amd import synth
-    cores = max(1, min(os.cpu_count() or 1, 32))
+    cores = max(1, min(os.cpu_count() or 1, 64))
     p = ob.Params(width, height, synth.PIX_RGB16_BE, 8, 8, 1, 1)
     ob.lib()
     out = [None] * cores
@@ -80,11 +80,57 @@ def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int, 
             "sample": f"{nfr} frames of the same {width}x{height} RGB16 workload, one frame per thread, oracle/ffv1_oracle.c (scalar C, not FFmpeg)"}
 
 
+def reference_check_baseline(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=16):
+    """cpu_baseline of the check path, kind "reference": the REAL reference binary (oracle/_ref/rawcooked, built from the reference's
+    own sources by oracle/Makefile.ref) decodes and verifies an MKV holding `nframes` of this run's packets, on the host's cores."""
+    import shutil
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref", "rawcooked")
+    if not os.path.exists(ref):
+        return None
+    work = tempfile.mkdtemp(prefix="rcgpu_bench_")
+    try:
+        os.makedirs(os.path.join(work, "seq"))
+        n = min(nframes, len(sizes))
+        for i in range(n):
+            with open(os.path.join(work, "seq", "f_%06d.dpx" % i), "wb") as f:
+                f.write(synth.dpx_file(None, pixfmt, frame_index=i, payload=bytes(frames[i].cpu().numpy()), size=(width, height)))
+        run = lambda cmd: subprocess.run(cmd, cwd=work, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=600)
+        r = run([ref, "--hash", "--no-check-padding", "-d", "-y", "seq"])     # analysis only: writes the reversibility data with the MD5 of every file
+        if r.returncode != 0:
+            return None
+        mux = api.MkvMuxer(os.path.join(work, "seq.mkv"))
+        t = mux.add_video(record, width, height, 24, 1)
+        mux.add_attachment("RAWcooked reversibility data", open(os.path.join(work, "seq.rawcooked_reversibility_data"), "rb").read())
+        mux.begin()
+        for i in range(n):
+            pkt = bytes(d_packets[i * stride:i * stride + sizes[i]].cpu().numpy())
+            mux.write_block(t, i * 1000000000 // 24, pkt)
+        mux.close()
+        t0 = time.perf_counter()
+        r = run([ref, "--check", "seq.mkv"])
+        dt = time.perf_counter() - t0
+        ok = r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout
+        return {"value": round(n / dt, 3), "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference",
+                "sample": f"rawcooked --check on an MKV of {n} of this run's {width}x{height} packets (files on local disk, page cache warm); "
+                          f"verdict: {'no issue detected' if ok else 'FAILED'}"}
+    except Exception as e:      # the baseline is a report, never a reason to fail the measurement
+        print("bench: reference check baseline skipped:", e, file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device):
     """Config 5: decode the MKV payloads back and verify them -- everything resident in HBM (single GPU)."""
     enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
     torch.cuda.synchronize()
     sizes = d_sizes.cpu().tolist()
+    cpu = None
+    if not args.no_cpu_baseline:
+        from rawcooked_amd import synth as _synth
+        cpu = reference_check_baseline(api, _synth, enc.config_record(), frames, d_packets, stride, sizes, width, height, pixfmt)
     # the decoder is latency-bound per slice chain, so its rate is chains in flight / chain latency: free the encoder's buffers
     # and decode D >= F frames per step (the F encoded packets, reused round-robin -- SURVEY.md 8d "ring reuse")
     enc.close()
@@ -127,7 +173,8 @@ def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, 
         "config": {"workload": f"{width}x{height} RGB16 FFV1 packets (slices={args.slices}) -> payload, byte compare + MD5 on device", "frames_per_step_per_gpu": F,
                    "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "verify_seconds_all_frames": round(t_verify, 3)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": None, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}}}))
+                     "traffic": None, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}},
+        **({"cpu_baseline": cpu} if cpu else {})}))
     dec.close()
     if not (same and ok_md5):
         sys.exit(2)

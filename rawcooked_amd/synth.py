@@ -118,16 +118,20 @@ def pack_payload(comp: np.ndarray, pixfmt: int, dpx_line_padding: bool = True, f
     return line.tobytes(), (0 if flags & FLAG_ALTERN else line_bytes)
 
 
-def dpx_file(comp: np.ndarray, pixfmt: int, fps: float = 24.0, frame_index: int = 0, big_endian_header: bool | None = None,
-             trailer: bytes = b"", flags: int = 0) -> bytes:
-    """A DPX v2.0 file (2048-byte header) whose image element uses `pixfmt`."""
+def dpx_file(comp: np.ndarray | None, pixfmt: int, fps: float = 24.0, frame_index: int = 0, big_endian_header: bool | None = None,
+             trailer: bytes = b"", flags: int = 0, payload: bytes | None = None, size: tuple[int, int] | None = None) -> bytes:
+    """A DPX v2.0 file (2048-byte header) whose image element uses `pixfmt`.  Either `comp` ([h, w, ncomp] samples) or a ready-made
+    `payload` in that layout with its picture `size` (w, h)."""
     bits, ncomp, bpp, be = PIX_INFO[pixfmt]
     if big_endian_header is None:
         big_endian_header = be if bits > 8 else True
     e = ">" if big_endian_header else "<"
-    h, w, _ = comp.shape
-    # 8-bit has no endianness in the payload; >8-bit payload endianness == header endianness in DPX
-    payload, _ = pack_payload(comp, pixfmt if bits == 8 else _with_endian(pixfmt, big_endian_header), True, flags)
+    if payload is None:
+        h, w, _ = comp.shape
+        # 8-bit has no endianness in the payload; >8-bit payload endianness == header endianness in DPX
+        payload, _ = pack_payload(comp, pixfmt if bits == 8 else _with_endian(pixfmt, big_endian_header), True, flags)
+    else:
+        w, h = size
     hdr = bytearray(b"\x00" * 2048)
     hdr[0:4] = b"SDPX" if big_endian_header else b"XPDS"
     struct.pack_into(e + "I", hdr, 4, 2048)
