@@ -270,7 +270,7 @@ def main():
     payload_bytes = line_bytes * height
     packet_avg = sum(sizes) / len(sizes)
 
-    verified = None
+    verified = verified_ref = None
     if rank == 0 and not args.no_verify:
         # parity spot check outside the timed region: packet 0 of the last step == the oracle's bytes and decodes to the source
         import oracle_binding as ob
@@ -280,6 +280,12 @@ def main():
         verified = ob.decode_payload(p, pk, line_bytes) == src
         if not verified:
             print("bench: GPU packet does not decode to the source payload", file=sys.stderr)
+            sys.exit(2)
+        # ... and the real reference (when its binary travelled with the repo) accepts an MKV of the first packets
+        rb = reference_check_baseline(api, synth, enc.config_record(), frames, d_packets, stride, sizes, width, height, pixfmt, nframes=4)
+        verified_ref = None if rb is None else rb["sample"].endswith("no issue detected")
+        if verified_ref is False:
+            print("bench: the reference rejected the GPU packets", file=sys.stderr)
             sys.exit(2)
 
     if rank == 0:
@@ -314,7 +320,7 @@ def main():
                                    f"coder=1 context=1 ({args.context_model} level maps) slicecrc=1, content={args.kind}",
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective",
                        "packet_bytes_avg": int(packet_avg), "compression_ratio": round(packet_avg / payload_bytes, 4),
-                       "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified,
+                       "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified, "verified_by_reference": verified_ref,
                        "hbm_in_use_gb": round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 1e9, 1)},
             "roofline": roof,
         }
