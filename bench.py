@@ -96,7 +96,13 @@ def reference_check_baseline(api, synth, record, frames, d_packets, stride, size
         for i in range(n):
             with open(os.path.join(work, "seq", "f_%06d.dpx" % i), "wb") as f:
                 f.write(synth.dpx_file(None, pixfmt, frame_index=i, payload=bytes(frames[i].cpu().numpy()), size=(width, height)))
-        run = lambda cmd: subprocess.run(cmd, cwd=work, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=600)
+        def run(cmd):       # the reference occasionally dead-locks in its own thread pool on many-core hosts: bounded, with one retry
+            for attempt in (0, 1):
+                try:
+                    return subprocess.run(cmd, cwd=work, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=60)
+                except subprocess.TimeoutExpired:
+                    if attempt:
+                        raise
         r = run([ref, "--hash", "--no-check-padding", "-d", "-y", "seq"])     # analysis only: writes the reversibility data with the MD5 of every file
         if r.returncode != 0:
             return None
