@@ -195,7 +195,7 @@ class Ffv1Encoder:
         optrs = (_VP * n)(*[C.cast(o, _VP) for o in outs])
         sizes = (_SZ * n)()
         _check(lib().rcgpu_ffv1_encode_host(self.h, ptrs, n, optrs, sizes), "rcgpu_ffv1_encode_host")
-        return [outs[i].raw[:sizes[i]] for i in range(n)]
+        return [C.string_at(outs[i], sizes[i]) for i in range(n)]      # only the packet, not the whole worst-case buffer
 
     def encode_device(self, frame_ptrs: list[int], d_packets: int, packet_stride: int, d_sizes: int, stream: int = 0) -> None:
         n = len(frame_ptrs)
@@ -266,7 +266,8 @@ def md5_device(ptrs: list[int], sizes: list[int], stream: int = 0) -> list[bytes
     n = len(ptrs)
     out = C.create_string_buffer(16 * n)
     _check(lib().rcgpu_md5_device((_VP * n)(*ptrs), (C.c_uint64 * n)(*sizes), n, out, stream), "rcgpu_md5_device")
-    return [out.raw[16 * i:16 * i + 16] for i in range(n)]
+    raw = out.raw
+    return [raw[16 * i:16 * i + 16] for i in range(n)]
 
 
 class FlacEncoder:
@@ -292,8 +293,9 @@ class FlacEncoder:
         keep = C.create_string_buffer(pcm, len(pcm))
         _check(lib().rcgpu_flac_encode_host(self.h, keep, len(pcm), out, cap, sizes, fcap, C.byref(n)), "rcgpu_flac_encode_host")
         frames, off = [], 0
+        raw = out.raw                      # one copy, not one per frame
         for i in range(n.value):
-            frames.append(out.raw[off:off + sizes[i]])
+            frames.append(raw[off:off + sizes[i]])
             off += sizes[i]
         cp = C.create_string_buffer(256)
         k = lib().rcgpu_flac_codec_private(self.h, cp, 256)

@@ -39,7 +39,7 @@ def encode_payload(p: Params, payload: bytes, line_bytes: int) -> bytes:
     out = C.create_string_buffer(cap)
     n = lib().ffv1o_encode_payload(C.byref(p), payload, C.c_size_t(line_bytes), out, C.c_size_t(cap), None)
     assert n > 0, "oracle encoder overflow"
-    return out.raw[:n]
+    return C.string_at(out, n)
 
 
 def decode_payload(p: Params, packet: bytes, line_bytes: int) -> bytes:
@@ -90,8 +90,9 @@ def flac_encode(ch, rate, bits, pcm: bytes, block_size=0, max_order=8):
     nf = L.flaco_encode(C.byref(p), pcm, C.c_uint64(len(pcm)), out, C.c_size_t(len(out)), fs, C.c_size_t(len(fs)))
     assert nf >= 0, nf
     frames, off = [], 0
+    raw = out.raw
     for i in range(nf):
-        frames.append(out.raw[off:off + fs[i]])
+        frames.append(raw[off:off + fs[i]])
         off += fs[i]
     md5 = C.create_string_buffer(16)
     spcm = pcm[:n * ch * (bits // 8)]

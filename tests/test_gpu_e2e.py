@@ -32,7 +32,7 @@ def make_package(work, w, h, pixfmt, nframes, kind, tiff=False, audio=None, star
             f.write(synth.wav_file(synth.pcm_samples(n, ch, abits, rate), abits, rate))
 
 
-def run(cmd, cwd, timeout=45, attempts=4):
+def run(cmd, cwd, timeout=20, attempts=5):
     """Run one step of the round trip.  The reference binary occasionally dead-locks in its own analysis thread pool on many-core
     hosts (seen ~1 in 200 invocations of `rawcooked -d` on the GPU box, never with this repo's code involved), so a step that
     times out is repeated -- every step is idempotent (-y)."""
