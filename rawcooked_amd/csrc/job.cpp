@@ -8,6 +8,7 @@
 #include "rc_common.h"
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <fcntl.h>
@@ -140,6 +141,12 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
 {
     clear_error();
     auto bail = [](int code) { fprintf(stderr, "Error: %s\n", rcgpu_last_error()); return code ? code : 1; };
+    // RCGPU_TRACE=1: wall-clock of the job's phases on stderr (prefix "rcgpu trace:", never "Error:")
+    const bool trace = getenv("RCGPU_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (trace) fprintf(stderr, "rcgpu trace: %8.3f s  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), what);
+    };
     if (!job || !job->streams || !job->n_streams || !job->output_path) return bail(fail(1, "job: missing streams or output path"));
     options opt;
     for (size_t i = 0; i + 1 < job->n_options; i += 2)
@@ -171,6 +178,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     if (dev0 >= ndev_visible || ndev <= 0) return bail(fail(4, "device selection %d+%d is outside the %d visible devices", dev0, job->device_count, ndev_visible));
     ndev = std::min(ndev, ndev_visible - dev0);
 
+    mark("options parsed, devices counted");
     // ---- analyse the streams
     std::vector<video_plan> videos; std::vector<audio_plan> audios;
     std::vector<std::pair<bool, size_t>> order;        // stream order -> (is_video, index)
@@ -211,6 +219,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         }
     }
 
+    mark("streams analysed");
     // ---- audio first: A_FLAC CodecPrivate (STREAMINFO) must be final before the header is written
     for (audio_plan& a : audios) {
         mapped_file f;
@@ -235,13 +244,19 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         if (r) return bail(r);
     }
 
+    mark("audio encoded");
     // ---- container header
     rcgpu_mkv* mux = nullptr;
     if (int r = rcgpu_mkv_open(job->output_path, 1, &mux)) return bail(r);
     struct mux_guard { rcgpu_mkv*& m; const char* path; bool ok = false; ~mux_guard() { if (m) { rcgpu_mkv_close(m); if (!ok) unlink(path); } } } guard{ mux, job->output_path };
 
     std::vector<std::unique_ptr<rcgpu_ffv1, void (*)(rcgpu_ffv1*)>> encoders;
-    const uint32_t batch = uint32_t(std::max(1L, opt.num("rcgpu_batch", 0)));
+    // Two workers per device: while one holds the muxer's turn (writing ~50 MB per frame to disk) the other maps the next files and
+    // runs the device.  Short jobs get by with one.
+    size_t longest = 0;
+    for (const video_plan& v : videos) longest = std::max(longest, v.files.size());
+    const int nworkers = ndev * (longest > 8 ? 2 : 1);
+    const uint32_t batch = uint32_t(std::max(0L, opt.num("rcgpu_batch", 0)));      // 0: sized from the picture and the sequence below
     for (auto& o : order) {
         if (o.first) {
             video_plan& v = videos[o.second];
@@ -250,12 +265,12 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             // frames in flight per device: bounded by HBM (intermediates ~1.3 GB per 4K frame) and by the sequence length
             const uint64_t px = uint64_t(v.info.width) * v.info.height;
             F = batch ? batch : uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (uint64_t(96) << 30) / (px * 160 + 1))));
-            F = uint32_t(std::min<uint64_t>(F, (v.files.size() + ndev - 1) / ndev));
+            F = uint32_t(std::min<uint64_t>(F, (v.files.size() + nworkers - 1) / nworkers));
             rcgpu_ffv1_config c{}; c.width = v.info.width; c.height = v.info.height; c.pixfmt = v.info.pixfmt; c.line_bytes = v.info.line_bytes;
             c.flags = (v.info.flags & RCGPU_FLAG_ALTERN) | (v.vflip ? RCGPU_FLAG_VFLIP : 0);
             c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.max_batch = F;
-            for (int d = 0; d < ndev; d++) {
-                c.device = dev0 + d;
+            for (int wk = 0; wk < nworkers; wk++) {               // one encoder per worker: worker wk drives device wk % ndev
+                c.device = dev0 + wk % ndev;
                 rcgpu_ffv1* e = nullptr;
                 if (int r = rcgpu_ffv1_create(&c, &e)) return bail(r);
                 encoders.emplace_back(e, rcgpu_ffv1_destroy);
@@ -281,6 +296,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         if (int r = attach(job->reversibility_path, "RAWcooked reversibility data")) return bail(r);
     if (int r = rcgpu_mkv_begin(mux)) return bail(r);
 
+    mark("encoders created, header written");
     // ---- blocks, in timestamp order: audio frames are interleaved in front of the video frame they precede
     std::vector<size_t> audio_pos(audios.size(), 0), audio_off(audios.size(), 0);
     auto write_audio_until = [&](uint64_t pts_ns_limit) -> int {
@@ -298,7 +314,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
 
     if (!videos.empty()) {
         // work items = (video, batch), ordered by the timestamp of their first frame so that tracks interleave in the file;
-        // item g goes to device g % ndev, a turnstile hands finished items to the muxer in that order
+        // item g goes to worker g % nworkers, a turnstile hands finished items to the muxer in that order
         struct item { size_t vi, first, n; uint64_t pts; };
         std::vector<item> items;
         for (size_t vi = 0; vi < videos.size(); vi++) {
@@ -309,8 +325,9 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         std::stable_sort(items.begin(), items.end(), [](const item& a, const item& b) { return a.pts < b.pts; });
         turnstile ts;
         auto worker = [&](int d) {
-            std::vector<std::vector<uint8_t>> packets;
-            for (size_t g = size_t(d); g < items.size(); g += size_t(ndev)) {
+            // packet buffers: one uninitialised allocation per slot (a value-initialised vector would touch 96 MB per 4K frame)
+            std::vector<std::unique_ptr<uint8_t[]>> packets; std::vector<size_t> packet_cap;
+            for (size_t g = size_t(d); g < items.size(); g += size_t(nworkers)) {
                 const item& it = items[g];
                 video_plan& v = videos[it.vi];
                 rcgpu_ffv1* enc = encoders[v.enc_first + size_t(d)].get();
@@ -319,7 +336,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                 int err = 0;
                 std::vector<std::unique_ptr<mapped_file>> maps(n);
                 std::vector<const uint8_t*> ptrs(n); std::vector<uint8_t*> outs(n); std::vector<size_t> sizes(n);
-                if (packets.size() < n) packets.resize(n);
+                if (packets.size() < n) { packets.resize(n); packet_cap.resize(n, 0); }
                 for (size_t i = 0; i < n && !err; i++) {
                     maps[i].reset(new mapped_file);
                     if (!maps[i]->open(v.files[first + i])) { err = fail(30, "cannot open %s: %s", v.files[first + i].c_str(), strerror(errno)); break; }
@@ -330,10 +347,12 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                     if (fi.width != v.info.width || fi.height != v.info.height || fi.pixfmt != v.info.pixfmt || fi.line_bytes != v.info.line_bytes || fi.flags != v.info.flags)
                         { err = fail(31, "%s differs in geometry/flavor from the first frame of the sequence", v.files[first + i].c_str()); break; }
                     ptrs[i] = maps[i]->data + fi.data_offset;
-                    if (packets[i].size() < cap) packets[i].resize(cap);
-                    outs[i] = packets[i].data();
+                    if (packet_cap[i] < cap) { packets[i].reset(new uint8_t[cap]); packet_cap[i] = cap; }
+                    outs[i] = packets[i].get();
                 }
+                if (trace) { char b[96]; snprintf(b, sizeof b, "item %zu: %zu files mapped and probed", g, n); mark(b); }
                 if (!err) err = rcgpu_ffv1_encode_host(enc, ptrs.data(), uint32_t(n), outs.data(), sizes.data());
+                if (trace) { char b[96]; snprintf(b, sizeof b, "item %zu: encoded on the device", g); mark(b); }
                 std::string msg = err ? rcgpu_last_error() : "";
                 ts.wait_turn(g);
                 if (!err && !ts.error) {
@@ -350,15 +369,17 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             }
         };
         std::vector<std::thread> threads;
-        for (int d = 1; d < ndev; d++) threads.emplace_back(worker, d);
+        for (int d = 1; d < nworkers; d++) threads.emplace_back(worker, d);
         worker(0);
         for (auto& t : threads) t.join();
         if (ts.error) { if (!*rcgpu_last_error()) fail(ts.error, "encode failed on a worker thread"); return bail(ts.error); }
     }
+    mark("all batches encoded and written");
     if (int r = write_audio_until(~0ull)) return bail(r);
     rcgpu_mkv* m = mux; mux = nullptr;
     if (int r = rcgpu_mkv_close(m)) { unlink(job->output_path); return bail(r); }
     guard.ok = true;
+    mark("file closed");
     return 0;
 }
 

@@ -36,7 +36,8 @@ shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
 t0 = time.time(); r = subprocess.run([ref, "--hash", "--no-check-padding", "-d", "-y", "pkg"], cwd=work, capture_output=True, text=True); t_an = time.time() - t0
 assert r.returncode == 0, r.stderr
 argv = shlex.split(r.stdout.strip())
-t0 = time.time(); r = subprocess.run([shim] + argv[1:], cwd=work, capture_output=True, text=True); t_enc = time.time() - t0
+t0 = time.time(); r = subprocess.run([shim] + argv[1:], cwd=work, capture_output=True, text=True, env=dict(os.environ, RCGPU_TRACE="1")); t_enc = time.time() - t0
+print(r.stderr)
 assert r.returncode == 0, r.stdout + r.stderr
 size = os.path.getsize(work + "/pkg.mkv")
 t0 = time.time(); r = subprocess.run([ref, "--check", "pkg.mkv"], cwd=work, capture_output=True, text=True); t_chk = time.time() - t0
