@@ -143,6 +143,8 @@ typedef struct {
     uint32_t segments;        /* hand-over granularity between state resolution and range coding: each slice's decision
                                  stream is produced/consumed in this many windows (0 = automatic, 1 = whole slice) */
     uint32_t flags;           /* RCGPU_FLAG_VFLIP | RCGPU_FLAG_ALTERN: how the payload is laid out (line_bytes is ignored for ALTERN) */
+    uint32_t coder;           /* -coder: 0 or 1 = range coder with the default state transitions; 2 = range coder whose transition
+                                 table travels in the configuration record (FFV1_Parameters.cpp:41-55) */
 } rcgpu_ffv1_config;
 
 typedef struct rcgpu_ffv1 rcgpu_ffv1;

@@ -37,6 +37,18 @@ static const uint8_t one_state_default[256] = {
     226,227,227,229,229,230,231,232,234,234,235,236,237,238,239,240,
     241,242,243,244,245,246,247,248,248,  0,  0,  0,  0,  0,  0,  0,
 };
+/* The table FFmpeg's encoder switches to with -coder 2 (its "ver2_state"), restated from memory [ffmpeg-knowledge]: any table is
+ * conformant, because with coder_type 2 it is part of the stream -- the decoder adds the transmitted deltas to its default table. */
+static const uint8_t one_state_alt[256] = {
+      0,  10,  10,  10,  10,  16,  16,  16,  28,  16,  16,  29,  42,  49,  20,  49,  59,  25,  26,  26,  27,  31,  33,  33,  33,  34,  34,  37,  67,  38,  39,  39,
+     40,  40,  41,  79,  43,  44,  45,  45,  48,  48,  64,  50,  51,  52,  88,  52,  53,  74,  55,  57,  58,  58,  74,  60, 101,  61,  62,  84,  66,  66,  68,  69,
+     87,  82,  71,  97,  73,  73,  82,  75, 111,  77,  94,  78,  87,  81,  83,  97,  85,  83,  94,  86,  99,  89,  90,  99, 111,  92,  93, 134,  95,  98, 105,  98,
+    105, 110, 102, 108, 102, 118, 103, 106, 106, 113, 109, 112, 114, 112, 116, 125, 115, 116, 117, 117, 126, 119, 125, 121, 121, 123, 145, 124, 126, 131, 127, 129,
+    165, 130, 132, 138, 133, 135, 145, 136, 137, 139, 146, 141, 143, 142, 144, 148, 147, 155, 151, 149, 151, 150, 152, 157, 153, 154, 156, 168, 158, 162, 161, 160,
+    172, 163, 169, 164, 166, 184, 167, 170, 177, 174, 171, 173, 182, 176, 180, 178, 175, 189, 179, 181, 186, 183, 192, 185, 200, 187, 191, 188, 190, 197, 193, 196,
+    197, 194, 195, 196, 198, 202, 199, 201, 210, 203, 207, 204, 205, 206, 208, 214, 209, 211, 221, 212, 213, 215, 224, 216, 217, 218, 219, 220, 222, 228, 223, 225,
+    226, 224, 227, 229, 240, 230, 231, 232, 233, 234, 235, 236, 238, 239, 237, 242, 241, 243, 242, 244, 245, 246, 247, 248, 249, 250, 251, 252, 252, 253, 254, 255,
+};
 
 /* Quantisation levels for indices 0..127 given as run lengths of equal levels (that is how the record
  * carries them, FFV1_Parameters.cpp:222-253).  These are the level maps FFmpeg's encoder uses
@@ -395,20 +407,21 @@ typedef struct {
 static __thread uint16_t* t_dec; static __thread size_t t_dec_cap, t_dec_n;
 static __thread uint32_t* t_sym; static __thread size_t t_sym_n;
 
-static void rc_tables(uint8_t* one, uint8_t* zero)
+static void rc_tables(uint8_t* one, uint8_t* zero, uint32_t coder)
 {
     /* AssignStateTransitions, FFV1_RangeCoder.cpp:35-41 */
-    memcpy(one, one_state_default, 256);
+    memcpy(one, coder == 2 ? one_state_alt : one_state_default, 256);
     zero[0] = 0;
     for (int i = 1; i < 256; i++)
         zero[i] = (uint8_t)(256 - one[256 - i]);
 }
-static void rce_init(rc_enc* c, uint8_t* buf, size_t cap)
+static void rce_init2(rc_enc* c, uint8_t* buf, size_t cap, uint32_t coder)
 {
     c->low = 0; c->range = 0xFF00; c->outstanding_byte = -1; c->outstanding_count = 0;
     c->p = buf; c->end = buf + cap; c->overflow = 0; c->decisions = 0;
-    rc_tables(c->one_state, c->zero_state);
+    rc_tables(c->one_state, c->zero_state, coder);
 }
+static void rce_init(rc_enc* c, uint8_t* buf, size_t cap) { rce_init2(c, buf, cap, 1); }      /* the record itself: default table */
 static inline void rce_out(rc_enc* c, int v) { if (c->p < c->end) *c->p++ = (uint8_t)v; else c->overflow = 1; }
 static void rce_renorm(rc_enc* c)
 {
@@ -481,7 +494,9 @@ size_t ffv1o_config_record(const ffv1o_params* p, uint8_t* out, size_t cap)
     uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);
     rce_symbol(&c, st, 3, 0);                        /* version */
     rce_symbol(&c, st, 4, 0);                        /* micro_version (>=4 required, :37-38) */
-    rce_symbol(&c, st, 1, 0);                        /* coder_type = range coder, default table */
+    rce_symbol(&c, st, p->coder == 2 ? 2 : 1, 0);    /* coder_type: range coder, default or custom table */
+    if (p->coder == 2)                               /* state_transition_delta[1..255], FFV1_Parameters.cpp:41-55 */
+        for (int i = 1; i < 256; i++) rce_symbol(&c, st, (int32_t)one_state_alt[i] - (int32_t)one_state_default[i], 1);
     rce_symbol(&c, st, is_rgb(p->pixfmt) ? 1 : 0, 0);/* colorspace_type */
     rce_symbol(&c, st, (int32_t)bps, 0);             /* bits_per_raw_sample */
     rce_put(&c, st, is_rgb(p->pixfmt) ? 1 : 0);      /* chroma_planes */
@@ -586,7 +601,7 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
 {
     uint32_t x0, y0, w, h;
     slice_rect(p, sx, sy, &x0, &y0, &w, &h);
-    rc_enc c; rce_init(&c, out, cap);
+    rc_enc c; rce_init2(&c, out, cap, p->coder);              /* coder_type 2: the custom table drives every slice */
     if (first) { uint8_t ks = 128; rce_put(&c, &ks, 1); }     /* keyframe, FFV1_Frame.cpp:148-156 */
     /* slice header, FFV1_Slice.cpp:113-177 */
     uint8_t hs[CONTEXT_SIZE]; memset(hs, 128, sizeof hs);
@@ -698,12 +713,13 @@ typedef struct {
     const uint8_t *beg, *cur, *end;
     uint8_t one_state[256], zero_state[256];
 } rc_dec;
-static void rcd_init(rc_dec* c, const uint8_t* buf, size_t n)
+static void rcd_init2(rc_dec* c, const uint8_t* buf, size_t n, uint32_t coder)
 {
     c->beg = buf; c->cur = buf; c->end = buf + n;
     c->current = n ? *c->cur : 0; c->mask = 0xFF; c->cur++;       /* AssignBuffer, :22-33 */
-    rc_tables(c->one_state, c->zero_state);
+    rc_tables(c->one_state, c->zero_state, coder);
 }
+static void rcd_init(rc_dec* c, const uint8_t* buf, size_t n) { rcd_init2(c, buf, n, 1); }
 static int rcd_b(rc_dec* c, uint8_t* state)
 {
     if (c->mask < 0x100) {
@@ -748,7 +764,7 @@ static int decode_slice(const ffv1o_params* p, const codec_ctx* k, const uint8_t
     const size_t tail = p->ec ? 8 : 3;
     if (size < tail) return 10;
     if (p->ec && ffv1o_crc32(buf, size)) return 11;             /* FFV1_Slice.cpp:247-249 */
-    rc_dec c; rcd_init(&c, buf, size - tail);
+    rc_dec c; rcd_init2(&c, buf, size - tail, p->coder);
     if (first) { uint8_t ks = 128; rcd_b(&c, &ks); }
     uint8_t hs[CONTEXT_SIZE]; memset(hs, 128, sizeof hs);
     uint32_t sx = rcd_u(&c, hs), sy = rcd_u(&c, hs);
@@ -807,7 +823,7 @@ int ffv1o_decode_frame(const ffv1o_params* p, const uint8_t* pkt, size_t size, i
     codec_ctx_init(k, p);
     const size_t tail = p->ec ? 8 : 3;
     /* keyframe bit, FFV1_Frame.cpp:148-156 */
-    { rc_dec c; rcd_init(&c, pkt, size); uint8_t ks = 128; if (!rcd_b(&c, &ks)) { free(k); return 1; } }
+    { rc_dec c; rcd_init2(&c, pkt, size, p->coder); uint8_t ks = 128; if (!rcd_b(&c, &ks)) { free(k); return 1; } }
     /* split from the tail, FFV1_Frame.cpp:177-198 */
     size_t pos = size; uint32_t count = 0; int err = 0;
     while (pos && !err) {
@@ -845,7 +861,13 @@ int ffv1o_parse_config_record(const uint8_t* rec, size_t size, ffv1o_params* p)
     uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);
     if (rcd_u(&c, st) != 3) return 3;
     if (rcd_u(&c, st) < 4) return 4;
-    if (rcd_u(&c, st) != 1) return 5;
+    {
+        const uint32_t coder_type = rcd_u(&c, st);
+        if (coder_type != (p->coder == 2 ? 2u : 1u)) return 5;
+        if (coder_type == 2)                                             /* FFV1_Parameters.cpp:41-55 */
+            for (int i = 1; i < 256; i++)
+                if ((int32_t)one_state_default[i] + rcd_s(&c, st) != (int32_t)one_state_alt[i]) return 5;
+    }
     uint32_t colorspace = rcd_u(&c, st);
     uint32_t bps = rcd_u(&c, st);
     int chroma = rcd_b(&c, st);

@@ -59,6 +59,8 @@ typedef struct {
     uint32_t ec;            /* slicecrc: 0/1 */
     uint32_t context_model; /* -context: 0 (3 inputs) / 1 (5 inputs, FFmpeg's level maps) / 2 (5 inputs, compact 5,5,3,3,3 maps) */
     uint32_t flags;         /* FFV1O_FLAG_* (payload layout only; the bitstream does not know about them) */
+    uint32_t coder;         /* -coder: 0/1 range coder with the default state transitions; 2 range coder with the alternate table, which
+                               then travels in the configuration record as 255 deltas (FFV1_Parameters.cpp:41-55) */
 } ffv1o_params;
 
 /* geometry helpers */

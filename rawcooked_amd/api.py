@@ -34,7 +34,7 @@ class AudioInfo(C.Structure):
 class Ffv1Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("pixfmt", C.c_uint32), ("line_bytes", C.c_uint32),
                 ("num_h_slices", C.c_uint32), ("num_v_slices", C.c_uint32), ("slicecrc", C.c_uint32), ("context", C.c_uint32),
-                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32)]
+                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32), ("coder", C.c_uint32)]
 
 
 class FlacConfig(C.Structure):
@@ -169,8 +169,8 @@ def md5(data: bytes) -> bytes:
 class Ffv1Encoder:
     """Device FFV1 encoder (rcgpu_ffv1_*).  Raises when no HIP device is visible."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0, flags=0):
-        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments, flags)
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0, flags=0, coder=1):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments, flags, coder)
         self.h = _VP()
         _check(lib().rcgpu_ffv1_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_create")
         self.max_packet = lib().rcgpu_ffv1_max_packet_bytes(self.h)
@@ -228,8 +228,8 @@ class Ffv1Encoder:
 class Ffv1Decoder:
     """Device FFV1 decoder + pack (the --check half).  Buffers are device pointers (ints)."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, flags=0):
-        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, 0, flags)
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, flags=0, coder=1):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, 0, flags, coder)
         self.h = _VP()
         _check(lib().rcgpu_ffv1_decoder_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_decoder_create")
 

@@ -504,8 +504,8 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     c.nsets = c.rgb ? (px.planes == 4 ? 3 : 2) : 1; c.ec = cfg->slicecrc ? 1 : 0; c.is5 = Q.q[3][127] != 0;
     c.index_count = c.rgb ? (px.planes == 4 ? 3u : 2u) : 2u; c.qidx = qidx;
     memcpy(c.q, Q.q, sizeof c.q);
-    memcpy(c.one_state, ffv1::kOneState, 256);
-    ffv1::make_zero_state(c.zero_state);
+    memcpy(c.one_state, ffv1::one_state_table(cfg->coder), 256);
+    ffv1::make_zero_state(c.zero_state, c.one_state);
     d->nkeys = c.nsets * c.nctx;
     d->payload_bytes = size_t(cfg->line_bytes) * cfg->height;
     const uint32_t F = cfg->max_batch; const size_t nchains = size_t(F) * c.S;

@@ -935,6 +935,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         return fail(2, "ffv1: more slices than pixels (FFV1_Frame.cpp:161-164)");
     if (!cfg->max_batch) return fail(2, "ffv1: max_batch is 0");
     if (cfg->segments > kMaxSeg) return fail(2, "ffv1: at most %u segments", kMaxSeg);
+    if (cfg->coder > 2) return fail(2, "ffv1: coder %u (0/1 default transitions, 2 transmitted table)", cfg->coder);
     const pix_desc& d = pix(cfg->pixfmt);
     const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
     if (altern && d.fields != kFieldsLow) return fail(2, "ffv1: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only (DPX.cpp:363-368)");
@@ -950,7 +951,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     e->cfg = *cfg;
     e->sp.bits_per_raw_sample = d.bits; e->sp.rgb = d.planes != 1; e->sp.alpha = d.planes == 4;
     e->sp.num_h_slices = cfg->num_h_slices; e->sp.num_v_slices = cfg->num_v_slices;
-    e->sp.ec = cfg->slicecrc ? 1 : 0; e->sp.context_model = cfg->context ? 1 : 0; e->sp.compact = cfg->context == 2;
+    e->sp.ec = cfg->slicecrc ? 1 : 0; e->sp.context_model = cfg->context ? 1 : 0; e->sp.compact = cfg->context == 2; e->sp.coder = cfg->coder == 2 ? 2 : 1;
     e->record = ffv1::config_record(e->sp);
 
     ffv1::quant_model qm[2];
@@ -966,8 +967,8 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     c.nsets = c.rgb ? (d.planes == 4 ? 3 : 2) : 1; c.ec = e->sp.ec; c.is5 = Q.q[3][127] != 0;
     c.samples_per_frame = cfg->width * cfg->height * d.planes;
     memcpy(c.q, Q.q, sizeof c.q);
-    memcpy(c.one_state, ffv1::kOneState, 256);
-    ffv1::make_zero_state(c.zero_state);
+    memcpy(c.one_state, ffv1::one_state_table(cfg->coder), 256);
+    ffv1::make_zero_state(c.zero_state, c.one_state);
     if (c.nctx > 8191) { delete e; return fail(2, "ffv1: context count %u does not fit the symbol format", c.nctx); }
     e->nkeys = c.nsets * c.nctx;
     e->resolve_lds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + 2 * 256 + ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);

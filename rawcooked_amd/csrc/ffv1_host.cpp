@@ -20,10 +20,21 @@ const uint8_t kOneState[256] = {
     226, 227, 227, 229, 229, 230, 231, 232, 234, 234, 235, 236, 237, 238, 239, 240, 241, 242, 243, 244, 245, 246, 247, 248, 248,   0,   0,   0,   0,   0,   0,   0,
 };
 
-void make_zero_state(uint8_t zero[256])
+const uint8_t kOneStateAlt[256] = {
+      0,  10,  10,  10,  10,  16,  16,  16,  28,  16,  16,  29,  42,  49,  20,  49,  59,  25,  26,  26,  27,  31,  33,  33,  33,  34,  34,  37,  67,  38,  39,  39,
+     40,  40,  41,  79,  43,  44,  45,  45,  48,  48,  64,  50,  51,  52,  88,  52,  53,  74,  55,  57,  58,  58,  74,  60, 101,  61,  62,  84,  66,  66,  68,  69,
+     87,  82,  71,  97,  73,  73,  82,  75, 111,  77,  94,  78,  87,  81,  83,  97,  85,  83,  94,  86,  99,  89,  90,  99, 111,  92,  93, 134,  95,  98, 105,  98,
+    105, 110, 102, 108, 102, 118, 103, 106, 106, 113, 109, 112, 114, 112, 116, 125, 115, 116, 117, 117, 126, 119, 125, 121, 121, 123, 145, 124, 126, 131, 127, 129,
+    165, 130, 132, 138, 133, 135, 145, 136, 137, 139, 146, 141, 143, 142, 144, 148, 147, 155, 151, 149, 151, 150, 152, 157, 153, 154, 156, 168, 158, 162, 161, 160,
+    172, 163, 169, 164, 166, 184, 167, 170, 177, 174, 171, 173, 182, 176, 180, 178, 175, 189, 179, 181, 186, 183, 192, 185, 200, 187, 191, 188, 190, 197, 193, 196,
+    197, 194, 195, 196, 198, 202, 199, 201, 210, 203, 207, 204, 205, 206, 208, 214, 209, 211, 221, 212, 213, 215, 224, 216, 217, 218, 219, 220, 222, 228, 223, 225,
+    226, 224, 227, 229, 240, 230, 231, 232, 233, 234, 235, 236, 238, 239, 237, 242, 241, 243, 242, 244, 245, 246, 247, 248, 249, 250, 251, 252, 252, 253, 254, 255,
+};
+
+void make_zero_state(uint8_t zero[256], const uint8_t* one)
 {
     zero[0] = 0;
-    for (int i = 1; i < 256; i++) zero[i] = uint8_t(256 - kOneState[256 - i]);
+    for (int i = 1; i < 256; i++) zero[i] = uint8_t(256 - one[256 - i]);
 }
 
 // Level maps over |difference| 0..127 as run lengths (the record carries exactly these runs, FFV1_Parameters.cpp:222-253).
@@ -73,7 +84,8 @@ struct host_rc {
     std::vector<uint8_t> out;
     std::vector<uint16_t>* trace = nullptr;
     uint8_t zero[256];
-    host_rc() { make_zero_state(zero); }
+    const uint8_t* one = kOneState;
+    explicit host_rc(uint32_t coder = 1) : one(one_state_table(coder)) { make_zero_state(zero, one); }
     void renorm()
     {
         while (range < 0x100) {
@@ -92,7 +104,7 @@ struct host_rc {
             if (bit) { low += range - r1; range = r1; } else range -= r1;
             renorm();
         }
-        st = bit ? kOneState[st] : zero[st];
+        st = bit ? one[st] : zero[st];
     }
     void symbol(uint8_t* st, int32_t v, bool is_signed)   // inverse of rangecoder::u / ::s, FFV1_RangeCoder.cpp:105-305
     {
@@ -126,7 +138,9 @@ std::vector<uint8_t> config_record(const stream_params& p)
     uint8_t st[kContextSize]; memset(st, 128, sizeof st);
     c.symbol(st, 3, false);                         // version
     c.symbol(st, 4, false);                         // micro_version
-    c.symbol(st, 1, false);                         // coder_type: range coder, default transitions (-coder 1)
+    c.symbol(st, p.coder == 2 ? 2 : 1, false);      // coder_type: range coder with the default (-coder 1) or a transmitted (-coder 2) table
+    if (p.coder == 2)                               // state_transition_delta[1..255]; the record itself is coded with the default table
+        for (int i = 1; i < 256; i++) c.symbol(st, int32_t(kOneStateAlt[i]) - int32_t(kOneState[i]), true);
     c.symbol(st, p.rgb ? 1 : 0, false);             // colorspace_type
     c.symbol(st, int32_t(p.bits_per_raw_sample), false);
     c.put(st[0], p.rgb ? 1 : 0);                    // chroma_planes
@@ -148,7 +162,7 @@ std::vector<uint8_t> config_record(const stream_params& p)
 std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx, uint32_t sy, bool first_slice)
 {
     std::vector<uint16_t> d;
-    host_rc c; c.trace = &d;
+    host_rc c(p.coder); c.trace = &d;
     if (first_slice) { uint8_t ks = 128; c.put(ks, 1); }           // keyframe
     uint8_t st[kContextSize]; memset(st, 128, sizeof st);
     c.symbol(st, int32_t(sx), false);

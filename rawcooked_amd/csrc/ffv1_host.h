@@ -11,7 +11,11 @@ constexpr int kContextSize = 32;      // states per context (Lib/CoDec/FFV1/FFV1
 // FFV1 default state transition table (bitstream constant; the decoder's copy is FFV1_Frame.cpp:35-55) and
 // its mirror zero_state[i] = 256 - one_state[256 - i] (FFV1_RangeCoder.cpp:35-41).
 extern const uint8_t kOneState[256];
-void make_zero_state(uint8_t zero[256]);
+// The table of `-coder 2` (coder_type 2: the transitions travel in the configuration record as deltas to the default table,
+// FFV1_Parameters.cpp:41-55).  FFmpeg's choice ("ver2_state"), restated from memory: any table is conformant.
+extern const uint8_t kOneStateAlt[256];
+inline const uint8_t* one_state_table(uint32_t coder) { return coder == 2 ? kOneStateAlt : kOneState; }
+void make_zero_state(uint8_t zero[256], const uint8_t* one = kOneState);
 
 struct quant_model {
     int16_t  q[5][256];           // value = level * scale, negative half mirrored (FFV1_Parameters.cpp:243-245)
@@ -31,6 +35,7 @@ struct stream_params {
     uint32_t ec;                  // slicecrc
     uint32_t context_model;       // quant table set index used by every plane (-context)
     bool     compact = false;     // table set 1 is the compact 5-input model
+    uint32_t coder = 1;           // 1: default state transitions; 2: kOneStateAlt, carried in the record
 };
 
 // Configuration record incl. CRC (what parameters::Parse reads, FFV1_Parameters.cpp:23-183).

@@ -154,7 +154,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     // What this encoder implements of the option surface (defaults: CLI/Global.cpp:938-989)
     if (const char* cv = opt.get("c:v")) if (strcmp(cv, "ffv1") != 0) return bail(fail(2, "video codec %s is not supported by rcgpu (only ffv1)", cv));
     if (const char* ca = opt.get("c:a")) if (strcmp(ca, "flac") != 0) return bail(fail(2, "audio codec %s is not supported by rcgpu (only flac)", ca));
-    if (opt.num("coder", 1) != 1) return bail(fail(2, "-coder %ld is not supported by rcgpu (only 1, range coder with default table)", opt.num("coder", 1)));
+    const long coder = opt.num("coder", 1);
+    if (coder != 1 && coder != 2) return bail(fail(2, "-coder %ld is not supported by rcgpu (1: range coder, 2: range coder with a transmitted state table)", coder));
     if (opt.num("level", 3) != 3) return bail(fail(2, "-level %ld is not supported by rcgpu (only 3)", opt.num("level", 3)));
     if (opt.num("g", 1) != 1) return bail(fail(2, "-g %ld is not supported by rcgpu (intra only)", opt.num("g", 1)));
     if (job->framemd5_path) return bail(fail(2, "-f framemd5 is not supported by rcgpu"));
@@ -268,7 +269,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             F = uint32_t(std::min<uint64_t>(F, (v.files.size() + nworkers - 1) / nworkers));
             rcgpu_ffv1_config c{}; c.width = v.info.width; c.height = v.info.height; c.pixfmt = v.info.pixfmt; c.line_bytes = v.info.line_bytes;
             c.flags = (v.info.flags & RCGPU_FLAG_ALTERN) | (v.vflip ? RCGPU_FLAG_VFLIP : 0);
-            c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.max_batch = F;
+            c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.max_batch = F; c.coder = uint32_t(coder);
             for (int wk = 0; wk < nworkers; wk++) {               // one encoder per worker: worker wk drives device wk % ndev
                 c.device = dev0 + wk % ndev;
                 rcgpu_ffv1* e = nullptr;

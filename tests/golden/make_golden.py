@@ -52,6 +52,8 @@ FFV1 = [  # name, w, h, pixfmt, frames, kind, tiff[, layout flags]
     ("dpx_y12packed_56x38", 56, 38, synth.PIX_Y12_PACKED_BE, 1, "film", False),
     ("dpx_y12packed_vflip_96x40", 96, 40, synth.PIX_Y12_PACKED_BE, 1, "noise", False, synth.FLAG_VFLIP),
     ("exr_rgb16_72x40", 72, 40, synth.PIX_EXR_RGB16, 2, "film", "exr"),
+    ("dpx_rgb16be_coder2_72x40", 72, 40, synth.PIX_RGB16_BE, 2, "film", False, 0, 2),      # -coder 2: transition table carried in the record
+    ("dpx_rgb10be_coder2_50x38", 50, 38, synth.PIX_RGB10_FILLEDA_BE, 1, "film", False, 0, 2),
     # the other TIFF flavors of TIFF.cpp:157-166
     ("tiff_rgb8_40x30", 40, 30, synth.PIX_RGB8, 1, "film", True),
     ("tiff_rgb16be_40x30", 40, 30, synth.PIX_RGB16_BE, 1, "film", True),
@@ -77,6 +79,7 @@ def main():
     vectors = {"ffv1": [], "flac": []}
     for name, w, h, pixfmt, nframes, kind, tiff, *rest in FFV1:
         flags = rest[0] if rest else 0
+        coder = rest[1] if len(rest) > 1 else 1
         work = tempfile.mkdtemp()
         os.makedirs(work + "/seq")
         bits, nc, _, _ = synth.PIX_INFO[pixfmt]
@@ -88,7 +91,7 @@ def main():
             open(fn, "wb").write(data)
             files.append(fn)
         ri = run([REF, "--info", "--no-encode", "--no-check-padding", "--check", "-y", "seq"], work)      # prints the flavor string of every track
-        r = run([REF, "--hash", "--no-check-padding", "--check", "-d", "-y", "seq"], work)      # --check: the reference refuses EXR without it (Main.cpp:121-127)
+        r = run([REF] + (["-coder", str(coder)] if coder != 1 else []) + ["--hash", "--no-check-padding", "--check", "-d", "-y", "seq"], work)      # --check: the reference refuses EXR without it (Main.cpp:121-127)
         assert r.returncode == 0, r.stderr
         first = open(files[0], "rb").read()
         info = api.exr_probe(first) if tiff == "exr" else api.tiff_probe(first) if tiff else api.dpx_probe(first)
@@ -96,14 +99,15 @@ def main():
         assert slices == info.slices and info.flags == flags and ("-vf vflip" in r.stdout) == bool(flags & synth.FLAG_VFLIP)
         assert (" " + info.flavor.decode() + "\n") in ri.stdout + ri.stderr, (info.flavor, ri.stdout, ri.stderr)
         nh, nv = api.slices_to_grid(slices)
-        p = ob.Params(w, h, pixfmt, nh, nv, 1, 1, flags)
+        assert ("-coder %d " % coder) in r.stdout
+        p = ob.Params(w, h, pixfmt, nh, nv, 1, 1, flags, coder)
         rec = ob.config_record(p)
         mux = api.MkvMuxer(work + "/seq.mkv")
         t = mux.add_video(rec, w, h, 24, 1)
         mux.add_attachment("RAWcooked reversibility data", open(work + "/seq.rawcooked_reversibility_data", "rb").read())
         mux.begin()
         entry = {"name": name, "width": w, "height": h, "pixfmt": pixfmt, "num_h": nh, "num_v": nv, "line_bytes": info.line_bytes,
-                 "flags": flags, "flavor": info.flavor.decode(), "slices": slices, "config_record": rec.hex(), "frames": []}
+                 "flags": flags, "coder": coder, "flavor": info.flavor.decode(), "slices": slices, "config_record": rec.hex(), "frames": []}
         for i, fn in enumerate(files):
             b = open(fn, "rb").read()
             payload = b[info.data_offset:info.data_offset + info.data_size]

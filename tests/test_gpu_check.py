@@ -25,7 +25,7 @@ def test_decode_golden_packets(built, v):
     n = len(v["frames"])
     payloads = [open(os.path.join(G, f["payload"]), "rb").read() for f in v["frames"]]
     packets = [open(os.path.join(G, f["packet"]), "rb").read() for f in v["frames"]]
-    dec = api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["num_h"], v["num_v"], 1, 1, max_batch=n, flags=v["flags"])
+    dec = api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["num_h"], v["num_v"], 1, 1, max_batch=n, flags=v["flags"], coder=v["coder"])
     dpk = [dev(p) for p in packets]
     dout = [torch.full((len(p),), 0xAA, dtype=torch.uint8, device="cuda") for p in payloads]
     flags = dec.decode_device([t.data_ptr() for t in dpk], [len(p) for p in packets], [t.data_ptr() for t in dout])

@@ -232,3 +232,21 @@ def test_package_with_two_video_tracks_and_two_audio_tracks(built, refbin, tmp_p
             assert open(src, "rb").read() == open(dst, "rb").read(), fn
             n += 1
     assert n == 8
+
+
+def test_coder_2_carries_its_state_table(built, refbin, tmp_path):
+    """`rawcooked -coder 2` (Global.cpp:380-393): range coder whose state-transition table travels in the configuration record as
+    deltas to the default one (FFV1_Parameters.cpp:41-55); smaller packets than -coder 1 on the same content."""
+    work = str(tmp_path)
+    make_package(work, 160, 90, synth.PIX_RGB16_BE, 3, "film")
+    sizes = {}
+    for coder in ("1", "2"):
+        r = run([refbin, "-coder", coder, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+        assert r.returncode == 0 and ("-coder %s " % coder) in r.stdout, r.stdout + r.stderr
+        argv = shlex.split(r.stdout.strip())
+        r = run([SHIM] + argv[1:], work)
+        assert r.returncode == 0, r.stdout + r.stderr
+        sizes[coder] = os.path.getsize(os.path.join(work, "pkg.mkv"))
+        r = run([refbin, "--check", "pkg.mkv"], work)
+        assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    assert sizes["2"] < sizes["1"]

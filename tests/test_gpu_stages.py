@@ -130,7 +130,7 @@ def test_encode_golden_payloads(built, v):
     byte-identically (tests/golden/make_golden.py).  This check needs neither the oracle nor /root/reference at run time."""
     payloads = [open(_os.path.join(_G, f["payload"]), "rb").read() for f in v["frames"]]
     packets = [open(_os.path.join(_G, f["packet"]), "rb").read() for f in v["frames"]]
-    enc = api.Ffv1Encoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["num_h"], v["num_v"], 1, 1, max_batch=len(payloads), flags=v["flags"])
+    enc = api.Ffv1Encoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["num_h"], v["num_v"], 1, 1, max_batch=len(payloads), flags=v["flags"], coder=v["coder"])
     assert enc.config_record().hex() == v["config_record"]
     assert enc.encode_host(payloads) == packets
     enc.close()

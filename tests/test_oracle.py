@@ -19,7 +19,7 @@ VEC = json.load(open(os.path.join(G, "vectors.json")))
 @pytest.mark.parametrize("v", VEC["ffv1"], ids=lambda v: v["name"])
 def test_ffv1_golden(built, v):
     assert v["reference_check"]
-    p = ob.Params(v["width"], v["height"], v["pixfmt"], v["num_h"], v["num_v"], 1, 1, v["flags"])
+    p = ob.Params(v["width"], v["height"], v["pixfmt"], v["num_h"], v["num_v"], 1, 1, v["flags"], v["coder"])
     assert ob.config_record(p).hex() == v["config_record"]
     for fr in v["frames"]:
         payload = open(os.path.join(G, fr["payload"]), "rb").read()
