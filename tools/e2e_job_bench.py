@@ -8,6 +8,17 @@ import subprocess
 import sys
 import time
 
+
+def run(cmd, cwd, env=None, timeout=180, attempts=3):
+    """The reference occasionally dead-locks in its own thread pool on many-core hosts: bounded, repeated (every step is idempotent)."""
+    for a in range(attempts):
+        try:
+            return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, env=env, stdin=subprocess.DEVNULL, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            print('step timed out, repeating:', ' '.join(cmd[:4]), file=sys.stderr)
+            if a + 1 == attempts:
+                raise
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np   # noqa: E402
@@ -33,14 +44,14 @@ with open(work + "/pkg/snd.wav", "wb") as f:
     f.write(synth.wav_file(synth.pcm_samples(n * 2000, 6, 24, 48000), 24, 48000))
 ref = os.path.join(ROOT, "oracle", "_ref", "rawcooked")
 shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
-t0 = time.time(); r = subprocess.run([ref, "--hash", "--no-check-padding", "-d", "-y", "pkg"], cwd=work, capture_output=True, text=True); t_an = time.time() - t0
+t0 = time.time(); r = run([ref, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work); t_an = time.time() - t0
 assert r.returncode == 0, r.stderr
 argv = shlex.split(r.stdout.strip())
-t0 = time.time(); r = subprocess.run([shim] + argv[1:], cwd=work, capture_output=True, text=True, env=dict(os.environ, RCGPU_TRACE="1")); t_enc = time.time() - t0
+t0 = time.time(); r = run([shim] + argv[1:], work, env=dict(os.environ, RCGPU_TRACE="1")); t_enc = time.time() - t0
 print(r.stderr)
 assert r.returncode == 0, r.stdout + r.stderr
 size = os.path.getsize(work + "/pkg.mkv")
-t0 = time.time(); r = subprocess.run([ref, "--check", "pkg.mkv"], cwd=work, capture_output=True, text=True); t_chk = time.time() - t0
+t0 = time.time(); r = run([ref, "--check", "pkg.mkv"], work, timeout=600); t_chk = time.time() - t0
 ok = r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout
 print({"frames": n, "analysis_s(reference, 1 thread, MD5 of every file)": round(t_an, 2), "rcgpu_encode_s(files->mkv, incl. process start + device init)": round(t_enc, 2),
        "encode_fps_end_to_end": round(n / t_enc, 2), "mkv_bytes": size, "source_bytes": n * (2048 + frames.shape[1]),
