@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, 
     const int bits = int(C->bits);
     const bool is5 = C->is5, ov16 = C->overflow16, rgb = C->rgb;
     unsigned long long local = 0;
-    uint32_t cur_seg = 0xFFFFFFFFu;
+    uint32_t cur_seg = 0xFFFFFFFFu, seg_end = 0;
     const uint32_t line_end = min(nlines, (blockIdx.x + 1) * 8);
     for (uint32_t line = blockIdx.x * 8; line < line_end; line++) {
         const uint32_t y = line / np, p = line - y * np;
@@ -205,8 +205,13 @@ __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, 
             if (ctx < 0) { ctx = -ctx; d = -d; }
             d = int32_t(uint32_t(d) << (32 - bits)) >> (32 - bits);                  // fold: sign-extend to `bits`
             const uint32_t a = uint32_t(d < 0 ? -d : d);
-            const uint32_t idx = line * G.w + x, seg = idx / G.seg_q;
-            if (seg != cur_seg) { if (local) atomicAdd(&segsum[cur_seg], local); local = 0; cur_seg = seg; }
+            const uint32_t idx = line * G.w + x;
+            if (idx >= seg_end) {                 // a thread's symbol index only grows: one division at its first symbol, then increments
+                if (local) atomicAdd(&segsum[cur_seg], local);
+                local = 0;
+                if (cur_seg == 0xFFFFFFFFu) { cur_seg = idx / G.seg_q; seg_end = (cur_seg + 1) * G.seg_q; }
+                else do { cur_seg++; seg_end += G.seg_q; } while (idx >= seg_end);
+            }
             local += a ? uint32_t(2 * (31 - __clz(int(a))) + 3) : 1u;
             out[size_t(idx)] = (set << 30) | (uint32_t(ctx) << 17) | (uint32_t(d) & 0x1FFFFu);
         }
