@@ -194,6 +194,16 @@ void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* dec);
  * junk 128, error_status 256); with NULL it is asynchronous on `hip_stream`. */
 int  rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* dec, const void* const* d_packets, const uint64_t* packet_sizes, uint32_t n,
                                       void* const* d_payloads, uint32_t* h_err_flags, void* hip_stream);
+/* Host-buffer convenience for a caller that holds the Matroska blocks in memory (what ffv1_wrapper::Process receives one at a
+ * time, Lib/CoDec/Wrapper.cpp:115-121): packets go up, payloads (payload_bytes each, see rcgpu_image_info.data_size) come back.
+ * Synchronous; returns an error if any slice of the batch is undecodable. */
+int  rcgpu_ffv1_decoder_decode_host(rcgpu_ffv1_decoder* dec, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n,
+                                    uint8_t* const* payloads);
+/* Fill the stream-dependent fields of `cfg` (num_h_slices, num_v_slices, slicecrc, context, coder) from a Matroska CodecPrivate =
+ * FFV1 configuration record, the way parameters::Parse reads it (FFV1_Parameters.cpp:23-183); width, height, pixfmt, line_bytes
+ * and flags describe the files and are the caller's (they come from the reversibility data / the probes).  Fails when the record
+ * does not describe `pixfmt` (colorspace, bit depth, alpha) or uses a feature this decoder lacks. */
+int  rcgpu_ffv1_config_from_record(const uint8_t* record, size_t size, rcgpu_ffv1_config* cfg);
 int  rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* dec, float ms[3]);   /* split+crc, slices, pack */
 /* First differing byte of two device buffers; *first_diff = UINT64_MAX when they are equal (FileWriter.cpp:448-463). */
 int  rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t* first_diff, void* hip_stream);

@@ -83,6 +83,8 @@ SYMBOLS = {
     "rcgpu_ffv1_decoder_create": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_destroy": (None, [_VP]),
     "rcgpu_ffv1_decoder_decode_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP), C.POINTER(C.c_uint32), _VP]),
+    "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
+    "rcgpu_ffv1_config_from_record": (C.c_int, [_U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rcgpu_compare_device": (C.c_int, [_VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     "rcgpu_md5_device": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _VP, _VP]),
@@ -140,6 +142,13 @@ def exr_probe(data: bytes) -> ImageInfo:
     info = ImageInfo()
     _check(lib().rcgpu_exr_probe(data, len(data), C.byref(info)), "rcgpu_exr_probe")
     return info
+
+
+def config_from_record(record: bytes, width: int, height: int, pixfmt: int, line_bytes: int, flags: int = 0, context: int = 1) -> Ffv1Config:
+    """Decoder configuration for a stream known only by its CodecPrivate (plus what the files' flavor says)."""
+    cfg = Ffv1Config(width, height, pixfmt, line_bytes, 0, 0, 0, context, 1, 0, 0, flags, 0)
+    _check(lib().rcgpu_ffv1_config_from_record(record, len(record), C.byref(cfg)), "rcgpu_ffv1_config_from_record")
+    return cfg
 
 
 def tiff_probe(data: bytes) -> ImageInfo:
@@ -248,6 +257,16 @@ class Ffv1Decoder:
         flags = C.c_uint32(0)
         _check(lib().rcgpu_ffv1_decoder_decode_device(self.h, pk, sz, n, out, C.byref(flags) if check else None, stream), "rcgpu_ffv1_decoder_decode_device")
         return flags.value
+
+    def decode_host(self, packets: list[bytes], payload_bytes: int) -> list[bytes]:
+        n = len(packets)
+        keep = [C.create_string_buffer(p, len(p)) for p in packets]
+        pk = (_VP * n)(*[C.cast(k, _VP) for k in keep])
+        sz = (C.c_uint64 * n)(*[len(p) for p in packets])
+        outs = [C.create_string_buffer(payload_bytes) for _ in range(n)]
+        op = (_VP * n)(*[C.cast(o, _VP) for o in outs])
+        _check(lib().rcgpu_ffv1_decoder_decode_host(self.h, pk, sz, n, op), "rcgpu_ffv1_decoder_decode_host")
+        return [o.raw for o in outs]
 
     def kernel_times(self) -> dict[str, float]:
         ms = (C.c_float * 3)()

@@ -574,6 +574,41 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     return 0;
 }
 
+extern "C" int rcgpu_ffv1_decoder_decode_host(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n,
+                                              uint8_t* const* payloads)
+{
+    clear_error();
+    if (!d || !packets || !packet_sizes || !payloads) return fail(1, "ffv1 decoder: null argument");
+    if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    const size_t out_bytes = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
+    const size_t out_stride = (out_bytes + 255) & ~size_t(255);
+    uint64_t in_total = 0;
+    for (uint32_t i = 0; i < n; i++) in_total += (packet_sizes[i] + 255) & ~uint64_t(255);
+    uint8_t* d_in = nullptr; uint8_t* d_out = nullptr;
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_in), size_t(in_total) + 256);
+    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_out), out_stride * n);
+    std::vector<const void*> pk(n); std::vector<void*> out(n);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n && he == hipSuccess; i++) {
+        he = hipMemcpyAsync(d_in + off, packets[i], packet_sizes[i], hipMemcpyHostToDevice, d->own_stream);
+        pk[i] = d_in + off; out[i] = d_out + size_t(i) * out_stride;
+        off += (packet_sizes[i] + 255) & ~uint64_t(255);
+    }
+    int rc = 0;
+    if (he == hipSuccess) {
+        uint32_t flags = 0;
+        rc = rcgpu_ffv1_decoder_decode_device(d, pk.data(), packet_sizes, n, out.data(), &flags, d->own_stream);
+        for (uint32_t i = 0; i < n && !rc && he == hipSuccess; i++)
+            he = hipMemcpyAsync(payloads[i], out[i], out_bytes, hipMemcpyDeviceToHost, d->own_stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(d->own_stream);
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (he != hipSuccess) return fail(100, "ffv1 decoder: %s", hipGetErrorString(he));
+    return rc;
+}
+
 extern "C" int rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* d, float ms[3])
 {
     if (!d || !d->ev_valid || hipEventSynchronize(d->ev[3]) != hipSuccess) return 1;

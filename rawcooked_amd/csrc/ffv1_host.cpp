@@ -176,3 +176,97 @@ std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx
 }
 
 }}  // namespace rc::ffv1
+
+// ---- configuration record reader (parameters::Parse, FFV1_Parameters.cpp:23-183): a scalar range decoder over a few hundred bytes
+namespace {
+struct host_rd {
+    const uint8_t* cur; const uint8_t* end; uint32_t current, mask; uint8_t zero[256];
+    host_rd(const uint8_t* p, size_t n) : cur(p), end(p + n) { current = n ? *cur : 0; mask = 0xFF; cur++; rc::ffv1::make_zero_state(zero); }
+    bool bit(uint8_t& st)
+    {
+        if (mask < 0x100) { current <<= 8; if (cur < end) current |= *cur; mask <<= 8; cur++; }
+        const uint32_t m2 = (mask * st) >> 8;
+        mask -= m2;
+        if (current < mask) { st = zero[st]; return false; }
+        current -= mask; mask = m2; st = rc::ffv1::kOneState[st];
+        return true;
+    }
+    uint32_t u(uint8_t* st)
+    {
+        if (bit(st[0])) return 0;
+        int e = 0;
+        while (bit(st[1 + (e < 9 ? e : 9)])) if (++e > 31) return 0;
+        uint32_t a = 1;
+        for (int i = e - 1; i >= 0; i--) a = (a << 1) | uint32_t(bit(st[22 + (i < 9 ? i : 9)]));
+        return a;
+    }
+    int32_t s(uint8_t* st)
+    {
+        if (bit(st[0])) return 0;
+        int e = 0;
+        while (bit(st[1 + (e < 9 ? e : 9)])) if (++e > 31) return 0;
+        int32_t a = 1;
+        for (int i = e - 1; i >= 0; i--) a = (a << 1) | int32_t(bit(st[22 + (i < 9 ? i : 9)]));
+        return bit(st[11 + (e < 10 ? e : 10)]) ? -a : a;
+    }
+};
+}  // namespace
+
+extern "C" int rcgpu_ffv1_config_from_record(const uint8_t* rec, size_t size, rcgpu_ffv1_config* cfg)
+{
+    using namespace rc; using namespace rc::ffv1;
+    clear_error();
+    if (!rec || !cfg) return fail(1, "ffv1 record: null argument");
+    if (cfg->pixfmt >= RCGPU_PIX_COUNT) return fail(2, "ffv1 record: unknown pixel format %u", cfg->pixfmt);
+    if (size < 5 || rcgpu_crc32_ffv1(rec, size)) return fail(3, "ffv1 record: CRC mismatch (FFV1_Frame.cpp:116)");
+    const pix_desc& d = pix(cfg->pixfmt);
+    host_rd r(rec, size - 4);
+    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
+    if (r.u(st) != 3) return fail(4, "ffv1 record: only version 3 is supported");
+    if (r.u(st) < 4) return fail(4, "ffv1 record: micro_version < 4 (FFV1_Parameters.cpp:36-37)");
+    const uint32_t coder = r.u(st);
+    if (coder != 1 && coder != 2) return fail(4, "ffv1 record: coder_type %u is not supported (range coder only)", coder);
+    if (coder == 2)
+        for (int i = 1; i < 256; i++)
+            if (int32_t(kOneState[i]) + r.s(st) != int32_t(kOneStateAlt[i])) return fail(4, "ffv1 record: unknown custom state-transition table");
+    const uint32_t colorspace = r.u(st), bps = r.u(st);
+    const bool chroma = r.bit(st[0]);
+    const uint32_t hs = r.u(st), vs = r.u(st);
+    const bool alpha = r.bit(st[0]);
+    const bool rgb = d.planes != 1;
+    if (colorspace != (rgb ? 1u : 0u) || bps != d.bits || chroma != rgb || hs || vs || alpha != (d.planes == 4))
+        return fail(5, "ffv1 record: stream (colorspace %u, %u bit%s) does not match the pixel format of the files", colorspace, bps, alpha ? ", alpha" : "");
+    cfg->num_h_slices = r.u(st) + 1; cfg->num_v_slices = r.u(st) + 1;
+    if (r.u(st) != 2) return fail(6, "ffv1 record: expected two quantisation table sets");
+    quant_model ref[2], compact[2];
+    build_quant_models(d.bits, ref, false); build_quant_models(d.bits, compact, true);
+    bool is_ref = true, is_compact = true;
+    for (int i = 0; i < 2; i++) {
+        int32_t scale = 1;
+        for (int j = 0; j < 5; j++) {
+            uint8_t qst[kContextSize]; memset(qst, 128, sizeof qst);
+            int32_t v = 0;
+            for (uint32_t k = 0; k < 128;) {
+                const uint32_t len1 = r.u(qst);
+                if (k + len1 >= 128) return fail(6, "ffv1 record: bad quantisation table (FFV1_Parameters.cpp:222-253)");
+                for (uint32_t a = 0; a <= len1; a++, k++) {
+                    is_ref &= ref[i].q[j][k] == int16_t(scale * v);
+                    is_compact &= compact[i].q[j][k] == int16_t(scale * v);
+                }
+                v++;
+            }
+            scale *= 2 * v - 1;
+        }
+    }
+    if (!is_ref && !is_compact) return fail(6, "ffv1 record: quantisation tables other than this encoder's two models");
+    for (int i = 0; i < 2; i++) if (r.bit(st[0])) return fail(7, "ffv1 record: coded initial states are not supported");
+    cfg->slicecrc = r.u(st);
+    if (cfg->slicecrc > 1) return fail(7, "ffv1 record: ec %u", cfg->slicecrc);
+    if (r.u(st) != 1) return fail(7, "ffv1 record: inter frames (intra = 0) are not supported");
+    // which of the two table sets the planes use is a per-slice field; this encoder always picks set 1 for -context 1 / compact,
+    // set 0 for -context 0 -- the caller keeps what it asked for unless the tables say "compact"
+    cfg->coder = coder;
+    if (is_compact && !is_ref) cfg->context = 2;
+    else if (cfg->context == 2) cfg->context = 1;
+    return 0;
+}

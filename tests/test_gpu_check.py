@@ -115,3 +115,19 @@ def test_corrupted_packets_never_hang_or_fault(built, name):
     assert dec.decode_device([g.data_ptr()], [len(good)], [dout[0].data_ptr()]) == 0
     assert bytes(dout[0].cpu().numpy()) == payload
     dec.close()
+
+
+@pytest.mark.parametrize("name", ["dpx_rgb16be_64x48", "dpx_rgb12packed_56x38", "dpx_rgb10be_coder2_50x38", "tiff_rgba16le_40x30"])
+def test_decode_host_from_codec_private(built, name):
+    """The caller of the --check half holds Matroska blocks and a CodecPrivate in host memory (ffv1_wrapper::Process/OutOfBand,
+    Wrapper.cpp:115-128): configuration from the record, packets up, payloads back."""
+    v = [x for x in VEC["ffv1"] if x["name"] == name][0]
+    payloads = [open(os.path.join(G, f["payload"]), "rb").read() for f in v["frames"]]
+    packets = [open(os.path.join(G, f["packet"]), "rb").read() for f in v["frames"]]
+    cfg = api.config_from_record(bytes.fromhex(v["config_record"]), v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["flags"])
+    dec = api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], cfg.num_h_slices, cfg.num_v_slices, cfg.slicecrc, cfg.context,
+                          max_batch=len(packets), flags=v["flags"], coder=cfg.coder)
+    assert dec.decode_host(packets, len(payloads[0])) == payloads
+    with pytest.raises(RuntimeError):
+        dec.decode_host([packets[0][:-9] + bytes([packets[0][-9] ^ 1]) + packets[0][-8:]], len(payloads[0]))
+    dec.close()

@@ -93,6 +93,20 @@ def test_dpx_probe_matches_what_the_reference_printed(built, v):
     assert i.data_offset + i.data_size == len(d)
 
 
+@pytest.mark.parametrize("v", json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["ffv1"], ids=lambda v: v["name"])
+def test_config_from_record(built, v):
+    """CodecPrivate of every golden stream -> slice grid, ec, coder, context model (parameters::Parse, FFV1_Parameters.cpp:23-183)."""
+    rec = bytes.fromhex(v["config_record"])
+    cfg = api.config_from_record(rec, v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["flags"])
+    assert (cfg.num_h_slices, cfg.num_v_slices, cfg.slicecrc, cfg.context, cfg.coder) == (v["num_h"], v["num_v"], 1, 1, v["coder"])
+    bad = bytearray(rec); bad[3] ^= 0x10
+    with pytest.raises(RuntimeError):
+        api.config_from_record(bytes(bad), v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["flags"])     # CRC
+    other = synth.PIX_Y8 if v["pixfmt"] != synth.PIX_Y8 else synth.PIX_RGB16_BE
+    with pytest.raises(RuntimeError):
+        api.config_from_record(rec, v["width"], v["height"], other, v["line_bytes"], 0)                         # stream does not match the files
+
+
 def test_exr_probe(built):
     v = [v for v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["ffv1"] if v["name"].startswith("exr")][0]
     d = synth.exr_file(synth.components(v["width"], v["height"], 3, 16, "film", seed=1), trailer=b"tail")
