@@ -209,6 +209,9 @@ int  rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* dec, float m
 int  rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t* first_diff, void* hip_stream);
 /* MD5 of n device buffers, one lane per buffer; out_md5 = n x 16 bytes on the host (FileWriter.cpp:596-727). */
 int  rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, void* hip_stream);
+/* The same for n host buffers, e.g. memory-mapped source files during analysis (input_base::Hash, Lib/Uncompressed/../Input_Base.cpp:54-81
+ * hashes them one at a time on one core): uploaded once, hashed side by side. */
+int  rcgpu_md5_host_batch(const uint8_t* const* bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, int device);
 
 /* ===========================================================================================
  * 4. FLAC encoder (device) -- replaces FFmpeg's flacenc; inverse of flac_wrapper (Lib/CoDec/Wrapper.cpp:131-373)

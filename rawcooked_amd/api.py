@@ -83,6 +83,7 @@ SYMBOLS = {
     "rcgpu_ffv1_decoder_create": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_destroy": (None, [_VP]),
     "rcgpu_ffv1_decoder_decode_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP), C.POINTER(C.c_uint32), _VP]),
+    "rcgpu_md5_host_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _U8P, C.c_int]),
     "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
     "rcgpu_ffv1_config_from_record": (C.c_int, [_U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
@@ -142,6 +143,17 @@ def exr_probe(data: bytes) -> ImageInfo:
     info = ImageInfo()
     _check(lib().rcgpu_exr_probe(data, len(data), C.byref(info)), "rcgpu_exr_probe")
     return info
+
+
+def md5_host_batch(bufs: list[bytes], device: int = 0) -> list[bytes]:
+    n = len(bufs)
+    keep = [C.create_string_buffer(b, len(b)) for b in bufs]
+    ptrs = (_VP * n)(*[C.cast(k, _VP) for k in keep])
+    sz = (C.c_uint64 * n)(*[len(b) for b in bufs])
+    out = C.create_string_buffer(16 * n)
+    _check(lib().rcgpu_md5_host_batch(ptrs, sz, n, out, device), "rcgpu_md5_host_batch")
+    raw = out.raw
+    return [raw[16 * i:16 * i + 16] for i in range(n)]
 
 
 def config_from_record(record: bytes, width: int, height: int, pixfmt: int, line_bytes: int, flags: int = 0, context: int = 1) -> Ffv1Config:

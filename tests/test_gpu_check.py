@@ -131,3 +131,11 @@ def test_decode_host_from_codec_private(built, name):
     with pytest.raises(RuntimeError):
         dec.decode_host([packets[0][:-9] + bytes([packets[0][-9] ^ 1]) + packets[0][-8:]], len(payloads[0]))
     dec.close()
+
+
+def test_md5_of_host_buffers(built):
+    """rcgpu_md5_host_batch == hashlib for sizes around the 64-byte block and padding boundaries (RFC 1321), incl. empty."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    bufs = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000, 65536, 1 << 20)]
+    assert api.md5_host_batch(bufs) == [hashlib.md5(b).digest() for b in bufs]
