@@ -60,6 +60,11 @@ def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int, 
     import oracle_binding as ob
     from rawcooked_amd import synth
     cores = max(1, min(os.cpu_count() or 1, 64))
+    try:                                            # ~0.7 GB of host memory per oracle thread at 4K: never let the baseline endanger the box
+        import psutil
+        cores = max(1, min(cores, int(psutil.virtual_memory().available / (1 << 30) / 1.5)))
+    except Exception:
+        cores = min(cores, 16)
     p = ob.Params(width, height, synth.PIX_RGB16_BE, 8, 8, 1, 1)
     ob.lib()
     out = [None] * cores
