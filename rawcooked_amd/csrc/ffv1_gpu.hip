@@ -983,7 +983,8 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     e->frame_payload = size_t(payload_bytes(cfg->pixfmt, cfg->width, cfg->height, cfg->line_bytes, cfg->flags));
 
     // segments: the decision stream of a slice is produced and consumed in nseg windows (double buffered) instead of
-    // being resident as a whole; auto = enough symbols per segment to keep launch overheads invisible
+    // being resident as a whole; auto = up to 32, at least 1024 symbols (16 chunks) of every slice per segment -- with 576 slices per
+    // 4K frame that is what keeps the two windows of a 256-frame batch at 2 x 17 GB instead of 2 x 70 GB
     uint32_t min_nsamp = ~0u;
     for (uint32_t sy = 0; sy < c.num_v; sy++)
         for (uint32_t sx = 0; sx < c.num_h; sx++) {
@@ -991,7 +992,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             const uint32_t h = uint32_t(uint64_t(sy + 1) * c.H / c.num_v) - uint32_t(uint64_t(sy) * c.H / c.num_v);
             min_nsamp = std::min(min_nsamp, w * h * c.planes);
         }
-    e->nseg = cfg->segments ? cfg->segments : std::max(1u, std::min(32u, min_nsamp / 8192));
+    e->nseg = cfg->segments ? cfg->segments : std::max(1u, std::min(32u, min_nsamp / 1024));
     c.nseg = e->nseg;
 
     // slice geometry (FFV1_Slice.cpp:153-156), header decisions, raw-byte buffers
