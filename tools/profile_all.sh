@@ -16,7 +16,7 @@ for mode in encode check; do
     python - "$(find gpurun_out/sq/$d -name '*.db' | head -1)" $mode <<'PY' >> gpurun_out/summary/${TAG}_sq_counters.csv
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
-keep = ("k_resolve<false>", "k_rangecode") if sys.argv[2] == "encode" else ("k_dec_slices",)
+keep = ("k_resolve<false>", "k_rangecode") if sys.argv[2] == "encode" else ("k_dec_slices<true>", "k_dec_slices<false>", "k_dec_slices")
 for k, c, n, s in db.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
     k = k.replace("(anonymous namespace)::", "").split("(")[0].strip()
     if k.startswith("void "): k = k[5:]
