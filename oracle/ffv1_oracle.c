@@ -487,6 +487,7 @@ static void write_quant_table(rc_enc* c, const int16_t* q)
 }
 size_t ffv1o_config_record(const ffv1o_params* p, uint8_t* out, size_t cap)
 {
+    if (p->level == 1) return 0;                     /* version 1 has no out-of-band record */
     quant_set qs[2];
     const uint32_t bps = ffv1o_bits_per_raw_sample(p->pixfmt);
     build_quant_sets_c(bps, qs, p->context_model == 2);
@@ -601,10 +602,26 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
 {
     uint32_t x0, y0, w, h;
     slice_rect(p, sx, sy, &x0, &y0, &w, &h);
-    rc_enc c; rce_init2(&c, out, cap, p->coder);              /* coder_type 2: the custom table drives every slice */
+    const int v1 = p->level == 1;
+    rc_enc c; rce_init2(&c, out, cap, v1 ? 1 : p->coder);    /* coder_type 2: the custom table drives every slice (v1: only after the header) */
     if (first) { uint8_t ks = 128; rce_put(&c, &ks, 1); }     /* keyframe, FFV1_Frame.cpp:148-156 */
-    /* slice header, FFV1_Slice.cpp:113-177 */
     uint8_t hs[CONTEXT_SIZE]; memset(hs, 128, sizeof hs);
+    if (v1) {
+        /* version 1: the stream header inside the frame, parameters::Parse(E, false) (FFV1_Parameters.cpp:23-104), read with the default
+         * transitions (FFV1_Slice.cpp:214, 254-255) */
+        rce_symbol(&c, hs, 1, 0);                             /* version */
+        rce_symbol(&c, hs, p->coder == 2 ? 2 : 1, 0);         /* coder_type */
+        if (p->coder == 2)
+            for (int i = 1; i < 256; i++) rce_symbol(&c, hs, (int32_t)one_state_alt[i] - (int32_t)one_state_default[i], 1);
+        rce_symbol(&c, hs, k->rgb ? 1 : 0, 0);                /* colorspace_type */
+        rce_symbol(&c, hs, (int32_t)k->bps, 0);               /* bits_per_raw_sample (version >= 1) */
+        rce_put(&c, hs, k->rgb ? 1 : 0);                      /* chroma_planes */
+        rce_symbol(&c, hs, 0, 0); rce_symbol(&c, hs, 0, 0);   /* chroma subsampling */
+        rce_put(&c, hs, k->planes == 4);                      /* alpha_plane */
+        for (int j = 0; j < 5; j++) write_quant_table(&c, k->qs[k->qidx].q[j]);      /* the one table set (-context) */
+        rc_tables(c.one_state, c.zero_state, p->coder);
+    } else {
+    /* slice header, FFV1_Slice.cpp:113-177 */
     rce_symbol(&c, hs, (int32_t)sx, 0);
     rce_symbol(&c, hs, (int32_t)sy, 0);
     rce_symbol(&c, hs, 0, 0);                                 /* slice_width - 1 (slice units) */
@@ -612,6 +629,7 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
     for (uint32_t i = 0; i < k->set_index_count; i++) rce_symbol(&c, hs, (int32_t)k->qidx, 0);
     rce_symbol(&c, hs, 3, 0);                                 /* picture_structure: progressive */
     rce_symbol(&c, hs, 0, 0); rce_symbol(&c, hs, 0, 0);       /* sar 0/0 = unknown */
+    }
 
     /* context states: one array per quant_table_set_index, all 128 (states_coded = 0), GOP_Init */
     const uint32_t nctx = k->qs[k->qidx].context_count;
@@ -650,6 +668,7 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
 
     size_t n = rce_terminate(&c, out, 1);
     g_last_decisions += c.decisions;
+    if (v1) return c.overflow ? 0 : n;                        /* version 1: the frame is the coder's bytes, nothing after them */
     /* footer, FFV1_Frame.cpp:177-196, FFV1_Slice.cpp:301-314 */
     if (c.overflow || n + 8 > cap || n > 0xFFFFFF) return 0;
     out[n] = (uint8_t)(n >> 16); out[n + 1] = (uint8_t)(n >> 8); out[n + 2] = (uint8_t)n; n += 3;

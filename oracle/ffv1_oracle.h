@@ -61,6 +61,8 @@ typedef struct {
     uint32_t flags;         /* FFV1O_FLAG_* (payload layout only; the bitstream does not know about them) */
     uint32_t coder;         /* -coder: 0/1 range coder with the default state transitions; 2 range coder with the alternate table, which
                                then travels in the configuration record as 255 deltas (FFV1_Parameters.cpp:41-55) */
+    uint32_t level;         /* -level: 0/3 = FFV1 version 3 (configuration record, slices, footers); 1 = version 1: one slice = the frame,
+                               the header travels inside every frame after the keyframe bit, no footer (FFV1_Slice.cpp:224-268) */
 } ffv1o_params;
 
 /* geometry helpers */

@@ -34,7 +34,7 @@ class AudioInfo(C.Structure):
 class Ffv1Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("pixfmt", C.c_uint32), ("line_bytes", C.c_uint32),
                 ("num_h_slices", C.c_uint32), ("num_v_slices", C.c_uint32), ("slicecrc", C.c_uint32), ("context", C.c_uint32),
-                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32), ("coder", C.c_uint32)]
+                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32), ("coder", C.c_uint32), ("level", C.c_uint32)]
 
 
 class FlacConfig(C.Structure):
@@ -158,7 +158,7 @@ def md5_host_batch(bufs: list[bytes], device: int = 0) -> list[bytes]:
 
 def config_from_record(record: bytes, width: int, height: int, pixfmt: int, line_bytes: int, flags: int = 0, context: int = 1) -> Ffv1Config:
     """Decoder configuration for a stream known only by its CodecPrivate (plus what the files' flavor says)."""
-    cfg = Ffv1Config(width, height, pixfmt, line_bytes, 0, 0, 0, context, 1, 0, 0, flags, 0)
+    cfg = Ffv1Config(width, height, pixfmt, line_bytes, 0, 0, 0, context, 1, 0, 0, flags, 0, 0)
     _check(lib().rcgpu_ffv1_config_from_record(record, len(record), C.byref(cfg)), "rcgpu_ffv1_config_from_record")
     return cfg
 
@@ -190,8 +190,8 @@ def md5(data: bytes) -> bytes:
 class Ffv1Encoder:
     """Device FFV1 encoder (rcgpu_ffv1_*).  Raises when no HIP device is visible."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0, flags=0, coder=1):
-        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments, flags, coder)
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0, flags=0, coder=1, level=3):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments, flags, coder, level)
         self.h = _VP()
         _check(lib().rcgpu_ffv1_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_create")
         self.max_packet = lib().rcgpu_ffv1_max_packet_bytes(self.h)

@@ -478,6 +478,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     *out = nullptr;
     if (cfg->pixfmt >= RCGPU_PIX_COUNT || !cfg->width || !cfg->height || !cfg->num_h_slices || !cfg->num_v_slices || !cfg->max_batch)
         return fail(2, "ffv1 decoder: bad configuration");
+    if (cfg->level == 1) return fail(2, "ffv1 decoder: FFV1 version 1 streams (-level 1) are not supported");
     const pix_desc& px = pix(cfg->pixfmt);
     const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
     if (altern && px.fields != kFieldsLow) return fail(2, "ffv1 decoder: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only");

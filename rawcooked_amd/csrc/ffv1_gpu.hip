@@ -40,6 +40,7 @@ struct enc_const {
     uint32_t W, H, line_bytes, pixfmt;
     uint32_t planes, bps, bits, rgb, gb_swap, big_endian, bytes_pp, overflow16;
     uint32_t fields, fill, vflip, altern;  // payload layout of the bit-packed DPX flavors (rc_common.h kFields*), RCGPU_FLAG_*
+    uint32_t v1;                           // FFV1 version 1: no slice footer
     uint32_t num_h, num_v, S, nctx, nsets, ec, is5;
     uint32_t samples_per_frame;            // W*H*planes
     uint32_t nseg;                         // segments a slice is cut into for the k_resolve -> k_rangecode hand-over
@@ -747,18 +748,21 @@ __global__ __launch_bounds__(256) void k_footer(const enc_const* __restrict__ C,
     const slice_geom G = geom[s];
     uint8_t* out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
     const uint32_t len = out_len[chain];
-    const uint32_t tail = C->ec ? 8 : 3;
-    if (len + tail > G.cbuf_cap || len > 0xFFFFFF) { if (tid == 0) { atomicOr(err, 2u); tot_len[chain] = 0; } return; }
+    const uint32_t tail = C->v1 ? 0 : C->ec ? 8 : 3;
+    if (len + tail > G.cbuf_cap || (!C->v1 && len > 0xFFFFFF)) { if (tid == 0) { atomicOr(err, 2u); tot_len[chain] = 0; } return; }
     if (tid == 0) {
         // carries that left k_rangecode's second stage after the bytes below them were already stored
         const uint32_t nev = err[1];
         if (nev > kMaxCarryEvents) atomicOr(err, 4u);
         for (uint32_t i = 0; i < nev && i < kMaxCarryEvents; i++)
             if (events[i].x == chain) { uint32_t p = events[i].y; while (p) { p--; const uint8_t b = uint8_t(out[p] + 1); out[p] = b; if (b) break; } }
-        out[len] = uint8_t(len >> 16); out[len + 1] = uint8_t(len >> 8); out[len + 2] = uint8_t(len);
-        if (C->ec) out[len + 3] = 0;                      // error_status
+        if (!C->v1) {
+            out[len] = uint8_t(len >> 16); out[len + 1] = uint8_t(len >> 8); out[len + 2] = uint8_t(len);
+            if (C->ec) out[len + 3] = 0;                  // error_status
+        }
     }
     __syncthreads();
+    if (C->v1) { if (tid == 0) tot_len[chain] = len; return; }      // version 1: the frame is the coder's bytes
     if (!C->ec) { if (tid == 0) tot_len[chain] = len + 3; return; }
     // Bulk: 16 KB tiles read fully coalesced -- thread t owns the 64-byte chunk t of every tile.  Its chunks are 16 KB
     // apart, so a Horner recurrence with the constant M = x^(8*16384) accumulates them:  acc = acc*M + crc(chunk);
@@ -941,6 +945,8 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (!cfg->max_batch) return fail(2, "ffv1: max_batch is 0");
     if (cfg->segments > kMaxSeg) return fail(2, "ffv1: at most %u segments", kMaxSeg);
     if (cfg->coder > 2) return fail(2, "ffv1: coder %u (0/1 default transitions, 2 transmitted table)", cfg->coder);
+    if (cfg->level != 0 && cfg->level != 1 && cfg->level != 3) return fail(2, "ffv1: level %u (1 or 3)", cfg->level);
+    if (cfg->level == 1 && (S != 1 || cfg->slicecrc)) return fail(2, "ffv1: level 1 (FFV1 version 1) means one slice and no slice CRC");
     const pix_desc& d = pix(cfg->pixfmt);
     const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
     if (altern && d.fields != kFieldsLow) return fail(2, "ffv1: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only (DPX.cpp:363-368)");
@@ -956,7 +962,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     e->cfg = *cfg;
     e->sp.bits_per_raw_sample = d.bits; e->sp.rgb = d.planes != 1; e->sp.alpha = d.planes == 4;
     e->sp.num_h_slices = cfg->num_h_slices; e->sp.num_v_slices = cfg->num_v_slices;
-    e->sp.ec = cfg->slicecrc ? 1 : 0; e->sp.context_model = cfg->context ? 1 : 0; e->sp.compact = cfg->context == 2; e->sp.coder = cfg->coder == 2 ? 2 : 1;
+    e->sp.ec = cfg->slicecrc ? 1 : 0; e->sp.context_model = cfg->context ? 1 : 0; e->sp.compact = cfg->context == 2; e->sp.coder = cfg->coder == 2 ? 2 : 1; e->sp.version = cfg->level == 1 ? 1 : 3;
     e->record = ffv1::config_record(e->sp);
 
     ffv1::quant_model qm[2];
@@ -965,7 +971,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     enc_const& c = e->hc;
     c.W = cfg->width; c.H = cfg->height; c.line_bytes = cfg->line_bytes; c.pixfmt = cfg->pixfmt;
     c.planes = d.planes; c.bps = d.bits; c.rgb = d.planes != 1; c.gb_swap = d.gb_swap; c.big_endian = d.big_endian; c.bytes_pp = d.bytes_pp;
-    c.fields = d.fields; c.fill = d.fill; c.vflip = (cfg->flags & RCGPU_FLAG_VFLIP) != 0; c.altern = altern;
+    c.fields = d.fields; c.fill = d.fill; c.vflip = (cfg->flags & RCGPU_FLAG_VFLIP) != 0; c.altern = altern; c.v1 = cfg->level == 1;
     c.bits = c.rgb ? d.bits + 1 : (d.bits <= 8 ? 8 : d.bits);                  // FFV1_Parameters.cpp:164-181
     c.overflow16 = (!c.rgb && d.bits == 16);                                   // FFV1_Parameters.cpp:160
     c.num_h = cfg->num_h_slices; c.num_v = cfg->num_v_slices; c.S = S; c.nctx = Q.context_count;
@@ -1005,14 +1011,15 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             g.w = uint32_t(uint64_t(sx + 1) * c.W / c.num_h) - g.x0; g.h = uint32_t(uint64_t(sy + 1) * c.H / c.num_v) - g.y0;
             g.sym_off = sym_off; g.nsamp = g.w * g.h * c.planes; sym_off += g.nsamp;
             g.seg_q = ((g.nsamp + e->nseg - 1) / e->nseg + 63) & ~63u;
-            const auto hd = ffv1::slice_header_decisions(e->sp, sx, sy, e->geom.empty());
+            const auto hd = e->sp.version == 1 ? ffv1::v1_frame_header_decisions(e->sp) : ffv1::slice_header_decisions(e->sp, sx, sy, e->geom.empty());
             g.hdr_off = uint32_t(hdr.size()); g.hdr_n = uint32_t(hd.size());
+            if (g.hdr_n > uint32_t(kStageEntries)) { delete e; return fail(2, "ffv1: %u header decisions do not fit k_resolve's stage", g.hdr_n); }
             for (uint16_t d16 : hd) hdr.push_back((d16 & 0x100) ? uint16_t(d16 & 0xFF) : uint16_t(0xFF00u | (256 - (d16 & 0xFF))));   // (state, bit) -> (t, c)
             // room for 1.5x the raw payload of the slice (incompressible 16-bit noise codes to ~1.1x once the contexts have
             // adapted) + what ~10^4 contexts x 32 states can cost before they have (tiny slices reach 1.7x), + header/footer
             const size_t raw15 = size_t(g.w) * g.h * (d.bytes_pp ? d.bytes_pp : d.planes * 2u) * 3 / 2;
             size_t cap = (raw15 + std::min<size_t>(raw15, 256u << 10) + 4096 + 15) & ~size_t(15);
-            if (cap > 0xFFFFFF + 64) cap = 0xFFFFFF + 64;          // slice size field is 24 bit
+            if (cap > 0xFFFFFF + 64 && e->sp.version != 1) cap = 0xFFFFFF + 64;          // slice size field is 24 bit (version 1 has none)
             cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here
             g.cbuf_off_lo = uint32_t(cb); g.cbuf_off_hi = uint32_t(uint64_t(cb) >> 32); g.cbuf_cap = uint32_t(cap);
             cb += cap;

@@ -132,6 +132,7 @@ void write_quant_table(host_rc& c, const int16_t* q)
 
 std::vector<uint8_t> config_record(const stream_params& p)
 {
+    if (p.version == 1) return {};                  // version 1: no out-of-band record
     quant_model m[2];
     build_quant_models(p.bits_per_raw_sample, m, p.compact);
     host_rc c;
@@ -157,6 +158,27 @@ std::vector<uint8_t> config_record(const stream_params& p)
     const uint32_t crc = rcgpu_crc32_ffv1(c.out.data(), c.out.size());
     for (int s = 24; s >= 0; s -= 8) c.out.push_back(uint8_t(crc >> s));   // parity: CRC(record || crc) == 0 (FFV1_Frame.cpp:116)
     return c.out;
+}
+
+std::vector<uint16_t> v1_frame_header_decisions(const stream_params& p)
+{
+    quant_model m[2];
+    build_quant_models(p.bits_per_raw_sample, m, p.compact);
+    std::vector<uint16_t> d;
+    host_rc c(1); c.trace = &d;                     // the header is read with the default transitions whatever coder_type says
+    { uint8_t ks = 128; c.put(ks, 1); }             // keyframe
+    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
+    c.symbol(st, 1, false);                         // version
+    c.symbol(st, p.coder == 2 ? 2 : 1, false);      // coder_type
+    if (p.coder == 2)
+        for (int i = 1; i < 256; i++) c.symbol(st, int32_t(kOneStateAlt[i]) - int32_t(kOneState[i]), true);
+    c.symbol(st, p.rgb ? 1 : 0, false);             // colorspace_type
+    c.symbol(st, int32_t(p.bits_per_raw_sample), false);
+    c.put(st[0], p.rgb ? 1 : 0);                    // chroma_planes
+    c.symbol(st, 0, false); c.symbol(st, 0, false); // chroma subsampling
+    c.put(st[0], p.alpha ? 1 : 0);                  // alpha_plane
+    for (int j = 0; j < 5; j++) write_quant_table(c, m[p.context_model].q[j]);     // the one table set
+    return d;
 }
 
 std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx, uint32_t sy, bool first_slice)

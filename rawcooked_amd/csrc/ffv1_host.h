@@ -36,6 +36,7 @@ struct stream_params {
     uint32_t context_model;       // quant table set index used by every plane (-context)
     bool     compact = false;     // table set 1 is the compact 5-input model
     uint32_t coder = 1;           // 1: default state transitions; 2: kOneStateAlt, carried in the record
+    uint32_t version = 3;         // 3 (-level 3) or 1 (-level 1: one slice, header inside every frame, no record, no footer)
 };
 
 // Configuration record incl. CRC (what parameters::Parse reads, FFV1_Parameters.cpp:23-183).
@@ -44,5 +45,8 @@ std::vector<uint8_t> config_record(const stream_params& p);
 // (state | bit << 8) decisions of [keyframe bit ||] slice header (FFV1_Frame.cpp:148-156, FFV1_Slice.cpp:113-177)
 // for slice (sx, sy); the adaptive states involved are private to the header, so the host can resolve them.
 std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx, uint32_t sy, bool first_slice);
+// version 1: (state | bit << 8) decisions of keyframe bit || stream header (parameters::Parse(E, false), FFV1_Parameters.cpp:23-104,
+// read with the default transitions, FFV1_Slice.cpp:214) -- there is no slice header.
+std::vector<uint16_t> v1_frame_header_decisions(const stream_params& p);
 
 }}  // namespace rc::ffv1

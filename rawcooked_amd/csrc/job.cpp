@@ -156,7 +156,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     if (const char* ca = opt.get("c:a")) if (strcmp(ca, "flac") != 0) return bail(fail(2, "audio codec %s is not supported by rcgpu (only flac)", ca));
     const long coder = opt.num("coder", 1);
     if (coder != 1 && coder != 2) return bail(fail(2, "-coder %ld is not supported by rcgpu (1: range coder, 2: range coder with a transmitted state table)", coder));
-    if (opt.num("level", 3) != 3) return bail(fail(2, "-level %ld is not supported by rcgpu (only 3)", opt.num("level", 3)));
+    const long level = opt.num("level", 3);
+    if (level != 1 && level != 3) return bail(fail(2, "-level %ld is not supported by rcgpu (3, or 1 with -slices 1)", level));
     if (opt.num("g", 1) != 1) return bail(fail(2, "-g %ld is not supported by rcgpu (intra only)", opt.num("g", 1)));
     if (job->framemd5_path) return bail(fail(2, "-f framemd5 is not supported by rcgpu"));
     // the only filter the reference ever asks for is `-vf vflip`, for DPX stored bottom-up (CLI/Main.cpp:207-211)
@@ -269,7 +270,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             F = uint32_t(std::min<uint64_t>(F, (v.files.size() + nworkers - 1) / nworkers));
             rcgpu_ffv1_config c{}; c.width = v.info.width; c.height = v.info.height; c.pixfmt = v.info.pixfmt; c.line_bytes = v.info.line_bytes;
             c.flags = (v.info.flags & RCGPU_FLAG_ALTERN) | (v.vflip ? RCGPU_FLAG_VFLIP : 0);
-            c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.max_batch = F; c.coder = uint32_t(coder);
+            c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.max_batch = F; c.coder = uint32_t(coder); c.level = uint32_t(level);
+            if (level == 1) { if (v.num_h * v.num_v != 1) return bail(fail(2, "-level 1 (FFV1 version 1) has no slices: use -slices 1")); c.slicecrc = 0; }
             for (int wk = 0; wk < nworkers; wk++) {               // one encoder per worker: worker wk drives device wk % ndev
                 c.device = dev0 + wk % ndev;
                 rcgpu_ffv1* e = nullptr;

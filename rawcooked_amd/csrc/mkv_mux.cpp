@@ -179,7 +179,7 @@ extern "C" int rcgpu_mkv_begin(rcgpu_mkv* m)
             e.str(0x22B59C, "und");
             e.str(0x86, t.video ? "V_FFV1" : "A_FLAC");
             const size_t cp_rel_before = e.b.size();
-            e.bin(0x63A2, t.codec_private.data(), t.codec_private.size());
+            if (!t.codec_private.empty()) e.bin(0x63A2, t.codec_private.data(), t.codec_private.size());      // FFV1 version 1 has none
             const size_t cp_payload_rel = e.b.size() - t.codec_private.size();
             (void)cp_rel_before;
             if (t.video) {

@@ -9,7 +9,7 @@ _lib = None
 
 
 class Params(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "pixfmt", "num_h_slices", "num_v_slices", "ec", "context_model", "flags", "coder")]
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "pixfmt", "num_h_slices", "num_v_slices", "ec", "context_model", "flags", "coder", "level")]
 
 
 def lib():

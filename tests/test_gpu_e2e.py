@@ -250,3 +250,16 @@ def test_coder_2_carries_its_state_table(built, refbin, tmp_path):
         r = run([refbin, "--check", "pkg.mkv"], work)
         assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
     assert sizes["2"] < sizes["1"]
+
+
+def test_slices_1_means_ffv1_version_1(built, refbin, tmp_path):
+    """`rawcooked -slices 1` turns into `-level 1 -slices 1` (Global.cpp:961-968): FFV1 version 1 frames, no CodecPrivate."""
+    work = str(tmp_path)
+    make_package(work, 96, 54, synth.PIX_RGB16_BE, 3, "film", audio=(2, 16, 48000, 6000))
+    r = run([refbin, "-slices", "1", "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0 and "-level 1 " in r.stdout and "-slices 1 " in r.stdout, r.stdout + r.stderr
+    argv = shlex.split(r.stdout.strip())
+    r = run([SHIM] + argv[1:], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = run([refbin, "--check", "pkg.mkv"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr

@@ -239,3 +239,24 @@ def test_tiny_pictures_and_extreme_values(built, w, h, slices, pixfmt):
         assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
         assert bytes(dout[f].cpu().numpy()) == payloads[f], f"frame {f}"
     enc.close(); dec.close()
+
+
+@pytest.mark.parametrize("pixfmt,coder,ctx", [(synth.PIX_RGB16_BE, 1, 1), (synth.PIX_RGB10_FILLEDA_BE, 2, 1), (synth.PIX_Y16_BE, 1, 0), (synth.PIX_RGBA8, 2, 1)])
+def test_level_1_single_slice_frames(built, pixfmt, coder, ctx):
+    """-level 1 (what the reference asks for with -slices 1, Global.cpp:961-968): FFV1 version 1 -- the stream header inside every
+    frame, one slice, no footer, no configuration record.  Same bytes as the oracle, whose version-1 frames the real reference decodes."""
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    w, h = 72, 40
+    payloads = []
+    for i in range(3):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, ["film", "noise", "flat"][i], seed=50 + i), pixfmt, True)
+        payloads.append(pl)
+    p = ob.Params(w, h, pixfmt, 1, 1, 0, ctx, 0, coder, 1)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 1, 1, 0, ctx, max_batch=3, coder=coder, level=1)
+    assert enc.config_record() == b""
+    packets = enc.encode_host(payloads)
+    for f in range(3):
+        assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
+    enc.close()
+    with pytest.raises(RuntimeError):
+        api.Ffv1Encoder(w, h, pixfmt, line_bytes, 2, 2, 0, ctx, level=1)

@@ -222,7 +222,7 @@ def test_argv_front_end_rejects_what_it_cannot_do(built, tmp_path):
     assert r.returncode == 0 and r.stdout.startswith("rcgpu version")                       # Main.cpp:751-774 parses "<name> version <x>"
     p = tmp_path / "a.dpx"
     p.write_bytes(synth.dpx_file(synth.components(16, 16, 3, 16), synth.PIX_RGB16_BE))
-    for extra in (["-coder", "0"], ["-level", "1"], ["-c:v", "ffv1_vulkan"], ["-g", "2"]):
+    for extra in (["-coder", "0"], ["-level", "0"], ["-level", "1", "-slices", "4"], ["-c:v", "ffv1_vulkan"], ["-g", "2"]):
         r = subprocess.run([shim, "-i", str(p), "-c:v", "ffv1", "-coder", "1", "-level", "3", "-g", "1"] + extra + ["-f", "matroska", str(tmp_path / "o.mkv")],
                            capture_output=True, text=True)
         assert r.returncode != 0 and "Error: " in r.stderr                                  # helpers.sh:81 greps for "Error:"
