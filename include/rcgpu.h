@@ -252,6 +252,8 @@ int  rcgpu_mkv_add_video(rcgpu_mkv* mux, const uint8_t* codec_private, size_t cp
 int  rcgpu_mkv_add_audio(rcgpu_mkv* mux, const uint8_t* codec_private, size_t cp_size, uint32_t channels,
                          uint32_t sample_rate, uint32_t bits_per_sample);
 int  rcgpu_mkv_add_attachment(rcgpu_mkv* mux, const char* name, const char* mime, const uint8_t* data, size_t size);
+/* A track-level SimpleTag (what FFmpeg writes for `-metadata:s:N name=value`; the reference adds one to EXR packages). */
+int  rcgpu_mkv_add_tag(rcgpu_mkv* mux, int track, const char* name, const char* value);
 /* Writes EBML header, Segment, SeekHead, Info, Tracks, Attachments.  Call once after all add_* calls. */
 int  rcgpu_mkv_begin(rcgpu_mkv* mux);
 /* One SimpleBlock (one FFV1 frame or >= 1 whole FLAC frames); pts in nanoseconds, non-decreasing per track. */

@@ -97,6 +97,7 @@ SYMBOLS = {
     "rcgpu_mkv_add_video": (C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rcgpu_mkv_add_audio": (C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rcgpu_mkv_add_attachment": (C.c_int, [_VP, C.c_char_p, C.c_char_p, _VP, _SZ]),
+    "rcgpu_mkv_add_tag": (C.c_int, [_VP, C.c_int, C.c_char_p, C.c_char_p]),
     "rcgpu_mkv_begin": (C.c_int, [_VP]),
     "rcgpu_mkv_write_block": (C.c_int, [_VP, C.c_int, C.c_uint64, _VP, _SZ, C.c_int]),
     "rcgpu_mkv_update_codec_private": (C.c_int, [_VP, C.c_int, _VP, _SZ]),
@@ -352,6 +353,9 @@ class MkvMuxer:
 
     def add_attachment(self, name: str, data: bytes, mime: str = "application/octet-stream"):
         _check(lib().rcgpu_mkv_add_attachment(self.h, name.encode(), mime.encode(), data, len(data)), "rcgpu_mkv_add_attachment")
+
+    def add_tag(self, track, name, value):
+        _check(lib().rcgpu_mkv_add_tag(self.h, track, name.encode(), value.encode()), "rcgpu_mkv_add_tag")
 
     def begin(self):
         _check(lib().rcgpu_mkv_begin(self.h), "rcgpu_mkv_begin")

@@ -282,6 +282,11 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             const size_t n = rcgpu_ffv1_config_record(encoders[v.enc_first].get(), rec, sizeof rec);
             v.track = rcgpu_mkv_add_video(mux, rec, n, v.info.width, v.info.height, v.fps.num, v.fps.den);
             if (v.track < 0) return bail(8);
+            if (const char* md = opt.get("metadata:s:v")) {
+                const std::string kv = md; const size_t eq = kv.find('=');
+                if (eq != std::string::npos && eq > 0)
+                    if (int r = rcgpu_mkv_add_tag(mux, v.track, kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str())) return bail(r);
+            }
         } else {
             audio_plan& a = audios[o.second];
             a.track = rcgpu_mkv_add_audio(mux, a.codec_private.data(), a.codec_private.size(), a.info.channels, a.info.sample_rate, a.info.bits_per_sample);
@@ -430,6 +435,7 @@ extern "C" int rcgpu_main_ffmpeg_argv(int argc, const char* const* argv)
         if (a.compare(0, 12, "-metadata:s:") == 0 && need(i)) {
             const std::string kv = argv[++i];
             if (kv.compare(0, 9, "filename=") == 0 && !attach_files.empty()) attach_files.back().second = kv.substr(9);
+            else if (a == "-metadata:s:v") out_opts["metadata:s:v"] = kv;          // e.g. the reference's WARNING=... on EXR packages
             continue;
         }
         if (a == "-map" && need(i)) { i++; continue; }

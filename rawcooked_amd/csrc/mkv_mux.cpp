@@ -48,9 +48,11 @@ struct track {
     uint32_t width = 0, height = 0, fps_num = 0, fps_den = 0;
     uint32_t channels = 0, sample_rate = 0, bits = 0;
     uint64_t cp_file_pos = 0;      // absolute file offset of the CodecPrivate payload
+    uint64_t uid = 0;              // TrackUID, referenced by Tags
     uint64_t last_pts_ms = 0, end_ms = 0;
 };
 struct attach { std::string name, mime; std::vector<uint8_t> data; };
+struct tag { int track; std::string name, value; };
 struct cue { uint64_t time_ms; int track; uint64_t cluster_pos; };
 
 }  // namespace
@@ -60,10 +62,11 @@ struct rcgpu_mkv {
     std::string path;
     std::vector<track> tracks;
     std::vector<attach> attachments;
+    std::vector<tag> tags;
     std::vector<cue> cues;
     uint64_t pos = 0;                 // bytes written so far
     uint64_t segment_data = 0;        // file offset of the first byte after the Segment size field
-    uint64_t seekhead_pos = 0, info_pos = 0, tracks_pos = 0, attachments_pos = 0, duration_pos = 0;
+    uint64_t seekhead_pos = 0, info_pos = 0, tracks_pos = 0, tags_pos = 0, attachments_pos = 0, duration_pos = 0;
     bool begun = false;
     // open cluster
     ebuf cluster; uint64_t cluster_ts = 0; bool cluster_open = false; uint64_t cluster_file_pos = 0;
@@ -95,7 +98,7 @@ struct rcgpu_mkv {
     }
 };
 
-static const uint64_t kSeekHeadReserve = 160;     // room for 5 Seek entries, padded with Void
+static const uint64_t kSeekHeadReserve = 192;     // room for 6 Seek entries (Info, Tracks, Tags, Attachments, Cues + one spare), padded with Void
 
 extern "C" int rcgpu_mkv_open(const char* path, int overwrite, rcgpu_mkv** out)
 {
@@ -139,6 +142,14 @@ extern "C" int rcgpu_mkv_add_attachment(rcgpu_mkv* m, const char* name, const ch
     return 0;
 }
 
+extern "C" int rcgpu_mkv_add_tag(rcgpu_mkv* m, int trk, const char* name, const char* value)
+{
+    if (!m || m->begun || !name || !value) return fail(1, "mkv: add_tag after begin or null argument");
+    if (trk < 1 || size_t(trk) > m->tracks.size()) return fail(1, "mkv: bad track number %d", trk);
+    m->tags.push_back({ trk, name, value });
+    return 0;
+}
+
 extern "C" int rcgpu_mkv_begin(rcgpu_mkv* m)
 {
     clear_error();
@@ -174,7 +185,8 @@ extern "C" int rcgpu_mkv_begin(rcgpu_mkv* m)
         for (size_t k = 0; k < m->tracks.size(); k++) {
             track& t = m->tracks[k];
             ebuf e;
-            e.uint(0xD7, k + 1); e.uint(0x73C5, m->next_uid() & 0x7FFFFFFFFFFFFFFFull);
+            t.uid = m->next_uid() & 0x7FFFFFFFFFFFFFFFull;
+            e.uint(0xD7, k + 1); e.uint(0x73C5, t.uid);
             e.uint(0x83, t.video ? 1 : 2); e.uint(0x9C, 0);
             e.str(0x22B59C, "und");
             e.str(0x86, t.video ? "V_FFV1" : "A_FLAC");
@@ -198,6 +210,17 @@ extern "C" int rcgpu_mkv_begin(rcgpu_mkv* m)
         ebuf tmp; tmp.id(0x1654AE6B); tmp.size(ts.b.size());
         for (track& t : m->tracks) t.cp_file_pos += f.b.size() + tmp.b.size();
         f.master(0x1654AE6B, ts);
+    }
+    if (!m->tags.empty()) {   // Tags: what FFmpeg writes for -metadata:s:N key=value (e.g. the reference's EXR warning, Main.cpp / Output.cpp:273-278)
+        m->tags_pos = f.b.size();
+        ebuf all;
+        for (const tag& g : m->tags) {
+            ebuf targets; targets.uint(0x68CA, 30); targets.uint(0x63C5, m->tracks[size_t(g.track) - 1].uid);      // TargetTypeValue 30 = track
+            ebuf simple; simple.str(0x45A3, g.name); simple.str(0x447A, "und"); simple.str(0x4487, g.value);
+            ebuf one; one.master(0x63C0, targets); one.master(0x67C8, simple);
+            all.master(0x7373, one);
+        }
+        f.master(0x1254C367, all);
     }
     if (int r = m->put(f.b.data(), f.b.size())) return r;
     if (!m->attachments.empty()) {   // Attachments (before any Cluster, Matroska.cpp:863-873); streamed to keep big sidecars out of one buffer
@@ -302,6 +325,7 @@ extern "C" int rcgpu_mkv_close(rcgpu_mkv* m)
                 ebuf e; ebuf idb; idb.id(id); e.bin(0x53AB, idb.b.data(), idb.b.size()); e.uint_n(0x53AC, at - m->segment_data, 8); sh.master(0x4DBB, e);
             };
             seek(0x1549A966, m->info_pos); seek(0x1654AE6B, m->tracks_pos);
+            if (m->tags_pos) seek(0x1254C367, m->tags_pos);
             if (m->attachments_pos) seek(0x1941A469, m->attachments_pos);
             if (cues_pos) seek(0x1C53BB6B, cues_pos);
             ebuf top; top.master(0x114D9B74, sh);

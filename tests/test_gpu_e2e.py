@@ -89,6 +89,8 @@ def test_reference_accepts_gpu_mkv(built, refbin, tmp_path, case):
     r = run([SHIM] + argv[1:], work)
     assert r.returncode == 0, r.stdout + r.stderr
     assert os.path.exists(os.path.join(work, "pkg.mkv"))
+    if case.get("exr"):                                                                     # Output.cpp:123 -metadata:s:v WARNING=... becomes a track tag
+        assert "-metadata:s:v" in argv and b"Pixel content is IEEE 754 floating-point format" in open(os.path.join(work, "pkg.mkv"), "rb").read(4096)
     # 3. the reference decodes the MKV and compares every rebuilt file with the hashes it stored
     r = run([refbin, "--check", "pkg.mkv"], work)
     assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr

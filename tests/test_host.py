@@ -182,6 +182,9 @@ def test_muxer_layout(built, tmp_path):
     ta = mux.add_audio(b"fLaC" + bytes(38), 6, 48000, 24)
     mux.add_attachment("side.txt", b"hello")
     mux.add_attachment("RAWcooked reversibility data", b"\x1a\x45\xdf\xa3rest")
+    mux.add_tag(tv, "WARNING", "Pixel content is IEEE 754 floating-point format")          # Output.cpp:123
+    with pytest.raises(api.RcgpuError):
+        mux.add_tag(7, "A", "B")
     mux.begin()
     big = os.urandom(3 << 20)
     for i in range(3):
@@ -195,9 +198,19 @@ def test_muxer_layout(built, tmp_path):
     ids = [e[0] for e in seg]
     assert ids.index(0x1654AE6B) < ids.index(0x1941A469) < ids.index(0x1F43B675)           # Tracks < Attachments < first Cluster
     assert ids[-1] == 0x1C53BB6B                                                           # Cues last
+    tag = _ebml(buf, *_ebml(buf, *[e for e in seg if e[0] == 0x1254C367][0][1:])[0][1:])
+    targets = {e[0]: buf[e[1]:e[2]] for e in _ebml(buf, *[e for e in tag if e[0] == 0x63C0][0][1:])}
+    simple = {e[0]: buf[e[1]:e[2]] for e in _ebml(buf, *[e for e in tag if e[0] == 0x67C8][0][1:])}
+    assert simple[0x45A3] == b"WARNING" and simple[0x4487].startswith(b"Pixel content is IEEE 754")
+    seek = [{x[0]: buf[x[1]:x[2]] for x in _ebml(buf, s_[1], s_[2])} for s_ in _ebml(buf, *[e for e in seg if e[0] == 0x114D9B74][0][1:])]
+    for sk in seek:                                                                        # every SeekHead entry points at the element it names
+        at = top[1][1] + int.from_bytes(sk[0x53AC], "big")
+        assert buf[at:at + len(sk[0x53AB])] == sk[0x53AB]
+    assert {sk[0x53AB] for sk in seek} >= {bytes.fromhex("1254C367"), bytes.fromhex("1654AE6B"), bytes.fromhex("1C53BB6B")}
     tracks = _ebml(buf, *[e for e in seg if e[0] == 0x1654AE6B][0][1:])
     assert len(tracks) == 2
     ent = {e[0]: buf[e[1]:e[2]] for e in _ebml(buf, tracks[0][1], tracks[0][2])}
+    assert targets[0x63C5] == ent[0x73C5]                                                  # the tag targets the video track's UID
     assert ent[0x86] == b"V_FFV1" and ent[0x63A2] == b"\x01\x02\x03" and ent[0xD7] == b"\x01"
     vid = {e[0]: buf[e[1]:e[2]] for e in _ebml(buf, *[e for e in _ebml(buf, tracks[0][1], tracks[0][2]) if e[0] == 0xE0][0][1:])}
     assert vid[0xB0] == b"\x10\x00" and vid[0xBA] == b"\x08\x70"                           # 2-byte uints
