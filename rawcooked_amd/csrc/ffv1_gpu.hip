@@ -20,6 +20,7 @@
 // The only serial recurrences are per-context state updates (K3) and low/range (K4); DESIGN.md explains why the
 // second one is mapped lane-per-slice rather than wave-per-slice.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <algorithm>
 #include <cstdio>
 #include <mutex>
@@ -63,6 +64,7 @@ constexpr int kPieceBytes = 64;
 constexpr int kGroupPieceBytes = 64 * kPieceBytes; // one piece of each of the 64 chains of a group
 constexpr int kMaxDecPerSample = 35;              // 2*16+3 for 17-bit residuals
 constexpr int kStageEntries = kPieceEntries + 64 * kMaxDecPerSample + 32;   // carry + one chunk (+ slack)
+constexpr int kResolveFixedLds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + 2 * 256;   // k_resolve: stage | slots | transitions | powers
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
@@ -240,6 +242,38 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int)
     return uint32_t(x);
 }
 
+// OR over the 64 lanes, same DPP ladder; the result is uniform (read from lane 63).
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    int x = int(v);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return uint32_t(__builtin_amdgcn_readlane(x, 63));
+}
+
+// Which of a context's 32 states does a residual touch exactly once?  Row r = 0 for a zero residual, else exponent + 1; the row
+// holds byte masks over the state registers S[0], S[1], S[2], S[5], S[6], S[7] (state k = byte k & 3 of S[k >> 2]): state 0 always,
+// 1 + t for exponent slots t <= e (t < 9), 22 + t for mantissa bits t < e (t < 9).  States 10 and 31 (repeated) and the sign
+// states are applied separately.
+struct act_masks { uint32_t m[18][8]; };
+constexpr act_masks make_act_masks()
+{
+    act_masks t{};
+    for (int r = 0; r < 18; r++)
+        for (int k = 0; k < 32; k++) {
+            const int e = r - 1;
+            const bool act = k == 0 || (r > 0 && ((k >= 1 && k <= 9 && k - 1 <= e) || (k >= 22 && k <= 30 && k - 22 < e)));
+            const int j = k >> 2, col = j < 3 ? j : j - 2;                 // S[5..7] -> columns 3..5
+            if (act) t.m[r][col] |= 0xFFu << (8 * (k & 3));
+        }
+    return t;
+}
+__device__ const act_masks kActMasks = make_act_masks();
+
 // A k_resolve workgroup is ONE wavefront: its LDS operations execute in issue order, so phases that hand data from lane to lane
 // through LDS need no barrier and, above all, no s_waitcnt vmcnt(0) -- which __syncthreads() implies and which would put the HBM
 // latency of every prefetch and store on the critical path.  Only the compiler must keep the order.
@@ -253,12 +287,15 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
 {
     // One launch handles segment `seg` of every slice.  What must survive between launches -- the < 32 decisions that
     // did not fill a piece and the first-touch bitmap -- lives in `resume` (per chain: count, 32 entries, bitmap).
+    // The arrays of fixed size are static LDS: their addresses are compile-time constants that fold into the instructions'
+    // offset fields.  What scales with the number of contexts follows as dynamic LDS.
+    __shared__ __attribute__((aligned(16))) uint8_t fixed[kResolveFixedLds];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t* stage = reinterpret_cast<uint16_t*>(smem);                           // kStageEntries u16
-    uint8_t*  slot = smem + ((kStageEntries * 2 + 15) & ~15);                      // 64 x 32
-    uint8_t*  trans = slot + 64 * 32;                                               // [bit][state]
+    uint16_t* stage = reinterpret_cast<uint16_t*>(fixed);                          // kStageEntries u16
+    uint8_t*  slot = fixed + ((kStageEntries * 2 + 15) & ~15);                     // 64 x 32
+    uint8_t*  trans = slot + 64 * 32;                                               // [256 +- state], see below
     uint8_t*  pw = trans + 512;                                                     // [2][256]: one_state applied 4 and 16 times
-    uint32_t* touched = reinterpret_cast<uint32_t*>(pw + 2 * 256);                  // nkeys bits
+    uint32_t* touched = reinterpret_cast<uint32_t*>(smem);                          // nkeys bits
     uint8_t*  Hk = reinterpret_cast<uint8_t*>(touched + ((nkeys + 31) / 32 + 3) / 4 * 4);   // nkeys u8
     // LDS_STATES (compact context model): every context's 32 states live here for the whole slice -- no HBM traffic per sample
     uint8_t*  lstates = Hk + ((nkeys + 15) & ~15u);                                          // nkeys x 32
@@ -273,7 +310,9 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
     // interleaved decision stream: piece k of this chain lives at group base + (k*64 + lane_of_chain)*64
     uint32_t* out32 = reinterpret_cast<uint32_t*>(stream + group_off[chain >> 6]) + (chain & 63) * 16;
 
-    for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; }
+    // transition table indexed by the signed decision: trans[256 + s] = next state after coding bit 1 in state s,
+    // trans[256 - s] = after coding bit 0 (states are 1..255)
+    for (int i = lane; i < 256; i += 64) { trans[(256 - i) & 255] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; }
     // powers of the "coded a 1" transition, for runs of zero residuals in one context (see below)
     WAVE_SYNC();
     for (int i = lane; i < 256; i += 64) { const uint8_t* o = trans + 256; pw[i] = o[o[o[o[i]]]]; }
@@ -345,6 +384,14 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
         const uint32_t a = uint32_t(d < 0 ? -d : d);
         const int e = a ? 31 - __clz(int(a)) : 0;
         const uint32_t ndec = valid ? (a ? uint32_t(2 * e + 3) : 1u) : 0u;
+        const uint32_t amax = wave_or(valid ? a : 0u);
+        const int emax = amax ? 31 - __clz(int(amax)) : -1;           // uniform: no lane of this chunk has a larger exponent
+        int sg_e[9], sg_m[9];                                          // per slot: +1 codes a 1, -1 codes a 0
+#pragma unroll
+        for (int t = 0; t < 9; t++) { sg_e[t] = t < e ? 1 : -1; sg_m[t] = (a >> t) & 1u ? 1 : -1; }
+        const uint4* mrow = reinterpret_cast<const uint4*>(kActMasks.m[a ? e + 1 : 0]);
+        const uint4 Ma = mrow[0];                                      // S[0], S[1], S[2], S[5]
+        const uint2 Mb = *reinterpret_cast<const uint2*>(mrow + 1);    // S[6], S[7]
         const uint32_t incl = wave_incl_scan(ndec, lane);
         const uint32_t excl = incl - ndec;
         const uint32_t total = __shfl(incl, 63);
@@ -437,74 +484,85 @@ __global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C,
                 // except state 10 (exponent bits 9 and up) and state 31 (mantissa bits 9 and up): so the transition look-ups of
                 // all other decisions are independent.  Phase 1 issues them back to back (nothing waits on LDS), phase 2 applies
                 // them; only the two short chains are walked with dependent LDS round trips.
-                uint32_t S[8];
-                { const uint4 v0 = reinterpret_cast<const uint4*>(sl)[0], v1 = reinterpret_cast<const uint4*>(sl)[1];
-                  S[0] = v0.x; S[1] = v0.y; S[2] = v0.z; S[3] = v0.w; S[4] = v1.x; S[5] = v1.y; S[6] = v1.z; S[7] = v1.w; }
+                // Slots are grouped by the register their states live in, and the body exists once per LEVEL = how many groups
+                // some lane of the chunk reaches (emax is uniform): 0 only the zero flag, 1 + S[0] and S[5], 2 + S[1] and S[6],
+                // 3 + S[2], S[7] and the chains.
+                auto binarise = [&](auto level) {
+                    constexpr int L = decltype(level)::value;
+                    uint32_t S[8];
+                    { const uint4 v0 = reinterpret_cast<const uint4*>(sl)[0], v1 = reinterpret_cast<const uint4*>(sl)[1];
+                      S[0] = v0.x; S[1] = v0.y; S[2] = v0.z; S[3] = v0.w; S[4] = v1.x; S[5] = v1.y; S[6] = v1.z; S[7] = v1.w; }
 #define ST_GET(k) ((S[(k) >> 2] >> (8 * ((k) & 3))) & 0xFFu)
 #define ST_PUT_IF(c, k, v) (S[(k) >> 2] = (c) ? ((S[(k) >> 2] & ~(0xFFu << (8 * ((k) & 3)))) | ((v) << (8 * ((k) & 3)))) : S[(k) >> 2])
-#define ENTRY(st, b) uint16_t((b) ? (st) : (0xFF00u | (256 - (st))))
-#define NEXT(st, b) uint32_t(trans[((b) << 8) + (st)])
-                const bool nz = a != 0;
-                const uint32_t neg = d < 0 ? 1u : 0u;
-                const int ks = 11 + (e < 10 ? e : 10);                  // sign state: the only index that depends on the symbol
-                // ---- phase 1: read states, emit decisions, issue the look-ups
-                const uint32_t st_z = ST_GET(0), b_z = nz ? 0u : 1u;
-                const uint32_t nx_z = NEXT(st_z, b_z);
-                op[0] = ENTRY(st_z, b_z);
-                const uint32_t st_s = nz ? uint32_t(sl[ks]) : 128u;     // sign states 11..21 are touched by nothing else: straight from LDS
-                uint32_t nxe[9], nxm[9];
-#pragma unroll
-                for (int t = 0; t < 9; t++) {                           // exponent in unary: ones for t < e, the zero at t == e
-                    nxe[t] = 0;
-                    if (__ballot(nz && t <= e)) {
-                        const uint32_t st = ST_GET(1 + t), b = t < e ? 1u : 0u;
-                        nxe[t] = NEXT(st, b);
-                        if (nz && t <= e) op[1 + t] = ENTRY(st, b);
+#define NEXT(en) uint32_t(trans[256 + (en)])                            /* en = +state for bit 1, -state for bit 0 */
+#define EXP_SLOT(t) { const int en = __mul24(int(ST_GET(1 + (t))), sg_e[t]); nxe[t] = NEXT(en); if (nz && (t) <= e) op[1 + (t)] = uint16_t(en); }
+#define MAN_SLOT(t) { const int en = __mul24(int(ST_GET(22 + (t))), sg_m[t]); nxm[t] = NEXT(en); if (nz && (t) < e) op[2 * e + 1 - (t)] = uint16_t(en); }
+#define MERGE(x, n, m) x = ((n) & (m)) | ((x) & ~(m))
+                    const bool nz = a != 0;
+                    const int ks = 11 + (e < 10 ? e : 10);              // sign state: the only index that depends on the symbol
+                    // ---- phase 1: read states, emit decisions, issue the look-ups.  A decision is (state, bit); its stream
+                    // entry (t, c) = bit ? (state, 0) : (256 - state, 255) is +-state as a 16-bit integer, and the same signed
+                    // number indexes the transition table.
+                    const int en_z = nz ? -int(ST_GET(0)) : int(ST_GET(0));
+                    const uint32_t nx_z = NEXT(en_z);
+                    op[0] = uint16_t(en_z);
+                    uint32_t nxe[9] = {}, nxm[9] = {}, nx_s = 0;
+                    if constexpr (L >= 1) {
+                        const int st_s = nz ? int(sl[ks]) : 128;       // sign states 11..21 are touched by nothing else: straight from LDS
+                        EXP_SLOT(0) EXP_SLOT(1) EXP_SLOT(2) MAN_SLOT(0) MAN_SLOT(1)
+                        if constexpr (L >= 2) { EXP_SLOT(3) EXP_SLOT(4) EXP_SLOT(5) EXP_SLOT(6) MAN_SLOT(2) MAN_SLOT(3) MAN_SLOT(4) MAN_SLOT(5) }
+                        if constexpr (L >= 3) { EXP_SLOT(7) EXP_SLOT(8) MAN_SLOT(6) MAN_SLOT(7) MAN_SLOT(8) }
+                        const int en_s = d < 0 ? st_s : -st_s;
+                        nx_s = NEXT(en_s);
+                        if (nz) op[2 * e + 2] = uint16_t(en_s);
                     }
-                }
-#pragma unroll
-                for (int t = 0; t < 9; t++) {                           // mantissa bits 8 .. 0
-                    nxm[t] = 0;
-                    if (__ballot(nz && t < e)) {
-                        const uint32_t st = ST_GET(22 + t), b = (a >> t) & 1u;
-                        nxm[t] = NEXT(st, b);
-                        if (nz && t < e) op[2 * e + 1 - t] = ENTRY(st, b);
+                    // ---- the two chains: state 10 for exponent bits 9.., state 31 for mantissa bits e-1 .. 9
+                    if constexpr (L >= 3) {
+#pragma unroll 1
+                        for (int t = 9; t <= emax; t++) {
+                            const bool act = nz && t <= e;
+                            const int en = t < e ? int(ST_GET(10)) : -int(ST_GET(10));
+                            if (act) op[1 + t] = uint16_t(en);
+                            const uint32_t nx = NEXT(en);
+                            ST_PUT_IF(act, 10, nx);
+                        }
+#pragma unroll 1
+                        for (int t = emax - 1; t >= 9; t--) {
+                            const bool act = nz && t < e;
+                            const int en = (a >> t) & 1u ? int(ST_GET(31)) : -int(ST_GET(31));
+                            if (act) op[2 * e + 1 - t] = uint16_t(en);
+                            const uint32_t nx = NEXT(en);
+                            ST_PUT_IF(act, 31, nx);
+                        }
                     }
-                }
-                const uint32_t nx_s = NEXT(st_s, neg);
-                if (nz) op[2 * e + 2] = ENTRY(st_s, neg);
-                // ---- the two chains: state 10 for exponent bits 9.., state 31 for mantissa bits e-1 .. 9
-#pragma unroll 1
-                for (int t = 9; t <= 16; t++) {
-                    const bool act = nz && t <= e;
-                    if (!__ballot(act)) break;
-                    const uint32_t st = ST_GET(10), b = t < e ? 1u : 0u;
-                    if (act) op[1 + t] = ENTRY(st, b);
-                    const uint32_t nx = NEXT(st, b);
-                    ST_PUT_IF(act, 10, nx);
-                }
-#pragma unroll 1
-                for (int t = 15; t >= 9; t--) {
-                    const bool act = nz && t < e;
-                    if (!__ballot(act)) continue;                       // no lane has mantissa bit t
-                    const uint32_t st = ST_GET(31), b = (a >> t) & 1u;
-                    if (act) op[2 * e + 1 - t] = ENTRY(st, b);
-                    const uint32_t nx = NEXT(st, b);
-                    ST_PUT_IF(act, 31, nx);
-                }
-                // ---- phase 2: apply the independent transitions
-                ST_PUT_IF(true, 0, nx_z);
-#pragma unroll
-                for (int t = 0; t < 9; t++) ST_PUT_IF(nz && t <= e, 1 + t, nxe[t]);
-#pragma unroll
-                for (int t = 0; t < 9; t++) ST_PUT_IF(nz && t < e, 22 + t, nxm[t]);
+                    // ---- phase 2: apply the independent transitions: pack the looked-up bytes, merge under the lane's mask
+                    if constexpr (L == 0) MERGE(S[0], nx_z, 0xFFu);
+                    if constexpr (L >= 1) {
+                        MERGE(S[0], nx_z | (nxe[0] << 8) | (nxe[1] << 16) | (nxe[2] << 24), Ma.x);
+                        MERGE(S[5], (nxm[0] << 16) | (nxm[1] << 24), Ma.w);
+                    }
+                    if constexpr (L >= 2) {
+                        MERGE(S[1], nxe[3] | (nxe[4] << 8) | (nxe[5] << 16) | (nxe[6] << 24), Ma.y);
+                        MERGE(S[6], nxm[2] | (nxm[3] << 8) | (nxm[4] << 16) | (nxm[5] << 24), Mb.x);
+                    }
+                    if constexpr (L >= 3) {
+                        MERGE(S[2], nxe[7] | (nxe[8] << 8), Ma.z);
+                        MERGE(S[7], nxm[6] | (nxm[7] << 8) | (nxm[8] << 16), Mb.y);
+                    }
+#undef MERGE
+#undef EXP_SLOT
+#undef MAN_SLOT
 #undef ST_GET
 #undef ST_PUT_IF
-#undef ENTRY
 #undef NEXT
-                reinterpret_cast<uint4*>(sl)[0] = make_uint4(S[0], S[1], S[2], S[3]);
-                reinterpret_cast<uint4*>(sl)[1] = make_uint4(S[4], S[5], S[6], S[7]);
-                if (nz) sl[ks] = uint8_t(nx_s);                          // after the bulk write-back (LDS operations of a wave stay in order)
+                    reinterpret_cast<uint4*>(sl)[0] = make_uint4(S[0], S[1], S[2], S[3]);
+                    reinterpret_cast<uint4*>(sl)[1] = make_uint4(S[4], S[5], S[6], S[7]);
+                    if (L >= 1 && nz) sl[ks] = uint8_t(nx_s);             // after the bulk write-back (LDS operations of a wave stay in order)
+                };
+                if (emax >= 7) binarise(std::integral_constant<int, 3>());
+                else if (emax >= 3) binarise(std::integral_constant<int, 2>());
+                else if (emax >= 0) binarise(std::integral_constant<int, 1>());
+                else binarise(std::integral_constant<int, 0>());
             }
             done |= __ballot(ready);
             pending = pending && !ready;
@@ -982,7 +1040,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     ffv1::make_zero_state(c.zero_state, c.one_state);
     if (c.nctx > 8191) { delete e; return fail(2, "ffv1: context count %u does not fit the symbol format", c.nctx); }
     e->nkeys = c.nsets * c.nctx;
-    e->resolve_lds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + 2 * 256 + ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);
+    e->resolve_lds = ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);      // dynamic part; kResolveFixedLds is static
     e->resume_stride = uint32_t((80 + ((e->nkeys + 31) / 32) * 4 + 15) & ~15u);
     e->lds_states = size_t(e->nkeys) * 32 <= (48u << 10);                        // 338 contexts x 2 (3) sets x 32 B = 21.6 (32.4) KB
     if (e->lds_states) { e->resolve_lds += size_t(e->nkeys) * 32; e->resume_stride = uint32_t(80 + e->nkeys * 32); }
