@@ -321,7 +321,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg_bytes_launch), "launch_ms": round(launch_ms, 3), "launches_per_step": nl,
                     "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items()},
-                    "note": "entropy coding: bound by VALU issue on serial chains, not by bytes -- SQ counters in profiles/ put 71 % of the chip's "
+                    "note": "entropy coding: bound by VALU issue on serial chains, not by bytes -- SQ counters in profiles/ put 83 % of the chip's "
                             "instruction-issue slots in use during the step (DESIGN.md section 5)"}
         result = {
             "metric": "4K-DCI 16-bit DPX->FFV1 frames/sec", "value": round(fps, 3), "unit": "frames/s",
