@@ -7,8 +7,9 @@
 // Lib/Transform/Transform.cpp, all inverted.
 //
 // Pipeline for a batch of F frames x S slices ("chains" = F*S independent range-coder chains):
-//   K1 k_unpack     thread / pixel      payload bytes -> planar Y,Cb,Cr(,A) int32       (inverse of Transform.cpp From())
-//   K2 k_model      thread / sample     neighbours -> context, folded residual, #decisions; symbols in coding order
+//   K1 unpack_px    thread / pixel      payload bytes -> Y,Cb,Cr(,A) values             (inverse of Transform.cpp From()); runs inside
+//   K2 k_model      thread / sample     K2, tile by tile through LDS; k_unpack writes whole planes only for the stage tests
+//                                       neighbours -> context, folded residual, #decisions; symbols in coding order
 //   K3 k_resolve    wave   / slice      adaptive-state resolution: walks the symbols 64 at a time, applies the state
 //                                       transitions in coding order (same-context lanes serialised through LDS) and
 //                                       emits (state, bit) decisions, interleaved [piece][lane of chain][32 x u16]
@@ -95,24 +96,21 @@ __device__ __forceinline__ uint32_t ld_field(const uint8_t* line, uint32_t idx, 
     return (v >> (fields == kFieldsTop ? 22 - 10 * slot : 10 * slot + fill)) & 0x3FF;
 }
 
-__global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C, const uint8_t* const* __restrict__ frames,
-                                                int32_t* __restrict__ planes, uint32_t frame0)
+// One pixel of the payload as FFV1 plane values: components in file order -> (g/b exchange) -> JPEG 2000 RCT with the offset
+// FFV1 adds to Cb, Cr (inverse of Transform.cpp From()).  v[0..planes-1].
+__device__ __forceinline__ void unpack_px(const enc_const* __restrict__ C, const uint8_t* __restrict__ frame, uint32_t x, uint32_t y, int32_t (&v)[4])
 {
     const uint32_t W = C->W, H = C->H;
-    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= W * H) return;
-    const uint32_t f = blockIdx.y;           // frame inside this sub-batch; planes hold one sub-batch
-    const uint32_t y = pix / W, x = pix - y * W;
     const uint32_t fy = C->vflip ? H - 1 - y : y;                    // line in the file (Transform.cpp:181-185)
-    const uint8_t* p = frames[frame0 + f] + size_t(fy) * C->line_bytes + size_t(x) * C->bytes_pp;
+    const uint8_t* p = frame + size_t(fy) * C->line_bytes + size_t(x) * C->bytes_pp;
     const bool be = C->big_endian;
     uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
     if (C->fields == kFieldsExr) {                                   // planar inside the line: B, G, R runs after an 8-byte line header
-        const uint16_t* l16 = reinterpret_cast<const uint16_t*>(frames[frame0 + f] + size_t(fy) * C->line_bytes + 8);
+        const uint16_t* l16 = reinterpret_cast<const uint16_t*>(frame + size_t(fy) * C->line_bytes + 8);
         c2 = l16[x]; c1 = l16[W + x]; c0 = l16[2 * W + x];
     } else if (C->fields != kFieldsBytes) {
         const uint32_t fields = C->fields, fill = C->fill, np = C->planes;
-        const uint8_t* line = frames[frame0 + f] + (C->altern ? size_t(0) : size_t(fy) * C->line_bytes);
+        const uint8_t* line = frame + (C->altern ? size_t(0) : size_t(fy) * C->line_bytes);
         const uint32_t i0 = C->altern ? fy * W + x : x * np;
         c0 = ld_field(line, i0, fields, fill, be);
         if (np > 1) { c1 = ld_field(line, i0 + 1, fields, fill, be); c2 = ld_field(line, i0 + 2, fields, fill, be); }
@@ -136,16 +134,31 @@ __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C,
     case RCGPU_PIX_Y8: c0 = p[0]; break;
     default: c0 = ld16(p, be); break;
     }
-    const size_t plane_sz = size_t(W) * H;
-    int32_t* dst = planes + size_t(f) * C->planes * plane_sz + pix;
-    if (!C->rgb) { dst[0] = int32_t(c0); return; }
+    v[0] = int32_t(c0); v[1] = v[2] = 0; v[3] = int32_t(c3);
+    if (!C->rgb) return;
     int32_t r = int32_t(c0), g = int32_t(c1), b = int32_t(c2);
     if (C->gb_swap) { const int32_t t = g; g = b; b = t; }
     b -= g; r -= g;
     g += (b + r) >> 2;
     const int32_t off = int32_t(1) << C->bps;
-    dst[0] = g; dst[plane_sz] = b + off; dst[2 * plane_sz] = r + off;
-    if (C->planes == 4) dst[3 * plane_sz] = int32_t(c3);
+    v[0] = g; v[1] = b + off; v[2] = r + off;
+}
+
+// K1 as a kernel of its own: int32 planes of a sub-batch, for the stage tests (rcgpu_ffv1_debug_fetch(0)).  The encoder itself
+// unpacks inside k_model.
+__global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C, const uint8_t* const* __restrict__ frames,
+                                                int32_t* __restrict__ planes, uint32_t frame0)
+{
+    const uint32_t W = C->W, H = C->H;
+    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= W * H) return;
+    const uint32_t f = blockIdx.y;           // frame inside this sub-batch; planes hold one sub-batch
+    const uint32_t y = pix / W, x = pix - y * W;
+    int32_t v[4];
+    unpack_px(C, frames[frame0 + f], x, y, v);
+    const size_t plane_sz = size_t(W) * H;
+    int32_t* dst = planes + size_t(f) * C->planes * plane_sz + pix;
+    for (uint32_t p = 0; p < C->planes; p++) dst[p * plane_sz] = v[p];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -153,43 +166,60 @@ __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C,
 // (:21-66), residual folded to `bits` (:469 inverse), and the number of binary decisions its symbol will take.
 // Output symbol = set << 30 | |ctx| << 17 | (residual & 0x1FFFF), stored in CODING order of the slice
 // (line-interleaved planes, SliceContent_LineThenPlane :427-441).
-// grid = (ceil(lines / 8), chains); a block walks 8 slice-plane-lines.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int32_t median3(int32_t a, int32_t b, int32_t c)
 {
     return max(min(a, b), min(max(a, b), c));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K1+K2 in one kernel: a block unpacks a tile of a slice -- kTileR picture rows x kTileW columns, plus the two rows above and the
+// columns the neighbour rules reach -- from the payload straight into LDS and models it from there, so the int32 planes never
+// exist in HBM (53 MB in + 106 MB out per 4K RGB16 frame instead of 371 MB through planes).
+// grid = (max tiles of a slice, chains)
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kTileW = 256, kTileR = 8, kTileCols = kTileW + 3, kTileRows = kTileR + 2;
 __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
-                                               const int32_t* __restrict__ planes, uint32_t* __restrict__ sym,
-                                               unsigned long long* __restrict__ chain_ndec, uint32_t frame0)
+                                                     const uint8_t* const* __restrict__ frames, uint32_t* __restrict__ sym,
+                                                     unsigned long long* __restrict__ chain_ndec)
 {
+    extern __shared__ int32_t tile[];                    // [planes][kTileRows][kTileCols]: rows y0-2 .. y0+R-1, columns x0-2 .. x0+TW
     __shared__ int16_t q[5][256];
     __shared__ unsigned long long segsum[64];
+    const uint32_t S = C->S, f = blockIdx.y / S, s = blockIdx.y - f * S, chain = blockIdx.y;
+    const slice_geom G = geom[s];
+    const uint32_t tiles_x = (G.w + kTileW - 1) / kTileW, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = int(ty) * kTileR, x0 = int(tx) * kTileW;
+    if (y0 >= int(G.h)) return;                          // whole block: this slice has fewer tiles than the largest one
     for (uint32_t i = threadIdx.x; i < 5 * 256; i += 256) (&q[0][0])[i] = (&C->q[0][0])[i];
     if (threadIdx.x < 64) segsum[threadIdx.x] = 0;
+    const uint32_t np = C->planes;
+    const uint8_t* frame = frames[f];
+    for (int i = threadIdx.x; i < kTileRows * kTileCols; i += 256) {
+        const int r = i / kTileCols, c = i - r * kTileCols, yy = y0 + r - 2, xx = x0 + c - 2;
+        if (yy >= 0 && yy < int(G.h) && xx >= 0 && xx < int(G.w)) {
+            int32_t v[4];
+            unpack_px(C, frame, G.x0 + uint32_t(xx), G.y0 + uint32_t(yy), v);
+            for (uint32_t p = 0; p < np; p++) tile[(p * kTileRows + r) * kTileCols + c] = v[p];
+        }
+    }
     __syncthreads();
-    const uint32_t S = C->S, fl = blockIdx.y / S, s = blockIdx.y - fl * S;     // fl: frame inside the sub-batch (planes)
-    const uint32_t f = frame0 + fl, chain = f * S + s;
-    const slice_geom G = geom[s];
-    const uint32_t W = C->W, np = C->planes;
-    const size_t plane_sz = size_t(W) * C->H;
-    const int32_t* fp = planes + size_t(fl) * np * plane_sz;
-    uint32_t* out = sym + size_t(f) * C->samples_per_frame + G.sym_off;
-    const uint32_t nlines = G.h * np;
     const int bits = int(C->bits);
     const bool is5 = C->is5, ov16 = C->overflow16, rgb = C->rgb;
+    const uint32_t nseg_c = C->nseg;
     unsigned long long local = 0;
     uint32_t cur_seg = 0xFFFFFFFFu, seg_end = 0;
-    const uint32_t line_end = min(nlines, (blockIdx.x + 1) * 8);
-    for (uint32_t line = blockIdx.x * 8; line < line_end; line++) {
-        const uint32_t y = line / np, p = line - y * np;
-        const int32_t* pl = fp + p * plane_sz + size_t(G.y0) * W + G.x0;     // slice origin in plane p
-        const uint32_t set = rgb ? (p + 1) >> 1 : 0;
-        for (uint32_t x = threadIdx.x; x < G.w; x += 256) {
-            // neighbours with the decoder's edge rules (FFV1_Slice.cpp:386-387 of SURVEY appendix A; :432-433)
-            auto at = [&](int yy, int xx) -> int32_t { return yy < 0 ? 0 : pl[size_t(yy) * W + xx]; };
-            const int yi = int(y), xi = int(x), wl = int(G.w) - 1;
+    uint32_t* out = sym + size_t(f) * C->samples_per_frame + G.sym_off;
+    const int xi = x0 + int(threadIdx.x), wl = int(G.w) - 1;
+    const int rows = min(kTileR, int(G.h) - y0);
+    if (xi <= wl)
+    for (int r = 0; r < rows; r++) {
+        const int yi = y0 + r;
+        for (uint32_t p = 0; p < np; p++) {
+            const int32_t* pl = tile + p * kTileRows * kTileCols;
+            // neighbours with the decoder's edge rules (FFV1_Slice.cpp:386-387 of SURVEY appendix A; :432-433), slice coordinates
+            auto at = [&](int yy, int xx) -> int32_t { return yy < 0 ? 0 : pl[(yy - y0 + 2) * kTileCols + (xx - x0 + 2)]; };
+            const uint32_t set = rgb ? (p + 1) >> 1 : 0;
             const int32_t cur = at(yi, xi);
             const int32_t T  = at(yi - 1, xi);
             const int32_t L  = xi > 0 ? at(yi, xi - 1) : at(yi - 1, 0);
@@ -208,7 +238,7 @@ __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, 
             if (ctx < 0) { ctx = -ctx; d = -d; }
             d = int32_t(uint32_t(d) << (32 - bits)) >> (32 - bits);                  // fold: sign-extend to `bits`
             const uint32_t a = uint32_t(d < 0 ? -d : d);
-            const uint32_t idx = line * G.w + x;
+            const uint32_t idx = (uint32_t(yi) * np + p) * G.w + uint32_t(xi);
             if (idx >= seg_end) {                 // a thread's symbol index only grows: one division at its first symbol, then increments
                 if (local) atomicAdd(&segsum[cur_seg], local);
                 local = 0;
@@ -219,10 +249,9 @@ __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, 
             out[size_t(idx)] = (set << 30) | (uint32_t(ctx) << 17) | (uint32_t(d) & 0x1FFFFu);
         }
     }
-    // per-segment decision counts: LDS first, then at most nseg global atomics per block
     if (local) atomicAdd(&segsum[cur_seg], local);
     __syncthreads();
-    if (threadIdx.x < C->nseg && segsum[threadIdx.x]) atomicAdd(&chain_ndec[size_t(chain) * C->nseg + threadIdx.x], segsum[threadIdx.x]);
+    if (threadIdx.x < nseg_c && segsum[threadIdx.x]) atomicAdd(&chain_ndec[size_t(chain) * nseg_c + threadIdx.x], segsum[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1095,7 +1124,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
 #define HM(p, b) if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&(p)), (b))
     DM(e->d_const, sizeof(enc_const)); DM(e->d_geom, sizeof(slice_geom) * S); DM(e->d_hdr, hdr.size() * 2 + 16);
     DM(e->d_frame_ptrs, sizeof(void*) * F);
-    DM(e->d_planes, size_t(std::min(F, kSubBatch)) * c.samples_per_frame * 4); DM(e->d_sym, size_t(F) * c.samples_per_frame * 4);
+    DM(e->d_sym, size_t(F) * c.samples_per_frame * 4);
     DM(e->d_states, e->lds_states ? 16 : nchains * e->nkeys * 32);
     DM(e->d_ndec, nchains * nseg * 8); DM(e->d_total_n, nchains * 8); DM(e->d_seg_pieces, nchains * nseg * 4); DM(e->d_group_off, ngroups * nseg * 8);
     DM(e->d_k3_resume, nchains * e->resume_stride); DM(e->d_k4_resume, nchains * sizeof(rc_resume));
@@ -1162,13 +1191,10 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(hipMemcpyAsync(e->d_frame_ptrs, e->h_frame_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(e->d_ndec, 0, size_t(nchains) * nseg * 8, st));
     HIP_TRY(hipMemsetAsync(e->d_err, 0, 16, st));
-    uint32_t max_lines = 0;
-    for (const slice_geom& g : e->geom) max_lines = std::max(max_lines, g.h * c.planes);
-    for (uint32_t f0 = 0; f0 < n; f0 += kSubBatch) {          // planes are transient: one sub-batch at a time
-        const uint32_t nf = std::min(kSubBatch, n - f0);
-        HIP_TRY(timed(0, st, [&] { hipLaunchKernelGGL(k_unpack, dim3((c.W * c.H + 255) / 256, nf), dim3(256), 0, st, e->d_const, e->d_frame_ptrs, e->d_planes, f0); }));
-        HIP_TRY(timed(1, st, [&] { hipLaunchKernelGGL(k_model, dim3((max_lines + 7) / 8, nf * S), dim3(256), 0, st, e->d_const, e->d_geom, e->d_planes, e->d_sym, e->d_ndec, f0); }));
-    }
+    uint32_t max_tiles = 0;
+    for (const slice_geom& g : e->geom) max_tiles = std::max(max_tiles, ((g.w + kTileW - 1) / kTileW) * ((g.h + kTileR - 1) / kTileR));
+    HIP_TRY(timed(1, st, [&] { hipLaunchKernelGGL(k_model, dim3(max_tiles, nchains), dim3(256), size_t(c.planes) * kTileRows * kTileCols * 4, st,
+                                                  e->d_const, e->d_geom, e->d_frame_ptrs, e->d_sym, e->d_ndec); }));
     // The exact decision counts size the stream windows: one host round trip per batch.
     HIP_TRY(hipMemcpyAsync(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * nseg * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1328,7 +1354,15 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
         return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? (long long)bytes : -3;
     };
     switch (what) {
-    case 0: return d2h(e->d_planes, size_t(std::min(e->last_n, kSubBatch)) * c.samples_per_frame * 4);
+    case 0: {      // int32 planes of the first frames of the last batch: k_unpack on demand (the caller's frame buffers must still be there)
+        const uint32_t nf = std::min(e->last_n, kSubBatch);
+        int32_t* planes = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&planes), size_t(nf) * c.samples_per_frame * 4) != hipSuccess) return -3;
+        hipLaunchKernelGGL(k_unpack, dim3((c.W * c.H + 255) / 256, nf), dim3(256), 0, nullptr, e->d_const, e->d_frame_ptrs, planes, 0u);
+        const long long r = hipDeviceSynchronize() == hipSuccess ? d2h(planes, size_t(nf) * c.samples_per_frame * 4) : -3;
+        (void)hipFree(planes);
+        return r;
+    }
     case 1: return d2h(e->d_sym, size_t(e->last_n) * c.samples_per_frame * 4);
     case 2: return d2h(e->d_total_n, size_t(e->last_n) * S * 8);
     case 3: {

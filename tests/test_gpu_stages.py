@@ -77,7 +77,7 @@ def test_segmented_handover_is_bit_exact(built, segments):
 
 
 def test_many_frames_cross_sub_batches(built):
-    """More frames than one k_unpack/k_model sub-batch (16) and more than one wavefront of chains."""
+    """More frames than debug_fetch returns planes for (16) and more than one wavefront of chains."""
     w, h, pixfmt, nh, nv, nframes = 96, 64, synth.PIX_RGB10_FILLEDA_BE, 2, 2, 37
     payloads = []
     for i in range(nframes):
