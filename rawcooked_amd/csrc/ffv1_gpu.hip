@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void k_gather(const enc_const* __restrict__ C,
 // Host side
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kMaxSeg = 64;
-constexpr uint32_t kSubBatch = 16;           // frames whose int32 planes are resident at once (k_unpack -> k_model)
+constexpr uint32_t kSubBatch = 16;           // frames whose int32 planes rcgpu_ffv1_debug_fetch(0) returns (k_unpack on demand)
 
 struct rcgpu_ffv1 {
     rcgpu_ffv1_config cfg{};
@@ -1136,7 +1136,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
 #undef HM
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->rc_stream, hipStreamNonBlocking);
-    e->ev.resize(2 * (5 + 2 * nseg + (F + kSubBatch - 1) / kSubBatch * 2));
+    e->ev.resize(2 * (6 + 2 * nseg));              // timing events: k_model, footer, scan, gather + two kernels per segment
     for (auto& ev : e->ev) if (he == hipSuccess) he = hipEventCreate(&ev);
     for (uint32_t j = 0; j < nseg; j++) {
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k3[j], hipEventDisableTiming);

@@ -11,8 +11,8 @@ cols = [r[1] for r in db.execute(f"pragma table_info({view})")]
 rows = db.execute(f"select name, start, end from {view} order by start").fetchall()
 rows = [(n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip(), s, e) for n, s, e in rows]
 rows = [r for r in rows if r[0].startswith("k_")]
-# last step = last occurrence of k_unpack group
-starts = [i for i, r in enumerate(rows) if r[0] == "k_unpack" and (i == 0 or rows[i - 1][0] != "k_unpack" and rows[i - 1][0] != "k_model")]
+# last step = from the last k_model launch on
+starts = [i for i, r in enumerate(rows) if r[0] == "k_model"]
 step = rows[starts[-1]:]
 t0 = step[0][1]
 print("step kernels:", len(step), "span %.1f ms" % ((max(e for _, _, e in step) - t0) / 1e6))
@@ -21,7 +21,7 @@ rc = [(s, e) for n, s, e in step if n == "k_rangecode"]
 print("first k_resolve starts at %.1f ms, last ends at %.1f ms; sum of durations %.1f ms; gaps between launches %.1f ms" % ((res[0][0] - t0) / 1e6, (res[-1][1] - t0) / 1e6, sum(e - s for s, e in res) / 1e6, sum(max(0, res[i + 1][0] - res[i][1]) for i in range(len(res) - 1)) / 1e6))
 print("first k_rangecode starts at %.1f ms, last ends at %.1f ms; sum %.1f ms; gaps %.1f ms" % ((rc[0][0] - t0) / 1e6, (rc[-1][1] - t0) / 1e6, sum(e - s for s, e in rc) / 1e6, sum(max(0, rc[i + 1][0] - rc[i][1]) for i in range(len(rc) - 1)) / 1e6))
 for n, s, e in step[-4:]: print("  tail: %-12s %.1f -> %.1f ms" % (n, (s - t0) / 1e6, (e - t0) / 1e6))
-km = [(n, s, e) for n, s, e in step if n in ("k_unpack", "k_model")]
-print("k_unpack/k_model: first start 0.0, last end %.1f ms, busy %.1f ms" % ((km[-1][2] - t0) / 1e6, sum(e - s for _, s, e in km) / 1e6))
+km = [(n, s, e) for n, s, e in step if n == "k_model"]
+print("k_model: first start 0.0, last end %.1f ms, busy %.1f ms" % ((km[-1][2] - t0) / 1e6, sum(e - s for _, s, e in km) / 1e6))
 PY
 rm -rf gpurun_out/tl
