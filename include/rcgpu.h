@@ -147,7 +147,8 @@ typedef struct {
                                  table travels in the configuration record (FFV1_Parameters.cpp:41-55) */
     uint32_t level;           /* -level: 0 or 3 = FFV1 version 3; 1 = version 1, what the reference asks for with -slices 1
                                  (Global.cpp:961-968): num_h = num_v = 1, slicecrc 0, no configuration record (the header travels inside
-                                 every frame, FFV1_Slice.cpp:224-268), no slice footer.  Encoder only; one chain per frame. */
+                                 every frame, FFV1_Slice.cpp:224-268), no slice footer.  One chain per frame; the decoder insists on exactly
+                                 the header this configuration produces. */
 } rcgpu_ffv1_config;
 
 typedef struct rcgpu_ffv1 rcgpu_ffv1;

@@ -250,8 +250,8 @@ class Ffv1Encoder:
 class Ffv1Decoder:
     """Device FFV1 decoder + pack (the --check half).  Buffers are device pointers (ints)."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, flags=0, coder=1):
-        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, 0, flags, coder)
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, flags=0, coder=1, level=3):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, 0, flags, coder, level)
         self.h = _VP()
         _check(lib().rcgpu_ffv1_decoder_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_decoder_create")
 

@@ -35,6 +35,7 @@ struct dec_const {
     uint32_t planes, bps, bits, rgb, gb_swap, big_endian, bytes_pp, overflow16;
     uint32_t fields, fill, vflip, altern;  // payload layout of the bit-packed DPX flavors (rc_common.h kFields*), RCGPU_FLAG_*
     uint32_t num_h, num_v, S, nctx, nsets, ec, is5, index_count, qidx;
+    uint32_t v1, hdr_n;                    // FFV1 version 1: one slice = the packet, hdr_n header decisions in front of it, no footer
     int16_t  q[5][256];
     uint8_t  one_state[256], zero_state[256];
 };
@@ -48,6 +49,7 @@ __global__ void k_dec_split(const dec_const* __restrict__ C, const uint8_t* cons
     if (f >= n) return;
     const uint8_t* p = packets[f];
     const uint32_t tail = C->ec ? 8 : 3, S = C->S;
+    if (C->v1) { slice_start[f] = 0; slice_len[f] = uint32_t(sizes[f]); return; }       // version 1: the packet is the one slice
     unsigned long long pos = sizes[f];
     uint32_t count = 0;
     while (pos && count < S) {                               // FFV1_Frame.cpp:177-198
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                                                    const unsigned long long* __restrict__ slice_start, const uint32_t* __restrict__ slice_len,
                                                    uint32_t nchains, uint8_t* __restrict__ states, uint32_t nkeys,
                                                    int32_t* __restrict__ planes, uint8_t* const* __restrict__ payloads, uint32_t ring_w,
-                                                   uint32_t* __restrict__ err)
+                                                   uint32_t* __restrict__ err, const uint16_t* __restrict__ hdr)
 {
     __shared__ uint8_t trans[512];
     __shared__ int16_t q[5][256];
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     const uint32_t chain = blockIdx.x * 64 + lane;
     if (chain >= nchains) return;
     const uint32_t S = C->S, f = chain / S;
-    const uint32_t tail = C->ec ? 8 : 3;
+    const uint32_t tail = C->v1 ? 0 : C->ec ? 8 : 3;
     const uint32_t len = slice_len[chain];
     if (len < tail) { atomicOr(err, 8u); return; }
     const uint8_t* buf = packets[f] + slice_start[chain];
@@ -253,14 +255,27 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     uint8_t* my = slot + lane * 4;
     uint32_t* myw = reinterpret_cast<uint32_t*>(my);               // dword k of this lane's states: myw[k * 64]
     auto fresh = [&]() { for (int k = 0; k < 8; k++) myw[k * 64] = 0x80808080u; };
+    uint32_t sx = 0, sy = 0;
+    bool bad = false;
+    if (C->v1) {
+        // version 1: keyframe bit and the stream header (parameters::Parse(E, false), FFV1_Parameters.cpp:23-104) sit in front of the
+        // one slice, in the same coder.  The header of a stream this decoder is configured for is fully determined: replay its
+        // decisions (state | bit << 8, ffv1_host.cpp v1_frame_header_decisions) and insist on every bit.
+        for (uint32_t i = 0; i < C->hdr_n; i++) {
+            const uint32_t d = hdr[i];
+            my[0] = uint8_t(d);
+            bad |= uint32_t(rd_bit(r, my, 0, trans)) != (d >> 8);
+        }
+    } else {
     if (slice_start[chain] == 0) { fresh(); if (!rd_bit(r, my, 0, trans)) atomicOr(err, 16u); }     // keyframe bit of the first slice in the packet
     // slice header, FFV1_Slice.cpp:113-177
     fresh();
-    const uint32_t sx = rd_u(r, my, trans), sy = rd_u(r, my, trans);
+    sx = rd_u(r, my, trans); sy = rd_u(r, my, trans);
     const uint32_t sw1 = rd_u(r, my, trans), sh1 = rd_u(r, my, trans);
-    bool bad = sx >= C->num_h || sy >= C->num_v || sw1 || sh1;
+    bad = sx >= C->num_h || sy >= C->num_v || sw1 || sh1;
     for (uint32_t i = 0; i < C->index_count; i++) bad |= rd_u(r, my, trans) != C->qidx;
     (void)rd_u(r, my, trans); (void)rd_u(r, my, trans); (void)rd_u(r, my, trans);
+    }
     if (bad) { atomicOr(err, 32u); return; }
     const uint32_t W = C->W, H = C->H, np = C->planes;
     const uint32_t x0 = uint32_t((unsigned long long)sx * W / C->num_h), y0 = uint32_t((unsigned long long)sy * H / C->num_v);
@@ -450,7 +465,7 @@ struct rcgpu_ffv1_decoder {
     size_t payload_bytes = 0;
     dec_const* d_const = nullptr;
     const uint8_t** d_pkt_ptrs = nullptr; uint8_t** d_out_ptrs = nullptr; unsigned long long* d_sizes = nullptr;
-    unsigned long long* d_slice_start = nullptr; uint32_t* d_slice_len = nullptr;
+    unsigned long long* d_slice_start = nullptr; uint32_t* d_slice_len = nullptr; uint16_t* d_hdr = nullptr;
     uint8_t* d_states = nullptr; int32_t* d_planes = nullptr; uint32_t* d_err = nullptr;
     void** h_ptrs = nullptr; unsigned long long* h_sizes = nullptr;
     hipStream_t own_stream = nullptr;
@@ -462,7 +477,7 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
 {
     if (!d) return;
     (void)hipSetDevice(d->cfg.device);
-    void* bufs[] = { d->d_const, d->d_pkt_ptrs, d->d_out_ptrs, d->d_sizes, d->d_slice_start, d->d_slice_len, d->d_states, d->d_planes, d->d_err };
+    void* bufs[] = { d->d_const, d->d_pkt_ptrs, d->d_out_ptrs, d->d_sizes, d->d_slice_start, d->d_slice_len, d->d_states, d->d_planes, d->d_err, d->d_hdr };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (d->h_ptrs) (void)hipHostFree(d->h_ptrs);
     if (d->h_sizes) (void)hipHostFree(d->h_sizes);
@@ -478,7 +493,8 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     *out = nullptr;
     if (cfg->pixfmt >= RCGPU_PIX_COUNT || !cfg->width || !cfg->height || !cfg->num_h_slices || !cfg->num_v_slices || !cfg->max_batch)
         return fail(2, "ffv1 decoder: bad configuration");
-    if (cfg->level == 1) return fail(2, "ffv1 decoder: FFV1 version 1 streams (-level 1) are not supported");
+    if (cfg->level == 1 && (cfg->num_h_slices * cfg->num_v_slices != 1 || cfg->slicecrc))
+        return fail(2, "ffv1 decoder: FFV1 version 1 (-level 1) has one slice and no slice CRC");
     const pix_desc& px = pix(cfg->pixfmt);
     const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
     if (altern && px.fields != kFieldsLow) return fail(2, "ffv1 decoder: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only");
@@ -507,13 +523,21 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     memcpy(c.q, Q.q, sizeof c.q);
     memcpy(c.one_state, ffv1::one_state_table(cfg->coder), 256);
     ffv1::make_zero_state(c.zero_state, c.one_state);
+    std::vector<uint16_t> hdr;
+    if (cfg->level == 1) {
+        ffv1::stream_params sp{};
+        sp.bits_per_raw_sample = px.bits; sp.rgb = px.planes != 1; sp.alpha = px.planes == 4; sp.num_h_slices = sp.num_v_slices = 1; sp.ec = 0;
+        sp.context_model = qidx; sp.compact = cfg->context == 2; sp.coder = cfg->coder == 2 ? 2 : 1; sp.version = 1;
+        hdr = ffv1::v1_frame_header_decisions(sp);
+    }
+    c.v1 = cfg->level == 1; c.hdr_n = uint32_t(hdr.size());
     d->nkeys = c.nsets * c.nctx;
     d->payload_bytes = size_t(cfg->line_bytes) * cfg->height;
     const uint32_t F = cfg->max_batch; const size_t nchains = size_t(F) * c.S;
     hipError_t he = hipSuccess;
 #define DM(p, b) if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&(p)), (b))
     DM(d->d_const, sizeof c); DM(d->d_pkt_ptrs, sizeof(void*) * F); DM(d->d_out_ptrs, sizeof(void*) * F); DM(d->d_sizes, 8 * F);
-    DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32);
+    DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32); DM(d->d_hdr, hdr.size() * 2 + 16);
     // whole-byte layouts (and EXR) are packed inline by the decoding lanes, which then only need three lines per plane and slice;
     // the word-stream layouts share words between neighbouring slices and keep the planes + k_pack_words route
     d->ring = c.fields == kFieldsBytes || c.fields == kFieldsExr;
@@ -525,6 +549,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking);
     for (auto& e : d->ev) if (he == hipSuccess) he = hipEventCreate(&e);
     if (he == hipSuccess) he = hipMemcpy(d->d_const, &c, sizeof c, hipMemcpyHostToDevice);
+    if (he == hipSuccess && !hdr.empty()) he = hipMemcpy(d->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
     if (he != hipSuccess) { const int r = fail(100, "ffv1 decoder: device setup failed: %s", hipGetErrorString(he)); rcgpu_ffv1_decoder_destroy(d); return r; }
     *out = d;
     return 0;
@@ -554,10 +579,10 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     HIP_TRY(hipEventRecord(d->ev[1], st));
     if (d->ring)
         hipLaunchKernelGGL(k_dec_slices<true>, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
-                           d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, d->ring_w, d->d_err);
+                           d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, d->ring_w, d->d_err, d->d_hdr);
     else
         hipLaunchKernelGGL(k_dec_slices<false>, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
-                           d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, 0u, d->d_err);
+                           d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, 0u, d->d_err, d->d_hdr);
     HIP_TRY(hipEventRecord(d->ev[2], st));
     if (d->ring) { /* packed inline */ }
     else {

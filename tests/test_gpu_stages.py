@@ -259,5 +259,14 @@ def test_level_1_single_slice_frames(built, pixfmt, coder, ctx):
     for f in range(3):
         assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
     enc.close()
+    # and back: the device decoder replays the in-band header, then the one slice
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, 1, 1, 0, ctx, max_batch=3, coder=coder, level=1)
+    assert dec.decode_host(packets, len(payloads[0])) == [bytes(x) for x in payloads]
+    broken = bytearray(packets[0]); broken[1] ^= 0x40                 # a different header is refused, not decoded as something else
+    with pytest.raises(RuntimeError):
+        dec.decode_host([bytes(broken)], len(payloads[0]))
+    dec.close()
     with pytest.raises(RuntimeError):
         api.Ffv1Encoder(w, h, pixfmt, line_bytes, 2, 2, 0, ctx, level=1)
+    with pytest.raises(RuntimeError):
+        api.Ffv1Decoder(w, h, pixfmt, line_bytes, 2, 2, 0, ctx, level=1)
