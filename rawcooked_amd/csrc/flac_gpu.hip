@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64) void k_flac_write(const flac_const* __restrict_
             if (lane == 0) { put_bits(words, p, param_bits == 5 ? 1 : 0, 2); put_bits(words, p + 2, uint32_t(sp->part_order), 4); }
             p += 6;
             // residual codes: every lane takes a contiguous run of samples; code lengths are prefix-summed across lanes
-            const uint32_t parts = 1u << sp->part_order, plen = n >> sp->part_order;
+            const uint32_t plen = n >> sp->part_order;
             const uint32_t nres = n - uint32_t(order);
             const uint32_t per = (nres + 63) / 64;
             const uint32_t i0 = min(n, uint32_t(order) + lane * per), i1 = min(n, i0 + per);
