@@ -178,7 +178,7 @@ __device__ __forceinline__ int32_t median3(int32_t a, int32_t b, int32_t c)
 // exist in HBM (53 MB in + 106 MB out per 4K RGB16 frame instead of 371 MB through planes).
 // grid = (max tiles of a slice, chains)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kTileW = 256, kTileR = 8, kTileCols = kTileW + 3, kTileRows = kTileR + 2;
+constexpr int kTileW = 256, kTileR = 4, kTileCols = kTileW + 3, kTileRows = kTileR + 2;
 __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                      const uint8_t* const* __restrict__ frames, uint32_t* __restrict__ sym,
                                                      unsigned long long* __restrict__ chain_ndec)
