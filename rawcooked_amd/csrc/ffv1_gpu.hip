@@ -1390,6 +1390,7 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
         const uint8_t* src = e->d_cbuf + size_t(chain / S) * e->cbuf_frame_stride + (size_t(g.cbuf_off_hi) << 32 | g.cbuf_off_lo);
         return d2h(src, len);
     }
+    case 5: return d2h(e->d_err, 16);      // [0] error flags, [1] carries k_rangecode handed to k_footer (events) in the last call
     default: return -5;
     }
 }
