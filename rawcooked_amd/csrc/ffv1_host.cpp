@@ -258,13 +258,15 @@ extern "C" int rcgpu_ffv1_config_from_record(const uint8_t* rec, size_t size, rc
     const bool rgb = d.planes != 1;
     if (colorspace != (rgb ? 1u : 0u) || bps != d.bits || chroma != rgb || hs || vs || alpha != (d.planes == 4))
         return fail(5, "ffv1 record: stream (colorspace %u, %u bit%s) does not match the pixel format of the files", colorspace, bps, alpha ? ", alpha" : "");
-    cfg->num_h_slices = r.u(st) + 1; cfg->num_v_slices = r.u(st) + 1;
+    const uint32_t nh1 = r.u(st), nv1 = r.u(st);
+    if (nh1 >= cfg->width || nv1 >= cfg->height || nh1 > 0xFFFF || nv1 > 0xFFFF) return fail(5, "ffv1 record: %u x %u slices do not fit the picture", nh1 + 1, nv1 + 1);
+    cfg->num_h_slices = nh1 + 1; cfg->num_v_slices = nv1 + 1;
     if (r.u(st) != 2) return fail(6, "ffv1 record: expected two quantisation table sets");
     quant_model ref[2], compact[2];
     build_quant_models(d.bits, ref, false); build_quant_models(d.bits, compact, true);
     bool is_ref = true, is_compact = true;
     for (int i = 0; i < 2; i++) {
-        int32_t scale = 1;
+        int64_t scale = 1;                                             // context_count so far; FFmpeg and the reference stop at 32768
         for (int j = 0; j < 5; j++) {
             uint8_t qst[kContextSize]; memset(qst, 128, sizeof qst);
             int32_t v = 0;
@@ -272,12 +274,13 @@ extern "C" int rcgpu_ffv1_config_from_record(const uint8_t* rec, size_t size, rc
                 const uint32_t len1 = r.u(qst);
                 if (k + len1 >= 128) return fail(6, "ffv1 record: bad quantisation table (FFV1_Parameters.cpp:222-253)");
                 for (uint32_t a = 0; a <= len1; a++, k++) {
-                    is_ref &= ref[i].q[j][k] == int16_t(scale * v);
-                    is_compact &= compact[i].q[j][k] == int16_t(scale * v);
+                    is_ref &= int64_t(ref[i].q[j][k]) == scale * v;
+                    is_compact &= int64_t(compact[i].q[j][k]) == scale * v;
                 }
                 v++;
             }
             scale *= 2 * v - 1;
+            if (scale > 32768) return fail(6, "ffv1 record: more than 32768 contexts (FFV1_Parameters.cpp:222-253)");
         }
     }
     if (!is_ref && !is_compact) return fail(6, "ffv1 record: quantisation tables other than this encoder's two models");

@@ -8,6 +8,7 @@ import re
 import struct
 import subprocess
 
+import numpy as np
 import pytest
 
 from rawcooked_amd import api, synth
@@ -105,6 +106,45 @@ def test_config_from_record(built, v):
     other = synth.PIX_Y8 if v["pixfmt"] != synth.PIX_Y8 else synth.PIX_RGB16_BE
     with pytest.raises(RuntimeError):
         api.config_from_record(rec, v["width"], v["height"], other, v["line_bytes"], 0)                         # stream does not match the files
+
+
+def test_hostile_records_and_files_are_refused_not_trusted(built):
+    """Mutated CodecPrivates re-sealed with a valid CRC, and mutated / truncated file headers: every call returns (an error or a
+    sane configuration).  tools/asan_cpu.sh runs this under ASan + UBSan; tools/fuzz/ holds the long-running version."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    vs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["ffv1"]
+    for v in vs[:6]:
+        rec = bytes.fromhex(v["config_record"])
+        for _ in range(1500):
+            b = bytearray(rec)
+            for _ in range(int(rng.integers(1, 5))):
+                b[int(rng.integers(0, len(b) - 4))] = int(rng.integers(0, 256))
+            c = api.lib().rcgpu_crc32_ffv1(bytes(b[:-4]), len(b) - 4)
+            b[-4:] = c.to_bytes(4, "big")
+            try:
+                cfg = api.config_from_record(bytes(b), v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["flags"])
+                assert 1 <= cfg.num_h_slices <= v["width"] and 1 <= cfg.num_v_slices <= v["height"] and cfg.slicecrc in (0, 1) and cfg.coder in (1, 2)
+            except RuntimeError:
+                pass
+    files = [synth.dpx_file(synth.components(33, 7, 3, 10, "film", seed=2), synth.PIX_RGB10_FILLEDA_BE),
+             synth.tiff_file(synth.components(32, 16, 3, 16, "film", seed=1), synth.PIX_RGB16_LE, trailer=b"xx"),
+             synth.exr_file(synth.components(32, 16, 3, 16, "film", seed=1)),
+             synth.wav_file(rng.integers(-1000, 1000, size=(300, 2)).astype(np.int32), 16)]
+    for d in files:
+        for _ in range(1500):
+            n = len(d) if rng.integers(0, 4) else int(rng.integers(0, min(len(d), 2048)))
+            b = bytearray(d[:n])
+            for _ in range(int(rng.integers(1, 6))):
+                if n:
+                    b[int(rng.integers(0, min(n, 2048)))] = int(rng.integers(0, 256))
+            for probe in (api.dpx_probe, api.tiff_probe, api.exr_probe, api.wav_probe):
+                try:
+                    i = probe(bytes(b))
+                    if hasattr(i, "data_offset"):
+                        assert i.data_offset + i.data_size <= len(b)
+                except RuntimeError:
+                    pass
 
 
 def test_exr_probe(built):

@@ -1,0 +1,31 @@
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "rcgpu.h"
+static std::vector<uint8_t> slurp(const char* p) { std::vector<uint8_t> v; FILE* f = fopen(p, "rb"); if (!f) return v; fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); v.resize(n); if (fread(v.data(), 1, n, f) != size_t(n)) v.clear(); fclose(f); return v; }
+static uint64_t rs = 0x1234567887654321ull;
+static uint32_t rnd() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return uint32_t(rs >> 16); }
+int main(int argc, char** argv)
+{
+    long iters = atol(argv[1]); size_t ok = 0, n_all = 0;
+    for (int a = 2; a < argc; a++) {
+        std::vector<uint8_t> seed = slurp(argv[a]);
+        for (long it = 0; it < iters; it++) {
+            size_t n = seed.size();
+            if (rnd() % 4 == 0) n = rnd() % (seed.size() + 1);
+            uint8_t* buf = static_cast<uint8_t*>(malloc(n ? n : 1));
+            memcpy(buf, seed.data(), n);
+            const int flips = rnd() % 5;
+            for (int k = 0; k < flips && n; k++) { const size_t at = rnd() % n; buf[at] = (rnd() & 1) ? uint8_t(rnd()) : uint8_t(buf[at] ^ (1u << (rnd() % 8))); }
+            if (n > 4 && (rnd() & 1)) { const uint32_t c = rcgpu_crc32_ffv1(buf, n - 4); buf[n - 4] = uint8_t(c >> 24); buf[n - 3] = uint8_t(c >> 16); buf[n - 2] = uint8_t(c >> 8); buf[n - 1] = uint8_t(c); }
+            for (uint32_t pf = 0; pf < RCGPU_PIX_COUNT; pf += 1 + rnd() % 5) {
+                rcgpu_ffv1_config cfg; memset(&cfg, 0, sizeof cfg); cfg.width = 64; cfg.height = 48; cfg.pixfmt = pf; cfg.line_bytes = 64 * 8;
+                ok += rcgpu_ffv1_config_from_record(buf, n, &cfg) == 0; n_all++;
+            }
+            free(buf);
+        }
+    }
+    printf("fuzz_rec: %zu calls, %zu accepted\n", n_all, ok);
+}

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Mutation fuzzing of everything that parses bytes it did not write, on the CPU under ASan + UBSan: the DPX / TIFF / EXR / WAV
+# probes and the FFV1 configuration-record reader (mutated records are re-sealed with a valid CRC).  Usage: bash tools/fuzz/run.sh [iterations per seed]
+set -e
+R=$(cd "$(dirname "$0")/../.." && pwd)
+T=$(mktemp -d); trap 'rm -rf $T' EXIT
+N=${1:-200000}
+mkdir -p $T/seeds $T/rec
+cd $R
+python - $T <<'PY'
+import sys, os
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+import oracle_binding as ob
+from rawcooked_amd import synth
+t = sys.argv[1]
+comp = synth.components(32, 16, 3, 16, "film", seed=1)
+w = lambda n, b: open(os.path.join(t, n), "wb").write(b)
+w("seeds/a.dpx", synth.dpx_file(comp, synth.PIX_RGB16_BE))
+w("seeds/b.dpx", synth.dpx_file(synth.components(33, 7, 3, 10, "film", seed=2), synth.PIX_RGB10_FILLEDA_BE))
+w("seeds/c.dpx", synth.dpx_file(synth.components(30, 9, 3, 12, "film", seed=2), synth.PIX_RGB12_PACKED_BE))
+w("seeds/a.tif", synth.tiff_file(comp, synth.PIX_RGB16_LE, trailer=b"xx"))
+w("seeds/a.exr", synth.exr_file(comp))
+s = np.random.default_rng(1).integers(-1000, 1000, size=(500, 2)).astype(np.int32)
+w("seeds/a.wav", synth.wav_file(s, 16))
+w("seeds/b.wav", synth.wav_file(np.tile(s, (1, 3)), 24, extensible=True, trailer_chunk=b"LIST\x04\x00\x00\x00abcd"))
+for i, (pixfmt, ctx, coder) in enumerate([(synth.PIX_RGB16_BE, 1, 1), (synth.PIX_RGB10_FILLEDA_BE, 0, 2), (synth.PIX_Y8, 1, 1), (synth.PIX_RGBA16_LE, 2, 2)]):
+    w("rec/rec%d.bin" % i, ob.config_record(ob.Params(64, 48, pixfmt, 2, 2, 1, ctx, 0, coder, 3)))
+PY
+cd $R/rawcooked_amd/csrc
+F="-O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=all -I../../include -I."
+g++ $F $R/tools/fuzz/fuzz_probes.cpp rc_common.cpp formats.cpp -o $T/fuzz_probes
+g++ $F $R/tools/fuzz/fuzz_record.cpp rc_common.cpp ffv1_host.cpp hashes.cpp -o $T/fuzz_record -lpthread
+$T/fuzz_probes $N $T/seeds/*
+$T/fuzz_record $N $T/rec/*
