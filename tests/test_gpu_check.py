@@ -83,7 +83,7 @@ def test_corrupted_packets_never_hang_or_fault(built, name):
     payload = open(os.path.join(G, v["frames"][0]["payload"]), "rb").read()
     rng = np.random.default_rng(5)
     variants = []
-    for k in range(24):
+    for k in range(24 * int(os.environ.get("RCGPU_SOAK_CORRUPT", "1"))):      # soak: RCGPU_SOAK_CORRUPT=40
         b = bytearray(good)
         kind = k % 4
         if kind == 0:
