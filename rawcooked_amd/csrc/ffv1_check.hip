@@ -493,6 +493,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     *out = nullptr;
     if (cfg->pixfmt >= RCGPU_PIX_COUNT || !cfg->width || !cfg->height || !cfg->num_h_slices || !cfg->num_v_slices || !cfg->max_batch)
         return fail(2, "ffv1 decoder: bad configuration");
+    if ((unsigned long long)cfg->width * cfg->height * 4 >= (1ull << 32)) return fail(2, "ffv1 decoder: %ux%u: sample indices are 32 bit (a picture may hold 2^30 pixels)", cfg->width, cfg->height);
     if (cfg->level == 1 && (cfg->num_h_slices * cfg->num_v_slices != 1 || cfg->slicecrc))
         return fail(2, "ffv1 decoder: FFV1 version 1 (-level 1) has one slice and no slice CRC");
     const pix_desc& px = pix(cfg->pixfmt);

@@ -1024,6 +1024,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     *out = nullptr;
     if (cfg->pixfmt >= RCGPU_PIX_COUNT) return fail(2, "ffv1: unknown pixel format %u", cfg->pixfmt);
     if (!cfg->width || !cfg->height) return fail(2, "ffv1: empty picture");
+    if ((unsigned long long)cfg->width * cfg->height * 4 >= (1ull << 32)) return fail(2, "ffv1: %ux%u: sample indices are 32 bit (a picture may hold 2^30 pixels)", cfg->width, cfg->height);
     if (!cfg->num_h_slices || !cfg->num_v_slices || cfg->num_h_slices < cfg->num_v_slices)
         return fail(2, "ffv1: slice grid %ux%u needs num_h >= num_v >= 1 (reference decoder limit, FFV1_Slice.cpp:127)", cfg->num_h_slices, cfg->num_v_slices);
     const uint32_t S = cfg->num_h_slices * cfg->num_v_slices;

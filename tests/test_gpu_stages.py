@@ -270,3 +270,18 @@ def test_level_1_single_slice_frames(built, pixfmt, coder, ctx):
         api.Ffv1Encoder(w, h, pixfmt, line_bytes, 2, 2, 0, ctx, level=1)
     with pytest.raises(RuntimeError):
         api.Ffv1Decoder(w, h, pixfmt, line_bytes, 2, 2, 0, ctx, level=1)
+
+
+def test_configurations_the_device_path_cannot_hold_are_refused(built):
+    """Argument errors come back as errors (rcgpu_last_error), not as device faults: empty and over-large pictures, slice grids the
+    reference's decoder would refuse, unknown layouts, a line stride shorter than a line."""
+    ok = dict(width=64, height=48, pixfmt=synth.PIX_RGB16_BE, line_bytes=64 * 6, num_h=2, num_v=2)
+    for bad in (dict(width=0), dict(height=0), dict(width=40000, height=40000, line_bytes=40000 * 6), dict(num_h=1, num_v=2), dict(num_h=65, num_v=1),
+                dict(pixfmt=99), dict(line_bytes=64 * 6 - 2)):
+        a = dict(ok, **bad)
+        with pytest.raises(RuntimeError):
+            api.Ffv1Encoder(a["width"], a["height"], a["pixfmt"], a["line_bytes"], a["num_h"], a["num_v"])
+    for bad in (dict(width=0), dict(width=40000, height=40000, line_bytes=40000 * 6), dict(pixfmt=99), dict(line_bytes=64 * 6 - 2)):
+        a = dict(ok, **bad)
+        with pytest.raises(RuntimeError):
+            api.Ffv1Decoder(a["width"], a["height"], a["pixfmt"], a["line_bytes"], a["num_h"], a["num_v"])
