@@ -1108,6 +1108,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             const size_t raw15 = size_t(g.w) * g.h * (d.bytes_pp ? d.bytes_pp : d.planes * 2u) * 3 / 2;
             size_t cap = (raw15 + std::min<size_t>(raw15, 256u << 10) + 4096 + 15) & ~size_t(15);
             if (cap > 0xFFFFFF + 64 && e->sp.version != 1) cap = 0xFFFFFF + 64;          // slice size field is 24 bit (version 1 has none)
+            if (cap >= (size_t(1) << 31)) { delete e; return fail(2, "ffv1: a version 1 frame of %ux%u does not fit the coder's 31-bit byte positions", g.w, g.h); }
             cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here
             g.cbuf_off_lo = uint32_t(cb); g.cbuf_off_hi = uint32_t(uint64_t(cb) >> 32); g.cbuf_cap = uint32_t(cap);
             cb += cap;
