@@ -114,6 +114,23 @@ def test_unmodified_rawcooked_drives_the_shim(built, refbin, tmp_path):
     assert os.path.exists(os.path.join(work, "pkg.mkv"))
 
 
+def test_output_version_2_appends_to_our_mkv(built, refbin, tmp_path):
+    """--output-version 2 (Main.cpp:905-929): the encoder gets no reversibility attachment; rawcooked appends its own EBML document
+    behind our Segment afterwards -- which only works because the Segment's size is exact -- and then reads the file back."""
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB10_FILLEDA_BE, 3, "film", audio=(2, 16, 48000, 6000))
+    r = run([refbin, "--output-version", "2", "--bin-name", SHIM, "--check", "--hash", "-y", "pkg"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    mkv = open(os.path.join(work, "pkg.mkv"), "rb").read()
+    assert mkv.count(b"\x1a\x45\xdf\xa3") >= 2                                           # a second EBML header follows the Segment
+    r = run([refbin, "-y", "pkg.mkv"], work)                                              # and the files come back byte for byte
+    assert r.returncode == 0, r.stdout + r.stderr
+    for dirpath, _, files in os.walk(os.path.join(work, "pkg")):
+        for fn in files:
+            src = os.path.join(dirpath, fn)
+            assert open(src, "rb").read() == open(os.path.join(work, "pkg.mkv.RAWcooked", os.path.relpath(src, work)), "rb").read(), fn
+
+
 def test_flipped_byte_is_detected(built, refbin, tmp_path):
     """Negative control (paddingbits.sh / check.sh style): corrupt one slice byte -> the reference must object."""
     work = str(tmp_path)
