@@ -216,6 +216,11 @@ int  rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes, uint32_t
 /* The same for n host buffers, e.g. memory-mapped source files during analysis (input_base::Hash, Lib/Uncompressed/../Input_Base.cpp:54-81
  * hashes them one at a time on one core): uploaded once, hashed side by side. */
 int  rcgpu_md5_host_batch(const uint8_t* const* bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, int device);
+/* The padding-bit test of the DPX analysis (dpx::ParseBuffer, Lib/Uncompressed/DPX/DPX.cpp:501-608) for n device payloads of one
+ * layout -- e.g. the frames just uploaded for encoding: first_nonzero[i] (host) = the reference's In_FirstNonZero relative to the
+ * payload, or UINT64_MAX when every padding bit is zero (then no "In" block is needed in the reversibility data). */
+int  rcgpu_dpx_padding_scan_device(const void* const* d_payloads, uint32_t n, uint32_t pixfmt, uint32_t width, uint32_t height, uint32_t flags,
+                                   uint64_t* first_nonzero, void* hip_stream);
 
 /* ===========================================================================================
  * 4. FLAC encoder (device) -- replaces FFmpeg's flacenc; inverse of flac_wrapper (Lib/CoDec/Wrapper.cpp:131-373)

@@ -104,6 +104,7 @@ SYMBOLS = {
     "rcgpu_mkv_close": (C.c_int, [_VP]),
     "rcgpu_md5": (None, [_VP, _SZ, _VP]),
     "rcgpu_crc32_ffv1": (C.c_uint32, [_VP, _SZ]),
+    "rcgpu_dpx_padding_scan_device": (C.c_int, [C.POINTER(_VP), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _VP]),
 }
 
 _lib = None
@@ -292,6 +293,14 @@ def compare_device(a: int, b: int, n: int, stream: int = 0) -> int:
     r = C.c_uint64()
     _check(lib().rcgpu_compare_device(a, b, n, C.byref(r), stream), "rcgpu_compare_device")
     return -1 if r.value == 0xFFFFFFFFFFFFFFFF else r.value
+
+
+def dpx_padding_scan_device(ptrs: list[int], pixfmt: int, width: int, height: int, flags: int = 0, stream: int = 0) -> list[int]:
+    """-> per payload the offset of the first non-zero padding position (DPX.cpp:501-608), or 2**64 - 1."""
+    n = len(ptrs)
+    out = (C.c_uint64 * n)()
+    _check(lib().rcgpu_dpx_padding_scan_device((_VP * n)(*ptrs), n, pixfmt, width, height, flags, out, stream), "rcgpu_dpx_padding_scan_device")
+    return list(out)
 
 
 def md5_device(ptrs: list[int], sizes: list[int], stream: int = 0) -> list[bytes]:

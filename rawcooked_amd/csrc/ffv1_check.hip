@@ -644,6 +644,102 @@ extern "C" int rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* d,
 }
 
 // First differing byte of two device buffers (frame_writer::CheckFile, FileWriter.cpp:448-463); *first_diff = ~0 when equal.
+// Padding-bit scan of DPX payloads, the test at the end of dpx::ParseBuffer (DPX.cpp:501-608): the reference walks the payload in
+// units of `step` bytes and tests one byte of each against `mask` (the 2 or 4 filler bits of the FilledA / FilledB layouts), except
+// for the unit that holds the end-of-line word of a line whose used bits do not fill it (packed layouts; Y 10-bit), which is
+// tested as a big-endian 32-bit word against `eol_mask`.  It stops at the first hit; In_FirstNonZero = min(i, EOL_i).
+struct pad_scan {
+    uint32_t step, start, byte_at, mask;   // for (i = start; i < total; i += step) test byte i & mask; byte_at = i's offset inside its unit
+    uint32_t eol_kind;                     // 0 none, 1 one word per line, 2 one word at the very end (RCGPU_FLAG_ALTERN)
+    uint32_t eol_off, line, eol_mask;      // kind 1: word at eol_off of every `line` bytes; kind 2: at total - 4
+    unsigned long long total;              // payload bytes
+};
+
+static int make_pad_scan(uint32_t pixfmt, uint32_t W, uint32_t H, uint32_t flags, pad_scan* out)
+{
+    if (pixfmt >= RCGPU_PIX_COUNT || pixfmt == RCGPU_PIX_EXR_RGB16) return fail(2, "padding scan: not a DPX layout (%u)", pixfmt);
+    const pix_desc& d = pix(pixfmt);
+    const bool altern = (flags & RCGPU_FLAG_ALTERN) != 0;
+    pad_scan s{};
+    const uint32_t line = payload_line_bytes(pixfmt, W, true);
+    s.total = payload_bytes(pixfmt, W, H, line, flags);
+    s.line = line;
+    const bool y10 = pixfmt == RCGPU_PIX_Y10_FILLEDA_BE || pixfmt == RCGPU_PIX_Y10_FILLEDB_BE;
+    const bool filled = y10 || pixfmt == RCGPU_PIX_RGB10_FILLEDA_BE || pixfmt == RCGPU_PIX_RGB10_FILLEDA_LE || pixfmt == RCGPU_PIX_RGB12_FILLEDA_BE ||
+                        pixfmt == RCGPU_PIX_RGB12_FILLEDA_LE || pixfmt == RCGPU_PIX_RGBA10_FILLEDA_BE || pixfmt == RCGPU_PIX_RGBA10_FILLEDA_LE ||
+                        pixfmt == RCGPU_PIX_RGBA12_FILLEDA_BE || pixfmt == RCGPU_PIX_RGBA12_FILLEDA_LE;
+    if (!filled) {                                                  // packing::Packed, DPX.cpp:507-521
+        const unsigned long long used = (unsigned long long)W * d.bits * d.planes;
+        const uint32_t rem = uint32_t(used % 32);
+        if (rem) { s.eol_kind = 1; s.eol_off = uint32_t(used / 32) * 4; s.line = s.eol_off + 4; s.step = s.line; s.start = s.eol_off; s.byte_at = 0; s.eol_mask = 0xFFFFFFFFu << rem; }
+        *out = s; return 0;
+    }
+    const bool filled_b = pixfmt == RCGPU_PIX_Y10_FILLEDB_BE;       // DPX.cpp:523-566
+    s.step = d.bits == 10 ? 4 : 2;
+    s.byte_at = (d.big_endian != filled_b) ? s.step - 1 : 0;
+    s.start = s.byte_at;
+    s.mask = d.bits == 10 ? 0x3 : 0xF;
+    if (filled_b) s.mask <<= d.bits == 10 ? 6 : 4;
+    if (y10) {
+        uint32_t rem = altern ? uint32_t(((unsigned long long)W * H) % 3) : W % 3;
+        if (rem) {
+            if (altern) s.eol_kind = 2;
+            else { s.eol_kind = 1; s.eol_off = (W / 3) * 4; s.line = s.eol_off + 4; }
+            rem *= 10;
+            if (!filled_b) rem += 2;
+            s.eol_mask = 0xFFFFFFFFu << rem;
+            if (!filled_b) s.eol_mask |= 0x3;
+        }
+    }
+    *out = s; return 0;
+}
+
+__global__ __launch_bounds__(256) void k_padscan(const uint8_t* const* __restrict__ payloads, pad_scan S, unsigned long long* __restrict__ first)
+{
+    const uint8_t* p = payloads[blockIdx.y];
+    const unsigned long long units = S.step && S.total > S.start ? (S.total - S.start + S.step - 1) / S.step : 0;
+    unsigned long long best = ~0ull;
+    for (unsigned long long u = blockIdx.x * 256ull + threadIdx.x; u < units; u += gridDim.x * 256ull) {
+        const unsigned long long i = S.start + u * S.step;
+        bool eol = false; unsigned long long at = 0;
+        if (S.eol_kind == 1) { const unsigned long long ln = i / S.line; eol = i - ln * S.line == S.eol_off + S.byte_at; at = ln * S.line + S.eol_off; }
+        else if (S.eol_kind == 2) { at = S.total - 4; eol = i >= at && i - S.step < at; }
+        bool hit;
+        if (eol) { const uint32_t w = (uint32_t(p[at]) << 24) | (uint32_t(p[at + 1]) << 16) | (uint32_t(p[at + 2]) << 8) | p[at + 3]; hit = (w & S.eol_mask) != 0; }
+        else { hit = (p[i] & S.mask) != 0; at = i; }
+        if (hit) { best = at; break; }            // a thread's units only grow: its first hit is its smallest
+    }
+    if (best != ~0ull) atomicMin(&first[blockIdx.y], best);
+}
+
+// First non-zero padding position of n device payloads of one layout (dpx::ParseBuffer's scan, DPX.cpp:501-608: In_FirstNonZero
+// relative to the payload), ~0 where all padding is zero -- the case in which the reversibility data needs no "In" block.
+extern "C" int rcgpu_dpx_padding_scan_device(const void* const* d_payloads, uint32_t n, uint32_t pixfmt, uint32_t width, uint32_t height, uint32_t flags,
+                                             uint64_t* first_nonzero, void* hip_stream)
+{
+    clear_error();
+    if (!d_payloads || !first_nonzero || !n) return fail(1, "padding scan: null argument");
+    pad_scan S;
+    if (int r = make_pad_scan(pixfmt, width, height, flags, &S)) return r;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    unsigned long long* d_res = nullptr; const uint8_t** d_ptrs = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_res), 8 * size_t(n)));
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_ptrs), sizeof(void*) * size_t(n));
+    if (he == hipSuccess) he = hipMemcpyAsync(d_ptrs, d_payloads, sizeof(void*) * size_t(n), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemsetAsync(d_res, 0xFF, 8 * size_t(n), st);
+    if (he == hipSuccess && S.step) {
+        const unsigned long long units = S.total > S.start ? (S.total - S.start + S.step - 1) / S.step : 0;
+        const uint32_t blocks = uint32_t(std::min<unsigned long long>((units + 255) / 256, 4096));
+        hipLaunchKernelGGL(k_padscan, dim3(blocks ? blocks : 1, n), dim3(256), 0, st, d_ptrs, S, d_res);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(first_nonzero, d_res, 8 * size_t(n), hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    (void)hipFree(d_res); if (d_ptrs) (void)hipFree(d_ptrs);
+    if (he != hipSuccess) return fail(100, "padding scan: %s", hipGetErrorString(he));
+    return 0;
+}
+
 extern "C" int rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t* first_diff, void* hip_stream)
 {
     clear_error();

@@ -24,6 +24,7 @@ def lib():
         L.ffv1o_payload_bytes.restype = C.c_size_t
         L.ffv1o_last_decisions.restype = C.c_uint64
         L.ffv1o_crc32.restype = C.c_uint32
+        L.dpxo_padding_first_nonzero.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -113,3 +114,8 @@ def flac_decode(ch, rate, bits, data: bytes, pcm_len: int) -> bytes:
     r = L.flaco_decode(C.byref(p), data, C.c_size_t(len(data)), out, C.c_size_t(len(out)))
     assert r >= 0, f"oracle FLAC decoder error {r}"
     return out.raw[:r]
+
+
+def dpx_padding_first_nonzero(payload: bytes, width: int, height: int, bit_depth: int, components: int, big_endian: bool, packing: int, altern: bool) -> int:
+    """DPX.cpp:501-608 restated (oracle/dpx_oracle.c); packing 0 Packed, 1 FilledA, 2 FilledB.  -> offset or 2**64 - 1."""
+    return lib().dpxo_padding_first_nonzero(payload, C.c_uint64(len(payload)), width, height, bit_depth, components, int(big_endian), packing, int(altern))

@@ -139,3 +139,40 @@ def test_md5_of_host_buffers(built):
     rng = np.random.default_rng(3)
     bufs = [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000, 65536, 1 << 20)]
     assert api.md5_host_batch(bufs) == [hashlib.md5(b).digest() for b in bufs]
+
+
+DPX_LAYOUTS = [p for p in range(23) if p != synth.PIX_EXR_RGB16]
+
+
+@pytest.mark.parametrize("pixfmt", DPX_LAYOUTS)
+def test_padding_scan_matches_the_reference_rule(built, pixfmt):
+    """rcgpu_dpx_padding_scan_device against oracle/dpx_oracle.c (DPX.cpp:501-608 restated from the header facts): clean payloads,
+    then payloads with single bits set at random places -- inside samples (must be ignored unless the reference's own mask covers
+    them), in filler bits, in line padding, in the last word."""
+    import numpy as np
+    bits, nc, _, be = synth.PIX_INFO[pixfmt]
+    packing = synth.DPX_PACKING.get(pixfmt, 1 if bits in (10, 12) else 0)
+    rng = np.random.default_rng(100 + pixfmt)
+    for (w, h) in ((37, 9), (64, 5), (50, 7), (3, 2)):
+        for altern in ((False, True) if pixfmt in (synth.PIX_Y10_FILLEDA_BE, synth.PIX_Y10_FILLEDB_BE) else (False,)):
+            flags = synth.FLAG_ALTERN if altern else 0
+            clean, _ = synth.pack_payload(synth.components(w, h, nc, bits, "noise", seed=w + h), pixfmt, True, flags)
+            variants = [bytes(clean)]
+            for k in range(40):
+                b = bytearray(clean)
+                for _ in range(int(rng.integers(1, 4))):
+                    at = int(rng.integers(0, len(b))) if k % 3 else len(b) - 1 - int(rng.integers(0, min(len(b), 8)))
+                    b[at] ^= 1 << int(rng.integers(0, 8))
+                variants.append(bytes(b))
+            zeroed = bytearray(len(clean))                                   # all-zero payload, then one bit anywhere
+            variants.append(bytes(zeroed))
+            for k in range(40):
+                b = bytearray(len(clean)); b[int(rng.integers(0, len(b)))] = 1 << int(rng.integers(0, 8))
+                variants.append(bytes(b))
+            want = [ob.dpx_padding_first_nonzero(v, w, h, bits, nc, be, packing, altern) for v in variants]
+            dv = [dev(v) for v in variants]
+            got = api.dpx_padding_scan_device([t.data_ptr() for t in dv], pixfmt, w, h, flags)
+            assert got == want, (pixfmt, w, h, altern, [i for i in range(len(want)) if got[i] != want[i]][:5])
+            assert want[0] == 2 ** 64 - 1 or packing == 0                     # synth writes zero filler bits
+    with pytest.raises(RuntimeError):
+        api.dpx_padding_scan_device([0], synth.PIX_EXR_RGB16, 8, 8)

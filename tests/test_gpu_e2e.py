@@ -131,6 +131,27 @@ def test_output_version_2_appends_to_our_mkv(built, refbin, tmp_path):
             assert open(src, "rb").read() == open(os.path.join(work, "pkg.mkv.RAWcooked", os.path.relpath(src, work)), "rb").read(), fn
 
 
+def test_non_zero_padding_bits_survive_through_the_reversibility_data(built, refbin, tmp_path):
+    """--check-padding: the reference's analysis finds filler bits that are not zero (DPX.cpp:501-608) and keeps them in the
+    reversibility data; the encoder must ignore them and the rebuilt files must carry them again."""
+    work = str(tmp_path)
+    make_package(work, 50, 38, synth.PIX_RGB10_FILLEDA_BE, 3, "film")
+    for i in range(3):
+        p = os.path.join(work, "pkg", "img", "f_%06d.dpx" % i)
+        d = bytearray(open(p, "rb").read())
+        off = int.from_bytes(d[4:8], "big")                               # offset to image data
+        for k in range(off + 3, len(d), 4 * (7 + i)):                     # low two bits of some big-endian words
+            d[k] |= 1 + (k % 3 == 0)
+        open(p, "wb").write(d)
+    r = run([refbin, "--bin-name", SHIM, "--check-padding", "--check", "--hash", "-y", "pkg"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    r = run([refbin, "-y", "pkg.mkv"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for i in range(3):
+        rel = os.path.join("pkg", "img", "f_%06d.dpx" % i)
+        assert open(os.path.join(work, rel), "rb").read() == open(os.path.join(work, "pkg.mkv.RAWcooked", rel), "rb").read()
+
+
 def test_flipped_byte_is_detected(built, refbin, tmp_path):
     """Negative control (paddingbits.sh / check.sh style): corrupt one slice byte -> the reference must object."""
     work = str(tmp_path)
