@@ -178,7 +178,9 @@ def test_random_geometries_mixed_content(built, seed):
     slices end in partial chunks of every length."""
     import torch
     rng = np.random.default_rng(1000 + seed)
-    pixfmt = [synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGB8, synth.PIX_Y16_LE, synth.PIX_RGBA16_LE, synth.PIX_Y8][seed % 6]
+    pixfmt = [synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGB8, synth.PIX_Y16_LE, synth.PIX_RGBA16_LE, synth.PIX_Y8,
+              synth.PIX_RGB12_PACKED_BE, synth.PIX_Y10_FILLEDA_BE, synth.PIX_RGBA10_FILLEDA_LE, synth.PIX_RGBA12_PACKED_BE, synth.PIX_Y12_PACKED_BE,
+              synth.PIX_RGB12_FILLEDA_LE][seed % 12]
     bits, nc, _, _ = synth.PIX_INFO[pixfmt]
     w, h = int(rng.integers(24, 200)), int(rng.integers(10, 120))
     slices = [1, 4, 6, 9, 12][int(rng.integers(0, 5))]
@@ -210,6 +212,9 @@ def test_random_geometries_mixed_content(built, seed):
         for f in range(3):
             assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"context model {ctx}, frame {f}, {w}x{h} {nh}x{nv} segments {segments}"
         enc.close()
+        dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=3)        # and back through the device decoder
+        assert dec.decode_host(packets, len(payloads[0])) == [bytes(x) for x in payloads], f"decoder, context model {ctx}, {w}x{h} {nh}x{nv}"
+        dec.close()
 
 
 @pytest.mark.parametrize("w,h,slices,pixfmt", [(2, 2, 1, synth.PIX_RGB16_BE), (3, 5, 1, synth.PIX_RGB10_FILLEDA_BE), (5, 4, 4, synth.PIX_RGB8), (64, 3, 1, synth.PIX_Y16_BE),
