@@ -257,14 +257,16 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     // runs the device.  Short jobs get by with one.
     size_t longest = 0;
     for (const video_plan& v : videos) longest = std::max(longest, v.files.size());
-    const int nworkers = ndev * (longest > 8 ? 2 : 1);
+    int per_dev = longest > 8 ? 2 : 1;
+    if (const char* w = getenv("RCGPU_WORKERS")) per_dev = std::max(1, std::min(8, atoi(w)));          // workers (encoders, host threads) per device
+    const int nworkers = ndev * per_dev;
     const uint32_t batch = uint32_t(std::max(0L, opt.num("rcgpu_batch", 0)));      // 0: sized from the picture and the sequence below
     for (auto& o : order) {
         if (o.first) {
             video_plan& v = videos[o.second];
             uint32_t& F = v.F;
             v.enc_first = encoders.size();
-            // frames in flight per device: bounded by HBM (intermediates ~1.3 GB per 4K frame) and by the sequence length
+            // frames in flight per worker: bounded by HBM (~0.5 GB per 4K frame) and by the sequence length
             const uint64_t px = uint64_t(v.info.width) * v.info.height;
             F = batch ? batch : uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (uint64_t(96) << 30) / (px * 160 + 1))));
             F = uint32_t(std::min<uint64_t>(F, (v.files.size() + nworkers - 1) / nworkers));

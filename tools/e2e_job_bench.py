@@ -50,6 +50,8 @@ argv = shlex.split(r.stdout.strip())
 t0 = time.time(); r = run([shim] + argv[1:], work, env=dict(os.environ, RCGPU_TRACE="1")); t_enc = time.time() - t0
 print(r.stderr)
 assert r.returncode == 0, r.stdout + r.stderr
+for wk in [int(x) for x in os.environ.get("RCGPU_E2E_WORKERS", "").split(",") if x]:      # optional sweep of workers per device
+    t1 = time.time(); r2 = run([shim] + argv[1:], work, env=dict(os.environ, RCGPU_WORKERS=str(wk))); print(f"RCGPU_WORKERS={wk}: {time.time() - t1:.2f} s, rc {r2.returncode}")
 size = os.path.getsize(work + "/pkg.mkv")
 t0 = time.time(); r = run([ref, "--check", "pkg.mkv"], work, timeout=600); t_chk = time.time() - t0
 ok = r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout
