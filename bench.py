@@ -149,14 +149,35 @@ def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, 
     D = max(F, args.check_batch)
     sizes = [sizes[i % F] for i in range(D)]
     dec = api.Ffv1Decoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=D, device=device)
-    outs = torch.empty((D, line_bytes * height), dtype=torch.uint8, device=frames.device)
+    payload_bytes = line_bytes * height
+    # Two sets of output buffers when they fit: while batch k is decoded, the MD5 of every frame of batch k-1 is computed on a second
+    # stream (one lane per frame: ~1.1 s for a 53 MB frame whatever the count, hidden behind the 3.7 s of decoding) and compared
+    # with hashlib's digest of the source -- FileWriter.cpp:596-727's verification, inside the timed region.
+    outs = [torch.empty((D, payload_bytes), dtype=torch.uint8, device=frames.device)]
+    try:
+        outs.append(torch.empty((D, payload_bytes), dtype=torch.uint8, device=frames.device))
+    except RuntimeError:
+        torch.cuda.empty_cache()
+    pipelined = len(outs) == 2
     pk = [d_packets.data_ptr() + (i % F) * stride for i in range(D)]
-    op = [outs[i].data_ptr() for i in range(D)]
+    ops = [[o[i].data_ptr() for i in range(D)] for o in outs]
+    op = ops[0]
     ptrs = [ptrs[i % F] for i in range(D)]
-    F = D
+    import hashlib
+    want = [hashlib.md5(bytes(frames[i].cpu().numpy())).digest() for i in range(F)]        # F distinct sources, reused round-robin
+    side = torch.cuda.Stream()
+    F0, F = F, D
+    state = {"k": 0, "bad": 0, "hashed": 0, "ev": None}
 
     def step():
-        dec.decode_device(pk, sizes, op, stream, check=False)
+        k = state["k"]; cur = k & 1 if pipelined else 0
+        dec.decode_device(pk, sizes, ops[cur], stream, check=False)
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+        if pipelined and state["ev"] is not None:
+            side.wait_event(state["ev"])
+            got = api.md5_device(ops[cur ^ 1], [payload_bytes] * D, side.cuda_stream)
+            state["bad"] += sum(got[i] != want[i % F0] for i in range(D)); state["hashed"] += D
+        state["ev"] = ev; state["k"] = k + 1
 
     for _ in range(max(0, args.warmup)):
         step()
@@ -166,13 +187,13 @@ def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, 
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    op = ops[(state["k"] - 1) & 1 if pipelined else 0]                                     # the batch decoded last: verified below
     kt = dec.kernel_times()
     t1 = time.perf_counter()
     same = all(api.compare_device(op[i], ptrs[i], line_bytes * height, stream) == -1 for i in range(F))
     md5 = api.md5_device(op[:min(F, 64)], [line_bytes * height] * min(F, 64), stream)
     t_verify = time.perf_counter() - t1
-    import hashlib
-    ok_md5 = md5[0] == hashlib.md5(bytes(frames[0].cpu().numpy())).digest()
+    ok_md5 = md5[0] == want[0] and state["bad"] == 0
     payload = line_bytes * height
     packet_avg = sum(sizes) / len(sizes)
     dom = "k_dec_slices"
@@ -182,7 +203,8 @@ def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, 
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u16", "data": "synthetic",
         "config": {"workload": f"{width}x{height} RGB16 FFV1 packets (slices={args.slices}) -> payload, byte compare + MD5 on device", "frames_per_step_per_gpu": F,
-                   "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "verify_seconds_all_frames": round(t_verify, 3)},
+                   "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "md5_inside_timed_region": state["hashed"],
+                   "verify_seconds_last_batch": round(t_verify, 3)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                      "traffic": None, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}},
         **({"cpu_baseline": cpu} if cpu else {})}))

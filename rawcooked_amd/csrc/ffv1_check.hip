@@ -764,16 +764,19 @@ extern "C" int rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes
     clear_error();
     if (!d_bufs || !sizes || !out_md5 || !n) return fail(1, "md5: null argument");
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    // everything is ordered on `st` alone (stream-ordered allocations, asynchronous copies): a caller may hash one batch on a side
+    // stream while another stream decodes the next one
     const uint8_t** d_p = nullptr; unsigned long long* d_s = nullptr; uint8_t* d_o = nullptr;
-    hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_p), sizeof(void*) * n);
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_s), 8 * n);
-    if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_o), 16 * n);
-    if (he == hipSuccess) he = hipMemcpy(d_p, d_bufs, sizeof(void*) * n, hipMemcpyHostToDevice);
-    if (he == hipSuccess) he = hipMemcpy(d_s, sizes, 8 * n, hipMemcpyHostToDevice);
+    hipError_t he = hipMallocAsync(reinterpret_cast<void**>(&d_p), sizeof(void*) * n, st);
+    if (he == hipSuccess) he = hipMallocAsync(reinterpret_cast<void**>(&d_s), 8 * size_t(n), st);
+    if (he == hipSuccess) he = hipMallocAsync(reinterpret_cast<void**>(&d_o), 16 * size_t(n), st);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_p, d_bufs, sizeof(void*) * n, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_s, sizes, 8 * size_t(n), hipMemcpyHostToDevice, st);
     if (he == hipSuccess) { hipLaunchKernelGGL(k_md5, dim3((n + 63) / 64), dim3(64), 0, st, d_p, d_s, n, d_o); he = hipGetLastError(); }
-    if (he == hipSuccess) he = hipStreamSynchronize(st);
-    if (he == hipSuccess) he = hipMemcpy(out_md5, d_o, 16 * n, hipMemcpyDeviceToHost);
-    for (void* p : { (void*)d_p, (void*)d_s, (void*)d_o }) if (p) (void)hipFree(p);
+    if (he == hipSuccess) he = hipMemcpyAsync(out_md5, d_o, 16 * size_t(n), hipMemcpyDeviceToHost, st);
+    for (void* p : { (void*)d_p, (void*)d_s, (void*)d_o }) if (p) (void)hipFreeAsync(p, st);
+    const hipError_t hs = hipStreamSynchronize(st);
+    if (he == hipSuccess) he = hs;
     if (he != hipSuccess) return fail(100, "md5: %s", hipGetErrorString(he));
     return 0;
 }
