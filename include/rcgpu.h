@@ -109,6 +109,7 @@ typedef struct {
     uint32_t block_align;
     uint64_t data_offset, data_size;
     char     flavor[64];        /* "WAV/PCM/48kHz/24bit/6ch/S/LE" */
+    uint32_t format_tag;        /* 1 integer PCM, 3 IEEE float (WAV.cpp:205-221); bits > 24 or float: only `-c:a copy` (CLI/Main.cpp:300-317) */
 } rcgpu_audio_info;
 
 int rcgpu_dpx_probe (const uint8_t* file, size_t size, rcgpu_image_info* out);
@@ -257,6 +258,9 @@ int  rcgpu_mkv_add_video(rcgpu_mkv* mux, const uint8_t* codec_private, size_t cp
                          uint32_t fps_num, uint32_t fps_den);
 int  rcgpu_mkv_add_audio(rcgpu_mkv* mux, const uint8_t* codec_private, size_t cp_size, uint32_t channels,
                          uint32_t sample_rate, uint32_t bits_per_sample);
+/* A PCM track for `-c:a copy` (CLI/Main.cpp:300-317, test/pcm.sh): CodecID A_PCM/INT/LIT or A_PCM/FLOAT/IEEE, no CodecPrivate;
+   the blocks carry whole sample frames of the WAV data chunk as they are (reader: pcm_wrapper, Lib/CoDec/Wrapper.cpp:376-388). */
+int  rcgpu_mkv_add_audio_pcm(rcgpu_mkv* mux, int is_float, uint32_t channels, uint32_t sample_rate, uint32_t bits_per_sample);
 int  rcgpu_mkv_add_attachment(rcgpu_mkv* mux, const char* name, const char* mime, const uint8_t* data, size_t size);
 /* A track-level SimpleTag (what FFmpeg writes for `-metadata:s:N name=value`; the reference adds one to EXR packages). */
 int  rcgpu_mkv_add_tag(rcgpu_mkv* mux, int track, const char* name, const char* value);

@@ -28,7 +28,7 @@ class ImageInfo(C.Structure):
 
 class AudioInfo(C.Structure):
     _fields_ = [("channels", C.c_uint32), ("sample_rate", C.c_uint32), ("bits_per_sample", C.c_uint32), ("block_align", C.c_uint32),
-                ("data_offset", C.c_uint64), ("data_size", C.c_uint64), ("flavor", C.c_char * 64)]
+                ("data_offset", C.c_uint64), ("data_size", C.c_uint64), ("flavor", C.c_char * 64), ("format_tag", C.c_uint32)]
 
 
 class Ffv1Config(C.Structure):
@@ -96,6 +96,7 @@ SYMBOLS = {
     "rcgpu_mkv_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_VP)]),
     "rcgpu_mkv_add_video": (C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rcgpu_mkv_add_audio": (C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rcgpu_mkv_add_audio_pcm": (C.c_int, [_VP, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rcgpu_mkv_add_attachment": (C.c_int, [_VP, C.c_char_p, C.c_char_p, _VP, _SZ]),
     "rcgpu_mkv_add_tag": (C.c_int, [_VP, C.c_int, C.c_char_p, C.c_char_p]),
     "rcgpu_mkv_begin": (C.c_int, [_VP]),

@@ -355,7 +355,7 @@ extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* 
                 if (rd16(f + pos + 18, false) != out->bits_per_sample) return fail(8, "wav: ValidBitsPerSample differs");
                 tag = uint16_t(rd32(f + pos + 24, false));
             }
-            if (tag != 1) return fail(9, "wav: format tag %u is not integer PCM", tag);
+            if (tag != 1 && tag != 3) return fail(9, "wav: format tag %u is neither integer PCM nor IEEE float", tag);
             have_fmt = true;
         } else if (name == 0x64617461) {          // "data"  WAV.cpp:390-436
             if (!have_fmt) return fail(10, "wav: data chunk before fmt chunk");
@@ -365,10 +365,14 @@ extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* 
             out->data_offset = pos; out->data_size = csize;
             // flavor table WAV.cpp:125-221: channels {1,2,4,6,8}... kept permissive up to 8 channels
             if (out->channels < 1 || out->channels > 8) return fail(13, "wav: %u channels not supported", out->channels);
-            if (out->bits_per_sample != 8 && out->bits_per_sample != 16 && out->bits_per_sample != 24)
-                return fail(14, "wav: %u-bit PCM cannot be coded as FLAC (reference forces -c:a copy, CLI/Main.cpp:300-317)", out->bits_per_sample);
+            // WAV_Tested, WAV.cpp:125-203: 8/16/24/32-bit integer, 32-bit float; more than 24 bits (and float) cannot be FLAC and
+            // travel as PCM (`-c:a copy`, CLI/Main.cpp:300-317) -- the job decides, the probe only describes
+            if (out->bits_per_sample != 8 && out->bits_per_sample != 16 && out->bits_per_sample != 24 && out->bits_per_sample != 32)
+                return fail(14, "wav: %u-bit PCM is not supported", out->bits_per_sample);
+            if (tag == 3 && out->bits_per_sample != 32) return fail(14, "wav: %u-bit float is not supported", out->bits_per_sample);
+            out->format_tag = tag;
             snprintf(out->flavor, sizeof out->flavor, "WAV/PCM/%ukHz/%ubit/%uch/%s/LE", out->sample_rate / 1000,
-                     out->bits_per_sample, out->channels, out->bits_per_sample == 8 ? "U" : "S");
+                     out->bits_per_sample, out->channels, tag == 3 ? "F" : out->bits_per_sample == 8 ? "U" : "S");
             return 0;
         }
         pos += csize;

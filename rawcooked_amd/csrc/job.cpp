@@ -112,7 +112,9 @@ struct audio_plan {
     rcgpu_audio_info info{};
     std::vector<uint8_t> frames;              // concatenated FLAC frames
     std::vector<uint32_t> frame_sizes;
-    uint32_t block_size = 0;
+    uint32_t block_size = 0;                  // samples per frame / per PCM block
+    std::unique_ptr<mapped_file> pcm;         // -c:a copy: the WAV itself; blocks are cut out of its data chunk
+    const uint8_t* bytes() const { return pcm ? pcm->data + info.data_offset : frames.data(); }
     std::vector<uint8_t> codec_private;
     int track = 0;
 };
@@ -153,7 +155,12 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         if (job->options[i]) opt.kv[job->options[i]] = job->options[i + 1] ? job->options[i + 1] : "";
     // What this encoder implements of the option surface (defaults: CLI/Global.cpp:938-989)
     if (const char* cv = opt.get("c:v")) if (strcmp(cv, "ffv1") != 0) return bail(fail(2, "video codec %s is not supported by rcgpu (only ffv1)", cv));
-    if (const char* ca = opt.get("c:a")) if (strcmp(ca, "flac") != 0) return bail(fail(2, "audio codec %s is not supported by rcgpu (only flac)", ca));
+    // -c:a copy: what the reference asks for above 24 bits (CLI/Main.cpp:300-317) and what test/pcm.sh asks for by hand
+    bool audio_copy = false;
+    if (const char* ca = opt.get("c:a")) {
+        audio_copy = !strcmp(ca, "copy");
+        if (!audio_copy && strcmp(ca, "flac") != 0) return bail(fail(2, "audio codec %s is not supported by rcgpu (flac or copy)", ca));
+    }
     const long coder = opt.num("coder", 1);
     if (coder != 1 && coder != 2) return bail(fail(2, "-coder %ld is not supported by rcgpu (1: range coder, 2: range coder with a transmitted state table)", coder));
     const long level = opt.num("level", 3);
@@ -173,12 +180,18 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     const bool overwrite = opt.has("y") && !opt.has("n");
     if (!overwrite && file_exists(job->output_path)) return bail(fail(3, "output file %s already exists (use -y)", job->output_path));
 
+    // Every coded byte comes from the device; the only job that needs none is one that codes nothing (PCM tracks copied as they are)
+    bool codes_something = !audio_copy;
+    for (size_t si = 0; si < job->n_streams && !codes_something; si++) codes_something = job->streams[si].slices != 0;
     int ndev_visible = rcgpu_device_count();
-    if (ndev_visible <= 0) return bail(fail(4, "no HIP device available -- rcgpu has no CPU encode path"));
+    if (ndev_visible <= 0 && codes_something) return bail(fail(4, "no HIP device available -- rcgpu has no CPU encode path"));
     const int dev0 = std::max(0, job->device_first);
     int ndev = job->device_count > 0 ? job->device_count : ndev_visible - dev0;
-    if (dev0 >= ndev_visible || ndev <= 0) return bail(fail(4, "device selection %d+%d is outside the %d visible devices", dev0, job->device_count, ndev_visible));
-    ndev = std::min(ndev, ndev_visible - dev0);
+    if (codes_something) {
+        if (dev0 >= ndev_visible || ndev <= 0) return bail(fail(4, "device selection %d+%d is outside the %d visible devices", dev0, job->device_count, ndev_visible));
+        ndev = std::min(ndev, ndev_visible - dev0);
+    } else
+        ndev = 1;
 
     mark("options parsed, devices counted");
     // ---- analyse the streams
@@ -224,6 +237,18 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     mark("streams analysed");
     // ---- audio first: A_FLAC CodecPrivate (STREAMINFO) must be final before the header is written
     for (audio_plan& a : audios) {
+        if (audio_copy) {
+            // blocks as FFmpeg's wav demuxer cuts them: at most 4096 bytes, whole sample frames (the reader concatenates them)
+            a.pcm.reset(new mapped_file);
+            if (!a.pcm->open(a.file)) return bail(fail(30, "cannot open %s", a.file.c_str()));
+            a.block_size = std::max(1u, 4096u / a.info.block_align);
+            const uint64_t nsamples = a.info.data_size / a.info.block_align;
+            a.frame_sizes.assign(size_t(nsamples / a.block_size), a.block_size * a.info.block_align);
+            if (nsamples % a.block_size) a.frame_sizes.push_back(uint32_t(nsamples % a.block_size) * a.info.block_align);
+            continue;
+        }
+        if (a.info.bits_per_sample > 24 || a.info.format_tag != 1)
+            return bail(fail(14, "FLAC encoding is not supported with %u-bit%s audio input, use -c:a copy", a.info.bits_per_sample, a.info.format_tag == 3 ? " float" : ""));   // wording: CLI/Main.cpp:311-313
         mapped_file f;
         if (!f.open(a.file)) return bail(fail(30, "cannot open %s", a.file.c_str()));
         rcgpu_flac_config fc{}; fc.channels = a.info.channels; fc.sample_rate = a.info.sample_rate; fc.bits_per_sample = a.info.bits_per_sample;
@@ -291,7 +316,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             }
         } else {
             audio_plan& a = audios[o.second];
-            a.track = rcgpu_mkv_add_audio(mux, a.codec_private.data(), a.codec_private.size(), a.info.channels, a.info.sample_rate, a.info.bits_per_sample);
+            a.track = audio_copy ? rcgpu_mkv_add_audio_pcm(mux, a.info.format_tag == 3, a.info.channels, a.info.sample_rate, a.info.bits_per_sample)
+                                 : rcgpu_mkv_add_audio(mux, a.codec_private.data(), a.codec_private.size(), a.info.channels, a.info.sample_rate, a.info.bits_per_sample);
             if (a.track < 0) return bail(8);
         }
     }
@@ -315,7 +341,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             while (audio_pos[ai] < a.frame_sizes.size()) {
                 const uint64_t pts = uint64_t(audio_pos[ai]) * a.block_size * 1000000000ull / a.info.sample_rate;
                 if (pts > pts_ns_limit) break;
-                if (int r = rcgpu_mkv_write_block(mux, a.track, pts, a.frames.data() + audio_off[ai], a.frame_sizes[audio_pos[ai]], 1)) return r;
+                if (int r = rcgpu_mkv_write_block(mux, a.track, pts, a.bytes() + audio_off[ai], a.frame_sizes[audio_pos[ai]], 1)) return r;
                 audio_off[ai] += a.frame_sizes[audio_pos[ai]++];
             }
         }

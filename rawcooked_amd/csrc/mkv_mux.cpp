@@ -47,6 +47,7 @@ struct track {
     std::vector<uint8_t> codec_private;
     uint32_t width = 0, height = 0, fps_num = 0, fps_den = 0;
     uint32_t channels = 0, sample_rate = 0, bits = 0;
+    const char* codec_id = nullptr; // audio only; nullptr = A_FLAC
     uint64_t cp_file_pos = 0;      // absolute file offset of the CodecPrivate payload
     uint64_t uid = 0;              // TrackUID, referenced by Tags
     uint64_t last_pts_ms = 0, end_ms = 0;
@@ -129,9 +130,18 @@ extern "C" int rcgpu_mkv_add_audio(rcgpu_mkv* m, const uint8_t* cp, size_t cp_si
 {
     if (!m || m->begun) { fail(1, "mkv: add_audio after begin"); return -1; }
     if (m->tracks.size() >= 126) { fail(1, "mkv: too many tracks"); return -1; }
-    track t; t.video = false; t.codec_private.assign(cp, cp + cp_size); t.channels = ch; t.sample_rate = rate; t.bits = bits;
+    track t; t.video = false; if (cp && cp_size) t.codec_private.assign(cp, cp + cp_size); t.channels = ch; t.sample_rate = rate; t.bits = bits;
     m->tracks.push_back(t);
     return int(m->tracks.size());
+}
+
+extern "C" int rcgpu_mkv_add_audio_pcm(rcgpu_mkv* m, int is_float, uint32_t ch, uint32_t rate, uint32_t bits)
+{
+    // what FFmpeg's muxer writes for pcm_u8 / pcm_s16le / pcm_s24le / pcm_s32le and pcm_f32le; the reader maps all of them to its
+    // pass-through wrapper (Lib/CoDec/Wrapper.cpp:41-49,376-388) and takes depth, sign and endianness from the reversibility data
+    const int trk = rcgpu_mkv_add_audio(m, nullptr, 0, ch, rate, bits);
+    if (trk > 0) m->tracks.back().codec_id = is_float ? "A_PCM/FLOAT/IEEE" : "A_PCM/INT/LIT";
+    return trk;
 }
 
 extern "C" int rcgpu_mkv_add_attachment(rcgpu_mkv* m, const char* name, const char* mime, const uint8_t* data, size_t size)
@@ -189,7 +199,7 @@ extern "C" int rcgpu_mkv_begin(rcgpu_mkv* m)
             e.uint(0xD7, k + 1); e.uint(0x73C5, t.uid);
             e.uint(0x83, t.video ? 1 : 2); e.uint(0x9C, 0);
             e.str(0x22B59C, "und");
-            e.str(0x86, t.video ? "V_FFV1" : "A_FLAC");
+            e.str(0x86, t.video ? "V_FFV1" : t.codec_id ? t.codec_id : "A_FLAC");
             const size_t cp_rel_before = e.b.size();
             if (!t.codec_private.empty()) e.bin(0x63A2, t.codec_private.data(), t.codec_private.size());      // FFV1 version 1 has none
             const size_t cp_payload_rel = e.b.size() - t.codec_private.size();

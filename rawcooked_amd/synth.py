@@ -265,9 +265,14 @@ def pcm_samples(n: int, channels: int, bits: int, rate: int = 48000, kind: str =
     return out
 
 
-def wav_file(samples: np.ndarray, bits: int, rate: int = 48000, extensible: bool = False, trailer_chunk: bytes = b"") -> bytes:
+def wav_file(samples: np.ndarray, bits: int, rate: int = 48000, extensible: bool = False, trailer_chunk: bytes = b"", float32: bool = False) -> bytes:
     n, ch = samples.shape
-    if bits == 8:
+    if float32:
+        bits = 32
+        raw = (samples.astype(np.float64) / float(1 << 23)).astype("<f4").tobytes()
+    elif bits == 32:
+        raw = (samples.astype("<i4") * 251 + 3).astype("<i4").tobytes()      # low bits set: not a padded 24-bit signal
+    elif bits == 8:
         raw = (samples + 128).astype(np.uint8).tobytes()
     elif bits == 16:
         raw = samples.astype("<i2").tobytes()
@@ -279,9 +284,9 @@ def wav_file(samples: np.ndarray, bits: int, rate: int = 48000, extensible: bool
     block = ch * bits // 8
     if extensible:
         fmt = struct.pack("<HHIIHHHHI", 0xFFFE, ch, rate, rate * block, block, bits, 22, bits, 0) + \
-            struct.pack("<IHH", 1, 0, 0x0010) + bytes([0x80, 0x00, 0x00, 0xAA, 0x00, 0x38, 0x9B, 0x71])
+            struct.pack("<IHH", 3 if float32 else 1, 0, 0x0010) + bytes([0x80, 0x00, 0x00, 0xAA, 0x00, 0x38, 0x9B, 0x71])
     else:
-        fmt = struct.pack("<HHIIHH", 1, ch, rate, rate * block, block, bits)
+        fmt = struct.pack("<HHIIHH", 3 if float32 else 1, ch, rate, rate * block, block, bits)
     chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(raw)) + raw
     if len(raw) & 1:
         chunks += b"\x00"

@@ -303,3 +303,21 @@ def test_slices_1_means_ffv1_version_1(built, refbin, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     r = run([refbin, "--check", "pkg.mkv"], work)
     assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+
+
+def test_flac_refuses_what_only_copy_can_carry(built, tmp_path):
+    """32-bit WAV with `-c:a flac`: the reference stops before the encoder (CLI/Main.cpp:308-314); the shim says the same."""
+    (tmp_path / "a.wav").write_bytes(synth.wav_file(synth.pcm_samples(5000, 2, 24), 32))
+    r = run([SHIM, "-i", str(tmp_path / "a.wav"), "-c:a", "flac", "-y", "-f", "matroska", str(tmp_path / "o.mkv")], str(tmp_path))
+    assert r.returncode != 0 and "Error: FLAC encoding is not supported with 32-bit audio input, use -c:a copy" in r.stderr, r.stderr
+    assert not os.path.exists(tmp_path / "o.mkv")
+
+
+def test_video_with_copied_32_bit_audio(built, refbin, tmp_path):
+    """A package whose WAV is 32-bit: the reference switches the whole job to `-c:a copy` by itself; FFV1 beside a PCM track."""
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB16_BE, 3, "film")
+    with open(os.path.join(work, "pkg", "snd.wav"), "wb") as f:
+        f.write(synth.wav_file(synth.pcm_samples(6000, 2, 24), 32, float32=True))
+    r = run([refbin, "--bin-name", SHIM, "--check", "-y", "pkg"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr

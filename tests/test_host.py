@@ -279,3 +279,65 @@ def test_argv_front_end_rejects_what_it_cannot_do(built, tmp_path):
         r = subprocess.run([shim, "-i", str(p), "-c:v", "ffv1", "-coder", "1", "-level", "3", "-g", "1"] + extra + ["-f", "matroska", str(tmp_path / "o.mkv")],
                            capture_output=True, text=True)
         assert r.returncode != 0 and "Error: " in r.stderr                                  # helpers.sh:81 greps for "Error:"
+
+
+def test_wav_probe_describes_what_only_copy_can_carry(built):
+    s = synth.pcm_samples(500, 2, 24)
+    wi = api.wav_probe(synth.wav_file(s, 32, 44100))
+    assert (wi.bits_per_sample, wi.format_tag, wi.flavor) == (32, 1, b"WAV/PCM/44kHz/32bit/2ch/S/LE")      # WAV_Tested, WAV.cpp:142-145
+    wf = api.wav_probe(synth.wav_file(s, 32, 48000, float32=True, extensible=True))
+    assert (wf.bits_per_sample, wf.format_tag, wf.flavor) == (32, 3, b"WAV/PCM/48kHz/32bit/2ch/F/LE")
+    assert api.wav_probe(synth.wav_file(s, 24)).format_tag == 1
+
+
+def _ebml_find(buf, wanted):
+    """payloads of every element with id `wanted` (depth-first through the master elements we write)"""
+    masters = {0x18538067, 0x1654AE6B, 0xAE, 0xE1, 0x1F43B675}
+    out, stack = [], [(0, len(buf))]
+    while stack:
+        pos, end = stack.pop()
+        while pos < end:
+            b = buf[pos]; n = 1 + (8 - b.bit_length()); eid = int.from_bytes(buf[pos:pos + n], "big"); pos += n
+            b = buf[pos]; n = 1 + (8 - b.bit_length()); size = int.from_bytes(buf[pos:pos + n], "big") & ((1 << (7 * n)) - 1); pos += n
+            if eid == wanted:
+                out.append((pos, bytes(buf[pos:pos + size])))
+            if eid in masters:
+                stack.append((pos, pos + size))
+            pos += size
+    return [p for _, p in sorted(out)]
+
+
+@pytest.mark.parametrize("kind", ["s16", "s32", "f32"])
+def test_audio_copy_needs_no_device_and_keeps_every_byte(built, tmp_path, kind):
+    """`-c:a copy` (test/pcm.sh; forced by the reference above 24 bits, CLI/Main.cpp:300-317): a PCM track whose blocks are the
+    WAV's data chunk cut at whole sample frames.  Nothing is coded, so this is the one job that runs without a GPU."""
+    shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+    s = synth.pcm_samples(30011, 6 if kind == "f32" else 2, 16 if kind == "s16" else 24)
+    wav = synth.wav_file(s, 16, 48000) if kind == "s16" else synth.wav_file(s, 32, 48000, float32=(kind == "f32"))
+    info = api.wav_probe(wav)
+    (tmp_path / "a.wav").write_bytes(wav)
+    out = tmp_path / "o.mkv"
+    r = subprocess.run([shim, "-xerror", "-i", str(tmp_path / "a.wav"), "-c:a", "copy", "-f", "matroska", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    mkv = out.read_bytes()
+    assert _ebml_find(mkv, 0x86) == [b"A_PCM/FLOAT/IEEE" if kind == "f32" else b"A_PCM/INT/LIT"]
+    assert _ebml_find(mkv, 0x63A2) == []                                                    # no CodecPrivate
+    assert [int.from_bytes(x, "big") for x in _ebml_find(mkv, 0x9F) + _ebml_find(mkv, 0x6264)] == [info.channels, info.bits_per_sample]
+    blocks = _ebml_find(mkv, 0xA3)
+    assert all(b[0] == 0x81 and (len(b) - 4) % info.block_align == 0 and len(b) - 4 <= 4096 for b in blocks)
+    assert b"".join(b[4:] for b in blocks) == wav[info.data_offset:info.data_offset + info.data_size]
+    if kind != "s16":                                                                       # FLAC cannot carry these: CLI/Main.cpp:308-314
+        r = subprocess.run([shim, "-i", str(tmp_path / "a.wav"), "-c:a", "flac", "-y", "-f", "matroska", str(out)], capture_output=True, text=True)
+        assert r.returncode != 0 and "Error: " in r.stderr                                   # here: no device; on a GPU box: "use -c:a copy"
+
+
+@pytest.mark.parametrize("kind", ["s16-by-hand", "s32", "f32"])
+def test_reference_round_trips_copied_audio(built, refbin, tmp_path, kind):
+    """The reference drives the shim (`--bin-name`) and checks the result itself; with 32-bit input it adds `-c:a copy` on its own."""
+    shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+    os.makedirs(tmp_path / "pkg")
+    s = synth.pcm_samples(20001, 2, 16 if kind == "s16-by-hand" else 24)
+    (tmp_path / "pkg" / "1.wav").write_bytes(synth.wav_file(s, 16) if kind == "s16-by-hand" else synth.wav_file(s, 32, float32=(kind == "f32")))
+    cmd = [refbin, "--bin-name", shim] + (["-c:a", "copy"] if kind == "s16-by-hand" else []) + ["-y", "--check", "pkg"]
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL)
+    assert r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout, r.stdout + r.stderr
