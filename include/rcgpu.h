@@ -178,6 +178,10 @@ int rcgpu_ffv1_encode_device(rcgpu_ffv1* enc, const void* const* d_frames, uint3
 int rcgpu_ffv1_encode_host(rcgpu_ffv1* enc, const uint8_t* const* frames, uint32_t n,
                            uint8_t* const* out_packets, size_t* out_sizes);
 
+/* `-f framemd5` (CLI/Output.cpp:312-332): MD5 of the first n frames of the LAST batch as the bytes FFmpeg's rawvideo encoder would hash
+ * (rgb24/rgba/gray, rgb48/rgba64/gray16 in the file's endianness, gbrp/gbrap/gray 10/12 little-endian planar) [ffmpeg-knowledge];
+ * *frame_bytes = size of one such frame.  Call between two batches. */
+int  rcgpu_ffv1_framemd5_last(rcgpu_ffv1* enc, uint32_t n, uint8_t* out_md5, uint64_t* frame_bytes);
 /* Per-kernel device time (summed over its launches) of the last encode call on this encoder, measured with HIP events
  * on the stream the kernels were launched on.  names[i] is a static string. Returns the number of entries written. */
 int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* enc, const char** names, float* ms, int cap);

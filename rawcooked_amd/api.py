@@ -77,6 +77,7 @@ SYMBOLS = {
     "rcgpu_ffv1_max_packet_bytes": (_SZ, [_VP]),
     "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
+    "rcgpu_ffv1_framemd5_last": (C.c_int, [_VP, C.c_uint32, _VP, C.POINTER(C.c_uint64)]),
     "rcgpu_ffv1_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "rcgpu_ffv1_last_kernel_launches": (C.c_int, [_VP, C.c_int]),
     "rcgpu_ffv1_last_stats": (C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -220,6 +221,13 @@ class Ffv1Encoder:
         sizes = (_SZ * n)()
         _check(lib().rcgpu_ffv1_encode_host(self.h, ptrs, n, optrs, sizes), "rcgpu_ffv1_encode_host")
         return [C.string_at(outs[i], sizes[i]) for i in range(n)]      # only the packet, not the whole worst-case buffer
+
+    def framemd5_last(self, n: int) -> tuple[list[bytes], int]:
+        """MD5 of the last batch's first n frames as FFmpeg's rawvideo bytes, and the size of one such frame (`-f framemd5`)."""
+        out = C.create_string_buffer(16 * n)
+        fb = C.c_uint64()
+        _check(lib().rcgpu_ffv1_framemd5_last(self.h, n, out, C.byref(fb)), "rcgpu_ffv1_framemd5_last")
+        return [out.raw[16 * i:16 * i + 16] for i in range(n)], fb.value
 
     def encode_device(self, frame_ptrs: list[int], d_packets: int, packet_stride: int, d_sizes: int, stream: int = 0) -> None:
         n = len(frame_ptrs)

@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t ld_field(const uint8_t* line, uint32_t idx, 
 
 // One pixel of the payload as FFV1 plane values: components in file order -> (g/b exchange) -> JPEG 2000 RCT with the offset
 // FFV1 adds to Cb, Cr (inverse of Transform.cpp From()).  v[0..planes-1].
-__device__ __forceinline__ void unpack_px(const enc_const* __restrict__ C, const uint8_t* __restrict__ frame, uint32_t x, uint32_t y, int32_t (&v)[4])
+__device__ __forceinline__ void unpack_px(const enc_const* __restrict__ C, const uint8_t* __restrict__ frame, uint32_t x, uint32_t y, int32_t (&v)[4], bool file_components = false)
 {
     const uint32_t W = C->W, H = C->H;
     const uint32_t fy = C->vflip ? H - 1 - y : y;                    // line in the file (Transform.cpp:181-185)
@@ -135,6 +135,7 @@ __device__ __forceinline__ void unpack_px(const enc_const* __restrict__ C, const
     default: c0 = ld16(p, be); break;
     }
     v[0] = int32_t(c0); v[1] = v[2] = 0; v[3] = int32_t(c3);
+    if (file_components) { v[1] = int32_t(c1); v[2] = int32_t(c2); return; }      // k_rawvideo: the components as the file orders them
     if (!C->rgb) return;
     int32_t r = int32_t(c0), g = int32_t(c1), b = int32_t(c2);
     if (C->gb_swap) { const int32_t t = g; g = b; b = t; }
@@ -159,6 +160,36 @@ __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C,
     const size_t plane_sz = size_t(W) * H;
     int32_t* dst = planes + size_t(f) * C->planes * plane_sz + pix;
     for (uint32_t p = 0; p < C->planes; p++) dst[p * plane_sz] = v[p];
+}
+
+// The frame as the bytes FFmpeg's `-f framemd5` output hashes (CLI/Output.cpp:312-332): the picture its dpx/tiff decoder hands on,
+// written by the rawvideo encoder without line padding [ffmpeg-knowledge].  8 bit: rgb24 / rgba / gray, bytes in file order;
+// 16 bit: rgb48 / rgba64 / gray16 in the FILE's endianness; 10 and 12 bit: planar little-endian 16-bit words, planes G, B, R(, A)
+// (gbrp10le, gbrap12le ...) or the one plane of gray10le / gray12le.  One thread per pixel, after `-vf vflip` where that is asked for.
+__global__ __launch_bounds__(256) void k_rawvideo(const enc_const* __restrict__ C, const uint8_t* const* __restrict__ frames, uint8_t* __restrict__ out,
+                                                  size_t out_stride)
+{
+    const uint32_t W = C->W, H = C->H;
+    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= W * H) return;
+    const uint32_t y = pix / W, x = pix - y * W, np = C->planes;
+    int32_t v[4];
+    unpack_px(C, frames[blockIdx.y], x, y, v, true);
+    uint8_t* dst = out + size_t(blockIdx.y) * out_stride;
+    if (C->bps == 8) {
+        for (uint32_t p = 0; p < np; p++) dst[size_t(pix) * np + p] = uint8_t(v[p]);
+    } else if (C->bps == 16) {
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(dst) + size_t(pix) * np;
+        for (uint32_t p = 0; p < np; p++) { const uint32_t c = uint32_t(v[p]); d16[p] = uint16_t(C->big_endian ? ((c >> 8) | (c << 8)) : c); }
+    } else {
+        uint16_t* d16 = reinterpret_cast<uint16_t*>(dst);
+        const size_t plane = size_t(W) * H;
+        if (np == 1) d16[pix] = uint16_t(v[0]);
+        else {
+            d16[pix] = uint16_t(v[1]); d16[plane + pix] = uint16_t(v[2]); d16[2 * plane + pix] = uint16_t(v[0]);
+            if (np > 3) d16[3 * plane + pix] = uint16_t(v[3]);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1339,6 +1370,28 @@ extern "C" int rcgpu_ffv1_encode_host(rcgpu_ffv1* e, const uint8_t* const* frame
     HIP_TRY(hipStreamSynchronize(st));
     e->last_packet_bytes = total;
     return 0;
+}
+
+// `-f framemd5` (CLI/Output.cpp:312-332): MD5 of the frames of the LAST batch as FFmpeg's rawvideo bytes (k_rawvideo).  The payloads are
+// still where the encoder read them (the caller's device buffers, or the staging area of rcgpu_ffv1_encode_host); the symbol buffer,
+// free between batches, holds the rawvideo bytes while they are hashed.
+extern "C" int rcgpu_ffv1_framemd5_last(rcgpu_ffv1* e, uint32_t n, uint8_t* out_md5 /* n x 16, host */, uint64_t* frame_bytes)
+{
+    clear_error();
+    if (!e || !out_md5 || !n) return fail(1, "ffv1: null argument");
+    if (n > e->last_n) return fail(2, "ffv1: framemd5 of %u frames, the last batch had %u", n, e->last_n);
+    const enc_const& c = e->hc;
+    if (c.fields == kFieldsExr) return fail(2, "ffv1: framemd5 of EXR input is not supported");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const uint64_t bytes = uint64_t(c.samples_per_frame) * (c.bps == 8 ? 1 : 2);
+    const size_t stride = size_t(c.samples_per_frame) * 4;
+    hipStream_t st = e->own_stream;
+    hipLaunchKernelGGL(k_rawvideo, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, e->d_const, e->d_frame_ptrs, reinterpret_cast<uint8_t*>(e->d_sym), stride);
+    HIP_TRY(hipGetLastError());
+    std::vector<const void*> bufs(n); std::vector<uint64_t> sizes(n, bytes);
+    for (uint32_t i = 0; i < n; i++) bufs[i] = reinterpret_cast<const uint8_t*>(e->d_sym) + size_t(i) * stride;
+    if (frame_bytes) *frame_bytes = bytes;
+    return rcgpu_md5_device(bufs.data(), sizes.data(), n, out_md5, st);
 }
 
 // Debug taps for the stage-by-stage parity tests (tests/test_gpu_stages.py): copies an intermediate of the LAST

@@ -7,6 +7,7 @@
 // muxer writes them in frame order.  No collective is involved: every frame is a key frame (-g 1).
 #include "rc_common.h"
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cmath>
@@ -166,7 +167,9 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     const long level = opt.num("level", 3);
     if (level != 1 && level != 3) return bail(fail(2, "-level %ld is not supported by rcgpu (3, or 1 with -slices 1)", level));
     if (opt.num("g", 1) != 1) return bail(fail(2, "-g %ld is not supported by rcgpu (intra only)", opt.num("g", 1)));
-    if (job->framemd5_path) return bail(fail(2, "-f framemd5 is not supported by rcgpu"));
+    // -f framemd5 (Output.cpp:312-332): a second output with FFmpeg's default stream choice -- one video stream, here the first, and one
+    // audio stream unless `-an` stands in front of it (--framemd5-an); audio checksums are not implemented
+    const bool want_framemd5 = job->framemd5_path && *job->framemd5_path;
     // the only filter the reference ever asks for is `-vf vflip`, for DPX stored bottom-up (CLI/Main.cpp:207-211)
     if (const char* vf = opt.get("vf")) if (strcmp(vf, "vflip") != 0) return bail(fail(2, "-vf %s is not supported by rcgpu (only vflip)", vf));
     const bool vflip_all = opt.has("vf");
@@ -234,6 +237,13 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         }
     }
 
+    if (want_framemd5) {
+        if (videos.empty()) return bail(fail(2, "-f framemd5 needs a video stream"));
+        if (!audios.empty() && !opt.has("an")) return bail(fail(2, "-f framemd5 of audio streams is not supported by rcgpu, use --framemd5-an"));
+        if (videos[0].info.pixfmt == RCGPU_PIX_EXR_RGB16) return bail(fail(2, "-f framemd5 of EXR input is not supported by rcgpu"));
+    }
+    std::vector<uint8_t> framemd5_sums(want_framemd5 ? videos[0].files.size() * 16 : 0);
+    std::atomic<uint64_t> framemd5_frame_bytes{ 0 };
     mark("streams analysed");
     // ---- audio first: A_FLAC CodecPrivate (STREAMINFO) must be final before the header is written
     for (audio_plan& a : audios) {
@@ -389,6 +399,11 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                 if (trace) { char b[96]; snprintf(b, sizeof b, "item %zu: %zu files mapped and probed", g, n); mark(b); }
                 if (!err) err = rcgpu_ffv1_encode_host(enc, ptrs.data(), uint32_t(n), outs.data(), sizes.data());
                 if (trace) { char b[96]; snprintf(b, sizeof b, "item %zu: encoded on the device", g); mark(b); }
+                if (!err && want_framemd5 && it.vi == 0) {       // the payloads of this item are still on the device
+                    uint64_t fb = 0;
+                    err = rcgpu_ffv1_framemd5_last(enc, uint32_t(n), framemd5_sums.data() + first * 16, &fb);
+                    if (!err) framemd5_frame_bytes = fb;         // same value from every worker
+                }
                 std::string msg = err ? rcgpu_last_error() : "";
                 ts.wait_turn(g);
                 if (!err && !ts.error) {
@@ -412,6 +427,21 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     }
     mark("all batches encoded and written");
     if (int r = write_audio_until(~0ull)) return bail(r);
+    if (want_framemd5) {
+        // libavformat's framehash layout, version 2 [ffmpeg-knowledge]: header, then one line per packet of the rawvideo stream
+        const video_plan& v = videos[0];
+        FILE* fh = fopen(job->framemd5_path, "w");
+        if (!fh) return bail(fail(30, "cannot create %s: %s", job->framemd5_path, strerror(errno)));
+        fprintf(fh, "#format: frame checksums\n#version: 2\n#hash: MD5\n#software: %s\n", rcgpu_version());
+        fprintf(fh, "#tb 0: %u/%u\n#media_type 0: video\n#codec_id 0: rawvideo\n#dimensions 0: %ux%u\n#sar 0: 0/1\n", v.fps.den, v.fps.num, v.info.width, v.info.height);
+        fprintf(fh, "#stream#, dts,        pts, duration,     size, hash\n");
+        for (size_t i = 0; i < v.files.size(); i++) {
+            fprintf(fh, "0, %10llu, %10llu, %8d, %8llu, ", (unsigned long long)i, (unsigned long long)i, 1, (unsigned long long)framemd5_frame_bytes.load());
+            for (int k = 0; k < 16; k++) fprintf(fh, "%02x", framemd5_sums[i * 16 + size_t(k)]);
+            fputc('\n', fh);
+        }
+        if (fclose(fh)) return bail(fail(30, "cannot write %s", job->framemd5_path));
+    }
     rcgpu_mkv* m = mux; mux = nullptr;
     if (int r = rcgpu_mkv_close(m)) { unlink(job->output_path); return bail(r); }
     guard.ok = true;
@@ -467,7 +497,7 @@ extern "C" int rcgpu_main_ffmpeg_argv(int argc, const char* const* argv)
             continue;
         }
         if (a == "-map" && need(i)) { i++; continue; }
-        if (a == "-an") continue;
+        if (a == "-an") { out_opts["an"] = ""; continue; }          // only ever in front of `-f framemd5` (Output.cpp:326-329)
         if (a[0] == '-' && need(i)) {
             const std::string k = a.substr(1), v = argv[++i];
             // options in front of an -i belong to that input (Output.cpp:111-131); the rest are output options
