@@ -478,6 +478,9 @@ extern "C" int rcgpu_main_ffmpeg_argv(int argc, const char* const* argv)
                     size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
                     std::string line = text.substr(p, e - p); p = e + 1;
                     if (line.compare(0, 6, "file '") == 0 && line.size() > 7 && line.back() == '\'') { if (!list.empty()) list += '\n'; list += line.substr(6, line.size() - 7); }
+                    // at exactly 25 frames per second the reference skips its own rewriting and the list holds bare paths (Output.cpp:162-163)
+                    else if (!line.empty() && line.compare(0, 9, "duration ") != 0 && line.compare(0, 5, "file ") != 0 && line[0] != '#' && line.compare(0, 8, "ffconcat") != 0)
+                        { if (!list.empty()) list += '\n'; list += line; }
                 }
                 cur.filelist = list; cur.path.clear();
             }

@@ -204,13 +204,17 @@ def test_start_number_sidecar_and_no_overwrite(built, refbin, tmp_path):
     assert r.returncode != 0 and "Error: " in r.stderr and "already exists" in r.stderr
 
 
-def test_gapped_sequence_uses_the_concat_list(built, refbin, tmp_path):
-    """--accept-gaps makes the reference write an ffconcat file list (Output.cpp:138-251); the shim must read it."""
+@pytest.mark.parametrize("rate", [None, "25"], ids=["file-header-rate", "25fps-bare-paths"])
+def test_gapped_sequence_uses_the_concat_list(built, refbin, tmp_path, rate):
+    """--accept-gaps makes the reference write an ffconcat file list (Output.cpp:138-251); the shim must read it.  At exactly 25 frames
+    per second the reference leaves the list as bare paths (Output.cpp:162-163) -- the shim reads those too."""
     work = str(tmp_path)
     make_package(work, 64, 48, synth.PIX_RGB16_BE, 5, "film")
     os.remove(os.path.join(work, "pkg", "img", "f_000002.dpx"))
-    r = run([refbin, "--hash", "--no-check-padding", "--accept-gaps", "-d", "-y", "pkg"], work)
+    r = run([refbin, "--hash", "--no-check-padding", "--accept-gaps", "-d", "-y"] + (["-framerate", rate] if rate else []) + ["pkg"], work)
     assert r.returncode == 0 and "-f concat" in r.stdout, r.stdout + r.stderr
+    listing = open([a for a in shlex.split(r.stdout.strip()) if a.endswith(".FileList.txt")][0]).read()
+    assert ("file '" in listing) == (rate is None)
     argv = shlex.split(r.stdout.strip())
     r = run([SHIM] + argv[1:], work)
     assert r.returncode == 0, r.stdout + r.stderr
