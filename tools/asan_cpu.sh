@@ -11,7 +11,7 @@ for f in rc_common formats mkv_mux hashes ffv1_host job; do
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o $T/librcgpu.so $T/*.o build/ffv1_gpu.o build/ffv1_check.o build/flac_gpu.o -lpthread
 cd $R/oracle
-gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o $T/liboracle.so ffv1_oracle.c flac_oracle.c -lm -lpthread
+gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o $T/liboracle.so ffv1_oracle.c flac_oracle.c dpx_oracle.c -lm -lpthread
 cd $R
 cp rawcooked_amd/librcgpu.so $T/librcgpu.orig; cp oracle/liboracle.so $T/liboracle.orig
 trap 'cp $T/librcgpu.orig rawcooked_amd/librcgpu.so; cp $T/liboracle.orig oracle/liboracle.so; rm -rf $T' EXIT
