@@ -213,7 +213,7 @@ def test_gapped_sequence_uses_the_concat_list(built, refbin, tmp_path, rate):
     os.remove(os.path.join(work, "pkg", "img", "f_000002.dpx"))
     r = run([refbin, "--hash", "--no-check-padding", "--accept-gaps", "-d", "-y"] + (["-framerate", rate] if rate else []) + ["pkg"], work)
     assert r.returncode == 0 and "-f concat" in r.stdout, r.stdout + r.stderr
-    listing = open([a for a in shlex.split(r.stdout.strip()) if a.endswith(".FileList.txt")][0]).read()
+    listing = open(os.path.join(work, [a for a in shlex.split(r.stdout.strip()) if a.endswith(".FileList.txt")][0])).read()
     assert ("file '" in listing) == (rate is None)
     argv = shlex.split(r.stdout.strip())
     r = run([SHIM] + argv[1:], work)
