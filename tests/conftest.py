@@ -24,7 +24,8 @@ def built():
     """Make sure librcgpu.so and liboracle.so exist (builds them when the toolchain is here)."""
     lib = os.path.join(ROOT, "rawcooked_amd", "librcgpu.so")
     ora = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not (os.path.exists(lib) and os.path.exists(ora)):
+    shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+    if not (os.path.exists(lib) and os.path.exists(ora) and os.path.exists(shim)):
         import __graft_entry__
         __graft_entry__.build()
     return lib, ora
