@@ -233,6 +233,17 @@ def main():
                     help="check: BASELINE config 5 -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # asked for several GPUs without a launcher: start one rank per GPU ourselves, the way the driver does
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     from rawcooked_amd import api, synth
 
