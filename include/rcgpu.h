@@ -180,7 +180,8 @@ int rcgpu_ffv1_encode_host(rcgpu_ffv1* enc, const uint8_t* const* frames, uint32
 
 /* `-f framemd5` (CLI/Output.cpp:312-332): MD5 of the first n frames of the LAST batch as the bytes FFmpeg's rawvideo encoder would hash
  * (rgb24/rgba/gray, rgb48/rgba64/gray16 in the file's endianness, gbrp/gbrap/gray 10/12 little-endian planar) [ffmpeg-knowledge];
- * *frame_bytes = size of one such frame.  Call between two batches. */
+ * *frame_bytes = size of one such frame.  Call between two batches, once the batch's stream is synchronised (rcgpu_ffv1_encode_host
+ * returns that way) and while the payload buffers it read are still alive; the symbol buffer serves as scratch.  Synchronous. */
 int  rcgpu_ffv1_framemd5_last(rcgpu_ffv1* enc, uint32_t n, uint8_t* out_md5, uint64_t* frame_bytes);
 /* Per-kernel device time (summed over its launches) of the last encode call on this encoder, measured with HIP events
  * on the stream the kernels were launched on.  names[i] is a static string. Returns the number of entries written. */
