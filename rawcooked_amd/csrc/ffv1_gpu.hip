@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, 
             int32_t v[4];
             unpack_px(C, frame, G.x0 + uint32_t(xx), G.y0 + uint32_t(yy), v);
             for (uint32_t p = 0; p < np; p++) tile[(p * kTileRows + r) * kTileCols + c] = v[p];
-        }
+        } else
+            for (uint32_t p = 0; p < np; p++) tile[(p * kTileRows + r) * kTileCols + c] = 0;     // above the slice: the decoder's zeros
     }
     __syncthreads();
     const int bits = int(C->bits);
@@ -243,23 +244,29 @@ __global__ __launch_bounds__(256) void k_model(const enc_const* __restrict__ C, 
     uint32_t* out = sym + size_t(f) * C->samples_per_frame + G.sym_off;
     const int xi = x0 + int(threadIdx.x), wl = int(G.w) - 1;
     const int rows = min(kTileR, int(G.h) - y0);
+    // neighbours with the decoder's edge rules (FFV1_Slice.cpp:386-387 of SURVEY appendix A; :432-433) as per-thread offsets inside the
+    // tile, fixed once: left of the slice L is the sample above, LT the one two above, LL the one above-left (or 0 in column 0);
+    // right of it RT is T; rows above the slice are zeros in the tile
+    const int oL  = xi > 0 ? -1 : -kTileCols;
+    const int oLT = xi > 0 ? -kTileCols - 1 : -2 * kTileCols;
+    const int oRT = xi < wl ? -kTileCols + 1 : -kTileCols;
+    const int oLL = xi > 1 ? -2 : -kTileCols - 1;
+    const int32_t mLL = xi > 0 ? -1 : 0;
     if (xi <= wl)
     for (int r = 0; r < rows; r++) {
         const int yi = y0 + r;
         for (uint32_t p = 0; p < np; p++) {
-            const int32_t* pl = tile + p * kTileRows * kTileCols;
-            // neighbours with the decoder's edge rules (FFV1_Slice.cpp:386-387 of SURVEY appendix A; :432-433), slice coordinates
-            auto at = [&](int yy, int xx) -> int32_t { return yy < 0 ? 0 : pl[(yy - y0 + 2) * kTileCols + (xx - x0 + 2)]; };
+            const int32_t* at = tile + (p * kTileRows + r + 2) * kTileCols + threadIdx.x + 2;
             const uint32_t set = rgb ? (p + 1) >> 1 : 0;
-            const int32_t cur = at(yi, xi);
-            const int32_t T  = at(yi - 1, xi);
-            const int32_t L  = xi > 0 ? at(yi, xi - 1) : at(yi - 1, 0);
-            const int32_t LT = xi > 0 ? at(yi - 1, xi - 1) : at(yi - 2, 0);
-            const int32_t RT = xi < wl ? at(yi - 1, xi + 1) : T;
+            const int32_t cur = at[0];
+            const int32_t T  = at[-kTileCols];
+            const int32_t L  = at[oL];
+            const int32_t LT = at[oLT];
+            const int32_t RT = at[oRT];
             int32_t ctx = q[0][(L - LT) & 0xFF] + q[1][(LT - T) & 0xFF] + q[2][(T - RT) & 0xFF];
             if (is5) {
-                const int32_t LL = xi > 1 ? at(yi, xi - 2) : (xi == 1 ? at(yi - 1, 0) : 0);
-                const int32_t TT = at(yi - 2, xi);
+                const int32_t LL = at[oLL] & mLL;
+                const int32_t TT = at[-2 * kTileCols];
                 ctx += q[3][(LL - L) & 0xFF] + q[4][(TT - T) & 0xFF];
             }
             int32_t pred;
@@ -339,7 +346,7 @@ __device__ const act_masks kActMasks = make_act_masks();
 // latency of every prefetch and store on the critical path.  Only the compiler must keep the order.
 #define WAVE_SYNC() asm volatile("" ::: "memory")
 template <bool LDS_STATES>
-__global__ __launch_bounds__(64) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+__global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
                                                 uint8_t* __restrict__ states, const unsigned long long* __restrict__ group_off,
                                                 uint8_t* __restrict__ stream, uint32_t nkeys, uint32_t seg,
@@ -759,7 +766,7 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
     }
 }
 
-__global__ __launch_bounds__(64) void k_rangecode(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+__global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                   const unsigned long long* __restrict__ total_n, const uint32_t* __restrict__ seg_pieces,
                                                   uint32_t seg, rc_resume* __restrict__ resume,
                                                   const unsigned long long* __restrict__ group_off,
