@@ -173,10 +173,46 @@ size_t rcgpu_ffv1_max_packet_bytes(const rcgpu_ffv1* enc);
 int rcgpu_ffv1_encode_device(rcgpu_ffv1* enc, const void* const* d_frames, uint32_t n,
                              void* d_packets, size_t packet_stride, uint64_t* d_packet_sizes, void* hip_stream);
 
-/* Host-buffer convenience used by rcgpu_encode: pinned staging, H2D, encode, D2H, synchronous.
+/* Error word of the last batch (the device-pointer call above enqueues work and cannot report it): bit 0 a slice outgrew its byte
+ * buffer, bit 1 a slice does not fit its footer or the 24-bit slice size field -- its packet is incomplete --, bit 2 more than 4096
+ * late carries.  Synchronises the encoder's streams; returns an error (and the text) when *flags != 0. */
+int rcgpu_ffv1_last_error_flags(rcgpu_ffv1* enc, uint32_t* flags);
+
+/* Host-buffer convenience for one batch: H2D, encode, D2H in series, synchronous (sequences: rcgpu_ffv1_encode_sequence below).
  * out_packets[i] must hold rcgpu_ffv1_max_packet_bytes(). */
 int rcgpu_ffv1_encode_host(rcgpu_ffv1* enc, const uint8_t* const* frames, uint32_t n,
                            uint8_t* const* out_packets, size_t* out_sizes);
+
+/* A whole picture sequence with upload, encoding and download overlapped: what the ffmpeg process RAWcooked starts at
+ * CLI/Output.cpp:356 does with the files of one `-i` (FileIO.cpp:274 maps them for the analysis before).  Reader threads call
+ * read_frame to fill PINNED upload slots, each device uploads batch k+1 and downloads batch k-1 while batch k is coded, and the packets
+ * come back in frame order: place_packet (one thread, frame order; may be NULL) says where packet `frame` of `size` bytes belongs --
+ * e.g. inside a mapped output file, see rcgpu_mkv_reserve_block -- and writer threads copy it there and call packet_done; when
+ * place_packet is NULL or returns NULL, packet_done receives the pinned buffer itself (valid during the call).  Frames shard over the
+ * selected devices by batch, no collective.  cfg->device and cfg->max_batch are ignored (options.batch, or sized from free device
+ * memory).  All callbacks return 0 for success; a failure ends the job with that code. */
+typedef struct {
+    int      (*read_frame)(void* user, uint64_t frame, uint8_t* dst, size_t payload_bytes);     /* reader threads, concurrent */
+    uint8_t* (*place_packet)(void* user, uint64_t frame, size_t size);                         /* one thread, frame order; optional */
+    int      (*packet_done)(void* user, uint64_t frame, const uint8_t* data, size_t size);     /* writer threads, concurrent */
+    void* user;
+} rcgpu_sequence_io;
+typedef struct {
+    int device_first, device_count;     /* 0 devices = all visible */
+    uint32_t batch;                     /* frames per batch and device; 0 = automatic */
+    uint32_t readers, writers;          /* host threads; 0 = automatic */
+    uint32_t in_ring_frames;            /* pinned upload slots; 0 = automatic */
+    uint64_t out_ring_bytes;            /* pinned download ring per device; 0 = automatic */
+} rcgpu_sequence_options;
+typedef struct {
+    double   seconds;                   /* first read_frame .. last packet_done */
+    double   first_packet_seconds, prepare_seconds, device_busy_seconds;
+    uint64_t frames, payload_bytes, packet_bytes, batches;
+    uint32_t batch_frames, devices, readers, writers;
+} rcgpu_sequence_stats;
+/* record/record_size: optional, the FFV1 configuration record (Matroska CodecPrivate), *record_size = capacity in, size out. */
+int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, const rcgpu_sequence_io* io,
+                               const rcgpu_sequence_options* options, rcgpu_sequence_stats* stats, uint8_t* record, size_t* record_size);
 
 /* `-f framemd5` (CLI/Output.cpp:312-332): MD5 of the first n frames of the LAST batch as the bytes FFmpeg's rawvideo encoder would hash
  * (rgb24/rgba/gray, rgb48/rgba64/gray16 in the file's endianness, gbrp/gbrap/gray 10/12 little-endian planar) [ffmpeg-knowledge];
@@ -273,6 +309,13 @@ int  rcgpu_mkv_add_tag(rcgpu_mkv* mux, int track, const char* name, const char* 
 int  rcgpu_mkv_begin(rcgpu_mkv* mux);
 /* One SimpleBlock (one FFV1 frame or >= 1 whole FLAC frames); pts in nanoseconds, non-decreasing per track. */
 int  rcgpu_mkv_write_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, const uint8_t* data, size_t size, int keyframe);
+/* Parallel writers (what lets the job write ~30 GB/s of packets): after begin(), announce an upper bound of the block payload still
+ * to come; the muxer sizes the file for it and maps that part (no-op where that is not possible).  reserve_block() then lays out one
+ * Cluster + SimpleBlock in stream order and returns where its `size` payload bytes belong: *dst inside the mapping (copy there from
+ * any thread), or *dst == NULL and *file_offset for rcgpu_mkv_fill() (pwrite; thread-safe).  close() cuts the file to its real size. */
+int  rcgpu_mkv_expect(rcgpu_mkv* mux, uint64_t max_block_bytes, uint64_t max_blocks);
+int  rcgpu_mkv_reserve_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, size_t size, int keyframe, uint8_t** dst, uint64_t* file_offset);
+int  rcgpu_mkv_fill(rcgpu_mkv* mux, uint64_t file_offset, const uint8_t* data, size_t size);
 /* Patches A_FLAC CodecPrivate written by begin() (same size) once STREAMINFO is final. */
 int  rcgpu_mkv_update_codec_private(rcgpu_mkv* mux, int track, const uint8_t* codec_private, size_t cp_size);
 /* Writes Cues, patches Segment size / SeekHead / Duration; closes the file. */

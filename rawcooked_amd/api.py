@@ -37,6 +37,26 @@ class Ffv1Config(C.Structure):
                 ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32), ("coder", C.c_uint32), ("level", C.c_uint32)]
 
 
+READ_FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t)
+PLACE_PACKET_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t)
+PACKET_DONE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t)
+
+
+class SequenceIo(C.Structure):
+    _fields_ = [("read_frame", READ_FRAME_FN), ("place_packet", PLACE_PACKET_FN), ("packet_done", PACKET_DONE_FN), ("user", C.c_void_p)]
+
+
+class SequenceOptions(C.Structure):
+    _fields_ = [("device_first", C.c_int), ("device_count", C.c_int), ("batch", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
+                ("in_ring_frames", C.c_uint32), ("out_ring_bytes", C.c_uint64)]
+
+
+class SequenceStats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("first_packet_seconds", C.c_double), ("prepare_seconds", C.c_double), ("device_busy_seconds", C.c_double),
+                ("frames", C.c_uint64), ("payload_bytes", C.c_uint64), ("packet_bytes", C.c_uint64), ("batches", C.c_uint64),
+                ("batch_frames", C.c_uint32), ("devices", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32)]
+
+
 class FlacConfig(C.Structure):
     _fields_ = [("channels", C.c_uint32), ("sample_rate", C.c_uint32), ("bits_per_sample", C.c_uint32), ("block_size", C.c_uint32),
                 ("max_lpc_order", C.c_uint32), ("device", C.c_int)]
@@ -77,6 +97,11 @@ SYMBOLS = {
     "rcgpu_ffv1_max_packet_bytes": (_SZ, [_VP]),
     "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
+    "rcgpu_ffv1_last_error_flags": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
+    "rcgpu_ffv1_encode_sequence": (C.c_int, [C.POINTER(Ffv1Config), C.c_uint64, C.POINTER(SequenceIo), C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
+    "rcgpu_mkv_expect": (C.c_int, [_VP, C.c_uint64, C.c_uint64]),
+    "rcgpu_mkv_reserve_block": (C.c_int, [_VP, C.c_int, C.c_uint64, _SZ, C.c_int, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
+    "rcgpu_mkv_fill": (C.c_int, [_VP, C.c_uint64, _VP, _SZ]),
     "rcgpu_ffv1_framemd5_last": (C.c_int, [_VP, C.c_uint32, _VP, C.POINTER(C.c_uint64)]),
     "rcgpu_ffv1_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
     "rcgpu_ffv1_last_kernel_launches": (C.c_int, [_VP, C.c_int]),
@@ -234,6 +259,12 @@ class Ffv1Encoder:
         ptrs = (_VP * n)(*frame_ptrs)
         _check(lib().rcgpu_ffv1_encode_device(self.h, ptrs, n, d_packets, packet_stride, d_sizes, stream), "rcgpu_ffv1_encode_device")
 
+    def error_flags(self) -> int:
+        """Device error word of the last batch (0 = fine); raises with the library's text when it is not."""
+        f = C.c_uint32()
+        _check(lib().rcgpu_ffv1_last_error_flags(self.h, C.byref(f)), "rcgpu_ffv1_last_error_flags")
+        return f.value
+
     def kernel_times(self) -> dict[str, float]:
         names = (C.c_char_p * 16)()
         ms = (C.c_float * 16)()
@@ -255,6 +286,23 @@ class Ffv1Encoder:
         if n < 0:
             raise RcgpuError(f"rcgpu_ffv1_debug_fetch({what}) -> {n}")
         return buf.raw[:n]
+
+
+def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, place_packet=None, batch=0, readers=0, writers=0,
+                    in_ring_frames=0, out_ring_bytes=0, device_first=0, device_count=0):
+    """rcgpu_ffv1_encode_sequence: `read_frame(frame, dst_address, nbytes) -> int` fills a pinned upload slot, `packet_done(frame,
+    address, size) -> int` receives each packet (writer threads), `place_packet(frame, size) -> address or None` is optional.
+    Returns (SequenceStats, configuration record)."""
+    rf = READ_FRAME_FN(lambda user, frame, dst, n: int(read_frame(frame, dst, n) or 0))
+    pd = PACKET_DONE_FN(lambda user, frame, data, n: int(packet_done(frame, data, n) or 0))
+    pp = PLACE_PACKET_FN(lambda user, frame, n: place_packet(frame, n) or 0) if place_packet else PLACE_PACKET_FN()
+    io = SequenceIo(rf, pp, pd, None)
+    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes)
+    st = SequenceStats()
+    rec = C.create_string_buffer(8192)
+    rs = _SZ(8192)
+    _check(lib().rcgpu_ffv1_encode_sequence(C.byref(cfg), n_frames, C.byref(io), C.byref(opt), C.byref(st), rec, C.byref(rs)), "rcgpu_ffv1_encode_sequence")
+    return st, rec.raw[:rs.value]
 
 
 class Ffv1Decoder:

@@ -30,6 +30,7 @@
 #include "ffv1_host.h"
 #include "rc_common.h"
 #include "crc_dev.h"
+#include "ffv1_internal.h"
 
 using namespace rc;
 
@@ -1025,6 +1026,9 @@ struct rcgpu_ffv1 {
     bool ev_valid = false;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
     uint32_t last_n = 0;
+    hipEvent_t gather_wait = nullptr;              // pipeline: k_gather of the next batch waits for the previous batch's download
+    size_t in_stride = 0;
+    uint32_t* h_err = nullptr;                     // pinned copy of d_err
 };
 
 static const char* const kKernelNames[rcgpu_ffv1::kNumK] = { "k_unpack", "k_model", "k_resolve", "k_rangecode", "k_footer", "k_scan", "k_gather" };
@@ -1044,7 +1048,7 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
                      e->d_group_off, e->d_k3_resume, e->d_k4_resume, e->d_window[0], e->d_window[1], e->d_cbuf, e->d_out_len, e->d_tot_len,
                      e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes };
     for (void* b : bufs) if (b) (void)hipFree(b);
-    void* hosts[] = { e->h_psizes, e->h_ndec_pinned, e->h_frame_ptrs, e->h_total_n, e->h_seg_pieces, e->h_group_off };
+    void* hosts[] = { e->h_psizes, e->h_ndec_pinned, e->h_frame_ptrs, e->h_total_n, e->h_seg_pieces, e->h_group_off, e->h_err };
     for (void* h : hosts) if (h) (void)hipHostFree(h);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_k3) if (ev) (void)hipEventDestroy(ev);
@@ -1145,6 +1149,8 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             // adapted) + what ~10^4 contexts x 32 states can cost before they have (tiny slices reach 1.7x), + header/footer
             const size_t raw15 = size_t(g.w) * g.h * (d.bytes_pp ? d.bytes_pp : d.planes * 2u) * 3 / 2;
             size_t cap = (raw15 + std::min<size_t>(raw15, 256u << 10) + 4096 + 15) & ~size_t(15);
+            // test hook: slice buffers a fraction of their size, so that the overflow reporting can be exercised (tests/test_gpu_pipeline.py)
+            if (const char* t = getenv("RCGPU_TEST_CBUF_DIV")) if (atoi(t) > 1) cap = std::max<size_t>(64, (cap / size_t(atoi(t))) & ~size_t(15));
             if (cap > 0xFFFFFF + 64 && e->sp.version != 1) cap = 0xFFFFFF + 64;          // slice size field is 24 bit (version 1 has none)
             if (cap >= (size_t(1) << 31)) { delete e; return fail(2, "ffv1: a version 1 frame of %ux%u does not fit the coder's 31-bit byte positions", g.w, g.h); }
             cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here
@@ -1298,6 +1304,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(timed(4, s2, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));
     HIP_TRY(timed(5, s2, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, s2, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
+    if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(s2, e->gather_wait, 0)); e->gather_wait = nullptr; }
     HIP_TRY(timed(6, s2, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
     HIP_TRY(hipEventRecord(e->ev_fork, s2));
@@ -1340,34 +1347,76 @@ extern "C" int rcgpu_ffv1_last_stats(const rcgpu_ffv1* e, uint64_t* decisions, u
     return 0;
 }
 
+namespace rc {
+const char* ffv1_error_flags_text(uint32_t flags)
+{
+    if (!flags) return "";
+    if (flags & 1u) return "a slice outgrew its byte buffer (content expands beyond 1.5x raw)";
+    if (flags & 2u) return "a slice does not fit its footer / the 24-bit slice size field";
+    if (flags & 4u) return "more late carries than the event table holds";
+    return "unknown device error";
+}
+
+int ffv1_staging(rcgpu_ffv1* e, enc_staging* out)
+{
+    if (!e || !out) return fail(1, "ffv1: null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const uint32_t F = e->cfg.max_batch;
+    if (!e->d_in) {
+        e->in_stride = (e->frame_payload + 255) & ~size_t(255);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_in), e->in_stride * F));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_packets), e->max_packet * F));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_psizes), 8 * F));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_psizes), 8 * F));
+    }
+    out->d_in = e->d_in; out->in_stride = e->in_stride; out->payload_bytes = e->frame_payload;
+    out->d_packets = e->d_packets; out->packet_stride = e->max_packet; out->d_psizes = reinterpret_cast<uint64_t*>(e->d_psizes);
+    out->d_err = e->d_err; out->compute_stream = e->own_stream; out->max_batch = F; out->device = e->cfg.device;
+    return 0;
+}
+
+void ffv1_set_gather_wait(rcgpu_ffv1* e, void* hip_event) { if (e) e->gather_wait = static_cast<hipEvent_t>(hip_event); }
+}  // namespace rc
+
+// Error word of the last batch: bit 0 a slice outgrew its byte buffer, bit 1 a slice does not fit its footer or the 24-bit size
+// field (its packet is incomplete), bit 2 more than 4096 late carries.  Synchronises the encoder's streams.
+extern "C" int rcgpu_ffv1_last_error_flags(rcgpu_ffv1* e, uint32_t* flags)
+{
+    clear_error();
+    if (!e || !flags) return fail(1, "ffv1: null argument");
+    *flags = 0;
+    if (!e->ev_valid) return 0;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (!e->h_err) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), 16));
+    // the batch's last kernels run on rc_stream; the caller's stream joined it at the end of the call
+    HIP_TRY(hipStreamSynchronize(e->rc_stream));
+    HIP_TRY(hipMemcpy(e->h_err, e->d_err, 16, hipMemcpyDeviceToHost));
+    *flags = e->h_err[0];
+    if (*flags) return fail(102, "ffv1: %s (flags %u)", ffv1_error_flags_text(*flags), *flags);
+    return 0;
+}
+
 extern "C" int rcgpu_ffv1_encode_host(rcgpu_ffv1* e, const uint8_t* const* frames, uint32_t n, uint8_t* const* out_packets, size_t* out_sizes)
 {
     clear_error();
     if (!e || !frames || !out_packets || !out_sizes) return fail(1, "ffv1: null argument");
     if (!n || n > e->cfg.max_batch) return fail(2, "ffv1: batch of %u frames (max_batch %u)", n, e->cfg.max_batch);
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    const uint32_t F = e->cfg.max_batch;
-    const size_t in_stride = (e->frame_payload + 255) & ~size_t(255);
-    if (!e->d_in) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_in), in_stride * F));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_packets), e->max_packet * F));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_psizes), 8 * F));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_psizes), 8 * F));
-    }
+    enc_staging sg;
+    if (int r = ffv1_staging(e, &sg)) return r;
     hipStream_t st = e->own_stream;
     std::vector<const void*> ptrs(n);
     for (uint32_t i = 0; i < n; i++) {
-        // straight from the caller's (pageable, typically memory-mapped) buffer: the runtime stages it in chunks; a pinned copy of the
-        // whole batch made here first cost 3.4 GB of page-locking per 64 4K frames and was 3x slower end to end
-        HIP_TRY(hipMemcpyAsync(e->d_in + i * in_stride, frames[i], e->frame_payload, hipMemcpyHostToDevice, st));
-        ptrs[i] = e->d_in + i * in_stride;
+        // straight from the caller's (pageable, typically memory-mapped) buffer: the runtime stages it in chunks.  Callers with a
+        // sequence to encode use rcgpu_ffv1_encode_sequence, which overlaps pinned uploads, encoding and downloads.
+        HIP_TRY(hipMemcpyAsync(sg.d_in + i * sg.in_stride, frames[i], e->frame_payload, hipMemcpyHostToDevice, st));
+        ptrs[i] = sg.d_in + i * sg.in_stride;
     }
     if (int r = rcgpu_ffv1_encode_device(e, ptrs.data(), n, e->d_packets, e->max_packet, reinterpret_cast<uint64_t*>(e->d_psizes), st)) return r;
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(e->h_psizes, e->d_psizes, 8 * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&err, e->d_err, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (err) return fail(102, "ffv1: a slice outgrew its buffer (flags %u) -- content expands beyond the slice buffer", err);
+    if (err) return fail(102, "ffv1: %s (flags %u)", ffv1_error_flags_text(err), err);
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; i++) {
         out_sizes[i] = size_t(e->h_psizes[i]);

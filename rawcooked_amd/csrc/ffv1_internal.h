@@ -1,0 +1,29 @@
+// ffv1_internal.h -- what the upload/download pipeline (pipeline.hip) needs from the encoder beyond the C ABI: its staging areas on
+// the device and one ordering hook.  Not part of include/rcgpu.h.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include "rcgpu.h"
+
+namespace rc {
+
+struct enc_staging {
+    uint8_t* d_in;            // max_batch payload slots, in_stride apart: read by k_model only, free again once k_model has run
+    size_t   in_stride, payload_bytes;
+    uint8_t* d_packets;       // max_batch packets, packet_stride apart: written by k_gather at the very end of a batch
+    size_t   packet_stride;
+    uint64_t* d_psizes;       // max_batch packet sizes
+    uint32_t* d_err;          // [0] error flags, [1] carry events of the batch
+    void*    compute_stream;  // the encoder's own stream (hipStream_t)
+    uint32_t max_batch;
+    int      device;
+};
+// Allocates the staging areas on first use.
+int  ffv1_staging(rcgpu_ffv1* e, enc_staging* out);
+// The next rcgpu_ffv1_encode_device call makes k_gather wait for this event (a hipEvent_t already recorded): the download of the
+// previous batch's packets out of d_packets.  nullptr = no wait.
+void ffv1_set_gather_wait(rcgpu_ffv1* e, void* hip_event);
+// Text for the device error word (0 = none).
+const char* ffv1_error_flags_text(uint32_t flags);
+
+}  // namespace rc

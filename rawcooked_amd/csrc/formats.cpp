@@ -348,6 +348,12 @@ extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* 
             const uint32_t avg = rd32(f + pos + 8, false);
             out->block_align = rd16(f + pos + 12, false);
             out->bits_per_sample = rd16(f + pos + 14, false);
+            // validated here, before any arithmetic uses them: an all-zero fmt chunk is coherent with itself (0 == 0) and would
+            // otherwise reach the `% block_align` of the data chunk (the reference rejects such files, WAV.cpp:125-221)
+            if (out->channels < 1 || out->channels > 8) return fail(13, "wav: %u channels not supported", out->channels);
+            if (out->bits_per_sample != 8 && out->bits_per_sample != 16 && out->bits_per_sample != 24 && out->bits_per_sample != 32)
+                return fail(14, "wav: %u-bit PCM is not supported", out->bits_per_sample);
+            if (!out->block_align || !out->sample_rate) return fail(7, "wav: BlockAlign or SamplesPerSec is zero");
             if (uint64_t(avg) * 8 != uint64_t(out->channels) * out->bits_per_sample * out->sample_rate) return fail(7, "wav: incoherent AvgBytesPerSec");
             if (out->block_align * 8u != out->channels * out->bits_per_sample) return fail(7, "wav: incoherent BlockAlign");
             if (tag == 0xFFFE) {
@@ -363,12 +369,9 @@ extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* 
             if (csize > size - pos) return fail(11, "wav: truncated data chunk");
             if (csize % out->block_align) return fail(12, "wav: data size is not a multiple of the block size");
             out->data_offset = pos; out->data_size = csize;
-            // flavor table WAV.cpp:125-221: channels {1,2,4,6,8}... kept permissive up to 8 channels
-            if (out->channels < 1 || out->channels > 8) return fail(13, "wav: %u channels not supported", out->channels);
+            // flavor table WAV.cpp:125-221: channels {1,2,4,6,8}... kept permissive up to 8 channels (checked with the fmt chunk).
             // WAV_Tested, WAV.cpp:125-203: 8/16/24/32-bit integer, 32-bit float; more than 24 bits (and float) cannot be FLAC and
             // travel as PCM (`-c:a copy`, CLI/Main.cpp:300-317) -- the job decides, the probe only describes
-            if (out->bits_per_sample != 8 && out->bits_per_sample != 16 && out->bits_per_sample != 24 && out->bits_per_sample != 32)
-                return fail(14, "wav: %u-bit PCM is not supported", out->bits_per_sample);
             if (tag == 3 && out->bits_per_sample != 32) return fail(14, "wav: %u-bit float is not supported", out->bits_per_sample);
             out->format_tag = tag;
             snprintf(out->flavor, sizeof out->flavor, "WAV/PCM/%ukHz/%ubit/%uch/%s/LE", out->sample_rate / 1000,

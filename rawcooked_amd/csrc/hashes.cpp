@@ -54,19 +54,24 @@ extern "C" void rcgpu_md5(const uint8_t* data, size_t size, uint8_t out[16])
     for (int k = 0; k < 16; k++) out[k] = uint8_t(w[k / 4] >> (8 * (k % 4)));
 }
 
-extern "C" uint32_t rcgpu_crc32_ffv1(const uint8_t* d, size_t n)
-{
-    static uint32_t table[256];
-    static bool ready = false;
-    if (!ready) {
+namespace {
+struct crc_table {
+    uint32_t t[256];
+    constexpr crc_table() : t{}
+    {
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i << 24;
             for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
-            table[i] = c;
+            t[i] = c;
         }
-        ready = true;
     }
+};
+constexpr crc_table kCrc{};      // built at compile time: concurrent callers (one worker per device) share a constant
+}
+
+extern "C" uint32_t rcgpu_crc32_ffv1(const uint8_t* d, size_t n)
+{
     uint32_t c = 0;
-    for (size_t i = 0; i < n; i++) c = (c << 8) ^ table[(c >> 24) ^ d[i]];
+    for (size_t i = 0; i < n; i++) c = (c << 8) ^ kCrc.t[(c >> 24) ^ d[i]];
     return c;
 }

@@ -6,6 +6,7 @@
 // round-robin over the selected devices in batches, packets come back over each device's own PCIe link and one
 // muxer writes them in frame order.  No collective is involved: every frame is a key frame (-g 1).
 #include "rc_common.h"
+#include "pipeline.h"
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
@@ -26,20 +27,32 @@ using namespace rc;
 namespace {
 
 struct mapped_file {
-    const uint8_t* data = nullptr; size_t size = 0;
+    const uint8_t* data = nullptr; size_t size = 0; int fd = -1;
     mapped_file() = default;
     mapped_file(const mapped_file&) = delete;
-    ~mapped_file() { if (data) munmap(const_cast<uint8_t*>(data), size); }
-    bool open(const std::string& path)
+    ~mapped_file() { if (data) munmap(const_cast<uint8_t*>(data), size); if (fd >= 0) ::close(fd); }
+    bool open(const std::string& path, bool keep_fd = false)
     {
-        int fd = ::open(path.c_str(), O_RDONLY);
-        if (fd < 0) return false;
+        int f = ::open(path.c_str(), O_RDONLY);
+        if (f < 0) return false;
         struct stat st;
-        if (fstat(fd, &st) != 0 || st.st_size <= 0) { ::close(fd); return false; }
-        void* p = mmap(nullptr, size_t(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);   // the reference's default reader, Lib/Utils/FileIO/FileIO.cpp:274
-        ::close(fd);
+        if (fstat(f, &st) != 0 || st.st_size <= 0) { ::close(f); return false; }
+        void* p = mmap(nullptr, size_t(st.st_size), PROT_READ, MAP_PRIVATE, f, 0);   // the reference's default reader, Lib/Utils/FileIO/FileIO.cpp:274
+        if (keep_fd) fd = f; else ::close(f);
         if (p == MAP_FAILED) return false;
         data = static_cast<const uint8_t*>(p); size = size_t(st.st_size);
+        return true;
+    }
+    // the bulk of a file into a (pinned) buffer: read() copies straight out of the page cache, without a fault per page
+    bool read_at(uint64_t off, uint8_t* dst, size_t n) const
+    {
+        if (fd < 0) { if (off + n > size) return false; memcpy(dst, data + off, n); return true; }
+        while (n) {
+            const ssize_t r = ::pread(fd, dst, n, off_t(off));
+            if (r < 0) { if (errno == EINTR) continue; return false; }
+            if (r == 0) return false;
+            dst += r; off += uint64_t(r); n -= size_t(r);
+        }
         return true;
     }
 };
@@ -105,8 +118,6 @@ struct video_plan {
     uint32_t num_h = 1, num_v = 1;
     bool vflip = false;
     int track = 0;
-    uint32_t F = 1;               // frames per batch (in flight per device)
-    size_t enc_first = 0;         // its encoders: encoders[enc_first + device]
 };
 struct audio_plan {
     std::string file;
@@ -130,13 +141,6 @@ int probe_image(const std::string& path, bool& tiff, rcgpu_image_info& info)
     if (f.size >= 4 && f.data[0] == 0x76 && f.data[1] == 0x2F && f.data[2] == 0x31 && f.data[3] == 0x01) { tiff = false; return rcgpu_exr_probe(f.data, f.size, &info); }
     return tiff ? rcgpu_tiff_probe(f.data, f.size, &info) : rcgpu_dpx_probe(f.data, f.size, &info);
 }
-
-// Ordered, single-writer hand-over of encoded batches to the muxer.
-struct turnstile {
-    std::mutex m; std::condition_variable cv; size_t next = 0; int error = 0;
-    void wait_turn(size_t idx) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return next == idx || error; }); }
-    void done(size_t idx, int err) { { std::lock_guard<std::mutex> l(m); if (err && !error) error = err; next = idx + 1; } cv.notify_all(); }
-};
 
 }  // namespace
 
@@ -287,36 +291,33 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     if (int r = rcgpu_mkv_open(job->output_path, 1, &mux)) return bail(r);
     struct mux_guard { rcgpu_mkv*& m; const char* path; bool ok = false; ~mux_guard() { if (m) { rcgpu_mkv_close(m); if (!ok) unlink(path); } } } guard{ mux, job->output_path };
 
-    std::vector<std::unique_ptr<rcgpu_ffv1, void (*)(rcgpu_ffv1*)>> encoders;
-    // Two workers per device: while one holds the muxer's turn (writing ~50 MB per frame to disk) the other maps the next files and
-    // runs the device.  Short jobs get by with one.
-    size_t longest = 0;
-    for (const video_plan& v : videos) longest = std::max(longest, v.files.size());
-    int per_dev = longest > 8 ? 2 : 1;
-    if (const char* w = getenv("RCGPU_WORKERS")) per_dev = std::max(1, std::min(8, atoi(w)));          // workers (encoders, host threads) per device
-    const int nworkers = ndev * per_dev;
-    const uint32_t batch = uint32_t(std::max(0L, opt.num("rcgpu_batch", 0)));      // 0: sized from the picture and the sequence below
+    // ---- the device side: one pipeline for all picture sequences of the job (pipeline.h): encoders per device, batches sized from the
+    // device's free memory, pinned upload slots and download rings
+    rc::pipeline pl;
+    std::vector<rc::pipe_video> pvideos;
+    for (video_plan& v : videos) {
+        rc::pipe_video pv; pv.frames = v.files.size();
+        rcgpu_ffv1_config& c = pv.cfg;
+        c.width = v.info.width; c.height = v.info.height; c.pixfmt = v.info.pixfmt; c.line_bytes = v.info.line_bytes;
+        c.flags = (v.info.flags & RCGPU_FLAG_ALTERN) | (v.vflip ? RCGPU_FLAG_VFLIP : 0);
+        c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.coder = uint32_t(coder); c.level = uint32_t(level);
+        if (level == 1) { if (v.num_h * v.num_v != 1) return bail(fail(2, "-level 1 (FFV1 version 1) has no slices: use -slices 1")); c.slicecrc = 0; }
+        pvideos.push_back(pv);
+    }
+    if (!videos.empty()) {
+        rc::pipe_options po;
+        po.device_first = dev0; po.device_count = ndev; po.trace = trace;
+        po.batch = uint32_t(std::max(0L, opt.num("rcgpu_batch", 0)));      // 0: sized from the device's free memory and the sequence
+        if (const char* e = getenv("RCGPU_BATCH")) if (!po.batch) po.batch = uint32_t(std::max(0, atoi(e)));
+        if (const char* e = getenv("RCGPU_READERS")) po.readers = uint32_t(std::max(1, atoi(e)));
+        if (const char* e = getenv("RCGPU_WRITERS")) po.writers = uint32_t(std::max(1, atoi(e)));
+        if (int r = pl.prepare(pvideos, po)) return bail(r);
+    }
     for (auto& o : order) {
         if (o.first) {
             video_plan& v = videos[o.second];
-            uint32_t& F = v.F;
-            v.enc_first = encoders.size();
-            // frames in flight per worker: bounded by HBM (~0.5 GB per 4K frame) and by the sequence length
-            const uint64_t px = uint64_t(v.info.width) * v.info.height;
-            F = batch ? batch : uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(64, (uint64_t(96) << 30) / (px * 160 + 1))));
-            F = uint32_t(std::min<uint64_t>(F, (v.files.size() + nworkers - 1) / nworkers));
-            rcgpu_ffv1_config c{}; c.width = v.info.width; c.height = v.info.height; c.pixfmt = v.info.pixfmt; c.line_bytes = v.info.line_bytes;
-            c.flags = (v.info.flags & RCGPU_FLAG_ALTERN) | (v.vflip ? RCGPU_FLAG_VFLIP : 0);
-            c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.max_batch = F; c.coder = uint32_t(coder); c.level = uint32_t(level);
-            if (level == 1) { if (v.num_h * v.num_v != 1) return bail(fail(2, "-level 1 (FFV1 version 1) has no slices: use -slices 1")); c.slicecrc = 0; }
-            for (int wk = 0; wk < nworkers; wk++) {               // one encoder per worker: worker wk drives device wk % ndev
-                c.device = dev0 + wk % ndev;
-                rcgpu_ffv1* e = nullptr;
-                if (int r = rcgpu_ffv1_create(&c, &e)) return bail(r);
-                encoders.emplace_back(e, rcgpu_ffv1_destroy);
-            }
             uint8_t rec[4096];
-            const size_t n = rcgpu_ffv1_config_record(encoders[v.enc_first].get(), rec, sizeof rec);
+            const size_t n = rcgpu_ffv1_config_record(pl.encoder(uint32_t(o.second)), rec, sizeof rec);
             v.track = rcgpu_mkv_add_video(mux, rec, n, v.info.width, v.info.height, v.fps.num, v.fps.den);
             if (v.track < 0) return bail(8);
             if (const char* md = opt.get("metadata:s:v")) {
@@ -359,71 +360,67 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     };
 
     if (!videos.empty()) {
-        // work items = (video, batch), ordered by the timestamp of their first frame so that tracks interleave in the file;
-        // item g goes to worker g % nworkers, a turnstile hands finished items to the muxer in that order
-        struct item { size_t vi, first, n; uint64_t pts; };
-        std::vector<item> items;
+        // frames of all picture sequences in timestamp order, so that tracks interleave in the file; the pipeline cuts them into
+        // batches, shards the batches over the devices and returns the packets in this order
+        std::vector<rc::pipe_frame> frames;
+        uint64_t max_bytes = 0;
         for (size_t vi = 0; vi < videos.size(); vi++) {
-            const video_plan& v = videos[vi];
-            for (size_t first = 0; first < v.files.size(); first += v.F)
-                items.push_back({ vi, first, std::min<size_t>(v.F, v.files.size() - first), uint64_t(first) * v.fps.den * 1000000000ull / v.fps.num });
+            for (size_t i = 0; i < videos[vi].files.size(); i++) frames.push_back({ uint32_t(vi), i });
+            max_bytes += uint64_t(videos[vi].files.size()) * rcgpu_ffv1_max_packet_bytes(pl.encoder(uint32_t(vi)));
         }
-        std::stable_sort(items.begin(), items.end(), [](const item& a, const item& b) { return a.pts < b.pts; });
-        turnstile ts;
-        auto worker = [&](int d) {
-            // packet buffers: one uninitialised allocation per slot (a value-initialised vector would touch 96 MB per 4K frame)
-            std::vector<std::unique_ptr<uint8_t[]>> packets; std::vector<size_t> packet_cap;
-            for (size_t g = size_t(d); g < items.size(); g += size_t(nworkers)) {
-                const item& it = items[g];
-                video_plan& v = videos[it.vi];
-                rcgpu_ffv1* enc = encoders[v.enc_first + size_t(d)].get();
-                const size_t cap = rcgpu_ffv1_max_packet_bytes(enc);
-                const size_t first = it.first, n = it.n;
-                int err = 0;
-                std::vector<std::unique_ptr<mapped_file>> maps(n);
-                std::vector<const uint8_t*> ptrs(n); std::vector<uint8_t*> outs(n); std::vector<size_t> sizes(n);
-                if (packets.size() < n) { packets.resize(n); packet_cap.resize(n, 0); }
-                for (size_t i = 0; i < n && !err; i++) {
-                    maps[i].reset(new mapped_file);
-                    if (!maps[i]->open(v.files[first + i])) { err = fail(30, "cannot open %s: %s", v.files[first + i].c_str(), strerror(errno)); break; }
-                    rcgpu_image_info fi{};
-                    const int r = v.info.pixfmt == RCGPU_PIX_EXR_RGB16 ? rcgpu_exr_probe(maps[i]->data, maps[i]->size, &fi)
-                                : v.tiff ? rcgpu_tiff_probe(maps[i]->data, maps[i]->size, &fi) : rcgpu_dpx_probe(maps[i]->data, maps[i]->size, &fi);
-                    if (r) { err = r; break; }
-                    if (fi.width != v.info.width || fi.height != v.info.height || fi.pixfmt != v.info.pixfmt || fi.line_bytes != v.info.line_bytes || fi.flags != v.info.flags)
-                        { err = fail(31, "%s differs in geometry/flavor from the first frame of the sequence", v.files[first + i].c_str()); break; }
-                    ptrs[i] = maps[i]->data + fi.data_offset;
-                    if (packet_cap[i] < cap) { packets[i].reset(new uint8_t[cap]); packet_cap[i] = cap; }
-                    outs[i] = packets[i].get();
-                }
-                if (trace) { char b[96]; snprintf(b, sizeof b, "item %zu: %zu files mapped and probed", g, n); mark(b); }
-                if (!err) err = rcgpu_ffv1_encode_host(enc, ptrs.data(), uint32_t(n), outs.data(), sizes.data());
-                if (trace) { char b[96]; snprintf(b, sizeof b, "item %zu: encoded on the device", g); mark(b); }
-                if (!err && want_framemd5 && it.vi == 0) {       // the payloads of this item are still on the device
-                    uint64_t fb = 0;
-                    err = rcgpu_ffv1_framemd5_last(enc, uint32_t(n), framemd5_sums.data() + first * 16, &fb);
-                    if (!err) framemd5_frame_bytes = fb;         // same value from every worker
-                }
-                std::string msg = err ? rcgpu_last_error() : "";
-                ts.wait_turn(g);
-                if (!err && !ts.error) {
-                    for (size_t i = 0; i < n && !err; i++) {
-                        const uint64_t pts = uint64_t(first + i) * v.fps.den * 1000000000ull / v.fps.num;
-                        err = write_audio_until(pts);
-                        if (!err) err = rcgpu_mkv_write_block(mux, v.track, pts, outs[i], sizes[i], 1);
-                    }
-                    if (err) msg = rcgpu_last_error();
-                }
-                if (err) { std::lock_guard<std::mutex> l(ts.m); if (!ts.error) fail(err, "%s", msg.c_str()); }
-                ts.done(g, err);
-                if (err || ts.error) break;
-            }
+        auto pts_of = [&](const rc::pipe_frame& f) { const video_plan& v = videos[f.video]; return uint64_t(f.index) * v.fps.den * 1000000000ull / v.fps.num; };
+        if (videos.size() > 1) std::stable_sort(frames.begin(), frames.end(), [&](const rc::pipe_frame& a, const rc::pipe_frame& b) { return pts_of(a) < pts_of(b); });
+        uint64_t audio_bytes = 0;
+        for (const audio_plan& a : audios) for (uint32_t fs : a.frame_sizes) audio_bytes += fs + 32;
+        if (int r = rcgpu_mkv_expect(mux, max_bytes + audio_bytes, frames.size())) return bail(r);
+        std::vector<std::vector<uint64_t>> block_off(videos.size());
+        std::vector<std::vector<uint8_t*>> block_dst(videos.size());
+        for (size_t vi = 0; vi < videos.size(); vi++) { block_off[vi].assign(videos[vi].files.size(), 0); block_dst[vi].assign(videos[vi].files.size(), nullptr); }
+        rc::pipe_io io;
+        io.read = [&](const rc::pipe_frame& f, uint8_t* dst) -> int {
+            const video_plan& v = videos[f.video];
+            const std::string& path = v.files[size_t(f.index)];
+            mapped_file m;
+            if (!m.open(path, true)) return fail(30, "cannot open %s: %s", path.c_str(), strerror(errno));
+            rcgpu_image_info fi{};
+            const int r = v.info.pixfmt == RCGPU_PIX_EXR_RGB16 ? rcgpu_exr_probe(m.data, m.size, &fi)
+                        : v.tiff ? rcgpu_tiff_probe(m.data, m.size, &fi) : rcgpu_dpx_probe(m.data, m.size, &fi);
+            if (r) return r;
+            if (fi.width != v.info.width || fi.height != v.info.height || fi.pixfmt != v.info.pixfmt || fi.line_bytes != v.info.line_bytes || fi.flags != v.info.flags)
+                return fail(31, "%s differs in geometry/flavor from the first frame of the sequence", path.c_str());
+            if (!m.read_at(fi.data_offset, dst, size_t(fi.data_size))) return fail(30, "cannot read %s: %s", path.c_str(), strerror(errno));
+            return 0;
         };
-        std::vector<std::thread> threads;
-        for (int d = 1; d < nworkers; d++) threads.emplace_back(worker, d);
-        worker(0);
-        for (auto& t : threads) t.join();
-        if (ts.error) { if (!*rcgpu_last_error()) fail(ts.error, "encode failed on a worker thread"); return bail(ts.error); }
+        io.place = [&](const rc::pipe_frame& f, size_t size) -> uint8_t* {
+            clear_error();
+            const video_plan& v = videos[f.video];
+            const uint64_t pts = pts_of(f);
+            if (write_audio_until(pts)) return nullptr;
+            uint8_t* dst = nullptr; uint64_t off = 0;
+            if (rcgpu_mkv_reserve_block(mux, v.track, pts, size, 1, &dst, &off)) return nullptr;
+            block_off[f.video][size_t(f.index)] = off; block_dst[f.video][size_t(f.index)] = dst;
+            return dst;
+        };
+        io.done = [&](const rc::pipe_frame& f, const uint8_t* data, size_t size) -> int {
+            if (block_dst[f.video][size_t(f.index)]) return 0;                   // a writer thread copied it into the mapped file
+            return rcgpu_mkv_fill(mux, block_off[f.video][size_t(f.index)], data, size);
+        };
+        if (want_framemd5)
+            io.after_batch = [&](uint32_t video, rcgpu_ffv1* enc, uint64_t first, uint32_t n) -> int {
+                if (video != 0) return 0;                                        // FFmpeg's default choice: the first video stream
+                uint64_t fb = 0;
+                if (int r = rcgpu_ffv1_framemd5_last(enc, n, framemd5_sums.data() + size_t(first) * 16, &fb)) return r;
+                framemd5_frame_bytes = fb;
+                return 0;
+            };
+        rc::pipe_stats ps;
+        if (int r = pl.run(frames, io, &ps)) return bail(r);
+        if (trace) {
+            char b[256];
+            snprintf(b, sizeof b, "pipeline: %llu frames in %.3f s (%.1f frames/s), prepare %.3f s, first packet after %.3f s, batches of %u on %u device(s), %u readers, %u writers",
+                     (unsigned long long)ps.frames, ps.seconds, double(ps.frames) / std::max(ps.seconds, 1e-9), ps.prepare_seconds, ps.first_packet_seconds, ps.batch_frames, ps.lanes, ps.readers, ps.writers);
+            mark(b);
+        }
     }
     mark("all batches encoded and written");
     if (int r = write_audio_until(~0ull)) return bail(r);

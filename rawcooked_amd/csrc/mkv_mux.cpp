@@ -10,6 +10,7 @@
 #include <cerrno>
 #include <cmath>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -72,13 +73,15 @@ struct rcgpu_mkv {
     // open cluster
     ebuf cluster; uint64_t cluster_ts = 0; bool cluster_open = false; uint64_t cluster_file_pos = 0;
     uint64_t uid_seed = 0x9E3779B97F4A7C15ull;
+    // parallel writers (rcgpu_mkv_expect / reserve_block / fill): the part of the file that will hold the blocks, mapped shared
+    uint8_t* map = nullptr; uint64_t map_base = 0, map_len = 0;
 
     uint64_t next_uid() { uid_seed ^= uid_seed << 13; uid_seed ^= uid_seed >> 7; uid_seed ^= uid_seed << 17; return uid_seed | 1; }
     int put(const void* p, size_t n)
     {
         const uint8_t* s = static_cast<const uint8_t*>(p);
         while (n) {
-            ssize_t w = ::write(fd, s, n);
+            ssize_t w = ::pwrite(fd, s, n, off_t(pos));     // positional: other threads fill reserved blocks through the same descriptor
             if (w < 0) { if (errno == EINTR) continue; return fail(20, "mkv: write to %s failed: %s", path.c_str(), strerror(errno)); }
             s += w; n -= size_t(w); pos += uint64_t(w);
         }
@@ -105,7 +108,7 @@ extern "C" int rcgpu_mkv_open(const char* path, int overwrite, rcgpu_mkv** out)
 {
     clear_error();
     if (!path || !out) return fail(1, "mkv: null argument");
-    int flags = O_WRONLY | O_CREAT | (overwrite ? O_TRUNC : O_EXCL);
+    int flags = O_RDWR | O_CREAT | (overwrite ? O_TRUNC : O_EXCL);       // O_RDWR: a shared mapping for writing needs read access
     int fd = ::open(path, flags, 0644);
     if (fd < 0) return fail(2, "mkv: cannot create %s: %s", path, strerror(errno));
     rcgpu_mkv* m = new rcgpu_mkv;
@@ -297,6 +300,63 @@ extern "C" int rcgpu_mkv_write_block(rcgpu_mkv* m, int trk, uint64_t pts_ns, con
     return 0;
 }
 
+// ---- parallel writers.  A job that moves ~30 GB/s of packets cannot push them through one write() loop (a tmpfs or page-cache write
+// is a single-threaded copy under the inode lock, ~5 GB/s).  The muxer therefore only lays the file out -- Cluster and SimpleBlock
+// heads in stream order, payload bytes reserved -- and hands back where each payload goes; any number of threads then copy payloads
+// into a shared mapping of the file (page faults on distinct pages do not serialise) or, without a mapping, pwrite() them.
+extern "C" int rcgpu_mkv_expect(rcgpu_mkv* m, uint64_t max_block_bytes, uint64_t max_blocks)
+{
+    clear_error();
+    if (!m || !m->begun) return fail(1, "mkv: expect before begin");
+    if (m->map) return 0;
+    if (const char* e = getenv("RCGPU_MKV_NO_MMAP")) if (*e && *e != '0') return 0;
+    const uint64_t page = 4096;
+    const uint64_t base = m->pos & ~(page - 1);
+    const uint64_t len = (m->pos - base) + max_block_bytes + max_blocks * 64 + (1u << 20);
+    if (ftruncate(m->fd, off_t(base + len)) != 0) return 0;                 // no sparse files here: stay with pwrite
+    void* p = mmap(nullptr, size_t(len), PROT_READ | PROT_WRITE, MAP_SHARED, m->fd, off_t(base));
+    if (p == MAP_FAILED) { if (ftruncate(m->fd, off_t(m->pos)) != 0) {} return 0; }
+    m->map = static_cast<uint8_t*>(p); m->map_base = base; m->map_len = len;
+    return 0;
+}
+
+extern "C" int rcgpu_mkv_reserve_block(rcgpu_mkv* m, int trk, uint64_t pts_ns, size_t size, int keyframe, uint8_t** dst, uint64_t* file_offset)
+{
+    if (!m || !m->begun) return fail(1, "mkv: reserve_block before begin");
+    if (trk < 1 || size_t(trk) > m->tracks.size()) return fail(1, "mkv: bad track number %d", trk);
+    if (!dst || !file_offset) return fail(1, "mkv: null argument");
+    track& t = m->tracks[size_t(trk) - 1];
+    const uint64_t ms = (pts_ns + 500000) / 1000000;
+    if (int r = m->flush_cluster()) return r;            // small blocks (audio) buffered so far come first
+    // one Cluster per reserved block: Timestamp + SimpleBlock head, payload reserved behind them
+    ebuf c; c.uint(0xE7, ms);
+    c.id(0xA3); c.size(size + 4);
+    c.b.push_back(uint8_t(0x80 | trk)); c.b.push_back(0); c.b.push_back(0); c.b.push_back(keyframe ? 0x80 : 0x00);
+    ebuf head; head.id(0x1F43B675); head.size(c.b.size() + size);
+    if (t.video && keyframe) m->cues.push_back({ ms, trk, m->pos - m->segment_data });
+    if (int r = m->put(head.b.data(), head.b.size())) return r;
+    if (int r = m->put(c.b.data(), c.b.size())) return r;
+    *file_offset = m->pos;
+    *dst = (m->map && m->pos >= m->map_base && m->pos + size <= m->map_base + m->map_len) ? m->map + (m->pos - m->map_base) : nullptr;
+    m->pos += size;
+    t.last_pts_ms = ms;
+    uint64_t end = ms;
+    if (t.video) end = ms + uint64_t(std::llround(1000.0 * t.fps_den / t.fps_num));
+    if (end > t.end_ms) t.end_ms = end;
+    return 0;
+}
+
+extern "C" int rcgpu_mkv_fill(rcgpu_mkv* m, uint64_t file_offset, const uint8_t* data, size_t size)
+{
+    if (!m || m->fd < 0) return fail(1, "mkv: fill on a closed file");
+    while (size) {
+        const ssize_t w = ::pwrite(m->fd, data, size, off_t(file_offset));
+        if (w < 0) { if (errno == EINTR) continue; return fail(20, "mkv: write to %s failed: %s", m->path.c_str(), strerror(errno)); }
+        data += w; size -= size_t(w); file_offset += uint64_t(w);
+    }
+    return 0;
+}
+
 extern "C" int rcgpu_mkv_update_codec_private(rcgpu_mkv* m, int trk, const uint8_t* cp, size_t cp_size)
 {
     if (!m || !m->begun) return fail(1, "mkv: update_codec_private before begin");
@@ -311,7 +371,11 @@ extern "C" int rcgpu_mkv_close(rcgpu_mkv* m)
 {
     if (!m) return 0;
     int r = 0;
-    if (m->begun) {
+    if (m->map) {      // blocks were laid out inside a mapping of a generously sized file: cut it back to what was used
+        munmap(m->map, size_t(m->map_len)); m->map = nullptr;
+        if (ftruncate(m->fd, off_t(m->pos)) != 0) r = fail(22, "mkv: cannot size %s: %s", m->path.c_str(), strerror(errno));
+    }
+    if (m->begun && !r) {
         r = m->flush_cluster();
         uint64_t cues_pos = 0;
         if (!r && !m->cues.empty()) {

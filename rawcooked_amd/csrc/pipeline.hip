@@ -1,0 +1,523 @@
+// pipeline.hip -- host side only (HIP runtime calls, no kernels): see pipeline.h for the picture.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include "pipeline.h"
+#include "ffv1_internal.h"
+#include "ffv1_host.h"
+#include "rc_common.h"
+
+namespace rc {
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+struct batch_t { uint32_t video; size_t first, n; int lane; };       // frames[first .. first+n) of the output order
+
+struct out_entry {            // one packet on its way down
+    size_t frame = 0; uint8_t* src = nullptr; size_t size = 0; int chunk = -1; hipEvent_t ev = nullptr; int device = 0, lane = 0;
+    uint8_t* dst = nullptr;
+};
+
+struct lane_t {
+    int id = 0, device = 0;
+    std::vector<rcgpu_ffv1*> enc;                 // per video
+    hipStream_t cin = nullptr, cout = nullptr;
+    std::vector<hipEvent_t> dl_done;              // per video: the download of the last batch out of that encoder's d_packets
+    std::vector<bool> dl_valid;
+    hipEvent_t ev_up = nullptr, ev_done = nullptr;
+    // download ring: pinned chunks, a chunk is re-entered when nothing in it is outstanding
+    std::vector<uint8_t*> chunks; std::vector<int> outstanding; size_t chunk_bytes = 0, max_chunks = 0; int cur = -1; size_t cur_off = 0;
+    std::deque<out_entry> outq;                   // issued downloads in frame order, consumed by the placer
+    std::vector<hipEvent_t> free_events;
+    uint64_t* h_sizes = nullptr; uint32_t* h_err = nullptr;     // pinned
+};
+
+}  // namespace
+
+struct pipeline::impl {
+    std::vector<pipe_video> videos;
+    pipe_options opt;
+    std::vector<lane_t> lanes;
+    std::vector<uint32_t> F;                      // batch frames per video
+    std::vector<size_t> payload;                  // payload bytes per video
+    std::vector<size_t> max_packet;
+    size_t slot_bytes = 0;
+    double prepare_seconds = 0;
+
+    // ---- run state (one big lock: events here are per frame, a few thousand per second)
+    std::mutex m; std::condition_variable cv;
+    int error = 0; std::string error_msg;
+    std::vector<uint8_t*> all_slots, free_slots; size_t slots_wanted = 0;
+    struct pending_up { uint8_t* slot; hipEvent_t ev; int lane; };
+    std::deque<pending_up> pending;               // uploads in flight: their slots return to the pool once the copy is done
+    std::vector<uint8_t*> ready;                  // per output frame: the filled slot (nullptr until read)
+    std::deque<out_entry> jobs;                   // placed packets waiting for a writer
+    bool placer_finished = false;
+    std::atomic<size_t> next_read{ 0 };
+    bool alloc_done = false;
+
+    void set_error(int code, const char* msg)
+    {
+        std::lock_guard<std::mutex> l(m);
+        if (!error) { error = code ? code : 1; error_msg = msg ? msg : ""; }
+        cv.notify_all();
+    }
+    bool failed() { std::lock_guard<std::mutex> l(m); return error != 0; }
+    ~impl();
+};
+
+pipeline::impl::~impl()
+{
+    for (lane_t& L : lanes) {
+        (void)hipSetDevice(L.device);
+        for (rcgpu_ffv1* e : L.enc) if (e) rcgpu_ffv1_destroy(e);
+        for (uint8_t* c : L.chunks) if (c) (void)hipHostFree(c);
+        for (hipEvent_t e : L.free_events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : L.dl_done) if (e) (void)hipEventDestroy(e);
+        if (L.ev_up) (void)hipEventDestroy(L.ev_up);
+        if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+        if (L.cin) (void)hipStreamDestroy(L.cin);
+        if (L.cout) (void)hipStreamDestroy(L.cout);
+        if (L.h_sizes) (void)hipHostFree(L.h_sizes);
+        if (L.h_err) (void)hipHostFree(L.h_err);
+    }
+    for (uint8_t* s : all_slots) (void)hipHostFree(s);
+}
+
+pipeline::pipeline() : p(new impl) {}
+pipeline::~pipeline() {}
+
+rcgpu_ffv1* pipeline::encoder(uint32_t video) const { return p->lanes.empty() || video >= p->lanes[0].enc.size() ? nullptr : p->lanes[0].enc[video]; }
+uint32_t pipeline::batch_frames(uint32_t video) const { return video < p->F.size() ? p->F[video] : 0; }
+
+uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& c)
+{
+    if (c.pixfmt >= RCGPU_PIX_COUNT) return 0;
+    const pix_desc& d = pix(c.pixfmt);
+    const uint64_t px = uint64_t(c.width) * c.height, samples = px * d.planes;
+    const uint64_t S = uint64_t(std::max(1u, c.num_h_slices)) * std::max(1u, c.num_v_slices);
+    const uint64_t raw = payload_bytes(c.pixfmt, c.width, c.height, c.line_bytes, c.flags);
+    // contexts: FFmpeg's maps give 5063 (5 inputs, > 8 bit) / 6561 (8 bit) / 365.. (3 inputs); the compact model 338
+    const uint64_t nctx = c.context == 2 ? 338 : c.context == 1 ? (d.bits > 8 ? 5063 : 6561) : (d.bits > 8 ? 365 : 666);
+    const uint64_t nsets = d.planes == 1 ? 1 : d.planes == 4 ? 3 : 2;
+    const uint64_t states = nctx * nsets * 32 <= (48u << 10) ? 0 : S * nctx * nsets * 32;
+    const uint64_t nseg = c.segments ? c.segments : std::max<uint64_t>(1, std::min<uint64_t>(32, samples / S / 1024));
+    const uint64_t windows = samples * 35 * 2 * (nseg > 1 ? 2 : 1) / nseg;                  // worst case: 35 decisions per sample
+    const uint64_t cbuf = raw * 3 / 2 + S * ((256u << 10) + 4096 + 32);
+    return samples * 4 + states + windows + 2 * cbuf + raw + (1u << 20);
+}
+
+int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options& opt)
+{
+    const auto t0 = clk::now();
+    impl& s = *p;
+    s.videos = videos; s.opt = opt;
+    if (videos.empty()) return fail(1, "pipeline: no video");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(4, "no HIP device available -- rcgpu has no CPU encode path");
+    const int dev0 = std::max(0, opt.device_first);
+    int cnt = opt.device_count > 0 ? opt.device_count : ndev - dev0;
+    if (dev0 >= ndev || cnt <= 0) return fail(4, "device selection %d+%d is outside the %d visible devices", dev0, opt.device_count, ndev);
+    cnt = std::min(cnt, ndev - dev0);
+    uint64_t longest = 0;
+    for (const pipe_video& v : videos) longest = std::max(longest, v.frames);
+    // no more lanes than there is work for: a short job on an 8-GPU node uses the devices it can fill
+    const uint64_t min_batch = 8;
+    cnt = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cnt), (longest + min_batch - 1) / min_batch)));
+    s.lanes.resize(size_t(cnt));
+    s.F.assign(videos.size(), 1); s.payload.assign(videos.size(), 0); s.max_packet.assign(videos.size(), 0);
+    for (int li = 0; li < cnt; li++) {
+        lane_t& L = s.lanes[size_t(li)];
+        L.id = li; L.device = dev0 + li;
+        if (hipSetDevice(L.device) != hipSuccess) return fail(4, "pipeline: cannot select device %d", L.device);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail(100, "pipeline: hipMemGetInfo failed");
+        L.enc.assign(videos.size(), nullptr);
+        for (size_t vi = 0; vi < videos.size(); vi++) {
+            rcgpu_ffv1_config c = videos[vi].cfg;
+            c.device = L.device;
+            if (li == 0) {
+                // frames in flight: what the device holds (85 % of its free memory, shared by the job's tracks), at most 384 -- where
+                // k_resolve's time, which grows with the batch, meets the serial range-coder chain of a slice, which does not
+                //  --, and evened out over the batches of the sequence
+                const uint64_t per = std::max<uint64_t>(1, ffv1_device_bytes_per_frame(c));
+                uint64_t f = opt.batch ? opt.batch : std::min<uint64_t>(384, uint64_t(double(free_b) * 0.85 / double(videos.size())) / per);
+                f = std::max<uint64_t>(1, f);
+                const uint64_t n = std::max<uint64_t>(1, videos[vi].frames);
+                const uint64_t per_lane = (n + uint64_t(cnt) - 1) / uint64_t(cnt);
+                if (!opt.batch) { const uint64_t nb = (per_lane + f - 1) / f; f = (per_lane + nb - 1) / nb; }
+                s.F[vi] = uint32_t(std::min<uint64_t>(f, n));
+            }
+            c.max_batch = s.F[vi];
+            rcgpu_ffv1* e = nullptr;
+            if (int r = rcgpu_ffv1_create(&c, &e)) return r;
+            L.enc[vi] = e;
+            enc_staging sg;
+            if (int r = ffv1_staging(e, &sg)) return r;
+            s.payload[vi] = sg.payload_bytes; s.max_packet[vi] = sg.packet_stride;
+        }
+        if (hipStreamCreateWithFlags(&L.cin, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&L.cout, hipStreamNonBlocking) != hipSuccess)
+            return fail(100, "pipeline: cannot create copy streams");
+        L.dl_done.assign(videos.size(), nullptr); L.dl_valid.assign(videos.size(), false);
+        for (auto& e : L.dl_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(100, "pipeline: cannot create events");
+        if (hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess)
+            return fail(100, "pipeline: cannot create events");
+        uint32_t maxF = 1;
+        for (uint32_t f : s.F) maxF = std::max(maxF, f);
+        if (hipHostMalloc(reinterpret_cast<void**>(&L.h_sizes), size_t(maxF) * 8, hipHostMallocPortable) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&L.h_err), 16, hipHostMallocPortable) != hipSuccess) return fail(100, "pipeline: cannot allocate pinned memory");
+    }
+    for (size_t vi = 0; vi < videos.size(); vi++) s.slot_bytes = std::max(s.slot_bytes, (s.payload[vi] + 4095) & ~size_t(4095));
+    s.prepare_seconds = since(t0);
+    return 0;
+}
+
+int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe_stats* stats)
+{
+    impl& s = *p;
+    const auto t0 = clk::now();
+    const size_t N = frames.size();
+    if (stats) { *stats = pipe_stats(); stats->prepare_seconds = s.prepare_seconds; }
+    if (!N) return 0;
+    if (s.lanes.empty()) return fail(1, "pipeline: run before prepare");
+    for (const pipe_frame& f : frames) if (f.video >= s.videos.size()) return fail(1, "pipeline: frame of an unknown video");
+    const int nl = int(s.lanes.size());
+
+    // ---- batches: runs of consecutive frames of one video, dealt round-robin to the lanes
+    std::vector<batch_t> batches; std::vector<uint32_t> batch_of(N);
+    for (size_t i = 0; i < N;) {
+        const uint32_t v = frames[i].video;
+        size_t n = 1;
+        while (i + n < N && n < s.F[v] && frames[i + n].video == v) n++;
+        for (size_t k = 0; k < n; k++) batch_of[i + k] = uint32_t(batches.size());
+        batches.push_back({ v, i, n, int(batches.size() % size_t(nl)) });
+        i += n;
+    }
+    uint32_t maxF = 1; size_t max_pkt = 0, max_payload = 0;
+    for (size_t vi = 0; vi < s.videos.size(); vi++) { maxF = std::max(maxF, s.F[vi]); max_pkt = std::max(max_pkt, s.max_packet[vi]); max_payload = std::max(max_payload, s.payload[vi]); }
+
+    unsigned hw = std::thread::hardware_concurrency(); if (!hw) hw = 8;
+    const uint32_t readers = s.opt.readers ? s.opt.readers : uint32_t(std::max(2u, std::min(hw / 2, 8u * unsigned(nl))));
+    const uint32_t writers = s.opt.writers ? s.opt.writers : uint32_t(std::max(2u, std::min(hw / 2, 8u * unsigned(nl))));
+    s.slots_wanted = s.opt.in_slots ? s.opt.in_slots : std::min<size_t>(N, std::max<size_t>(2 * readers, std::min<size_t>(64 * size_t(nl), (size_t(8) << 30) / std::max<size_t>(1, s.slot_bytes))));
+    s.slots_wanted = std::max<size_t>(s.slots_wanted, std::min<size_t>(N, 2));
+    for (lane_t& L : s.lanes) {
+        // ring: one batch of packets at the payload's size (FFV1 rarely expands), within 1..32 GB, in chunks that hold at least two
+        // worst-case packets
+        L.chunk_bytes = std::max<size_t>(size_t(256) << 20, 2 * max_pkt);
+        uint64_t want = s.opt.out_ring_bytes ? s.opt.out_ring_bytes : std::min<uint64_t>(uint64_t(32) << 30, std::max<uint64_t>(uint64_t(1) << 30, uint64_t(maxF) * max_payload));
+        uint64_t total_need = 0; for (const batch_t& b : batches) if (b.lane == L.id) total_need += uint64_t(b.n) * s.max_packet[b.video];
+        want = std::min<uint64_t>(want, std::max<uint64_t>(total_need, L.chunk_bytes));
+        L.max_chunks = std::max<size_t>(2, size_t((want + L.chunk_bytes - 1) / L.chunk_bytes));
+        L.cur = -1; L.cur_off = 0; L.outq.clear();
+        std::fill(L.dl_valid.begin(), L.dl_valid.end(), false);
+    }
+    s.ready.assign(N, nullptr); s.jobs.clear(); s.pending.clear(); s.placer_finished = false; s.next_read = 0; s.alloc_done = false;
+    s.error = 0; s.error_msg.clear();
+
+    std::atomic<uint64_t> packet_bytes{ 0 };
+    std::atomic<bool> first_seen{ false }; double first_packet_seconds = 0;
+    double busy0 = 0;
+    const bool trace = s.opt.trace;
+    auto mark = [&](const char* what, long a = -1) {
+        if (trace) fprintf(stderr, "rcgpu trace: %8.3f s  pipeline: %s%s%s\n", since(t0), what, a >= 0 ? " " : "", a >= 0 ? std::to_string(a).c_str() : "");
+    };
+
+    // ---- pinned memory is page-locked at ~13 GB/s: allocated in the background, first users served first
+    std::thread allocator([&] {
+        (void)hipSetDevice(s.lanes[0].device);
+        size_t have = s.all_slots.size();
+        { std::lock_guard<std::mutex> l(s.m); s.free_slots = s.all_slots; }
+        bool more = true;
+        while (more && !s.failed()) {
+            more = false;
+            if (have < s.slots_wanted) {
+                uint8_t* ptr = nullptr;
+                if (hipHostMalloc(reinterpret_cast<void**>(&ptr), s.slot_bytes, hipHostMallocPortable) != hipSuccess) {
+                    if (have < 2) { s.set_error(100, "pipeline: cannot allocate pinned upload slots"); break; }
+                    s.slots_wanted = have;
+                } else {
+                    std::lock_guard<std::mutex> l(s.m);
+                    s.all_slots.push_back(ptr); s.free_slots.push_back(ptr); have++;
+                    s.cv.notify_all();
+                }
+                more = true;
+            }
+            for (lane_t& L : s.lanes) {
+                bool need;
+                { std::lock_guard<std::mutex> l(s.m); need = L.chunks.size() < L.max_chunks; }
+                if (!need) continue;
+                // the first chunks of every lane come before the bulk of the upload slots
+                if (L.chunks.size() >= 2 && have < s.slots_wanted) continue;
+                uint8_t* ptr = nullptr;
+                (void)hipSetDevice(L.device);
+                if (hipHostMalloc(reinterpret_cast<void**>(&ptr), L.chunk_bytes, hipHostMallocPortable) != hipSuccess) {
+                    std::lock_guard<std::mutex> l(s.m);
+                    if (L.chunks.size() < 2) { s.error = 100; s.error_msg = "pipeline: cannot allocate the pinned download ring"; }
+                    L.max_chunks = L.chunks.size();
+                    s.cv.notify_all();
+                } else {
+                    std::lock_guard<std::mutex> l(s.m);
+                    L.chunks.push_back(ptr); L.outstanding.push_back(0);
+                    s.cv.notify_all();
+                }
+                more = true;
+            }
+        }
+        { std::lock_guard<std::mutex> l(s.m); s.alloc_done = true; s.cv.notify_all(); }
+    });
+
+    // uploads whose copy has completed give their slot back; called with the lock held
+    auto reap = [&]() {
+        for (auto it = s.pending.begin(); it != s.pending.end();) {
+            if (hipEventQuery(it->ev) != hipSuccess) { ++it; continue; }
+            s.free_slots.push_back(it->slot);
+            s.lanes[size_t(it->lane)].free_events.push_back(it->ev);  // back to its lane's pool: an event stays with the device that made it
+            it = s.pending.erase(it);
+        }
+    };
+
+    // ---- readers
+    auto reader = [&] {
+        (void)hipSetDevice(s.lanes[0].device);
+        for (;;) {
+            const size_t i = s.next_read.fetch_add(1);
+            if (i >= N) return;
+            uint8_t* slot = nullptr;
+            {
+                std::unique_lock<std::mutex> l(s.m);
+                for (;;) {
+                    if (s.error) return;
+                    reap();
+                    if (!s.free_slots.empty()) { slot = s.free_slots.back(); s.free_slots.pop_back(); break; }
+                    s.cv.wait_for(l, std::chrono::microseconds(200));
+                }
+            }
+            if (int r = io.read(frames[i], slot)) { s.set_error(r, rcgpu_last_error()); return; }
+            { std::lock_guard<std::mutex> l(s.m); s.ready[i] = slot; }
+            s.cv.notify_all();
+        }
+    };
+
+    // ---- lanes
+    auto lane_main = [&](lane_t& L) {
+        if (hipSetDevice(L.device) != hipSuccess) { s.set_error(100, "pipeline: hipSetDevice failed"); return; }
+        std::vector<size_t> mine;
+        for (size_t b = 0; b < batches.size(); b++) if (batches[b].lane == L.id) mine.push_back(b);
+        auto hip_ok = [&](hipError_t e, const char* what) { if (e == hipSuccess) return true; char t[256]; snprintf(t, sizeof t, "pipeline: %s: %s", what, hipGetErrorString(e)); s.set_error(100, t); return false; };
+        auto get_event = [&]() -> hipEvent_t {
+            { std::lock_guard<std::mutex> l(s.m); if (!L.free_events.empty()) { hipEvent_t e = L.free_events.back(); L.free_events.pop_back(); return e; } }
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            return e;
+        };
+        auto issue_uploads = [&](const batch_t& B) -> bool {
+            enc_staging sg; if (ffv1_staging(L.enc[B.video], &sg)) { s.set_error(100, rcgpu_last_error()); return false; }
+            for (size_t k = 0; k < B.n; k++) {
+                uint8_t* slot = nullptr;
+                {
+                    std::unique_lock<std::mutex> l(s.m);
+                    s.cv.wait(l, [&] { return s.error || s.ready[B.first + k]; });
+                    if (s.error) return false;
+                    slot = s.ready[B.first + k];
+                }
+                if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, slot, sg.payload_bytes, hipMemcpyHostToDevice, L.cin), "upload")) return false;
+                hipEvent_t ev = get_event();
+                if (!ev || !hip_ok(hipEventRecord(ev, L.cin), "hipEventRecord")) return false;
+                { std::lock_guard<std::mutex> l(s.m); s.pending.push_back({ slot, ev, L.id }); }
+            }
+            return hip_ok(hipEventRecord(L.ev_up, L.cin), "hipEventRecord");
+        };
+        auto ring_alloc = [&](size_t size, int& chunk) -> uint8_t* {
+            const size_t need = (size + 4095) & ~size_t(4095);
+            std::unique_lock<std::mutex> l(s.m);
+            for (;;) {
+                if (s.error) return nullptr;
+                if (L.cur >= 0) {
+                    if (L.outstanding[size_t(L.cur)] == 0) L.cur_off = 0;          // everything in it was consumed: start over
+                    if (L.cur_off + need <= L.chunk_bytes) break;
+                }
+                const int nc = int(L.chunks.size());
+                int pick = -1;
+                for (int k = 1; k <= nc && pick < 0; k++) { const int c = (L.cur + k) % nc; if (c != L.cur && L.outstanding[size_t(c)] == 0) pick = c; }
+                if (pick >= 0) { L.cur = pick; L.cur_off = 0; continue; }
+                s.cv.wait_for(l, std::chrono::milliseconds(1));
+            }
+            chunk = L.cur;
+            uint8_t* ptr = L.chunks[size_t(L.cur)] + L.cur_off;
+            L.cur_off += need; L.outstanding[size_t(L.cur)]++;
+            return ptr;
+        };
+        hipStream_t st = nullptr;
+        if (!mine.empty() && !issue_uploads(batches[mine[0]])) return;
+        for (size_t k = 0; k < mine.size(); k++) {
+            const batch_t& B = batches[mine[k]];
+            rcgpu_ffv1* enc = L.enc[B.video];
+            enc_staging sg; if (ffv1_staging(enc, &sg)) { s.set_error(100, rcgpu_last_error()); return; }
+            st = static_cast<hipStream_t>(sg.compute_stream);
+            if (!hip_ok(hipStreamWaitEvent(st, L.ev_up, 0), "hipStreamWaitEvent")) return;
+            ffv1_set_gather_wait(enc, L.dl_valid[B.video] ? L.dl_done[B.video] : nullptr);
+            std::vector<const void*> ptrs(B.n);
+            for (size_t i = 0; i < B.n; i++) ptrs[i] = sg.d_in + i * sg.in_stride;
+            const auto tb = clk::now();
+            if (int r = rcgpu_ffv1_encode_device(enc, ptrs.data(), uint32_t(B.n), sg.d_packets, sg.packet_stride, sg.d_psizes, st)) { s.set_error(r, rcgpu_last_error()); return; }
+            // (the call returns once k_model has run: d_in is free again)
+            if (!hip_ok(hipMemcpyAsync(L.h_sizes, sg.d_psizes, 8 * B.n, hipMemcpyDeviceToHost, st), "sizes") ||
+                !hip_ok(hipMemcpyAsync(L.h_err, sg.d_err, 16, hipMemcpyDeviceToHost, st), "flags") ||
+                !hip_ok(hipEventRecord(L.ev_done, st), "hipEventRecord")) return;
+            if (trace && L.id == 0) mark("modelled, rest of batch enqueued:", long(mine[k]));
+            const bool serial = bool(io.after_batch);
+            if (serial) {
+                if (!hip_ok(hipEventSynchronize(L.ev_done), "batch")) return;
+                if (int r = io.after_batch(B.video, enc, frames[B.first].index, uint32_t(B.n))) { s.set_error(r, rcgpu_last_error()); return; }
+            }
+            if (k + 1 < mine.size() && !issue_uploads(batches[mine[k + 1]])) return;
+            if (!hip_ok(hipEventSynchronize(L.ev_done), "batch")) return;
+            if (L.id == 0) busy0 += since(tb);
+            if (trace && L.id == 0) mark("batch complete:", long(mine[k]));
+            if (L.h_err[0]) { char t[256]; snprintf(t, sizeof t, "ffv1: %s (flags %u)", ffv1_error_flags_text(L.h_err[0]), L.h_err[0]); s.set_error(102, t); return; }
+            // downloads: ordered behind the batch on the second copy stream
+            if (!hip_ok(hipStreamWaitEvent(L.cout, L.ev_done, 0), "hipStreamWaitEvent")) return;
+            for (size_t i = 0; i < B.n; i++) {
+                out_entry o; o.frame = B.first + i; o.size = size_t(L.h_sizes[i]); o.device = L.device; o.lane = L.id;
+                if (!o.size || o.size > sg.packet_stride) { s.set_error(102, "ffv1: the device returned an impossible packet size"); return; }
+                o.src = ring_alloc(o.size, o.chunk);
+                if (!o.src) return;
+                if (!hip_ok(hipMemcpyAsync(o.src, sg.d_packets + i * sg.packet_stride, o.size, hipMemcpyDeviceToHost, L.cout), "download")) return;
+                o.ev = get_event();
+                if (!o.ev || !hip_ok(hipEventRecord(o.ev, L.cout), "hipEventRecord")) return;
+                { std::lock_guard<std::mutex> l(s.m); L.outq.push_back(o); }
+                s.cv.notify_all();
+            }
+            if (!hip_ok(hipEventRecord(L.dl_done[B.video], L.cout), "hipEventRecord")) return;
+            L.dl_valid[B.video] = true;
+        }
+    };
+
+    // ---- placer: output order
+    auto placer = [&] {
+        for (size_t i = 0; i < N; i++) {
+            lane_t& L = s.lanes[size_t(batches[batch_of[i]].lane)];
+            out_entry o;
+            {
+                std::unique_lock<std::mutex> l(s.m);
+                s.cv.wait(l, [&] { return s.error || (!L.outq.empty() && L.outq.front().frame == i); });
+                if (s.error) break;
+                o = L.outq.front(); L.outq.pop_front();
+            }
+            o.dst = io.place ? io.place(frames[i], o.size) : nullptr;
+            if (io.place && !o.dst && *rcgpu_last_error()) { s.set_error(20, rcgpu_last_error()); break; }
+            { std::lock_guard<std::mutex> l(s.m); s.jobs.push_back(o); }
+            s.cv.notify_all();
+        }
+        { std::lock_guard<std::mutex> l(s.m); s.placer_finished = true; }
+        s.cv.notify_all();
+    };
+
+    // ---- writers
+    auto writer = [&] {
+        int cur_dev = -1;
+        for (;;) {
+            out_entry o;
+            {
+                std::unique_lock<std::mutex> l(s.m);
+                s.cv.wait(l, [&] { return s.error || !s.jobs.empty() || s.placer_finished; });
+                if (s.jobs.empty()) return;             // error or finished
+                o = s.jobs.front(); s.jobs.pop_front();
+            }
+            if (cur_dev != o.device) { (void)hipSetDevice(o.device); cur_dev = o.device; }
+            int r = 0;
+            if (hipEventSynchronize(o.ev) != hipSuccess) r = fail(100, "pipeline: a download failed");
+            if (!r) {
+                if (!first_seen.exchange(true)) first_packet_seconds = since(t0);
+                if (o.dst) memcpy(o.dst, o.src, o.size);
+                if (io.done) r = io.done(frames[o.frame], o.dst ? o.dst : o.src, o.size);
+                packet_bytes += o.size;
+            }
+            {
+                std::lock_guard<std::mutex> l(s.m);
+                lane_t& L = s.lanes[size_t(o.lane)];
+                L.outstanding[size_t(o.chunk)]--;
+                L.free_events.push_back(o.ev);
+                if (r && !s.error) { s.error = r; s.error_msg = rcgpu_last_error(); }
+            }
+            s.cv.notify_all();
+        }
+    };
+
+    std::vector<std::thread> threads;
+    for (uint32_t i = 0; i < readers; i++) threads.emplace_back(reader);
+    for (lane_t& L : s.lanes) threads.emplace_back(lane_main, std::ref(L));
+    std::thread placer_thread(placer);
+    std::vector<std::thread> wthreads;
+    for (uint32_t i = 0; i < writers; i++) wthreads.emplace_back(writer);
+    for (auto& t : threads) t.join();
+    // a lane that stopped early (error) leaves the placer waiting: the error flag wakes it
+    placer_thread.join();
+    for (auto& t : wthreads) t.join();
+    allocator.join();
+    for (lane_t& L : s.lanes) { (void)hipSetDevice(L.device); (void)hipDeviceSynchronize(); }
+    {   // slots still listed as pending are free now
+        std::lock_guard<std::mutex> l(s.m);
+        for (auto& u : s.pending) s.lanes[size_t(u.lane)].free_events.push_back(u.ev);
+        s.pending.clear(); s.free_slots.clear();
+    }
+    if (stats) {
+        stats->seconds = since(t0); stats->first_packet_seconds = first_packet_seconds; stats->frames = N;
+        for (const pipe_frame& f : frames) stats->payload_bytes += s.payload[f.video];
+        stats->packet_bytes = packet_bytes; stats->batches = batches.size(); stats->batch_frames = maxF; stats->lanes = uint32_t(nl);
+        stats->readers = readers; stats->writers = writers; stats->device_busy_seconds = busy0;
+    }
+    if (s.error) return fail(s.error, "%s", s.error_msg.c_str());
+    return 0;
+}
+
+}  // namespace rc
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI: one picture sequence through the pipeline, with the caller's callbacks on both ends
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, const rcgpu_sequence_io* io,
+                                          const rcgpu_sequence_options* opt, rcgpu_sequence_stats* stats, uint8_t* record, size_t* record_size)
+{
+    using namespace rc;
+    clear_error();
+    if (!cfg || !io || !io->read_frame || !io->packet_done) return fail(1, "sequence: null argument");
+    pipe_video v; v.cfg = *cfg; v.frames = n_frames;
+    pipe_options po;
+    if (opt) { po.device_first = opt->device_first; po.device_count = opt->device_count; po.readers = opt->readers; po.writers = opt->writers;
+               po.in_slots = opt->in_ring_frames; po.out_ring_bytes = opt->out_ring_bytes; po.batch = opt->batch; }
+    if (!po.batch) po.batch = cfg->max_batch > 1 ? cfg->max_batch : 0;
+    po.trace = getenv("RCGPU_TRACE") != nullptr;
+    pipeline pl;
+    if (int r = pl.prepare({ v }, po)) return r;
+    if (record_size) {
+        const size_t cap = *record_size;
+        *record_size = rcgpu_ffv1_config_record(pl.encoder(0), record, record ? cap : 0);
+    }
+    std::vector<pipe_frame> frames(n_frames);
+    for (uint64_t i = 0; i < n_frames; i++) frames[i] = { 0, i };
+    const size_t payload = size_t(payload_bytes(cfg->pixfmt, cfg->width, cfg->height, cfg->line_bytes, cfg->flags));
+    pipe_io pio;
+    pio.read = [&](const pipe_frame& f, uint8_t* dst) { return io->read_frame(io->user, f.index, dst, payload); };
+    if (io->place_packet) pio.place = [&](const pipe_frame& f, size_t size) { return io->place_packet(io->user, f.index, size); };
+    pio.done = [&](const pipe_frame& f, const uint8_t* data, size_t size) { return io->packet_done(io->user, f.index, data, size); };
+    pipe_stats ps;
+    const int r = pl.run(frames, pio, &ps);
+    if (stats) {
+        stats->seconds = ps.seconds; stats->first_packet_seconds = ps.first_packet_seconds; stats->prepare_seconds = ps.prepare_seconds;
+        stats->frames = ps.frames; stats->payload_bytes = ps.payload_bytes; stats->packet_bytes = ps.packet_bytes; stats->batches = ps.batches;
+        stats->batch_frames = ps.batch_frames; stats->devices = ps.lanes; stats->readers = ps.readers; stats->writers = ps.writers;
+        stats->device_busy_seconds = ps.device_busy_seconds;
+    }
+    return r;
+}

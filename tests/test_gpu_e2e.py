@@ -325,3 +325,55 @@ def test_video_with_copied_32_bit_audio(built, refbin, tmp_path):
         f.write(synth.wav_file(synth.pcm_samples(6000, 2, 24), 32, float32=True))
     r = run([refbin, "--bin-name", SHIM, "--check", "-y", "pkg"], work)
     assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("opts", [["-slicecrc", "0"], ["-context", "0"], ["-slicecrc", "0", "-context", "0"]], ids=lambda o: "".join(o))
+def test_slicecrc_0_and_context_0_through_the_reference(built, refbin, tmp_path, opts):
+    """`rawcooked -slicecrc 0` / `-context 0` (Source/CLI/Global.cpp:337-485; accepted values Project/GNU/CLI/test/check.sh:87-98) at
+    -level 3, multi-slice, with audio: the reference passes the options on, the shim codes them on the GPU, the reference decodes."""
+    work = str(tmp_path)
+    make_package(work, 160, 90, synth.PIX_RGB16_BE, 4, "film", audio=(2, 24, 48000, 5000))
+    r = run([refbin] + opts + ["--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in range(0, len(opts), 2):
+        assert ("%s %s " % (opts[k], opts[k + 1])) in r.stdout, r.stdout
+    assert "-level 3 " in r.stdout
+    argv = shlex.split(r.stdout.strip())
+    r = run([SHIM] + argv[1:], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = run([refbin, "--check", "pkg.mkv"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+    r = run([refbin, "-y", "pkg.mkv"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for i in range(4):
+        rel = os.path.join("pkg", "img", "f_%06d.dpx" % i)
+        assert open(os.path.join(work, rel), "rb").read() == open(os.path.join(work, "pkg.mkv.RAWcooked", rel), "rb").read()
+
+
+@pytest.mark.parametrize("env", [{}, {"RCGPU_MKV_NO_MMAP": "1"}], ids=["mapped-output", "pwrite-output"])
+def test_long_sequence_crosses_batches_and_ring_slots(built, refbin, tmp_path, env):
+    """70 frames in batches of 16 with audio: several batches in flight (upload k+1, code k, download k-1), pinned slots and ring chunks
+    reused, packets placed in frame order by parallel writers -- into the mapped file, or with pwrite where mapping is refused."""
+    work = str(tmp_path)
+    make_package(work, 96, 64, synth.PIX_RGB16_BE, 70, "film", audio=(2, 16, 48000, 140000))
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    argv = shlex.split(r.stdout.strip())
+    r = subprocess.run([SHIM] + argv[1:] + [], cwd=work, capture_output=True, text=True, env=dict(os.environ, RCGPU_BATCH="16", **env), timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = run([refbin, "--check", "pkg.mkv"], work, timeout=60)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+
+
+def test_error_text_of_a_reader_thread_reaches_the_user(built, refbin, tmp_path):
+    """A frame in the middle of the sequence differs in geometry: the message of the reader thread that met it is what the user sees."""
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB16_BE, 12, "film")
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    argv = shlex.split(r.stdout.strip())
+    bits, nc, _, _ = synth.PIX_INFO[synth.PIX_RGB16_BE]
+    with open(os.path.join(work, "pkg", "img", "f_000007.dpx"), "wb") as f:
+        f.write(synth.dpx_file(synth.components(80, 48, nc, bits, "film", seed=3), synth.PIX_RGB16_BE, frame_index=7))
+    r = run([SHIM] + argv[1:], work)
+    assert r.returncode != 0 and "Error: " in r.stderr and "f_000007.dpx differs in geometry" in r.stderr, r.stderr
+    assert not os.path.exists(os.path.join(work, "pkg.mkv"))

@@ -1,0 +1,121 @@
+"""The upload / encode / download pipeline (rcgpu_ffv1_encode_sequence, rawcooked_amd/csrc/pipeline.hip): what the ffmpeg process
+started at Source/CLI/Output.cpp:356 does with one picture sequence.  Packets must equal the oracle's, whatever the batching."""
+import ctypes as C
+import threading
+
+import pytest
+
+from rawcooked_amd import api, synth
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def _sequence(w, h, pixfmt, n, kind="film"):
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    out = []
+    for i in range(n):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, kind, seed=100 + i), pixfmt, True)
+        out.append(pl)
+    return out, line_bytes
+
+
+@pytest.mark.parametrize("n,batch,in_ring,out_ring", [(37, 8, 3, 1 << 20), (5, 16, 0, 0), (64, 0, 0, 0), (1, 0, 0, 0)])
+def test_sequence_equals_oracle(n, batch, in_ring, out_ring):
+    w, h, pixfmt = 192, 96, synth.PIX_RGB16_BE
+    payloads, line_bytes = _sequence(w, h, pixfmt, n)
+    keep = [C.create_string_buffer(p, len(p)) for p in payloads]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 3, 2, 1, 1, 0, 0, 0, 0, 1, 3)
+    got, lock, order = {}, threading.Lock(), []
+
+    def read_frame(frame, dst, nbytes):
+        assert nbytes == len(payloads[frame])
+        C.memmove(dst, keep[frame], nbytes)
+        return 0
+
+    def packet_done(frame, data, size):
+        b = C.string_at(data, size)
+        with lock:
+            got[frame] = b
+            order.append(frame)
+        return 0
+
+    st, rec = api.encode_sequence(cfg, n, read_frame, packet_done, batch=batch, in_ring_frames=in_ring, out_ring_bytes=out_ring, readers=3, writers=2)
+    assert st.frames == n and len(got) == n
+    assert st.packet_bytes == sum(len(v) for v in got.values())
+    p = ob.Params(w, h, pixfmt, 3, 2, 1, 1)
+    for i in range(n):
+        assert got[i] == ob.encode_payload(p, payloads[i], line_bytes), f"packet {i} differs from the oracle's"
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 3, 2, 1, 1, max_batch=1)
+    assert rec == enc.config_record()
+    enc.close()
+
+
+def test_place_packet_is_called_in_frame_order_and_filled():
+    w, h, pixfmt, n = 128, 64, synth.PIX_RGB10_FILLEDA_BE, 23
+    payloads, line_bytes = _sequence(w, h, pixfmt, n)
+    keep = [C.create_string_buffer(p, len(p)) for p in payloads]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 2, 2, 1, 1, 0, 0, 0, 0, 1, 3)
+    arena = C.create_string_buffer(n * (1 << 16))
+    base = C.addressof(arena)
+    placed, sizes = [], {}
+
+    def place(frame, size):
+        placed.append(frame)
+        sizes[frame] = size
+        return base + frame * (1 << 16)
+
+    def done(frame, data, size):
+        assert data == base + frame * (1 << 16) and size == sizes[frame]
+        return 0
+
+    api.encode_sequence(cfg, n, lambda f, d, nb: C.memmove(d, keep[f], nb) and 0, done, place_packet=place, batch=5)
+    assert placed == list(range(n))
+    p = ob.Params(w, h, pixfmt, 2, 2, 1, 1)
+    for i in range(n):
+        assert arena.raw[i * (1 << 16):i * (1 << 16) + sizes[i]] == ob.encode_payload(p, payloads[i], line_bytes)
+
+
+def test_a_failing_reader_ends_the_job_with_its_code():
+    w, h, pixfmt, n = 64, 48, synth.PIX_RGB16_BE, 40
+    payloads, line_bytes = _sequence(w, h, pixfmt, 1)
+    keep = C.create_string_buffer(payloads[0], len(payloads[0]))
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 2, 2, 1, 1, 0, 0, 0, 0, 1, 3)
+
+    def read_frame(frame, dst, nbytes):
+        if frame == 17:
+            return 77
+        C.memmove(dst, keep, nbytes)
+        return 0
+
+    with pytest.raises(api.RcgpuError):
+        api.encode_sequence(cfg, n, read_frame, lambda f, d, s: 0, batch=4)
+    # the library is usable afterwards
+    st, _ = api.encode_sequence(cfg, 3, lambda f, d, nb: C.memmove(d, keep, nb) and 0, lambda f, d, s: 0, batch=4)
+    assert st.frames == 3
+
+
+def test_device_pointer_api_reports_a_slice_that_outgrew_its_buffer():
+    """rcgpu_ffv1_encode_device only enqueues work; rcgpu_ffv1_last_error_flags is how its callers learn about an overflow.  Forced
+    here with RCGPU_TEST_CBUF_DIV (slice buffers a fraction of their normal size) and incompressible content."""
+    import os
+    import torch
+    w, h, pixfmt = 256, 128, synth.PIX_RGB16_BE
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, "noise", seed=5), pixfmt, True)
+    os.environ["RCGPU_TEST_CBUF_DIV"] = "64"
+    try:
+        enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 2, 2, 1, 1, max_batch=1)
+    finally:
+        del os.environ["RCGPU_TEST_CBUF_DIV"]
+    d = torch.frombuffer(bytearray(pl), dtype=torch.uint8).cuda()
+    pk = torch.empty(enc.max_packet, dtype=torch.uint8, device="cuda")
+    sz = torch.zeros(1, dtype=torch.int64, device="cuda")
+    enc.encode_device([d.data_ptr()], pk.data_ptr(), enc.max_packet, sz.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(api.RcgpuError, match="outgrew|does not fit"):
+        enc.error_flags()
+    enc.close()
+    ok = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 2, 2, 1, 1, max_batch=1)
+    ok.encode_device([d.data_ptr()], pk.data_ptr(), ok.max_packet, sz.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert ok.error_flags() == 0
+    ok.close()

@@ -290,3 +290,36 @@ def test_configurations_the_device_path_cannot_hold_are_refused(built):
         a = dict(ok, **bad)
         with pytest.raises(RuntimeError):
             api.Ffv1Decoder(a["width"], a["height"], a["pixfmt"], a["line_bytes"], a["num_h"], a["num_v"])
+
+
+@pytest.mark.parametrize("slicecrc,context", [(0, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize("pixfmt,w,h,slices", [(synth.PIX_RGB16_BE, 200, 120, 6), (synth.PIX_RGB10_FILLEDA_BE, 130, 67, 9), (synth.PIX_RGBA16_LE, 64, 48, 4),
+                                                (synth.PIX_Y16_BE, 80, 40, 4), (synth.PIX_RGB8, 257, 131, 16)])
+def test_level3_without_slicecrc_and_with_the_3_input_model(built, pixfmt, w, h, slices, slicecrc, context):
+    """`-slicecrc 0` (3-byte slice tail, ec = 0 in the record: k_footer's !ec branch, the decoder's tail = 3) and `-context 0`
+    (3-input context model: is5 == 0 in k_model) at -level 3, both reachable from rawcooked's command line
+    (Source/CLI/Global.cpp:337-485): multi-slice, several frames, segmented hand-over; bytes equal the oracle's and the device
+    decoder rebuilds the payloads."""
+    import torch
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    nh, nv = api.slices_to_grid(slices)
+    payloads = []
+    for i in range(3):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, ["film", "noise", "flat"][i], seed=170 + i), pixfmt, True)
+        payloads.append(pl)
+    p = ob.Params(w, h, pixfmt, nh, nv, slicecrc, context)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, slicecrc, context, max_batch=3, segments=3)
+    assert enc.config_record() == ob.config_record(p)
+    packets = enc.encode_host(payloads)
+    for f in range(3):
+        assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"frame {f}"
+        assert ob.decode_payload(p, packets[f], line_bytes) == payloads[f]
+    cfg = api.config_from_record(enc.config_record(), w, h, pixfmt, line_bytes, context=context)
+    assert (cfg.slicecrc, cfg.num_h_slices, cfg.num_v_slices) == (slicecrc, nh, nv)
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, slicecrc, context, max_batch=3)
+    dpk = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in packets]
+    dout = [torch.empty(len(x), dtype=torch.uint8, device="cuda") for x in payloads]
+    assert dec.decode_device([t.data_ptr() for t in dpk], [len(x) for x in packets], [t.data_ptr() for t in dout]) == 0
+    for f in range(3):
+        assert bytes(dout[f].cpu().numpy()) == payloads[f]
+    enc.close(); dec.close()
