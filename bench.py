@@ -7,7 +7,15 @@ already resident in HBM, -slices 64 (8x8), -coder 1 -context 1 -slicecrc 1 -g 1 
 passes (Source/CLI/Global.cpp:938-989).  Frames shard across ranks with no collective: every rank
 encodes its own batch; torch.distributed (RCCL) is used only for the barriers and the max-over-ranks timing.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch F] [--kind film|flat|noise]
+The JSON line carries, beside the device-resident headline (`value`, the driver's contract):
+  host_pipeline  the same workload with payloads starting and packets ending in HOST memory: reader threads fill pinned slots, every
+                 batch is uploaded while the previous one is coded and downloaded while the next one is (rcgpu_ffv1_encode_sequence);
+                 every rank runs it, so at N > 1 it shows where the GPUs contend (host memory, PCIe root)
+  e2e            files on tmpfs -> rcgpu-ffmpeg (the argv the reference prints) -> MKV on tmpfs, process start to exit (N = 1)
+  check          BASELINE config 5: device FFV1 decode + byte compare + MD5 of the same packets (N = 1)
+  cpu_baseline   the scalar oracle on all host cores and on one (kind "port": the reference's encoder is FFmpeg, absent here)
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch F] [--kind film|flat|noise] [--legs host,e2e,check,cpu]
 """
 from __future__ import annotations
 
@@ -55,11 +63,11 @@ def make_frames(torch, n, width, height, kind, seed, device):
     return out
 
 
-def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int, frames_done_per_thread: int = 1):
-    """The oracle (scalar C restatement, kind 'port') on the host cores: one frame per thread, all cores."""
+def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int):
+    """The oracle (scalar C restatement, kind 'port') on the host: one frame per thread on all cores, and one frame on one core."""
     import oracle_binding as ob
     from rawcooked_amd import synth
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = max(1, os.cpu_count() or 1)
     try:                                            # ~0.7 GB of host memory per oracle thread at 4K: never let the baseline endanger the box
         import psutil
         cores = max(1, min(cores, int(psutil.virtual_memory().available / (1 << 30) / 1.5)))
@@ -67,22 +75,23 @@ def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int, 
         cores = min(cores, 16)
     p = ob.Params(width, height, synth.PIX_RGB16_BE, 8, 8, 1, 1)
     ob.lib()
-    out = [None] * cores
 
-    def work(i):
-        for _ in range(frames_done_per_thread):
-            out[i] = len(ob.encode_payload(p, payload_host, line_bytes))
+    def run(nthreads):
+        def work():
+            ob.encode_payload(p, payload_host, line_bytes)
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=work) for _ in range(nthreads)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return nthreads / (time.perf_counter() - t0)
 
-    t0 = time.perf_counter()
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
-    nfr = cores * frames_done_per_thread
-    return {"value": round(nfr / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{nfr} frames of the same {width}x{height} RGB16 workload, one frame per thread, oracle/ffv1_oracle.c (scalar C, not FFmpeg)"}
+    one = run(1)
+    allc = run(cores)
+    return {"value": round(allc, 4), "unit": "frames/s", "cores": cores, "kind": "port", "one_core": round(one, 4),
+            "sample": f"{cores} frames of the same {width}x{height} RGB16 workload, one frame per thread on {cores} threads (and 1 frame on 1 thread: "
+                      f"{one:.3f} frames/s), oracle/ffv1_oracle.c (scalar C, not FFmpeg; the reference's own encoder is the ffmpeg binary, absent here)"}
 
 
 def reference_check_baseline(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=16):
@@ -133,18 +142,14 @@ def reference_check_baseline(api, synth, record, frames, d_packets, stride, size
         shutil.rmtree(work, ignore_errors=True)
 
 
-def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device):
-    """Config 5: decode the MKV payloads back and verify them -- everything resident in HBM (single GPU)."""
-    enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
-    torch.cuda.synchronize()
-    sizes = d_sizes.cpu().tolist()
-    cpu = None
-    if not args.no_cpu_baseline:
+def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device, steps, warmup, cpu=True):
+    """Config 5: decode the packets back and verify them -- everything resident in HBM (single GPU).  The caller has released the
+    encoder: the decoder is latency-bound per slice chain, its rate is chains in flight / chain latency, so D >= F frames are decoded per
+    step (the F encoded packets, reused round-robin -- SURVEY.md 8d "ring reuse")."""
+    cpu_rec = None
+    if cpu:
         from rawcooked_amd import synth as _synth
-        cpu = reference_check_baseline(api, _synth, enc.config_record(), frames, d_packets, stride, sizes, width, height, pixfmt)
-    # the decoder is latency-bound per slice chain, so its rate is chains in flight / chain latency: free the encoder's buffers
-    # and decode D >= F frames per step (the F encoded packets, reused round-robin -- SURVEY.md 8d "ring reuse")
-    enc.close()
+        cpu_rec = reference_check_baseline(api, _synth, record, frames, d_packets, stride, sizes, width, height, pixfmt)
     torch.cuda.empty_cache()
     D = max(F, args.check_batch)
     sizes = [sizes[i % F] for i in range(D)]
@@ -161,12 +166,11 @@ def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, 
     pipelined = len(outs) == 2
     pk = [d_packets.data_ptr() + (i % F) * stride for i in range(D)]
     ops = [[o[i].data_ptr() for i in range(D)] for o in outs]
-    op = ops[0]
     ptrs = [ptrs[i % F] for i in range(D)]
     import hashlib
-    want = [hashlib.md5(bytes(frames[i].cpu().numpy())).digest() for i in range(F)]        # F distinct sources, reused round-robin
+    F0 = min(F, 32)                                                                        # distinct sources hashed on the host
+    want = {i: hashlib.md5(bytes(frames[i].cpu().numpy())).digest() for i in range(F0)}
     side = torch.cuda.Stream()
-    F0, F = F, D
     state = {"k": 0, "bad": 0, "hashed": 0, "ev": None}
 
     def step():
@@ -176,41 +180,145 @@ def check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, 
         if pipelined and state["ev"] is not None:
             side.wait_event(state["ev"])
             got = api.md5_device(ops[cur ^ 1], [payload_bytes] * D, side.cuda_stream)
-            state["bad"] += sum(got[i] != want[i % F0] for i in range(D)); state["hashed"] += D
+            state["bad"] += sum(got[i] != want[i % F] for i in range(D) if (i % F) in want); state["hashed"] += D
         state["ev"] = ev; state["k"] = k + 1
 
-    for _ in range(max(0, args.warmup)):
+    for _ in range(max(0, warmup)):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     op = ops[(state["k"] - 1) & 1 if pipelined else 0]                                     # the batch decoded last: verified below
     kt = dec.kernel_times()
     t1 = time.perf_counter()
-    same = all(api.compare_device(op[i], ptrs[i], line_bytes * height, stream) == -1 for i in range(F))
-    md5 = api.md5_device(op[:min(F, 64)], [line_bytes * height] * min(F, 64), stream)
+    same = all(api.compare_device(op[i], ptrs[i], line_bytes * height, stream) == -1 for i in range(D))
+    md5 = api.md5_device(op[:min(D, 64)], [line_bytes * height] * min(D, 64), stream)
     t_verify = time.perf_counter() - t1
     ok_md5 = md5[0] == want[0] and state["bad"] == 0
     payload = line_bytes * height
     packet_avg = sum(sizes) / len(sizes)
     dom = "k_dec_slices"
-    achieved = F * (packet_avg + payload) / (kt[dom] * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "4K-DCI 16-bit FFV1->DPX check frames/sec", "value": round(F * args.steps / dt, 3), "unit": "frames/s", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+    achieved = D * (packet_avg + payload) / (kt[dom] * 1e-3) / 1e9
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        try:
+            per_frame = json.load(open(tj)).get(dom, {}).get("per_frame_bytes")
+            traffic = int(per_frame * D) if per_frame else None
+        except Exception:
+            traffic = None
+    rec = {
+        "metric": "4K-DCI 16-bit FFV1->DPX check frames/sec", "value": round(D * steps / dt, 3), "unit": "frames/s", "n_gpus": 1,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-        "config": {"workload": f"{width}x{height} RGB16 FFV1 packets (slices={args.slices}) -> payload, byte compare + MD5 on device", "frames_per_step_per_gpu": F,
+        "config": {"workload": f"{width}x{height} RGB16 FFV1 packets (slices={args.slices}) -> payload, byte compare + MD5 on device", "frames_per_step_per_gpu": D,
                    "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "md5_inside_timed_region": state["hashed"],
                    "verify_seconds_last_batch": round(t_verify, 3)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": None, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}},
-        **({"cpu_baseline": cpu} if cpu else {})}))
+                     "traffic": traffic, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}},
+        **({"cpu_baseline": cpu_rec} if cpu_rec else {})}
     dec.close()
-    if not (same and ok_md5):
-        sys.exit(2)
+    del outs
+    torch.cuda.empty_cache()
+    return rec, bool(same and ok_md5)
+
+
+def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barrier, reduce_max):
+    """The workload again with payloads starting and packets ending in host memory (pageable, like the page cache the reference's
+    mmaps read from): rcgpu_ffv1_encode_sequence -- reader threads copy into pinned slots, upload / code / download overlap, writer
+    threads copy every packet out of the pinned ring into host buffers.  expect_packets: device-resident packets of the ring's
+    frames, byte-compared with what arrives here."""
+    import ctypes as C
+    import numpy as np
+    R = len(host_ring)
+    payload = host_ring[0].nbytes
+    src = [a.ctypes.data for a in host_ring]
+    nout = 64
+    outs = [np.empty(int(payload * 1.3) + (1 << 20), dtype=np.uint8) for _ in range(nout)]       # where packets end: pageable host memory, reused
+    dst = [a.ctypes.data for a in outs]
+    sizes = [0] * n_frames
+    bad = []
+    check_until = min(n_frames, R, len(expect_packets))
+
+    def read_frame(frame, d, nbytes):
+        C.memmove(d, src[frame % R], nbytes)
+        return 0
+
+    def packet_done(frame, data, size):
+        sizes[frame] = size
+        if size > outs[0].nbytes:
+            return 90
+        C.memmove(dst[frame % nout], data, size)
+        if frame < check_until and C.string_at(dst[frame % nout], size) != expect_packets[frame]:
+            bad.append(frame)
+        return 0
+
+    barrier()
+    t0 = time.perf_counter()
+    st, _ = api.encode_sequence(cfg, n_frames, read_frame, packet_done, batch=batch, device_first=cfg.device, device_count=1)
+    wall = time.perf_counter() - t0
+    dt = reduce_max(st.seconds)          # the pipeline's own clock: first read to last packet, encoder creation (prepare_seconds) beside it
+    return {"frames_per_gpu": n_frames, "seconds": round(dt, 3), "prepare_seconds": round(st.prepare_seconds, 3),
+            "call_seconds": round(wall, 3), "first_packet_seconds": round(st.first_packet_seconds, 3),
+            "h2d_GBps": round(st.payload_bytes / st.seconds / 1e9, 2), "d2h_GBps": round(st.packet_bytes / st.seconds / 1e9, 2),
+            "batch_frames": st.batch_frames, "batches": st.batches, "readers": st.readers, "writers": st.writers,
+            "device_busy_seconds": round(st.device_busy_seconds, 3),
+            "packets_identical_to_device_resident_run": (not bad) if check_until else None,
+            "source": f"ring of {R} distinct frames in pageable host memory, reused", "_local": (n_frames, st.seconds, dt)}, (not bad)
+
+
+def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packet0):
+    """Files on tmpfs -> `rcgpu-ffmpeg` with the argv grammar the reference assembles (Source/CLI/Output.cpp:81-310) -> MKV on tmpfs:
+    the disk is out of the number, everything else (process start, device init, buffers, readers, muxer) is in it."""
+    import shutil
+    import struct
+    import subprocess
+    import numpy as np
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    work = os.path.join(base, "rcgpu_e2e_%d" % os.getpid())
+    shutil.rmtree(work, ignore_errors=True)
+    try:
+        os.makedirs(os.path.join(work, "uniq"))
+        os.makedirs(os.path.join(work, "img"))
+        R = len(host_ring)
+        payload = host_ring[0].nbytes
+        need = R * payload + int(n_frames * payload * 1.05)
+        if shutil.disk_usage(base).free < need * 1.2:
+            return {"skipped": f"{base} has no room for {need >> 30} GiB"}, True
+        hdr = synth.dpx_file(np.zeros((1, 1, 3), dtype=np.uint16), synth.PIX_RGB16_BE)[:2048]
+        for i in range(R):
+            h = bytearray(hdr)
+            struct.pack_into(">I", h, 772, width); struct.pack_into(">I", h, 776, height); struct.pack_into(">I", h, 16, 2048 + payload)
+            with open(os.path.join(work, "uniq", "u_%03d.dpx" % i), "wb") as f:
+                f.write(h); f.write(memoryview(host_ring[i]))
+        for i in range(n_frames):                           # the sequence: hard links to the ring's files (SURVEY.md 8d: "ring reuse")
+            os.link(os.path.join(work, "uniq", "u_%03d.dpx" % (i % R)), os.path.join(work, "img", "f_%06d.dpx" % i))
+        shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+        argv = [shim, "-xerror", "-framerate", "24.000000", "-r", "24.000000", "-f", "image2", "-c:v", "dpx", "-start_number", "000000",
+                "-i", "img/f_%06d.dpx", "-c:v", "ffv1", "-coder", "1", "-context", "1", "-f", "matroska", "-g", "1", "-level", "3",
+                "-slicecrc", "1", "-slices", str(slices), "-y", "-f", "matroska", "out.mkv"]
+        t0 = time.perf_counter()
+        r = subprocess.run(argv, cwd=work, capture_output=True, text=True, env=dict(os.environ, RCGPU_TRACE="1"), timeout=600)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-400:]}, False
+        size = os.path.getsize(os.path.join(work, "out.mkv"))
+        ok = None
+        if expect_packet0:
+            with open(os.path.join(work, "out.mkv"), "rb") as f:
+                headb = f.read(len(expect_packet0) + (1 << 20))
+            at = headb.find(expect_packet0[:64])
+            ok = at > 0 and headb[at:at + len(expect_packet0)] == expect_packet0
+        pl = [ln for ln in r.stderr.splitlines() if "pipeline:" in ln and "frames in" in ln]
+        return {"frames": n_frames, "seconds": round(dt, 3), "value": round(n_frames / dt, 2), "unit": "frames/s", "mkv_bytes": size,
+                "read_GBps": round(n_frames * (payload + 2048) / dt / 1e9, 2), "write_GBps": round(size / dt / 1e9, 2),
+                "first_block_identical_to_device_resident_run": ok, "trace": pl[-1].split("pipeline: ", 1)[1] if pl else None,
+                "what": f"process start to exit of rcgpu-ffmpeg: {n_frames} x {width}x{height} RGB16 DPX on tmpfs ({R} distinct, hard-linked) -> FFV1 slices={slices} -> MKV on tmpfs"}, ok is not False
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def main():
@@ -220,18 +328,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "384")), help="frames in flight per GPU per step")
     ap.add_argument("--segments", type=int, default=0, help="hand-over windows per slice between k_resolve and k_rangecode (0 = library default)")
-    ap.add_argument("--check-batch", type=int, default=1600, help="--mode check: frames decoded per step (>= --batch)")
+    ap.add_argument("--check-batch", type=int, default=1600, help="check leg: frames decoded per step (>= --batch)")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--legs", default="host,e2e,check,cpu", help="comma list of the extra records: host (host_pipeline), e2e, check, cpu (cpu_baseline); '' = none")
+    ap.add_argument("--host-frames", type=int, default=1920, help="host_pipeline: frames per GPU")
+    ap.add_argument("--e2e-frames", type=int, default=1000, help="e2e: frames of the sequence (BASELINE config 2: 1000)")
     ap.add_argument("--context-model", default="ffmpeg", choices=["ffmpeg", "compact"],
                     help="level maps of the 5-input context model: FFmpeg's (5063 contexts, states in HBM) or compact (338 contexts, states in LDS)")
     ap.add_argument("--mode", default="encode", choices=["encode", "check"],
-                    help="check: BASELINE config 5 -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
+                    help="check: BASELINE config 5 alone -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
+    legs = {x for x in args.legs.split(",") if x}
+    if args.no_cpu_baseline:
+        legs.discard("cpu")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # asked for several GPUs without a launcher: start one rank per GPU ourselves, the way the driver does
@@ -246,20 +360,20 @@ def main():
 
     import torch
     from rawcooked_amd import api, synth
+    from rawcooked_amd import dist as rdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        dist = None
-        torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = rdist.init(world, rank, local_rank, "nccl", dev)          # None at world == 1
+
+    def barrier():
+        rdist.barrier(dist)
+
+    def reduce_max(x):
+        return rdist.max_over_ranks(dist, x, dev)
 
     width, height, F = args.width, args.height, args.batch
     pixfmt = synth.PIX_RGB16_BE
@@ -277,35 +391,18 @@ def main():
     def step():
         enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
     if args.mode == "check":
-        return check_mode(args, torch, api, enc, frames, d_packets, d_sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, local_rank)
+        step(); torch.cuda.synchronize()
+        sizes = d_sizes.cpu().tolist(); record = enc.config_record(); enc.close()
+        rec, ok = check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, local_rank,
+                            args.steps, args.warmup, cpu="cpu" in legs)
+        print(json.dumps(rec))
+        sys.exit(0 if ok else 2)
 
-    for _ in range(max(0, args.warmup)):
-        step()
-    torch.cuda.synchronize()
-    # per-kernel device time of one (untimed) step, HIP events recorded on the launch stream
-    ktimes = enc.kernel_times()
-
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    ksum = {k: 0.0 for k in ktimes}
-    kt = enc.kernel_times()          # events of the last timed step
-    for k in kt:
-        ksum[k] = kt[k]
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- the headline: device-resident steps, timed as the driver's contract says (barrier + synchronize on both sides, max over ranks)
+    dt = rdist.timed_steps(dist, dev, step, args.steps, args.warmup, torch.cuda.synchronize)
+    kt = enc.kernel_times()          # HIP events of the last timed step, recorded on the launch streams
+    flags = enc.error_flags()        # the device-pointer API only enqueues: this is where an overflow would show (raises)
 
     sizes = d_sizes.cpu().tolist()
     decisions, _ = enc.stats()
@@ -313,10 +410,12 @@ def main():
     fps = total_frames / dt
     payload_bytes = line_bytes * height
     packet_avg = sum(sizes) / len(sizes)
+    hbm_in_use = round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 1e9, 1)
 
     verified = verified_ref = None
+    R = min(F, 32)
     if rank == 0 and not args.no_verify:
-        # parity spot check outside the timed region: packet 0 of the last step == the oracle's bytes and decodes to the source
+        # parity spot check outside the timed region: packet 0 of the last step decodes to the source through the oracle
         import oracle_binding as ob
         p = ob.Params(width, height, pixfmt, nh, nv, 1, ctx)
         pk = bytes(d_packets[:sizes[0]].cpu().numpy())
@@ -332,6 +431,7 @@ def main():
             print("bench: the reference rejected the GPU packets", file=sys.stderr)
             sys.exit(2)
 
+    result = None
     if rank == 0:
         dom = max(kt, key=lambda k: kt[k]) if kt else None
         launches = enc.kernel_launches()
@@ -342,20 +442,21 @@ def main():
             alg_bytes_launch = F * (payload_bytes + packet_avg) / nl
             launch_ms = kt[dom] / nl
             achieved = alg_bytes_launch / (launch_ms * 1e-3) / 1e9
-            traffic = None
+            traffic = note = None
             tj = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tj):
                 try:
-                    per_frame = json.load(open(tj)).get(dom, {}).get("per_frame_bytes")
+                    tjd = json.load(open(tj))
+                    per_frame = tjd.get(dom, {}).get("per_frame_bytes")
                     traffic = int(per_frame * F / nl) if per_frame else None      # PMC-measured HBM bytes per launch (scales with the batch)
+                    note = tjd.get("note")
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg_bytes_launch), "launch_ms": round(launch_ms, 3), "launches_per_step": nl,
                     "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0},
-                    "note": "entropy coding: bound by VALU issue on serial chains, not by bytes -- SQ counters in profiles/ put 83 % of the chip's "
-                            "instruction-issue slots in use during the step (DESIGN.md section 5)"}
+                    "note": note or "entropy coding: serial per slice and per context, bound by instruction issue rather than bytes (DESIGN.md section 5)"}
         result = {
             "metric": "4K-DCI 16-bit DPX->FFV1 frames/sec", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -365,16 +466,50 @@ def main():
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective",
                        "packet_bytes_avg": int(packet_avg), "compression_ratio": round(packet_avg / payload_bytes, 4),
                        "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified, "verified_by_reference": verified_ref,
-                       "hbm_in_use_gb": round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 1e9, 1)},
+                       "device_error_flags": flags, "hbm_in_use_gb": hbm_in_use},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(bytes(frames[0].cpu().numpy()), line_bytes, width, height)
-        print(json.dumps(result))
+
+    # ---- the extra legs.  What they need of the headline run is kept on the host; the encoder's 170 GB go back first.
+    record = enc.config_record()
+    host_ring = [frames[i].cpu().numpy() for i in range(R)] if (legs & {"host", "e2e"}) else []
+    expect = [bytes(d_packets[i * stride:i * stride + sizes[i]].cpu().numpy()) for i in range(R)] if (legs & {"host", "e2e"}) else []
+    cfg = api.Ffv1Config(width, height, pixfmt, line_bytes, nh, nv, 1, ctx, 0, local_rank, args.segments, 0, 1, 3)
+    ok_all = True
+    if "check" in legs and world == 1:
+        keep_pk = d_packets
+    else:
+        keep_pk = None
     enc.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if keep_pk is None:
+        del d_packets
+    torch.cuda.empty_cache()
+
+    if "host" in legs:
+        hp, ok = host_pipeline_leg(api, cfg, host_ring, args.host_frames, F, expect, barrier, reduce_max)
+        ok_all &= ok
+        n_loc, _, dt_all = hp.pop("_local")
+        if result is not None:
+            hp["value"] = round(world * n_loc / dt_all, 2); hp["unit"] = "frames/s"; hp["n_gpus"] = world
+            hp["fraction_of_device_resident"] = round(hp["value"] / fps, 3)
+            result["host_pipeline"] = hp
+    if rank == 0 and world == 1:
+        if "e2e" in legs:
+            rec, ok = e2e_leg(synth, host_ring, width, height, args.e2e_frames, args.slices, expect[0] if expect else None)
+            ok_all &= ok
+            result["e2e"] = rec
+        if "check" in legs:
+            rec, ok = check_leg(args, torch, api, record, frames, keep_pk, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, local_rank,
+                                steps=2, warmup=1, cpu="cpu" in legs)
+            ok_all &= ok
+            result["check"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline") if k in rec}
+        if "cpu" in legs:
+            result["cpu_baseline"] = cpu_baseline(host_ring[0].tobytes() if host_ring else bytes(frames[0].cpu().numpy()), line_bytes, width, height)
+    if rank == 0:
+        print(json.dumps(result))
+    rdist.finish(dist)
+    if not ok_all:
+        sys.exit(2)
 
 
 if __name__ == "__main__":

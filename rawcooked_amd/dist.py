@@ -15,7 +15,52 @@ def shard_frames(n_frames: int, rank: int, world: int, batch: int = 1) -> list[i
 
 def max_over_ranks(dist, seconds: float, device) -> float:
     """Wall time of the slowest rank (the driver's contract for bench.py)."""
+    if dist is None:
+        return seconds
     import torch
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def init(world: int, rank: int, local_rank: int, backend: str, device):
+    """One process per GPU (bench.py, launched by torch.distributed.run): RCCL ("nccl") on the GPU box, gloo in the CPU tests.
+    Returns torch.distributed, or None for a single process."""
+    if world <= 1:
+        return None
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    kw = {"device_id": device} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return dist
+
+
+def barrier(dist) -> None:
+    if dist is not None:
+        dist.barrier()
+
+
+def timed_steps(dist, device, step, steps: int, warmup: int, synchronize) -> float:
+    """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by barrier + device synchronize on
+    both sides; the result is the slowest rank's wall time."""
+    import time
+    for _ in range(max(0, warmup)):
+        step()
+    synchronize()
+    barrier(dist)
+    synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    synchronize()
+    barrier(dist)
+    dt = time.perf_counter() - t0
+    return max_over_ranks(dist, dt, device) if dist is not None else dt
+
+
+def finish(dist) -> None:
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -26,15 +26,21 @@ def test_two_ranks_gloo(tmp_path):
         import os, sys, time
         sys.path.insert(0, {ROOT!r})
         import torch, torch.distributed as dist
+        from rawcooked_amd import dist as rdist
         from rawcooked_amd.dist import shard_frames, max_over_ranks
-        dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+        # the same calls bench.py makes at N > 1, with gloo in place of RCCL
+        d2 = rdist.init(int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), 0, "gloo", torch.device("cpu"))
+        assert d2 is dist
         r = dist.get_rank()
         mine = shard_frames(10, r, 2, batch=2)
-        dist.barrier()
+        rdist.barrier(dist)
         t = max_over_ranks(dist, 1.0 + r, torch.device("cpu"))
+        calls = []
+        dt = rdist.timed_steps(dist, torch.device("cpu"), lambda: (calls.append(1), time.sleep(0.05 * (r + 1))), 3, 2, lambda: None)
+        assert len(calls) == 5 and dt >= 0.29, (calls, dt)          # 2 warm-up + 3 timed steps; the slower rank's 3 x 0.1 s
         n = torch.tensor([len(mine)]); dist.all_reduce(n)          # test-side bookkeeping only: the encode path has no collective
         assert t == 2.0 and int(n) == 10, (t, int(n))
-        dist.barrier(); dist.destroy_process_group()
+        rdist.finish(dist)
         print("rank", r, "ok", mine)
     """))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
