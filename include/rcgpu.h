@@ -119,6 +119,9 @@ int rcgpu_tiff_probe(const uint8_t* file, size_t size, rcgpu_image_info* out);
 int rcgpu_exr_probe (const uint8_t* file, size_t size, rcgpu_image_info* out);
 int rcgpu_wav_probe (const uint8_t* file, size_t size, rcgpu_audio_info* out);
 
+/* The reference's flavor string (stream::Flavor, CLI/Output.h:28; DPX_Flavor_String DPX.cpp:762-778, TIFF.cpp:744-750, EXR.cpp:660-666)
+ * -> RCGPU_PIX_*: what a decode-side binding has at hand (raw_frame::Flavor / Flavor_Private restored from the reversibility data). */
+int rcgpu_pixfmt_from_flavor(const char* flavor, uint32_t* pixfmt);
 /* slice_x*slice_y the reference computes for a DPX/TIFF picture (DPX.cpp:428-458, TIFF.cpp:657-672): pixels_per_block > 1
  * models the flavors whose slices must start on a block boundary (e.g. 3 for DPX RGBA 10-bit FilledA); 0 = unsupported. */
 uint32_t rcgpu_reference_slices(uint32_t width, uint32_t height, uint32_t bitdepth, uint32_t pixels_per_block);
@@ -203,12 +206,15 @@ typedef struct {
     uint32_t readers, writers;          /* host threads; 0 = automatic */
     uint32_t in_ring_frames;            /* pinned upload slots; 0 = automatic */
     uint64_t out_ring_bytes;            /* pinned download ring per device; 0 = automatic */
+    uint32_t lanes_per_device;          /* encoder instances per device, their batches staggered (shorter head and tail of a job); 0 = 1 */
 } rcgpu_sequence_options;
 typedef struct {
     double   seconds;                   /* first read_frame .. last packet_done */
     double   first_packet_seconds, prepare_seconds, device_busy_seconds;
     uint64_t frames, payload_bytes, packet_bytes, batches;
     uint32_t batch_frames, devices, readers, writers;
+    double   steady_frames_per_second;  /* all batches but the first / time from the first batch's completion to the last's */
+    double   reads_done_seconds, last_batch_seconds;
 } rcgpu_sequence_stats;
 /* record/record_size: optional, the FFV1 configuration record (Matroska CodecPrivate), *record_size = capacity in, size out. */
 int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, const rcgpu_sequence_io* io,

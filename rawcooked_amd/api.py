@@ -48,13 +48,14 @@ class SequenceIo(C.Structure):
 
 class SequenceOptions(C.Structure):
     _fields_ = [("device_first", C.c_int), ("device_count", C.c_int), ("batch", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
-                ("in_ring_frames", C.c_uint32), ("out_ring_bytes", C.c_uint64)]
+                ("in_ring_frames", C.c_uint32), ("out_ring_bytes", C.c_uint64), ("lanes_per_device", C.c_uint32)]
 
 
 class SequenceStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("first_packet_seconds", C.c_double), ("prepare_seconds", C.c_double), ("device_busy_seconds", C.c_double),
                 ("frames", C.c_uint64), ("payload_bytes", C.c_uint64), ("packet_bytes", C.c_uint64), ("batches", C.c_uint64),
-                ("batch_frames", C.c_uint32), ("devices", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32)]
+                ("batch_frames", C.c_uint32), ("devices", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
+                ("steady_frames_per_second", C.c_double), ("reads_done_seconds", C.c_double), ("last_batch_seconds", C.c_double)]
 
 
 class FlacConfig(C.Structure):
@@ -89,6 +90,7 @@ SYMBOLS = {
     "rcgpu_tiff_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
     "rcgpu_exr_probe": (C.c_int, [_U8P, _SZ, C.POINTER(ImageInfo)]),
     "rcgpu_wav_probe": (C.c_int, [_U8P, _SZ, C.POINTER(AudioInfo)]),
+    "rcgpu_pixfmt_from_flavor": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32)]),
     "rcgpu_reference_slices": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rcgpu_slices_to_grid": (C.c_int, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rcgpu_ffv1_create": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP)]),
@@ -289,7 +291,7 @@ class Ffv1Encoder:
 
 
 def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, place_packet=None, batch=0, readers=0, writers=0,
-                    in_ring_frames=0, out_ring_bytes=0, device_first=0, device_count=0):
+                    in_ring_frames=0, out_ring_bytes=0, device_first=0, device_count=0, lanes_per_device=0):
     """rcgpu_ffv1_encode_sequence: `read_frame(frame, dst_address, nbytes) -> int` fills a pinned upload slot, `packet_done(frame,
     address, size) -> int` receives each packet (writer threads), `place_packet(frame, size) -> address or None` is optional.
     Returns (SequenceStats, configuration record)."""
@@ -297,7 +299,7 @@ def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, pla
     pd = PACKET_DONE_FN(lambda user, frame, data, n: int(packet_done(frame, data, n) or 0))
     pp = PLACE_PACKET_FN(lambda user, frame, n: place_packet(frame, n) or 0) if place_packet else PLACE_PACKET_FN()
     io = SequenceIo(rf, pp, pd, None)
-    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes)
+    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes, lanes_per_device)
     st = SequenceStats()
     rec = C.create_string_buffer(8192)
     rs = _SZ(8192)

@@ -384,6 +384,26 @@ extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* 
     return fail(15, "wav: no data chunk");
 }
 
+// The reference's flavor string -> pixel layout: "DPX/Raw/RGB/10bit/U/BE/FilledA", "TIFF/Raw/RGBA/16bit/U/LE", "EXR/Raw/RGB/16bit/F/BE"
+// (DPX_Flavor_String DPX.cpp:762-778, TIFF_Flavor_String TIFF.cpp:744-750, EXR.cpp:660-666).  What a decoder-side binding has at hand:
+// the flavor restored from the reversibility data (raw_frame::Flavor / Flavor_Private).
+extern "C" int rcgpu_pixfmt_from_flavor(const char* flavor, uint32_t* pixfmt)
+{
+    clear_error();
+    if (!flavor || !pixfmt) return fail(1, "flavor: null argument");
+    if (!strcmp(flavor, "EXR/Raw/RGB/16bit/F/BE")) { *pixfmt = RCGPU_PIX_EXR_RGB16; return 0; }
+    for (uint32_t pf = 0; pf < RCGPU_PIX_COUNT; pf++) {
+        if (pf == RCGPU_PIX_EXR_RGB16) continue;
+        const pix_desc& d = pix(pf);
+        const char* packing = d.fields == kFieldsPacked ? "Packed" : (d.fields == kFieldsLow && d.fill == 0) ? "FilledB" : "FilledA";
+        char t[64];
+        flavor_string(t, "DPX", pf, packing);
+        if (!strcmp(t, flavor)) { *pixfmt = pf; return 0; }
+        if (d.bits % 8 == 0) { flavor_string(t, "TIFF", pf, nullptr); if (!strcmp(t, flavor)) { *pixfmt = pf; return 0; } }
+    }
+    return fail(14, "flavor %s is not supported", flavor);
+}
+
 extern "C" uint32_t rcgpu_reference_slices(uint32_t width, uint32_t height, uint32_t bitdepth, uint32_t pixels_per_block)
 {
     uint32_t sx = reference_slice_x(width, height, bitdepth);

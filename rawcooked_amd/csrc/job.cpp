@@ -309,6 +309,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         po.device_first = dev0; po.device_count = ndev; po.trace = trace;
         po.batch = uint32_t(std::max(0L, opt.num("rcgpu_batch", 0)));      // 0: sized from the device's free memory and the sequence
         if (const char* e = getenv("RCGPU_BATCH")) if (!po.batch) po.batch = uint32_t(std::max(0, atoi(e)));
+        if (const char* e = getenv("RCGPU_LANES")) po.lanes_per_device = uint32_t(std::max(1, atoi(e)));
         if (const char* e = getenv("RCGPU_READERS")) po.readers = uint32_t(std::max(1, atoi(e)));
         if (const char* e = getenv("RCGPU_WRITERS")) po.writers = uint32_t(std::max(1, atoi(e)));
         if (int r = pl.prepare(pvideos, po)) return bail(r);
@@ -416,9 +417,11 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         rc::pipe_stats ps;
         if (int r = pl.run(frames, io, &ps)) return bail(r);
         if (trace) {
-            char b[256];
-            snprintf(b, sizeof b, "pipeline: %llu frames in %.3f s (%.1f frames/s), prepare %.3f s, first packet after %.3f s, batches of %u on %u device(s), %u readers, %u writers",
-                     (unsigned long long)ps.frames, ps.seconds, double(ps.frames) / std::max(ps.seconds, 1e-9), ps.prepare_seconds, ps.first_packet_seconds, ps.batch_frames, ps.lanes, ps.readers, ps.writers);
+            char b[512];
+            snprintf(b, sizeof b, "pipeline: %llu frames in %.3f s (%.1f frames/s; %.1f between the first and the last batch), prepare %.3f s, all files read after %.3f s, "
+                     "last batch coded after %.3f s, first packet after %.3f s, batches of %u on %u lane(s), %u readers, %u writers",
+                     (unsigned long long)ps.frames, ps.seconds, double(ps.frames) / std::max(ps.seconds, 1e-9), ps.steady_frames_per_second, ps.prepare_seconds, ps.reads_done_seconds,
+                     ps.last_batch_seconds, ps.first_packet_seconds, ps.batch_frames, ps.lanes, ps.readers, ps.writers);
             mark(b);
         }
     }

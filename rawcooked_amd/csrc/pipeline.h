@@ -40,6 +40,7 @@ struct pipe_io {
 
 struct pipe_options {
     int device_first = 0, device_count = 0;     // 0 = all visible
+    uint32_t lanes_per_device = 0;               // encoder instances per device whose batches run staggered; 0 = 1
     uint32_t batch = 0;                          // frames per batch; 0 = from free device memory and the sequence length
     uint32_t readers = 0, writers = 0;           // host threads; 0 = automatic
     uint32_t in_slots = 0;                       // pinned upload slots; 0 = automatic
@@ -52,6 +53,8 @@ struct pipe_stats {
     uint64_t frames = 0, payload_bytes = 0, packet_bytes = 0, batches = 0;
     uint32_t batch_frames = 0, lanes = 0, readers = 0, writers = 0;
     double device_busy_seconds = 0;             // sum over batches of (batch complete - encode call), lane 0
+    double steady_frames_per_second = 0;        // frames of all batches but the first / time from the first batch's completion to the last's
+    double reads_done_seconds = 0, last_batch_seconds = 0;
 };
 
 class pipeline {

@@ -132,12 +132,14 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
     for (const pipe_video& v : videos) longest = std::max(longest, v.frames);
     // no more lanes than there is work for: a short job on an 8-GPU node uses the devices it can fill
     const uint64_t min_batch = 8;
-    cnt = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cnt), (longest + min_batch - 1) / min_batch)));
+    const int ndev_used = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cnt), (longest + min_batch - 1) / min_batch)));
+    const int per_dev = int(std::max(1u, std::min(4u, opt.lanes_per_device)));
+    cnt = int(std::max<uint64_t>(ndev_used, std::min<uint64_t>(uint64_t(ndev_used) * per_dev, (longest + min_batch - 1) / min_batch)));
     s.lanes.resize(size_t(cnt));
     s.F.assign(videos.size(), 1); s.payload.assign(videos.size(), 0); s.max_packet.assign(videos.size(), 0);
     for (int li = 0; li < cnt; li++) {
         lane_t& L = s.lanes[size_t(li)];
-        L.id = li; L.device = dev0 + li;
+        L.id = li; L.device = dev0 + li % ndev_used;
         if (hipSetDevice(L.device) != hipSuccess) return fail(4, "pipeline: cannot select device %d", L.device);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail(100, "pipeline: hipMemGetInfo failed");
@@ -150,7 +152,8 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
                 // k_resolve's time, which grows with the batch, meets the serial range-coder chain of a slice, which does not
                 //  --, and evened out over the batches of the sequence
                 const uint64_t per = std::max<uint64_t>(1, ffv1_device_bytes_per_frame(c));
-                uint64_t f = opt.batch ? opt.batch : std::min<uint64_t>(384, uint64_t(double(free_b) * 0.85 / double(videos.size())) / per);
+                const uint64_t share = videos.size() * uint64_t((cnt + ndev_used - 1) / ndev_used);      // encoders that will live on this device
+                uint64_t f = opt.batch ? opt.batch : std::min<uint64_t>(384 / uint64_t((cnt + ndev_used - 1) / ndev_used), uint64_t(double(free_b) * 0.85 / double(share)) / per);
                 f = std::max<uint64_t>(1, f);
                 const uint64_t n = std::max<uint64_t>(1, videos[vi].frames);
                 const uint64_t per_lane = (n + uint64_t(cnt) - 1) / uint64_t(cnt);
@@ -224,6 +227,8 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     s.ready.assign(N, nullptr); s.jobs.clear(); s.pending.clear(); s.placer_finished = false; s.next_read = 0; s.alloc_done = false;
     s.error = 0; s.error_msg.clear();
 
+    std::vector<double> batch_done(batches.size(), 0.0);
+    double reads_done = 0;
     std::atomic<uint64_t> packet_bytes{ 0 };
     std::atomic<bool> first_seen{ false }; double first_packet_seconds = 0;
     double busy0 = 0;
@@ -290,15 +295,17 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     auto reader = [&] {
         (void)hipSetDevice(s.lanes[0].device);
         for (;;) {
-            const size_t i = s.next_read.fetch_add(1);
-            if (i >= N) return;
-            uint8_t* slot = nullptr;
+            // slot first, frame second, under one lock: the filled slots then always hold the LOWEST frames not yet uploaded, which are
+            // the ones the lanes wait for (a reader that took its frame number first could be overtaken for the last free slot by
+            // readers of later frames, and the pool would fill up with frames nobody can use yet)
+            uint8_t* slot = nullptr; size_t i = 0;
             {
                 std::unique_lock<std::mutex> l(s.m);
                 for (;;) {
                     if (s.error) return;
+                    if (s.next_read >= N) { if (!reads_done) reads_done = since(t0); return; }
                     reap();
-                    if (!s.free_slots.empty()) { slot = s.free_slots.back(); s.free_slots.pop_back(); break; }
+                    if (!s.free_slots.empty()) { slot = s.free_slots.back(); s.free_slots.pop_back(); i = s.next_read++; break; }
                     s.cv.wait_for(l, std::chrono::microseconds(200));
                 }
             }
@@ -383,6 +390,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (k + 1 < mine.size() && !issue_uploads(batches[mine[k + 1]])) return;
             if (!hip_ok(hipEventSynchronize(L.ev_done), "batch")) return;
             if (L.id == 0) busy0 += since(tb);
+            batch_done[mine[k]] = since(t0);
             if (trace && L.id == 0) mark("batch complete:", long(mine[k]));
             if (L.h_err[0]) { char t[256]; snprintf(t, sizeof t, "ffv1: %s (flags %u)", ffv1_error_flags_text(L.h_err[0]), L.h_err[0]); s.set_error(102, t); return; }
             // downloads: ordered behind the batch on the second copy stream
@@ -476,6 +484,13 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         for (const pipe_frame& f : frames) stats->payload_bytes += s.payload[f.video];
         stats->packet_bytes = packet_bytes; stats->batches = batches.size(); stats->batch_frames = maxF; stats->lanes = uint32_t(nl);
         stats->readers = readers; stats->writers = writers; stats->device_busy_seconds = busy0;
+        stats->reads_done_seconds = reads_done;
+        if (!batches.empty()) {
+            double first = 1e300, last = 0; size_t first_b = 0;
+            for (size_t b = 0; b < batches.size(); b++) { if (batch_done[b] < first) { first = batch_done[b]; first_b = b; } last = std::max(last, batch_done[b]); }
+            stats->last_batch_seconds = last;
+            if (batches.size() > 1 && last > first) stats->steady_frames_per_second = double(N - batches[first_b].n) / (last - first);
+        }
     }
     if (s.error) return fail(s.error, "%s", s.error_msg.c_str());
     return 0;
@@ -495,7 +510,8 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
     pipe_video v; v.cfg = *cfg; v.frames = n_frames;
     pipe_options po;
     if (opt) { po.device_first = opt->device_first; po.device_count = opt->device_count; po.readers = opt->readers; po.writers = opt->writers;
-               po.in_slots = opt->in_ring_frames; po.out_ring_bytes = opt->out_ring_bytes; po.batch = opt->batch; }
+               po.in_slots = opt->in_ring_frames; po.out_ring_bytes = opt->out_ring_bytes; po.batch = opt->batch; po.lanes_per_device = opt->lanes_per_device; }
+    if (const char* e = getenv("RCGPU_LANES")) if (!po.lanes_per_device) po.lanes_per_device = uint32_t(std::max(1, atoi(e)));
     if (!po.batch) po.batch = cfg->max_batch > 1 ? cfg->max_batch : 0;
     po.trace = getenv("RCGPU_TRACE") != nullptr;
     pipeline pl;
@@ -517,7 +533,8 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
         stats->seconds = ps.seconds; stats->first_packet_seconds = ps.first_packet_seconds; stats->prepare_seconds = ps.prepare_seconds;
         stats->frames = ps.frames; stats->payload_bytes = ps.payload_bytes; stats->packet_bytes = ps.packet_bytes; stats->batches = ps.batches;
         stats->batch_frames = ps.batch_frames; stats->devices = ps.lanes; stats->readers = ps.readers; stats->writers = ps.writers;
-        stats->device_busy_seconds = ps.device_busy_seconds;
+        stats->device_busy_seconds = ps.device_busy_seconds; stats->steady_frames_per_second = ps.steady_frames_per_second;
+        stats->reads_done_seconds = ps.reads_done_seconds; stats->last_batch_seconds = ps.last_batch_seconds;
     }
     return r;
 }

@@ -38,3 +38,13 @@ def refbin():
     if not os.path.exists(p):
         pytest.skip("oracle/_ref/rawcooked not built (needs /root/reference)")
     return p
+
+
+@pytest.fixture(scope="session")
+def linkedbin():
+    """oracle/_ref/rawcooked_linked: the reference with librcgpu.so linked in through the two patches of INTEGRATION.md routes B and C
+    (oracle/Makefile.ref, target `linked`)."""
+    p = os.path.join(ROOT, "oracle", "_ref", "rawcooked_linked")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref/rawcooked_linked not built (needs /root/reference)")
+    return p

@@ -377,3 +377,44 @@ def test_error_text_of_a_reader_thread_reaches_the_user(built, refbin, tmp_path)
     r = run([SHIM] + argv[1:], work)
     assert r.returncode != 0 and "Error: " in r.stderr and "f_000007.dpx differs in geometry" in r.stderr, r.stderr
     assert not os.path.exists(os.path.join(work, "pkg.mkv"))
+
+
+@pytest.mark.parametrize("case", [dict(w=64, h=48, pixfmt=synth.PIX_RGB16_BE, audio=(2, 16, 48000, 6000)),
+                                  dict(w=50, h=38, pixfmt=synth.PIX_RGB10_FILLEDA_BE, padding=True),
+                                  dict(w=96, h=40, pixfmt=synth.PIX_RGB12_PACKED_BE, flags=synth.FLAG_VFLIP),
+                                  dict(w=40, h=30, pixfmt=synth.PIX_RGB16_LE, tiff=True)],
+                         ids=["rgb16+wav", "rgb10-nonzero-padding", "rgb12packed-vflip", "tiff16"])
+def test_linked_reference_encodes_and_checks_on_the_device(built, linkedbin, refbin, tmp_path, case):
+    """INTEGRATION.md routes B and C compiled: the reference built with oracle/route_b_output_cpp.patch (rcgpu_encode() in place of the
+    system() call, Source/CLI/Output.cpp:354-375) and oracle/route_c_ffv1_frame_cpp.patch (the device decoder in place of the slice
+    pool in ffv1_frame::Process, FFV1_Frame.cpp:134-228; raw_frame::Process then merges the `In` data, RawFrame.cpp:184-206) encodes
+    AND checks in one run; the unmodified reference then checks the same file with its CPU decoder, and the linked binary checks a file
+    it did not make."""
+    work = str(tmp_path)
+    make_package(work, case["w"], case["h"], case["pixfmt"], 3, "film", case.get("tiff", False), case.get("audio"), flags=case.get("flags", 0))
+    if case.get("padding"):
+        for i in range(3):
+            p = os.path.join(work, "pkg", "img", "f_%06d.dpx" % i)
+            d = bytearray(open(p, "rb").read())
+            off = int.from_bytes(d[4:8], "big")
+            for k in range(off + 3, len(d), 4 * (5 + i)):
+                d[k] |= 1 + (k % 3 == 0)
+            open(p, "wb").write(d)
+    r = run([linkedbin, "--check-padding" if case.get("padding") else "--no-check-padding", "--check", "--hash", "-y", "pkg"], work, timeout=60)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+    assert "ffmpeg" not in r.stderr.lower()                                   # nothing was spawned
+    r = run([refbin, "--check", "pkg.mkv"], work)                             # the CPU decoder agrees
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    r = run([linkedbin, "-y", "pkg.mkv"], work, timeout=60)                   # full decode through the device decoder, byte compare
+    assert r.returncode == 0, r.stdout + r.stderr
+    for dirpath, _, files in os.walk(os.path.join(work, "pkg")):
+        for fn in files:
+            src = os.path.join(dirpath, fn)
+            assert open(src, "rb").read() == open(os.path.join(work, "pkg.mkv.RAWcooked", os.path.relpath(src, work)), "rb").read(), fn
+    # a corrupted slice is refused by the device decoder behind the reference's own error path
+    p = os.path.join(work, "pkg.mkv")
+    data = bytearray(open(p, "rb").read())
+    data[len(data) - 300] ^= 0x20
+    open(p, "wb").write(data)
+    r = run([linkedbin, "--check", "pkg.mkv"], work, timeout=60)
+    assert r.returncode != 0 or "Error" in (r.stdout + r.stderr) or OK_LINE not in r.stdout

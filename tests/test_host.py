@@ -92,6 +92,24 @@ def test_dpx_probe_matches_what_the_reference_printed(built, v):
     assert (i.width, i.height, i.pixfmt, i.flags, i.line_bytes, i.slices, i.flavor.decode()) == \
            (v["width"], v["height"], v["pixfmt"], v["flags"], v["line_bytes"], v["slices"], v["flavor"])
     assert i.data_offset + i.data_size == len(d)
+    # and back: the flavor string the reference printed names this pixel layout (what a decode-side binding starts from)
+    import ctypes
+    pf = ctypes.c_uint32(99)
+    assert api.lib().rcgpu_pixfmt_from_flavor(v["flavor"].encode(), ctypes.byref(pf)) == 0 and pf.value == v["pixfmt"], v["flavor"]
+
+
+def test_wav_probe_rejects_an_all_zero_fmt_chunk(built):
+    """A fmt chunk with channels = block_align = avg = 0 is coherent with itself (0 == 0); the data chunk must not divide by it
+    (the reference rejects such files, WAV.cpp:125-221)."""
+    import struct
+    fmt = struct.pack("<HHIIHH", 1, 0, 48000, 0, 0, 0)
+    wav = b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + 16) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", 16) + bytes(16)
+    with pytest.raises(api.RcgpuError):
+        api.wav_probe(wav)
+    fmt = struct.pack("<HHIIHH", 1, 2, 0, 0, 4, 16)          # sample rate 0
+    wav = b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + 16) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", 16) + bytes(16)
+    with pytest.raises(api.RcgpuError):
+        api.wav_probe(wav)
 
 
 @pytest.mark.parametrize("v", json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["ffv1"], ids=lambda v: v["name"])
@@ -341,3 +359,20 @@ def test_reference_round_trips_copied_audio(built, refbin, tmp_path, kind):
     cmd = [refbin, "--bin-name", shim] + (["-c:a", "copy"] if kind == "s16-by-hand" else []) + ["-y", "--check", "pkg"]
     r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL)
     assert r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout, r.stdout + r.stderr
+
+
+def test_linked_reference_reports_the_missing_device(built, tmp_path):
+    """Route B compiled (oracle/_ref/rawcooked_linked): without a GPU the reference's own error path shows rcgpu_encode's message and
+    exit status -- there is no CPU encode path to fall back to."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "rawcooked_linked")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/rawcooked_linked not built (needs /root/reference)")
+    if api.lib().rcgpu_device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    os.makedirs(tmp_path / "pkg" / "img")
+    for i in range(2):
+        (tmp_path / "pkg" / "img" / ("f_%06d.dpx" % i)).write_bytes(synth.dpx_file(synth.components(64, 48, 3, 16, "film", seed=i), synth.PIX_RGB16_BE, frame_index=i))
+    r = subprocess.run([exe, "--hash", "-y", "pkg"], cwd=tmp_path, capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL)
+    assert r.returncode != 0 and "Error: no HIP device available -- rcgpu has no CPU encode path" in r.stderr, r.stdout + r.stderr
+    assert not os.path.exists(tmp_path / "pkg.mkv")
