@@ -220,6 +220,13 @@ typedef struct {
 int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, const rcgpu_sequence_io* io,
                                const rcgpu_sequence_options* options, rcgpu_sequence_stats* stats, uint8_t* record, size_t* record_size);
 
+/* The same with host memory on both ends: frame i = frames[i % n_in], packet i -> out[i % n_out] (out_cap bytes each, may be NULL to
+ * drop the bytes) and sizes[i] (n_frames entries, may be NULL).  n_in == n_out == n_frames: rcgpu_ffv1_encode_host for a whole
+ * sequence, pipelined. */
+int rcgpu_ffv1_encode_sequence_memory(const rcgpu_ffv1_config* cfg, const uint8_t* const* frames, uint64_t n_in, uint64_t n_frames,
+                                      uint8_t* const* out, uint64_t n_out, size_t out_cap, uint64_t* sizes,
+                                      const rcgpu_sequence_options* options, rcgpu_sequence_stats* stats, uint8_t* record, size_t* record_size);
+
 /* `-f framemd5` (CLI/Output.cpp:312-332): MD5 of the first n frames of the LAST batch as the bytes FFmpeg's rawvideo encoder would hash
  * (rgb24/rgba/gray, rgb48/rgba64/gray16 in the file's endianness, gbrp/gbrap/gray 10/12 little-endian planar) [ffmpeg-knowledge];
  * *frame_bytes = size of one such frame.  Call between two batches, once the batch's stream is synchronised (rcgpu_ffv1_encode_host

@@ -101,6 +101,8 @@ SYMBOLS = {
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rcgpu_ffv1_last_error_flags": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
     "rcgpu_ffv1_encode_sequence": (C.c_int, [C.POINTER(Ffv1Config), C.c_uint64, C.POINTER(SequenceIo), C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
+    "rcgpu_ffv1_encode_sequence_memory": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP), C.c_uint64, C.c_uint64, C.POINTER(_VP), C.c_uint64, _SZ, C.POINTER(C.c_uint64),
+                                          C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
     "rcgpu_mkv_expect": (C.c_int, [_VP, C.c_uint64, C.c_uint64]),
     "rcgpu_mkv_reserve_block": (C.c_int, [_VP, C.c_int, C.c_uint64, _SZ, C.c_int, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     "rcgpu_mkv_fill": (C.c_int, [_VP, C.c_uint64, _VP, _SZ]),
@@ -305,6 +307,19 @@ def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, pla
     rs = _SZ(8192)
     _check(lib().rcgpu_ffv1_encode_sequence(C.byref(cfg), n_frames, C.byref(io), C.byref(opt), C.byref(st), rec, C.byref(rs)), "rcgpu_ffv1_encode_sequence")
     return st, rec.raw[:rs.value]
+
+
+def encode_sequence_memory(cfg: Ffv1Config, frame_addrs: list[int], n_frames: int, out_addrs: list[int], out_cap: int, batch=0, readers=0, writers=0,
+                           device_first=0, device_count=0, lanes_per_device=0):
+    """rcgpu_ffv1_encode_sequence_memory: frame i = frame_addrs[i % len], packet i -> out_addrs[i % len].  Returns (stats, sizes)."""
+    fin = (_VP * len(frame_addrs))(*frame_addrs)
+    fout = (_VP * len(out_addrs))(*out_addrs) if out_addrs else None
+    sizes = (C.c_uint64 * n_frames)()
+    opt = SequenceOptions(device_first, device_count, batch, readers, writers, 0, 0, lanes_per_device)
+    st = SequenceStats()
+    _check(lib().rcgpu_ffv1_encode_sequence_memory(C.byref(cfg), fin, len(frame_addrs), n_frames, fout, len(out_addrs), out_cap, sizes, C.byref(opt), C.byref(st), None, None),
+           "rcgpu_ffv1_encode_sequence_memory")
+    return st, list(sizes)
 
 
 class Ffv1Decoder:

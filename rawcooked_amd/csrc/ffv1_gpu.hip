@@ -1027,6 +1027,7 @@ struct rcgpu_ffv1 {
     uint64_t last_decisions = 0, last_packet_bytes = 0;
     uint32_t last_n = 0;
     hipEvent_t gather_wait = nullptr;              // pipeline: k_gather of the next batch waits for the previous batch's download
+    bool defer_gather = false;                     // pipeline: encode_device stops after k_scan, ffv1_gather() follows later
     size_t in_stride = 0;
     uint32_t* h_err = nullptr;                     // pinned copy of d_err
 };
@@ -1304,15 +1305,38 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(timed(4, s2, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));
     HIP_TRY(timed(5, s2, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, s2, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
-    if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(s2, e->gather_wait, 0)); e->gather_wait = nullptr; }
-    HIP_TRY(timed(6, s2, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
-                                                  e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
+    if (!e->defer_gather) {
+        if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(s2, e->gather_wait, 0)); e->gather_wait = nullptr; }
+        HIP_TRY(timed(6, s2, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+                                                      e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
+    }
     HIP_TRY(hipEventRecord(e->ev_fork, s2));
     HIP_TRY(hipStreamWaitEvent(st, e->ev_fork, 0));
     HIP_TRY(hipGetLastError());
     e->ev_valid = true; e->last_n = n;
     return 0;
 }
+
+namespace rc {
+void ffv1_set_defer_gather(rcgpu_ffv1* e, bool on) { if (e) e->defer_gather = on; }
+
+int ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream)
+{
+    if (!e || !d_packets || !e->ev_valid) return fail(1, "ffv1: gather without a batch");
+    if (packet_stride < e->max_packet || (packet_stride & 3)) return fail(2, "ffv1: packet_stride must be a multiple of 4 and >= %zu", e->max_packet);
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const uint32_t nchains = e->last_n * e->hc.S;
+    if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(st, e->gather_wait, 0)); e->gather_wait = nullptr; }
+    const bool ev_room = e->ev_used + 2 <= e->ev.size();
+    if (ev_room) HIP_TRY(hipEventRecord(e->ev[e->ev_used], st));
+    hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+                       e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride);
+    if (ev_room) { HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st)); e->ev_used += 2; e->ev_kernel.push_back(6); }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+}  // namespace rc
 
 // Sum of the device time of every launch of each kernel in the last encode call (HIP events on the launch stream).
 extern "C" int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap)

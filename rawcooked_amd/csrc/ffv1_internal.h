@@ -23,6 +23,11 @@ int  ffv1_staging(rcgpu_ffv1* e, enc_staging* out);
 // The next rcgpu_ffv1_encode_device call makes k_gather wait for this event (a hipEvent_t already recorded): the download of the
 // previous batch's packets out of d_packets.  nullptr = no wait.
 void ffv1_set_gather_wait(rcgpu_ffv1* e, void* hip_event);
+// Deferred gather: with `on`, rcgpu_ffv1_encode_device stops after k_scan (slice sizes and packet layout are known, the slices still sit
+// in their own buffers) and ffv1_gather() compacts them into the packets later, on the same stream.  The pipeline uses the gap to issue
+// the previous batch's downloads AFTER the next batch has been started: the device never waits for the host between two batches.
+void ffv1_set_defer_gather(rcgpu_ffv1* e, bool on);
+int  ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream);
 // Text for the device error word (0 = none).
 const char* ffv1_error_flags_text(uint32_t flags);
 

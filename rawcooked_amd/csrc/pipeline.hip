@@ -33,12 +33,12 @@ struct lane_t {
     hipStream_t cin = nullptr, cout = nullptr;
     std::vector<hipEvent_t> dl_done;              // per video: the download of the last batch out of that encoder's d_packets
     std::vector<bool> dl_valid;
-    hipEvent_t ev_up = nullptr, ev_done = nullptr;
+    hipEvent_t ev_up = nullptr, ev_done[2] = { nullptr, nullptr };
     // download ring: pinned chunks, a chunk is re-entered when nothing in it is outstanding
     std::vector<uint8_t*> chunks; std::vector<int> outstanding; size_t chunk_bytes = 0, max_chunks = 0; int cur = -1; size_t cur_off = 0;
     std::deque<out_entry> outq;                   // issued downloads in frame order, consumed by the placer
     std::vector<hipEvent_t> free_events;
-    uint64_t* h_sizes = nullptr; uint32_t* h_err = nullptr;     // pinned
+    uint64_t* h_sizes = nullptr; uint32_t* h_err = nullptr; size_t h_sizes_stride = 0;     // pinned, two batches' worth
 };
 
 }  // namespace
@@ -84,7 +84,7 @@ pipeline::impl::~impl()
         for (hipEvent_t e : L.free_events) (void)hipEventDestroy(e);
         for (hipEvent_t e : L.dl_done) if (e) (void)hipEventDestroy(e);
         if (L.ev_up) (void)hipEventDestroy(L.ev_up);
-        if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+        for (hipEvent_t e : L.ev_done) if (e) (void)hipEventDestroy(e);
         if (L.cin) (void)hipStreamDestroy(L.cin);
         if (L.cout) (void)hipStreamDestroy(L.cout);
         if (L.h_sizes) (void)hipHostFree(L.h_sizes);
@@ -172,12 +172,13 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
             return fail(100, "pipeline: cannot create copy streams");
         L.dl_done.assign(videos.size(), nullptr); L.dl_valid.assign(videos.size(), false);
         for (auto& e : L.dl_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(100, "pipeline: cannot create events");
-        if (hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess)
-            return fail(100, "pipeline: cannot create events");
+        if (hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L.ev_done[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L.ev_done[1], hipEventDisableTiming) != hipSuccess) return fail(100, "pipeline: cannot create events");
         uint32_t maxF = 1;
         for (uint32_t f : s.F) maxF = std::max(maxF, f);
-        if (hipHostMalloc(reinterpret_cast<void**>(&L.h_sizes), size_t(maxF) * 8, hipHostMallocPortable) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void**>(&L.h_err), 16, hipHostMallocPortable) != hipSuccess) return fail(100, "pipeline: cannot allocate pinned memory");
+        L.h_sizes_stride = maxF;
+        if (hipHostMalloc(reinterpret_cast<void**>(&L.h_sizes), size_t(maxF) * 8 * 2, hipHostMallocPortable) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&L.h_err), 32, hipHostMallocPortable) != hipSuccess) return fail(100, "pipeline: cannot allocate pinned memory");
     }
     for (size_t vi = 0; vi < videos.size(); vi++) s.slot_bytes = std::max(s.slot_bytes, (s.payload[vi] + 4095) & ~size_t(4095));
     s.prepare_seconds = since(t0);
@@ -364,50 +365,71 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             L.cur_off += need; L.outstanding[size_t(L.cur)]++;
             return ptr;
         };
-        hipStream_t st = nullptr;
-        if (!mine.empty() && !issue_uploads(batches[mine[0]])) return;
-        for (size_t k = 0; k < mine.size(); k++) {
-            const batch_t& B = batches[mine[k]];
+        // One batch = upload | k_model ... k_scan | k_gather | download.  The loop keeps the DEVICE busy: batch k+1 is started (its call
+        // returns once k_model(k+1) has run, i.e. after everything of batch k) before the host turns to batch k's sizes and downloads.
+        auto start_batch = [&](const batch_t& B) -> bool {        // uploads of B are on their way
             rcgpu_ffv1* enc = L.enc[B.video];
-            enc_staging sg; if (ffv1_staging(enc, &sg)) { s.set_error(100, rcgpu_last_error()); return; }
-            st = static_cast<hipStream_t>(sg.compute_stream);
-            if (!hip_ok(hipStreamWaitEvent(st, L.ev_up, 0), "hipStreamWaitEvent")) return;
-            ffv1_set_gather_wait(enc, L.dl_valid[B.video] ? L.dl_done[B.video] : nullptr);
+            enc_staging sg; if (ffv1_staging(enc, &sg)) { s.set_error(100, rcgpu_last_error()); return false; }
+            hipStream_t st = static_cast<hipStream_t>(sg.compute_stream);
+            if (!hip_ok(hipStreamWaitEvent(st, L.ev_up, 0), "hipStreamWaitEvent")) return false;
+            ffv1_set_defer_gather(enc, true);
             std::vector<const void*> ptrs(B.n);
             for (size_t i = 0; i < B.n; i++) ptrs[i] = sg.d_in + i * sg.in_stride;
-            const auto tb = clk::now();
-            if (int r = rcgpu_ffv1_encode_device(enc, ptrs.data(), uint32_t(B.n), sg.d_packets, sg.packet_stride, sg.d_psizes, st)) { s.set_error(r, rcgpu_last_error()); return; }
-            // (the call returns once k_model has run: d_in is free again)
-            if (!hip_ok(hipMemcpyAsync(L.h_sizes, sg.d_psizes, 8 * B.n, hipMemcpyDeviceToHost, st), "sizes") ||
-                !hip_ok(hipMemcpyAsync(L.h_err, sg.d_err, 16, hipMemcpyDeviceToHost, st), "flags") ||
-                !hip_ok(hipEventRecord(L.ev_done, st), "hipEventRecord")) return;
-            if (trace && L.id == 0) mark("modelled, rest of batch enqueued:", long(mine[k]));
-            const bool serial = bool(io.after_batch);
-            if (serial) {
-                if (!hip_ok(hipEventSynchronize(L.ev_done), "batch")) return;
-                if (int r = io.after_batch(B.video, enc, frames[B.first].index, uint32_t(B.n))) { s.set_error(r, rcgpu_last_error()); return; }
-            }
-            if (k + 1 < mine.size() && !issue_uploads(batches[mine[k + 1]])) return;
-            if (!hip_ok(hipEventSynchronize(L.ev_done), "batch")) return;
-            if (L.id == 0) busy0 += since(tb);
-            batch_done[mine[k]] = since(t0);
-            if (trace && L.id == 0) mark("batch complete:", long(mine[k]));
-            if (L.h_err[0]) { char t[256]; snprintf(t, sizeof t, "ffv1: %s (flags %u)", ffv1_error_flags_text(L.h_err[0]), L.h_err[0]); s.set_error(102, t); return; }
-            // downloads: ordered behind the batch on the second copy stream
-            if (!hip_ok(hipStreamWaitEvent(L.cout, L.ev_done, 0), "hipStreamWaitEvent")) return;
+            if (int r = rcgpu_ffv1_encode_device(enc, ptrs.data(), uint32_t(B.n), sg.d_packets, sg.packet_stride, sg.d_psizes, st)) { s.set_error(r, rcgpu_last_error()); return false; }
+            return true;
+        };
+        auto finish_batch = [&](const batch_t& B, int par) -> bool {   // k_gather behind the previous download, then sizes and flags to the host
+            rcgpu_ffv1* enc = L.enc[B.video];
+            enc_staging sg; if (ffv1_staging(enc, &sg)) { s.set_error(100, rcgpu_last_error()); return false; }
+            hipStream_t st = static_cast<hipStream_t>(sg.compute_stream);
+            ffv1_set_gather_wait(enc, L.dl_valid[B.video] ? L.dl_done[B.video] : nullptr);
+            if (int r = ffv1_gather(enc, sg.d_packets, sg.packet_stride, st)) { s.set_error(r, rcgpu_last_error()); return false; }
+            return hip_ok(hipMemcpyAsync(L.h_sizes + size_t(par) * L.h_sizes_stride, sg.d_psizes, 8 * B.n, hipMemcpyDeviceToHost, st), "sizes") &&
+                   hip_ok(hipMemcpyAsync(L.h_err + 4 * par, sg.d_err, 16, hipMemcpyDeviceToHost, st), "flags") &&
+                   hip_ok(hipEventRecord(L.ev_done[par], st), "hipEventRecord");
+        };
+        auto download_batch = [&](const batch_t& B, int par) -> bool {
+            enc_staging sg; if (ffv1_staging(L.enc[B.video], &sg)) { s.set_error(100, rcgpu_last_error()); return false; }
+            const uint32_t* err = L.h_err + 4 * par;
+            if (err[0]) { char t[256]; snprintf(t, sizeof t, "ffv1: %s (flags %u)", ffv1_error_flags_text(err[0]), err[0]); s.set_error(102, t); return false; }
+            const uint64_t* sizes = L.h_sizes + size_t(par) * L.h_sizes_stride;
+            if (!hip_ok(hipStreamWaitEvent(L.cout, L.ev_done[par], 0), "hipStreamWaitEvent")) return false;
             for (size_t i = 0; i < B.n; i++) {
-                out_entry o; o.frame = B.first + i; o.size = size_t(L.h_sizes[i]); o.device = L.device; o.lane = L.id;
-                if (!o.size || o.size > sg.packet_stride) { s.set_error(102, "ffv1: the device returned an impossible packet size"); return; }
+                out_entry o; o.frame = B.first + i; o.size = size_t(sizes[i]); o.device = L.device; o.lane = L.id;
+                if (!o.size || o.size > sg.packet_stride) { s.set_error(102, "ffv1: the device returned an impossible packet size"); return false; }
                 o.src = ring_alloc(o.size, o.chunk);
-                if (!o.src) return;
-                if (!hip_ok(hipMemcpyAsync(o.src, sg.d_packets + i * sg.packet_stride, o.size, hipMemcpyDeviceToHost, L.cout), "download")) return;
+                if (!o.src) return false;
+                if (!hip_ok(hipMemcpyAsync(o.src, sg.d_packets + i * sg.packet_stride, o.size, hipMemcpyDeviceToHost, L.cout), "download")) return false;
                 o.ev = get_event();
-                if (!o.ev || !hip_ok(hipEventRecord(o.ev, L.cout), "hipEventRecord")) return;
+                if (!o.ev || !hip_ok(hipEventRecord(o.ev, L.cout), "hipEventRecord")) return false;
                 { std::lock_guard<std::mutex> l(s.m); L.outq.push_back(o); }
                 s.cv.notify_all();
             }
-            if (!hip_ok(hipEventRecord(L.dl_done[B.video], L.cout), "hipEventRecord")) return;
+            if (!hip_ok(hipEventRecord(L.dl_done[B.video], L.cout), "hipEventRecord")) return false;
             L.dl_valid[B.video] = true;
+            return true;
+        };
+        if (mine.empty()) return;
+        const bool serial = bool(io.after_batch);
+        if (!issue_uploads(batches[mine[0]]) || !start_batch(batches[mine[0]])) return;
+        for (size_t k = 0; k < mine.size(); k++) {
+            const batch_t& B = batches[mine[k]];
+            const int par = int(k & 1);
+            const bool more = k + 1 < mine.size();
+            if (trace && L.id == 0) mark("modelled:", long(mine[k]));
+            if (serial) {      // the hook wants the payloads on the device: nothing may overwrite them before it has run
+                if (!finish_batch(B, par) || !hip_ok(hipEventSynchronize(L.ev_done[par]), "batch")) return;
+                if (int r = io.after_batch(B.video, L.enc[B.video], frames[B.first].index, uint32_t(B.n))) { s.set_error(r, rcgpu_last_error()); return; }
+                if (more && !issue_uploads(batches[mine[k + 1]])) return;
+            } else {
+                if (more && !issue_uploads(batches[mine[k + 1]])) return;     // d_in is free: k_model(k) has run
+                if (!finish_batch(B, par)) return;
+            }
+            if (more && !start_batch(batches[mine[k + 1]])) return;           // returns after k_model(k+1), which follows batch k on the stream
+            if (!hip_ok(hipEventSynchronize(L.ev_done[par]), "batch")) return;
+            batch_done[mine[k]] = since(t0);
+            if (trace && L.id == 0) mark("batch complete:", long(mine[k]));
+            if (!download_batch(B, par)) return;
         }
     };
 
@@ -537,4 +559,37 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
         stats->reads_done_seconds = ps.reads_done_seconds; stats->last_batch_seconds = ps.last_batch_seconds;
     }
     return r;
+}
+
+// Host memory in, host memory out: frame i is frames[i % n_in], packet i lands in out[i % n_out] (out_cap bytes each) and sizes[i].
+// With n_in == n_out == n_frames this is rcgpu_ffv1_encode_host for a whole sequence, pipelined; smaller rings re-use buffers (the
+// bench's synthetic sequence; a caller that consumes packets as they arrive would rather pass its own callbacks).
+namespace {
+struct memory_io { const uint8_t* const* frames; uint64_t n_in; uint8_t* const* out; uint64_t n_out; size_t out_cap; uint64_t* sizes; };
+int memory_read(void* user, uint64_t frame, uint8_t* dst, size_t bytes)
+{
+    const memory_io* m = static_cast<const memory_io*>(user);
+    memcpy(dst, m->frames[frame % m->n_in], bytes);
+    return 0;
+}
+int memory_done(void* user, uint64_t frame, const uint8_t* data, size_t size)
+{
+    const memory_io* m = static_cast<const memory_io*>(user);
+    if (m->sizes) m->sizes[frame] = size;
+    if (!m->out || !m->n_out) return 0;
+    if (size > m->out_cap) return rc::fail(90, "sequence: packet %llu of %zu bytes does not fit the caller's %zu-byte buffers", (unsigned long long)frame, size, m->out_cap);
+    memcpy(m->out[frame % m->n_out], data, size);
+    return 0;
+}
+}  // namespace
+
+extern "C" int rcgpu_ffv1_encode_sequence_memory(const rcgpu_ffv1_config* cfg, const uint8_t* const* frames, uint64_t n_in, uint64_t n_frames,
+                                                 uint8_t* const* out, uint64_t n_out, size_t out_cap, uint64_t* sizes,
+                                                 const rcgpu_sequence_options* opt, rcgpu_sequence_stats* stats, uint8_t* record, size_t* record_size)
+{
+    rc::clear_error();
+    if (!cfg || !frames || !n_in) return rc::fail(1, "sequence: null argument");
+    memory_io m{ frames, n_in, out, n_out, out_cap, sizes };
+    rcgpu_sequence_io io{ memory_read, nullptr, memory_done, &m };
+    return rcgpu_ffv1_encode_sequence(cfg, n_frames, &io, opt, stats, record, record_size);
 }

@@ -119,3 +119,24 @@ def test_device_pointer_api_reports_a_slice_that_outgrew_its_buffer():
     ok.encode_device([d.data_ptr()], pk.data_ptr(), ok.max_packet, sz.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert ok.error_flags() == 0
     ok.close()
+
+
+def test_sequence_memory_host_buffers_in_and_out():
+    """rcgpu_ffv1_encode_sequence_memory: host buffers on both ends, rings of buffers re-used (frame i = in[i % n_in], packet i ->
+    out[i % n_out]); several batches, so the deferred gather and the batch k+1 / download k order are exercised."""
+    import numpy as np
+    w, h, pixfmt, n_in, n = 160, 90, synth.PIX_RGB16_BE, 5, 43
+    payloads, line_bytes = _sequence(w, h, pixfmt, n_in)
+    src = [np.frombuffer(p, dtype=np.uint8).copy() for p in payloads]
+    out_cap = len(payloads[0]) * 2
+    outs = [np.zeros(out_cap, dtype=np.uint8) for _ in range(n)]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 3, 2, 1, 1, 0, 0, 0, 0, 1, 3)
+    st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], n, [a.ctypes.data for a in outs], out_cap, batch=6)
+    assert st.frames == n and st.batches == 8 and st.packet_bytes == sum(sizes)
+    p = ob.Params(w, h, pixfmt, 3, 2, 1, 1)
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
+    for i in range(n):
+        assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
+    # buffers too small for a packet: an error, not a silent truncation
+    with pytest.raises(api.RcgpuError, match="does not fit"):
+        api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], 4, [a.ctypes.data for a in outs], 64, batch=2)

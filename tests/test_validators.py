@@ -1,0 +1,150 @@
+"""CPU: the two specification-level validators (tests/rfc9043_validator.py, tests/mkv_validator.py) on everything the CPU suite can
+produce -- golden streams blessed by the real reference, oracle streams over the option surface, files written by the muxer through
+both of its block paths -- and their own negative controls.  Stock FFmpeg / mkvalidator do not exist in this environment; these stand
+where they would."""
+import ctypes as C
+import json
+import os
+import subprocess
+import threading
+
+import pytest
+
+import mkv_validator
+import oracle_binding as ob
+import rfc9043_validator as rfc
+from rawcooked_amd import api, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+VEC = json.load(open(os.path.join(G, "vectors.json")))
+
+
+@pytest.mark.parametrize("v", [v for v in VEC["ffv1"] if v["config_record"]], ids=lambda v: v["name"])
+def test_golden_streams_are_structurally_valid_ffv1(built, v):
+    packets = [open(os.path.join(G, fr["packet"]), "rb").read() for fr in v["frames"]]
+    r = rfc.validate_stream(bytes.fromhex(v["config_record"]), packets, v["width"], v["height"])
+    assert (r.num_h_slices, r.num_v_slices) == (v["num_h"], v["num_v"]) and r.coder_type == v["coder"]
+
+
+@pytest.mark.parametrize("pixfmt,w,h,nh,nv,slicecrc,context,coder", [
+    (synth.PIX_RGB16_BE, 200, 120, 3, 2, 0, 1, 1), (synth.PIX_RGB16_BE, 200, 120, 3, 2, 1, 0, 1), (synth.PIX_RGB10_FILLEDA_BE, 130, 67, 3, 3, 0, 0, 1),
+    (synth.PIX_RGBA16_LE, 64, 48, 2, 2, 1, 1, 2), (synth.PIX_Y16_BE, 80, 40, 2, 2, 1, 1, 1), (synth.PIX_RGB8, 257, 131, 4, 4, 1, 2, 1)])
+def test_oracle_streams_over_the_option_surface_are_valid(built, pixfmt, w, h, nh, nv, slicecrc, context, coder):
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    p = ob.Params(w, h, pixfmt, nh, nv, slicecrc, context, 0, coder)
+    packets = []
+    for i in range(2):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, "film" if i else "noise", seed=9 + i), pixfmt, True)
+        packets.append(ob.encode_payload(p, pl, line_bytes))
+    r = rfc.validate_stream(ob.config_record(p), packets, w, h)
+    assert r.ec == slicecrc and r.bits_per_raw_sample == bits and r.alpha_plane == (nc == 4) and r.colorspace_type == (0 if nc == 1 else 1)
+    assert len(r.context_count) == 2 and r.context_count[1] == (338 if context == 2 else 6561 if bits <= 8 else 5063)      # 4.9.3
+
+
+def test_ffv1_validator_negative_controls(built):
+    w, h, pixfmt = 96, 64, synth.PIX_RGB16_BE
+    p = ob.Params(w, h, pixfmt, 2, 2, 1, 1)
+    pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 16, "film", seed=1), pixfmt, True)
+    rec, pk = ob.config_record(p), ob.encode_payload(p, pl, line_bytes)
+    rfc.validate_stream(rec, [pk], w, h)
+    with pytest.raises(AssertionError, match="crc_parity"):
+        rfc.parse_record(rec[:-1] + bytes([rec[-1] ^ 1]))
+    with pytest.raises(AssertionError):
+        rfc.validate_stream(rec, [pk[:-1] + bytes([pk[-1] ^ 0x10])], w, h)          # slice CRC
+    with pytest.raises(AssertionError):
+        rfc.validate_stream(rec, [pk + pk], w, h)                                    # eight slices in a 2x2 grid
+    bad = bytearray(pk); bad[len(pk) - 7] ^= 0x01                                    # slice_size of the last slice
+    with pytest.raises(AssertionError):
+        rfc.validate_stream(rec, [bytes(bad)], w, h)
+
+
+@pytest.mark.parametrize("mode", ["write", "mapped", "pwrite"])
+def test_muxer_files_are_valid_matroska_and_the_reference_reads_them(built, tmp_path, monkeypatch, mode):
+    """The same package through the muxer's three block paths: identical blocks in the file, valid by the Matroska rules, and -- where
+    the real reference is built -- rebuilt bit-exactly by it."""
+    if mode == "pwrite":
+        monkeypatch.setenv("RCGPU_MKV_NO_MMAP", "1")
+    work = str(tmp_path)
+    os.makedirs(work + "/pkg/img")
+    w, h, pixfmt, n = 72, 40, synth.PIX_RGB16_BE, 7
+    files = []
+    for i in range(n):
+        fn = work + "/pkg/img/f_%06d.dpx" % i
+        open(fn, "wb").write(synth.dpx_file(synth.components(w, h, 3, 16, "film", seed=i), pixfmt, frame_index=i))
+        files.append(fn)
+    info = api.dpx_probe(open(files[0], "rb").read())
+    nh, nv = api.slices_to_grid(info.slices)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    packets = [ob.encode_payload(p, open(fn, "rb").read()[info.data_offset:info.data_offset + info.data_size], info.line_bytes) for fn in files]
+    ref = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "rawcooked")
+    have_ref = os.path.exists(ref)
+    path = work + "/pkg.mkv"
+    if have_ref:
+        r = subprocess.run([ref, "--hash", "--no-check-padding", "-d", "-y", "pkg"], cwd=work, capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL)
+        assert r.returncode == 0, r.stderr
+    L = api.lib()
+    mux = api.MkvMuxer(path)
+    tv = mux.add_video(ob.config_record(p), w, h, 24, 1)
+    if have_ref:
+        mux.add_attachment("RAWcooked reversibility data", open(work + "/pkg.rawcooked_reversibility_data", "rb").read())
+    mux.add_tag(tv, "ENCODER", "rcgpu test")
+    mux.begin()
+    if mode != "write":
+        assert L.rcgpu_mkv_expect(mux.h, sum(len(x) for x in packets) + 4096, n) == 0
+    jobs = []
+    for i, pk in enumerate(packets):
+        if mode == "write":
+            mux.write_block(tv, i * 10 ** 9 // 24, pk)
+        else:
+            dst, off = C.c_void_p(), C.c_uint64()
+            assert L.rcgpu_mkv_reserve_block(mux.h, tv, i * 10 ** 9 // 24, len(pk), 1, C.byref(dst), C.byref(off)) == 0
+            assert bool(dst.value) == (mode == "mapped")
+            jobs.append((dst.value, off.value, pk))
+
+    def fill(part):
+        for dst, off, pk in part:
+            if dst:
+                C.memmove(dst, pk, len(pk))
+            else:
+                assert L.rcgpu_mkv_fill(mux.h, off, pk, len(pk)) == 0
+    ths = [threading.Thread(target=fill, args=(jobs[k::3],)) for k in range(3)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    mux.close()
+    rep = mkv_validator.validate(path)
+    assert rep["tracks"][1] == {"type": 1, "codec": "V_FFV1", "blocks": n} and rep["cues"] == n and rep["trailing_bytes"] == 0
+    data = open(path, "rb").read()
+    at = 0
+    for pk in packets:                                     # every packet is in the file, whole and in order
+        at = data.index(pk, at) + len(pk)
+    if have_ref:
+        r = subprocess.run([ref, "--check", "pkg.mkv"], cwd=work, capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL)
+        assert r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout, r.stdout + r.stderr
+
+
+def test_mkv_validator_negative_controls(built, tmp_path):
+    path = str(tmp_path / "a.mkv")
+    mux = api.MkvMuxer(path)
+    tv = mux.add_video(b"\x01\x02", 64, 48, 24, 1)
+    ta = mux.add_audio(b"fLaC" + bytes(38), 2, 48000, 16)
+    mux.begin()
+    for i in range(4):
+        mux.write_block(ta, i * 96000000, b"A" * 50)
+        mux.write_block(tv, i * 10 ** 9 // 24, os.urandom(2 << 20) if i == 2 else b"V" * 90)
+    mux.close()
+    rep = mkv_validator.validate(path)
+    assert rep["tracks"][1]["blocks"] == 4 and rep["tracks"][2]["blocks"] == 4
+    good = open(path, "rb").read()
+    seg = good.index(bytes.fromhex("18538067"))
+    bad = bytearray(good); bad[seg + 11] ^= 0x01                               # Segment size no longer matches
+    (tmp_path / "b.mkv").write_bytes(bad)
+    with pytest.raises(AssertionError):
+        mkv_validator.validate(str(tmp_path / "b.mkv"))
+    blk = good.index(b"V" * 90) - 4                                           # track number byte of a SimpleBlock
+    bad = bytearray(good); bad[blk] = 0x80 | 9
+    (tmp_path / "c.mkv").write_bytes(bad)
+    with pytest.raises(AssertionError, match="unknown track"):
+        mkv_validator.validate(str(tmp_path / "c.mkv"))
+    (tmp_path / "d.mkv").write_bytes(good + b"junk after the segment")
+    with pytest.raises(AssertionError):
+        mkv_validator.validate(str(tmp_path / "d.mkv"))

@@ -55,7 +55,9 @@ for base in ("/dev/shm", "/tmp"):
     try: print(f"{base:9s} mmap+MADV_HUGEPAGE 16 threads: {run(base + '/rcgpu_fsprobe.bin', 'mmap', 16, True):6.2f} GB/s")
     except Exception as e: print("huge failed", e)
 # tmpfs: pages allocated ahead by fallocate (one thread, under the inode lock, no copy), then 16 threads copy into the mapping
-def prealloc(path, nt):
+libc = ctypes.CDLL(None, use_errno=True)
+libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+def prealloc(path, nt, how="memcpy"):
     if os.path.exists(path): os.unlink(path)
     fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o644)
     t0 = time.perf_counter(); os.posix_fallocate(fd, 0, total); t_fa = time.perf_counter() - t0
@@ -67,6 +69,8 @@ def prealloc(path, nt):
             with lock:
                 i = nxt[0]; nxt[0] += 1
             if i >= nblk: return
+            if how == "pwrite": os.pwrite(fd, memoryview(src), i * blk); continue
+            if how == "populate": libc.madvise(base + i * blk, blk, 23)        # MADV_POPULATE_WRITE
             ctypes.memmove(base + i * blk, src.ctypes.data, blk)
     t0 = time.perf_counter(); th = [threading.Thread(target=work) for _ in range(nt)]
     [t.start() for t in th]; [t.join() for t in th]; t_cp = time.perf_counter() - t0
@@ -74,8 +78,9 @@ def prealloc(path, nt):
     return total / t_fa / 1e9, total / t_cp / 1e9
 for base in ("/dev/shm", "/tmp"):
     try:
-        a, b = prealloc(base + "/rcgpu_fsprobe.bin", 16)
-        print(f"{base:9s} fallocate 1 thread: {a:6.2f} GB/s, then 16 threads memcpy into the mapping: {b:6.2f} GB/s")
+        for how, nt in (("memcpy", 16), ("memcpy", 4), ("populate", 16), ("pwrite", 16), ("pwrite", 1)):
+            a, b = prealloc(base + "/rcgpu_fsprobe.bin", nt, how)
+            print(f"{base:9s} fallocate 1 thread: {a:6.2f} GB/s, then {nt} threads {how}: {b:6.2f} GB/s", flush=True)
     except Exception as e:
         print(base, "prealloc failed:", e)
 # 16 separate files, pwrite, one thread each: is the limit per inode?
