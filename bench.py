@@ -226,7 +226,7 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     return rec, bool(same and ok_md5)
 
 
-def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barrier, reduce_max, lanes=1):
+def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barrier, reduce_max, lanes=1, readers=0, writers=0, slots=0):
     """The workload again with payloads starting and packets ending in host memory (pageable, like the page cache the reference's
     mmaps read from): rcgpu_ffv1_encode_sequence -- reader threads copy into pinned slots, upload / code / download overlap, writer
     threads copy every packet out of the pinned ring into host buffers.  expect_packets: device-resident packets of the ring's
@@ -241,7 +241,7 @@ def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barr
     barrier()
     t0 = time.perf_counter()
     st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in host_ring], n_frames, [a.ctypes.data for a in outs], out_cap, batch=batch // lanes,
-                                           device_first=cfg.device, device_count=1, lanes_per_device=lanes)
+                                           device_first=cfg.device, device_count=1, lanes_per_device=lanes, readers=readers, writers=writers, in_ring_frames=slots)
     wall = time.perf_counter() - t0
     dt = reduce_max(st.seconds)          # the pipeline's own clock: first read to last packet, encoder creation (prepare_seconds) beside it
     # the last `nout` packets are still in their buffers: byte-compare them with the device-resident run's packets of the same frames
@@ -257,8 +257,9 @@ def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barr
             "call_seconds": round(wall, 3), "first_packet_seconds": round(st.first_packet_seconds, 3),
             "h2d_GBps": round(st.payload_bytes / st.seconds / 1e9, 2), "d2h_GBps": round(st.packet_bytes / st.seconds / 1e9, 2),
             "batch_frames": st.batch_frames, "batches": st.batches, "readers": st.readers, "writers": st.writers,
-            "device_busy_seconds": round(st.device_busy_seconds, 3), "steady_frames_per_second": round(st.steady_frames_per_second, 2),
+            "steady_frames_per_second": round(st.steady_frames_per_second, 2),
             "reads_done_seconds": round(st.reads_done_seconds, 3), "last_batch_seconds": round(st.last_batch_seconds, 3),
+            "upload_wait_seconds": round(st.upload_wait_seconds, 3), "h2d_span_seconds": round(st.h2d_span_seconds, 3),
             "packets_identical_to_device_resident_run": (not bad) if check_until else None,
             "source": f"ring of {R} distinct frames in pageable host memory, reused", "_local": (n_frames, st.seconds, dt)}, (not bad)
 
@@ -331,6 +332,9 @@ def main():
     ap.add_argument("--legs", default="host,e2e,check,cpu", help="comma list of the extra records: host (host_pipeline), e2e, check, cpu (cpu_baseline); '' = none")
     ap.add_argument("--host-frames", type=int, default=3840, help="host_pipeline: frames per GPU")
     ap.add_argument("--host-lanes", type=int, default=1, help="host_pipeline: encoder instances per GPU, batches staggered")
+    ap.add_argument("--host-readers", type=int, default=0)
+    ap.add_argument("--host-writers", type=int, default=0)
+    ap.add_argument("--host-slots", type=int, default=0)
     ap.add_argument("--e2e-frames", type=int, default=1000, help="e2e: frames of the sequence (BASELINE config 2: 1000)")
     ap.add_argument("--context-model", default="ffmpeg", choices=["ffmpeg", "compact"],
                     help="level maps of the 5-input context model: FFmpeg's (5063 contexts, states in HBM) or compact (338 contexts, states in LDS)")
@@ -480,7 +484,7 @@ def main():
     torch.cuda.empty_cache()
 
     if "host" in legs:
-        hp, ok = host_pipeline_leg(api, cfg, host_ring, args.host_frames, F, expect, barrier, reduce_max, args.host_lanes)
+        hp, ok = host_pipeline_leg(api, cfg, host_ring, args.host_frames, F, expect, barrier, reduce_max, args.host_lanes, args.host_readers, args.host_writers, args.host_slots)
         ok_all &= ok
         n_loc, _, dt_all = hp.pop("_local")
         if result is not None:

@@ -215,6 +215,8 @@ typedef struct {
     uint32_t batch_frames, devices, readers, writers;
     double   steady_frames_per_second;  /* all batches but the first / time from the first batch's completion to the last's */
     double   reads_done_seconds, last_batch_seconds;
+    double   upload_wait_seconds;       /* device 0: time its host thread waited for the readers */
+    double   h2d_span_seconds;          /* device 0: sum over batches of first upload start .. last upload end */
 } rcgpu_sequence_stats;
 /* record/record_size: optional, the FFV1 configuration record (Matroska CodecPrivate), *record_size = capacity in, size out. */
 int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, const rcgpu_sequence_io* io,
@@ -263,6 +265,9 @@ int  rcgpu_ffv1_decoder_decode_host(rcgpu_ffv1_decoder* dec, const uint8_t* cons
  * and flags describe the files and are the caller's (they come from the reversibility data / the probes).  Fails when the record
  * does not describe `pixfmt` (colorspace, bit depth, alpha) or uses a feature this decoder lacks. */
 int  rcgpu_ffv1_config_from_record(const uint8_t* record, size_t size, rcgpu_ffv1_config* cfg);
+/* The same plus the one stream fact the record does not hold: which of its table sets the planes use (quant_table_set_index in every
+ * slice header, FFV1_Slice.cpp:159-168), read from the first slice header of `packet` (the first frame of the track). */
+int  rcgpu_ffv1_config_from_stream(const uint8_t* record, size_t size, const uint8_t* packet, size_t packet_size, rcgpu_ffv1_config* cfg);
 int  rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* dec, float ms[3]);   /* split+crc, slices, pack */
 /* First differing byte of two device buffers; *first_diff = UINT64_MAX when they are equal (FileWriter.cpp:448-463). */
 int  rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t* first_diff, void* hip_stream);
@@ -322,13 +327,15 @@ int  rcgpu_mkv_add_tag(rcgpu_mkv* mux, int track, const char* name, const char* 
 int  rcgpu_mkv_begin(rcgpu_mkv* mux);
 /* One SimpleBlock (one FFV1 frame or >= 1 whole FLAC frames); pts in nanoseconds, non-decreasing per track. */
 int  rcgpu_mkv_write_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, const uint8_t* data, size_t size, int keyframe);
-/* Parallel writers (what lets the job write ~30 GB/s of packets): after begin(), announce an upper bound of the block payload still
- * to come; the muxer sizes the file for it and maps that part (no-op where that is not possible).  reserve_block() then lays out one
+/* Parallel writers: after begin(), announce an upper bound of the block payload still to come.  On tmpfs the muxer sizes the file for
+ * it, maps that part and allocates its pages ahead of the writers (one output file is one inode: through write() it takes 6 GB/s
+ * there, through pre-allocated mapped pages 50+); on other file systems this is a no-op and the payloads go through pwrite().  reserve_block() then lays out one
  * Cluster + SimpleBlock in stream order and returns where its `size` payload bytes belong: *dst inside the mapping (copy there from
  * any thread), or *dst == NULL and *file_offset for rcgpu_mkv_fill() (pwrite; thread-safe).  close() cuts the file to its real size. */
 int  rcgpu_mkv_expect(rcgpu_mkv* mux, uint64_t max_block_bytes, uint64_t max_blocks);
 int  rcgpu_mkv_reserve_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, size_t size, int keyframe, uint8_t** dst, uint64_t* file_offset);
 int  rcgpu_mkv_fill(rcgpu_mkv* mux, uint64_t file_offset, const uint8_t* data, size_t size);
+void rcgpu_mkv_prefault(rcgpu_mkv* mux, uint8_t* dst, size_t size);   /* optional, before copying to a *dst: maps the range in one call */
 /* Patches A_FLAC CodecPrivate written by begin() (same size) once STREAMINFO is final. */
 int  rcgpu_mkv_update_codec_private(rcgpu_mkv* mux, int track, const uint8_t* codec_private, size_t cp_size);
 /* Writes Cues, patches Segment size / SeekHead / Duration; closes the file. */

@@ -4,9 +4,11 @@
  * 501-608: the walk over the payload, the per-unit byte mask of the FilledA / FilledB layouts (:523-533), the end-of-line word of
  * the packed layouts (:507-521) and of Y 10-bit (:535-566), and In_FirstNonZero = min(i, EOL_i) (:582-591).  It is written from the
  * header facts the reference uses (bit depth, component count, endianness, packing, Altern), not from this repository's layout table,
- * so that the two can disagree.  Parity unpinned: the reference exposes this result only inside the reversibility data's In block;
- * tests/test_gpu_e2e.py round-trips files with non-zero padding bits through the reference itself (--check-padding), which pins the
- * encode path's handling of such files, not this function's return value.
+ * so that the two can disagree.  Parity PINNED: tests/golden/padding_vectors.json holds In_FirstNonZero as the real parser computed
+ * it for 684 files (every layout with filler bits or line padding, clean and with bits poked into samples, filler bits, line padding
+ * and the last word) -- oracle/ref_padding_probe.cpp drives the reference's own dpx::ParseBuffer and prints the private member;
+ * tests/test_oracle.py::test_padding_oracle_matches_the_reference_parser compares this function with it, and
+ * tests/test_gpu_check.py compares rcgpu_dpx_padding_scan_device with both.
  */
 #include <stddef.h>
 #include <stdint.h>

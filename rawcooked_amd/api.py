@@ -55,7 +55,8 @@ class SequenceStats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("first_packet_seconds", C.c_double), ("prepare_seconds", C.c_double), ("device_busy_seconds", C.c_double),
                 ("frames", C.c_uint64), ("payload_bytes", C.c_uint64), ("packet_bytes", C.c_uint64), ("batches", C.c_uint64),
                 ("batch_frames", C.c_uint32), ("devices", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
-                ("steady_frames_per_second", C.c_double), ("reads_done_seconds", C.c_double), ("last_batch_seconds", C.c_double)]
+                ("steady_frames_per_second", C.c_double), ("reads_done_seconds", C.c_double), ("last_batch_seconds", C.c_double),
+                ("upload_wait_seconds", C.c_double), ("h2d_span_seconds", C.c_double)]
 
 
 class FlacConfig(C.Structure):
@@ -105,6 +106,7 @@ SYMBOLS = {
                                           C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
     "rcgpu_mkv_expect": (C.c_int, [_VP, C.c_uint64, C.c_uint64]),
     "rcgpu_mkv_reserve_block": (C.c_int, [_VP, C.c_int, C.c_uint64, _SZ, C.c_int, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
+    "rcgpu_mkv_prefault": (None, [_VP, _VP, _SZ]),
     "rcgpu_mkv_fill": (C.c_int, [_VP, C.c_uint64, _VP, _SZ]),
     "rcgpu_ffv1_framemd5_last": (C.c_int, [_VP, C.c_uint32, _VP, C.POINTER(C.c_uint64)]),
     "rcgpu_ffv1_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
@@ -116,6 +118,7 @@ SYMBOLS = {
     "rcgpu_md5_host_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _U8P, C.c_int]),
     "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
     "rcgpu_ffv1_config_from_record": (C.c_int, [_U8P, _SZ, C.POINTER(Ffv1Config)]),
+    "rcgpu_ffv1_config_from_stream": (C.c_int, [_U8P, _SZ, _U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rcgpu_compare_device": (C.c_int, [_VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     "rcgpu_md5_device": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _VP, _VP]),
@@ -310,12 +313,12 @@ def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, pla
 
 
 def encode_sequence_memory(cfg: Ffv1Config, frame_addrs: list[int], n_frames: int, out_addrs: list[int], out_cap: int, batch=0, readers=0, writers=0,
-                           device_first=0, device_count=0, lanes_per_device=0):
+                           device_first=0, device_count=0, lanes_per_device=0, in_ring_frames=0):
     """rcgpu_ffv1_encode_sequence_memory: frame i = frame_addrs[i % len], packet i -> out_addrs[i % len].  Returns (stats, sizes)."""
     fin = (_VP * len(frame_addrs))(*frame_addrs)
     fout = (_VP * len(out_addrs))(*out_addrs) if out_addrs else None
     sizes = (C.c_uint64 * n_frames)()
-    opt = SequenceOptions(device_first, device_count, batch, readers, writers, 0, 0, lanes_per_device)
+    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, 0, lanes_per_device)
     st = SequenceStats()
     _check(lib().rcgpu_ffv1_encode_sequence_memory(C.byref(cfg), fin, len(frame_addrs), n_frames, fout, len(out_addrs), out_cap, sizes, C.byref(opt), C.byref(st), None, None),
            "rcgpu_ffv1_encode_sequence_memory")

@@ -202,7 +202,7 @@ std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx
 // ---- configuration record reader (parameters::Parse, FFV1_Parameters.cpp:23-183): a scalar range decoder over a few hundred bytes
 namespace {
 struct host_rd {
-    const uint8_t* cur; const uint8_t* end; uint32_t current, mask; uint8_t zero[256];
+    const uint8_t* cur; const uint8_t* end; uint32_t current, mask; uint8_t zero[256]; const uint8_t* one = rc::ffv1::kOneState;
     host_rd(const uint8_t* p, size_t n) : cur(p), end(p + n) { current = n ? *cur : 0; mask = 0xFF; cur++; rc::ffv1::make_zero_state(zero); }
     bool bit(uint8_t& st)
     {
@@ -210,7 +210,7 @@ struct host_rd {
         const uint32_t m2 = (mask * st) >> 8;
         mask -= m2;
         if (current < mask) { st = zero[st]; return false; }
-        current -= mask; mask = m2; st = rc::ffv1::kOneState[st];
+        current -= mask; mask = m2; st = one[st];
         return true;
     }
     uint32_t u(uint8_t* st)
@@ -293,5 +293,30 @@ extern "C" int rcgpu_ffv1_config_from_record(const uint8_t* rec, size_t size, rc
     cfg->coder = coder;
     if (is_compact && !is_ref) cfg->context = 2;
     else if (cfg->context == 2) cfg->context = 1;
+    return 0;
+}
+
+// The record says which table sets exist; which one the planes USE stands in every slice header (quant_table_set_index,
+// FFV1_Slice.cpp:159-168).  A decoder-side caller that holds the first packet of the stream settles it here: the header of the slice
+// at the packet's start is read with the default transitions' sibling of the record's coder (the header states are fresh).
+extern "C" int rcgpu_ffv1_config_from_stream(const uint8_t* rec, size_t size, const uint8_t* packet, size_t packet_size, rcgpu_ffv1_config* cfg)
+{
+    using namespace rc; using namespace rc::ffv1;
+    if (int r = rcgpu_ffv1_config_from_record(rec, size, cfg)) return r;
+    if (!packet || packet_size < 8) return fail(8, "ffv1 stream: packet too small for a slice header");
+    host_rd r(packet, packet_size);
+    if (cfg->coder == 2) { make_zero_state(r.zero, kOneStateAlt); r.one = kOneStateAlt; }
+    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
+    if (!r.bit(st[0])) return fail(8, "ffv1 stream: the first frame is not a key frame");
+    memset(st, 128, sizeof st);
+    const uint32_t sx = r.u(st), sy = r.u(st), sw1 = r.u(st), sh1 = r.u(st);
+    if (sx >= cfg->num_h_slices || sy >= cfg->num_v_slices || sw1 || sh1) return fail(8, "ffv1 stream: unexpected slice geometry in the first slice header");
+    const pix_desc& d = pix(cfg->pixfmt);
+    const uint32_t count = d.planes == 1 ? 2 : d.planes - 1;                      // FFV1_Parameters.cpp:170,175
+    uint32_t idx = r.u(st);
+    for (uint32_t i = 1; i < count; i++) if (r.u(st) != idx) return fail(8, "ffv1 stream: planes with different quantisation table sets are not supported");
+    if (idx > 1) return fail(8, "ffv1 stream: quant_table_set_index %u", idx);
+    if (idx == 0) cfg->context = 0;
+    else if (cfg->context != 2) cfg->context = 1;
     return 0;
 }

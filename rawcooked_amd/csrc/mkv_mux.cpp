@@ -10,8 +10,12 @@
 #include <cerrno>
 #include <cmath>
 #include <fcntl.h>
+#include <atomic>
+#include <chrono>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/vfs.h>
+#include <thread>
 #include <unistd.h>
 
 using namespace rc;
@@ -75,6 +79,9 @@ struct rcgpu_mkv {
     uint64_t uid_seed = 0x9E3779B97F4A7C15ull;
     // parallel writers (rcgpu_mkv_expect / reserve_block / fill): the part of the file that will hold the blocks, mapped shared
     uint8_t* map = nullptr; uint64_t map_base = 0, map_len = 0;
+    // tmpfs: pages are allocated ahead of the writers by one thread (fallocate: ~17 GB/s under the inode lock, no copy), so that the
+    // writers' page faults only map pages that exist (see rcgpu_mkv_expect)
+    std::thread prealloc; std::atomic<bool> prealloc_stop{ false }; std::atomic<uint64_t> reserved_to{ 0 };
 
     uint64_t next_uid() { uid_seed ^= uid_seed << 13; uid_seed ^= uid_seed >> 7; uid_seed ^= uid_seed << 17; return uid_seed | 1; }
     int put(const void* p, size_t n)
@@ -310,6 +317,13 @@ extern "C" int rcgpu_mkv_expect(rcgpu_mkv* m, uint64_t max_block_bytes, uint64_t
     if (!m || !m->begun) return fail(1, "mkv: expect before begin");
     if (m->map) return 0;
     if (const char* e = getenv("RCGPU_MKV_NO_MMAP")) if (*e && *e != '0') return 0;
+    // Measured on the GPU box (tools/probe_fs.py, one 8 GiB file): a page-cache file takes ~12 GB/s through pwrite() from one or
+    // many threads, and only 2-4 GB/s through a shared mapping (every fault allocates a page under the file's locks); tmpfs takes
+    // 6 GB/s through pwrite, 3-4 GB/s through a mapping -- but 57 GB/s through a mapping once fallocate() has allocated the pages
+    // (17 GB/s, one thread) and the writers pre-fault their range with MADV_POPULATE_WRITE.  So: map on tmpfs only, and allocate ahead.
+    struct statfs sf;
+    const bool force = getenv("RCGPU_MKV_MMAP") != nullptr;
+    if (!force && (fstatfs(m->fd, &sf) != 0 || uint32_t(sf.f_type) != 0x01021994u)) return 0;          // TMPFS_MAGIC
     const uint64_t page = 4096;
     const uint64_t base = m->pos & ~(page - 1);
     const uint64_t len = (m->pos - base) + max_block_bytes + max_blocks * 64 + (1u << 20);
@@ -317,7 +331,30 @@ extern "C" int rcgpu_mkv_expect(rcgpu_mkv* m, uint64_t max_block_bytes, uint64_t
     void* p = mmap(nullptr, size_t(len), PROT_READ | PROT_WRITE, MAP_SHARED, m->fd, off_t(base));
     if (p == MAP_FAILED) { if (ftruncate(m->fd, off_t(m->pos)) != 0) {} return 0; }
     m->map = static_cast<uint8_t*>(p); m->map_base = base; m->map_len = len;
+    m->reserved_to = m->pos;
+    m->prealloc = std::thread([m] {
+        const uint64_t chunk = uint64_t(256) << 20, ahead = uint64_t(6) << 30;
+        uint64_t done = m->map_base;
+        while (!m->prealloc_stop.load()) {
+            const uint64_t want = std::min<uint64_t>(m->map_base + m->map_len, m->reserved_to.load() + ahead);
+            if (done >= want) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
+            const uint64_t n = std::min<uint64_t>(chunk, want - done);
+            if (fallocate(m->fd, 0, off_t(done), off_t(n)) != 0) return;      // not supported or no room: the faults allocate, as before
+            done += n;
+        }
+    });
     return 0;
+}
+
+// Writer threads, before they copy a payload to where reserve_block() put it: map the range in one call instead of one fault per page.
+extern "C" void rcgpu_mkv_prefault(rcgpu_mkv* m, uint8_t* dst, size_t size)
+{
+    if (!m || !m->map || !dst || dst < m->map || dst + size > m->map + m->map_len) return;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(dst) & ~uintptr_t(4095), b = (reinterpret_cast<uintptr_t>(dst) + size + 4095) & ~uintptr_t(4095);
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+    (void)madvise(reinterpret_cast<void*>(a), size_t(b - a), MADV_POPULATE_WRITE);      // older kernels: EINVAL, the copy faults page by page
 }
 
 extern "C" int rcgpu_mkv_reserve_block(rcgpu_mkv* m, int trk, uint64_t pts_ns, size_t size, int keyframe, uint8_t** dst, uint64_t* file_offset)
@@ -339,6 +376,7 @@ extern "C" int rcgpu_mkv_reserve_block(rcgpu_mkv* m, int trk, uint64_t pts_ns, s
     *file_offset = m->pos;
     *dst = (m->map && m->pos >= m->map_base && m->pos + size <= m->map_base + m->map_len) ? m->map + (m->pos - m->map_base) : nullptr;
     m->pos += size;
+    m->reserved_to = m->pos;
     t.last_pts_ms = ms;
     uint64_t end = ms;
     if (t.video) end = ms + uint64_t(std::llround(1000.0 * t.fps_den / t.fps_num));
@@ -371,6 +409,7 @@ extern "C" int rcgpu_mkv_close(rcgpu_mkv* m)
 {
     if (!m) return 0;
     int r = 0;
+    if (m->prealloc.joinable()) { m->prealloc_stop = true; m->prealloc.join(); }
     if (m->map) {      // blocks were laid out inside a mapping of a generously sized file: cut it back to what was used
         munmap(m->map, size_t(m->map_len)); m->map = nullptr;
         if (ftruncate(m->fd, off_t(m->pos)) != 0) r = fail(22, "mkv: cannot size %s: %s", m->path.c_str(), strerror(errno));

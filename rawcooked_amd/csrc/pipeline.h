@@ -33,6 +33,8 @@ struct pipe_io {
     std::function<uint8_t*(const pipe_frame& f, size_t size)> place;
     // writer threads, concurrently: the packet is at `data` (== the place, or a pinned buffer valid during the call).  0 = ok.
     std::function<int(const pipe_frame& f, const uint8_t* data, size_t size)> done;
+    // optional, writer threads: called with the place right before the packet is copied there (e.g. to pre-fault a mapped file range)
+    std::function<void(uint8_t* dst, size_t size)> before_copy;
     // optional, lane thread, after a batch has run and while its payloads are still on the device (e.g. frame checksums).
     // Setting it serialises upload and encoding of consecutive batches.
     std::function<int(uint32_t video, rcgpu_ffv1* enc, uint64_t first_index, uint32_t n)> after_batch;
@@ -55,6 +57,8 @@ struct pipe_stats {
     double device_busy_seconds = 0;             // sum over batches of (batch complete - encode call), lane 0
     double steady_frames_per_second = 0;        // frames of all batches but the first / time from the first batch's completion to the last's
     double reads_done_seconds = 0, last_batch_seconds = 0;
+    double upload_wait_seconds = 0;             // lane 0: time its thread waited for the readers to fill a slot
+    double h2d_span_seconds = 0;                // lane 0: sum over batches of first upload start .. last upload end (device clock)
 };
 
 class pipeline {

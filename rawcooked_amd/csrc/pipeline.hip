@@ -33,7 +33,8 @@ struct lane_t {
     hipStream_t cin = nullptr, cout = nullptr;
     std::vector<hipEvent_t> dl_done;              // per video: the download of the last batch out of that encoder's d_packets
     std::vector<bool> dl_valid;
-    hipEvent_t ev_up = nullptr, ev_done[2] = { nullptr, nullptr };
+    hipEvent_t ev_up = nullptr, ev_up0 = nullptr, ev_done[2] = { nullptr, nullptr };     // ev_up0 / ev_up time the uploads of a batch
+    double upload_wait = 0, h2d_span = 0;
     // download ring: pinned chunks, a chunk is re-entered when nothing in it is outstanding
     std::vector<uint8_t*> chunks; std::vector<int> outstanding; size_t chunk_bytes = 0, max_chunks = 0; int cur = -1; size_t cur_off = 0;
     std::deque<out_entry> outq;                   // issued downloads in frame order, consumed by the placer
@@ -84,6 +85,7 @@ pipeline::impl::~impl()
         for (hipEvent_t e : L.free_events) (void)hipEventDestroy(e);
         for (hipEvent_t e : L.dl_done) if (e) (void)hipEventDestroy(e);
         if (L.ev_up) (void)hipEventDestroy(L.ev_up);
+        if (L.ev_up0) (void)hipEventDestroy(L.ev_up0);
         for (hipEvent_t e : L.ev_done) if (e) (void)hipEventDestroy(e);
         if (L.cin) (void)hipStreamDestroy(L.cin);
         if (L.cout) (void)hipStreamDestroy(L.cout);
@@ -172,7 +174,7 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
             return fail(100, "pipeline: cannot create copy streams");
         L.dl_done.assign(videos.size(), nullptr); L.dl_valid.assign(videos.size(), false);
         for (auto& e : L.dl_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(100, "pipeline: cannot create events");
-        if (hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L.ev_done[0], hipEventDisableTiming) != hipSuccess ||
+        if (hipEventCreate(&L.ev_up) != hipSuccess || hipEventCreate(&L.ev_up0) != hipSuccess || hipEventCreateWithFlags(&L.ev_done[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L.ev_done[1], hipEventDisableTiming) != hipSuccess) return fail(100, "pipeline: cannot create events");
         uint32_t maxF = 1;
         for (uint32_t f : s.F) maxF = std::max(maxF, f);
@@ -222,7 +224,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         uint64_t total_need = 0; for (const batch_t& b : batches) if (b.lane == L.id) total_need += uint64_t(b.n) * s.max_packet[b.video];
         want = std::min<uint64_t>(want, std::max<uint64_t>(total_need, L.chunk_bytes));
         L.max_chunks = std::max<size_t>(2, size_t((want + L.chunk_bytes - 1) / L.chunk_bytes));
-        L.cur = -1; L.cur_off = 0; L.outq.clear();
+        L.cur = -1; L.cur_off = 0; L.outq.clear(); L.upload_wait = 0; L.h2d_span = 0;
         std::fill(L.dl_valid.begin(), L.dl_valid.end(), false);
     }
     s.ready.assign(N, nullptr); s.jobs.clear(); s.pending.clear(); s.placer_finished = false; s.next_read = 0; s.alloc_done = false;
@@ -333,11 +335,14 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             for (size_t k = 0; k < B.n; k++) {
                 uint8_t* slot = nullptr;
                 {
+                    const auto tw = clk::now();
                     std::unique_lock<std::mutex> l(s.m);
                     s.cv.wait(l, [&] { return s.error || s.ready[B.first + k]; });
                     if (s.error) return false;
                     slot = s.ready[B.first + k];
+                    L.upload_wait += since(tw);
                 }
+                if (k == 0 && !hip_ok(hipEventRecord(L.ev_up0, L.cin), "hipEventRecord")) return false;
                 if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, slot, sg.payload_bytes, hipMemcpyHostToDevice, L.cin), "upload")) return false;
                 hipEvent_t ev = get_event();
                 if (!ev || !hip_ok(hipEventRecord(ev, L.cin), "hipEventRecord")) return false;
@@ -372,6 +377,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             enc_staging sg; if (ffv1_staging(enc, &sg)) { s.set_error(100, rcgpu_last_error()); return false; }
             hipStream_t st = static_cast<hipStream_t>(sg.compute_stream);
             if (!hip_ok(hipStreamWaitEvent(st, L.ev_up, 0), "hipStreamWaitEvent")) return false;
+            { float ms = 0; if (hipEventSynchronize(L.ev_up) == hipSuccess && hipEventElapsedTime(&ms, L.ev_up0, L.ev_up) == hipSuccess) L.h2d_span += ms * 1e-3; }
             ffv1_set_defer_gather(enc, true);
             std::vector<const void*> ptrs(B.n);
             for (size_t i = 0; i < B.n; i++) ptrs[i] = sg.d_in + i * sg.in_stride;
@@ -469,7 +475,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (hipEventSynchronize(o.ev) != hipSuccess) r = fail(100, "pipeline: a download failed");
             if (!r) {
                 if (!first_seen.exchange(true)) first_packet_seconds = since(t0);
-                if (o.dst) memcpy(o.dst, o.src, o.size);
+                if (o.dst) { if (io.before_copy) io.before_copy(o.dst, o.size); memcpy(o.dst, o.src, o.size); }
                 if (io.done) r = io.done(frames[o.frame], o.dst ? o.dst : o.src, o.size);
                 packet_bytes += o.size;
             }
@@ -506,7 +512,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         for (const pipe_frame& f : frames) stats->payload_bytes += s.payload[f.video];
         stats->packet_bytes = packet_bytes; stats->batches = batches.size(); stats->batch_frames = maxF; stats->lanes = uint32_t(nl);
         stats->readers = readers; stats->writers = writers; stats->device_busy_seconds = busy0;
-        stats->reads_done_seconds = reads_done;
+        stats->reads_done_seconds = reads_done; stats->upload_wait_seconds = s.lanes[0].upload_wait; stats->h2d_span_seconds = s.lanes[0].h2d_span;
         if (!batches.empty()) {
             double first = 1e300, last = 0; size_t first_b = 0;
             for (size_t b = 0; b < batches.size(); b++) { if (batch_done[b] < first) { first = batch_done[b]; first_b = b; } last = std::max(last, batch_done[b]); }
@@ -557,6 +563,7 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
         stats->batch_frames = ps.batch_frames; stats->devices = ps.lanes; stats->readers = ps.readers; stats->writers = ps.writers;
         stats->device_busy_seconds = ps.device_busy_seconds; stats->steady_frames_per_second = ps.steady_frames_per_second;
         stats->reads_done_seconds = ps.reads_done_seconds; stats->last_batch_seconds = ps.last_batch_seconds;
+        stats->upload_wait_seconds = ps.upload_wait_seconds; stats->h2d_span_seconds = ps.h2d_span_seconds;
     }
     return r;
 }

@@ -176,3 +176,22 @@ def test_padding_scan_matches_the_reference_rule(built, pixfmt):
             assert want[0] == 2 ** 64 - 1 or packing == 0                     # synth writes zero filler bits
     with pytest.raises(RuntimeError):
         api.dpx_padding_scan_device([0], synth.PIX_EXR_RGB16, 8, 8)
+
+
+def test_padding_scan_matches_the_reference_parser(built):
+    """rcgpu_dpx_padding_scan_device against tests/golden/padding_vectors.json: the reference's own In_FirstNonZero for 684 files
+    (dpx::ParseBuffer, DPX.cpp:501-608, run by oracle/ref_padding_probe.cpp; recipe in tests/golden/make_padding_golden.py)."""
+    import json
+    from test_oracle import _padding_payload, _padding_vectors
+    vs = _padding_vectors()
+    groups = {}
+    for v in vs:
+        groups.setdefault((v["pixfmt"], v["width"], v["height"], v["flags"]), []).append(v)
+    checked = 0
+    for (pixfmt, w, h, flags), items in groups.items():
+        dv = [dev(_padding_payload(v)) for v in items]
+        got = api.dpx_padding_scan_device([t.data_ptr() for t in dv], pixfmt, w, h, flags)
+        want = [2 ** 64 - 1 if v["first_nonzero"] < 0 else v["first_nonzero"] for v in items]
+        assert got == want, (items[0]["flavor"], w, h, flags, [i for i in range(len(want)) if got[i] != want[i]][:5])
+        checked += len(items)
+    assert checked == len(vs) > 600

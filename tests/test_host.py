@@ -376,3 +376,21 @@ def test_linked_reference_reports_the_missing_device(built, tmp_path):
     r = subprocess.run([exe, "--hash", "-y", "pkg"], cwd=tmp_path, capture_output=True, text=True, timeout=60, stdin=subprocess.DEVNULL)
     assert r.returncode != 0 and "Error: no HIP device available -- rcgpu has no CPU encode path" in r.stderr, r.stdout + r.stderr
     assert not os.path.exists(tmp_path / "pkg.mkv")
+
+
+@pytest.mark.parametrize("context,coder,pixfmt", [(0, 1, synth.PIX_RGB16_BE), (1, 1, synth.PIX_RGB16_BE), (2, 1, synth.PIX_RGB10_FILLEDA_BE), (0, 2, synth.PIX_RGBA16_LE), (1, 2, synth.PIX_Y16_BE)])
+def test_config_from_stream_reads_the_table_set_from_the_first_slice_header(built, context, coder, pixfmt):
+    """What the record cannot say -- which quantisation table set the planes use (FFV1_Slice.cpp:159-168) -- comes from the first packet."""
+    import ctypes
+    import oracle_binding as ob
+    w, h = 96, 64
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    p = ob.Params(w, h, pixfmt, 3, 2, 1, context, 0, coder)
+    pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, "film", seed=4), pixfmt, True)
+    rec, pk = ob.config_record(p), ob.encode_payload(p, pl, line_bytes)
+    for hint in (0, 1):
+        cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 0, 0, 0, hint, 1, 0, 0, 0, 0, 0)
+        assert api.lib().rcgpu_ffv1_config_from_stream(rec, len(rec), pk, len(pk), ctypes.byref(cfg)) == 0, api.last_error()
+        assert (cfg.context, cfg.coder, cfg.num_h_slices, cfg.num_v_slices, cfg.slicecrc) == (context, coder, 3, 2, 1)
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0)
+    assert api.lib().rcgpu_ffv1_config_from_stream(rec, len(rec), pk[:4], 4, ctypes.byref(cfg)) != 0

@@ -115,3 +115,29 @@ def test_oracle_packets_pass_the_real_reference(built, refbin, tmp_path):
     mux.close()
     r = _run_ref([refbin, "--check", "pkg.mkv"], work)
     assert r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout, r.stdout + r.stderr
+
+
+def _padding_vectors():
+    return json.load(open(os.path.join(G, "padding_vectors.json")))["vectors"]
+
+
+def _padding_payload(v):
+    bits, nc, _, _ = synth.PIX_INFO[v["pixfmt"]]
+    pl, _ = synth.pack_payload(synth.components(v["width"], v["height"], nc, bits, "noise", seed=v["seed"]), v["pixfmt"], True, v["flags"])
+    b = bytearray(len(pl)) if v["zero"] else bytearray(pl)
+    for at, x in v["pokes"]:
+        b[at] ^= x
+    return bytes(b)
+
+
+def test_padding_oracle_matches_the_reference_parser(built):
+    """oracle/dpx_oracle.c against tests/golden/padding_vectors.json: In_FirstNonZero as the REAL dpx::ParseBuffer computed it
+    (DPX.cpp:501-608; made observable by oracle/ref_padding_probe.cpp, see tests/golden/make_padding_golden.py)."""
+    vs = _padding_vectors()
+    assert len(vs) > 600 and sum(1 for v in vs if v["first_nonzero"] >= 0) > 100
+    for v in vs:
+        bits, nc, _, be = synth.PIX_INFO[v["pixfmt"]]
+        packing = synth.DPX_PACKING.get(v["pixfmt"], 1 if bits in (10, 12) else 0)
+        got = ob.dpx_padding_first_nonzero(_padding_payload(v), v["width"], v["height"], bits, nc, be, packing, bool(v["flags"] & synth.FLAG_ALTERN))
+        want = 2 ** 64 - 1 if v["first_nonzero"] < 0 else v["first_nonzero"]
+        assert got == want, (v["flavor"], v["width"], v["height"], v["flags"], v["pokes"], got, want)

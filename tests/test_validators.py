@@ -59,13 +59,31 @@ def test_ffv1_validator_negative_controls(built):
         rfc.validate_stream(rec, [bytes(bad)], w, h)
 
 
-@pytest.mark.parametrize("mode", ["write", "mapped", "pwrite"])
+@pytest.mark.parametrize("mode", ["write", "mapped", "tmpfs", "pwrite"])
 def test_muxer_files_are_valid_matroska_and_the_reference_reads_them(built, tmp_path, monkeypatch, mode):
-    """The same package through the muxer's three block paths: identical blocks in the file, valid by the Matroska rules, and -- where
-    the real reference is built -- rebuilt bit-exactly by it."""
+    """The same package through the muxer's block paths -- buffered writes; payloads copied into a mapping of the file (forced on
+    whatever file system the test runs on, and on tmpfs, where the muxer chooses it itself, allocates the pages ahead and the writers
+    pre-fault their range); payloads through pwrite(): identical blocks in the file, valid by the Matroska rules, and -- where the real
+    reference is built -- rebuilt bit-exactly by it."""
+    import shutil
+    import tempfile
     if mode == "pwrite":
         monkeypatch.setenv("RCGPU_MKV_NO_MMAP", "1")
+    if mode == "mapped":
+        monkeypatch.setenv("RCGPU_MKV_MMAP", "1")
     work = str(tmp_path)
+    if mode == "tmpfs":
+        if not os.path.isdir("/dev/shm"):
+            pytest.skip("no /dev/shm")
+        work = tempfile.mkdtemp(prefix="rcgpu_test_", dir="/dev/shm")
+    try:
+        _muxer_paths(work, mode)
+    finally:
+        if mode == "tmpfs":
+            shutil.rmtree(work, ignore_errors=True)
+
+
+def _muxer_paths(work, mode):
     os.makedirs(work + "/pkg/img")
     w, h, pixfmt, n = 72, 40, synth.PIX_RGB16_BE, 7
     files = []
@@ -99,12 +117,13 @@ def test_muxer_files_are_valid_matroska_and_the_reference_reads_them(built, tmp_
         else:
             dst, off = C.c_void_p(), C.c_uint64()
             assert L.rcgpu_mkv_reserve_block(mux.h, tv, i * 10 ** 9 // 24, len(pk), 1, C.byref(dst), C.byref(off)) == 0
-            assert bool(dst.value) == (mode == "mapped")
+            assert bool(dst.value) == (mode in ("mapped", "tmpfs"))
             jobs.append((dst.value, off.value, pk))
 
     def fill(part):
         for dst, off, pk in part:
             if dst:
+                L.rcgpu_mkv_prefault(mux.h, dst, len(pk))
                 C.memmove(dst, pk, len(pk))
             else:
                 assert L.rcgpu_mkv_fill(mux.h, off, pk, len(pk)) == 0
