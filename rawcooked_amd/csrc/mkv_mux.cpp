@@ -81,7 +81,7 @@ struct rcgpu_mkv {
     uint8_t* map = nullptr; uint64_t map_base = 0, map_len = 0;
     // tmpfs: pages are allocated ahead of the writers by one thread (fallocate: ~17 GB/s under the inode lock, no copy), so that the
     // writers' page faults only map pages that exist (see rcgpu_mkv_expect)
-    std::thread prealloc; std::atomic<bool> prealloc_stop{ false }; std::atomic<uint64_t> reserved_to{ 0 };
+    std::thread prealloc; std::atomic<bool> prealloc_stop{ false }, prealloc_alive{ false }; std::atomic<uint64_t> reserved_to{ 0 }, prealloc_to{ 0 };
 
     uint64_t next_uid() { uid_seed ^= uid_seed << 13; uid_seed ^= uid_seed >> 7; uid_seed ^= uid_seed << 17; return uid_seed | 1; }
     int put(const void* p, size_t n)
@@ -331,17 +331,19 @@ extern "C" int rcgpu_mkv_expect(rcgpu_mkv* m, uint64_t max_block_bytes, uint64_t
     void* p = mmap(nullptr, size_t(len), PROT_READ | PROT_WRITE, MAP_SHARED, m->fd, off_t(base));
     if (p == MAP_FAILED) { if (ftruncate(m->fd, off_t(m->pos)) != 0) {} return 0; }
     m->map = static_cast<uint8_t*>(p); m->map_base = base; m->map_len = len;
-    m->reserved_to = m->pos;
+    m->reserved_to = m->pos; m->prealloc_to = base; m->prealloc_alive = true;
     m->prealloc = std::thread([m] {
-        const uint64_t chunk = uint64_t(256) << 20, ahead = uint64_t(6) << 30;
+        const uint64_t chunk = uint64_t(128) << 20, ahead = uint64_t(4) << 30;
         uint64_t done = m->map_base;
         while (!m->prealloc_stop.load()) {
             const uint64_t want = std::min<uint64_t>(m->map_base + m->map_len, m->reserved_to.load() + ahead);
-            if (done >= want) { std::this_thread::sleep_for(std::chrono::milliseconds(1)); continue; }
+            if (done >= want) { std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }
             const uint64_t n = std::min<uint64_t>(chunk, want - done);
-            if (fallocate(m->fd, 0, off_t(done), off_t(n)) != 0) return;      // not supported or no room: the faults allocate, as before
+            if (fallocate(m->fd, 0, off_t(done), off_t(n)) != 0) break;       // not supported or no room: the faults allocate, as before
             done += n;
+            m->prealloc_to = done;
         }
+        m->prealloc_alive = false;
     });
     return 0;
 }
@@ -351,6 +353,10 @@ extern "C" void rcgpu_mkv_prefault(rcgpu_mkv* m, uint8_t* dst, size_t size)
 {
     if (!m || !m->map || !dst || dst < m->map || dst + size > m->map + m->map_len) return;
     const uintptr_t a = reinterpret_cast<uintptr_t>(dst) & ~uintptr_t(4095), b = (reinterpret_cast<uintptr_t>(dst) + size + 4095) & ~uintptr_t(4095);
+    // not before the allocating thread has passed this range: a fault on a page that does not exist yet allocates it the slow way and
+    // contends with fallocate() for the file's locks
+    const uint64_t end_off = m->map_base + uint64_t((dst + size) - m->map);
+    while (m->prealloc_alive.load() && m->prealloc_to.load() < end_off) std::this_thread::sleep_for(std::chrono::microseconds(100));
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif

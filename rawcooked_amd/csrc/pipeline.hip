@@ -39,6 +39,8 @@ struct lane_t {
     std::vector<uint8_t*> chunks; std::vector<int> outstanding; size_t chunk_bytes = 0, max_chunks = 0; int cur = -1; size_t cur_off = 0;
     std::deque<out_entry> outq;                   // issued downloads in frame order, consumed by the placer
     std::vector<hipEvent_t> free_events;
+    struct pending_up { uint8_t* slot; hipEvent_t ev; };
+    std::deque<pending_up> pending;                // uploads in flight, in issue order: their slots return to the pool once the copy is done
     uint64_t* h_sizes = nullptr; uint32_t* h_err = nullptr; size_t h_sizes_stride = 0;     // pinned, two batches' worth
 };
 
@@ -58,8 +60,6 @@ struct pipeline::impl {
     std::mutex m; std::condition_variable cv;
     int error = 0; std::string error_msg;
     std::vector<uint8_t*> all_slots, free_slots; size_t slots_wanted = 0;
-    struct pending_up { uint8_t* slot; hipEvent_t ev; int lane; };
-    std::deque<pending_up> pending;               // uploads in flight: their slots return to the pool once the copy is done
     std::vector<uint8_t*> ready;                  // per output frame: the filled slot (nullptr until read)
     std::deque<out_entry> jobs;                   // placed packets waiting for a writer
     bool placer_finished = false;
@@ -227,7 +227,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         L.cur = -1; L.cur_off = 0; L.outq.clear(); L.upload_wait = 0; L.h2d_span = 0;
         std::fill(L.dl_valid.begin(), L.dl_valid.end(), false);
     }
-    s.ready.assign(N, nullptr); s.jobs.clear(); s.pending.clear(); s.placer_finished = false; s.next_read = 0; s.alloc_done = false;
+    s.ready.assign(N, nullptr); s.jobs.clear(); for (lane_t& L : s.lanes) L.pending.clear(); s.placer_finished = false; s.next_read = 0; s.alloc_done = false;
     s.error = 0; s.error_msg.clear();
 
     std::vector<double> batch_done(batches.size(), 0.0);
@@ -284,14 +284,21 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         { std::lock_guard<std::mutex> l(s.m); s.alloc_done = true; s.cv.notify_all(); }
     });
 
-    // uploads whose copy has completed give their slot back; called with the lock held
+    // uploads whose copy has completed give their slot back; called with the lock held.  Copies of one lane complete in order, so only
+    // the oldest pending one of each lane is asked about, and not more often than every 100 us whoever asks: the HIP runtime's locks
+    // are shared with the lane thread that is launching kernels.
+    clk::time_point last_reap = clk::now();
     auto reap = [&]() {
-        for (auto it = s.pending.begin(); it != s.pending.end();) {
-            if (hipEventQuery(it->ev) != hipSuccess) { ++it; continue; }
-            s.free_slots.push_back(it->slot);
-            s.lanes[size_t(it->lane)].free_events.push_back(it->ev);  // back to its lane's pool: an event stays with the device that made it
-            it = s.pending.erase(it);
-        }
+        const auto now = clk::now();
+        if (std::chrono::duration<double>(now - last_reap).count() < 100e-6) return;
+        last_reap = now;
+        for (lane_t& L : s.lanes)
+            while (!L.pending.empty()) {
+                if (hipEventQuery(L.pending.front().ev) != hipSuccess) break;
+                s.free_slots.push_back(L.pending.front().slot);
+                L.free_events.push_back(L.pending.front().ev);
+                L.pending.pop_front();
+            }
     };
 
     // ---- readers
@@ -327,7 +334,8 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         auto get_event = [&]() -> hipEvent_t {
             { std::lock_guard<std::mutex> l(s.m); if (!L.free_events.empty()) { hipEvent_t e = L.free_events.back(); L.free_events.pop_back(); return e; } }
             hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            // blocking sync: a writer waiting for a download sleeps in the kernel instead of spinning on the runtime
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return nullptr;
             return e;
         };
         auto issue_uploads = [&](const batch_t& B) -> bool {
@@ -346,7 +354,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, slot, sg.payload_bytes, hipMemcpyHostToDevice, L.cin), "upload")) return false;
                 hipEvent_t ev = get_event();
                 if (!ev || !hip_ok(hipEventRecord(ev, L.cin), "hipEventRecord")) return false;
-                { std::lock_guard<std::mutex> l(s.m); s.pending.push_back({ slot, ev, L.id }); }
+                { std::lock_guard<std::mutex> l(s.m); L.pending.push_back({ slot, ev }); }
             }
             return hip_ok(hipEventRecord(L.ev_up, L.cin), "hipEventRecord");
         };
@@ -504,8 +512,8 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     for (lane_t& L : s.lanes) { (void)hipSetDevice(L.device); (void)hipDeviceSynchronize(); }
     {   // slots still listed as pending are free now
         std::lock_guard<std::mutex> l(s.m);
-        for (auto& u : s.pending) s.lanes[size_t(u.lane)].free_events.push_back(u.ev);
-        s.pending.clear(); s.free_slots.clear();
+        for (lane_t& L : s.lanes) { for (auto& u : L.pending) L.free_events.push_back(u.ev); L.pending.clear(); }
+        s.free_slots.clear();
     }
     if (stats) {
         stats->seconds = since(t0); stats->first_packet_seconds = first_packet_seconds; stats->frames = N;

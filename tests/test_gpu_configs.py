@@ -62,3 +62,106 @@ def test_flat_and_noise_extremes_4k(built):
     s_flat = roundtrip(4096, 2160, synth.PIX_RGB16_BE, 64, 1, "flat", oracle_frames=1)
     s_noise = roundtrip(4096, 2160, synth.PIX_RGB16_BE, 64, 1, "noise", oracle_frames=0)
     assert s_flat[0] < 4096 * 2160 * 6 // 50 and s_noise[0] > 4096 * 2160 * 6
+
+
+# ---- whole jobs at the configs' full picture size: files -> rcgpu-ffmpeg (GPU) -> MKV -> the REAL reference's --check ----
+import os          # noqa: E402
+import shlex       # noqa: E402
+import shutil      # noqa: E402
+import subprocess  # noqa: E402
+import tempfile    # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+OK_LINE = "Reversibility was checked, no issue detected."
+
+
+def _run(cmd, cwd, timeout, attempts=3, env=None):
+    for a in range(attempts):                      # the reference occasionally dead-locks in its own thread pool on many-core hosts
+        try:
+            return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, stdin=subprocess.DEVNULL, env=env)
+        except subprocess.TimeoutExpired:
+            if a + 1 == attempts:
+                raise
+
+
+def _film_payloads(n, w, h):
+    """n synthetic RGB16 big-endian 'film' payloads, made on the device (numpy needs seconds per 4K frame)."""
+    import bench
+    return bench.make_frames(torch, n, w, h, "film", 7, torch.device("cuda", 0)).cpu().numpy()
+
+
+def _job(work, n_expected_slices, extra_check=None):
+    ref = os.path.join(ROOT, "oracle", "_ref", "rawcooked")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/rawcooked not built (needs /root/reference)")
+    r = _run([ref, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work, 300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ("-slices %d " % n_expected_slices) in r.stdout, r.stdout
+    argv = shlex.split(r.stdout.strip())
+    r = _run([SHIM] + argv[1:], work, 300, env=dict(os.environ, RCGPU_TRACE="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    import mkv_validator
+    rep = mkv_validator.validate(os.path.join(work, "pkg.mkv"))
+    r2 = _run([ref, "--check", "pkg.mkv"], work, 900)
+    assert r2.returncode == 0 and OK_LINE in r2.stdout and "Error" not in (r2.stdout + r2.stderr), r2.stdout + r2.stderr
+    return rep, r.stderr
+
+
+def test_config3_job_4k_dpx_with_6ch_wav_through_the_reference(built):
+    """BASELINE config 3 as a job: 4K-DCI 16-bit DPX + 6 ch / 24 bit / 48 kHz WAV -> FFV1 + FLAC in one MKV, coded on the GPU from the
+    command the reference prints, several batches (RCGPU_BATCH), then rebuilt and hash-checked by the reference's CPU decoders."""
+    n, w, h = 20, 4096, 2160
+    work = tempfile.mkdtemp(prefix="rcgpu_cfg3_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        os.makedirs(os.path.join(work, "pkg", "img"))
+        frames = _film_payloads(n, w, h)
+        for i in range(n):
+            with open(os.path.join(work, "pkg", "img", "f_%06d.dpx" % i), "wb") as f:
+                f.write(synth.dpx_file(None, synth.PIX_RGB16_BE, frame_index=i, payload=frames[i].tobytes(), size=(w, h)))
+        with open(os.path.join(work, "pkg", "snd.wav"), "wb") as f:
+            f.write(synth.wav_file(synth.pcm_samples(n * 2000, 6, 24, 48000), 24, 48000))        # n / 24 s of audio
+        os.environ["RCGPU_BATCH"] = "8"
+        try:
+            rep, trace = _job(work, 576)                                                          # the reference's own choice for 4K 16 bit
+        finally:
+            del os.environ["RCGPU_BATCH"]
+        assert rep["tracks"][1] == {"type": 1, "codec": "V_FFV1", "blocks": n} and rep["tracks"][2]["codec"] == "A_FLAC" and rep["tracks"][2]["blocks"] >= 8
+        assert "batches of 8" in trace
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def test_config4_job_8k_tiff_sequence_through_the_reference(built):
+    """BASELINE config 4's shape as a job: 8 frames of 8192x4320 16-bit little-endian TIFF, the reference's default 576 slices, batches
+    of 3 (several batches in flight, a ragged last one), rebuilt and hash-checked by the reference."""
+    n, w, h = 8, 8192, 4320
+    work = tempfile.mkdtemp(prefix="rcgpu_cfg4_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        os.makedirs(os.path.join(work, "pkg", "img"))
+        be = _film_payloads(n, w, h)
+        import struct
+        import numpy as np
+        # header and IFD of a small TIFF from synth, patched to w x h; the payload follows them
+        small = synth.tiff_file(np.zeros((2, 2, 3), dtype=np.uint16), synth.PIX_RGB16_LE)
+        head = bytearray(small[:api.tiff_probe(small).data_offset])
+        for t in range(struct.unpack_from("<H", head, 8)[0]):
+            at = 10 + 12 * t
+            tag = struct.unpack_from("<H", head, at)[0]
+            if tag == 256:
+                struct.pack_into("<I", head, at + 8, w)
+            if tag in (257, 278):
+                struct.pack_into("<I", head, at + 8, h)
+            if tag == 279:
+                struct.pack_into("<I", head, at + 8, w * h * 6)
+        for i in range(n):
+            with open(os.path.join(work, "pkg", "img", "f_%06d.tif" % i), "wb") as f:
+                f.write(bytes(head)); f.write(be[i].reshape(-1, 2)[:, ::-1].tobytes())           # the same samples, little endian
+        os.environ["RCGPU_BATCH"] = "3"
+        try:
+            rep, trace = _job(work, 576)
+        finally:
+            del os.environ["RCGPU_BATCH"]
+        assert rep["tracks"][1]["blocks"] == n and "batches of 3" in trace
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
