@@ -336,6 +336,7 @@ def main():
     ap.add_argument("--host-writers", type=int, default=0)
     ap.add_argument("--host-slots", type=int, default=0)
     ap.add_argument("--e2e-frames", type=int, default=1000, help="e2e: frames of the sequence (BASELINE config 2: 1000)")
+    ap.add_argument("--dma-noise", action="store_true", help="experiment: pinned H2D + D2H copies at full rate on two side streams during the timed steps")
     ap.add_argument("--context-model", default="ffmpeg", choices=["ffmpeg", "compact"],
                     help="level maps of the 5-input context model: FFmpeg's (5063 contexts, states in HBM) or compact (338 contexts, states in LDS)")
     ap.add_argument("--mode", default="encode", choices=["encode", "check"],
@@ -397,8 +398,29 @@ def main():
         print(json.dumps(rec))
         sys.exit(0 if ok else 2)
 
+    noise = None
+    if args.dma_noise:
+        import threading as _th
+        stop = _th.Event()
+        hp_in = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True); hp_out = torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True)
+        dd_in = torch.empty(1 << 30, dtype=torch.uint8, device=dev); dd_out = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        moved = [0]
+
+        def pump():
+            s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            while not stop.is_set():
+                with torch.cuda.stream(s1):
+                    dd_in.copy_(hp_in, non_blocking=True)
+                with torch.cuda.stream(s2):
+                    hp_out.copy_(dd_out, non_blocking=True)
+                s1.synchronize(); s2.synchronize(); moved[0] += 2
+        noise = _th.Thread(target=pump); noise.start()
+
     # ---- the headline: device-resident steps, timed as the driver's contract says (barrier + synchronize on both sides, max over ranks)
     dt = rdist.timed_steps(dist, dev, step, args.steps, args.warmup, torch.cuda.synchronize)
+    if noise is not None:
+        stop.set(); noise.join()
+        print("bench: dma noise moved %d GiB during warm-up and timed steps" % moved[0], file=sys.stderr)
     kt = enc.kernel_times()          # HIP events of the last timed step, recorded on the launch streams
     flags = enc.error_flags()        # the device-pointer API only enqueues: this is where an overflow would show (raises)
 

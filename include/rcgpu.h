@@ -335,7 +335,8 @@ int  rcgpu_mkv_write_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, const uin
 int  rcgpu_mkv_expect(rcgpu_mkv* mux, uint64_t max_block_bytes, uint64_t max_blocks);
 int  rcgpu_mkv_reserve_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, size_t size, int keyframe, uint8_t** dst, uint64_t* file_offset);
 int  rcgpu_mkv_fill(rcgpu_mkv* mux, uint64_t file_offset, const uint8_t* data, size_t size);
-void rcgpu_mkv_prefault(rcgpu_mkv* mux, uint8_t* dst, size_t size);   /* optional, before copying to a *dst: maps the range in one call */
+void rcgpu_mkv_copy_in(rcgpu_mkv* mux, uint8_t* dst, const uint8_t* src, size_t size);   /* copies a payload to its *dst (any thread): waits for the
+                                     pages to exist, maps the range in one call, copies */
 /* Patches A_FLAC CodecPrivate written by begin() (same size) once STREAMINFO is final. */
 int  rcgpu_mkv_update_codec_private(rcgpu_mkv* mux, int track, const uint8_t* codec_private, size_t cp_size);
 /* Writes Cues, patches Segment size / SeekHead / Duration; closes the file. */

@@ -989,6 +989,51 @@ __global__ __launch_bounds__(256) void k_gather(const enc_const* __restrict__ C,
 constexpr uint32_t kMaxSeg = 64;
 constexpr uint32_t kSubBatch = 16;           // frames whose int32 planes rcgpu_ffv1_debug_fetch(0) returns (k_unpack on demand)
 
+// What an encoder of this configuration writes into its configuration record.
+static ffv1::stream_params stream_params_of(const rcgpu_ffv1_config& cfg)
+{
+    const pix_desc& d = pix(cfg.pixfmt);
+    ffv1::stream_params sp{};
+    sp.bits_per_raw_sample = d.bits; sp.rgb = d.planes != 1; sp.alpha = d.planes == 4;
+    sp.num_h_slices = cfg.num_h_slices; sp.num_v_slices = cfg.num_v_slices;
+    sp.ec = cfg.slicecrc ? 1 : 0; sp.context_model = cfg.context ? 1 : 0; sp.compact = cfg.context == 2; sp.coder = cfg.coder == 2 ? 2 : 1; sp.version = cfg.level == 1 ? 1 : 3;
+    return sp;
+}
+
+// Byte buffer of one slice: room for 1.5x its raw payload (incompressible 16-bit noise codes to ~1.1x once the contexts have adapted)
+// + what ~10^4 contexts x 32 states can cost before they have (tiny slices reach 1.7x), + header/footer.
+static size_t slice_buffer_bytes(const pix_desc& d, uint32_t w, uint32_t h, uint32_t version)
+{
+    const size_t raw15 = size_t(w) * h * (d.bytes_pp ? d.bytes_pp : d.planes * 2u) * 3 / 2;
+    size_t cap = (raw15 + std::min<size_t>(raw15, 256u << 10) + 4096 + 15) & ~size_t(15);
+    // test hook: slice buffers a fraction of their size, so that the overflow reporting can be exercised (tests/test_gpu_pipeline.py)
+    if (const char* t = getenv("RCGPU_TEST_CBUF_DIV")) if (atoi(t) > 1) cap = std::max<size_t>(64, (cap / size_t(atoi(t))) & ~size_t(15));
+    if (cap > 0xFFFFFF + 64 && version != 1) cap = 0xFFFFFF + 64;          // slice size field is 24 bit (version 1 has none)
+    return cap;
+}
+
+namespace rc {
+std::vector<uint8_t> ffv1_config_record_for(const rcgpu_ffv1_config& cfg)
+{
+    if (cfg.pixfmt >= RCGPU_PIX_COUNT || !cfg.num_h_slices || !cfg.num_v_slices) return {};
+    return ffv1::config_record(stream_params_of(cfg));
+}
+
+size_t ffv1_max_packet_bytes_for(const rcgpu_ffv1_config& cfg)
+{
+    if (cfg.pixfmt >= RCGPU_PIX_COUNT || !cfg.num_h_slices || !cfg.num_v_slices) return 0;
+    const pix_desc& d = pix(cfg.pixfmt);
+    size_t cb = 0;
+    for (uint32_t sy = 0; sy < cfg.num_v_slices; sy++)
+        for (uint32_t sx = 0; sx < cfg.num_h_slices; sx++) {
+            const uint32_t w = uint32_t(uint64_t(sx + 1) * cfg.width / cfg.num_h_slices) - uint32_t(uint64_t(sx) * cfg.width / cfg.num_h_slices);
+            const uint32_t h = uint32_t(uint64_t(sy + 1) * cfg.height / cfg.num_v_slices) - uint32_t(uint64_t(sy) * cfg.height / cfg.num_v_slices);
+            cb += 16 + slice_buffer_bytes(d, w, h, cfg.level == 1 ? 1 : 3);
+        }
+    return (cb + 15) & ~size_t(15);
+}
+}  // namespace rc
+
 struct rcgpu_ffv1 {
     rcgpu_ffv1_config cfg{};
     ffv1::stream_params sp{};
@@ -1091,9 +1136,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
 
     rcgpu_ffv1* e = new rcgpu_ffv1;
     e->cfg = *cfg;
-    e->sp.bits_per_raw_sample = d.bits; e->sp.rgb = d.planes != 1; e->sp.alpha = d.planes == 4;
-    e->sp.num_h_slices = cfg->num_h_slices; e->sp.num_v_slices = cfg->num_v_slices;
-    e->sp.ec = cfg->slicecrc ? 1 : 0; e->sp.context_model = cfg->context ? 1 : 0; e->sp.compact = cfg->context == 2; e->sp.coder = cfg->coder == 2 ? 2 : 1; e->sp.version = cfg->level == 1 ? 1 : 3;
+    e->sp = stream_params_of(*cfg);
     e->record = ffv1::config_record(e->sp);
 
     ffv1::quant_model qm[2];
@@ -1146,13 +1189,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             g.hdr_off = uint32_t(hdr.size()); g.hdr_n = uint32_t(hd.size());
             if (g.hdr_n > uint32_t(kStageEntries)) { delete e; return fail(2, "ffv1: %u header decisions do not fit k_resolve's stage", g.hdr_n); }
             for (uint16_t d16 : hd) hdr.push_back((d16 & 0x100) ? uint16_t(d16 & 0xFF) : uint16_t(0xFF00u | (256 - (d16 & 0xFF))));   // (state, bit) -> (t, c)
-            // room for 1.5x the raw payload of the slice (incompressible 16-bit noise codes to ~1.1x once the contexts have
-            // adapted) + what ~10^4 contexts x 32 states can cost before they have (tiny slices reach 1.7x), + header/footer
-            const size_t raw15 = size_t(g.w) * g.h * (d.bytes_pp ? d.bytes_pp : d.planes * 2u) * 3 / 2;
-            size_t cap = (raw15 + std::min<size_t>(raw15, 256u << 10) + 4096 + 15) & ~size_t(15);
-            // test hook: slice buffers a fraction of their size, so that the overflow reporting can be exercised (tests/test_gpu_pipeline.py)
-            if (const char* t = getenv("RCGPU_TEST_CBUF_DIV")) if (atoi(t) > 1) cap = std::max<size_t>(64, (cap / size_t(atoi(t))) & ~size_t(15));
-            if (cap > 0xFFFFFF + 64 && e->sp.version != 1) cap = 0xFFFFFF + 64;          // slice size field is 24 bit (version 1 has none)
+            const size_t cap = slice_buffer_bytes(d, g.w, g.h, e->sp.version);
             if (cap >= (size_t(1) << 31)) { delete e; return fail(2, "ffv1: a version 1 frame of %ux%u does not fit the coder's 31-bit byte positions", g.w, g.h); }
             cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here
             g.cbuf_off_lo = uint32_t(cb); g.cbuf_off_hi = uint32_t(uint64_t(cb) >> 32); g.cbuf_cap = uint32_t(cap);

@@ -3,6 +3,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 #include "rcgpu.h"
 
 namespace rc {
@@ -28,6 +29,10 @@ void ffv1_set_gather_wait(rcgpu_ffv1* e, void* hip_event);
 // the previous batch's downloads AFTER the next batch has been started: the device never waits for the host between two batches.
 void ffv1_set_defer_gather(rcgpu_ffv1* e, bool on);
 int  ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream);
+// The configuration record and the worst-case packet size of an encoder of this configuration, without a device (the container's header
+// can be written, and its file laid out, while the encoders are still being created).
+std::vector<uint8_t> ffv1_config_record_for(const rcgpu_ffv1_config& cfg);
+size_t ffv1_max_packet_bytes_for(const rcgpu_ffv1_config& cfg);
 // Text for the device error word (0 = none).
 const char* ffv1_error_flags_text(uint32_t flags);
 

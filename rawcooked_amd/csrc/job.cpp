@@ -7,6 +7,7 @@
 // muxer writes them in frame order.  No collective is involved: every frame is a key frame (-g 1).
 #include "rc_common.h"
 #include "pipeline.h"
+#include "ffv1_internal.h"
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
@@ -304,22 +305,12 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         if (level == 1) { if (v.num_h * v.num_v != 1) return bail(fail(2, "-level 1 (FFV1 version 1) has no slices: use -slices 1")); c.slicecrc = 0; }
         pvideos.push_back(pv);
     }
-    if (!videos.empty()) {
-        rc::pipe_options po;
-        po.device_first = dev0; po.device_count = ndev; po.trace = trace;
-        po.batch = uint32_t(std::max(0L, opt.num("rcgpu_batch", 0)));      // 0: sized from the device's free memory and the sequence
-        if (const char* e = getenv("RCGPU_BATCH")) if (!po.batch) po.batch = uint32_t(std::max(0, atoi(e)));
-        if (const char* e = getenv("RCGPU_LANES")) po.lanes_per_device = uint32_t(std::max(1, atoi(e)));
-        if (const char* e = getenv("RCGPU_READERS")) po.readers = uint32_t(std::max(1, atoi(e)));
-        if (const char* e = getenv("RCGPU_WRITERS")) po.writers = uint32_t(std::max(1, atoi(e)));
-        if (int r = pl.prepare(pvideos, po)) return bail(r);
-    }
     for (auto& o : order) {
         if (o.first) {
             video_plan& v = videos[o.second];
-            uint8_t rec[4096];
-            const size_t n = rcgpu_ffv1_config_record(pl.encoder(uint32_t(o.second)), rec, sizeof rec);
-            v.track = rcgpu_mkv_add_video(mux, rec, n, v.info.width, v.info.height, v.fps.num, v.fps.den);
+            // the record depends on the configuration only: the header is written, and the file laid out, before the encoders exist
+            const std::vector<uint8_t> rec = rc::ffv1_config_record_for(pvideos[o.second].cfg);
+            v.track = rcgpu_mkv_add_video(mux, rec.data(), rec.size(), v.info.width, v.info.height, v.fps.num, v.fps.den);
             if (v.track < 0) return bail(8);
             if (const char* md = opt.get("metadata:s:v")) {
                 const std::string kv = md; const size_t eq = kv.find('=');
@@ -343,8 +334,33 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     if (job->reversibility_path)
         if (int r = attach(job->reversibility_path, "RAWcooked reversibility data")) return bail(r);
     if (int r = rcgpu_mkv_begin(mux)) return bail(r);
-
-    mark("encoders created, header written");
+    mark("header written");
+    uint64_t max_bytes = 0, n_blocks = 0;
+    for (size_t vi = 0; vi < videos.size(); vi++) {
+        max_bytes += uint64_t(videos[vi].files.size()) * rc::ffv1_max_packet_bytes_for(pvideos[vi].cfg);
+        n_blocks += videos[vi].files.size();
+    }
+    for (const audio_plan& a : audios) for (uint32_t fs : a.frame_sizes) max_bytes += fs + 32;
+    // on tmpfs the muxer now starts allocating the file's pages -- while the encoders (170 GB of device buffers: seconds) come up
+    if (!videos.empty()) if (int r = rcgpu_mkv_expect(mux, max_bytes, n_blocks)) return bail(r);
+    if (!videos.empty()) {
+        rc::pipe_options po;
+        po.device_first = dev0; po.device_count = ndev; po.trace = trace;
+        po.batch = uint32_t(std::max(0L, opt.num("rcgpu_batch", 0)));      // 0: sized from the device's free memory and the sequence
+        if (const char* e = getenv("RCGPU_BATCH")) if (!po.batch) po.batch = uint32_t(std::max(0, atoi(e)));
+        if (const char* e = getenv("RCGPU_LANES")) po.lanes_per_device = uint32_t(std::max(1, atoi(e)));
+        if (const char* e = getenv("RCGPU_READERS")) po.readers = uint32_t(std::max(1, atoi(e)));
+        if (const char* e = getenv("RCGPU_WRITERS")) po.writers = uint32_t(std::max(1, atoi(e)));
+        if (int r = pl.prepare(pvideos, po)) return bail(r);
+        for (size_t vi = 0; vi < videos.size(); vi++) {          // what was promised to the container is what the encoders do
+            uint8_t rec[4096];
+            const size_t n = rcgpu_ffv1_config_record(pl.encoder(uint32_t(vi)), rec, sizeof rec);
+            const std::vector<uint8_t> want = rc::ffv1_config_record_for(pvideos[vi].cfg);
+            if (n != want.size() || memcmp(rec, want.data(), n) != 0 || rcgpu_ffv1_max_packet_bytes(pl.encoder(uint32_t(vi))) > rc::ffv1_max_packet_bytes_for(pvideos[vi].cfg))
+                return bail(fail(100, "internal: the encoder's configuration record differs from the one in the container header"));
+        }
+    }
+    mark("encoders created");
     // ---- blocks, in timestamp order: audio frames are interleaved in front of the video frame they precede
     std::vector<size_t> audio_pos(audios.size(), 0), audio_off(audios.size(), 0);
     auto write_audio_until = [&](uint64_t pts_ns_limit) -> int {
@@ -364,16 +380,10 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         // frames of all picture sequences in timestamp order, so that tracks interleave in the file; the pipeline cuts them into
         // batches, shards the batches over the devices and returns the packets in this order
         std::vector<rc::pipe_frame> frames;
-        uint64_t max_bytes = 0;
-        for (size_t vi = 0; vi < videos.size(); vi++) {
+        for (size_t vi = 0; vi < videos.size(); vi++)
             for (size_t i = 0; i < videos[vi].files.size(); i++) frames.push_back({ uint32_t(vi), i });
-            max_bytes += uint64_t(videos[vi].files.size()) * rcgpu_ffv1_max_packet_bytes(pl.encoder(uint32_t(vi)));
-        }
         auto pts_of = [&](const rc::pipe_frame& f) { const video_plan& v = videos[f.video]; return uint64_t(f.index) * v.fps.den * 1000000000ull / v.fps.num; };
         if (videos.size() > 1) std::stable_sort(frames.begin(), frames.end(), [&](const rc::pipe_frame& a, const rc::pipe_frame& b) { return pts_of(a) < pts_of(b); });
-        uint64_t audio_bytes = 0;
-        for (const audio_plan& a : audios) for (uint32_t fs : a.frame_sizes) audio_bytes += fs + 32;
-        if (int r = rcgpu_mkv_expect(mux, max_bytes + audio_bytes, frames.size())) return bail(r);
         std::vector<std::vector<uint64_t>> block_off(videos.size());
         std::vector<std::vector<uint8_t*>> block_dst(videos.size());
         for (size_t vi = 0; vi < videos.size(); vi++) { block_off[vi].assign(videos[vi].files.size(), 0); block_dst[vi].assign(videos[vi].files.size(), nullptr); }
@@ -402,7 +412,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             block_off[f.video][size_t(f.index)] = off; block_dst[f.video][size_t(f.index)] = dst;
             return dst;
         };
-        io.before_copy = [&](uint8_t* dst, size_t size) { rcgpu_mkv_prefault(mux, dst, size); };
+        io.copy = [&](uint8_t* dst, const uint8_t* src, size_t size) { rcgpu_mkv_copy_in(mux, dst, src, size); };
         io.done = [&](const rc::pipe_frame& f, const uint8_t* data, size_t size) -> int {
             if (block_dst[f.video][size_t(f.index)]) return 0;                   // a writer thread copied it into the mapped file
             return rcgpu_mkv_fill(mux, block_off[f.video][size_t(f.index)], data, size);

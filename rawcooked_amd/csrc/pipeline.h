@@ -33,8 +33,8 @@ struct pipe_io {
     std::function<uint8_t*(const pipe_frame& f, size_t size)> place;
     // writer threads, concurrently: the packet is at `data` (== the place, or a pinned buffer valid during the call).  0 = ok.
     std::function<int(const pipe_frame& f, const uint8_t* data, size_t size)> done;
-    // optional, writer threads: called with the place right before the packet is copied there (e.g. to pre-fault a mapped file range)
-    std::function<void(uint8_t* dst, size_t size)> before_copy;
+    // optional, writer threads: how a packet gets to its place (default: memcpy); a mapped file wants its range pre-faulted first
+    std::function<void(uint8_t* dst, const uint8_t* src, size_t size)> copy;
     // optional, lane thread, after a batch has run and while its payloads are still on the device (e.g. frame checksums).
     // Setting it serialises upload and encoding of consecutive batches.
     std::function<int(uint32_t video, rcgpu_ffv1* enc, uint64_t first_index, uint32_t n)> after_batch;

@@ -483,7 +483,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (hipEventSynchronize(o.ev) != hipSuccess) r = fail(100, "pipeline: a download failed");
             if (!r) {
                 if (!first_seen.exchange(true)) first_packet_seconds = since(t0);
-                if (o.dst) { if (io.before_copy) io.before_copy(o.dst, o.size); memcpy(o.dst, o.src, o.size); }
+                if (o.dst) { if (io.copy) io.copy(o.dst, o.src, o.size); else memcpy(o.dst, o.src, o.size); }
                 if (io.done) r = io.done(frames[o.frame], o.dst ? o.dst : o.src, o.size);
                 packet_bytes += o.size;
             }

@@ -123,8 +123,7 @@ def _muxer_paths(work, mode):
     def fill(part):
         for dst, off, pk in part:
             if dst:
-                L.rcgpu_mkv_prefault(mux.h, dst, len(pk))
-                C.memmove(dst, pk, len(pk))
+                L.rcgpu_mkv_copy_in(mux.h, dst, pk, len(pk))
             else:
                 assert L.rcgpu_mkv_fill(mux.h, off, pk, len(pk)) == 0
     ths = [threading.Thread(target=fill, args=(jobs[k::3],)) for k in range(3)]
