@@ -260,6 +260,7 @@ def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barr
             "steady_frames_per_second": round(st.steady_frames_per_second, 2),
             "reads_done_seconds": round(st.reads_done_seconds, 3), "last_batch_seconds": round(st.last_batch_seconds, 3),
             "upload_wait_seconds": round(st.upload_wait_seconds, 3), "h2d_span_seconds": round(st.h2d_span_seconds, 3),
+            "read_call_ms": round(st.read_call_seconds * 1e3, 2), "write_call_ms": round(st.write_call_seconds * 1e3, 2),
             "packets_identical_to_device_resident_run": (not bad) if check_until else None,
             "source": f"ring of {R} distinct frames in pageable host memory, reused", "_local": (n_frames, st.seconds, dt)}, (not bad)
 
@@ -315,6 +316,16 @@ def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packet0):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def bind_to_numa_node(node: int) -> None:
+    """Experiment: keep this process (and every thread the library starts) on the cores of one NUMA node, so that first-touch places
+    pinned and pageable buffers there."""
+    cpus = set()
+    for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+        a, _, b = part.partition("-")
+        cpus |= set(range(int(a), int(b or a) + 1))
+    os.sched_setaffinity(0, cpus)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,6 +353,8 @@ def main():
     ap.add_argument("--mode", default="encode", choices=["encode", "check"],
                     help="check: BASELINE config 5 alone -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
+    if os.environ.get("RCGPU_NUMA_NODE"):
+        bind_to_numa_node(int(os.environ["RCGPU_NUMA_NODE"]))
     legs = {x for x in args.legs.split(",") if x}
     if args.no_cpu_baseline:
         legs.discard("cpu")

@@ -217,6 +217,7 @@ typedef struct {
     double   reads_done_seconds, last_batch_seconds;
     double   upload_wait_seconds;       /* device 0: time its host thread waited for the readers */
     double   h2d_span_seconds;          /* device 0: sum over batches of first upload start .. last upload end */
+    double   read_call_seconds, write_call_seconds;   /* average duration of one read_frame call / one packet copy + packet_done call */
 } rcgpu_sequence_stats;
 /* record/record_size: optional, the FFV1 configuration record (Matroska CodecPrivate), *record_size = capacity in, size out. */
 int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, const rcgpu_sequence_io* io,

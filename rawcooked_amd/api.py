@@ -56,7 +56,7 @@ class SequenceStats(C.Structure):
                 ("frames", C.c_uint64), ("payload_bytes", C.c_uint64), ("packet_bytes", C.c_uint64), ("batches", C.c_uint64),
                 ("batch_frames", C.c_uint32), ("devices", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
                 ("steady_frames_per_second", C.c_double), ("reads_done_seconds", C.c_double), ("last_batch_seconds", C.c_double),
-                ("upload_wait_seconds", C.c_double), ("h2d_span_seconds", C.c_double)]
+                ("upload_wait_seconds", C.c_double), ("h2d_span_seconds", C.c_double), ("read_call_seconds", C.c_double), ("write_call_seconds", C.c_double)]
 
 
 class FlacConfig(C.Structure):

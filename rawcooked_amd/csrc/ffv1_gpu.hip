@@ -1067,6 +1067,7 @@ struct rcgpu_ffv1 {
     std::vector<hipEvent_t> ev;                    // pairs, in launch order
     std::vector<int> ev_kernel;                    // kernel index of each pair
     size_t ev_used = 0;
+    std::vector<hipEvent_t> ev_prev; std::vector<int> ev_kernel_prev; size_t ev_used_prev = 0;   // the call before: still readable while the next batch runs
     hipEvent_t ev_k3[kMaxSeg]{}, ev_k4[kMaxSeg]{}, ev_fork = nullptr;
     bool ev_valid = false;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
@@ -1097,6 +1098,7 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
     void* hosts[] = { e->h_psizes, e->h_ndec_pinned, e->h_frame_ptrs, e->h_total_n, e->h_seg_pieces, e->h_group_off, e->h_err };
     for (void* h : hosts) if (h) (void)hipHostFree(h);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_prev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_k3) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_k4) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -1222,6 +1224,8 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->rc_stream, hipStreamNonBlocking);
     e->ev.resize(2 * (6 + 2 * nseg));              // timing events: k_model, footer, scan, gather + two kernels per segment
     for (auto& ev : e->ev) if (he == hipSuccess) he = hipEventCreate(&ev);
+    e->ev_prev.resize(e->ev.size());
+    for (auto& ev : e->ev_prev) if (he == hipSuccess) he = hipEventCreate(&ev);
     for (uint32_t j = 0; j < nseg; j++) {
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k3[j], hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k4[j], hipEventDisableTiming);
@@ -1261,6 +1265,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     hipStream_t s2 = e->rc_stream;
     const enc_const& c = e->hc;
     const uint32_t S = c.S, nchains = n * S, ngroups = (nchains + 63) / 64, nseg = e->nseg;
+    std::swap(e->ev, e->ev_prev); std::swap(e->ev_kernel, e->ev_kernel_prev); e->ev_used_prev = e->ev_used;      // timing events alternate between two sets
     e->ev_used = 0; e->ev_kernel.clear();
     auto timed = [&](int kernel, hipStream_t stream, auto&& launch) -> hipError_t {
         if (e->ev_used + 2 > e->ev.size()) { launch(); return hipGetLastError(); }
@@ -1390,6 +1395,23 @@ extern "C" int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* e, const char** na
     }
     return k;
 }
+
+namespace rc {
+// The same for the call BEFORE the last one (the pipeline starts batch k+1 before batch k has finished).
+int ffv1_prev_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap)
+{
+    if (!e || !e->ev_used_prev) return 0;
+    int k = 0;
+    for (; k < rcgpu_ffv1::kNumK && k < cap; k++) { names[k] = kKernelNames[k]; ms[k] = 0; }
+    for (size_t i = 0; i < e->ev_kernel_prev.size() && 2 * i + 1 < e->ev_used_prev; i++) {
+        float t = 0;
+        if (hipEventSynchronize(e->ev_prev[2 * i + 1]) != hipSuccess) continue;
+        (void)hipEventElapsedTime(&t, e->ev_prev[2 * i], e->ev_prev[2 * i + 1]);
+        if (e->ev_kernel_prev[i] < k) ms[e->ev_kernel_prev[i]] += t;
+    }
+    return k;
+}
+}  // namespace rc
 
 // launches of kernel `index` in the last encode call (k_resolve / k_rangecode run once per segment)
 extern "C" int rcgpu_ffv1_last_kernel_launches(const rcgpu_ffv1* e, int index)

@@ -33,6 +33,8 @@ int  ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip
 // can be written, and its file laid out, while the encoders are still being created).
 std::vector<uint8_t> ffv1_config_record_for(const rcgpu_ffv1_config& cfg);
 size_t ffv1_max_packet_bytes_for(const rcgpu_ffv1_config& cfg);
+// Per-kernel device time of the call before the last one (see rcgpu_ffv1_last_kernel_times).
+int  ffv1_prev_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap);
 // Text for the device error word (0 = none).
 const char* ffv1_error_flags_text(uint32_t flags);
 

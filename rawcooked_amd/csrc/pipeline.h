@@ -58,6 +58,7 @@ struct pipe_stats {
     double steady_frames_per_second = 0;        // frames of all batches but the first / time from the first batch's completion to the last's
     double reads_done_seconds = 0, last_batch_seconds = 0;
     double upload_wait_seconds = 0;             // lane 0: time its thread waited for the readers to fill a slot
+    double read_call_seconds = 0, write_call_seconds = 0;   // average duration of one read callback / one packet copy + done callback
     double h2d_span_seconds = 0;                // lane 0: sum over batches of first upload start .. last upload end (device clock)
 };
 

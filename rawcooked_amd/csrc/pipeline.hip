@@ -20,10 +20,13 @@ namespace {
 using clk = std::chrono::steady_clock;
 double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
 
+constexpr size_t kUploadGroup = 8, kDownloadGroup = 16;       // copies per completion event
+
 struct batch_t { uint32_t video; size_t first, n; int lane; };       // frames[first .. first+n) of the output order
 
 struct out_entry {            // one packet on its way down
     size_t frame = 0; uint8_t* src = nullptr; size_t size = 0; int chunk = -1; hipEvent_t ev = nullptr; int device = 0, lane = 0;
+    int* ev_users = nullptr;      // the event is shared by a group of packets: the last one done with it returns it
     uint8_t* dst = nullptr;
 };
 
@@ -34,12 +37,12 @@ struct lane_t {
     std::vector<hipEvent_t> dl_done;              // per video: the download of the last batch out of that encoder's d_packets
     std::vector<bool> dl_valid;
     hipEvent_t ev_up = nullptr, ev_up0 = nullptr, ev_done[2] = { nullptr, nullptr };     // ev_up0 / ev_up time the uploads of a batch
-    double upload_wait = 0, h2d_span = 0;
+    double upload_wait = 0, h2d_span = 0, copy_calls = 0, dl_calls = 0, dl_wait = 0;
     // download ring: pinned chunks, a chunk is re-entered when nothing in it is outstanding
     std::vector<uint8_t*> chunks; std::vector<int> outstanding; size_t chunk_bytes = 0, max_chunks = 0; int cur = -1; size_t cur_off = 0;
     std::deque<out_entry> outq;                   // issued downloads in frame order, consumed by the placer
     std::vector<hipEvent_t> free_events;
-    struct pending_up { uint8_t* slot; hipEvent_t ev; };
+    struct pending_up { std::vector<uint8_t*> slots; hipEvent_t ev; };     // a group of copies and the event recorded behind the last of them
     std::deque<pending_up> pending;                // uploads in flight, in issue order: their slots return to the pool once the copy is done
     uint64_t* h_sizes = nullptr; uint32_t* h_err = nullptr; size_t h_sizes_stride = 0;     // pinned, two batches' worth
 };
@@ -57,7 +60,11 @@ struct pipeline::impl {
     double prepare_seconds = 0;
 
     // ---- run state (one big lock: events here are per frame, a few thousand per second)
-    std::mutex m; std::condition_variable cv;
+    std::mutex m;
+    // one condition per kind of waiter (a single one woke ~20 threads for every frame event)
+    std::condition_variable cv_slots /* readers: a free upload slot */, cv_ready /* lanes: a frame was read */, cv_ring /* lanes: ring space, chunks */,
+                            cv_out /* placer: a download was issued */, cv_jobs /* writers: a packet was placed */;
+    void wake_all() { cv_slots.notify_all(); cv_ready.notify_all(); cv_ring.notify_all(); cv_out.notify_all(); cv_jobs.notify_all(); }
     int error = 0; std::string error_msg;
     std::vector<uint8_t*> all_slots, free_slots; size_t slots_wanted = 0;
     std::vector<uint8_t*> ready;                  // per output frame: the filled slot (nullptr until read)
@@ -70,7 +77,7 @@ struct pipeline::impl {
     {
         std::lock_guard<std::mutex> l(m);
         if (!error) { error = code ? code : 1; error_msg = msg ? msg : ""; }
-        cv.notify_all();
+        wake_all();
     }
     bool failed() { std::lock_guard<std::mutex> l(m); return error != 0; }
     ~impl();
@@ -170,7 +177,15 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
             if (int r = ffv1_staging(e, &sg)) return r;
             s.payload[vi] = sg.payload_bytes; s.max_packet[vi] = sg.packet_stride;
         }
-        if (hipStreamCreateWithFlags(&L.cin, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&L.cout, hipStreamNonBlocking) != hipSuccess)
+        // The two copy streams get priorities of their own.  Events and stream waits are barrier packets in a stream's HARDWARE queue, the
+        // runtime has four of those per priority level, and streams of one level share them: with both copy streams at the default level
+        // the uploads' barriers stood in one queue behind the downloads' -- measured: not one upload of batch k+1 completed before the last
+        // download of batch k-1 had (0.33 s per batch).  A level per copy stream keeps their barriers apart from each other and from the
+        // encoder's two compute streams.
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        if (hipStreamCreateWithPriority(&L.cin, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&L.cout, hipStreamNonBlocking, prio_least) != hipSuccess)
             return fail(100, "pipeline: cannot create copy streams");
         L.dl_done.assign(videos.size(), nullptr); L.dl_valid.assign(videos.size(), false);
         for (auto& e : L.dl_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(100, "pipeline: cannot create events");
@@ -224,7 +239,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         uint64_t total_need = 0; for (const batch_t& b : batches) if (b.lane == L.id) total_need += uint64_t(b.n) * s.max_packet[b.video];
         want = std::min<uint64_t>(want, std::max<uint64_t>(total_need, L.chunk_bytes));
         L.max_chunks = std::max<size_t>(2, size_t((want + L.chunk_bytes - 1) / L.chunk_bytes));
-        L.cur = -1; L.cur_off = 0; L.outq.clear(); L.upload_wait = 0; L.h2d_span = 0;
+        L.cur = -1; L.cur_off = 0; L.outq.clear(); L.upload_wait = 0; L.h2d_span = 0; L.copy_calls = L.dl_calls = L.dl_wait = 0;
         std::fill(L.dl_valid.begin(), L.dl_valid.end(), false);
     }
     s.ready.assign(N, nullptr); s.jobs.clear(); for (lane_t& L : s.lanes) L.pending.clear(); s.placer_finished = false; s.next_read = 0; s.alloc_done = false;
@@ -233,6 +248,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     std::vector<double> batch_done(batches.size(), 0.0);
     double reads_done = 0;
     std::atomic<uint64_t> packet_bytes{ 0 };
+    std::atomic<double> read_busy{ 0.0 }, write_busy{ 0.0 };
     std::atomic<bool> first_seen{ false }; double first_packet_seconds = 0;
     double busy0 = 0;
     const bool trace = s.opt.trace;
@@ -256,7 +272,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 } else {
                     std::lock_guard<std::mutex> l(s.m);
                     s.all_slots.push_back(ptr); s.free_slots.push_back(ptr); have++;
-                    s.cv.notify_all();
+                    s.cv_slots.notify_one();
                 }
                 more = true;
             }
@@ -272,16 +288,16 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                     std::lock_guard<std::mutex> l(s.m);
                     if (L.chunks.size() < 2) { s.error = 100; s.error_msg = "pipeline: cannot allocate the pinned download ring"; }
                     L.max_chunks = L.chunks.size();
-                    s.cv.notify_all();
+                    s.wake_all();
                 } else {
                     std::lock_guard<std::mutex> l(s.m);
                     L.chunks.push_back(ptr); L.outstanding.push_back(0);
-                    s.cv.notify_all();
+                    s.cv_ring.notify_all();
                 }
                 more = true;
             }
         }
-        { std::lock_guard<std::mutex> l(s.m); s.alloc_done = true; s.cv.notify_all(); }
+        { std::lock_guard<std::mutex> l(s.m); s.alloc_done = true; s.wake_all(); }
     });
 
     // uploads whose copy has completed give their slot back; called with the lock held.  Copies of one lane complete in order, so only
@@ -295,7 +311,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         for (lane_t& L : s.lanes)
             while (!L.pending.empty()) {
                 if (hipEventQuery(L.pending.front().ev) != hipSuccess) break;
-                s.free_slots.push_back(L.pending.front().slot);
+                for (uint8_t* sl : L.pending.front().slots) s.free_slots.push_back(sl);
                 L.free_events.push_back(L.pending.front().ev);
                 L.pending.pop_front();
             }
@@ -316,12 +332,14 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                     if (s.next_read >= N) { if (!reads_done) reads_done = since(t0); return; }
                     reap();
                     if (!s.free_slots.empty()) { slot = s.free_slots.back(); s.free_slots.pop_back(); i = s.next_read++; break; }
-                    s.cv.wait_for(l, std::chrono::microseconds(200));
+                    s.cv_slots.wait_for(l, std::chrono::microseconds(200));
                 }
             }
+            const auto tr = clk::now();
             if (int r = io.read(frames[i], slot)) { s.set_error(r, rcgpu_last_error()); return; }
+            { const double d = since(tr); double cur = read_busy.load(); while (!read_busy.compare_exchange_weak(cur, cur + d)) {} }
             { std::lock_guard<std::mutex> l(s.m); s.ready[i] = slot; }
-            s.cv.notify_all();
+            s.cv_ready.notify_all();
         }
     };
 
@@ -338,25 +356,35 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return nullptr;
             return e;
         };
-        auto issue_uploads = [&](const batch_t& B) -> bool {
-            enc_staging sg; if (ffv1_staging(L.enc[B.video], &sg)) { s.set_error(100, rcgpu_last_error()); return false; }
-            for (size_t k = 0; k < B.n; k++) {
-                uint8_t* slot = nullptr;
-                {
-                    const auto tw = clk::now();
-                    std::unique_lock<std::mutex> l(s.m);
-                    s.cv.wait(l, [&] { return s.error || s.ready[B.first + k]; });
-                    if (s.error) return false;
-                    slot = s.ready[B.first + k];
-                    L.upload_wait += since(tw);
-                }
-                if (k == 0 && !hip_ok(hipEventRecord(L.ev_up0, L.cin), "hipEventRecord")) return false;
-                if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, slot, sg.payload_bytes, hipMemcpyHostToDevice, L.cin), "upload")) return false;
+        // ---- transfers.  Uploads of one batch and downloads of another are issued by ONE loop, a copy of each per turn: a whole batch of
+        // downloads queued at once kept every upload issued after it waiting until the last download had finished (measured: 0.33 s
+        // per batch in which the device-to-host direction ran at 48 GB/s and the host-to-device direction stood still), although the two
+        // directions overlap perfectly when their copies are issued side by side (tools/probe_dma.py).
+        std::vector<uint8_t*> ugroup;
+        // a group must never hold so much of the pool (or of the ring) that what it waits for cannot happen before its event is recorded
+        const size_t ugroup_max = std::max<size_t>(1, std::min<size_t>(kUploadGroup, s.slots_wanted / 4));
+        const size_t dgroup_max = std::max<size_t>(1, std::min<size_t>(kDownloadGroup, L.max_chunks * (L.chunk_bytes / std::max<size_t>(1, (max_pkt + 4095) & ~size_t(4095))) / 4));
+        auto upload_one = [&](const batch_t& B, const enc_staging& sg, size_t k) -> bool {
+            uint8_t* slot = nullptr;
+            {
+                const auto tw = clk::now();
+                std::unique_lock<std::mutex> l(s.m);
+                s.cv_ready.wait(l, [&] { return s.error || s.ready[B.first + k]; });
+                if (s.error) return false;
+                slot = s.ready[B.first + k];
+                L.upload_wait += since(tw);
+            }
+            const auto tc = clk::now();
+            if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, slot, sg.payload_bytes, hipMemcpyHostToDevice, L.cin), "upload")) return false;
+            ugroup.push_back(slot);                          // one completion event per group of copies: an event is a barrier packet
+            if (ugroup.size() >= ugroup_max || k + 1 == B.n) {
                 hipEvent_t ev = get_event();
                 if (!ev || !hip_ok(hipEventRecord(ev, L.cin), "hipEventRecord")) return false;
-                { std::lock_guard<std::mutex> l(s.m); L.pending.push_back({ slot, ev }); }
+                { std::lock_guard<std::mutex> l(s.m); L.pending.push_back({ ugroup, ev }); }
+                ugroup.clear();
             }
-            return hip_ok(hipEventRecord(L.ev_up, L.cin), "hipEventRecord");
+            L.copy_calls += since(tc);
+            return true;
         };
         auto ring_alloc = [&](size_t size, int& chunk) -> uint8_t* {
             const size_t need = (size + 4095) & ~size_t(4095);
@@ -371,7 +399,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 int pick = -1;
                 for (int k = 1; k <= nc && pick < 0; k++) { const int c = (L.cur + k) % nc; if (c != L.cur && L.outstanding[size_t(c)] == 0) pick = c; }
                 if (pick >= 0) { L.cur = pick; L.cur_off = 0; continue; }
-                s.cv.wait_for(l, std::chrono::milliseconds(1));
+                s.cv_ring.wait_for(l, std::chrono::milliseconds(1));
             }
             chunk = L.cur;
             uint8_t* ptr = L.chunks[size_t(L.cur)] + L.cur_off;
@@ -385,7 +413,6 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             enc_staging sg; if (ffv1_staging(enc, &sg)) { s.set_error(100, rcgpu_last_error()); return false; }
             hipStream_t st = static_cast<hipStream_t>(sg.compute_stream);
             if (!hip_ok(hipStreamWaitEvent(st, L.ev_up, 0), "hipStreamWaitEvent")) return false;
-            { float ms = 0; if (hipEventSynchronize(L.ev_up) == hipSuccess && hipEventElapsedTime(&ms, L.ev_up0, L.ev_up) == hipSuccess) L.h2d_span += ms * 1e-3; }
             ffv1_set_defer_gather(enc, true);
             std::vector<const void*> ptrs(B.n);
             for (size_t i = 0; i < B.n; i++) ptrs[i] = sg.d_in + i * sg.in_stride;
@@ -402,48 +429,82 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                    hip_ok(hipMemcpyAsync(L.h_err + 4 * par, sg.d_err, 16, hipMemcpyDeviceToHost, st), "flags") &&
                    hip_ok(hipEventRecord(L.ev_done[par], st), "hipEventRecord");
         };
-        auto download_batch = [&](const batch_t& B, int par) -> bool {
-            enc_staging sg; if (ffv1_staging(L.enc[B.video], &sg)) { s.set_error(100, rcgpu_last_error()); return false; }
-            const uint32_t* err = L.h_err + 4 * par;
-            if (err[0]) { char t[256]; snprintf(t, sizeof t, "ffv1: %s (flags %u)", ffv1_error_flags_text(err[0]), err[0]); s.set_error(102, t); return false; }
+        std::vector<out_entry> dgroup;
+        auto download_one = [&](const batch_t& B, const enc_staging& sg, int par, size_t i) -> bool {
             const uint64_t* sizes = L.h_sizes + size_t(par) * L.h_sizes_stride;
-            if (!hip_ok(hipStreamWaitEvent(L.cout, L.ev_done[par], 0), "hipStreamWaitEvent")) return false;
-            for (size_t i = 0; i < B.n; i++) {
-                out_entry o; o.frame = B.first + i; o.size = size_t(sizes[i]); o.device = L.device; o.lane = L.id;
-                if (!o.size || o.size > sg.packet_stride) { s.set_error(102, "ffv1: the device returned an impossible packet size"); return false; }
-                o.src = ring_alloc(o.size, o.chunk);
-                if (!o.src) return false;
-                if (!hip_ok(hipMemcpyAsync(o.src, sg.d_packets + i * sg.packet_stride, o.size, hipMemcpyDeviceToHost, L.cout), "download")) return false;
-                o.ev = get_event();
-                if (!o.ev || !hip_ok(hipEventRecord(o.ev, L.cout), "hipEventRecord")) return false;
-                { std::lock_guard<std::mutex> l(s.m); L.outq.push_back(o); }
-                s.cv.notify_all();
+            out_entry o; o.frame = B.first + i; o.size = size_t(sizes[i]); o.device = L.device; o.lane = L.id;
+            if (!o.size || o.size > sg.packet_stride) { s.set_error(102, "ffv1: the device returned an impossible packet size"); return false; }
+            const auto tw = clk::now();
+            o.src = ring_alloc(o.size, o.chunk);
+            if (!o.src) return false;
+            const auto tc = clk::now();
+            L.dl_wait += std::chrono::duration<double>(tc - tw).count();
+            if (!hip_ok(hipMemcpyAsync(o.src, sg.d_packets + i * sg.packet_stride, o.size, hipMemcpyDeviceToHost, L.cout), "download")) return false;
+            L.dl_calls += since(tc);
+            dgroup.push_back(o);
+            if (dgroup.size() >= dgroup_max || i + 1 == B.n) {       // the group becomes visible once its event is recorded
+                hipEvent_t ev = get_event();
+                if (!ev || !hip_ok(hipEventRecord(ev, L.cout), "hipEventRecord")) return false;
+                int* users = new int(int(dgroup.size()));
+                { std::lock_guard<std::mutex> l(s.m); for (out_entry& g : dgroup) { g.ev = ev; g.ev_users = users; L.outq.push_back(g); } }
+                dgroup.clear();
+                s.cv_out.notify_one();
             }
-            if (!hip_ok(hipEventRecord(L.dl_done[B.video], L.cout), "hipEventRecord")) return false;
-            L.dl_valid[B.video] = true;
+            return true;
+        };
+        // downloads of batch D (complete on the device, sizes and flags on the host) and uploads of batch U, either may be absent
+        auto transfers = [&](const batch_t* D, int par, const batch_t* U) -> bool {
+            enc_staging sd{}, su{};
+            if (D) {
+                if (ffv1_staging(L.enc[D->video], &sd)) { s.set_error(100, rcgpu_last_error()); return false; }
+                const uint32_t* err = L.h_err + 4 * par;
+                if (err[0]) { char t[256]; snprintf(t, sizeof t, "ffv1: %s (flags %u)", ffv1_error_flags_text(err[0]), err[0]); s.set_error(102, t); return false; }
+                if (!hip_ok(hipStreamWaitEvent(L.cout, L.ev_done[par], 0), "hipStreamWaitEvent")) return false;
+            }
+            if (U && ffv1_staging(L.enc[U->video], &su)) { s.set_error(100, rcgpu_last_error()); return false; }
+            const auto tu = clk::now();
+            const size_t nd = D ? D->n : 0, nu = U ? U->n : 0;
+            for (size_t i = 0; i < std::max(nd, nu); i++) {
+                if (i < nd && !download_one(*D, sd, par, i)) return false;
+                if (i < nu && !upload_one(*U, su, i)) return false;
+            }
+            if (D) {
+                if (!hip_ok(hipEventRecord(L.dl_done[D->video], L.cout), "hipEventRecord")) return false;
+                L.dl_valid[D->video] = true;
+            }
+            if (U && !hip_ok(hipEventRecord(L.ev_up, L.cin), "hipEventRecord")) return false;
+            if (trace && L.id == 0) { char b[160]; snprintf(b, sizeof b, "transfers issued in %.3f s: %zu downloads, %zu uploads", since(tu), nd, nu); mark(b); }
             return true;
         };
         if (mine.empty()) return;
         const bool serial = bool(io.after_batch);
-        if (!issue_uploads(batches[mine[0]]) || !start_batch(batches[mine[0]])) return;
+        if (!transfers(nullptr, 0, &batches[mine[0]]) || !start_batch(batches[mine[0]])) return;
+        if (!serial && mine.size() > 1 && !transfers(nullptr, 0, &batches[mine[1]])) return;      // d_in is free: k_model(0) has run
         for (size_t k = 0; k < mine.size(); k++) {
             const batch_t& B = batches[mine[k]];
             const int par = int(k & 1);
             const bool more = k + 1 < mine.size();
-            if (trace && L.id == 0) mark("modelled:", long(mine[k]));
+            // here: batch k is modelled and running, the uploads of batch k+1 are issued (not in serial mode)
             if (serial) {      // the hook wants the payloads on the device: nothing may overwrite them before it has run
                 if (!finish_batch(B, par) || !hip_ok(hipEventSynchronize(L.ev_done[par]), "batch")) return;
                 if (int r = io.after_batch(B.video, L.enc[B.video], frames[B.first].index, uint32_t(B.n))) { s.set_error(r, rcgpu_last_error()); return; }
-                if (more && !issue_uploads(batches[mine[k + 1]])) return;
-            } else {
-                if (more && !issue_uploads(batches[mine[k + 1]])) return;     // d_in is free: k_model(k) has run
-                if (!finish_batch(B, par)) return;
-            }
+                if (more && !transfers(nullptr, 0, &batches[mine[k + 1]])) return;
+            } else if (!finish_batch(B, par)) return;
             if (more && !start_batch(batches[mine[k + 1]])) return;           // returns after k_model(k+1), which follows batch k on the stream
             if (!hip_ok(hipEventSynchronize(L.ev_done[par]), "batch")) return;
             batch_done[mine[k]] = since(t0);
-            if (trace && L.id == 0) mark("batch complete:", long(mine[k]));
-            if (!download_batch(B, par)) return;
+            if (trace && L.id == 0) {      // this batch's kernel times (HIP events): the next batch is already running on the other event set
+                mark("batch complete:", long(mine[k]));
+                const char* names[8]; float ms[8];
+                const int nk = more ? ffv1_prev_kernel_times(L.enc[B.video], names, ms, 8) : rcgpu_ffv1_last_kernel_times(L.enc[B.video], names, ms, 8);
+                std::string t = "kernel ms of this batch:";
+                for (int i = 0; i < nk; i++) if (ms[i] > 0) { char b[64]; snprintf(b, sizeof b, " %s %.1f", names[i], ms[i]); t += b; }
+                mark(t.c_str());
+                char b[200]; snprintf(b, sizeof b, "lane 0 so far: waiting for readers %.3f s, inside upload calls %.3f s, waiting for ring space %.3f s, inside download calls %.3f s",
+                                      L.upload_wait, L.copy_calls, L.dl_wait, L.dl_calls); mark(b);
+            }
+            // downloads of this batch side by side with the uploads of the batch after the next (d_in is free: k_model(k+1) has run)
+            if (!transfers(&B, par, !serial && k + 2 < mine.size() ? &batches[mine[k + 2]] : nullptr)) return;
         }
     };
 
@@ -454,17 +515,17 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             out_entry o;
             {
                 std::unique_lock<std::mutex> l(s.m);
-                s.cv.wait(l, [&] { return s.error || (!L.outq.empty() && L.outq.front().frame == i); });
+                s.cv_out.wait(l, [&] { return s.error || (!L.outq.empty() && L.outq.front().frame == i); });
                 if (s.error) break;
                 o = L.outq.front(); L.outq.pop_front();
             }
             o.dst = io.place ? io.place(frames[i], o.size) : nullptr;
             if (io.place && !o.dst && *rcgpu_last_error()) { s.set_error(20, rcgpu_last_error()); break; }
             { std::lock_guard<std::mutex> l(s.m); s.jobs.push_back(o); }
-            s.cv.notify_all();
+            s.cv_jobs.notify_one();
         }
         { std::lock_guard<std::mutex> l(s.m); s.placer_finished = true; }
-        s.cv.notify_all();
+        s.cv_jobs.notify_all();
     };
 
     // ---- writers
@@ -474,7 +535,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             out_entry o;
             {
                 std::unique_lock<std::mutex> l(s.m);
-                s.cv.wait(l, [&] { return s.error || !s.jobs.empty() || s.placer_finished; });
+                s.cv_jobs.wait(l, [&] { return s.error || !s.jobs.empty() || s.placer_finished; });
                 if (s.jobs.empty()) return;             // error or finished
                 o = s.jobs.front(); s.jobs.pop_front();
             }
@@ -483,18 +544,20 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (hipEventSynchronize(o.ev) != hipSuccess) r = fail(100, "pipeline: a download failed");
             if (!r) {
                 if (!first_seen.exchange(true)) first_packet_seconds = since(t0);
+                const auto tw = clk::now();
                 if (o.dst) { if (io.copy) io.copy(o.dst, o.src, o.size); else memcpy(o.dst, o.src, o.size); }
                 if (io.done) r = io.done(frames[o.frame], o.dst ? o.dst : o.src, o.size);
+                { const double d = since(tw); double cur = write_busy.load(); while (!write_busy.compare_exchange_weak(cur, cur + d)) {} }
                 packet_bytes += o.size;
             }
             {
                 std::lock_guard<std::mutex> l(s.m);
                 lane_t& L = s.lanes[size_t(o.lane)];
                 L.outstanding[size_t(o.chunk)]--;
-                L.free_events.push_back(o.ev);
+                if (--*o.ev_users == 0) { L.free_events.push_back(o.ev); delete o.ev_users; }
                 if (r && !s.error) { s.error = r; s.error_msg = rcgpu_last_error(); }
             }
-            s.cv.notify_all();
+            if (r) s.wake_all(); else s.cv_ring.notify_all();
         }
     };
 
@@ -520,6 +583,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         for (const pipe_frame& f : frames) stats->payload_bytes += s.payload[f.video];
         stats->packet_bytes = packet_bytes; stats->batches = batches.size(); stats->batch_frames = maxF; stats->lanes = uint32_t(nl);
         stats->readers = readers; stats->writers = writers; stats->device_busy_seconds = busy0;
+        stats->read_call_seconds = read_busy.load() / double(N); stats->write_call_seconds = write_busy.load() / double(N);
         stats->reads_done_seconds = reads_done; stats->upload_wait_seconds = s.lanes[0].upload_wait; stats->h2d_span_seconds = s.lanes[0].h2d_span;
         if (!batches.empty()) {
             double first = 1e300, last = 0; size_t first_b = 0;
@@ -572,6 +636,7 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
         stats->device_busy_seconds = ps.device_busy_seconds; stats->steady_frames_per_second = ps.steady_frames_per_second;
         stats->reads_done_seconds = ps.reads_done_seconds; stats->last_batch_seconds = ps.last_batch_seconds;
         stats->upload_wait_seconds = ps.upload_wait_seconds; stats->h2d_span_seconds = ps.h2d_span_seconds;
+        stats->read_call_seconds = ps.read_call_seconds; stats->write_call_seconds = ps.write_call_seconds;
     }
     return r;
 }

@@ -2,7 +2,7 @@
 # between k_resolve launches.  GPU box: bash tools/timeline_pipe.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/tlp
-rocprofv3 --kernel-trace --memory-copy-trace -d gpurun_out/tlp -o tlp -- python bench.py --steps 1 --warmup 1 --legs host --host-frames 1920 --no-verify > gpurun_out/tlp/log 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/tlp -o tlp -- python bench.py --steps 1 --warmup 1 --legs host --host-frames 1920 --no-verify > gpurun_out/tlp/log 2>&1
 tail -c 1500 gpurun_out/tlp/log
 python - "$(find gpurun_out/tlp -name '*.db' | head -1)" <<'PY'
 import sqlite3, sys
