@@ -140,3 +140,22 @@ def test_sequence_memory_host_buffers_in_and_out():
     # buffers too small for a packet: an error, not a silent truncation
     with pytest.raises(api.RcgpuError, match="does not fit"):
         api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], 4, [a.ctypes.data for a in outs], 64, batch=2)
+
+
+@pytest.mark.parametrize("lanes,n,batch", [(2, 41, 6), (3, 50, 4), (4, 9, 8)])
+def test_several_lanes_return_packets_in_frame_order(lanes, n, batch):
+    """Several encoder instances ("lanes") whose batches run staggered -- on one device here, one per device on a multi-GPU node: batch b
+    goes to lane b mod lanes, every lane has its own copy streams and download ring, and one placer hands the packets on in frame order."""
+    import numpy as np
+    w, h, pixfmt, n_in = 128, 72, synth.PIX_RGB16_BE, 7
+    payloads, line_bytes = _sequence(w, h, pixfmt, n_in)
+    src = [np.frombuffer(p, dtype=np.uint8).copy() for p in payloads]
+    out_cap = len(payloads[0]) * 2
+    outs = [np.zeros(out_cap, dtype=np.uint8) for _ in range(n)]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 2, 2, 1, 1, 0, 0, 0, 0, 1, 3)
+    st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], n, [a.ctypes.data for a in outs], out_cap, batch=batch, lanes_per_device=lanes)
+    assert st.frames == n and st.devices == min(lanes, (n + 7) // 8)          # no more lanes than there is work for (8 frames each at least)
+    p = ob.Params(w, h, pixfmt, 2, 2, 1, 1)
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
+    for i in range(n):
+        assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
