@@ -2,7 +2,7 @@
 # decision at batch 64.  Usage on the GPU box: bash tools/count_insts.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/ci
-RCGPU_BENCH_BATCH=64 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d gpurun_out/ci -o ci -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-verify > gpurun_out/ci/log 2>&1
+RCGPU_BENCH_BATCH=64 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d gpurun_out/ci -o ci -- python bench.py --steps 1 --warmup 0 --legs "" --no-verify > gpurun_out/ci/log 2>&1
 python - "$(find gpurun_out/ci -name '*.db' | head -1)" <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])

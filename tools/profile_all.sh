@@ -3,7 +3,7 @@
 TAG=${1:-r01c}
 R=$GRAFT_REPO_ROOT
 cd $R
-bash tools/profile_r01.sh > /dev/null 2>&1
+bash tools/profile_round.sh > /dev/null 2>&1
 mkdir -p gpurun_out/summary
 python tools/rocprof_summary.py stats $(find gpurun_out/prof/stats -name "*.db" | head -1) > gpurun_out/summary/${TAG}_kernel_stats.csv
 python tools/rocprof_summary.py pmc $(find gpurun_out/prof/pmc_fetch -name "*.db" | head -1) FETCH_SIZE > gpurun_out/summary/${TAG}_pmc_fetch_size.csv

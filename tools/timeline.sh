@@ -1,7 +1,7 @@
 # Kernel timeline of one bench step (start/end of every launch, gaps between k_resolve launches).  GPU box: bash tools/timeline.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/tl
-rocprofv3 --kernel-trace -d gpurun_out/tl -o tl -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify > gpurun_out/tl/log 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/tl -o tl -- python bench.py --steps 1 --warmup 1 --legs "" --no-verify > gpurun_out/tl/log 2>&1
 python - "$(find gpurun_out/tl -name '*.db' | head -1)" <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
