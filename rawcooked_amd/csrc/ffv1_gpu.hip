@@ -102,7 +102,8 @@ __device__ __forceinline__ uint32_t ld_field(const uint8_t* line, uint32_t idx, 
 __device__ __forceinline__ void unpack_px(const enc_const* __restrict__ C, const uint8_t* __restrict__ frame, uint32_t x, uint32_t y, int32_t (&v)[4], bool file_components = false)
 {
     const uint32_t W = C->W, H = C->H;
-    const uint32_t fy = C->vflip ? H - 1 - y : y;                    // line in the file (Transform.cpp:181-185)
+    // line in the file (Transform.cpp:181-185); k_rawvideo wants the lines as they are stored: `-vf vflip` belongs to the Matroska output only
+    const uint32_t fy = (C->vflip && !file_components) ? H - 1 - y : y;
     const uint8_t* p = frame + size_t(fy) * C->line_bytes + size_t(x) * C->bytes_pp;
     const bool be = C->big_endian;
     uint32_t c0, c1 = 0, c2 = 0, c3 = 0;
@@ -166,7 +167,9 @@ __global__ __launch_bounds__(256) void k_unpack(const enc_const* __restrict__ C,
 // The frame as the bytes FFmpeg's `-f framemd5` output hashes (CLI/Output.cpp:312-332): the picture its dpx/tiff decoder hands on,
 // written by the rawvideo encoder without line padding [ffmpeg-knowledge].  8 bit: rgb24 / rgba / gray, bytes in file order;
 // 16 bit: rgb48 / rgba64 / gray16 in the FILE's endianness; 10 and 12 bit: planar little-endian 16-bit words, planes G, B, R(, A)
-// (gbrp10le, gbrap12le ...) or the one plane of gray10le / gray12le.  One thread per pixel, after `-vf vflip` where that is asked for.
+// (gbrp10le, gbrap12le ...) or the one plane of gray10le / gray12le.  One thread per pixel.  Lines in FILE order: the reference puts `-vf vflip`
+// (DPX stored bottom-up) in front of `-f matroska <out>`, and FFmpeg's output options belong to the output that follows them -- the framemd5
+// output behind it sees the decoder's frames as they are [ffmpeg-knowledge].
 __global__ __launch_bounds__(256) void k_rawvideo(const enc_const* __restrict__ C, const uint8_t* const* __restrict__ frames, uint8_t* __restrict__ out,
                                                   size_t out_stride)
 {

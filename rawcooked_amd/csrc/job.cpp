@@ -172,8 +172,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     const long level = opt.num("level", 3);
     if (level != 1 && level != 3) return bail(fail(2, "-level %ld is not supported by rcgpu (3, or 1 with -slices 1)", level));
     if (opt.num("g", 1) != 1) return bail(fail(2, "-g %ld is not supported by rcgpu (intra only)", opt.num("g", 1)));
-    // -f framemd5 (Output.cpp:312-332): a second output with FFmpeg's default stream choice -- one video stream, here the first, and one
-    // audio stream unless `-an` stands in front of it (--framemd5-an); audio checksums are not implemented
+    // -f framemd5 (Output.cpp:312-332): a second output with FFmpeg's default stream choice -- one video stream and one audio stream,
+    // the latter unless `-an` stands in front of it (--framemd5-an)
     const bool want_framemd5 = job->framemd5_path && *job->framemd5_path;
     // the only filter the reference ever asks for is `-vf vflip`, for DPX stored bottom-up (CLI/Main.cpp:207-211)
     if (const char* vf = opt.get("vf")) if (strcmp(vf, "vflip") != 0) return bail(fail(2, "-vf %s is not supported by rcgpu (only vflip)", vf));
@@ -242,12 +242,21 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         }
     }
 
+    // FFmpeg's default stream choice for an output without -map: the video stream with the most pixels, the audio stream with the most
+    // channels (first one on a tie) [ffmpeg-knowledge]; `-an` in front of it (--framemd5-an) drops the audio
+    size_t md5_video = 0, md5_audio = size_t(-1);
     if (want_framemd5) {
         if (videos.empty()) return bail(fail(2, "-f framemd5 needs a video stream"));
-        if (!audios.empty() && !opt.has("an")) return bail(fail(2, "-f framemd5 of audio streams is not supported by rcgpu, use --framemd5-an"));
-        if (videos[0].info.pixfmt == RCGPU_PIX_EXR_RGB16) return bail(fail(2, "-f framemd5 of EXR input is not supported by rcgpu"));
+        for (size_t vi = 1; vi < videos.size(); vi++)
+            if (uint64_t(videos[vi].info.width) * videos[vi].info.height > uint64_t(videos[md5_video].info.width) * videos[md5_video].info.height) md5_video = vi;
+        if (!opt.has("an"))
+            for (size_t ai = 0; ai < audios.size(); ai++)
+                if (md5_audio == size_t(-1) || audios[ai].info.channels > audios[md5_audio].info.channels) md5_audio = ai;
+        if (md5_audio != size_t(-1) && (audios[md5_audio].info.format_tag != 1 || audios[md5_audio].info.bits_per_sample > 32))
+            return bail(fail(2, "-f framemd5 of float audio is not supported by rcgpu, use --framemd5-an"));
+        if (videos[md5_video].info.pixfmt == RCGPU_PIX_EXR_RGB16) return bail(fail(2, "-f framemd5 of EXR input is not supported by rcgpu"));
     }
-    std::vector<uint8_t> framemd5_sums(want_framemd5 ? videos[0].files.size() * 16 : 0);
+    std::vector<uint8_t> framemd5_sums(want_framemd5 ? videos[md5_video].files.size() * 16 : 0);
     std::atomic<uint64_t> framemd5_frame_bytes{ 0 };
     mark("streams analysed");
     // ---- audio first: A_FLAC CodecPrivate (STREAMINFO) must be final before the header is written
@@ -419,7 +428,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         };
         if (want_framemd5)
             io.after_batch = [&](uint32_t video, rcgpu_ffv1* enc, uint64_t first, uint32_t n) -> int {
-                if (video != 0) return 0;                                        // FFmpeg's default choice: the first video stream
+                if (video != md5_video) return 0;
                 uint64_t fb = 0;
                 if (int r = rcgpu_ffv1_framemd5_last(enc, n, framemd5_sums.data() + size_t(first) * 16, &fb)) return r;
                 framemd5_frame_bytes = fb;
@@ -439,18 +448,52 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     mark("all batches encoded and written");
     if (int r = write_audio_until(~0ull)) return bail(r);
     if (want_framemd5) {
-        // libavformat's framehash layout, version 2 [ffmpeg-knowledge]: header, then one line per packet of the rawvideo stream
-        const video_plan& v = videos[0];
+        // libavformat's framehash layout, version 2 [ffmpeg-knowledge]: header, then one line per packet, streams interleaved by time.
+        // Audio: the framemd5 muxer's default audio codec is pcm_s16le, its packets are the WAV demuxer's (at most 4096 bytes of whole
+        // sample frames), samples converted the way libswresample does without dither (24/32 bit: arithmetic shift, 8 bit: offset binary
+        // to signed, << 8).
+        const video_plan& v = videos[md5_video];
         FILE* fh = fopen(job->framemd5_path, "w");
         if (!fh) return bail(fail(30, "cannot create %s: %s", job->framemd5_path, strerror(errno)));
         fprintf(fh, "#format: frame checksums\n#version: 2\n#hash: MD5\n#software: %s\n", rcgpu_version());
         fprintf(fh, "#tb 0: %u/%u\n#media_type 0: video\n#codec_id 0: rawvideo\n#dimensions 0: %ux%u\n#sar 0: 0/1\n", v.fps.den, v.fps.num, v.info.width, v.info.height);
+        mapped_file wav;
+        const audio_plan* a = md5_audio == size_t(-1) ? nullptr : &audios[md5_audio];
+        uint64_t a_samples = 0, a_pos = 0; uint32_t a_per_packet = 0;
+        if (a) {
+            if (!wav.open(a->file)) { fclose(fh); return bail(fail(30, "cannot open %s", a->file.c_str())); }
+            const uint32_t ch = a->info.channels;
+            const char* layout = ch == 1 ? "mono" : ch == 2 ? "stereo" : ch == 4 ? "quad" : ch == 6 ? "5.1" : ch == 8 ? "7.1" : nullptr;
+            fprintf(fh, "#tb 1: 1/%u\n#media_type 1: audio\n#codec_id 1: pcm_s16le\n#sample_rate 1: %u\n", a->info.sample_rate, a->info.sample_rate);
+            if (layout) fprintf(fh, "#channel_layout_name 1: %s\n", layout); else fprintf(fh, "#channel_layout_name 1: %u channels\n", ch);
+            a_samples = a->info.data_size / a->info.block_align;
+            a_per_packet = std::max(1u, 4096u / a->info.block_align);
+        }
         fprintf(fh, "#stream#, dts,        pts, duration,     size, hash\n");
+        auto audio_row = [&]() {
+            const uint32_t n = uint32_t(std::min<uint64_t>(a_per_packet, a_samples - a_pos)), ch = a->info.channels, bps = a->info.bits_per_sample / 8;
+            std::vector<uint8_t> s16(size_t(n) * ch * 2);
+            const uint8_t* src = wav.data + a->info.data_offset + a_pos * a->info.block_align;
+            for (size_t k = 0; k < size_t(n) * ch; k++) {
+                int32_t x;
+                if (bps == 1) x = (int32_t(src[k]) - 128) << 8;
+                else { uint32_t u = 0; for (uint32_t b = 0; b < bps; b++) u |= uint32_t(src[k * bps + b]) << (8 * (b + 4 - bps)); x = int32_t(u) >> 16; }      // left-justified in 32 bits, then >> 16
+                s16[2 * k] = uint8_t(x); s16[2 * k + 1] = uint8_t(x >> 8);
+            }
+            uint8_t md[16]; rcgpu_md5(s16.data(), s16.size(), md);
+            fprintf(fh, "1, %10llu, %10llu, %8u, %8zu, ", (unsigned long long)a_pos, (unsigned long long)a_pos, n, s16.size());
+            for (int k = 0; k < 16; k++) fprintf(fh, "%02x", md[k]);
+            fputc('\n', fh);
+            a_pos += n;
+        };
         for (size_t i = 0; i < v.files.size(); i++) {
+            // audio packets that start before this frame (a tie goes to the video frame)
+            while (a && a_pos < a_samples && a_pos * uint64_t(v.fps.num) < uint64_t(i) * v.fps.den * a->info.sample_rate) audio_row();
             fprintf(fh, "0, %10llu, %10llu, %8d, %8llu, ", (unsigned long long)i, (unsigned long long)i, 1, (unsigned long long)framemd5_frame_bytes.load());
             for (int k = 0; k < 16; k++) fprintf(fh, "%02x", framemd5_sums[i * 16 + size_t(k)]);
             fputc('\n', fh);
         }
+        while (a && a_pos < a_samples) audio_row();
         if (fclose(fh)) return bail(fail(30, "cannot write %s", job->framemd5_path));
     }
     rcgpu_mkv* m = mux; mux = nullptr;

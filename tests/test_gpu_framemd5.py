@@ -44,8 +44,9 @@ def test_device_hashes_the_rawvideo_bytes_of_every_layout(built, pixfmt, flags):
         sums, frame_bytes = enc.framemd5_last(n)
     finally:
         enc.close()
-    # with FLAG_VFLIP pack_payload stored the lines bottom-up; `-vf vflip` turns them back: the hashed picture is `comp` itself
-    want = [rawvideo_bytes(c, pixfmt) for c in comps]
+    # with FLAG_VFLIP pack_payload stored the lines bottom-up, and that is how FFmpeg's DPX decoder hands them on; the reference's
+    # `-vf vflip` stands in front of the Matroska output and belongs to it alone: the framemd5 output hashes the lines in file order
+    want = [rawvideo_bytes(c[::-1] if flags & synth.FLAG_VFLIP else c, pixfmt) for c in comps]
     assert frame_bytes == len(want[0])
     assert sums == [hashlib.md5(x).digest() for x in want]
 
@@ -81,6 +82,20 @@ def test_rawcooked_framemd5_through_the_shim(built, refbin, tmp_path):
     for i, row in enumerate(rows):
         src = open(os.path.join(work, "pkg", "img", "f_%06d.dpx" % i), "rb").read()
         assert row == "0, %10d, %10d, %8d, %8d, %s" % (i, i, 1, 64 * 48 * 6, hashlib.md5(src[2048:2048 + 64 * 48 * 6]).hexdigest())
-    # without -an the audio stream would need checksums too: refused, not half done
-    r = run([refbin, "--bin-name", SHIM, "--framemd5", "-y", "pkg"], work)
-    assert "framemd5 of audio streams is not supported" in r.stdout + r.stderr
+    # without -an the audio stream is in the file too: pcm_s16le packets as FFmpeg's WAV demuxer cuts them (4096 bytes = 1024 stereo
+    # 16-bit sample frames), time base 1/48000, interleaved with the video rows by time
+    r = run([refbin, "--bin-name", SHIM, "--framemd5", "--check", "-y", "pkg"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    lines = open(os.path.join(work, "pkg.framemd5")).read().splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    assert "#tb 1: 1/48000" in head and "#codec_id 1: pcm_s16le" in head and "#channel_layout_name 1: stereo" in head
+    rows = [l for l in lines if not l.startswith("#")]
+    wav = open(os.path.join(work, "pkg", "snd.wav"), "rb").read()
+    pcm = wav[api.wav_probe(wav).data_offset:][:12000 * 4]
+    arows = [l for l in rows if l.startswith("1,")]
+    assert len(arows) == 12 and len([l for l in rows if l.startswith("0,")]) == 5
+    for j, row in enumerate(arows):
+        n = min(1024, 12000 - 1024 * j)
+        assert row == "1, %10d, %10d, %8d, %8d, %s" % (1024 * j, 1024 * j, n, n * 4, hashlib.md5(pcm[4096 * j:4096 * j + n * 4]).hexdigest())
+    t = [(int(l.split(",")[1]) / 24.0, 0) if l.startswith("0,") else (int(l.split(",")[1]) / 48000.0, 1) for l in rows]
+    assert t == sorted(t)                                                          # by time, the video frame first on a tie
