@@ -22,7 +22,7 @@ int main(int argc, char** argv)
             size_t n = seed.size();
             const uint32_t mode = rnd() % 8;
             if (mode == 0) n = rnd() % (head + 1);                    // truncate inside the header
-            else if (mode == 1) n = seed.size() - (rnd() % 64);       // cut the tail
+            else if (mode == 1) n = seed.size() - (rnd() % std::min<size_t>(64, seed.size() + 1));       // cut the tail
             uint8_t* buf = static_cast<uint8_t*>(malloc(n ? n : 1));
             memcpy(buf, seed.data(), n);
             const int flips = 1 + rnd() % 6;

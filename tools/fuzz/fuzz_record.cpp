@@ -23,6 +23,9 @@ int main(int argc, char** argv)
             for (uint32_t pf = 0; pf < RCGPU_PIX_COUNT; pf += 1 + rnd() % 5) {
                 rcgpu_ffv1_config cfg; memset(&cfg, 0, sizeof cfg); cfg.width = 64; cfg.height = 48; cfg.pixfmt = pf; cfg.line_bytes = 64 * 8;
                 ok += rcgpu_ffv1_config_from_record(buf, n, &cfg) == 0; n_all++;
+                // ... and the reader of the first slice header, with the same bytes as a "packet" and with a mutated packet behind a good record
+                ok += rcgpu_ffv1_config_from_stream(buf, n, buf, n, &cfg) == 0; n_all++;
+                ok += rcgpu_ffv1_config_from_stream(seed.data(), seed.size(), buf, n, &cfg) == 0; n_all++;
             }
             free(buf);
         }

@@ -24,6 +24,9 @@ w("seeds/a.exr", synth.exr_file(comp))
 s = np.random.default_rng(1).integers(-1000, 1000, size=(500, 2)).astype(np.int32)
 w("seeds/a.wav", synth.wav_file(s, 16))
 w("seeds/b.wav", synth.wav_file(np.tile(s, (1, 3)), 24, extensible=True, trailer_chunk=b"LIST\x04\x00\x00\x00abcd"))
+import struct
+fmt0 = struct.pack("<HHIIHH", 1, 0, 48000, 0, 0, 0)          # the all-zero fmt chunk that once divided by zero (round 1 advice)
+w("seeds/c.wav", b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt0) + 8 + 16) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt0)) + fmt0 + b"data" + struct.pack("<I", 16) + bytes(16))
 for i, (pixfmt, ctx, coder) in enumerate([(synth.PIX_RGB16_BE, 1, 1), (synth.PIX_RGB10_FILLEDA_BE, 0, 2), (synth.PIX_Y8, 1, 1), (synth.PIX_RGBA16_LE, 2, 2)]):
     w("rec/rec%d.bin" % i, ob.config_record(ob.Params(64, 48, pixfmt, 2, 2, 1, ctx, 0, coder, 3)))
 PY
