@@ -311,6 +311,7 @@ def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packet0):
         return {"frames": n_frames, "seconds": round(dt, 3), "value": round(n_frames / dt, 2), "unit": "frames/s", "mkv_bytes": size,
                 "read_GBps": round(n_frames * (payload + 2048) / dt / 1e9, 2), "write_GBps": round(size / dt / 1e9, 2),
                 "first_block_identical_to_device_resident_run": ok, "trace": pl[-1].split("pipeline: ", 1)[1] if pl else None,
+                "phases": [ln.split("rcgpu trace:", 1)[1].strip() for ln in r.stderr.splitlines() if "rcgpu trace:" in ln and "pipeline:" not in ln],
                 "what": f"process start to exit of rcgpu-ffmpeg: {n_frames} x {width}x{height} RGB16 DPX on tmpfs ({R} distinct, hard-linked) -> FFV1 slices={slices} -> MKV on tmpfs"}, ok is not False
     finally:
         shutil.rmtree(work, ignore_errors=True)

@@ -303,7 +303,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
 
     // ---- the device side: one pipeline for all picture sequences of the job (pipeline.h): encoders per device, batches sized from the
     // device's free memory, pinned upload slots and download rings
-    rc::pipeline pl;
+    std::unique_ptr<rc::pipeline> plp(new rc::pipeline);
+    rc::pipeline& pl = *plp;
     std::vector<rc::pipe_video> pvideos;
     for (video_plan& v : videos) {
         rc::pipe_video pv; pv.frames = v.files.size();
@@ -500,6 +501,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     if (int r = rcgpu_mkv_close(m)) { unlink(job->output_path); return bail(r); }
     guard.ok = true;
     mark("file closed");
+    plp.reset();                 // encoders, pinned slots and rings go back here, not behind the caller's back
+    mark("device and pinned memory released");
     return 0;
 }
 

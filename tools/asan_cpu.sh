@@ -9,7 +9,7 @@ cd $R/rawcooked_amd/csrc
 for f in rc_common formats mkv_mux hashes ffv1_host job; do
   g++ -O1 -g -fPIC -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I../../include -I. -c $f.cpp -o $T/$f.o
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o $T/librcgpu.so $T/*.o build/ffv1_gpu.o build/ffv1_check.o build/flac_gpu.o -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -o $T/librcgpu.so $T/*.o build/ffv1_gpu.o build/ffv1_check.o build/flac_gpu.o build/pipeline.o -lpthread
 cd $R/oracle
 gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o $T/liboracle.so ffv1_oracle.c flac_oracle.c dpx_oracle.c -lm -lpthread
 cd $R
