@@ -497,12 +497,15 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         while (a && a_pos < a_samples) audio_row();
         if (fclose(fh)) return bail(fail(30, "cannot write %s", job->framemd5_path));
     }
+    // closing the file (unmapping ~50 GB of it: seconds) and giving back the device and pinned memory (seconds, too) side by side
+    std::thread release([&] { plp.reset(); });
     rcgpu_mkv* m = mux; mux = nullptr;
-    if (int r = rcgpu_mkv_close(m)) { unlink(job->output_path); return bail(r); }
-    guard.ok = true;
+    const int rc_close = rcgpu_mkv_close(m);
     mark("file closed");
-    plp.reset();                 // encoders, pinned slots and rings go back here, not behind the caller's back
+    release.join();
     mark("device and pinned memory released");
+    if (rc_close) { unlink(job->output_path); return bail(rc_close); }
+    guard.ok = true;
     return 0;
 }
 
