@@ -12,7 +12,7 @@
 //                                       neighbours -> context, folded residual, #decisions; symbols in coding order
 //   K3 k_resolve    wave   / slice      adaptive-state resolution: walks the symbols 64 at a time, applies the state
 //                                       transitions in coding order (same-context lanes serialised through LDS) and
-//                                       emits (state, bit) decisions, interleaved [piece][lane of chain][32 x u16]
+//                                       emits (state, bit) decisions at 9 bits each, interleaved [piece][lane of chain][64 bytes = 56 decisions]
 //   K4 k_rangecode  LANE   / slice      the serial low/range recurrence + carry-resolved byte emission; 64 slices per
 //                                       wave advance in lock-step over the interleaved decision stream
 //   K5 k_footer     wave   / slice      slice size, error_status, parallel CRC-32 (segment CRCs + GF(2) combine)
@@ -61,12 +61,17 @@ struct slice_geom {
     uint32_t seg_q;       // symbols per segment (multiple of 64)
 };
 
-constexpr int kPieceEntries = 32;                 // decisions per 64-byte piece
+// A piece = 64 bytes of the decision stream = 56 decisions at 9 bits: bytes 0..55 hold t of each decision (state for a coded 1,
+// 256 - state for a coded 0), bytes 56..62 the 56 coded bits (decision k = bit k & 7 of byte 56 + k / 8), byte 63 is 0.  (Round 1 spent
+// 16 bits per decision: t and c = 0 / 255; c is the coded bit said with eight.)
+constexpr int kPieceEntries = 56;                 // decisions per 64-byte piece
 constexpr int kPieceBytes = 64;
 constexpr int kGroupPieceBytes = 64 * kPieceBytes; // one piece of each of the 64 chains of a group
 constexpr int kMaxDecPerSample = 35;              // 2*16+3 for 17-bit residuals
-constexpr int kStageEntries = kPieceEntries + 64 * kMaxDecPerSample + 32;   // carry + one chunk (+ slack)
-constexpr int kResolveFixedLds = ((kStageEntries * 2 + 15) & ~15) + 64 * 32 + 512 + 2 * 256;   // k_resolve: stage | slots | transitions | powers
+constexpr int kStageEntries = kPieceEntries + 64 * kMaxDecPerSample + 24;   // carry + one chunk (+ slack); a multiple of 16
+constexpr int kStageBitDwords = (kStageEntries + 31) / 32 + 7;              // the coded bits of the staged decisions (+ room for the widest OR)
+constexpr int kResolveFixedLds = kStageEntries + kStageBitDwords * 4 + 64 * 32 + 512 + 2 * 256;   // k_resolve: stage bytes | stage bits | slots | transitions | powers
+static_assert(kStageEntries % 16 == 0 && (kStageBitDwords * 4) % 16 == 0, "LDS areas stay 16-byte aligned");
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
@@ -362,8 +367,9 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     // offset fields.  What scales with the number of contexts follows as dynamic LDS.
     __shared__ __attribute__((aligned(16))) uint8_t fixed[kResolveFixedLds];
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t* stage = reinterpret_cast<uint16_t*>(fixed);                          // kStageEntries u16
-    uint8_t*  slot = fixed + ((kStageEntries * 2 + 15) & ~15);                     // 64 x 32
+    uint8_t*  stage = fixed;                                                       // kStageEntries t-bytes
+    uint32_t* sbits = reinterpret_cast<uint32_t*>(fixed + kStageEntries);          // their coded bits, decision i = bit i & 31 of dword i >> 5; zero beyond stage_count
+    uint8_t*  slot = fixed + kStageEntries + kStageBitDwords * 4;                  // 64 x 32
     uint8_t*  trans = slot + 64 * 32;                                               // [256 +- state], see below
     uint8_t*  pw = trans + 512;                                                     // [2][256]: one_state applied 4 and 16 times
     uint32_t* touched = reinterpret_cast<uint32_t*>(smem);                          // nkeys bits
@@ -396,12 +402,19 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     if (seg == 0) {
         if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) reinterpret_cast<uint4*>(lstates)[i] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
         else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = 0;
-        for (uint32_t i = lane; i < G.hdr_n; i += 64) stage[i] = hdr[G.hdr_off + i];
+        for (uint32_t i = lane; i < uint32_t(kStageBitDwords); i += 64) sbits[i] = 0;
+        WAVE_SYNC();
+        for (uint32_t i = lane; i < G.hdr_n; i += 64) {                 // header decisions from the host: t | coded bit << 8
+            const uint32_t hd = hdr[G.hdr_off + i];
+            stage[i] = uint8_t(hd);
+            if (hd >> 8) atomicOr(&sbits[i >> 5], 1u << (i & 31));
+        }
         stage_count = G.hdr_n;
     } else {
         if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) reinterpret_cast<uint4*>(lstates)[i] = rs_states[i];
         else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = rs_touched[i];
-        if (lane < 16) reinterpret_cast<uint32_t*>(stage)[lane] = reinterpret_cast<const uint32_t*>(rs + 16)[lane];
+        for (uint32_t i = lane; i < uint32_t(kStageBitDwords); i += 64) sbits[i] = i < 2 ? reinterpret_cast<const uint32_t*>(rs + 72)[i] : 0u;
+        if (lane < 14) reinterpret_cast<uint32_t*>(stage)[lane] = reinterpret_cast<const uint32_t*>(rs + 16)[lane];
         stage_count = *reinterpret_cast<const uint32_t*>(rs);
     }
     uint32_t piece_base = 0;              // piece index inside this segment's window
@@ -409,21 +422,35 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     const bool last_seg = seg + 1 == C->nseg;
     WAVE_SYNC();
 
+    // bits [7 * byte .. 7 * byte + 56) of the bit stage as two dwords (the second one's top byte is 0): byte-aligned, not dword-aligned
+    auto bits56 = [&](uint32_t byte) -> uint2 {
+        const uint32_t w = byte >> 2, sh = (byte & 3) * 8;
+        const uint32_t a = sbits[w], b = sbits[w + 1], c = sbits[w + 2];
+        const uint32_t lo = sh ? __builtin_amdgcn_alignbit(b, a, sh) : a, hi = sh ? __builtin_amdgcn_alignbit(c, b, sh) : b;
+        return make_uint2(lo, hi & 0x00FFFFFFu);
+    };
     auto flush_full = [&]() {
         WAVE_SYNC();
         const uint32_t np = stage_count / kPieceEntries;
-        const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
-        const uint4* s128 = reinterpret_cast<const uint4*>(stage);
         uint4* out128 = reinterpret_cast<uint4*>(out32);
         for (uint32_t idx = lane; idx < np * 4; idx += 64) {          // 16 bytes per lane: four lanes cover one 64-byte piece
             const uint32_t pc = idx >> 2, q = idx & 3;
-            out128[size_t(piece_base + pc) * (kGroupPieceBytes / 16) + q] = s128[idx];
+            const uint2* tp = reinterpret_cast<const uint2*>(stage + pc * kPieceEntries + q * 16);      // 8-byte aligned: 56 = 7 x 8
+            uint4 v;
+            const uint2 t0 = tp[0];
+            if (q < 3) { const uint2 t1 = tp[1]; v = make_uint4(t0.x, t0.y, t1.x, t1.y); }
+            else { const uint2 b = bits56(pc * 7); v = make_uint4(t0.x, t0.y, b.x, b.y); }
+            out128[size_t(piece_base + pc) * (kGroupPieceBytes / 16) + q] = v;
         }
+        // what did not fill a piece (< 56 decisions: 14 dwords of t, 7 bytes of bits) moves to the front; the bit stage is zero behind it
         const uint32_t rem = stage_count - np * kPieceEntries;
         uint32_t keep = 0;
-        if (lane < 16) keep = s32[np * 16 + lane];
+        if (lane < 14) keep = reinterpret_cast<const uint32_t*>(stage)[np * 14 + lane];
+        const uint2 kb = bits56(np * 7);
+        const uint32_t m0 = rem >= 32 ? 0xFFFFFFFFu : (1u << rem) - 1, m1 = rem > 32 ? (1u << (rem - 32)) - 1 : 0u;
         WAVE_SYNC();
-        if (lane < 16 && np) reinterpret_cast<uint32_t*>(stage)[lane] = keep;
+        if (lane < 14 && np) reinterpret_cast<uint32_t*>(stage)[lane] = keep;
+        for (uint32_t i = lane; i < uint32_t(kStageBitDwords); i += 64) sbits[i] = i == 0 ? (kb.x & m0) : i == 1 ? (kb.y & m1) : 0u;
         piece_base += np;
         stage_count = rem;
         WAVE_SYNC();
@@ -531,7 +558,22 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         unsigned long long done = 0;
         bool pending = valid;
         uint8_t* sl = LDS_STATES ? lstates + size_t(key) * 32 : slot + leader * 32;
-        uint16_t* op = stage + stage_count + excl;
+        uint8_t* op = stage + stage_count + excl;
+        {   // the coded bits of this lane's decisions do not depend on any state: zero flag | e ones, a zero | mantissa from the top | sign
+            uint32_t blo = 1, bhi = 0;                                    // a == 0: one decision, a coded 1
+            if (a) {
+                const uint32_t mant = a & ((1u << e) - 1), rev = e ? __brev(mant) >> (32 - e) : 0u;          // mantissa bit e-1 first
+                const unsigned long long v = ((unsigned long long)(((1u << e) - 1) << 1)) | ((unsigned long long)rev << (e + 2)) | ((unsigned long long)(d < 0) << (2 * e + 2));
+                blo = uint32_t(v); bhi = uint32_t(v >> 32);
+            }
+            if (valid) {
+                const uint32_t o = stage_count + excl, w = o >> 5, sh = o & 31;
+                const uint32_t p0 = blo << sh, p1 = sh ? __builtin_amdgcn_alignbit(bhi, blo, 32 - sh) : bhi, p2 = sh ? bhi >> (32 - sh) : 0u;
+                atomicOr(&sbits[w], p0);
+                if (p1) atomicOr(&sbits[w + 1], p1);
+                if (p2) atomicOr(&sbits[w + 2], p2);
+            }
+        }
         // Lanes of one context that all carry a zero residual (flat picture areas, letterbox bars) need no rounds: the r-th of them
         // sees state 0 after r "coded a 1" transitions, which the power tables give in a few look-ups.
         if (__ballot(zrun)) {
@@ -540,7 +582,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                 for (uint32_t r = rank & 3; r; r--) st = trans[256 + st];          // rank = 16 a + 4 b + c: at most 3 + 3 + 3 look-ups
                 for (uint32_t r = (rank >> 2) & 3; r; r--) st = pw[st];
                 for (uint32_t r = rank >> 4; r; r--) st = pw[256 + st];
-                op[0] = uint16_t(st);                                  // bit 1: (t, c) = (state, 0)
+                op[0] = uint8_t(st);                                   // a coded 1: t = state
                 if (last) sl[0] = trans[256 + st];
             }
             done |= __ballot(zrun);
@@ -566,17 +608,17 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 #define ST_GET(k) ((S[(k) >> 2] >> (8 * ((k) & 3))) & 0xFFu)
 #define ST_PUT_IF(c, k, v) (S[(k) >> 2] = (c) ? ((S[(k) >> 2] & ~(0xFFu << (8 * ((k) & 3)))) | ((v) << (8 * ((k) & 3)))) : S[(k) >> 2])
 #define NEXT(en) uint32_t(trans[256 + (en)])                            /* en = +state for bit 1, -state for bit 0 */
-#define EXP_SLOT(t) { const int en = __mul24(int(ST_GET(1 + (t))), sg_e[t]); nxe[t] = NEXT(en); if (nz && (t) <= e) op[1 + (t)] = uint16_t(en); }
-#define MAN_SLOT(t) { const int en = __mul24(int(ST_GET(22 + (t))), sg_m[t]); nxm[t] = NEXT(en); if (nz && (t) < e) op[2 * e + 1 - (t)] = uint16_t(en); }
+#define EXP_SLOT(t) { const int en = __mul24(int(ST_GET(1 + (t))), sg_e[t]); nxe[t] = NEXT(en); if (nz && (t) <= e) op[1 + (t)] = uint8_t(en); }
+#define MAN_SLOT(t) { const int en = __mul24(int(ST_GET(22 + (t))), sg_m[t]); nxm[t] = NEXT(en); if (nz && (t) < e) op[2 * e + 1 - (t)] = uint8_t(en); }
 #define MERGE(x, n, m) x = ((n) & (m)) | ((x) & ~(m))
                     const bool nz = a != 0;
                     const int ks = 11 + (e < 10 ? e : 10);              // sign state: the only index that depends on the symbol
-                    // ---- phase 1: read states, emit decisions, issue the look-ups.  A decision is (state, bit); its stream
-                    // entry (t, c) = bit ? (state, 0) : (256 - state, 255) is +-state as a 16-bit integer, and the same signed
-                    // number indexes the transition table.
+                    // ---- phase 1: read states, emit decisions, issue the look-ups.  A decision is (state, bit); en = +state for
+                    // a coded 1, -state for a coded 0: its low byte is the stream's t (state or 256 - state), and the same signed
+                    // number indexes the transition table.  (The coded bits went into the bit stage before the rounds.)
                     const int en_z = nz ? -int(ST_GET(0)) : int(ST_GET(0));
                     const uint32_t nx_z = NEXT(en_z);
-                    op[0] = uint16_t(en_z);
+                    op[0] = uint8_t(en_z);
                     uint32_t nxe[9] = {}, nxm[9] = {}, nx_s = 0;
                     if constexpr (L >= 1) {
                         const int st_s = nz ? int(sl[ks]) : 128;       // sign states 11..21 are touched by nothing else: straight from LDS
@@ -585,7 +627,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                         if constexpr (L >= 3) { EXP_SLOT(7) EXP_SLOT(8) MAN_SLOT(6) MAN_SLOT(7) MAN_SLOT(8) }
                         const int en_s = d < 0 ? st_s : -st_s;
                         nx_s = NEXT(en_s);
-                        if (nz) op[2 * e + 2] = uint16_t(en_s);
+                        if (nz) op[2 * e + 2] = uint8_t(en_s);
                     }
                     // ---- the two chains: state 10 for exponent bits 9.., state 31 for mantissa bits e-1 .. 9
                     if constexpr (L >= 3) {
@@ -593,7 +635,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                         for (int t = 9; t <= emax; t++) {
                             const bool act = nz && t <= e;
                             const int en = t < e ? int(ST_GET(10)) : -int(ST_GET(10));
-                            if (act) op[1 + t] = uint16_t(en);
+                            if (act) op[1 + t] = uint8_t(en);
                             const uint32_t nx = NEXT(en);
                             ST_PUT_IF(act, 10, nx);
                         }
@@ -601,7 +643,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                         for (int t = emax - 1; t >= 9; t--) {
                             const bool act = nz && t < e;
                             const int en = (a >> t) & 1u ? int(ST_GET(31)) : -int(ST_GET(31));
-                            if (act) op[2 * e + 1 - t] = uint16_t(en);
+                            if (act) op[2 * e + 1 - t] = uint8_t(en);
                             const uint32_t nx = NEXT(en);
                             ST_PUT_IF(act, 31, nx);
                         }
@@ -653,16 +695,17 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     if (!last_seg) {      // park the unfinished piece and the bitmap (or the state table) for the next segment
         if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) rs_states[i] = reinterpret_cast<const uint4*>(lstates)[i];
         else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) rs_touched[i] = touched[i];
-        if (lane < 16) reinterpret_cast<uint32_t*>(rs + 16)[lane] = reinterpret_cast<const uint32_t*>(stage)[lane];
+        if (lane < 14) reinterpret_cast<uint32_t*>(rs + 16)[lane] = reinterpret_cast<const uint32_t*>(stage)[lane];
+        if (lane < 2) reinterpret_cast<uint32_t*>(rs + 72)[lane] = sbits[lane];
         if (lane == 0) *reinterpret_cast<uint32_t*>(rs) = stage_count;
         return;
     }
     // end-of-slice bit (state 129, FFV1_Slice.cpp:336-340), then pad the last piece
-    if (lane == 0) stage[stage_count] = uint16_t(0xFF00u | (256 - 129));     // state 129, bit 0
+    if (lane == 0) stage[stage_count] = uint8_t(256 - 129);                  // state 129, a coded 0 (its bit in the bit stage is already 0)
     stage_count += 1;
     WAVE_SYNC();
     const uint32_t padded = (stage_count + kPieceEntries - 1) / kPieceEntries * kPieceEntries;
-    for (uint32_t i = stage_count + lane; i < padded; i += 64) stage[i] = 0x0080;
+    for (uint32_t i = stage_count + lane; i < padded; i += 64) stage[i] = 0x80;     // never coded: k_rangecode knows the slice's decision count
     stage_count = padded;
     flush_full();
 }
@@ -673,9 +716,9 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 // K4: range coder, one LANE per slice (chain).  The 64 chains of a wavefront read the same piece index of their
 // interleaved streams each iteration and run the low/range recurrence of RFC 9043 3.8.1 in lock-step.
 //
-// Decision entries arrive pre-digested by k_resolve as (t, c): t = bit ? state : 256 - state, c = bit ? 0 : 255, so
+// Decisions arrive pre-digested by k_resolve as t = bit ? state : 256 - state plus the coded bit; with c = bit ? 0 : 255
 //     new_range = (range * t + c) >> 8          [ == bit ? range*state>>8 : range - (range*state>>8) ]
-//     low      += bit ? range - new_range : 0
+//     low      += bit ? range - new_range : 0   [ the bit as an all-ones / zero mask: one v_bfe_i32, one v_and ]
 // and the dependent chain per decision is mad -> shift -> (compare || shift) -> select.  A single wavefront issues
 // in order, so the length of that chain -- not the instruction count -- sets the time per decision; everything else
 // (low, byte bookkeeping) is independent work that fills the gaps.  There is no branch in the steady state:
@@ -689,7 +732,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 //     event, which ripples it through the bytes already in HBM.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kMaxCarryEvents = 4096;
-constexpr int kOutRows = 9;           // 32 decisions renormalise at most 32 times: 8 flushes (+1 carried in)
+constexpr int kOutRows = kPieceEntries / 4 + 1;   // the decisions of a piece renormalise at most once each: a flush per four bytes (+1 carried in)
 
 struct rc_resume { uint32_t range, nb, pd; int pos; unsigned long long low; unsigned long long pad; };   // per chain, between segments
 
@@ -700,10 +743,12 @@ struct rc_lane {
     int pos; uint8_t* out; int cap; uint32_t chain;
 };
 
-__device__ __forceinline__ void rc_step(rc_lane& r, uint32_t t, uint32_t c)
+// m = all ones for a coded 1, zero for a coded 0 (one v_bfe_i32 off the piece's bit words); c = 255 for a coded 0
+__device__ __forceinline__ void rc_step(rc_lane& r, uint32_t t, uint32_t m)
 {
+    const uint32_t c = 255u & ~m;
     const uint32_t nr = (__umul24(r.range, t) + c) >> 8;
-    const uint32_t inc = c ? 0u : r.range - nr;               // c == 0 <=> bit 1
+    const uint32_t inc = (r.range - nr) & m;
     const uint32_t sh = nr < 0x100 ? 8u : 0u;                 // renormalise: one byte at most, since t >= 1 keeps nr >= range >> 8
     r.range = nr << sh;
     r.low = (r.low + inc) << sh;
@@ -753,18 +798,19 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
     if (cnt == kPieceEntries) {
 #pragma unroll
         for (int j = 0; j < kPieceEntries; j++) {
-            const uint32_t word = w[j >> 1];
-            rc_step(r, (j & 1) ? (word >> 16) & 0xFF : word & 0xFF, (j & 1) ? word >> 24 : (word >> 8) & 0xFF);
+            const uint32_t t = (w[j >> 2] >> (8 * (j & 3))) & 0xFF;
+            const uint32_t m = uint32_t(__builtin_amdgcn_sbfe(int(w[14 + (j >> 5)]), uint32_t(j & 31), 1u));
+            rc_step(r, t, m);
             if (j & 1) rc_check(r, ev_count, ev);
         }
     } else {
 #pragma unroll 1
-        for (uint32_t j = 0; j < cnt; j++) {      // last (partial) piece only: pick dword j/2 without indexing registers dynamically
+        for (uint32_t j = 0; j < cnt; j++) {      // last (partial) piece only: pick dword j/4 without indexing registers dynamically
             uint32_t ww = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) ww = (j >> 1) == uint32_t(k) ? w[k] : ww;
-            const uint32_t ent = (ww >> (16 * (j & 1))) & 0xFFFF;
-            rc_step(r, ent & 0xFF, ent >> 8);
+            for (int k = 0; k < 14; k++) ww = (j >> 2) == uint32_t(k) ? w[k] : ww;
+            const uint32_t bw = j < 32 ? w[14] : w[15];
+            rc_step(r, (ww >> (8 * (j & 3))) & 0xFF, 0u - ((bw >> (j & 31)) & 1u));
             rc_check(r, ev_count, ev);
         }
     }
@@ -1193,7 +1239,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             const auto hd = e->sp.version == 1 ? ffv1::v1_frame_header_decisions(e->sp) : ffv1::slice_header_decisions(e->sp, sx, sy, e->geom.empty());
             g.hdr_off = uint32_t(hdr.size()); g.hdr_n = uint32_t(hd.size());
             if (g.hdr_n > uint32_t(kStageEntries)) { delete e; return fail(2, "ffv1: %u header decisions do not fit k_resolve's stage", g.hdr_n); }
-            for (uint16_t d16 : hd) hdr.push_back((d16 & 0x100) ? uint16_t(d16 & 0xFF) : uint16_t(0xFF00u | (256 - (d16 & 0xFF))));   // (state, bit) -> (t, c)
+            for (uint16_t d16 : hd) hdr.push_back(uint16_t(((d16 & 0x100) ? (d16 & 0xFF) : (256 - (d16 & 0xFF))) | (d16 & 0x100)));   // (state, bit) -> t | bit << 8
             const size_t cap = slice_buffer_bytes(d, g.w, g.h, e->sp.version);
             if (cap >= (size_t(1) << 31)) { delete e; return fail(2, "ffv1: a version 1 frame of %ux%u does not fit the coder's 31-bit byte positions", g.w, g.h); }
             cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here
@@ -1573,10 +1619,12 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
         const uint8_t* base = e->d_window[0] + e->h_group_off[chain >> 6] + (chain & 63) * kPieceBytes;
         (void)nchains;
         if (hipMemcpy2D(tmp.data(), kPieceBytes, base, kGroupPieceBytes, kPieceBytes, pieces, hipMemcpyDeviceToHost) != hipSuccess) return -3;
-        const uint16_t* ent = reinterpret_cast<const uint16_t*>(tmp.data());
         uint16_t* o = static_cast<uint16_t*>(dst);
-        for (unsigned long long i = 0; i < nd; i++)          // (t, c) -> state | bit << 8, the oracle's trace form
-            o[i] = (ent[i] >> 8) ? uint16_t(256 - (ent[i] & 0xFF)) : uint16_t((ent[i] & 0xFF) | 0x100);
+        for (unsigned long long i = 0; i < nd; i++) {        // piece bytes -> state | bit << 8, the oracle's trace form
+            const uint8_t* pcs = tmp.data() + (i / kPieceEntries) * kPieceBytes;
+            const uint32_t k = uint32_t(i % kPieceEntries), t = pcs[k], bit = (pcs[kPieceEntries + (k >> 3)] >> (k & 7)) & 1;
+            o[i] = bit ? uint16_t(t | 0x100) : uint16_t(256 - t);
+        }
         return (long long)(nd * 2);
     }
     case 4: {

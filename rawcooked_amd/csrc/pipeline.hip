@@ -120,7 +120,7 @@ uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& c)
     const uint64_t nsets = d.planes == 1 ? 1 : d.planes == 4 ? 3 : 2;
     const uint64_t states = nctx * nsets * 32 <= (48u << 10) ? 0 : S * nctx * nsets * 32;
     const uint64_t nseg = c.segments ? c.segments : std::max<uint64_t>(1, std::min<uint64_t>(32, samples / S / 1024));
-    const uint64_t windows = samples * 35 * 2 * (nseg > 1 ? 2 : 1) / nseg;                  // worst case: 35 decisions per sample
+    const uint64_t windows = samples * 35 * 8 / 7 * (nseg > 1 ? 2 : 1) / nseg;              // worst case: 35 decisions per sample, 64 bytes per 56 of them
     const uint64_t cbuf = raw * 3 / 2 + S * ((256u << 10) + 4096 + 32);
     return samples * 4 + states + windows + 2 * cbuf + raw + (1u << 20);
 }
