@@ -332,7 +332,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "384")), help="frames in flight per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "336")), help="frames in flight per GPU per step")
     ap.add_argument("--segments", type=int, default=0, help="hand-over windows per slice between k_resolve and k_rangecode (0 = library default)")
     ap.add_argument("--check-batch", type=int, default=1600, help="check leg: frames decoded per step (>= --batch)")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])

@@ -70,8 +70,10 @@ constexpr int kGroupPieceBytes = 64 * kPieceBytes; // one piece of each of the 6
 constexpr int kMaxDecPerSample = 35;              // 2*16+3 for 17-bit residuals
 constexpr int kStageEntries = kPieceEntries + 64 * kMaxDecPerSample + 24;   // carry + one chunk (+ slack); a multiple of 16
 constexpr int kStageBitDwords = (kStageEntries + 31) / 32 + 7;              // the coded bits of the staged decisions (+ room for the widest OR)
-constexpr int kResolveFixedLds = kStageEntries + kStageBitDwords * 4 + 64 * 32 + 512 + 2 * 256;   // k_resolve: stage bytes | stage bits | slots | transitions | powers
+constexpr int kStageMaxPieces = kStageEntries / kPieceEntries + 1;         // pieces one flush can emit (41) + 1
 static_assert(kStageEntries % 16 == 0 && (kStageBitDwords * 4) % 16 == 0, "LDS areas stay 16-byte aligned");
+constexpr int kResolveFixedLds = kStageEntries + kStageBitDwords * 4 + kStageMaxPieces * 16 + 64 * 32 + 512 + 2 * 256;   // k_resolve: stage bytes | stage bits | piece tails | slots | transitions | powers
+
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
@@ -369,7 +371,8 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t*  stage = fixed;                                                       // kStageEntries t-bytes
     uint32_t* sbits = reinterpret_cast<uint32_t*>(fixed + kStageEntries);          // their coded bits, decision i = bit i & 31 of dword i >> 5; zero beyond stage_count
-    uint8_t*  slot = fixed + kStageEntries + kStageBitDwords * 4;                  // 64 x 32
+    uint4*    ptail = reinterpret_cast<uint4*>(fixed + kStageEntries + kStageBitDwords * 4);   // last quarter of every piece about to leave: t 48..55 | 56 bits | 0
+    uint8_t*  slot = fixed + kStageEntries + kStageBitDwords * 4 + kStageMaxPieces * 16;       // 64 x 32
     uint8_t*  trans = slot + 64 * 32;                                               // [256 +- state], see below
     uint8_t*  pw = trans + 512;                                                     // [2][256]: one_state applied 4 and 16 times
     uint32_t* touched = reinterpret_cast<uint32_t*>(smem);                          // nkeys bits
@@ -431,28 +434,30 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     };
     auto flush_full = [&]() {
         WAVE_SYNC();
-        const uint32_t np = stage_count / kPieceEntries;
+        const uint32_t np = stage_count / kPieceEntries, ndw = (stage_count + 31) / 32 + 1;      // ndw: bit-stage dwords that may hold a bit
         uint4* out128 = reinterpret_cast<uint4*>(out32);
+        if (uint32_t(lane) < np) {                                     // lane p puts piece p's last quarter together: t 48..55, then its 56 bits
+            const uint2 t = *reinterpret_cast<const uint2*>(stage + lane * kPieceEntries + 48), b = bits56(uint32_t(lane) * 7);
+            ptail[lane] = make_uint4(t.x, t.y, b.x, b.y);
+        }
+        WAVE_SYNC();
         for (uint32_t idx = lane; idx < np * 4; idx += 64) {          // 16 bytes per lane: four lanes cover one 64-byte piece
             const uint32_t pc = idx >> 2, q = idx & 3;
-            const uint2* tp = reinterpret_cast<const uint2*>(stage + pc * kPieceEntries + q * 16);      // 8-byte aligned: 56 = 7 x 8
-            uint4 v;
-            const uint2 t0 = tp[0];
-            if (q < 3) { const uint2 t1 = tp[1]; v = make_uint4(t0.x, t0.y, t1.x, t1.y); }
-            else { const uint2 b = bits56(pc * 7); v = make_uint4(t0.x, t0.y, b.x, b.y); }
-            out128[size_t(piece_base + pc) * (kGroupPieceBytes / 16) + q] = v;
+            const uint2* tp = q < 3 ? reinterpret_cast<const uint2*>(stage + pc * kPieceEntries + q * 16)      // 8-byte aligned: 56 = 7 x 8
+                                    : reinterpret_cast<const uint2*>(ptail + pc);
+            const uint2 t0 = tp[0], t1 = tp[1];
+            out128[size_t(piece_base + pc) * (kGroupPieceBytes / 16) + q] = make_uint4(t0.x, t0.y, t1.x, t1.y);
         }
-        // what did not fill a piece (< 56 decisions: 14 dwords of t, 7 bytes of bits) moves to the front; the bit stage is zero behind it
-        const uint32_t rem = stage_count - np * kPieceEntries;
+        // what did not fill a piece (< 56 decisions: 14 dwords of t, 7 bytes of bits) moves to the front; the bit stage is zero behind the
+        // staged decisions at all times, so the 56 bits read here need no mask
         uint32_t keep = 0;
         if (lane < 14) keep = reinterpret_cast<const uint32_t*>(stage)[np * 14 + lane];
         const uint2 kb = bits56(np * 7);
-        const uint32_t m0 = rem >= 32 ? 0xFFFFFFFFu : (1u << rem) - 1, m1 = rem > 32 ? (1u << (rem - 32)) - 1 : 0u;
         WAVE_SYNC();
         if (lane < 14 && np) reinterpret_cast<uint32_t*>(stage)[lane] = keep;
-        for (uint32_t i = lane; i < uint32_t(kStageBitDwords); i += 64) sbits[i] = i == 0 ? (kb.x & m0) : i == 1 ? (kb.y & m1) : 0u;
+        for (uint32_t i = lane; i < ndw; i += 64) sbits[i] = i == 0 ? kb.x : i == 1 ? kb.y : 0u;
         piece_base += np;
-        stage_count = rem;
+        stage_count -= np * kPieceEntries;
         WAVE_SYNC();
     };
     flush_full();
@@ -559,19 +564,27 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         bool pending = valid;
         uint8_t* sl = LDS_STATES ? lstates + size_t(key) * 32 : slot + leader * 32;
         uint8_t* op = stage + stage_count + excl;
-        {   // the coded bits of this lane's decisions do not depend on any state: zero flag | e ones, a zero | mantissa from the top | sign
-            uint32_t blo = 1, bhi = 0;                                    // a == 0: one decision, a coded 1
-            if (a) {
-                const uint32_t mant = a & ((1u << e) - 1), rev = e ? __brev(mant) >> (32 - e) : 0u;          // mantissa bit e-1 first
-                const unsigned long long v = ((unsigned long long)(((1u << e) - 1) << 1)) | ((unsigned long long)rev << (e + 2)) | ((unsigned long long)(d < 0) << (2 * e + 2));
-                blo = uint32_t(v); bhi = uint32_t(v >> 32);
-            }
-            if (valid) {
-                const uint32_t o = stage_count + excl, w = o >> 5, sh = o & 31;
-                const uint32_t p0 = blo << sh, p1 = sh ? __builtin_amdgcn_alignbit(bhi, blo, 32 - sh) : bhi, p2 = sh ? bhi >> (32 - sh) : 0u;
-                atomicOr(&sbits[w], p0);
-                if (p1) atomicOr(&sbits[w + 1], p1);
-                if (p2) atomicOr(&sbits[w + 2], p2);
+        {   // the coded bits of this lane's decisions do not depend on any state: zero flag | e ones, a zero | mantissa from the top | sign.
+            // 2e + 3 bits: one dword unless some lane of the chunk has e >= 15 (emax is uniform)
+            const uint32_t o = stage_count + excl, w = o >> 5, sh = o & 31;
+            if (emax < 15) {
+                const uint32_t mant = a & ((1u << e) - 1), rev = __brev(mant) >> ((32 - e) & 31);            // mantissa bit e-1 first (e == 0: mant == 0)
+                uint32_t b = a ? ((((1u << e) - 1) << 1) | (rev << (e + 2)) | (uint32_t(d < 0) << (2 * e + 2))) : 1u;
+                b = valid ? b : 0u;
+                atomicOr(&sbits[w], b << sh);
+                atomicOr(&sbits[w + 1], (b >> 1) >> (31 - sh));                                               // b >> (32 - sh), also right for sh == 0
+            } else {
+                uint32_t blo = 1, bhi = 0;
+                if (a) {
+                    const uint32_t mant = a & ((1u << e) - 1), rev = e ? __brev(mant) >> (32 - e) : 0u;
+                    const unsigned long long v = ((unsigned long long)(((1u << e) - 1) << 1)) | ((unsigned long long)rev << (e + 2)) | ((unsigned long long)(d < 0) << (2 * e + 2));
+                    blo = uint32_t(v); bhi = uint32_t(v >> 32);
+                }
+                if (!valid) blo = bhi = 0;
+                const unsigned long long v = ((unsigned long long)bhi << 32) | blo;
+                atomicOr(&sbits[w], blo << sh);
+                atomicOr(&sbits[w + 1], uint32_t((v >> 1) >> (31 - sh)));
+                atomicOr(&sbits[w + 2], (bhi >> 1) >> (31 - sh));
             }
         }
         // Lanes of one context that all carry a zero residual (flat picture areas, letterbox bars) need no rounds: the r-th of them
@@ -1210,6 +1223,15 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     e->resolve_lds = ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);      // dynamic part; kResolveFixedLds is static
     e->resume_stride = uint32_t((80 + ((e->nkeys + 31) / 32) * 4 + 15) & ~15u);
     e->lds_states = size_t(e->nkeys) * 32 <= (48u << 10);                        // 338 contexts x 2 (3) sets x 32 B = 21.6 (32.4) KB
+    // How many k_resolve workgroups the dispatcher packs beside the four k_rangecode workgroups of a CU decides how the two kernels share
+    // its SIMDs, and the step time with it.  Measured with the 9-bit stream (4096x2160, 384 frames; workgroup LDS = 5 712 B static + this):
+    // 17.1 KB (what the kernel needs) 463 frames/s, 17.9 KB 493, 18.1-19.2 KB 622-643, 19.4 KB and more 453-471.  The workgroup asks for
+    // what puts it in the good band.
+    {
+        const size_t sweet = 19088, have = size_t(kResolveFixedLds) + e->resolve_lds;
+        if (!(size_t(e->nkeys) * 32 <= (48u << 10)) && have < sweet) e->resolve_lds += sweet - have;
+        if (const char* x = getenv("RCGPU_RESOLVE_LDS_PAD")) e->resolve_lds += size_t(std::max(0, atoi(x)));       // for re-measuring the band
+    }
     if (e->lds_states) { e->resolve_lds += size_t(e->nkeys) * 32; e->resume_stride = uint32_t(80 + e->nkeys * 32); }
     e->frame_payload = size_t(payload_bytes(cfg->pixfmt, cfg->width, cfg->height, cfg->line_bytes, cfg->flags));
 

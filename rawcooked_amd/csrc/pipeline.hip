@@ -157,12 +157,12 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
             rcgpu_ffv1_config c = videos[vi].cfg;
             c.device = L.device;
             if (li == 0) {
-                // frames in flight: what the device holds (85 % of its free memory, shared by the job's tracks), at most 384 -- where
+                // frames in flight: what the device holds (85 % of its free memory, shared by the job's tracks), at most 336 -- where
                 // k_resolve's time, which grows with the batch, meets the serial range-coder chain of a slice, which does not
                 //  --, and evened out over the batches of the sequence
                 const uint64_t per = std::max<uint64_t>(1, ffv1_device_bytes_per_frame(c));
                 const uint64_t share = videos.size() * uint64_t((cnt + ndev_used - 1) / ndev_used);      // encoders that will live on this device
-                uint64_t f = opt.batch ? opt.batch : std::min<uint64_t>(384 / uint64_t((cnt + ndev_used - 1) / ndev_used), uint64_t(double(free_b) * 0.85 / double(share)) / per);
+                uint64_t f = opt.batch ? opt.batch : std::min<uint64_t>(336 / uint64_t((cnt + ndev_used - 1) / ndev_used), uint64_t(double(free_b) * 0.85 / double(share)) / per);
                 f = std::max<uint64_t>(1, f);
                 const uint64_t n = std::max<uint64_t>(1, videos[vi].frames);
                 const uint64_t per_lane = (n + uint64_t(cnt) - 1) / uint64_t(cnt);

@@ -13,7 +13,7 @@ rows = db.execute(f"select name, start, end from {view} order by start").fetchal
 rows = [(n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip(), s, e) for n, s, e in rows]
 rows = [r for r in rows if r[0].startswith("k_")]
 starts = [i for i, r in enumerate(rows) if r[0] == "k_model"]
-# the pipeline leg = the last 5 k_model launches (1920 frames / 384)
+# the pipeline leg = the last 5 k_model launches (1920 frames / the batch)
 starts = starts[-5:]
 t00 = rows[starts[0]][1]
 prev_end = None
