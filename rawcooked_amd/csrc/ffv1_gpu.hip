@@ -71,6 +71,7 @@ constexpr int kMaxDecPerSample = 35;              // 2*16+3 for 17-bit residuals
 constexpr int kStageEntries = kPieceEntries + 64 * kMaxDecPerSample + 24;   // carry + one chunk (+ slack); a multiple of 16
 constexpr int kStageBitDwords = (kStageEntries + 31) / 32 + 7;              // the coded bits of the staged decisions (+ room for the widest OR)
 constexpr int kStageMaxPieces = kStageEntries / kPieceEntries + 1;         // pieces one flush can emit (41) + 1
+static_assert(kStageBitDwords <= 128, "the bit stage is cleared in two passes of 64 lanes");
 static_assert(kStageEntries % 16 == 0 && (kStageBitDwords * 4) % 16 == 0, "LDS areas stay 16-byte aligned");
 constexpr int kResolveFixedLds = kStageEntries + kStageBitDwords * 4 + kStageMaxPieces * 16 + 64 * 32 + 512 + 2 * 256;   // k_resolve: stage bytes | stage bits | piece tails | slots | transitions | powers
 
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = rs_touched[i];
         for (uint32_t i = lane; i < uint32_t(kStageBitDwords); i += 64) sbits[i] = i < 2 ? reinterpret_cast<const uint32_t*>(rs + 72)[i] : 0u;
         if (lane < 14) reinterpret_cast<uint32_t*>(stage)[lane] = reinterpret_cast<const uint32_t*>(rs + 16)[lane];
-        stage_count = *reinterpret_cast<const uint32_t*>(rs);
+        stage_count = uint32_t(__builtin_amdgcn_readfirstlane(int(*reinterpret_cast<const uint32_t*>(rs))));
     }
     uint32_t piece_base = 0;              // piece index inside this segment's window
     const uint32_t sym_begin = min(G.nsamp, seg * G.seg_q), sym_end = min(G.nsamp, (seg + 1) * G.seg_q);
@@ -429,35 +430,46 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     auto bits56 = [&](uint32_t byte) -> uint2 {
         const uint32_t w = byte >> 2, sh = (byte & 3) * 8;
         const uint32_t a = sbits[w], b = sbits[w + 1], c = sbits[w + 2];
-        const uint32_t lo = sh ? __builtin_amdgcn_alignbit(b, a, sh) : a, hi = sh ? __builtin_amdgcn_alignbit(c, b, sh) : b;
-        return make_uint2(lo, hi & 0x00FFFFFFu);
+        return make_uint2(__builtin_amdgcn_alignbit(b, a, sh), __builtin_amdgcn_alignbit(c, b, sh) & 0x00FFFFFFu);     // a shift of 0 hands back the low dword
     };
+    // Full pieces leave for HBM, what did not fill one moves to the front.  Every loop here is written out with its trip structure (a
+    // piece index per lane, at most three passes): left to itself the compiler unrolls such loops eightfold with 64-bit indices and
+    // splits the 16-byte stores -- three hundred instructions per chunk for forty stores.
+    uint8_t* const out_bytes = reinterpret_cast<uint8_t*>(out32);
     auto flush_full = [&]() {
         WAVE_SYNC();
-        const uint32_t np = stage_count / kPieceEntries, ndw = (stage_count + 31) / 32 + 1;      // ndw: bit-stage dwords that may hold a bit
-        uint4* out128 = reinterpret_cast<uint4*>(out32);
-        if (uint32_t(lane) < np) {                                     // lane p puts piece p's last quarter together: t 48..55, then its 56 bits
-            const uint2 t = *reinterpret_cast<const uint2*>(stage + lane * kPieceEntries + 48), b = bits56(uint32_t(lane) * 7);
-            ptail[lane] = make_uint4(t.x, t.y, b.x, b.y);
+        const uint32_t np = stage_count / kPieceEntries;                  // uniform, < kStageMaxPieces
+        if (np) {
+            if (uint32_t(lane) < np) {                                    // lane p puts piece p's last quarter together: t 48..55, then its 56 bits
+                const uint2 t = *reinterpret_cast<const uint2*>(stage + lane * kPieceEntries + 48), b = bits56(uint32_t(lane) * 7);
+                ptail[lane] = make_uint4(t.x, t.y, b.x, b.y);
+            }
+            WAVE_SYNC();
+            // 16 bytes per lane, four lanes cover one 64-byte piece, sixteen pieces per pass
+            const uint32_t q = lane & 3;
+            uint32_t pc = uint32_t(lane) >> 2;
+            const uint8_t* lsrc = q < 3 ? stage + pc * kPieceEntries + q * 16                                  // 8-byte aligned: 56 = 7 x 8
+                                        : reinterpret_cast<const uint8_t*>(ptail + pc);
+            const uint32_t lstep = q < 3 ? 16u * kPieceEntries : 16u * 16u;
+            size_t goff = size_t(piece_base + pc) * kGroupPieceBytes + q * 16;
+#pragma clang loop unroll(disable) vectorize(disable)
+            for (; pc < np; pc += 16, lsrc += lstep, goff += 16u * size_t(kGroupPieceBytes)) {
+                const uint2 t0 = reinterpret_cast<const uint2*>(lsrc)[0], t1 = reinterpret_cast<const uint2*>(lsrc)[1];
+                *reinterpret_cast<uint4*>(out_bytes + goff) = make_uint4(t0.x, t0.y, t1.x, t1.y);
+            }
+            // what did not fill a piece (< 56 decisions: 14 dwords of t, 7 bytes of bits) moves to the front; the bit stage is zero behind
+            // the staged decisions at all times, so the 56 bits read here need no mask
+            uint32_t keep = 0;
+            if (lane < 14) keep = reinterpret_cast<const uint32_t*>(stage)[np * 14 + lane];
+            const uint2 kb = bits56(np * 7);
+            const uint32_t ndw = (stage_count + 31) / 32 + 1;             // bit-stage dwords that may hold a bit: at most kStageBitDwords - 6
+            WAVE_SYNC();
+            if (lane < 14) reinterpret_cast<uint32_t*>(stage)[lane] = keep;
+            if (uint32_t(lane) < ndw) sbits[lane] = lane == 0 ? kb.x : lane == 1 ? kb.y : 0u;
+            if (uint32_t(lane) + 64 < ndw) sbits[lane + 64] = 0u;
+            piece_base += np;
+            stage_count -= np * kPieceEntries;
         }
-        WAVE_SYNC();
-        for (uint32_t idx = lane; idx < np * 4; idx += 64) {          // 16 bytes per lane: four lanes cover one 64-byte piece
-            const uint32_t pc = idx >> 2, q = idx & 3;
-            const uint2* tp = q < 3 ? reinterpret_cast<const uint2*>(stage + pc * kPieceEntries + q * 16)      // 8-byte aligned: 56 = 7 x 8
-                                    : reinterpret_cast<const uint2*>(ptail + pc);
-            const uint2 t0 = tp[0], t1 = tp[1];
-            out128[size_t(piece_base + pc) * (kGroupPieceBytes / 16) + q] = make_uint4(t0.x, t0.y, t1.x, t1.y);
-        }
-        // what did not fill a piece (< 56 decisions: 14 dwords of t, 7 bytes of bits) moves to the front; the bit stage is zero behind the
-        // staged decisions at all times, so the 56 bits read here need no mask
-        uint32_t keep = 0;
-        if (lane < 14) keep = reinterpret_cast<const uint32_t*>(stage)[np * 14 + lane];
-        const uint2 kb = bits56(np * 7);
-        WAVE_SYNC();
-        if (lane < 14 && np) reinterpret_cast<uint32_t*>(stage)[lane] = keep;
-        for (uint32_t i = lane; i < ndw; i += 64) sbits[i] = i == 0 ? kb.x : i == 1 ? kb.y : 0u;
-        piece_base += np;
-        stage_count -= np * kPieceEntries;
         WAVE_SYNC();
     };
     flush_full();
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         const uint2 Mb = *reinterpret_cast<const uint2*>(mrow + 1);    // S[6], S[7]
         const uint32_t incl = wave_incl_scan(ndec, lane);
         const uint32_t excl = incl - ndec;
-        const uint32_t total = __shfl(incl, 63);
+        const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));        // a scalar: stage_count and what the flush derives from it stay in SGPRs
 
         // --- which lanes share a context?  One LDS write/read finds the colliding lanes; a scalar loop over the
         // distinct colliding keys gives every lane its predecessor, its group leader and whether it is the last.
