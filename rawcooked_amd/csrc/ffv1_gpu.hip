@@ -357,6 +357,13 @@ __device__ const act_masks kActMasks = make_act_masks();
 // through LDS need no barrier and, above all, no s_waitcnt vmcnt(0) -- which __syncthreads() implies and which would put the HBM
 // latency of every prefetch and store on the critical path.  Only the compiler must keep the order.
 #define WAVE_SYNC() asm volatile("" ::: "memory")
+// Timing build (-DRCGPU_EXP_PROF, tools/prof_resolve.py): the shader clock around the phases of a chunk, summed over all wavefronts.
+#ifdef RCGPU_EXP_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_T(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += now_ - tlast; tlast = now_; }
+#else
+#define PROF_T(i)
+#endif
 template <bool LDS_STATES>
 __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
@@ -475,6 +482,9 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     flush_full();
 
     const unsigned long long lane_bit = 1ull << lane;
+#ifdef RCGPU_EXP_PROF
+    unsigned long long prof[12] = {}; unsigned long long tlast = __builtin_readcyclecounter();
+#endif
     // Software pipeline over chunks of 64 symbols.  While chunk k is binarised, the symbols of chunk k+2 and the context states of
     // chunk k+1 are already on their way from HBM, so neither latency sits on the chunk's critical path:
     //   sv_cur / sv_nxt   symbols of chunk k (in registers) and k+1 (loaded one chunk ago)
@@ -510,6 +520,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         const uint32_t incl = wave_incl_scan(ndec, lane);
         const uint32_t excl = incl - ndec;
         const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));        // a scalar: stage_count and what the flush derives from it stay in SGPRs
+        PROF_T(0)
 
         // --- which lanes share a context?  One LDS write/read finds the colliding lanes; a scalar loop over the
         // distinct colliding keys gives every lane its predecessor, its group leader and whether it is the last.
@@ -543,11 +554,13 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
             lm &= ~m;
         }
 
+        PROF_T(1)
         // --- group leaders install the context's 32 states in their LDS slot: all 128 on first use in this slice (states_coded = 0),
         // the previous chunk's result if it used the same context, else what was prefetched from the slice's state array in HBM.
         // Everything this wavefront has in flight is at least most of a chunk old: the wait is (almost) free, and it also makes
         // the write-backs of the previous chunk visible before the next prefetch is issued.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PROF_T(2)
         const bool first = !LDS_STATES && valid && pred < 0;
         uint4 s0 = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u), s1 = s0;
         if (first) {
@@ -571,6 +584,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         sv_nxt = i + 128 < sym_end ? in[i + 128] : 0;
         WAVE_SYNC();
 
+        PROF_T(3)
         // --- rounds: a lane runs once its predecessor (same context, earlier in coding order) is done.
         unsigned long long done = 0;
         bool pending = valid;
@@ -599,6 +613,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                 atomicOr(&sbits[w + 2], (bhi >> 1) >> (31 - sh));
             }
         }
+        PROF_T(4)
         // Lanes of one context that all carry a zero residual (flat picture areas, letterbox bars) need no rounds: the r-th of them
         // sees state 0 after r "coded a 1" transitions, which the power tables give in a few look-ups.
         if (__ballot(zrun)) {
@@ -654,6 +669,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                         nx_s = NEXT(en_s);
                         if (nz) op[2 * e + 2] = uint8_t(en_s);
                     }
+                    PROF_T(9)
                     // ---- the two chains: state 10 for exponent bits 9.., state 31 for mantissa bits e-1 .. 9
                     if constexpr (L >= 3) {
 #pragma unroll 1
@@ -673,6 +689,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                             ST_PUT_IF(act, 31, nx);
                         }
                     }
+                    PROF_T(10)
                     // ---- phase 2: apply the independent transitions: pack the looked-up bytes, merge under the lane's mask
                     if constexpr (L == 0) MERGE(S[0], nx_z, 0xFFu);
                     if constexpr (L >= 1) {
@@ -695,8 +712,10 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 #undef NEXT
                     reinterpret_cast<uint4*>(sl)[0] = make_uint4(S[0], S[1], S[2], S[3]);
                     reinterpret_cast<uint4*>(sl)[1] = make_uint4(S[4], S[5], S[6], S[7]);
+                    PROF_T(11)
                     if (L >= 1 && nz) sl[ks] = uint8_t(nx_s);             // after the bulk write-back (LDS operations of a wave stay in order)
                 };
+                PROF_T(5)
                 if (emax >= 7) binarise(std::integral_constant<int, 3>());
                 else if (emax >= 3) binarise(std::integral_constant<int, 2>());
                 else if (emax >= 0) binarise(std::integral_constant<int, 1>());
@@ -707,16 +726,25 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
             WAVE_SYNC();
         }
 
+        PROF_T(5)
         // --- last lane of each group writes the states back
         if (!LDS_STATES && valid && last) {
             const uint4* sp = reinterpret_cast<const uint4*>(sl);
             uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
             gp[0] = sp[0]; gp[1] = sp[1];
         }
+        PROF_T(6)
         stage_count += total;
         flush_full();
+        PROF_T(7)
+#ifdef RCGPU_EXP_PROF
+        prof[8] += 1;
+#endif
         pkey = valid ? key : 0xFFFFFFFFu; pleader = leader;
     }
+#ifdef RCGPU_EXP_PROF
+    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_prof[i], prof[i]);
+#endif
     if (!last_seg) {      // park the unfinished piece and the bitmap (or the state table) for the next segment
         if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) rs_states[i] = reinterpret_cast<const uint4*>(lstates)[i];
         else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) rs_touched[i] = touched[i];
@@ -1673,3 +1701,12 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
     default: return -5;
     }
 }
+
+#ifdef RCGPU_EXP_PROF
+extern "C" int rcgpu_debug_prof(unsigned long long* out)      // timing build only: see PROF_T
+{
+    unsigned long long z[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof z) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess;
+}
+#endif

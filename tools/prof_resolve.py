@@ -16,7 +16,7 @@ buf = io.StringIO()
 with redirect_stdout(buf):
     bench.main()
 assert api.lib().rcgpu_debug_prof(out) == 0       # loaded by bench after torch's HIP runtime
-names = ["scan/decode symbol", "collision analysis", "vmcnt(0) wait", "install + prefetch issue", "coded bits", "rounds (binarise)", "state write-back", "flush", None, "  binarise: load + phase 1", "  binarise: chains", "  binarise: phase 2"]
+names = ["scan/decode symbol", "collision analysis", "vmcnt(0) wait", "install + prefetch issue", "coded bits", "rounds: rest (LDS drain, loop)", "state write-back", "flush", None, "  binarise: load + phase 1", "  binarise: chains", "  binarise: phase 2"]
 chunks = out[8]
 tot = sum(out[i] for i in range(12) if i != 8)
 print("chunks %d, cycles per chunk %.0f" % (chunks, tot / max(1, chunks)))
