@@ -498,8 +498,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(key_of(sv_cur)) * 32);
         P0 = gp[0]; P1 = gp[1];
     }
-    uint32_t pkey = 0xFFFFFFFFu;          // previous chunk: this lane's key (none yet) and its group's slot
-    int pleader = 0;
+    uint32_t ppack = 0xFFFFu;             // previous chunk: this lane's key (keys stay below 2^14; 0xFFFF = none yet) | its group's slot << 16
     for (uint32_t base = sym_begin; base < sym_end; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < sym_end;
@@ -526,9 +525,9 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         // distinct colliding keys gives every lane its predecessor, its group leader and whether it is the last.
         // did the previous chunk use this lane's context?  Its Hk entry still names one of the lanes that did.
         const uint32_t hp = valid ? uint32_t(Hk[key]) & 63u : 0u;
-        const uint32_t hp_key = uint32_t(__shfl(int(pkey), int(hp)));      // all lanes take part: the source lane may be past the end of this chunk
-        const bool fwd = !LDS_STATES && valid && hp_key == key;
-        const int fwd_slot = __shfl(pleader, int(hp));
+        const uint32_t hp_pack = uint32_t(__shfl(int(ppack), int(hp)));    // all lanes take part: the source lane may be past the end of this chunk
+        const bool fwd = !LDS_STATES && valid && (hp_pack & 0xFFFFu) == key;
+        const int fwd_slot = int(hp_pack >> 16);
         WAVE_SYNC();
         if (valid) Hk[key] = uint8_t(lane);
         WAVE_SYNC();
@@ -539,7 +538,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         unsigned long long lm = __ballot(valid && seen != uint32_t(lane));
         while (lm) {
             const int src = __ffsll((long long)lm) - 1;
-            const uint32_t k = __shfl(key, src);
+            const uint32_t k = uint32_t(__builtin_amdgcn_readlane(int(key), src));      // src is uniform: no trip through the LDS crossbar
             const bool mine = valid && key == k;
             const unsigned long long m = __ballot(mine);
             const bool allzero = __ballot(mine && a == 0) == m;        // a run of zero residuals: only state 0 moves, always by "coded a 1"
@@ -740,7 +739,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 #ifdef RCGPU_EXP_PROF
         prof[8] += 1;
 #endif
-        pkey = valid ? key : 0xFFFFFFFFu; pleader = leader;
+        ppack = (valid ? key : 0xFFFFu) | uint32_t(leader) << 16;
     }
 #ifdef RCGPU_EXP_PROF
     if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_prof[i], prof[i]);
