@@ -959,17 +959,10 @@ __global__ __launch_bounds__(256) void k_footer(const enc_const* __restrict__ C,
                                                 const uint32_t* __restrict__ out_len, uint32_t* __restrict__ tot_len,
                                                 uint32_t* __restrict__ err, const uint2* __restrict__ events)
 {
-    // slicing-by-4 tables: T[k][b] = crc of byte b followed by k zero bytes
-    __shared__ uint32_t T[4][256];
-    __shared__ uint32_t part[256];
+    __shared__ uint32_t T[4][256], TM[4][256];          // slicing-by-4 tables and the tile multiplier's (crc_dev.h)
+    __shared__ uint32_t part[4];
     const int tid = threadIdx.x;
-    {
-        uint32_t c = uint32_t(tid) << 24;
-        for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
-        T[0][tid] = c;
-    }
-    __syncthreads();
-    for (int k = 1; k < 4; k++) { const uint32_t p = T[k - 1][tid]; T[k][tid] = (p << 8) ^ T[0][p >> 24]; __syncthreads(); }
+    crc_tables(T, tid);
     const uint32_t chain = blockIdx.x;
     const uint32_t S = C->S, f = chain / S, s = chain - f * S;
     const slice_geom G = geom[s];
@@ -991,40 +984,7 @@ __global__ __launch_bounds__(256) void k_footer(const enc_const* __restrict__ C,
     __syncthreads();
     if (C->v1) { if (tid == 0) tot_len[chain] = len; return; }      // version 1: the frame is the coder's bytes
     if (!C->ec) { if (tid == 0) tot_len[chain] = len + 3; return; }
-    // Bulk: 16 KB tiles read fully coalesced -- thread t owns the 64-byte chunk t of every tile.  Its chunks are 16 KB
-    // apart, so a Horner recurrence with the constant M = x^(8*16384) accumulates them:  acc = acc*M + crc(chunk);
-    // multiplication by M is four table look-ups (TM, built once per block).  The sub-tile remainder is done with
-    // contiguous per-thread segments.  crc(A||B) = crc(A) * x^(8|B|) + crc(B) glues everything together.
-    constexpr uint32_t kTile = 16384, kChunk = kTile / 256;
-    __shared__ uint32_t TM[4][256];
-    const uint32_t total = len + 4;
-    const uint32_t ntiles = total / kTile, rem = total - ntiles * kTile;
-    const uint32_t M = gf_xpow8(kTile);
-    for (int k = 0; k < 4; k++) TM[k][tid] = gf_mulmod(uint32_t(tid) << (8 * k), M);
-    __syncthreads();
-    uint32_t acc = 0;
-    for (uint32_t t = 0; t < ntiles; t++) {
-        const uint4* p4 = reinterpret_cast<const uint4*>(out + size_t(t) * kTile + size_t(tid) * kChunk);
-        uint32_t cc = 0;
-#pragma unroll
-        for (int q = 0; q < int(kChunk / 16); q++) {
-            const uint4 v = p4[q];
-            const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                cc ^= __builtin_bswap32(w[j]);
-                cc = T[3][cc >> 24] ^ T[2][(cc >> 16) & 0xFF] ^ T[1][(cc >> 8) & 0xFF] ^ T[0][cc & 0xFF];
-            }
-        }
-        acc = TM[3][acc >> 24] ^ TM[2][(acc >> 16) & 0xFF] ^ TM[1][(acc >> 8) & 0xFF] ^ TM[0][acc & 0xFF] ^ cc;
-    }
-    if (ntiles) acc = gf_mulmod(acc, gf_xpow8((unsigned long long)kChunk * (255 - tid) + rem));
-    const uint8_t* rp = out + size_t(ntiles) * kTile;
-    const uint32_t seg = ((rem + 255) / 256 + 3) & ~3u;
-    const uint32_t beg = min(rem, uint32_t(tid) * seg), end = min(rem, beg + seg);
-    uint32_t c = 0;
-    for (uint32_t i = beg; i < end; i++) c = (c << 8) ^ T[0][(c >> 24) ^ rp[i]];
-    c = gf_mulmod(c, gf_xpow8(rem - end)) ^ acc;
+    uint32_t c = block_crc_share(out, len + 4, T, TM, tid);       // the tiled CRC the decoder's k_dec_crc uses too
     // xor-reduce over the block
     for (int o = 32; o; o >>= 1) c ^= __shfl_xor(c, o);
     if ((tid & 63) == 0) part[tid >> 6] = c;
@@ -1061,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_gather(const enc_const* __restrict__ C,
                                                 const uint32_t* __restrict__ tot_len, const unsigned long long* __restrict__ slice_dst,
                                                 uint8_t* __restrict__ packets, unsigned long long packet_stride)
 {
-    const uint32_t chain = blockIdx.x;           // chains on x: grid.y is limited to 65535
+    const uint32_t chain = blockIdx.x;           // chains on x, the eight blocks of a slice on y
     const uint32_t S = C->S, f = chain / S, s = chain - f * S;
     const slice_geom G = geom[s];
     const uint8_t* src = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
