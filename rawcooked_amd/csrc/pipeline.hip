@@ -85,16 +85,12 @@ struct pipeline::impl {
 
 pipeline::impl::~impl()
 {
-    // Pinned buffers (unpinning 7 GB: ~1.5 s) and device buffers (140 GB: ~1.5 s) are given back side by side.
+    // Device buffers (140 GB: ~2 s) first, then the pinned ones (download ring + upload slots, ~7 GB: 0.5 s).  Side by side they
+    // take longer than one after the other (measured: 4.0 against 3.3 s): both unmap address space of this process, as does the muxer
+    // closing its mapped file meanwhile.
     const bool tr = getenv("RCGPU_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    std::thread pinned([&] {
-        for (lane_t& L : lanes) for (uint8_t*& c : L.chunks) if (c) { (void)hipHostFree(c); c = nullptr; }
-        for (uint8_t* s : all_slots) (void)hipHostFree(s);
-        all_slots.clear();
-        if (tr) fprintf(stderr, "rcgpu trace: release: pinned buffers after %.3f s\n", since());
-    });
     for (lane_t& L : lanes) {
         (void)hipSetDevice(L.device);
         for (rcgpu_ffv1* e : L.enc) if (e) rcgpu_ffv1_destroy(e);
@@ -109,7 +105,9 @@ pipeline::impl::~impl()
         if (L.h_sizes) (void)hipHostFree(L.h_sizes);
         if (L.h_err) (void)hipHostFree(L.h_err);
     }
-    pinned.join();
+    for (lane_t& L : lanes) for (uint8_t* c : L.chunks) if (c) (void)hipHostFree(c);
+    for (uint8_t* s : all_slots) (void)hipHostFree(s);
+    if (tr) fprintf(stderr, "rcgpu trace: release: pinned buffers after %.3f s\n", since());
 }
 
 pipeline::pipeline() : p(new impl) {}
@@ -242,10 +240,12 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     s.slots_wanted = s.opt.in_slots ? s.opt.in_slots : std::min<size_t>(N, std::max<size_t>(2 * readers, std::min<size_t>(64 * size_t(nl), (size_t(8) << 30) / std::max<size_t>(1, s.slot_bytes))));
     s.slots_wanted = std::max<size_t>(s.slots_wanted, std::min<size_t>(N, 2));
     for (lane_t& L : s.lanes) {
-        // ring: one batch of packets at the payload's size (FFV1 rarely expands), within 1..32 GB, in chunks that hold at least two
-        // worst-case packets
+        // ring: 1..4 GB in chunks that hold at least two worst-case packets.  It only has to cover the writers' reaction time: a ring that
+        // held a whole batch of packets (17.8 GB at 4K) gave the same rates (host to host 482 frames/s with 2, 4, 8 or 17.8 GB) and cost
+        // 1.4 s of page-locking at the start of a job and as much again when it ended (1000 4K files: 7.4 s with 17.8 GB, 6.5 s with 4)
         L.chunk_bytes = std::max<size_t>(size_t(256) << 20, 2 * max_pkt);
-        uint64_t want = s.opt.out_ring_bytes ? s.opt.out_ring_bytes : std::min<uint64_t>(uint64_t(32) << 30, std::max<uint64_t>(uint64_t(1) << 30, uint64_t(maxF) * max_payload));
+        uint64_t want = s.opt.out_ring_bytes ? s.opt.out_ring_bytes : std::min<uint64_t>(uint64_t(4) << 30, std::max<uint64_t>(uint64_t(1) << 30, uint64_t(maxF) * max_payload));
+        if (const char* x = getenv("RCGPU_OUT_RING_MB")) if (!s.opt.out_ring_bytes && atoll(x) > 0) want = uint64_t(atoll(x)) << 20;        // for sizing experiments
         uint64_t total_need = 0; for (const batch_t& b : batches) if (b.lane == L.id) total_need += uint64_t(b.n) * s.max_packet[b.video];
         want = std::min<uint64_t>(want, std::max<uint64_t>(total_need, L.chunk_bytes));
         L.max_chunks = std::max<size_t>(2, size_t((want + L.chunk_bytes - 1) / L.chunk_bytes));
