@@ -425,20 +425,49 @@ def main():
         moved = [0]
 
         def pump():
-            s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            # knobs for finding out what a copy pattern costs beside the kernels (all through hipMemcpyAsync on one stream per direction)
+            mode = os.environ.get("RCGPU_DMA_NOISE", "both")             # both | up | down
+            mb = float(os.environ.get("RCGPU_DMA_NOISE_MB", "1024"))     # bytes per copy
+            per_sync = int(os.environ.get("RCGPU_DMA_NOISE_SYNC", "20")) # copies per direction between two host synchronisations
+            nbuf = int(os.environ.get("RCGPU_DMA_NOISE_BUFS", "0"))      # > 0: that many separate pinned buffers per direction (hipHostMalloc)
+            flags = int(os.environ.get("RCGPU_DMA_NOISE_FLAGS", "1"), 0) # hipHostMalloc flags for them (1 = portable)
+            spread = int(os.environ.get("RCGPU_DMA_NOISE_SPREAD_GB", "1"))   # device region the copies walk through
+            ev_every = int(os.environ.get("RCGPU_DMA_NOISE_EVENTS", "0"))    # > 0: record an event every so many copies
+            sz = int(mb * (1 << 20)) & ~4095
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+            hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            s_up, s_dn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            dreg_in = torch.empty(spread << 30, dtype=torch.uint8, device=dev); dreg_out = torch.empty(spread << 30, dtype=torch.uint8, device=dev)
+            if nbuf > 0:
+                def pinned(n):
+                    q = ctypes.c_void_p(); assert hip.hipHostMalloc(ctypes.byref(q), ctypes.c_size_t(n), ctypes.c_uint(flags)) == 0; return q.value
+                hin = [pinned(sz) for _ in range(nbuf)]; hout = [pinned(sz) for _ in range(nbuf)]
+            else:
+                nbuf = max(1, (1 << 30) // sz)
+                hin = [hp_in.data_ptr() + k * sz for k in range(nbuf)]; hout = [hp_out.data_ptr() + k * sz for k in range(nbuf)]
+            evs = []
+            for _ in range(64):
+                e_ = ctypes.c_void_p(); hip.hipEventCreateWithFlags(ctypes.byref(e_), ctypes.c_uint(2)); evs.append(e_)
+            nd = max(1, (spread << 30) // sz)
+            k = 0
             while not stop.is_set():
-                with torch.cuda.stream(s1):
-                    dd_in.copy_(hp_in, non_blocking=True)
-                with torch.cuda.stream(s2):
-                    hp_out.copy_(dd_out, non_blocking=True)
-                s1.synchronize(); s2.synchronize(); moved[0] += 2
-        noise = _th.Thread(target=pump); noise.start()
+                for _ in range(per_sync):
+                    if mode != "down":
+                        assert hip.hipMemcpyAsync(dreg_in.data_ptr() + (k % nd) * sz, hin[k % nbuf], sz, 1, s_up.cuda_stream) == 0; moved[0] += sz
+                    if mode != "up":
+                        assert hip.hipMemcpyAsync(hout[k % nbuf], dreg_out.data_ptr() + (k % nd) * sz, sz, 2, s_dn.cuda_stream) == 0; moved[0] += sz
+                    k += 1
+                    if ev_every and k % ev_every == 0:
+                        hip.hipEventRecord(evs[(k // ev_every) % 64], s_up.cuda_stream); hip.hipEventRecord(evs[(k // ev_every + 32) % 64], s_dn.cuda_stream)
+                s_up.synchronize(); s_dn.synchronize()
+        noise = _th.Thread(target=pump); noise.start(); t_noise = time.perf_counter()
 
     # ---- the headline: device-resident steps, timed as the driver's contract says (barrier + synchronize on both sides, max over ranks)
     dt = rdist.timed_steps(dist, dev, step, args.steps, args.warmup, torch.cuda.synchronize)
     if noise is not None:
         stop.set(); noise.join()
-        print("bench: dma noise moved %d GiB during warm-up and timed steps" % moved[0], file=sys.stderr)
+        print("bench: dma noise moved %.0f GB during warm-up and timed steps = %.1f GB/s beside the kernels" % (moved[0] / 1e9, moved[0] / 1e9 / max(1e-9, time.perf_counter() - t_noise)), file=sys.stderr)
     kt = enc.kernel_times()          # HIP events of the last timed step, recorded on the launch streams
     flags = enc.error_flags()        # the device-pointer API only enqueues: this is where an overflow would show (raises)
 
@@ -524,8 +553,14 @@ def main():
     torch.cuda.empty_cache()
 
     if "host" in legs:
+        if os.environ.get("RCGPU_DMA_NOISE_HOST"):       # experiment: the copy pump beside the host pipeline -- do the engines have room?
+            stop.clear(); moved[0] = 0; t_noise = time.perf_counter()
+            noise = threading.Thread(target=pump); noise.start()
         hp, ok = host_pipeline_leg(api, cfg, host_ring, args.host_frames, F, expect, barrier, reduce_max, args.host_lanes, args.host_readers, args.host_writers, args.host_slots)
         ok_all &= ok
+        if os.environ.get("RCGPU_DMA_NOISE_HOST"):
+            stop.set(); noise.join()
+            print("bench: dma noise beside the host pipeline: %.0f GB = %.1f GB/s" % (moved[0] / 1e9, moved[0] / 1e9 / max(1e-9, time.perf_counter() - t_noise)), file=sys.stderr)
         n_loc, _, dt_all = hp.pop("_local")
         if result is not None:
             hp["value"] = round(world * n_loc / dt_all, 2); hp["unit"] = "frames/s"; hp["n_gpus"] = world

@@ -1048,6 +1048,7 @@ __global__ __launch_bounds__(256) void k_gather(const enc_const* __restrict__ C,
 // Host side
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kMaxSeg = 64;
+constexpr uint32_t kMaxWindows = 8, kWindows = 2;      // hand-over windows between k_resolve and k_rangecode
 constexpr uint32_t kSubBatch = 16;           // frames whose int32 planes rcgpu_ffv1_debug_fetch(0) returns (k_unpack on demand)
 
 // What an encoder of this configuration writes into its configuration record.
@@ -1095,6 +1096,29 @@ size_t ffv1_max_packet_bytes_for(const rcgpu_ffv1_config& cfg)
 }
 }  // namespace rc
 
+// Small control transfers (decision counts to the host, window offsets back, packet sizes, the error word) go through a kernel on the
+// encoder's stream, not through hipMemcpyAsync: a copy is a command for the copy engines, which the pipeline keeps busy with batches of
+// 50 MB payload and packet copies; a kernel keeps the control path independent of their queues.  (No measurable difference on the
+// host pipeline's rate, 530 against 534 frames/s; what that rate was waiting for were more copy streams, pipeline.hip.)
+// Pinned host memory is mapped into the device's address space: a kernel reads and writes it directly.
+namespace {
+__global__ __launch_bounds__(256) void k_copy8(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, size_t n)
+{
+    for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256) dst[i] = src[i];
+}
+}  // namespace
+namespace rc {
+hipError_t copy_by_kernel(void* dst, const void* src, size_t bytes, hipStream_t stream)       // bytes: a multiple of 8, both 8-byte aligned
+{
+    if (!bytes) return hipSuccess;
+    const size_t n = bytes / 8;
+    hipLaunchKernelGGL(k_copy8, dim3(unsigned(std::min<size_t>(1024, (n + 255) / 256))), dim3(256), 0, stream,
+                       static_cast<unsigned long long*>(dst), static_cast<const unsigned long long*>(src), n);
+    return hipGetLastError();
+}
+int copy_by_kernel_on(void* dst, const void* src, size_t bytes, void* hip_stream) { return int(copy_by_kernel(dst, src, bytes, static_cast<hipStream_t>(hip_stream))); }
+}  // namespace rc
+
 struct rcgpu_ffv1 {
     rcgpu_ffv1_config cfg{};
     ffv1::stream_params sp{};
@@ -1115,7 +1139,7 @@ struct rcgpu_ffv1 {
     uint32_t* d_seg_pieces = nullptr;              // [seg][chain] 64-byte pieces produced in a segment
     unsigned long long* d_group_off = nullptr;     // [seg][group] byte offset inside the segment's window
     uint8_t* d_k3_resume = nullptr; rc_resume* d_k4_resume = nullptr;
-    uint8_t* d_window[2] = { nullptr, nullptr }; size_t window_cap = 0;
+    uint8_t* d_window[kMaxWindows] = {}; size_t window_cap = 0; uint32_t nwin = 2;
     uint8_t* d_cbuf = nullptr; uint32_t* d_out_len = nullptr; uint32_t* d_tot_len = nullptr;
     unsigned long long* d_slice_dst = nullptr; uint32_t* d_err = nullptr; uint2* d_events = nullptr;
     // host staging for the convenience path
@@ -1153,9 +1177,10 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     void* bufs[] = { e->d_const, e->d_geom, e->d_hdr, e->d_frame_ptrs, e->d_planes, e->d_sym, e->d_states, e->d_ndec, e->d_total_n, e->d_seg_pieces,
-                     e->d_group_off, e->d_k3_resume, e->d_k4_resume, e->d_window[0], e->d_window[1], e->d_cbuf, e->d_out_len, e->d_tot_len,
+                     e->d_group_off, e->d_k3_resume, e->d_k4_resume, e->d_cbuf, e->d_out_len, e->d_tot_len,
                      e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes };
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (uint8_t* w : e->d_window) if (w) (void)hipFree(w);
     void* hosts[] = { e->h_psizes, e->h_ndec_pinned, e->h_frame_ptrs, e->h_total_n, e->h_seg_pieces, e->h_group_off, e->h_err };
     for (void* h : hosts) if (h) (void)hipHostFree(h);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1246,6 +1271,8 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         }
     e->nseg = cfg->segments ? cfg->segments : std::max(1u, std::min(32u, min_nsamp / 1024));
     c.nseg = e->nseg;
+    e->nwin = kWindows;
+    if (const char* x = getenv("RCGPU_WINDOWS")) e->nwin = uint32_t(std::min<int>(kMaxWindows, std::max(2, atoi(x))));       // for measuring
 
     // slice geometry (FFV1_Slice.cpp:153-156), header decisions, raw-byte buffers
     std::vector<uint16_t> hdr;
@@ -1282,12 +1309,12 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     DM(e->d_frame_ptrs, sizeof(void*) * F);
     DM(e->d_sym, size_t(F) * c.samples_per_frame * 4);
     DM(e->d_states, e->lds_states ? 16 : nchains * e->nkeys * 32);
-    DM(e->d_ndec, nchains * nseg * 8); DM(e->d_total_n, nchains * 8); DM(e->d_seg_pieces, nchains * nseg * 4); DM(e->d_group_off, ngroups * nseg * 8);
+    DM(e->d_ndec, nchains * nseg * 8); DM(e->d_total_n, nchains * 8); DM(e->d_seg_pieces, nchains * nseg * 4 + 8); DM(e->d_group_off, ngroups * nseg * 8);
     DM(e->d_k3_resume, nchains * e->resume_stride); DM(e->d_k4_resume, nchains * sizeof(rc_resume));
     DM(e->d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
     DM(e->d_out_len, nchains * 4); DM(e->d_tot_len, nchains * 4); DM(e->d_slice_dst, nchains * 8); DM(e->d_err, 16); DM(e->d_events, sizeof(uint2) * kMaxCarryEvents);
     HM(e->h_ndec_pinned, nchains * nseg * 8); HM(e->h_frame_ptrs, sizeof(void*) * F); HM(e->h_total_n, nchains * 8);
-    HM(e->h_seg_pieces, nchains * nseg * 4); HM(e->h_group_off, ngroups * nseg * 8);
+    HM(e->h_seg_pieces, nchains * nseg * 4 + 8); HM(e->h_group_off, ngroups * nseg * 8);
 #undef DM
 #undef HM
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
@@ -1347,7 +1374,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     };
 
     for (uint32_t i = 0; i < n; i++) e->h_frame_ptrs[i] = d_frames[i];
-    HIP_TRY(hipMemcpyAsync(e->d_frame_ptrs, e->h_frame_ptrs, sizeof(void*) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(rc::copy_by_kernel(e->d_frame_ptrs, e->h_frame_ptrs, sizeof(void*) * n, st));
     HIP_TRY(hipMemsetAsync(e->d_ndec, 0, size_t(nchains) * nseg * 8, st));
     HIP_TRY(hipMemsetAsync(e->d_err, 0, 16, st));
     uint32_t max_tiles = 0;
@@ -1355,7 +1382,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(timed(1, st, [&] { hipLaunchKernelGGL(k_model, dim3(max_tiles, nchains), dim3(256), size_t(c.planes) * kTileRows * kTileCols * 4, st,
                                                   e->d_const, e->d_geom, e->d_frame_ptrs, e->d_sym, e->d_ndec); }));
     // The exact decision counts size the stream windows: one host round trip per batch.
-    HIP_TRY(hipMemcpyAsync(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * nseg * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(rc::copy_by_kernel(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * nseg * 8, st));
     HIP_TRY(hipStreamSynchronize(st));
     uint64_t total_dec = 0;
     for (uint32_t chain = 0; chain < nchains; chain++) {
@@ -1386,21 +1413,21 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         for (auto& w : e->d_window) { if (w) HIP_TRY(hipFree(w)); w = nullptr; }
         e->window_cap = 0;
         const size_t want = window_need + window_need / 8 + (1u << 20);
-        for (int k = 0; k < (nseg > 1 ? 2 : 1); k++) {
+        for (uint32_t k = 0; k < (nseg > 1 ? e->nwin : 1u); k++) {
             hipError_t he = hipMalloc(reinterpret_cast<void**>(&e->d_window[k]), want);
             if (he != hipSuccess) return fail(101, "ffv1: cannot allocate %zu bytes for a decision-stream window of %u frames: %s -- lower max_batch", want, n, hipGetErrorString(he));
         }
         e->window_cap = want;
     }
-    HIP_TRY(hipMemcpyAsync(e->d_total_n, e->h_total_n, size_t(nchains) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(e->d_seg_pieces, e->h_seg_pieces, size_t(nchains) * nseg * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(e->d_group_off, e->h_group_off, size_t(ngroups) * nseg * 8, hipMemcpyHostToDevice, st));
-    // k_resolve(seg j) on the caller's stream, k_rangecode(seg j) on rc_stream; window j&1 is reused once k_rangecode(j-2) is done
+    HIP_TRY(rc::copy_by_kernel(e->d_total_n, e->h_total_n, size_t(nchains) * 8, st));
+    HIP_TRY(rc::copy_by_kernel(e->d_seg_pieces, e->h_seg_pieces, (size_t(nchains) * nseg * 4 + 7) & ~size_t(7), st));
+    HIP_TRY(rc::copy_by_kernel(e->d_group_off, e->h_group_off, size_t(ngroups) * nseg * 8, st));
+    // k_resolve(seg j) on the caller's stream, k_rangecode(seg j) on rc_stream; window j % nwin is reused once k_rangecode(j - nwin) is done
     HIP_TRY(hipEventRecord(e->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
     for (uint32_t j = 0; j < nseg; j++) {
-        uint8_t* win = e->d_window[j & 1];
-        if (j >= 2) HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[j - 2], 0));
+        uint8_t* win = e->d_window[j % e->nwin];
+        if (j >= e->nwin) HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[j - e->nwin], 0));
         HIP_TRY(timed(2, st, [&] {
             if (e->lds_states) hipLaunchKernelGGL(k_resolve<true>, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
                                                   e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride);
@@ -1480,6 +1507,26 @@ int ffv1_prev_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, i
         if (e->ev_kernel_prev[i] < k) ms[e->ev_kernel_prev[i]] += t;
     }
     return k;
+}
+// Device-side timeline of the call before the last one, in ms from the start of its k_model: [0] first k_resolve starts, [1] last k_resolve
+// ends, [2] sum of the gaps between consecutive k_resolve launches, [3] last k_rangecode ends, [4] k_gather (or k_scan) ends, [5] the NEXT
+// call's k_model starts.  For RCGPU_TRACE.
+int ffv1_prev_timeline(const rcgpu_ffv1* e, float* t6)
+{
+    if (!e || !e->ev_used_prev || !e->ev_used) return 0;
+    for (int i = 0; i < 6; i++) t6[i] = 0;
+    hipEvent_t z = e->ev_prev[0];
+    auto at = [&](hipEvent_t ev) { float t = 0; if (hipEventSynchronize(ev) != hipSuccess) return 0.f; (void)hipEventElapsedTime(&t, z, ev); return t; };
+    float last_end = 0; bool first = true;
+    for (size_t i = 0; i < e->ev_kernel_prev.size() && 2 * i + 1 < e->ev_used_prev; i++) {
+        const float s0 = at(e->ev_prev[2 * i]), s1 = at(e->ev_prev[2 * i + 1]);
+        const int k = e->ev_kernel_prev[i];
+        if (k == 2) { if (first) { t6[0] = s0; first = false; } else t6[2] += std::max(0.f, s0 - last_end); last_end = s1; t6[1] = s1; }
+        if (k == 3) t6[3] = s1;
+        if (k >= 4) t6[4] = std::max(t6[4], s1);
+    }
+    t6[5] = at(e->ev[0]);
+    return 6;
 }
 }  // namespace rc
 

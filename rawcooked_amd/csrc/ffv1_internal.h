@@ -35,6 +35,10 @@ std::vector<uint8_t> ffv1_config_record_for(const rcgpu_ffv1_config& cfg);
 size_t ffv1_max_packet_bytes_for(const rcgpu_ffv1_config& cfg);
 // Per-kernel device time of the call before the last one (see rcgpu_ffv1_last_kernel_times).
 int  ffv1_prev_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap);
+int  ffv1_prev_timeline(const rcgpu_ffv1* e, float* t6);      // see ffv1_gpu.hip; for RCGPU_TRACE
+// A small copy done by a kernel on `hip_stream` (hipStream_t) instead of a copy engine: device <-> pinned host memory, 8-byte granules.
+// Control data must not queue behind the payload copies that keep the engines busy.  Returns a hipError_t as int.
+int  copy_by_kernel_on(void* dst, const void* src, size_t bytes, void* hip_stream);
 // Text for the device error word (0 = none).
 const char* ffv1_error_flags_text(uint32_t flags);
 

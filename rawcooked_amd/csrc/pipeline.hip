@@ -21,6 +21,7 @@ using clk = std::chrono::steady_clock;
 double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
 
 constexpr size_t kUploadGroup = 8, kDownloadGroup = 16;       // copies per completion event
+constexpr uint32_t kCopyStreams = 2;                          // copy streams per direction and lane
 
 struct batch_t { uint32_t video; size_t first, n; int lane; };       // frames[first .. first+n) of the output order
 
@@ -33,7 +34,9 @@ struct out_entry {            // one packet on its way down
 struct lane_t {
     int id = 0, device = 0;
     std::vector<rcgpu_ffv1*> enc;                 // per video
-    hipStream_t cin = nullptr, cout = nullptr;
+    std::vector<hipStream_t> cin, cout;          // copy streams per direction: groups of copies are dealt to them in turn
+    std::vector<hipEvent_t> join_ev;             // one per extra stream: joins it to stream 0 of its direction at the end of a batch
+    size_t up_turn = 0, dn_turn = 0;
     std::vector<hipEvent_t> dl_done;              // per video: the download of the last batch out of that encoder's d_packets
     std::vector<bool> dl_valid;
     hipEvent_t ev_up = nullptr, ev_up0 = nullptr, ev_done[2] = { nullptr, nullptr };     // ev_up0 / ev_up time the uploads of a batch
@@ -100,8 +103,9 @@ pipeline::impl::~impl()
         if (L.ev_up) (void)hipEventDestroy(L.ev_up);
         if (L.ev_up0) (void)hipEventDestroy(L.ev_up0);
         for (hipEvent_t e : L.ev_done) if (e) (void)hipEventDestroy(e);
-        if (L.cin) (void)hipStreamDestroy(L.cin);
-        if (L.cout) (void)hipStreamDestroy(L.cout);
+        for (hipStream_t c : L.cin) if (c) (void)hipStreamDestroy(c);
+        for (hipStream_t c : L.cout) if (c) (void)hipStreamDestroy(c);
+        for (hipEvent_t e : L.join_ev) if (e) (void)hipEventDestroy(e);
         if (L.h_sizes) (void)hipHostFree(L.h_sizes);
         if (L.h_err) (void)hipHostFree(L.h_err);
     }
@@ -192,9 +196,19 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
         // encoder's two compute streams.
         int prio_least = 0, prio_greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        if (hipStreamCreateWithPriority(&L.cin, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
-            hipStreamCreateWithPriority(&L.cout, hipStreamNonBlocking, prio_least) != hipSuccess)
-            return fail(100, "pipeline: cannot create copy streams");
+        // Two streams per direction: the copies of ONE stream run strictly one after the other, and beside the kernels that chain got 26-36
+        // GB/s per direction while the engines had room for twice as much (a pump of copies beside the pipeline moved 44 GB/s more, and
+        // the pipeline itself got faster).  Measured, frames/s between the first and the last batch: 529 with one stream per direction,
+        // 643 with two (= the device-resident rate), 649 with three, 460 with four.
+        uint32_t ncopy = kCopyStreams;
+        if (const char* x = getenv("RCGPU_COPY_STREAMS")) ncopy = uint32_t(std::max(1, std::min(8, atoi(x))));
+        L.cin.assign(ncopy, nullptr); L.cout.assign(ncopy, nullptr); L.join_ev.assign(2 * ncopy, nullptr);
+        for (uint32_t k = 0; k < ncopy; k++)
+            if (hipStreamCreateWithPriority(&L.cin[k], hipStreamNonBlocking, prio_greatest) != hipSuccess ||
+                hipStreamCreateWithPriority(&L.cout[k], hipStreamNonBlocking, prio_least) != hipSuccess ||
+                hipEventCreateWithFlags(&L.join_ev[2 * k], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&L.join_ev[2 * k + 1], hipEventDisableTiming) != hipSuccess)
+                return fail(100, "pipeline: cannot create copy streams");
         L.dl_done.assign(videos.size(), nullptr); L.dl_valid.assign(videos.size(), false);
         for (auto& e : L.dl_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(100, "pipeline: cannot create events");
         if (hipEventCreate(&L.ev_up) != hipSuccess || hipEventCreate(&L.ev_up0) != hipSuccess || hipEventCreateWithFlags(&L.ev_done[0], hipEventDisableTiming) != hipSuccess ||
@@ -318,13 +332,16 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         const auto now = clk::now();
         if (std::chrono::duration<double>(now - last_reap).count() < 100e-6) return;
         last_reap = now;
-        for (lane_t& L : s.lanes)
-            while (!L.pending.empty()) {
-                if (hipEventQuery(L.pending.front().ev) != hipSuccess) break;
-                for (uint8_t* sl : L.pending.front().slots) s.free_slots.push_back(sl);
-                L.free_events.push_back(L.pending.front().ev);
-                L.pending.pop_front();
+        for (lane_t& L : s.lanes) {
+            // the groups of one stream complete in order: of every stream's groups only the oldest is asked about
+            size_t asked = 0;
+            for (auto it = L.pending.begin(); it != L.pending.end() && asked < L.cin.size();) {
+                if (hipEventQuery(it->ev) != hipSuccess) { ++it; ++asked; continue; }
+                for (uint8_t* sl : it->slots) s.free_slots.push_back(sl);
+                L.free_events.push_back(it->ev);
+                it = L.pending.erase(it);
             }
+        }
     };
 
     // ---- readers
@@ -385,13 +402,14 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 L.upload_wait += since(tw);
             }
             const auto tc = clk::now();
-            if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, slot, sg.payload_bytes, hipMemcpyHostToDevice, L.cin), "upload")) return false;
+            hipStream_t cs = L.cin[L.up_turn % L.cin.size()];          // a group stays on one stream: its event covers all of it
+            if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, slot, sg.payload_bytes, hipMemcpyHostToDevice, cs), "upload")) return false;
             ugroup.push_back(slot);                          // one completion event per group of copies: an event is a barrier packet
             if (ugroup.size() >= ugroup_max || k + 1 == B.n) {
                 hipEvent_t ev = get_event();
-                if (!ev || !hip_ok(hipEventRecord(ev, L.cin), "hipEventRecord")) return false;
+                if (!ev || !hip_ok(hipEventRecord(ev, cs), "hipEventRecord")) return false;
                 { std::lock_guard<std::mutex> l(s.m); L.pending.push_back({ ugroup, ev }); }
-                ugroup.clear();
+                ugroup.clear(); L.up_turn++;
             }
             L.copy_calls += since(tc);
             return true;
@@ -435,8 +453,9 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             hipStream_t st = static_cast<hipStream_t>(sg.compute_stream);
             ffv1_set_gather_wait(enc, L.dl_valid[B.video] ? L.dl_done[B.video] : nullptr);
             if (int r = ffv1_gather(enc, sg.d_packets, sg.packet_stride, st)) { s.set_error(r, rcgpu_last_error()); return false; }
-            return hip_ok(hipMemcpyAsync(L.h_sizes + size_t(par) * L.h_sizes_stride, sg.d_psizes, 8 * B.n, hipMemcpyDeviceToHost, st), "sizes") &&
-                   hip_ok(hipMemcpyAsync(L.h_err + 4 * par, sg.d_err, 16, hipMemcpyDeviceToHost, st), "flags") &&
+            // by a kernel, not by a copy engine: these few bytes must not wait behind the packets of the previous batch (ffv1_internal.h)
+            return hip_ok(hipError_t(copy_by_kernel_on(L.h_sizes + size_t(par) * L.h_sizes_stride, sg.d_psizes, 8 * B.n, st)), "sizes") &&
+                   hip_ok(hipError_t(copy_by_kernel_on(L.h_err + 4 * par, sg.d_err, 16, st)), "flags") &&
                    hip_ok(hipEventRecord(L.ev_done[par], st), "hipEventRecord");
         };
         std::vector<out_entry> dgroup;
@@ -449,17 +468,29 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (!o.src) return false;
             const auto tc = clk::now();
             L.dl_wait += std::chrono::duration<double>(tc - tw).count();
-            if (!hip_ok(hipMemcpyAsync(o.src, sg.d_packets + i * sg.packet_stride, o.size, hipMemcpyDeviceToHost, L.cout), "download")) return false;
+            // whole 4 KB pages: a copy of an odd number of bytes does not take the copy engines' fast path (the slot in the ring and the
+            // packet's stride on the device both have the room)
+            const size_t whole = std::min<size_t>((o.size + 4095) & ~size_t(4095), sg.packet_stride);
+            hipStream_t cs = L.cout[L.dn_turn % L.cout.size()];
+            if (!hip_ok(hipMemcpyAsync(o.src, sg.d_packets + i * sg.packet_stride, whole, hipMemcpyDeviceToHost, cs), "download")) return false;
             L.dl_calls += since(tc);
             dgroup.push_back(o);
             if (dgroup.size() >= dgroup_max || i + 1 == B.n) {       // the group becomes visible once its event is recorded
                 hipEvent_t ev = get_event();
-                if (!ev || !hip_ok(hipEventRecord(ev, L.cout), "hipEventRecord")) return false;
+                if (!ev || !hip_ok(hipEventRecord(ev, cs), "hipEventRecord")) return false;
+                L.dn_turn++;
                 int* users = new int(int(dgroup.size()));
                 { std::lock_guard<std::mutex> l(s.m); for (out_entry& g : dgroup) { g.ev = ev; g.ev_users = users; L.outq.push_back(g); } }
                 dgroup.clear();
                 s.cv_out.notify_one();
             }
+            return true;
+        };
+        // everything issued so far on the streams of one direction is behind what stream 0 of it does next
+        auto join = [&](std::vector<hipStream_t>& cs, int dir) -> bool {
+            for (size_t k = 1; k < cs.size(); k++)
+                if (!hip_ok(hipEventRecord(L.join_ev[2 * k + size_t(dir)], cs[k]), "hipEventRecord") ||
+                    !hip_ok(hipStreamWaitEvent(cs[0], L.join_ev[2 * k + size_t(dir)], 0), "hipStreamWaitEvent")) return false;
             return true;
         };
         // downloads of batch D (complete on the device, sizes and flags on the host) and uploads of batch U, either may be absent
@@ -469,7 +500,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 if (ffv1_staging(L.enc[D->video], &sd)) { s.set_error(100, rcgpu_last_error()); return false; }
                 const uint32_t* err = L.h_err + 4 * par;
                 if (err[0]) { char t[256]; snprintf(t, sizeof t, "ffv1: %s (flags %u)", ffv1_error_flags_text(err[0]), err[0]); s.set_error(102, t); return false; }
-                if (!hip_ok(hipStreamWaitEvent(L.cout, L.ev_done[par], 0), "hipStreamWaitEvent")) return false;
+                for (hipStream_t c : L.cout) if (!hip_ok(hipStreamWaitEvent(c, L.ev_done[par], 0), "hipStreamWaitEvent")) return false;
             }
             if (U && ffv1_staging(L.enc[U->video], &su)) { s.set_error(100, rcgpu_last_error()); return false; }
             const auto tu = clk::now();
@@ -479,10 +510,10 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 if (i < nu && !upload_one(*U, su, i)) return false;
             }
             if (D) {
-                if (!hip_ok(hipEventRecord(L.dl_done[D->video], L.cout), "hipEventRecord")) return false;
+                if (!join(L.cout, 0) || !hip_ok(hipEventRecord(L.dl_done[D->video], L.cout[0]), "hipEventRecord")) return false;
                 L.dl_valid[D->video] = true;
             }
-            if (U && !hip_ok(hipEventRecord(L.ev_up, L.cin), "hipEventRecord")) return false;
+            if (U && (!join(L.cin, 1) || !hip_ok(hipEventRecord(L.ev_up, L.cin[0]), "hipEventRecord"))) return false;
             if (trace && L.id == 0) { char b[160]; snprintf(b, sizeof b, "transfers issued in %.3f s: %zu downloads, %zu uploads", since(tu), nd, nu); mark(b); }
             return true;
         };
@@ -510,6 +541,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 std::string t = "kernel ms of this batch:";
                 for (int i = 0; i < nk; i++) if (ms[i] > 0) { char b[64]; snprintf(b, sizeof b, " %s %.1f", names[i], ms[i]); t += b; }
                 mark(t.c_str());
+                if (more) { float tl[6]; if (ffv1_prev_timeline(L.enc[B.video], tl)) { char b2[256]; snprintf(b2, sizeof b2, "device timeline from k_model: first k_resolve +%.1f, last k_resolve ends +%.1f (gaps between them %.1f), last k_rangecode ends +%.1f, gather ends +%.1f, next k_model starts +%.1f ms", tl[0], tl[1], tl[2], tl[3], tl[4], tl[5]); mark(b2); } }
                 char b[200]; snprintf(b, sizeof b, "lane 0 so far: waiting for readers %.3f s, inside upload calls %.3f s, waiting for ring space %.3f s, inside download calls %.3f s",
                                       L.upload_wait, L.copy_calls, L.dl_wait, L.dl_calls); mark(b);
             }
