@@ -200,7 +200,7 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
         // GB/s per direction while the engines had room for twice as much (a pump of copies beside the pipeline moved 44 GB/s more, and
         // the pipeline itself got faster).  Measured, frames/s between the first and the last batch: 529 with one stream per direction,
         // 643 with two (= the device-resident rate), 649 with three, 460 with four.
-        uint32_t ncopy = kCopyStreams;
+        uint32_t ncopy = cnt > ndev_used ? 1 : kCopyStreams;         // several lanes on a device: their streams add up, and four per direction were worse
         if (const char* x = getenv("RCGPU_COPY_STREAMS")) ncopy = uint32_t(std::max(1, std::min(8, atoi(x))));
         L.cin.assign(ncopy, nullptr); L.cout.assign(ncopy, nullptr); L.join_ev.assign(2 * ncopy, nullptr);
         for (uint32_t k = 0; k < ncopy; k++)
