@@ -159,3 +159,40 @@ def test_several_lanes_return_packets_in_frame_order(lanes, n, batch):
     want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
     for i in range(n):
         assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RCGPU_SOAK_PIPE", "6"))))      # soak: RCGPU_SOAK_PIPE=200
+def test_random_pipeline_shapes_equal_the_oracle(seed, monkeypatch):
+    """Sequence lengths, batch sizes, slot and ring sizes, thread counts, lanes and copy streams drawn at random: the packets are the
+    oracle's whatever the shape (ordering of groups over several copy streams, slot recycling, ring wrap-around, evened batches)."""
+    import random
+    r = random.Random(1000 + seed)
+    w, h = r.choice([(64, 48), (96, 64), (160, 80)])
+    pixfmt = r.choice([synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGB8])
+    n = r.choice([1, 2, 7, 19, 33, 50, 77])
+    nh, nv = r.choice([(1, 1), (2, 2), (3, 2)])
+    monkeypatch.setenv("RCGPU_COPY_STREAMS", str(r.choice([1, 2, 3])))
+    payloads, line_bytes = _sequence(w, h, pixfmt, min(n, 12), kind=r.choice(["film", "noise", "flat"]))
+    keep = [C.create_string_buffer(p, len(p)) for p in payloads]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, nh, nv, 1, 1, 0, 0, 0, 0, 1, 3)
+    got, lock = {}, threading.Lock()
+
+    def read_frame(frame, dst, nbytes):
+        C.memmove(dst, keep[frame % len(keep)], nbytes)
+        return 0
+
+    def packet_done(frame, data, size):
+        b = C.string_at(data, size)
+        with lock:
+            assert frame not in got
+            got[frame] = b
+        return 0
+
+    st, _ = api.encode_sequence(cfg, n, read_frame, packet_done, batch=r.choice([0, 1, 3, 8, 16]), in_ring_frames=r.choice([0, 2, 3, 9]),
+                                out_ring_bytes=r.choice([0, 1 << 16, 1 << 20]), readers=r.choice([1, 2, 5]), writers=r.choice([1, 3]),
+                                lanes_per_device=r.choice([0, 1, 2]))
+    assert st.frames == n and sorted(got) == list(range(n))
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
+    for i in range(n):
+        assert got[i] == want[i % len(want)], f"seed {seed}: packet {i} differs from the oracle's"
