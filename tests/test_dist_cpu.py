@@ -47,3 +47,11 @@ def test_two_ranks_gloo(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29617", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and r.stdout.count("ok") == 2, r.stdout + r.stderr
+
+
+def test_bench_command_line_is_the_contract():
+    """`python bench.py --gpus N --steps K --warmup W` is what the driver runs: the options exist, and the file at least parses here."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    for opt in ("--gpus", "--steps", "--warmup", "--legs", "--mode"):
+        assert opt in r.stdout, opt
