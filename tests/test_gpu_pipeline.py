@@ -196,3 +196,32 @@ def test_random_pipeline_shapes_equal_the_oracle(seed, monkeypatch):
     want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
     for i in range(n):
         assert got[i] == want[i % len(want)], f"seed {seed}: packet {i} differs from the oracle's"
+
+
+@pytest.mark.parametrize("copy_streams,lanes", [(1, 1), (3, 1), (2, 2)])
+def test_hd_sequence_with_real_transfers_equals_the_oracle(copy_streams, lanes, monkeypatch):
+    """1920x1080 frames (12 MB payloads, ~11 MB packets): uploads, kernels and downloads really overlap here; a download ring of two
+    chunks and eight upload slots keep every recycling path busy.  Packets are the oracle's, in any stream / lane arrangement."""
+    monkeypatch.setenv("RCGPU_COPY_STREAMS", str(copy_streams))
+    w, h, pixfmt, n, distinct = 1920, 1080, synth.PIX_RGB16_BE, 60, 6
+    payloads, line_bytes = _sequence(w, h, pixfmt, distinct)
+    keep = [C.create_string_buffer(p, len(p)) for p in payloads]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 4, 4, 1, 1, 0, 0, 0, 0, 1, 3)
+    got, lock = {}, threading.Lock()
+
+    def read_frame(frame, dst, nbytes):
+        C.memmove(dst, keep[frame % distinct], nbytes)
+        return 0
+
+    def packet_done(frame, data, size):
+        b = C.string_at(data, size)
+        with lock:
+            got[frame] = b
+        return 0
+
+    st, _ = api.encode_sequence(cfg, n, read_frame, packet_done, batch=7, in_ring_frames=8, out_ring_bytes=1 << 20, readers=4, writers=3, lanes_per_device=lanes)
+    assert st.frames == n and sorted(got) == list(range(n))
+    p = ob.Params(w, h, pixfmt, 4, 4, 1, 1)
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
+    for i in range(n):
+        assert got[i] == want[i % distinct], f"packet {i} differs from the oracle's"
