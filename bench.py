@@ -469,7 +469,12 @@ def main():
         stop.set(); noise.join()
         print("bench: dma noise moved %.0f GB during warm-up and timed steps = %.1f GB/s beside the kernels" % (moved[0] / 1e9, moved[0] / 1e9 / max(1e-9, time.perf_counter() - t_noise)), file=sys.stderr)
     kt = enc.kernel_times()          # HIP events of the last timed step, recorded on the launch streams
-    flags = enc.error_flags()        # the device-pointer API only enqueues: this is where an overflow would show (raises)
+    try:
+        flags = enc.error_flags()    # the device-pointer API only enqueues: this is where an overflow would show (raises)
+    except Exception:
+        if not os.environ.get("RCGPU_BENCH_TIMING_BUILD"):      # timing builds (tools/sweep_lds.sh) code wrong bytes on purpose
+            raise
+        flags = -1
 
     sizes = d_sizes.cpu().tolist()
     decisions, _ = enc.stats()

@@ -153,7 +153,14 @@ typedef struct {
                                  (Global.cpp:961-968): num_h = num_v = 1, slicecrc 0, no configuration record (the header travels inside
                                  every frame, FFV1_Slice.cpp:224-268), no slice footer.  One chain per frame; the decoder insists on exactly
                                  the header this configuration produces. */
+    uint32_t rc_span;         /* how the range coder is mapped: 0 = automatic; RCGPU_RC_WHOLE = one lane codes a whole slice (few, long
+                                 chains: right when there are thousands of slices in flight); N >= 8 = split coder -- one lane per slice
+                                 runs only the serial `range` recurrence and leaves a checkpoint every N 56-decision pieces, one lane
+                                 per (slice, span of N pieces) then codes the span's bytes from its checkpoint, and the spans' residual
+                                 `low` values are added into the bytes that follow them.  Same bytes either way. */
+    uint32_t slice_buffer_div; /* 0 or 1 = slice byte buffers of the normal size; k > 1 = a k-th of it (tests of the overflow report) */
 } rcgpu_ffv1_config;
+#define RCGPU_RC_WHOLE 1u
 
 typedef struct rcgpu_ffv1 rcgpu_ffv1;
 

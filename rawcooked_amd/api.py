@@ -34,7 +34,8 @@ class AudioInfo(C.Structure):
 class Ffv1Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("pixfmt", C.c_uint32), ("line_bytes", C.c_uint32),
                 ("num_h_slices", C.c_uint32), ("num_v_slices", C.c_uint32), ("slicecrc", C.c_uint32), ("context", C.c_uint32),
-                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32), ("coder", C.c_uint32), ("level", C.c_uint32)]
+                ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32), ("coder", C.c_uint32), ("level", C.c_uint32),
+                ("rc_span", C.c_uint32), ("slice_buffer_div", C.c_uint32)]
 
 
 READ_FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t)
@@ -226,8 +227,10 @@ def md5(data: bytes) -> bytes:
 class Ffv1Encoder:
     """Device FFV1 encoder (rcgpu_ffv1_*).  Raises when no HIP device is visible."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0, flags=0, coder=1, level=3):
-        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments, flags, coder, level)
+    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, segments=0, flags=0, coder=1, level=3,
+                 rc_span=0, slice_buffer_div=0):
+        self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, segments, flags, coder, level,
+                              rc_span, slice_buffer_div)
         self.h = _VP()
         _check(lib().rcgpu_ffv1_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_create")
         self.max_packet = lib().rcgpu_ffv1_max_packet_bytes(self.h)
@@ -279,7 +282,7 @@ class Ffv1Encoder:
         return {names[i].decode(): float(ms[i]) for i in range(k)}
 
     def kernel_launches(self) -> dict[str, int]:
-        names = ["k_unpack", "k_model", "k_resolve", "k_rangecode", "k_footer", "k_scan", "k_gather"]
+        names = ["k_unpack", "k_model", "k_resolve", "k_rangecode", "k_footer", "k_scan", "k_gather", "k_rc_range", "k_rc_tails"]
         return {n: lib().rcgpu_ffv1_last_kernel_launches(self.h, i) for i, n in enumerate(names)}
 
     def stats(self) -> tuple[int, int]:

@@ -73,7 +73,8 @@ constexpr int kStageBitDwords = (kStageEntries + 31) / 32 + 7;              // t
 constexpr int kStageMaxPieces = kStageEntries / kPieceEntries + 1;         // pieces one flush can emit (41) + 1
 static_assert(kStageBitDwords <= 128, "the bit stage is cleared in two passes of 64 lanes");
 static_assert(kStageEntries % 16 == 0 && (kStageBitDwords * 4) % 16 == 0, "LDS areas stay 16-byte aligned");
-constexpr int kResolveFixedLds = kStageEntries + kStageBitDwords * 4 + kStageMaxPieces * 16 + 64 * 32 + 512 + 2 * 256;   // k_resolve: stage bytes | stage bits | piece tails | slots | transitions | powers
+constexpr int kCandBytes = 512;                  // k_resolve: which lane of the previous chunk may hold a context, by the context's low bits
+constexpr int kResolveFixedLds = kStageEntries + kStageBitDwords * 4 + kStageMaxPieces * 16 + 64 * 32 + 512 + 2 * 256 + kCandBytes;   // k_resolve: stage bytes | stage bits | piece tails | slots | transitions | powers | candidates
 
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
@@ -371,8 +372,9 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                                                 uint8_t* __restrict__ stream, uint32_t nkeys, uint32_t seg,
                                                 uint8_t* __restrict__ resume, uint32_t resume_stride)
 {
-    // One launch handles segment `seg` of every slice.  What must survive between launches -- the < 32 decisions that
-    // did not fill a piece and the first-touch bitmap -- lives in `resume` (per chain: count, 32 entries, bitmap).
+    // One launch handles segment `seg` of every slice.  What must survive between launches -- the < 56 decisions that
+    // did not fill a piece -- lives in `resume` (per chain: count, entries, their bits).  The context states of a batch are preset
+    // to 128 in HBM by the host (states_coded = 0): 20 MB per 4K frame, against 3 GB of traffic the kernel itself causes.
     // The arrays of fixed size are static LDS: their addresses are compile-time constants that fold into the instructions'
     // offset fields.  What scales with the number of contexts follows as dynamic LDS.
     __shared__ __attribute__((aligned(16))) uint8_t fixed[kResolveFixedLds];
@@ -383,10 +385,13 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     uint8_t*  slot = fixed + kStageEntries + kStageBitDwords * 4 + kStageMaxPieces * 16;       // 64 x 32
     uint8_t*  trans = slot + 64 * 32;                                               // [256 +- state], see below
     uint8_t*  pw = trans + 512;                                                     // [2][256]: one_state applied 4 and 16 times
-    uint32_t* touched = reinterpret_cast<uint32_t*>(smem);                          // nkeys bits
-    uint8_t*  Hk = reinterpret_cast<uint8_t*>(touched + ((nkeys + 31) / 32 + 3) / 4 * 4);   // nkeys u8
+    uint8_t*  cand = pw + 512;                                                      // kCandBytes
+    // Two bitmaps over the contexts, used by even and odd chunks in turn: a chunk marks its contexts in one (the atomic's return value
+    // tells every lane but one of a context that it shares it), finds in the other what the chunk before it used, and clears that one.
+    const uint32_t bmw = ((nkeys + 31) / 32 + 3) / 4 * 4;
+    uint32_t* cbm = reinterpret_cast<uint32_t*>(smem);                              // 2 x bmw dwords
     // LDS_STATES (compact context model): every context's 32 states live here for the whole slice -- no HBM traffic per sample
-    uint8_t*  lstates = Hk + ((nkeys + 15) & ~15u);                                          // nkeys x 32
+    uint8_t*  lstates = reinterpret_cast<uint8_t*>(cbm + 2 * bmw);                  // nkeys x 32
 
     const int lane = threadIdx.x;
     const uint32_t chain = blockIdx.x;
@@ -407,12 +412,10 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     WAVE_SYNC();
     for (int i = lane; i < 256; i += 64) pw[256 + i] = pw[pw[pw[pw[i]]]];
     uint8_t* rs = resume + size_t(chain) * resume_stride;
-    uint32_t* rs_touched = reinterpret_cast<uint32_t*>(rs + 80);
     uint4* rs_states = reinterpret_cast<uint4*>(rs + 80);             // LDS_STATES: the state table itself is parked here
     uint32_t stage_count;
     if (seg == 0) {
         if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) reinterpret_cast<uint4*>(lstates)[i] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-        else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = 0;
         for (uint32_t i = lane; i < uint32_t(kStageBitDwords); i += 64) sbits[i] = 0;
         WAVE_SYNC();
         for (uint32_t i = lane; i < G.hdr_n; i += 64) {                 // header decisions from the host: t | coded bit << 8
@@ -423,11 +426,11 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         stage_count = G.hdr_n;
     } else {
         if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) reinterpret_cast<uint4*>(lstates)[i] = rs_states[i];
-        else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) touched[i] = rs_touched[i];
         for (uint32_t i = lane; i < uint32_t(kStageBitDwords); i += 64) sbits[i] = i < 2 ? reinterpret_cast<const uint32_t*>(rs + 72)[i] : 0u;
         if (lane < 14) reinterpret_cast<uint32_t*>(stage)[lane] = reinterpret_cast<const uint32_t*>(rs + 16)[lane];
         stage_count = uint32_t(__builtin_amdgcn_readfirstlane(int(*reinterpret_cast<const uint32_t*>(rs))));
     }
+    for (uint32_t i = lane; i < 2 * bmw; i += 64) cbm[i] = 0;
     uint32_t piece_base = 0;              // piece index inside this segment's window
     const uint32_t sym_begin = min(G.nsamp, seg * G.seg_q), sym_end = min(G.nsamp, (seg + 1) * G.seg_q);
     const bool last_seg = seg + 1 == C->nseg;
@@ -521,21 +524,37 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         const uint32_t total = uint32_t(__builtin_amdgcn_readlane(int(incl), 63));        // a scalar: stage_count and what the flush derives from it stay in SGPRs
         PROF_T(0)
 
-        // --- which lanes share a context?  One LDS write/read finds the colliding lanes; a scalar loop over the
-        // distinct colliding keys gives every lane its predecessor, its group leader and whether it is the last.
-        // did the previous chunk use this lane's context?  Its Hk entry still names one of the lanes that did.
-        const uint32_t hp = valid ? uint32_t(Hk[key]) & 63u : 0u;
+        // --- which lanes share a context?  Marking the contexts in this chunk's bitmap tells every lane of a context but one that it is
+        // not alone; a scalar loop over the distinct shared contexts then gives every lane its predecessor, its group leader and whether it
+        // is the last.  Did the previous chunk use this lane's context?  Its bitmap says so exactly; the candidate table, indexed by the
+        // context's low bits, names the lane that most probably did (checked against that lane's key), and the few lanes whose candidate
+        // was overwritten by another context find theirs by ballot.
+        const uint32_t kbit = 1u << (key & 31), kw = key >> 5;
+        uint32_t* const cur_bm = cbm + ((base >> 6) & 1 ? bmw : 0u);
+        uint32_t* const prv_bm = cbm + ((base >> 6) & 1 ? 0u : bmw);
+        const bool pbit = !LDS_STATES && valid && (prv_bm[kw] & kbit);
+        const uint32_t hp = valid ? uint32_t(cand[key & (kCandBytes - 1)]) & 63u : 0u;
         const uint32_t hp_pack = uint32_t(__shfl(int(ppack), int(hp)));    // all lanes take part: the source lane may be past the end of this chunk
-        const bool fwd = !LDS_STATES && valid && (hp_pack & 0xFFFFu) == key;
-        const int fwd_slot = int(hp_pack >> 16);
+        bool fwd = pbit && (hp_pack & 0xFFFFu) == key;
+        int fwd_slot = int(hp_pack >> 16);
         WAVE_SYNC();
-        if (valid) Hk[key] = uint8_t(lane);
+        if (valid) cand[key & (kCandBytes - 1)] = uint8_t(lane);
+        const uint32_t old = valid ? atomicOr(&cur_bm[kw], kbit) : 0u;
+        if ((ppack & 0xFFFFu) != 0xFFFFu) atomicAnd(&prv_bm[(ppack & 0xFFFFu) >> 5], ~(1u << (ppack & 31)));     // the next chunk's bitmap is clean again
         WAVE_SYNC();
-        const uint32_t seen = valid ? Hk[key] : uint32_t(lane);
+        for (unsigned long long fm = __ballot(pbit && !fwd); fm; ) {
+            const int src = __ffsll((long long)fm) - 1;
+            const uint32_t k = uint32_t(__builtin_amdgcn_readlane(int(key), src));
+            const unsigned long long pm = __ballot((ppack & 0xFFFFu) == k);          // not empty: the bitmap said so
+            const uint32_t pslot = uint32_t(__builtin_amdgcn_readlane(int(ppack), __ffsll((long long)pm) - 1)) >> 16;
+            const bool mine = valid && key == k;
+            if (mine) { fwd = true; fwd_slot = int(pslot); }
+            fm &= ~__ballot(mine);
+        }
         int leader = lane, pred = -1;
         bool last = true, zrun = false;
         uint32_t rank = 0;
-        unsigned long long lm = __ballot(valid && seen != uint32_t(lane));
+        unsigned long long lm = __ballot(valid && (old & kbit));
         while (lm) {
             const int src = __ffsll((long long)lm) - 1;
             const uint32_t k = uint32_t(__builtin_amdgcn_readlane(int(key), src));      // src is uniform: no trip through the LDS crossbar
@@ -563,17 +582,14 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         const bool first = !LDS_STATES && valid && pred < 0;
         uint4 s0 = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u), s1 = s0;
         if (first) {
-            const bool was = (touched[key >> 5] >> (key & 31)) & 1;
             if (fwd) { const uint4* fp = reinterpret_cast<const uint4*>(slot + fwd_slot * 32); s0 = fp[0]; s1 = fp[1]; }
-            else if (was) { s0 = P0; s1 = P1; }
+            else { s0 = P0; s1 = P1; }
         }
         WAVE_SYNC();                      // forwarded reads come before this chunk's leaders overwrite the slots
         if (first) {
             uint4* sp = reinterpret_cast<uint4*>(slot + lane * 32);
             sp[0] = s0; sp[1] = s1;
         }
-        WAVE_SYNC();
-        if (first) atomicOr(&touched[key >> 5], 1u << (key & 31));
         // --- next chunk's states and the symbols after it leave for HBM now
         sv_cur = sv_nxt;
         if (!LDS_STATES && i + 64 < sym_end) {
@@ -746,7 +762,6 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 #endif
     if (!last_seg) {      // park the unfinished piece and the bitmap (or the state table) for the next segment
         if (LDS_STATES) for (uint32_t i = lane; i < nkeys * 2; i += 64) rs_states[i] = reinterpret_cast<const uint4*>(lstates)[i];
-        else for (uint32_t i = lane; i < (nkeys + 31) / 32; i += 64) rs_touched[i] = touched[i];
         if (lane < 14) reinterpret_cast<uint32_t*>(rs + 16)[lane] = reinterpret_cast<const uint32_t*>(stage)[lane];
         if (lane < 2) reinterpret_cast<uint32_t*>(rs + 72)[lane] = sbits[lane];
         if (lane == 0) *reinterpret_cast<uint32_t*>(rs) = stage_count;
@@ -784,7 +799,12 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 //     event, which ripples it through the bytes already in HBM.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kMaxCarryEvents = 4096;
-constexpr int kOutRows = kPieceEntries / 4 + 1;   // the decisions of a piece renormalise at most once each: a flush per four bytes (+1 carried in)
+// Parked dwords between two drains: the decisions renormalise at most once each, a flush per four bytes (+1 carried in).  The whole-slice
+// coder drains once per piece (kDrainWhole decisions), always before the next prefetch is issued; the span coder of the split mapping is a
+// throughput kernel that must fit beside k_resolve's LDS, and drains every kDrainSpan decisions into a quarter of the rows.
+constexpr int kDrainWhole = kPieceEntries, kDrainSpan = 14;
+constexpr int out_rows(int drain_every) { return drain_every / 4 + 1 + (drain_every % 4 ? 1 : 0); }
+constexpr int kOutRows = out_rows(kDrainWhole);
 
 struct rc_resume { uint32_t range, nb, pd; int pos; unsigned long long low; unsigned long long pad; };   // per chain, between segments
 
@@ -793,6 +813,7 @@ struct rc_lane {
     uint32_t ocnt;                    // dwords parked during this piece
     uint32_t* obuf;                   // LDS [kOutRows + 1][64], this lane's column
     int pos; uint8_t* out; int cap; uint32_t chain;
+    int lo;                           // first byte position this lane codes (0 for a whole slice, the checkpoint's for a span)
 };
 
 // m = all ones for a coded 1, zero for a coded 0 (one v_bfe_i32 off the piece's bit words); c = 255 for a coded 0
@@ -830,12 +851,15 @@ __device__ __forceinline__ void rc_check(rc_lane& r, uint32_t* ev_count, uint2* 
     r.nb &= 31;                                               // -32 when f
 }
 
+template <int ROWS = kOutRows>
 __device__ __forceinline__ void rc_drain(rc_lane& r)
 {
 #pragma unroll
-    for (int k = 0; k < kOutRows; k++) {
+    for (int k = 0; k < ROWS; k++) {
         if (uint32_t(k) < r.ocnt) {
-            const int at = r.pos + 4 <= r.cap ? r.pos : r.cap - 4;     // r.pos == -4 the first time: lands in the slack in front
+            // the first dword a lane parks is its still empty second stage (r.pos == r.lo - 4): it lands in the slack in front of the slice
+            int at = r.pos + 4 <= r.cap ? r.pos : r.cap - 4;
+            if (k == 0) at = r.pos < r.lo ? -4 : at;
             *reinterpret_cast<uint32_t*>(r.out + at) = r.obuf[k * 64];
             r.pos += 4;
         }
@@ -843,6 +867,7 @@ __device__ __forceinline__ void rc_drain(rc_lane& r)
     r.ocnt = 0;
 }
 
+template <int DRAIN = kDrainWhole>
 __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32_t cnt, uint32_t* ev_count, uint2* ev)
 {
     const uint32_t w[16] = { q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
@@ -854,6 +879,7 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
             const uint32_t m = uint32_t(__builtin_amdgcn_sbfe(int(w[14 + (j >> 5)]), uint32_t(j & 31), 1u));
             rc_step(r, t, m);
             if (j & 1) rc_check(r, ev_count, ev);
+            if (DRAIN < kPieceEntries && (j + 1) % DRAIN == 0 && j + 1 < kPieceEntries) rc_drain<out_rows(DRAIN)>(r);
         }
     } else {
 #pragma unroll 1
@@ -864,21 +890,34 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
             const uint32_t bw = j < 32 ? w[14] : w[15];
             rc_step(r, (ww >> (8 * (j & 3))) & 0xFF, 0u - ((bw >> (j & 31)) & 1u));
             rc_check(r, ev_count, ev);
+            if (DRAIN < kPieceEntries && (j & 3) == 3) rc_drain<out_rows(DRAIN)>(r);       // a check per decision here: at most four rows between drains
         }
     }
 }
 
+// A checkpoint of the split coder, per (span, chain): k_rc_range leaves the chain's `range` and byte position at the start of the span,
+// k_rangecode<true> replaces the range by the span's tail -- the 16 live bits of `low` its bytes do not hold yet.
+struct rc_ckpt { uint32_t v, pos; };
+
+// SPAN = false: one lane codes its slice's pieces of this segment, state parked in `resume` between segments.
+// SPAN = true (split coder): blockIdx.y = span; the lane codes pieces [span * span_pieces, + span_pieces) of its slice's segment from the
+// checkpoint k_rc_range left, with low = 0: all operations on `low` are additions and shifts, so the true stream is the sum of the spans'
+// streams, each at its own byte position -- the bytes of a span plus its tail, which k_rc_tails adds into the bytes that follow.  A span
+// started at low = 0 never carries out of its own first byte (low + range <= the checkpoint's range < 2^16 throughout).
+template <bool SPAN>
 __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                   const unsigned long long* __restrict__ total_n, const uint32_t* __restrict__ seg_pieces,
                                                   uint32_t seg, rc_resume* __restrict__ resume,
                                                   const unsigned long long* __restrict__ group_off,
                                                   const uint8_t* __restrict__ stream, uint8_t* __restrict__ cbuf,
                                                   unsigned long long cbuf_frame_stride, uint32_t nchains,
-                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ err, uint2* __restrict__ events)
+                                                  uint32_t* __restrict__ out_len, uint32_t* __restrict__ err, uint2* __restrict__ events,
+                                                  rc_ckpt* __restrict__ ckpt, uint32_t span_pieces)
 {
-    __shared__ uint32_t obuf[(kOutRows + 1) * 64];
-    // This kernel is latency-bound and shares SIMDs with throughput-bound k_resolve wavefronts: take issue priority.
-    __builtin_amdgcn_s_setprio(3);
+    constexpr int kDrain = SPAN ? kDrainSpan : kDrainWhole, kRows = out_rows(kDrain);
+    __shared__ uint32_t obuf[(kRows + 1) * 64];
+    // The whole-slice coder is latency-bound and shares SIMDs with throughput-bound k_resolve wavefronts: take issue priority.
+    if (!SPAN) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const uint32_t chain = blockIdx.x * 64 + lane;
     const bool active = chain < nchains;
@@ -888,15 +927,21 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
     const slice_geom G = geom[s];
     // this launch codes the pieces k_resolve produced for segment `seg`; only the last piece of the last segment is partial
     const bool last_seg = seg + 1 == C->nseg;
-    const unsigned long long npieces = active ? seg_pieces[cc] : 0;
-    unsigned long long n = npieces * kPieceEntries;
-    if (active && last_seg && npieces) n -= (kPieceEntries - 1) - ((total_n[cc] - 1) % kPieceEntries);
-    const uint4* src = reinterpret_cast<const uint4*>(stream + group_off[blockIdx.x]) + lane * 4;
+    const unsigned long long seg_np = active ? seg_pieces[cc] : 0;
+    unsigned long long n = seg_np * kPieceEntries;
+    if (active && last_seg && seg_np) n -= (kPieceEntries - 1) - ((total_n[cc] - 1) % kPieceEntries);
+    // the pieces this lane codes: [p0, p0 + npieces) of the segment
+    const unsigned long long p0 = SPAN ? (unsigned long long)blockIdx.y * span_pieces : 0ull;
+    const unsigned long long npieces = SPAN ? (seg_np > p0 ? (seg_np - p0 < span_pieces ? seg_np - p0 : span_pieces) : 0ull) : seg_np;
+    const bool ends_chain = last_seg && npieces && p0 + npieces == seg_np;       // this lane codes the slice's last decision
+    const uint4* src = reinterpret_cast<const uint4*>(stream + group_off[blockIdx.x]) + p0 * (kGroupPieceBytes / 16) + lane * 4;
+    rc_ckpt* const ck = SPAN ? ckpt + size_t(blockIdx.y) * nchains + cc : nullptr;
 
     rc_lane r;
     r.obuf = obuf + lane; r.ocnt = 0;
-    r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.pos = -4; r.chain = cc;
-    if (seg) { const rc_resume v = resume[cc]; r.range = v.range; r.low = v.low; r.nb = v.nb; r.pd = v.pd; r.pos = v.pos; }   // nb in bits
+    r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.pos = -4; r.chain = cc; r.lo = 0;
+    if (SPAN) { const rc_ckpt v = *ck; r.range = v.v; r.lo = int(v.pos); r.pos = r.lo - 4; }
+    else if (seg) { const rc_resume v = resume[cc]; r.range = v.range; r.low = v.low; r.nb = v.nb; r.pd = v.pd; r.pos = v.pos; }   // nb in bits
     r.out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
     r.cap = int(G.cbuf_cap);
 
@@ -906,6 +951,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
     // Loads are unconditional (the index is clamped to a valid piece) so that they stay plain global_load_dwordx4
     // (a select against a zero constant turns them into flat loads of an unknown address space).
     uint4 cur[4], nxt[4];
+    if (SPAN && !maxp) { if (active) ck->v = 0; return; }               // a span past the end of every slice of this group (uniform)
 #pragma unroll
     for (int k = 0; k < 4; k++) cur[k] = src[k];
     for (unsigned long long pc = 0; pc < maxp; pc++) {
@@ -913,39 +959,180 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
         // sits here (covering only loads issued a whole piece ago), not behind the next prefetch.
 #pragma unroll
         for (int k = 0; k < 4; k++) { asm volatile("" : "+v"(cur[k].x), "+v"(cur[k].y), "+v"(cur[k].z), "+v"(cur[k].w)); }
-        rc_drain(r);
+        rc_drain<kRows>(r);
         const unsigned long long pn = pc + 1 < npieces ? pc + 1 : (npieces ? npieces - 1 : 0);
         const uint4* p = src + pn * (kGroupPieceBytes / 16);
 #pragma unroll
         for (int k = 0; k < 4; k++) nxt[k] = p[k];                      // prefetch: in flight while this piece is coded
         if (pc < npieces) {
-            const unsigned long long left = n - pc * kPieceEntries;
-            rc_piece(r, cur, left < kPieceEntries ? uint32_t(left) : uint32_t(kPieceEntries), err + 1, events);
+            const unsigned long long left = n - (p0 + pc) * kPieceEntries;
+            rc_piece<kDrain>(r, cur, left < kPieceEntries ? uint32_t(left) : uint32_t(kPieceEntries), err + 1, events);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
-    rc_drain(r);
-    if (active && !last_seg) { rc_resume v; v.range = r.range; v.low = r.low; v.nb = r.nb; v.pd = r.pd; v.pos = r.pos; v.pad = 0; resume[cc] = v; }
-    if (active && last_seg) {
+    rc_drain<kRows>(r);
+    if (!SPAN && active && !last_seg) { rc_resume v; v.range = r.range; v.low = r.low; v.nb = r.nb; v.pd = r.pd; v.pos = r.pos; v.pad = 0; resume[cc] = v; }
+    if (SPAN && active && !ends_chain) {
+        // End of a span: the second stage and the finished bytes leave one by one (the next span's first byte follows directly), the 16
+        // live bits are the tail.  A lane without pieces leaves a zero tail.
+        uint32_t tail = 0;
+        if (npieces) {
+            const uint32_t nby = r.nb >> 3;                                         // <= 3 finished bytes above the live bits (a span ends with a full piece: checked)
+            const uint32_t carry = uint32_t(r.low >> (16 + 8 * nby));
+            const uint32_t npd = r.pd + carry;
+            if (npd < carry) { const uint32_t slot = atomicAdd(err + 1, 1u); if (slot < kMaxCarryEvents) events[slot] = make_uint2(r.chain, uint32_t(r.pos)); }
+            if (r.pos >= r.lo) for (int t = 0; t < 4; t++) if (r.pos + t < r.cap) r.out[r.pos + t] = uint8_t(npd >> (24 - 8 * t));
+            r.pos += 4;
+            for (int t = int(nby) - 1; t >= 0; t--) { if (r.pos < r.cap) r.out[r.pos] = uint8_t(r.low >> (16 + 8 * t)); r.pos++; }
+            tail = uint32_t(r.low) & 0xFFFFu;
+        }
+        ck->v = tail;
+    }
+    if (active && ends_chain) {
         // terminate (the state-129 end bit is already the last decision): two forced renormalisations; the last
-        // latched byte is not emitted -- the decoder reads bytes past the end as zero (FFV1_RangeCoder.cpp:79-85).
+        // latched byte is not part of the slice -- the decoder reads bytes past the end as zero (FFV1_RangeCoder.cpp:79-85).
         r.nb >>= 3;                            // back to bytes for the tail
-        r.low += 0xFF;                         // nb <= 3 here
+        r.low += 0xFF;                         // nb <= 3 here: a flush check follows the last decision of a piece, full or partial
         r.low <<= 8; r.nb++;
         r.low <<= 8; r.nb++;                   // nb <= 5: 16 + 40 + carry bits still fit
         const uint32_t carry = uint32_t(r.low >> (16 + 8 * r.nb));
         const uint32_t npd = r.pd + carry;
         if (npd < carry) { const uint32_t slot = atomicAdd(err + 1, 1u); if (slot < kMaxCarryEvents) events[slot] = make_uint2(r.chain, uint32_t(r.pos)); }
         bool overflow = false;
-        if (r.pos + 4 <= r.cap) *reinterpret_cast<uint32_t*>(r.out + r.pos) = __builtin_bswap32(npd); else overflow = true;
+        if (r.pos >= r.lo) { if (r.pos + 4 <= r.cap) *reinterpret_cast<uint32_t*>(r.out + r.pos) = __builtin_bswap32(npd); else overflow = true; }
         r.pos += 4;
-        for (int t = int(r.nb) - 1; t >= 1; t--) {
+        // the split coder also stores the latched byte behind the slice's last one: a tail added there may still carry into the slice
+        for (int t = int(r.nb) - 1; t >= (SPAN ? 0 : 1); t--) {
             if (r.pos < r.cap) r.out[r.pos] = uint8_t(r.low >> (16 + 8 * t)); else overflow = true;
             r.pos++;
         }
-        out_len[chain] = uint32_t(r.pos);
+        out_len[chain] = uint32_t(SPAN ? r.pos - 1 : r.pos);
         if (overflow) atomicOr(err, 1u);
+        if (SPAN) ck->v = 0;
+    }
+}
+
+// Split coder, first pass: the serial part of the range coder and nothing else.  One lane per slice walks the decisions of this segment
+// with  range' = renormalised((range * t + c) >> 8)  and counts the renormalisations (= bytes); at the start of every span of
+// `span_pieces` pieces it leaves (range, byte position) for the lane of k_rangecode<true> that will code the span.  Nine VALU
+// instructions per decision instead of twenty-one: this chain is what a batch's latency is made of.
+__device__ __forceinline__ void rr_step(uint32_t& range, uint32_t& cnt, uint32_t t, uint32_t m)
+{
+    const uint32_t x = __umul24(range, t) + (255u & ~m);
+    const uint32_t nr = x >> 8;
+    const bool ren = x < 0x10000u;                            // nr < 0x100
+    range = ren ? (x & 0xFFFFFF00u) : nr;                     // nr << 8
+    cnt += ren ? 1u : 0u;
+}
+
+// The same step for the decisions of a full piece, written out (tools/gen_rc_range_asm.py): this wavefront is alone on its SIMD's issue port for most of its life, every
+// VALU instruction costs it ~4.7 cycles and a dependent one 8.1 (tools/valu_peak), so the count is nine and the order keeps two
+// independent instructions between every pair on the range -> range path.  t and c = bit ? 0 : 255 of decision j arrive in registers, the
+// step extracts those of decision j + 1 in the gaps -- which is also what keeps two instructions between the compare and the select that
+// reads VCC (the hazard the compiler covers with s_nop 1).  One asm block: between two blocks the compiler puts an s_nop.
+// A full piece: tA / cA hold t and c = bit ? 0 : 255 of decision 0 on entry.
+__device__ __forceinline__ void rr_piece_asm(uint32_t& range, uint32_t& cnt, const uint32_t (&w)[16], uint32_t k255)
+{
+    uint32_t tA = w[0] & 0xFF, cA = (w[14] & 1u) ? 0u : 255u, tB, cB, x, nr, hi, m;
+    asm volatile(
+#include "rc_range_asm.inc"
+                 : [range] "+v"(range), [cnt] "+v"(cnt), [tA] "+v"(tA), [cA] "+v"(cA), [tB] "=&v"(tB), [cB] "=&v"(cB),
+                   [x] "=&v"(x), [nr] "=&v"(nr), [hi] "=&v"(hi), [m] "=&v"(m)
+                 : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]), [w7] "v"(w[7]),
+                   [w8] "v"(w[8]), [w9] "v"(w[9]), [w10] "v"(w[10]), [w11] "v"(w[11]), [w12] "v"(w[12]), [w13] "v"(w[13]),
+                   [b0] "v"(w[14]), [b1] "v"(w[15]), [k255] "s"(k255)
+                 : "vcc");
+}
+
+__global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rc_range(const enc_const* __restrict__ C,
+                                                  const unsigned long long* __restrict__ total_n, const uint32_t* __restrict__ seg_pieces,
+                                                  uint32_t seg, rc_resume* __restrict__ resume,
+                                                  const unsigned long long* __restrict__ group_off,
+                                                  const uint8_t* __restrict__ stream, uint32_t nchains,
+                                                  rc_ckpt* __restrict__ ckpt, uint32_t span_pieces, uint32_t nspans)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x;
+    const uint32_t chain = blockIdx.x * 64 + lane;
+    const bool active = chain < nchains;
+    const uint32_t cc = active ? chain : nchains - 1;
+    const bool last_seg = seg + 1 == C->nseg;
+    const unsigned long long npieces = active ? seg_pieces[cc] : 0;
+    unsigned long long n = npieces * kPieceEntries;
+    if (active && last_seg && npieces) n -= (kPieceEntries - 1) - ((total_n[cc] - 1) % kPieceEntries);
+    const uint4* src = reinterpret_cast<const uint4*>(stream + group_off[blockIdx.x]) + lane * 4;
+    uint32_t range = 0xFF00, cnt = 0;
+    if (seg) { const rc_resume v = resume[cc]; range = v.range; cnt = uint32_t(v.pos); }
+    rc_ckpt* ck = ckpt + cc;
+
+    unsigned long long maxp = npieces;
+    for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_xor(maxp, o); maxp = t > maxp ? t : maxp; }
+    uint4 cur[4], nxt[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = src[k];
+    uint32_t to_ckpt = 0, spans_done = 0;
+    for (unsigned long long pc = 0; pc < maxp; pc++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { asm volatile("" : "+v"(cur[k].x), "+v"(cur[k].y), "+v"(cur[k].z), "+v"(cur[k].w)); }
+        if (to_ckpt == 0) {                                             // uniform: a span starts here (a slice that has run out repeats its state)
+            if (active) { rc_ckpt v; v.v = range; v.pos = cnt; *ck = v; }
+            ck += nchains; to_ckpt = span_pieces; spans_done++;
+        }
+        to_ckpt--;
+        const unsigned long long pn = pc + 1 < npieces ? pc + 1 : (npieces ? npieces - 1 : 0);
+        const uint4* p = src + pn * (kGroupPieceBytes / 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) nxt[k] = p[k];
+        if (pc < npieces) {
+            const uint32_t w[16] = { cur[0].x, cur[0].y, cur[0].z, cur[0].w, cur[1].x, cur[1].y, cur[1].z, cur[1].w,
+                                     cur[2].x, cur[2].y, cur[2].z, cur[2].w, cur[3].x, cur[3].y, cur[3].z, cur[3].w };
+            const unsigned long long left = n - pc * kPieceEntries;
+            if (left >= kPieceEntries) {
+                rr_piece_asm(range, cnt, w, 255u);
+            } else {
+#pragma unroll 1
+                for (uint32_t j = 0; j < uint32_t(left); j++) {
+                    uint32_t ww = 0;
+#pragma unroll
+                    for (int k = 0; k < 14; k++) ww = (j >> 2) == uint32_t(k) ? w[k] : ww;
+                    const uint32_t bw = j < 32 ? w[14] : w[15];
+                    rr_step(range, cnt, (ww >> (8 * (j & 3))) & 0xFF, 0u - ((bw >> (j & 31)) & 1u));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+    }
+    for (; spans_done < nspans; spans_done++, ck += nchains) if (active) { rc_ckpt v; v.v = range; v.pos = cnt; *ck = v; }
+    if (active && !last_seg) { rc_resume v; v.range = range; v.low = 0; v.nb = 0; v.pd = 0; v.pos = int(cnt); v.pad = 0; resume[cc] = v; }
+}
+
+// Split coder, last pass: the tail of span g -- the 16 live bits of `low` its coder ended with -- belongs to the two bytes that follow the
+// span, i.e. to the start of span g + 1; carries ripple towards the front of the slice.  One lane per slice adds its tails in order; the
+// checkpoints of all segments of the batch are laid out [span][chain].
+__global__ __launch_bounds__(64) void k_rc_tails(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
+                                                 const rc_ckpt* __restrict__ ckpt, uint32_t total_spans, uint32_t nchains,
+                                                 uint8_t* __restrict__ cbuf, unsigned long long cbuf_frame_stride)
+{
+    const uint32_t chain = blockIdx.x * 64 + threadIdx.x;
+    if (chain >= nchains) return;
+    const uint32_t S = C->S, f = chain / S, s = chain - f * S;
+    const slice_geom G = geom[s];
+    uint8_t* out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
+    const int cap = int(G.cbuf_cap);
+    const rc_ckpt* ck = ckpt + chain;
+    uint32_t tail = total_spans ? ck->v : 0;
+    for (uint32_t g = 1; g < total_spans; g++) {
+        ck += nchains;
+        const rc_ckpt v = *ck;
+        const int q = int(v.pos);
+        if (tail && q + 2 <= cap) {
+            const uint32_t sum = (uint32_t(out[q]) << 8 | out[q + 1]) + tail;
+            out[q + 1] = uint8_t(sum); out[q] = uint8_t(sum >> 8);
+            if (sum >> 16) { int p = q; while (p > 0) { p--; const uint8_t b = uint8_t(out[p] + 1); out[p] = b; if (b) break; } }
+        }
+        tail = v.v;
     }
 }
 
@@ -1064,12 +1251,11 @@ static ffv1::stream_params stream_params_of(const rcgpu_ffv1_config& cfg)
 
 // Byte buffer of one slice: room for 1.5x its raw payload (incompressible 16-bit noise codes to ~1.1x once the contexts have adapted)
 // + what ~10^4 contexts x 32 states can cost before they have (tiny slices reach 1.7x), + header/footer.
-static size_t slice_buffer_bytes(const pix_desc& d, uint32_t w, uint32_t h, uint32_t version)
+static size_t slice_buffer_bytes(const pix_desc& d, uint32_t w, uint32_t h, uint32_t version, uint32_t div)
 {
     const size_t raw15 = size_t(w) * h * (d.bytes_pp ? d.bytes_pp : d.planes * 2u) * 3 / 2;
     size_t cap = (raw15 + std::min<size_t>(raw15, 256u << 10) + 4096 + 15) & ~size_t(15);
-    // test hook: slice buffers a fraction of their size, so that the overflow reporting can be exercised (tests/test_gpu_pipeline.py)
-    if (const char* t = getenv("RCGPU_TEST_CBUF_DIV")) if (atoi(t) > 1) cap = std::max<size_t>(64, (cap / size_t(atoi(t))) & ~size_t(15));
+    if (div > 1) cap = std::max<size_t>(64, (cap / div) & ~size_t(15));      // rcgpu_ffv1_config::slice_buffer_div: the overflow report can be exercised
     if (cap > 0xFFFFFF + 64 && version != 1) cap = 0xFFFFFF + 64;          // slice size field is 24 bit (version 1 has none)
     return cap;
 }
@@ -1090,7 +1276,7 @@ size_t ffv1_max_packet_bytes_for(const rcgpu_ffv1_config& cfg)
         for (uint32_t sx = 0; sx < cfg.num_h_slices; sx++) {
             const uint32_t w = uint32_t(uint64_t(sx + 1) * cfg.width / cfg.num_h_slices) - uint32_t(uint64_t(sx) * cfg.width / cfg.num_h_slices);
             const uint32_t h = uint32_t(uint64_t(sy + 1) * cfg.height / cfg.num_v_slices) - uint32_t(uint64_t(sy) * cfg.height / cfg.num_v_slices);
-            cb += 16 + slice_buffer_bytes(d, w, h, cfg.level == 1 ? 1 : 3);
+            cb += 16 + slice_buffer_bytes(d, w, h, cfg.level == 1 ? 1 : 3, cfg.slice_buffer_div);
         }
     return (cb + 15) & ~size_t(15);
 }
@@ -1130,6 +1316,11 @@ struct rcgpu_ffv1 {
     size_t resolve_lds = 0;
     size_t frame_payload = 0, cbuf_frame_stride = 0, max_packet = 0;
     hipStream_t own_stream = nullptr, rc_stream = nullptr;      // rc_stream: k_rangecode runs beside k_resolve
+    hipStream_t rr_stream = nullptr;                            // split coder: k_rc_range's stream (the spans are coded on rc_stream)
+    uint32_t span_pieces = 0;                                   // split coder: pieces per span; 0 = one lane codes a whole slice
+    bool exp_skip_rc = false;                                   // RCGPU_EXP_SKIP_RC: no range coder at all (timing runs of k_resolve alone; no valid output)
+    rc_ckpt* d_ckpt = nullptr; size_t ckpt_cap = 0;             // [span of the batch][chain]
+    std::vector<uint32_t> seg_spans, seg_span_off;
     // device buffers
     enc_const* d_const = nullptr; slice_geom* d_geom = nullptr; uint16_t* d_hdr = nullptr;
     const uint8_t** d_frame_ptrs = nullptr;
@@ -1148,12 +1339,12 @@ struct rcgpu_ffv1 {
     unsigned long long* h_ndec_pinned = nullptr; const void** h_frame_ptrs = nullptr;
     unsigned long long* h_total_n = nullptr; uint32_t* h_seg_pieces = nullptr; unsigned long long* h_group_off = nullptr;
     // instrumentation: start/stop event pairs on the stream each kernel is launched on
-    static constexpr int kNumK = 7;
+    static constexpr int kNumK = 9;
     std::vector<hipEvent_t> ev;                    // pairs, in launch order
     std::vector<int> ev_kernel;                    // kernel index of each pair
     size_t ev_used = 0;
     std::vector<hipEvent_t> ev_prev; std::vector<int> ev_kernel_prev; size_t ev_used_prev = 0;   // the call before: still readable while the next batch runs
-    hipEvent_t ev_k3[kMaxSeg]{}, ev_k4[kMaxSeg]{}, ev_fork = nullptr;
+    hipEvent_t ev_k3[kMaxSeg]{}, ev_k4[kMaxSeg]{}, ev_rr[kMaxSeg]{}, ev_fork = nullptr;
     bool ev_valid = false;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
     uint32_t last_n = 0;
@@ -1163,7 +1354,7 @@ struct rcgpu_ffv1 {
     uint32_t* h_err = nullptr;                     // pinned copy of d_err
 };
 
-static const char* const kKernelNames[rcgpu_ffv1::kNumK] = { "k_unpack", "k_model", "k_resolve", "k_rangecode", "k_footer", "k_scan", "k_gather" };
+static const char* const kKernelNames[rcgpu_ffv1::kNumK] = { "k_unpack", "k_model", "k_resolve", "k_rangecode", "k_footer", "k_scan", "k_gather", "k_rc_range", "k_rc_tails" };
 
 extern "C" int rcgpu_device_count(void)
 {
@@ -1178,7 +1369,7 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
     (void)hipSetDevice(e->cfg.device);
     void* bufs[] = { e->d_const, e->d_geom, e->d_hdr, e->d_frame_ptrs, e->d_planes, e->d_sym, e->d_states, e->d_ndec, e->d_total_n, e->d_seg_pieces,
                      e->d_group_off, e->d_k3_resume, e->d_k4_resume, e->d_cbuf, e->d_out_len, e->d_tot_len,
-                     e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes };
+                     e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes, e->d_ckpt };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (uint8_t* w : e->d_window) if (w) (void)hipFree(w);
     void* hosts[] = { e->h_psizes, e->h_ndec_pinned, e->h_frame_ptrs, e->h_total_n, e->h_seg_pieces, e->h_group_off, e->h_err };
@@ -1187,9 +1378,11 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
     for (auto& ev : e->ev_prev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_k3) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_k4) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_rr) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     if (e->rc_stream) (void)hipStreamDestroy(e->rc_stream);
+    if (e->rr_stream) (void)hipStreamDestroy(e->rr_stream);
     delete e;
 }
 
@@ -1211,6 +1404,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (cfg->coder > 2) return fail(2, "ffv1: coder %u (0/1 default transitions, 2 transmitted table)", cfg->coder);
     if (cfg->level != 0 && cfg->level != 1 && cfg->level != 3) return fail(2, "ffv1: level %u (1 or 3)", cfg->level);
     if (cfg->level == 1 && (S != 1 || cfg->slicecrc)) return fail(2, "ffv1: level 1 (FFV1 version 1) means one slice and no slice CRC");
+    if (cfg->rc_span > RCGPU_RC_WHOLE && cfg->rc_span < 8) return fail(2, "ffv1: rc_span %u (0 automatic, %u whole slices, or at least 8 pieces per span)", cfg->rc_span, RCGPU_RC_WHOLE);
     const pix_desc& d = pix(cfg->pixfmt);
     const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
     if (altern && d.fields != kFieldsLow) return fail(2, "ffv1: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only (DPX.cpp:363-368)");
@@ -1244,17 +1438,29 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     ffv1::make_zero_state(c.zero_state, c.one_state);
     if (c.nctx > 8191) { delete e; return fail(2, "ffv1: context count %u does not fit the symbol format", c.nctx); }
     e->nkeys = c.nsets * c.nctx;
-    e->resolve_lds = ((e->nkeys + 31) / 32 + 3) / 4 * 16 + ((e->nkeys + 15) & ~15u);      // dynamic part; kResolveFixedLds is static
-    e->resume_stride = uint32_t((80 + ((e->nkeys + 31) / 32) * 4 + 15) & ~15u);
+    e->resolve_lds = ((e->nkeys + 31) / 32 + 3) / 4 * 16 * 2;                              // dynamic part (two bitmaps over the contexts); kResolveFixedLds is static
+    e->resume_stride = 80;
     e->lds_states = size_t(e->nkeys) * 32 <= (48u << 10);                        // 338 contexts x 2 (3) sets x 32 B = 21.6 (32.4) KB
-    // How many k_resolve workgroups the dispatcher packs beside the four k_rangecode workgroups of a CU decides how the two kernels share
-    // its SIMDs, and the step time with it.  Measured with the 9-bit stream (4096x2160, 384 frames; workgroup LDS = 5 712 B static + this):
-    // 17.1 KB (what the kernel needs) 463 frames/s, 17.9 KB 493, 18.1-19.2 KB 622-643, 19.4 KB and more 453-471.  The workgroup asks for
-    // what puts it in the good band.
+    // Workgroup LDS = kResolveFixedLds + two bitmaps: 9.4 KB with the 10 126 contexts of the default model, so that the registers (four
+    // wavefronts per SIMD) and not the LDS bound k_resolve's occupancy.  A total can be forced to re-measure what occupancy is worth.
+    // Range coder mapping.  One lane per slice is a serial chain of 21 VALU instructions per decision; a batch holds max_batch x S of them,
+    // 64 to a wavefront.  With fewer wavefronts than the chip has SIMDs (1024) the chains, not the chip, set the batch time: then the
+    // coder is split (k_rc_range / k_rangecode<true> / k_rc_tails).  With thousands of slices in flight the whole-slice coder is already a
+    // throughput kernel and the first pass would only add its nine instructions per decision.
     {
-        const size_t sweet = 19088, have = size_t(kResolveFixedLds) + e->resolve_lds;
-        if (!(size_t(e->nkeys) * 32 <= (48u << 10)) && have < sweet) e->resolve_lds += sweet - have;
-        if (const char* x = getenv("RCGPU_RESOLVE_LDS_PAD")) e->resolve_lds += size_t(std::max(0, atoi(x)));       // for re-measuring the band
+        const size_t waves = (size_t(cfg->max_batch) * S + 63) / 64;
+        e->span_pieces = cfg->rc_span == RCGPU_RC_WHOLE ? 0u : cfg->rc_span ? cfg->rc_span : (waves < 1024 && e->sp.version != 1 ? 64u : 0u);
+        e->exp_skip_rc = getenv("RCGPU_EXP_SKIP_RC") != nullptr;
+        if (const char* x = getenv("RCGPU_RC_SPAN")) { const int v = atoi(x); e->span_pieces = v >= 8 ? uint32_t(v) : 0u; }      // for measuring
+    }
+    // Measured (4096x2160, 336 frames, round 3): k_resolve alone 390 / 372 / 408 / 431 / 509 / 617 ms per step at 16 / 12 / 10 / 8 / 6 / 4
+    // wavefronts per CU; beside the whole-slice range coder 10 per CU (16 000 B) is best, beside the split coder 11-12 (13 600 B): the
+    // other kernels' wavefronts need room in the CU too.
+    {
+        const size_t have = size_t(kResolveFixedLds) + e->resolve_lds;
+        size_t want = e->lds_states ? 0 : e->span_pieces ? 13600 : 16000;
+        if (const char* x = getenv("RCGPU_RESOLVE_LDS_TOTAL")) want = size_t(atoi(x));
+        if (want > have) e->resolve_lds += want - have;
     }
     if (e->lds_states) { e->resolve_lds += size_t(e->nkeys) * 32; e->resume_stride = uint32_t(80 + e->nkeys * 32); }
     e->frame_payload = size_t(payload_bytes(cfg->pixfmt, cfg->width, cfg->height, cfg->line_bytes, cfg->flags));
@@ -1288,7 +1494,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
             g.hdr_off = uint32_t(hdr.size()); g.hdr_n = uint32_t(hd.size());
             if (g.hdr_n > uint32_t(kStageEntries)) { delete e; return fail(2, "ffv1: %u header decisions do not fit k_resolve's stage", g.hdr_n); }
             for (uint16_t d16 : hd) hdr.push_back(uint16_t(((d16 & 0x100) ? (d16 & 0xFF) : (256 - (d16 & 0xFF))) | (d16 & 0x100)));   // (state, bit) -> t | bit << 8
-            const size_t cap = slice_buffer_bytes(d, g.w, g.h, e->sp.version);
+            const size_t cap = slice_buffer_bytes(d, g.w, g.h, e->sp.version, cfg->slice_buffer_div);
             if (cap >= (size_t(1) << 31)) { delete e; return fail(2, "ffv1: a version 1 frame of %ux%u does not fit the coder's 31-bit byte positions", g.w, g.h); }
             cb += 16;        // slack in front of every slice buffer: k_rangecode's first (empty) second-stage store lands here
             g.cbuf_off_lo = uint32_t(cb); g.cbuf_off_hi = uint32_t(uint64_t(cb) >> 32); g.cbuf_cap = uint32_t(cap);
@@ -1319,13 +1525,15 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
 #undef HM
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->rc_stream, hipStreamNonBlocking);
-    e->ev.resize(2 * (6 + 2 * nseg));              // timing events: k_model, footer, scan, gather + two kernels per segment
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->rr_stream, hipStreamNonBlocking);
+    e->ev.resize(2 * (7 + 3 * nseg));              // timing events: k_model, tails, footer, scan, gather + up to three kernels per segment
     for (auto& ev : e->ev) if (he == hipSuccess) he = hipEventCreate(&ev);
     e->ev_prev.resize(e->ev.size());
     for (auto& ev : e->ev_prev) if (he == hipSuccess) he = hipEventCreate(&ev);
     for (uint32_t j = 0; j < nseg; j++) {
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k3[j], hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k4[j], hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_rr[j], hipEventDisableTiming);
     }
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
     if (he == hipSuccess) he = hipMemcpy(e->d_const, &e->hc, sizeof(enc_const), hipMemcpyHostToDevice);
@@ -1360,6 +1568,8 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(hip_stream);       // NULL = the default stream: ordered after the caller's earlier work
     hipStream_t s2 = e->rc_stream;
+    static const bool exp_serial = getenv("RCGPU_EXP_SERIAL") != nullptr;      // timing runs: every kernel alone on the device, one after the other
+    if (exp_serial) s2 = st;
     const enc_const& c = e->hc;
     const uint32_t S = c.S, nchains = n * S, ngroups = (nchains + 63) / 64, nseg = e->nseg;
     std::swap(e->ev, e->ev_prev); std::swap(e->ev_kernel, e->ev_kernel_prev); e->ev_used_prev = e->ev_used;      // timing events alternate between two sets
@@ -1381,6 +1591,8 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     for (const slice_geom& g : e->geom) max_tiles = std::max(max_tiles, ((g.w + kTileW - 1) / kTileW) * ((g.h + kTileR - 1) / kTileR));
     HIP_TRY(timed(1, st, [&] { hipLaunchKernelGGL(k_model, dim3(max_tiles, nchains), dim3(256), size_t(c.planes) * kTileRows * kTileCols * 4, st,
                                                   e->d_const, e->d_geom, e->d_frame_ptrs, e->d_sym, e->d_ndec); }));
+    // states_coded = 0: every context starts at 128 (beside the host round trip below)
+    if (!e->lds_states) HIP_TRY(hipMemsetAsync(e->d_states, 0x80, size_t(nchains) * e->nkeys * 32, st));
     // The exact decision counts size the stream windows: one host round trip per batch.
     HIP_TRY(rc::copy_by_kernel(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * nseg * 8, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -1409,6 +1621,25 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         window_need = std::max<size_t>(window_need, off);
     }
     e->last_decisions = total_dec;
+    uint32_t total_spans = 0;
+    if (e->span_pieces) {
+        e->seg_spans.assign(nseg, 0); e->seg_span_off.assign(nseg, 0);
+        for (uint32_t j = 0; j < nseg; j++) {
+            uint32_t mx = 0;
+            for (uint32_t chain = 0; chain < nchains; chain++) mx = std::max(mx, e->h_seg_pieces[size_t(j) * nchains + chain]);
+            e->seg_span_off[j] = total_spans;
+            e->seg_spans[j] = std::max(1u, (mx + e->span_pieces - 1) / e->span_pieces);
+            total_spans += e->seg_spans[j];
+        }
+        const size_t need = size_t(total_spans) * nchains * sizeof(rc_ckpt);
+        if (need > e->ckpt_cap) {
+            if (e->d_ckpt) HIP_TRY(hipFree(e->d_ckpt));
+            e->d_ckpt = nullptr; e->ckpt_cap = 0;
+            const size_t want = need + need / 8 + (1u << 20);
+            if (hipMalloc(reinterpret_cast<void**>(&e->d_ckpt), want) != hipSuccess) return fail(101, "ffv1: cannot allocate %zu bytes of range-coder checkpoints for %u frames -- lower max_batch", want, n);
+            e->ckpt_cap = want;
+        }
+    }
     if (window_need > e->window_cap) {
         for (auto& w : e->d_window) { if (w) HIP_TRY(hipFree(w)); w = nullptr; }
         e->window_cap = 0;
@@ -1422,9 +1653,13 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(rc::copy_by_kernel(e->d_total_n, e->h_total_n, size_t(nchains) * 8, st));
     HIP_TRY(rc::copy_by_kernel(e->d_seg_pieces, e->h_seg_pieces, (size_t(nchains) * nseg * 4 + 7) & ~size_t(7), st));
     HIP_TRY(rc::copy_by_kernel(e->d_group_off, e->h_group_off, size_t(ngroups) * nseg * 8, st));
-    // k_resolve(seg j) on the caller's stream, k_rangecode(seg j) on rc_stream; window j % nwin is reused once k_rangecode(j - nwin) is done
+    // k_resolve(seg j) on the caller's stream, k_rangecode(seg j) on rc_stream; window j % nwin is reused once k_rangecode(j - nwin) is done.
+    // Split coder: k_rc_range(seg j) on rr_stream between the two -- it follows k_resolve(j) and its own previous segment, the spans of
+    // segment j follow it and nothing else.
+    hipStream_t s3 = exp_serial ? st : e->rr_stream;
     HIP_TRY(hipEventRecord(e->ev_fork, st));
     HIP_TRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
+    if (e->span_pieces) HIP_TRY(hipStreamWaitEvent(s3, e->ev_fork, 0));
     for (uint32_t j = 0; j < nseg; j++) {
         uint8_t* win = e->d_window[j % e->nwin];
         if (j >= e->nwin) HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[j - e->nwin], 0));
@@ -1434,12 +1669,29 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
             else hipLaunchKernelGGL(k_resolve<false>, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
                                     e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride); }));
         HIP_TRY(hipEventRecord(e->ev_k3[j], st));
-        HIP_TRY(hipStreamWaitEvent(s2, e->ev_k3[j], 0));
-        HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
-                                                      j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
-                                                      (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events); }));
+        if (e->exp_skip_rc) { HIP_TRY(hipStreamWaitEvent(s2, e->ev_k3[j], 0)); HIP_TRY(hipEventRecord(e->ev_k4[j], s2)); continue; }    // timing runs: k_resolve alone
+        if (e->span_pieces) {
+            rc_ckpt* ck = e->d_ckpt + size_t(e->seg_span_off[j]) * nchains;
+            const uint32_t nsp = e->seg_spans[j];
+            HIP_TRY(hipStreamWaitEvent(s3, e->ev_k3[j], 0));
+            HIP_TRY(timed(7, s3, [&] { hipLaunchKernelGGL(k_rc_range, dim3(ngroups), dim3(64), 0, s3, e->d_const, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
+                                                          j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, nchains, ck, e->span_pieces, nsp); }));
+            HIP_TRY(hipEventRecord(e->ev_rr[j], s3));
+            HIP_TRY(hipStreamWaitEvent(s2, e->ev_rr[j], 0));
+            HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<true>, dim3(ngroups, nsp), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
+                                                          j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
+                                                          (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, ck, e->span_pieces); }));
+        } else {
+            HIP_TRY(hipStreamWaitEvent(s2, e->ev_k3[j], 0));
+            HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<false>, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
+                                                          j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
+                                                          (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, static_cast<rc_ckpt*>(nullptr), 0u); }));
+        }
         HIP_TRY(hipEventRecord(e->ev_k4[j], s2));
     }
+    if (e->span_pieces && !e->exp_skip_rc)
+        HIP_TRY(timed(8, s2, [&] { hipLaunchKernelGGL(k_rc_tails, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_ckpt, total_spans, nchains,
+                                                      e->d_cbuf, (unsigned long long)e->cbuf_frame_stride); }));
     // footer / scan / gather follow the last range-coder segment on its stream; the caller's stream then joins
     HIP_TRY(timed(4, s2, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));

@@ -536,8 +536,8 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             batch_done[mine[k]] = since(t0);
             if (trace && L.id == 0) {      // this batch's kernel times (HIP events): the next batch is already running on the other event set
                 mark("batch complete:", long(mine[k]));
-                const char* names[8]; float ms[8];
-                const int nk = more ? ffv1_prev_kernel_times(L.enc[B.video], names, ms, 8) : rcgpu_ffv1_last_kernel_times(L.enc[B.video], names, ms, 8);
+                const char* names[12]; float ms[12];
+                const int nk = more ? ffv1_prev_kernel_times(L.enc[B.video], names, ms, 12) : rcgpu_ffv1_last_kernel_times(L.enc[B.video], names, ms, 12);
                 std::string t = "kernel ms of this batch:";
                 for (int i = 0; i < nk; i++) if (ms[i] > 0) { char b[64]; snprintf(b, sizeof b, " %s %.1f", names[i], ms[i]); t += b; }
                 mark(t.c_str());

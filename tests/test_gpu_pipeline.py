@@ -103,11 +103,7 @@ def test_device_pointer_api_reports_a_slice_that_outgrew_its_buffer():
     w, h, pixfmt = 256, 128, synth.PIX_RGB16_BE
     bits, nc, _, _ = synth.PIX_INFO[pixfmt]
     pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, "noise", seed=5), pixfmt, True)
-    os.environ["RCGPU_TEST_CBUF_DIV"] = "64"
-    try:
-        enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 2, 2, 1, 1, max_batch=1)
-    finally:
-        del os.environ["RCGPU_TEST_CBUF_DIV"]
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 2, 2, 1, 1, max_batch=1, slice_buffer_div=64)
     d = torch.frombuffer(bytearray(pl), dtype=torch.uint8).cuda()
     pk = torch.empty(enc.max_packet, dtype=torch.uint8, device="cuda")
     sz = torch.zeros(1, dtype=torch.int64, device="cuda")

@@ -19,8 +19,10 @@ CASES = [
 ]
 
 
+# rc_span: 1 = one lane codes a whole slice, N = split coder with N-piece spans (0 = automatic: split when chains are few, as here)
+@pytest.mark.parametrize("rc_span", [0, 1, 8])
 @pytest.mark.parametrize("w,h,pixfmt,slices,kind,nframes", CASES)
-def test_stages_match_oracle(built, w, h, pixfmt, slices, kind, nframes):
+def test_stages_match_oracle(built, w, h, pixfmt, slices, kind, nframes, rc_span):
     bits, nc, bpp, be = synth.PIX_INFO[pixfmt]
     nh, nv = api.slices_to_grid(slices)
     payloads = []
@@ -28,7 +30,7 @@ def test_stages_match_oracle(built, w, h, pixfmt, slices, kind, nframes):
         comp = synth.components(w, h, nc, bits, kind, seed=100 + i)
         pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
         payloads.append(pl)
-    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=1)   # whole decision stream stays resident: every stage can be fetched
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=1, rc_span=rc_span)   # whole decision stream stays resident: every stage can be fetched
     p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
     assert enc.config_record() == ob.config_record(p)
     packets = enc.encode_host(payloads)
@@ -59,20 +61,22 @@ def test_stages_match_oracle(built, w, h, pixfmt, slices, kind, nframes):
     enc.close()
 
 
+@pytest.mark.parametrize("rc_span", [1, 8, 13, 64, 100000])
 @pytest.mark.parametrize("segments", [0, 2, 5, 16, 64])
-def test_segmented_handover_is_bit_exact(built, segments):
-    """The k_resolve -> k_rangecode hand-over in windows (resumable kernels, two streams) must not change a byte."""
+def test_segmented_handover_is_bit_exact(built, segments, rc_span):
+    """The k_resolve -> k_rangecode hand-over in windows (resumable kernels, two or three streams) must not change a byte, whether one
+    lane codes a whole slice (rc_span 1) or the coder is split into spans of rc_span pieces (k_rc_range / k_rangecode<true> / k_rc_tails)."""
     w, h, pixfmt, nh, nv, nframes = 200, 120, synth.PIX_RGB16_BE, 3, 2, 3
     payloads = []
     for i in range(nframes):
         pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 16, "film" if i else "noise", seed=50 + i), pixfmt, True)
         payloads.append(pl)
     p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
-    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=segments)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=segments, rc_span=rc_span)
     for rep in range(2):          # second call reuses every buffer and resume record
         packets = enc.encode_host(payloads)
         for f in range(nframes):
-            assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"segments={segments} call {rep} frame {f}"
+            assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"segments={segments} rc_span={rc_span} call {rep} frame {f}"
     enc.close()
 
 
@@ -188,6 +192,7 @@ def test_random_geometries_mixed_content(built, seed):
     if nh >= w or nv >= h:
         nh = nv = 1
     segments = [0, 1, 3, 7][int(rng.integers(0, 4))]
+    rc_span = [0, 1, 8, 9, 31, 64][int(rng.integers(0, 6))]      # range-coder mapping: automatic, whole slices, split into spans of N pieces
     maxv = (1 << bits) - 1
     payloads = []
     for f in range(3):
@@ -207,10 +212,10 @@ def test_random_geometries_mixed_content(built, seed):
         payloads.append(pl)
     for ctx in (1, 2):
         p = ob.Params(w, h, pixfmt, nh, nv, 1, ctx)
-        enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=3, segments=segments)
+        enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=3, segments=segments, rc_span=rc_span)
         packets = enc.encode_host(payloads)
         for f in range(3):
-            assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"context model {ctx}, frame {f}, {w}x{h} {nh}x{nv} segments {segments}"
+            assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"context model {ctx}, frame {f}, {w}x{h} {nh}x{nv} segments {segments} rc_span {rc_span}"
         enc.close()
         dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=3)        # and back through the device decoder
         assert dec.decode_host(packets, len(payloads[0])) == [bytes(x) for x in payloads], f"decoder, context model {ctx}, {w}x{h} {nh}x{nv}"
