@@ -370,8 +370,10 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                                                 const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
                                                 uint8_t* __restrict__ states, const unsigned long long* __restrict__ group_off,
                                                 uint8_t* __restrict__ stream, uint32_t nkeys, uint32_t seg,
-                                                uint8_t* __restrict__ resume, uint32_t resume_stride)
+                                                uint8_t* __restrict__ resume, uint32_t resume_stride, uint32_t prio)
 {
+    // Issue priority against the range coder's wavefronts on the same SIMD (the split coder's spans run at 0, its serial pass at 3).
+    if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     // One launch handles segment `seg` of every slice.  What must survive between launches -- the < 56 decisions that
     // did not fill a piece -- lives in `resume` (per chain: count, entries, their bits).  The context states of a batch are preset
     // to 128 in HBM by the host (states_coded = 0): 20 MB per 4K frame, against 3 GB of traffic the kernel itself causes.
@@ -952,6 +954,22 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
     // (a select against a zero constant turns them into flat loads of an unknown address space).
     uint4 cur[4], nxt[4];
     if (SPAN && !maxp) { if (active) ck->v = 0; return; }               // a span past the end of every slice of this group (uniform)
+    if (SPAN) {
+        // The span coder is a throughput kernel: its wavefronts fill the issue slots k_resolve's leave while they wait for the LDS, and
+        // what counts is how many of them fit beside those -- 64 registers instead of 80 without the second piece buffer.  The load's
+        // latency is covered by the other wavefronts of the SIMD.
+        for (unsigned long long pc = 0; pc < maxp; pc++) {
+            const unsigned long long pi = pc < npieces ? pc : (npieces ? npieces - 1 : 0);
+            const uint4* p = src + pi * (kGroupPieceBytes / 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[k] = p[k];
+            rc_drain<kRows>(r);
+            if (pc < npieces) {
+                const unsigned long long left = n - (p0 + pc) * kPieceEntries;
+                rc_piece<kDrain>(r, cur, left < kPieceEntries ? uint32_t(left) : uint32_t(kPieceEntries), err + 1, events);
+            }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) cur[k] = src[k];
     for (unsigned long long pc = 0; pc < maxp; pc++) {
@@ -970,6 +988,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+    }
     }
     rc_drain<kRows>(r);
     if (!SPAN && active && !last_seg) { rc_resume v; v.range = r.range; v.low = r.low; v.nb = r.nb; v.pd = r.pd; v.pos = r.pos; v.pad = 0; resume[cc] = v; }
@@ -1318,6 +1337,7 @@ struct rcgpu_ffv1 {
     hipStream_t own_stream = nullptr, rc_stream = nullptr;      // rc_stream: k_rangecode runs beside k_resolve
     hipStream_t rr_stream = nullptr;                            // split coder: k_rc_range's stream (the spans are coded on rc_stream)
     uint32_t span_pieces = 0;                                   // split coder: pieces per span; 0 = one lane codes a whole slice
+    uint32_t resolve_prio = 0;                                  // k_resolve's s_setprio
     bool exp_skip_rc = false;                                   // RCGPU_EXP_SKIP_RC: no range coder at all (timing runs of k_resolve alone; no valid output)
     rc_ckpt* d_ckpt = nullptr; size_t ckpt_cap = 0;             // [span of the batch][chain]
     std::vector<uint32_t> seg_spans, seg_span_off;
@@ -1451,6 +1471,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         const size_t waves = (size_t(cfg->max_batch) * S + 63) / 64;
         e->span_pieces = cfg->rc_span == RCGPU_RC_WHOLE ? 0u : cfg->rc_span ? cfg->rc_span : (waves < 1024 && e->sp.version != 1 ? 64u : 0u);
         e->exp_skip_rc = getenv("RCGPU_EXP_SKIP_RC") != nullptr;
+        if (const char* x = getenv("RCGPU_RESOLVE_PRIO")) e->resolve_prio = uint32_t(atoi(x));        // for measuring
         if (const char* x = getenv("RCGPU_RC_SPAN")) { const int v = atoi(x); e->span_pieces = v >= 8 ? uint32_t(v) : 0u; }      // for measuring
     }
     // Measured (4096x2160, 336 frames, round 3): k_resolve alone 390 / 372 / 408 / 431 / 509 / 617 ms per step at 16 / 12 / 10 / 8 / 6 / 4
@@ -1477,7 +1498,9 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         }
     e->nseg = cfg->segments ? cfg->segments : std::max(1u, std::min(32u, min_nsamp / 1024));
     c.nseg = e->nseg;
-    e->nwin = kWindows;
+    // the split coder keeps a window until its spans are coded, two kernels behind k_resolve: a third window keeps k_resolve from waiting
+    // (4096x2160, 168 frames per step: 476 frames/s with two windows, 565 with three or four)
+    e->nwin = e->span_pieces ? kWindows + 1 : kWindows;
     if (const char* x = getenv("RCGPU_WINDOWS")) e->nwin = uint32_t(std::min<int>(kMaxWindows, std::max(2, atoi(x))));       // for measuring
 
     // slice geometry (FFV1_Slice.cpp:153-156), header decisions, raw-byte buffers
@@ -1665,9 +1688,9 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         if (j >= e->nwin) HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[j - e->nwin], 0));
         HIP_TRY(timed(2, st, [&] {
             if (e->lds_states) hipLaunchKernelGGL(k_resolve<true>, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
-                                                  e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride);
+                                                  e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride, e->resolve_prio);
             else hipLaunchKernelGGL(k_resolve<false>, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
-                                    e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride); }));
+                                    e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride, e->resolve_prio); }));
         HIP_TRY(hipEventRecord(e->ev_k3[j], st));
         if (e->exp_skip_rc) { HIP_TRY(hipStreamWaitEvent(s2, e->ev_k3[j], 0)); HIP_TRY(hipEventRecord(e->ev_k4[j], s2)); continue; }    // timing runs: k_resolve alone
         if (e->span_pieces) {
@@ -1678,6 +1701,8 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
                                                           j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, nchains, ck, e->span_pieces, nsp); }));
             HIP_TRY(hipEventRecord(e->ev_rr[j], s3));
             HIP_TRY(hipStreamWaitEvent(s2, e->ev_rr[j], 0));
+            static const bool exp_skip_b = getenv("RCGPU_EXP_SKIP_B") != nullptr;        // timing runs: no span coder (no valid output)
+            if (!exp_skip_b)
             HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<true>, dim3(ngroups, nsp), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
                                                           j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
                                                           (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, ck, e->span_pieces); }));

@@ -132,9 +132,10 @@ uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& c)
     const uint64_t nsets = d.planes == 1 ? 1 : d.planes == 4 ? 3 : 2;
     const uint64_t states = nctx * nsets * 32 <= (48u << 10) ? 0 : S * nctx * nsets * 32;
     const uint64_t nseg = c.segments ? c.segments : std::max<uint64_t>(1, std::min<uint64_t>(32, samples / S / 1024));
-    const uint64_t windows = samples * 35 * 8 / 7 * (nseg > 1 ? 2 : 1) / nseg;              // worst case: 35 decisions per sample, 64 bytes per 56 of them
+    const uint64_t windows = samples * 35 * 8 / 7 * (nseg > 1 ? 3 : 1) / nseg;              // worst case: 35 decisions per sample, 64 bytes per 56 of them; three windows (split coder)
+    const uint64_t ckpt = samples * 35 / 56 / 8 + S * nseg * 8;                              // split coder: 8 bytes per span of >= 8 pieces and slice
     const uint64_t cbuf = raw * 3 / 2 + S * ((256u << 10) + 4096 + 32);
-    return samples * 4 + states + windows + 2 * cbuf + raw + (1u << 20);
+    return samples * 4 + states + windows + ckpt + 2 * cbuf + raw + (1u << 20);
 }
 
 int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options& opt)
