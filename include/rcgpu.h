@@ -199,8 +199,9 @@ int rcgpu_ffv1_encode_host(rcgpu_ffv1* enc, const uint8_t* const* frames, uint32
  * come back in frame order: place_packet (one thread, frame order; may be NULL) says where packet `frame` of `size` bytes belongs --
  * e.g. inside a mapped output file, see rcgpu_mkv_reserve_block -- and writer threads copy it there and call packet_done; when
  * place_packet is NULL or returns NULL, packet_done receives the pinned buffer itself (valid during the call).  Frames shard over the
- * selected devices by batch, no collective.  cfg->device and cfg->max_batch are ignored (options.batch, or sized from free device
- * memory).  All callbacks return 0 for success; a failure ends the job with that code. */
+ * selected devices by batch, no collective.  cfg->device is ignored (options.device_first / device_count); the batch is options.batch,
+ * else cfg->max_batch when that is above 1, else sized from the device's free memory and the sequence length.  All callbacks return 0
+ * for success; a failure ends the job with that code. */
 typedef struct {
     int      (*read_frame)(void* user, uint64_t frame, uint8_t* dst, size_t payload_bytes);     /* reader threads, concurrent */
     uint8_t* (*place_packet)(void* user, uint64_t frame, size_t size);                         /* one thread, frame order; optional */
@@ -217,13 +218,14 @@ typedef struct {
 } rcgpu_sequence_options;
 typedef struct {
     double   seconds;                   /* first read_frame .. last packet_done */
-    double   first_packet_seconds, prepare_seconds, device_busy_seconds;
+    double   first_packet_seconds, prepare_seconds;
+    double   device_busy_seconds;       /* device 0: first encode call .. completion of its last batch */
     uint64_t frames, payload_bytes, packet_bytes, batches;
     uint32_t batch_frames, devices, readers, writers;
     double   steady_frames_per_second;  /* all batches but the first / time from the first batch's completion to the last's */
     double   reads_done_seconds, last_batch_seconds;
     double   upload_wait_seconds;       /* device 0: time its host thread waited for the readers */
-    double   h2d_span_seconds;          /* device 0: sum over batches of first upload start .. last upload end */
+    double   h2d_span_seconds;          /* device 0: sum over batches of first upload start .. last upload end (device clock, HIP events) */
     double   read_call_seconds, write_call_seconds;   /* average duration of one read_frame call / one packet copy + packet_done call */
 } rcgpu_sequence_stats;
 /* record/record_size: optional, the FFV1 configuration record (Matroska CodecPrivate), *record_size = capacity in, size out. */
@@ -343,8 +345,9 @@ int  rcgpu_mkv_write_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, const uin
 int  rcgpu_mkv_expect(rcgpu_mkv* mux, uint64_t max_block_bytes, uint64_t max_blocks);
 int  rcgpu_mkv_reserve_block(rcgpu_mkv* mux, int track, uint64_t pts_ns, size_t size, int keyframe, uint8_t** dst, uint64_t* file_offset);
 int  rcgpu_mkv_fill(rcgpu_mkv* mux, uint64_t file_offset, const uint8_t* data, size_t size);
-void rcgpu_mkv_copy_in(rcgpu_mkv* mux, uint8_t* dst, const uint8_t* src, size_t size);   /* copies a payload to its *dst (any thread): waits for the
-                                     pages to exist, maps the range in one call, copies */
+int  rcgpu_mkv_copy_in(rcgpu_mkv* mux, uint8_t* dst, const uint8_t* src, size_t size);   /* copies a payload to its *dst (any thread): waits for the
+                                     pages to exist, maps the range in one call, copies.  When the pages cannot be had (the file system is
+                                     full) the payload goes through pwrite() instead and its error comes back: never a SIGBUS */
 /* Patches A_FLAC CodecPrivate written by begin() (same size) once STREAMINFO is final. */
 int  rcgpu_mkv_update_codec_private(rcgpu_mkv* mux, int track, const uint8_t* codec_private, size_t cp_size);
 /* Writes Cues, patches Segment size / SeekHead / Duration; closes the file. */

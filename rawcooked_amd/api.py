@@ -107,7 +107,7 @@ SYMBOLS = {
                                           C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
     "rcgpu_mkv_expect": (C.c_int, [_VP, C.c_uint64, C.c_uint64]),
     "rcgpu_mkv_reserve_block": (C.c_int, [_VP, C.c_int, C.c_uint64, _SZ, C.c_int, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
-    "rcgpu_mkv_copy_in": (None, [_VP, _VP, _VP, _SZ]),
+    "rcgpu_mkv_copy_in": (C.c_int, [_VP, _VP, _VP, _SZ]),
     "rcgpu_mkv_fill": (C.c_int, [_VP, C.c_uint64, _VP, _SZ]),
     "rcgpu_ffv1_framemd5_last": (C.c_int, [_VP, C.c_uint32, _VP, C.POINTER(C.c_uint64)]),
     "rcgpu_ffv1_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),

@@ -425,7 +425,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
             block_off[f.video][size_t(f.index)] = off; block_dst[f.video][size_t(f.index)] = dst;
             return dst;
         };
-        io.copy = [&](uint8_t* dst, const uint8_t* src, size_t size) { rcgpu_mkv_copy_in(mux, dst, src, size); };
+        io.copy = [&](uint8_t* dst, const uint8_t* src, size_t size) -> int { return rcgpu_mkv_copy_in(mux, dst, src, size); };
         io.done = [&](const rc::pipe_frame& f, const uint8_t* data, size_t size) -> int {
             if (block_dst[f.video][size_t(f.index)]) return 0;                   // a writer thread copied it into the mapped file
             return rcgpu_mkv_fill(mux, block_off[f.video][size_t(f.index)], data, size);

@@ -15,6 +15,8 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/vfs.h>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 
@@ -83,6 +85,9 @@ struct rcgpu_mkv {
     // writers' page faults only map pages that exist (see rcgpu_mkv_expect)
     std::thread prealloc; std::atomic<bool> prealloc_stop{ false }, prealloc_alive{ false }, allocating{ false };
     std::atomic<uint64_t> reserved_to{ 0 }, prealloc_to{ 0 }; std::atomic<int> active_copies{ 0 }; uint64_t prealloc_first = 0;
+    // fallocate() said no (ENOSPC, or a file system without it): nothing behind prealloc_to is written through the mapping from then on --
+    // a fault on a page tmpfs cannot back is a SIGBUS, a pwrite() there is an error code
+    std::atomic<bool> alloc_failed{ false };
 
     uint64_t next_uid() { uid_seed ^= uid_seed << 13; uid_seed ^= uid_seed >> 7; uid_seed ^= uid_seed << 17; return uid_seed | 1; }
     int put(const void* p, size_t n)
@@ -90,7 +95,7 @@ struct rcgpu_mkv {
         const uint8_t* s = static_cast<const uint8_t*>(p);
         // inside the mapped part of the file the bytes go through the mapping: a pwrite() there would queue behind the thread that
         // allocates pages ahead (fallocate holds the file's lock for a whole chunk) -- 7 ms per block head, measured
-        if (map && pos >= map_base && pos + n <= map_base + map_len) { memcpy(map + (pos - map_base), p, n); pos += n; return 0; }
+        if (map && pos >= map_base && pos + n <= map_base + map_len && !(alloc_failed.load() && pos + n > prealloc_to.load())) { memcpy(map + (pos - map_base), p, n); pos += n; return 0; }
         while (n) {
             ssize_t w = ::pwrite(fd, s, n, off_t(pos));     // positional: other threads fill reserved blocks through the same descriptor
             if (w < 0) { if (errno == EINTR) continue; return fail(20, "mkv: write to %s failed: %s", path.c_str(), strerror(errno)); }
@@ -336,7 +341,10 @@ extern "C" int rcgpu_mkv_expect(rcgpu_mkv* m, uint64_t max_block_bytes, uint64_t
     if (p == MAP_FAILED) { if (ftruncate(m->fd, off_t(m->pos)) != 0) {} return 0; }
     m->map = static_cast<uint8_t*>(p); m->map_base = base; m->map_len = len;
     m->reserved_to = m->pos; m->prealloc_to = base; m->prealloc_alive = true;
-    m->prealloc_first = base + max_block_bytes / 2;      // packets are about half of their worst case: what a whole job probably needs
+    // the first stride starts at once, while the encoders are still being set up: packets are about half of their worst case, and a
+    // small job must not hold more memory than it writes
+    m->prealloc_first = base + std::min<uint64_t>(max_block_bytes / 2, uint64_t(8) << 30);
+
     m->prealloc = std::thread([m] {
         // fallocate() and the writers' page faults slow each other down when they overlap (a fault that meets an allocation in progress
         // takes the file's spin lock; measured: 6 GB/s together against 17 GB/s + 57 GB/s apart), so they take turns: allocation
@@ -354,10 +362,11 @@ extern "C" int rcgpu_mkv_expect(rcgpu_mkv* m, uint64_t max_block_bytes, uint64_t
             bool ok = true;
             while (done < upto && !m->prealloc_stop.load()) {
                 const uint64_t n = std::min<uint64_t>(chunk, upto - done);
-                if (fallocate(m->fd, 0, off_t(done), off_t(n)) != 0) { ok = false; break; }   // not supported or no room: the faults allocate, as before
+                if (fallocate(m->fd, 0, off_t(done), off_t(n)) != 0) { ok = false; break; }   // not supported, or no room
                 done += n;
                 m->prealloc_to = done;
             }
+            if (!ok) m->alloc_failed = true;         // before the writers are let go: they take the pwrite() path behind prealloc_to
             m->allocating = false;
             if (!ok) break;
         }
@@ -370,23 +379,34 @@ extern "C" int rcgpu_mkv_expect(rcgpu_mkv* m, uint64_t max_block_bytes, uint64_t
 // Writer threads: copy a payload to where reserve_block() put it.  Waits until the allocating thread has passed the range (a fault on a
 // page that does not exist yet allocates it the slow way), stays out of its strides, maps the range in one call instead of one fault
 // per page, copies.
-extern "C" void rcgpu_mkv_copy_in(rcgpu_mkv* m, uint8_t* dst, const uint8_t* src, size_t size)
+extern "C" int rcgpu_mkv_copy_in(rcgpu_mkv* m, uint8_t* dst, const uint8_t* src, size_t size)
 {
-    if (!m || !m->map || !dst || dst < m->map || dst + size > m->map + m->map_len) { if (dst && src) memcpy(dst, src, size); return; }
-    const uint64_t end_off = m->map_base + uint64_t((dst + size) - m->map);
+    if (!m || !m->map || !dst || dst < m->map || dst + size > m->map + m->map_len) { if (dst && src) memcpy(dst, src, size); return 0; }
+    const uint64_t begin_off = m->map_base + uint64_t(dst - m->map), end_off = begin_off + size;
     for (;;) {
         while (m->prealloc_alive.load() && (m->prealloc_to.load() < end_off || m->allocating.load())) std::this_thread::sleep_for(std::chrono::microseconds(50));
         m->active_copies++;
         if (!m->prealloc_alive.load() || !m->allocating.load()) break;
         m->active_copies--;                                  // a stride began in between: step back
     }
+    if (m->alloc_failed.load() && end_off > m->prealloc_to.load()) {
+        // the pages were never allocated: through the descriptor, where "no space left" is an error code and not a SIGBUS
+        m->active_copies--;
+        return rcgpu_mkv_fill(m, begin_off, src, size);
+    }
     const uintptr_t a = reinterpret_cast<uintptr_t>(dst) & ~uintptr_t(4095), b = (reinterpret_cast<uintptr_t>(dst) + size + 4095) & ~uintptr_t(4095);
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif
-    (void)madvise(reinterpret_cast<void*>(a), size_t(b - a), MADV_POPULATE_WRITE);      // older kernels: EINVAL, the copy faults page by page
+    // maps the range in one call instead of one fault per page.  EINVAL: a kernel without it, the copy faults page by page.  Anything
+    // else (ENOMEM, EFAULT: the pages cannot be had) would be a SIGBUS inside the memcpy: pwrite() instead, and report what it says.
+    if (madvise(reinterpret_cast<void*>(a), size_t(b - a), MADV_POPULATE_WRITE) != 0 && errno != EINVAL) {
+        m->active_copies--;
+        return rcgpu_mkv_fill(m, begin_off, src, size);
+    }
     memcpy(dst, src, size);
     m->active_copies--;
+    return 0;
 }
 
 extern "C" int rcgpu_mkv_reserve_block(rcgpu_mkv* m, int trk, uint64_t pts_ns, size_t size, int keyframe, uint8_t** dst, uint64_t* file_offset)
@@ -406,7 +426,8 @@ extern "C" int rcgpu_mkv_reserve_block(rcgpu_mkv* m, int trk, uint64_t pts_ns, s
     if (int r = m->put(head.b.data(), head.b.size())) return r;
     if (int r = m->put(c.b.data(), c.b.size())) return r;
     *file_offset = m->pos;
-    *dst = (m->map && m->pos >= m->map_base && m->pos + size <= m->map_base + m->map_len) ? m->map + (m->pos - m->map_base) : nullptr;
+    *dst = (m->map && m->pos >= m->map_base && m->pos + size <= m->map_base + m->map_len
+            && !(m->alloc_failed.load() && m->pos + size > m->prealloc_to.load())) ? m->map + (m->pos - m->map_base) : nullptr;
     m->pos += size;
     m->reserved_to = m->pos;
     t.last_pts_ms = ms;
@@ -446,6 +467,8 @@ extern "C" int rcgpu_mkv_close(rcgpu_mkv* m)
         // (12 million page-table entries for a 50 GB file: 1.8 s in this one thread.  Dropping them per packet with MADV_DONTNEED cost the
         // pipeline 1.9 s in TLB shoot-downs, dropping them here from eight threads took 4 s: measured, not kept.  The job overlaps this
         // call with giving back its device and pinned memory instead.)
+        // Unmapping finished ranges during the allocation strides instead was measured in round 3: close() 1.8 -> 0.3 s, the pipeline
+        // 4.3 -> 6.0 s -- the strides wait for the unmapping, the writers for the strides.
         munmap(m->map, size_t(m->map_len)); m->map = nullptr;
         if (ftruncate(m->fd, off_t(m->pos)) != 0) r = fail(22, "mkv: cannot size %s: %s", m->path.c_str(), strerror(errno));
     }

@@ -33,8 +33,8 @@ struct pipe_io {
     std::function<uint8_t*(const pipe_frame& f, size_t size)> place;
     // writer threads, concurrently: the packet is at `data` (== the place, or a pinned buffer valid during the call).  0 = ok.
     std::function<int(const pipe_frame& f, const uint8_t* data, size_t size)> done;
-    // optional, writer threads: how a packet gets to its place (default: memcpy); a mapped file wants its range pre-faulted first
-    std::function<void(uint8_t* dst, const uint8_t* src, size_t size)> copy;
+    // optional, writer threads: how a packet gets to its place (default: memcpy); a mapped file wants its range pre-faulted first.  0 = ok.
+    std::function<int(uint8_t* dst, const uint8_t* src, size_t size)> copy;
     // optional, lane thread, after a batch has run and while its payloads are still on the device (e.g. frame checksums).
     // Setting it serialises upload and encoding of consecutive batches.
     std::function<int(uint32_t video, rcgpu_ffv1* enc, uint64_t first_index, uint32_t n)> after_batch;
@@ -54,7 +54,7 @@ struct pipe_stats {
     double seconds = 0, first_packet_seconds = 0, prepare_seconds = 0;
     uint64_t frames = 0, payload_bytes = 0, packet_bytes = 0, batches = 0;
     uint32_t batch_frames = 0, lanes = 0, readers = 0, writers = 0;
-    double device_busy_seconds = 0;             // sum over batches of (batch complete - encode call), lane 0
+    double device_busy_seconds = 0;             // lane 0: first encode call .. completion of its last batch (its device has a batch in flight throughout)
     double steady_frames_per_second = 0;        // frames of all batches but the first / time from the first batch's completion to the last's
     double reads_done_seconds = 0, last_batch_seconds = 0;
     double upload_wait_seconds = 0;             // lane 0: time its thread waited for the readers to fill a slot

@@ -41,6 +41,7 @@ struct lane_t {
     std::vector<bool> dl_valid;
     hipEvent_t ev_up = nullptr, ev_up0 = nullptr, ev_done[2] = { nullptr, nullptr };     // ev_up0 / ev_up time the uploads of a batch
     double upload_wait = 0, h2d_span = 0, copy_calls = 0, dl_calls = 0, dl_wait = 0;
+    bool up_span_valid = false;                   // ev_up0 / ev_up hold a recorded pair
     // download ring: pinned chunks, a chunk is re-entered when nothing in it is outstanding
     std::vector<uint8_t*> chunks; std::vector<int> outstanding; size_t chunk_bytes = 0, max_chunks = 0; int cur = -1; size_t cur_off = 0;
     std::deque<out_entry> outq;                   // issued downloads in frame order, consumed by the placer
@@ -237,11 +238,22 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     const int nl = int(s.lanes.size());
 
     // ---- batches: runs of consecutive frames of one video, dealt round-robin to the lanes
+    // RCGPU_RAMP=1 makes the first two batches of a long sequence short (a fifth and a half).  Measured in round 3 on 1000 4K files:
+    // the first packet leaves after 0.8 s instead of 1.3 s, but five batches instead of three have five starts and drains -- the job
+    // takes 8.1 s instead of 7.1 s, host to host 550 instead of 573 frames/s.  For callers that want the first packet early, not the last.
     std::vector<batch_t> batches; std::vector<uint32_t> batch_of(N);
+    std::vector<uint32_t> made(s.videos.size(), 0);
+    static const bool ramp = getenv("RCGPU_RAMP") != nullptr;
     for (size_t i = 0; i < N;) {
         const uint32_t v = frames[i].video;
+        size_t cap = s.F[v];
+        if (ramp && s.videos[v].frames > 2 * uint64_t(s.F[v]) && s.F[v] >= 40) {
+            const uint32_t k = made[v] / uint32_t(nl);                       // every lane gets a short first and second batch
+            if (k == 0) cap = s.F[v] / 5; else if (k == 1) cap = s.F[v] / 2;
+        }
+        made[v]++;
         size_t n = 1;
-        while (i + n < N && n < s.F[v] && frames[i + n].video == v) n++;
+        while (i + n < N && n < cap && frames[i + n].video == v) n++;
         for (size_t k = 0; k < n; k++) batch_of[i + k] = uint32_t(batches.size());
         batches.push_back({ v, i, n, int(batches.size() % size_t(nl)) });
         i += n;
@@ -258,13 +270,15 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         // ring: 1..4 GB in chunks that hold at least two worst-case packets.  It only has to cover the writers' reaction time: a ring that
         // held a whole batch of packets (17.8 GB at 4K) gave the same rates (host to host 482 frames/s with 2, 4, 8 or 17.8 GB) and cost
         // 1.4 s of page-locking at the start of a job and as much again when it ended (1000 4K files: 7.4 s with 17.8 GB, 6.5 s with 4)
-        L.chunk_bytes = std::max<size_t>(size_t(256) << 20, 2 * max_pkt);
+        uint64_t total_need = 0; for (const batch_t& b : batches) if (b.lane == L.id) total_need += uint64_t(b.n) * s.max_packet[b.video];
+        // ... and a small job pins what it needs, not 512 MB per lane: chunks of half the lane's packets, at least two worst-case packets
+        // (chunks of an earlier run() on this pipeline are kept, and their size with them)
+        if (L.chunks.empty()) L.chunk_bytes = std::max<size_t>(2 * max_pkt, size_t(std::min<uint64_t>(uint64_t(256) << 20, ((total_need / 2 + 4095) & ~uint64_t(4095)))));
         uint64_t want = s.opt.out_ring_bytes ? s.opt.out_ring_bytes : std::min<uint64_t>(uint64_t(4) << 30, std::max<uint64_t>(uint64_t(1) << 30, uint64_t(maxF) * max_payload));
         if (const char* x = getenv("RCGPU_OUT_RING_MB")) if (!s.opt.out_ring_bytes && atoll(x) > 0) want = uint64_t(atoll(x)) << 20;        // for sizing experiments
-        uint64_t total_need = 0; for (const batch_t& b : batches) if (b.lane == L.id) total_need += uint64_t(b.n) * s.max_packet[b.video];
         want = std::min<uint64_t>(want, std::max<uint64_t>(total_need, L.chunk_bytes));
-        L.max_chunks = std::max<size_t>(2, size_t((want + L.chunk_bytes - 1) / L.chunk_bytes));
-        L.cur = -1; L.cur_off = 0; L.outq.clear(); L.upload_wait = 0; L.h2d_span = 0; L.copy_calls = L.dl_calls = L.dl_wait = 0;
+        L.max_chunks = total_need ? std::max<size_t>(2, size_t((want + L.chunk_bytes - 1) / L.chunk_bytes)) : 0;      // a lane without batches pins nothing
+        L.cur = -1; L.cur_off = 0; L.outq.clear(); std::fill(L.outstanding.begin(), L.outstanding.end(), 0); L.up_span_valid = false; L.upload_wait = 0; L.h2d_span = 0; L.copy_calls = L.dl_calls = L.dl_wait = 0;
         std::fill(L.dl_valid.begin(), L.dl_valid.end(), false);
     }
     s.ready.assign(N, nullptr); s.jobs.clear(); for (lane_t& L : s.lanes) L.pending.clear(); s.placer_finished = false; s.next_read = 0; s.alloc_done = false;
@@ -389,35 +403,63 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         // per batch in which the device-to-host direction ran at 48 GB/s and the host-to-device direction stood still), although the two
         // directions overlap perfectly when their copies are issued side by side (tools/probe_dma.py).
         std::vector<uint8_t*> ugroup;
-        // a group must never hold so much of the pool (or of the ring) that what it waits for cannot happen before its event is recorded
-        const size_t ugroup_max = std::max<size_t>(1, std::min<size_t>(kUploadGroup, s.slots_wanted / 4));
-        const size_t dgroup_max = std::max<size_t>(1, std::min<size_t>(kDownloadGroup, L.max_chunks * (L.chunk_bytes / std::max<size_t>(1, (max_pkt + 4095) & ~size_t(4095))) / 4));
+        // A group must never hold so much of the pool (or of the ring) that what it waits for cannot happen before its event is recorded:
+        // at most a quarter of this lane's share, from the sizes as they are NOW (the allocator shrinks slots_wanted and max_chunks when
+        // pinned memory runs short; both are read under the lock), and a group that is still open is closed before its lane blocks.
+        auto flush_ugroup = [&]() -> bool {
+            if (ugroup.empty()) return true;
+            hipStream_t cs = L.cin[L.up_turn % L.cin.size()];
+            hipEvent_t ev = get_event();
+            if (!ev) { s.set_error(100, "pipeline: cannot create an event"); return false; }
+            if (!hip_ok(hipEventRecord(ev, cs), "hipEventRecord")) { std::lock_guard<std::mutex> l(s.m); L.free_events.push_back(ev); return false; }
+            { std::lock_guard<std::mutex> l(s.m); L.pending.push_back({ ugroup, ev }); }
+            ugroup.clear(); L.up_turn++;
+            return true;
+        };
         auto upload_one = [&](const batch_t& B, const enc_staging& sg, size_t k) -> bool {
             uint8_t* slot = nullptr;
+            size_t ugroup_max = 1;
             {
                 const auto tw = clk::now();
                 std::unique_lock<std::mutex> l(s.m);
+                if (!s.error && !s.ready[B.first + k] && !ugroup.empty()) {      // about to wait for a reader: what is open becomes reclaimable first
+                    l.unlock();
+                    if (!flush_ugroup()) return false;
+                    l.lock();
+                }
                 s.cv_ready.wait(l, [&] { return s.error || s.ready[B.first + k]; });
                 if (s.error) return false;
                 slot = s.ready[B.first + k];
+                ugroup_max = std::max<size_t>(1, std::min<size_t>(kUploadGroup, s.slots_wanted / (4 * size_t(nl))));
                 L.upload_wait += since(tw);
             }
             const auto tc = clk::now();
             hipStream_t cs = L.cin[L.up_turn % L.cin.size()];          // a group stays on one stream: its event covers all of it
             if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, slot, sg.payload_bytes, hipMemcpyHostToDevice, cs), "upload")) return false;
             ugroup.push_back(slot);                          // one completion event per group of copies: an event is a barrier packet
-            if (ugroup.size() >= ugroup_max || k + 1 == B.n) {
-                hipEvent_t ev = get_event();
-                if (!ev || !hip_ok(hipEventRecord(ev, cs), "hipEventRecord")) return false;
-                { std::lock_guard<std::mutex> l(s.m); L.pending.push_back({ ugroup, ev }); }
-                ugroup.clear(); L.up_turn++;
-            }
+            if ((ugroup.size() >= ugroup_max || k + 1 == B.n) && !flush_ugroup()) return false;
             L.copy_calls += since(tc);
+            return true;
+        };
+        std::vector<out_entry> dgroup;
+        size_t dgroup_max = 1;
+        auto flush_dgroup = [&]() -> bool {                 // the group becomes visible to the placer once its event is recorded
+            if (dgroup.empty()) return true;
+            hipStream_t cs = L.cout[L.dn_turn % L.cout.size()];
+            hipEvent_t ev = get_event();
+            if (!ev) { s.set_error(100, "pipeline: cannot create an event"); return false; }
+            if (!hip_ok(hipEventRecord(ev, cs), "hipEventRecord")) { std::lock_guard<std::mutex> l(s.m); L.free_events.push_back(ev); return false; }
+            L.dn_turn++;
+            int* users = new int(int(dgroup.size()));
+            { std::lock_guard<std::mutex> l(s.m); for (out_entry& g : dgroup) { g.ev = ev; g.ev_users = users; L.outq.push_back(g); } }
+            dgroup.clear();
+            s.cv_out.notify_one();
             return true;
         };
         auto ring_alloc = [&](size_t size, int& chunk) -> uint8_t* {
             const size_t need = (size + 4095) & ~size_t(4095);
             std::unique_lock<std::mutex> l(s.m);
+            dgroup_max = std::max<size_t>(1, std::min<size_t>(kDownloadGroup, L.max_chunks * (L.chunk_bytes / std::max<size_t>(1, (max_pkt + 4095) & ~size_t(4095))) / 4));
             for (;;) {
                 if (s.error) return nullptr;
                 if (L.cur >= 0) {
@@ -428,6 +470,12 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 int pick = -1;
                 for (int k = 1; k <= nc && pick < 0; k++) { const int c = (L.cur + k) % nc; if (c != L.cur && L.outstanding[size_t(c)] == 0) pick = c; }
                 if (pick >= 0) { L.cur = pick; L.cur_off = 0; continue; }
+                if (!dgroup.empty()) {                      // the writers cannot see an open group, and this lane is about to wait for them
+                    l.unlock();
+                    if (!flush_dgroup()) return nullptr;
+                    l.lock();
+                    continue;
+                }
                 s.cv_ring.wait_for(l, std::chrono::milliseconds(1));
             }
             chunk = L.cur;
@@ -459,7 +507,6 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                    hip_ok(hipError_t(copy_by_kernel_on(L.h_err + 4 * par, sg.d_err, 16, st)), "flags") &&
                    hip_ok(hipEventRecord(L.ev_done[par], st), "hipEventRecord");
         };
-        std::vector<out_entry> dgroup;
         auto download_one = [&](const batch_t& B, const enc_staging& sg, int par, size_t i) -> bool {
             const uint64_t* sizes = L.h_sizes + size_t(par) * L.h_sizes_stride;
             out_entry o; o.frame = B.first + i; o.size = size_t(sizes[i]); o.device = L.device; o.lane = L.id;
@@ -476,15 +523,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (!hip_ok(hipMemcpyAsync(o.src, sg.d_packets + i * sg.packet_stride, whole, hipMemcpyDeviceToHost, cs), "download")) return false;
             L.dl_calls += since(tc);
             dgroup.push_back(o);
-            if (dgroup.size() >= dgroup_max || i + 1 == B.n) {       // the group becomes visible once its event is recorded
-                hipEvent_t ev = get_event();
-                if (!ev || !hip_ok(hipEventRecord(ev, cs), "hipEventRecord")) return false;
-                L.dn_turn++;
-                int* users = new int(int(dgroup.size()));
-                { std::lock_guard<std::mutex> l(s.m); for (out_entry& g : dgroup) { g.ev = ev; g.ev_users = users; L.outq.push_back(g); } }
-                dgroup.clear();
-                s.cv_out.notify_one();
-            }
+            if ((dgroup.size() >= dgroup_max || i + 1 == B.n) && !flush_dgroup()) return false;
             return true;
         };
         // everything issued so far on the streams of one direction is behind what stream 0 of it does next
@@ -504,6 +543,13 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 for (hipStream_t c : L.cout) if (!hip_ok(hipStreamWaitEvent(c, L.ev_done[par], 0), "hipStreamWaitEvent")) return false;
             }
             if (U && ffv1_staging(L.enc[U->video], &su)) { s.set_error(100, rcgpu_last_error()); return false; }
+            if (U) {
+                // device clock around this batch's uploads; the pair recorded for the previous batch has completed (its k_model has run)
+                float ms = 0;
+                if (L.up_span_valid && hipEventElapsedTime(&ms, L.ev_up0, L.ev_up) == hipSuccess) L.h2d_span += double(ms) * 1e-3;
+                if (!hip_ok(hipEventRecord(L.ev_up0, L.cin[0]), "hipEventRecord")) return false;
+                L.up_span_valid = true;
+            }
             const auto tu = clk::now();
             const size_t nd = D ? D->n : 0, nu = U ? U->n : 0;
             for (size_t i = 0; i < std::max(nd, nu); i++) {
@@ -520,7 +566,9 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         };
         if (mine.empty()) return;
         const bool serial = bool(io.after_batch);
-        if (!transfers(nullptr, 0, &batches[mine[0]]) || !start_batch(batches[mine[0]])) return;
+        if (!transfers(nullptr, 0, &batches[mine[0]])) return;
+        const double first_call = since(t0);
+        if (!start_batch(batches[mine[0]])) return;
         if (!serial && mine.size() > 1 && !transfers(nullptr, 0, &batches[mine[1]])) return;      // d_in is free: k_model(0) has run
         for (size_t k = 0; k < mine.size(); k++) {
             const batch_t& B = batches[mine[k]];
@@ -535,6 +583,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (more && !start_batch(batches[mine[k + 1]])) return;           // returns after k_model(k+1), which follows batch k on the stream
             if (!hip_ok(hipEventSynchronize(L.ev_done[par]), "batch")) return;
             batch_done[mine[k]] = since(t0);
+            if (L.id == 0) busy0 = batch_done[mine[k]] - first_call;       // the device of lane 0 has had a batch in flight since its first encode call
             if (trace && L.id == 0) {      // this batch's kernel times (HIP events): the next batch is already running on the other event set
                 mark("batch complete:", long(mine[k]));
                 const char* names[12]; float ms[12];
@@ -588,8 +637,8 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             if (!r) {
                 if (!first_seen.exchange(true)) first_packet_seconds = since(t0);
                 const auto tw = clk::now();
-                if (o.dst) { if (io.copy) io.copy(o.dst, o.src, o.size); else memcpy(o.dst, o.src, o.size); }
-                if (io.done) r = io.done(frames[o.frame], o.dst ? o.dst : o.src, o.size);
+                if (o.dst) { if (io.copy) r = io.copy(o.dst, o.src, o.size); else memcpy(o.dst, o.src, o.size); }
+                if (!r && io.done) r = io.done(frames[o.frame], o.dst ? o.dst : o.src, o.size);
                 { const double d = since(tw); double cur = write_busy.load(); while (!write_busy.compare_exchange_weak(cur, cur + d)) {} }
                 packet_bytes += o.size;
             }
@@ -615,10 +664,26 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     placer_thread.join();
     for (auto& t : wthreads) t.join();
     allocator.join();
-    for (lane_t& L : s.lanes) { (void)hipSetDevice(L.device); (void)hipDeviceSynchronize(); }
-    {   // slots still listed as pending are free now
+    for (lane_t& L : s.lanes) {
+        (void)hipSetDevice(L.device); (void)hipDeviceSynchronize();
+        float ms = 0;
+        if (L.up_span_valid && hipEventElapsedTime(&ms, L.ev_up0, L.ev_up) == hipSuccess) L.h2d_span += double(ms) * 1e-3;      // the last batch's uploads
+        L.up_span_valid = false;
+    }
+    {   // slots still listed as pending are free now; after an error, so is whatever the placer and the writers left behind: their
+        // events go back, and the ring is empty again for the next run() on this pipeline
         std::lock_guard<std::mutex> l(s.m);
-        for (lane_t& L : s.lanes) { for (auto& u : L.pending) L.free_events.push_back(u.ev); L.pending.clear(); }
+        auto drop = [&](std::deque<out_entry>& q) {
+            for (out_entry& o : q) if (o.ev_users && --*o.ev_users == 0) { s.lanes[size_t(o.lane)].free_events.push_back(o.ev); delete o.ev_users; }
+            q.clear();
+        };
+        for (lane_t& L : s.lanes) {
+            for (auto& u : L.pending) L.free_events.push_back(u.ev);
+            L.pending.clear();
+            drop(L.outq);
+        }
+        drop(s.jobs);
+        for (lane_t& L : s.lanes) { std::fill(L.outstanding.begin(), L.outstanding.end(), 0); L.cur = -1; L.cur_off = 0; }
         s.free_slots.clear();
     }
     if (stats) {

@@ -6,6 +6,7 @@ import ctypes as C
 import json
 import os
 import subprocess
+import sys
 import threading
 
 import pytest
@@ -123,7 +124,7 @@ def _muxer_paths(work, mode):
     def fill(part):
         for dst, off, pk in part:
             if dst:
-                L.rcgpu_mkv_copy_in(mux.h, dst, pk, len(pk))
+                assert L.rcgpu_mkv_copy_in(mux.h, dst, pk, len(pk)) == 0
             else:
                 assert L.rcgpu_mkv_fill(mux.h, off, pk, len(pk)) == 0
     ths = [threading.Thread(target=fill, args=(jobs[k::3],)) for k in range(3)]
@@ -166,3 +167,43 @@ def test_mkv_validator_negative_controls(built, tmp_path):
     (tmp_path / "d.mkv").write_bytes(good + b"junk after the segment")
     with pytest.raises(AssertionError):
         mkv_validator.validate(str(tmp_path / "d.mkv"))
+
+
+_FULL_FS_SCRIPT = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, sys.argv[2])
+from rawcooked_amd import api
+L = api.lib()
+mux = api.MkvMuxer(os.path.join(sys.argv[1], "out.mkv"))
+tv = mux.add_video(b"\x00" * 8, 64, 48, 24, 1)
+mux.begin()
+block = bytes(range(256)) * 4096                        # 1 MiB
+assert L.rcgpu_mkv_expect(mux.h, 64 << 20, 64) == 0      # the file system holds 8 MiB
+errors = 0
+for i in range(24):
+    dst, off = C.c_void_p(), C.c_uint64()
+    if L.rcgpu_mkv_reserve_block(mux.h, tv, i * 10 ** 9 // 24, len(block), 1, C.byref(dst), C.byref(off)) != 0:
+        errors += 1; break
+    r = L.rcgpu_mkv_copy_in(mux.h, dst, block, len(block)) if dst.value else L.rcgpu_mkv_fill(mux.h, off, block, len(block))
+    if r != 0:
+        errors += 1
+        assert "No space left" in api.last_error() or "failed" in api.last_error(), api.last_error()
+        break
+assert errors == 1, "24 MiB went into an 8 MiB file system without an error"
+print("full file system reported:", api.last_error())
+"""
+
+
+def test_a_full_tmpfs_is_an_error_code_not_a_sigbus(built, tmp_path):
+    """The muxer maps its output on tmpfs and allocates pages ahead with fallocate(); when the file system is full, the payloads must
+    come back as a write error (the job then exits with a code and removes the partial file), not as a SIGBUS inside a memcpy."""
+    fs = str(tmp_path / "fs")
+    os.makedirs(fs)
+    if subprocess.run(["mount", "-t", "tmpfs", "-o", "size=8m", "none", fs], capture_output=True).returncode != 0:
+        pytest.skip("cannot mount a small tmpfs here")
+    try:
+        r = subprocess.run([sys.executable, "-c", _FULL_FS_SCRIPT, fs, os.path.dirname(HERE)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, "exit %d (-7 = SIGBUS)\n%s\n%s" % (r.returncode, r.stdout, r.stderr)
+        assert "full file system reported" in r.stdout
+    finally:
+        subprocess.run(["umount", fs], capture_output=True)
