@@ -63,38 +63,93 @@ def make_frames(torch, n, width, height, kind, seed, device):
     return out
 
 
-def cpu_baseline(payload_host: bytes, line_bytes: int, width: int, height: int):
-    """The oracle (scalar C restatement, kind 'port') on the host: one frame per thread on all cores, and one frame on one core."""
-    import oracle_binding as ob
-    from rawcooked_amd import synth
-    cores = max(1, os.cpu_count() or 1)
-    try:                                            # ~0.7 GB of host memory per oracle thread at 4K: never let the baseline endanger the box
+def usable_cores() -> int:
+    """Hardware threads this process may really keep busy: the affinity mask, cut by the cgroup's CPU quota (the GPU boxes of this pool show
+    256 threads and grant 16 CPUs' worth of time -- cpu.max "1600000 100000" --, which is why round 2's "256-thread" baselines scaled 13x)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+_CPU_WORKER = r"""
+import hashlib, os, sys, time
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import oracle_binding as ob
+from rawcooked_amd import synth
+width, height, line_bytes, nframes, go_at = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), float(sys.argv[7])
+payload = open(sys.argv[2], "rb").read()
+p = ob.Params(width, height, synth.PIX_RGB16_BE, 8, 8, 1, 1)
+ob.lib()
+while time.time() < go_at:
+    time.sleep(0.001)
+t0 = time.time()
+for _ in range(nframes):
+    pk = ob.encode_payload(p, payload, line_bytes)
+print(t0, time.time(), hashlib.md5(pk).hexdigest())
+"""
+
+
+def cpu_baseline(payloads: list, line_bytes: int, width: int, height: int, gpu_packet_md5: list):
+    """The oracle (scalar C restatement, kind 'port') on the host.  One PROCESS per core -- round 2 ran it in threads of one process and
+    got 13x on 256 threads: the oracle allocates ~0.7 GB per call, and one process's allocator and page-fault path serialised them.
+    Worker k encodes distinct frame k % len(payloads), so the baseline doubles as a packet-by-packet check of the GPU's output
+    (gpu_packet_md5[k]: MD5 of the device-resident run's packet of that frame)."""
+    import hashlib
+    import subprocess
+    import tempfile
+    cores = usable_cores()
+    try:                                            # ~0.8 GB per worker at 4K: never let the baseline endanger the box
         import psutil
-        cores = max(1, min(cores, int(psutil.virtual_memory().available / (1 << 30) / 1.5)))
+        cores = max(1, min(cores, int(psutil.virtual_memory().available / (1 << 30) / 2)))
     except Exception:
         cores = min(cores, 16)
-    p = ob.Params(width, height, synth.PIX_RGB16_BE, 8, 8, 1, 1)
-    ob.lib()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    files = []
+    for k, pl in enumerate(payloads):
+        fn = os.path.join(base, "rcgpu_cpu_%d_%d.bin" % (os.getpid(), k))
+        with open(fn, "wb") as f:
+            f.write(pl)
+        files.append(fn)
 
-    def run(nthreads):
-        def work():
-            ob.encode_payload(p, payload_host, line_bytes)
-        t0 = time.perf_counter()
-        ths = [threading.Thread(target=work) for _ in range(nthreads)]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        return nthreads / (time.perf_counter() - t0)
+    def run(nproc, nframes):
+        go_at = time.time() + 1.0 + nproc * 0.012            # every worker has loaded its input and the library before the clock starts
+        procs = [subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, files[k % len(files)], str(width), str(height), str(line_bytes), str(nframes), repr(go_at)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(nproc)]
+        rows = []
+        for k, pr in enumerate(procs):
+            out, err = pr.communicate(timeout=600)
+            if pr.returncode != 0:
+                raise RuntimeError("oracle worker failed: " + err[-300:])
+            t0, t1, md5 = out.split()
+            rows.append((float(t0), float(t1), md5, k % len(files)))
+        span = max(r[1] for r in rows) - min(r[0] for r in rows)
+        return nproc * nframes / span, rows
 
-    one = run(1)
-    allc = run(cores)
-    return {"value": round(allc, 4), "unit": "frames/s", "cores": cores, "kind": "port", "one_core": round(one, 4),
-            "sample": f"{cores} frames of the same {width}x{height} RGB16 workload, one frame per thread on {cores} threads (and 1 frame on 1 thread: "
-                      f"{one:.3f} frames/s), oracle/ffv1_oracle.c (scalar C, not FFmpeg; the reference's own encoder is the ffmpeg binary, absent here)"}
+    try:
+        one, rows1 = run(1, 1)
+        allc, rows = run(cores, 2)
+        checked = [(r[3], r[2]) for r in rows + rows1 if r[3] < len(gpu_packet_md5)]
+        bad = sorted({k for k, md5 in checked if md5 != gpu_packet_md5[k]})
+    finally:
+        for fn in files:
+            try:
+                os.unlink(fn)
+            except OSError:
+                pass
+    return {"value": round(allc, 4), "unit": "frames/s", "cores": cores, "cores_busy": cores, "hardware_threads_visible": os.cpu_count(), "kind": "port", "one_core": round(one, 4),
+            "speedup_over_one_core": round(allc / one, 1),
+            "gpu_packets_equal_to_oracle": {"frames_checked": len({k for k, _ in checked}), "differing": bad},
+            "sample": f"{cores} processes x 2 frames of the same {width}x{height} RGB16 workload ({len(files)} distinct frames), started together, first start to last end "
+                      f"(and 1 frame on 1 core: {one:.3f} frames/s); oracle/ffv1_oracle.c (scalar C, not FFmpeg; the reference's own encoder is the ffmpeg binary, "
+                      f"absent here)"}, not bad
 
 
-def reference_check_baseline(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=16):
+def reference_check_baseline(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=16, parallel=1):
     """cpu_baseline of the check path, kind "reference": the REAL reference binary (oracle/_ref/rawcooked, built from the reference's
     own sources by oracle/Makefile.ref) decodes and verifies an MKV holding `nframes` of this run's packets, on the host's cores."""
     import shutil
@@ -132,9 +187,28 @@ def reference_check_baseline(api, synth, record, frames, d_packets, stride, size
         r = run([ref, "--check", "seq.mkv"])
         dt = time.perf_counter() - t0
         ok = r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout
-        return {"value": round(n / dt, 3), "unit": "frames/s", "cores": os.cpu_count(), "kind": "reference",
-                "sample": f"rawcooked --check on an MKV of {n} of this run's {width}x{height} packets (files on local disk, page cache warm); "
-                          f"verdict: {'no issue detected' if ok else 'FAILED'}"}
+        rec = {"value": round(n / dt, 3), "unit": "frames/s", "cores": usable_cores(), "hardware_threads_visible": os.cpu_count(), "kind": "reference",
+               "sample": f"rawcooked --check on an MKV of {n} of this run's {width}x{height} packets (files on local disk, page cache warm); "
+                         f"verdict: {'no issue detected' if ok else 'FAILED'}"}
+        if parallel > 1 and ok:
+            # the reference decodes one frame at a time on a pool of 64 slice tasks: one process cannot fill a 256-thread host.  Its own
+            # documentation runs packages side by side with GNU parallel (Doc/Case_study.md:81); so does this.
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([ref, "--check", "seq.mkv"], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, text=True)
+                     for _ in range(parallel)]
+            good = 0
+            for pr in procs:
+                try:
+                    out, _ = pr.communicate(timeout=120)
+                    good += pr.returncode == 0 and "Reversibility was checked, no issue detected." in out
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+            dtp = time.perf_counter() - t0
+            if good == parallel:
+                rec.update({"one_process": rec["value"], "value": round(parallel * n / dtp, 3), "processes": parallel,
+                            "cores_busy": min(usable_cores(), parallel * 64)})
+                rec["sample"] += f"; value = {parallel} such processes side by side ({n} frames each, {dtp:.1f} s), one process alone {rec['one_process']} frames/s"
+        return rec
     except Exception as e:      # the baseline is a report, never a reason to fail the measurement
         print("bench: reference check baseline skipped:", e, file=sys.stderr)
         return None
@@ -142,16 +216,17 @@ def reference_check_baseline(api, synth, record, frames, d_packets, stride, size
         shutil.rmtree(work, ignore_errors=True)
 
 
-def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device, steps, warmup, cpu=True):
+def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device, steps, warmup, cpu=True,
+              check_batch=None):
     """Config 5: decode the packets back and verify them -- everything resident in HBM (single GPU).  The caller has released the
     encoder: the decoder is latency-bound per slice chain, its rate is chains in flight / chain latency, so D >= F frames are decoded per
     step (the F encoded packets, reused round-robin -- SURVEY.md 8d "ring reuse")."""
     cpu_rec = None
     if cpu:
         from rawcooked_amd import synth as _synth
-        cpu_rec = reference_check_baseline(api, _synth, record, frames, d_packets, stride, sizes, width, height, pixfmt)
+        cpu_rec = reference_check_baseline(api, _synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, parallel=max(1, min(8, usable_cores() // 32)))
     torch.cuda.empty_cache()
-    D = max(F, args.check_batch)
+    D = max(F, check_batch or args.check_batch)
     sizes = [sizes[i % F] for i in range(D)]
     dec = api.Ffv1Decoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=D, device=device)
     payload_bytes = line_bytes * height
@@ -171,16 +246,24 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     F0 = min(F, 32)                                                                        # distinct sources hashed on the host
     want = {i: hashlib.md5(bytes(frames[i].cpu().numpy())).digest() for i in range(F0)}
     side = torch.cuda.Stream()
-    state = {"k": 0, "bad": 0, "hashed": 0, "ev": None}
+    state = {"k": 0, "bad": 0, "hashed": 0, "compared": 0, "differing": 0, "ev": None}
+
+    def verify(prev, st):
+        # frame_writer's two checks (FileWriter.cpp:448-463 byte compare with the source, :596-727 MD5), on the device
+        diffs = api.compare_device_batch(prev, ptrs, [payload_bytes] * D, st)
+        state["differing"] += sum(d != -1 for d in diffs); state["compared"] += D
+        got = api.md5_device(prev, [payload_bytes] * D, st)
+        state["bad"] += sum(got[i] != want[i % F] for i in range(D) if (i % F) in want); state["hashed"] += D
 
     def step():
         k = state["k"]; cur = k & 1 if pipelined else 0
         dec.decode_device(pk, sizes, ops[cur], stream, check=False)
         ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
-        if pipelined and state["ev"] is not None:
+        if pipelined and state["ev"] is not None:         # batch k-1 is verified on the side stream while batch k is decoded
             side.wait_event(state["ev"])
-            got = api.md5_device(ops[cur ^ 1], [payload_bytes] * D, side.cuda_stream)
-            state["bad"] += sum(got[i] != want[i % F] for i in range(D) if (i % F) in want); state["hashed"] += D
+            verify(ops[cur ^ 1], side.cuda_stream)
+        elif not pipelined:
+            verify(ops[0], stream)
         state["ev"] = ev; state["k"] = k + 1
 
     for _ in range(max(0, warmup)):
@@ -194,14 +277,14 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     op = ops[(state["k"] - 1) & 1 if pipelined else 0]                                     # the batch decoded last: verified below
     kt = dec.kernel_times()
     t1 = time.perf_counter()
-    same = all(api.compare_device(op[i], ptrs[i], line_bytes * height, stream) == -1 for i in range(D))
+    same = all(d == -1 for d in api.compare_device_batch(op, ptrs, [payload_bytes] * D, stream)) and state["differing"] == 0     # the last batch, outside the clock
     md5 = api.md5_device(op[:min(D, 64)], [line_bytes * height] * min(D, 64), stream)
     t_verify = time.perf_counter() - t1
     ok_md5 = md5[0] == want[0] and state["bad"] == 0
     payload = line_bytes * height
     packet_avg = sum(sizes) / len(sizes)
     dom = "k_dec_slices"
-    achieved = D * (packet_avg + payload) / (kt[dom] * 1e-3) / 1e9
+    achieved = D * (packet_avg + 2 * payload) / (kt[dom] * 1e-3) / 1e9          # packet in + payload out + the source again for the compare
     traffic = None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
@@ -214,9 +297,9 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
         "metric": "4K-DCI 16-bit FFV1->DPX check frames/sec", "value": round(D * steps / dt, 3), "unit": "frames/s", "n_gpus": 1,
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-        "config": {"workload": f"{width}x{height} RGB16 FFV1 packets (slices={args.slices}) -> payload, byte compare + MD5 on device", "frames_per_step_per_gpu": D,
+        "config": {"workload": f"{width}x{height} RGB16 FFV1 packets (slices={nh * nv}) -> payload, byte compare with the source + MD5 of every frame on device", "frames_per_step_per_gpu": D,
                    "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "md5_inside_timed_region": state["hashed"],
-                   "verify_seconds_last_batch": round(t_verify, 3)},
+                   "compared_inside_timed_region": state["compared"], "verify_seconds_last_batch": round(t_verify, 3)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                      "traffic": traffic, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}},
         **({"cpu_baseline": cpu_rec} if cpu_rec else {})}
@@ -265,7 +348,7 @@ def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barr
             "source": f"ring of {R} distinct frames in pageable host memory, reused", "_local": (n_frames, st.seconds, dt)}, (not bad)
 
 
-def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packet0):
+def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packets, with_audio=True):
     """Files on tmpfs -> `rcgpu-ffmpeg` with the argv grammar the reference assembles (Source/CLI/Output.cpp:81-310) -> MKV on tmpfs:
     the disk is out of the number, everything else (process start, device init, buffers, readers, muxer) is in it."""
     import shutil
@@ -293,8 +376,16 @@ def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packet0):
             os.link(os.path.join(work, "uniq", "u_%03d.dpx" % (i % R)), os.path.join(work, "img", "f_%06d.dpx" % i))
         shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
         argv = [shim, "-xerror", "-framerate", "24.000000", "-r", "24.000000", "-f", "image2", "-c:v", "dpx", "-start_number", "000000",
-                "-i", "img/f_%06d.dpx", "-c:v", "ffv1", "-coder", "1", "-context", "1", "-f", "matroska", "-g", "1", "-level", "3",
-                "-slicecrc", "1", "-slices", str(slices), "-y", "-f", "matroska", "out.mkv"]
+                "-i", "img/f_%06d.dpx"]
+        audio_note = ""
+        if with_audio:      # BASELINE config 3: 6 ch / 24 bit / 48 kHz for the length of the sequence, the argv the reference prints for such a package
+            nsamp = n_frames * 48000 // 24
+            with open(os.path.join(work, "snd.wav"), "wb") as f:
+                f.write(synth.wav_file(synth.pcm_samples(nsamp, 6, 24, 48000), 24, 48000))
+            argv += ["-i", "snd.wav", "-map", "0", "-map", "1", "-c:a", "flac"]
+            audio_note = f" + snd.wav (6 ch / 24 bit / 48 kHz, {nsamp} samples per channel) -> FLAC"
+        argv += ["-c:v", "ffv1", "-coder", "1", "-context", "1", "-f", "matroska", "-g", "1", "-level", "3",
+                 "-slicecrc", "1", "-slices", str(slices), "-y", "-f", "matroska", "out.mkv"]
         # The legs before this one have just given ~140 GB of device memory back, which the driver wipes in the background: a hipMalloc that
         # comes within ~3 s waits for the wipe (measured: encoder creation 3.2 s instead of 0.1 s).  A job does not follow another one's exit
         # by milliseconds, so the wipe is allowed to finish before the clock starts.
@@ -306,19 +397,150 @@ def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packet0):
             return {"error": (r.stderr or r.stdout)[-400:]}, False
         size = os.path.getsize(os.path.join(work, "out.mkv"))
         ok = None
-        if expect_packet0:
+        blocks = {"video": 0, "audio": 0, "differing": []}
+        if expect_packets:
+            # every SimpleBlock of the video track against the device-resident run's packet of that frame (the file is walked by the
+            # structural validator of the tests, the payloads are compared through a mapping: no copy)
+            import mmap
+            import mkv_validator
             with open(os.path.join(work, "out.mkv"), "rb") as f:
-                headb = f.read(len(expect_packet0) + (1 << 20))
-            at = headb.find(expect_packet0[:64])
-            ok = at > 0 and headb[at:at + len(expect_packet0)] == expect_packet0
+                mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                view = memoryview(mm)
+                expv = [memoryview(e) for e in expect_packets]
+
+                def on_block(trk, t_abs, a, b):
+                    if trk != 1:
+                        blocks["audio"] += 1
+                        return
+                    i = blocks["video"]; blocks["video"] += 1
+                    e = expv[i % R]
+                    if b - a != len(e) or view[a:b] != e:
+                        blocks["differing"].append(i)
+                rep_ = mkv_validator.validate(os.path.join(work, "out.mkv"), on_block=on_block)
+                del view, expv
+                mm.close()
+            ok = blocks["video"] == n_frames and not blocks["differing"] and rep_["tracks"][1]["codec"] == "V_FFV1"
         pl = [ln for ln in r.stderr.splitlines() if "pipeline:" in ln and "frames in" in ln]
         return {"frames": n_frames, "seconds": round(dt, 3), "value": round(n_frames / dt, 2), "unit": "frames/s", "mkv_bytes": size,
                 "read_GBps": round(n_frames * (payload + 2048) / dt / 1e9, 2), "write_GBps": round(size / dt / 1e9, 2),
-                "first_block_identical_to_device_resident_run": ok, "trace": pl[-1].split("pipeline: ", 1)[1] if pl else None,
+                "all_blocks_identical_to_device_resident_run": ok, "video_blocks": blocks["video"], "audio_blocks": blocks["audio"], "differing_blocks": blocks["differing"][:8],
+                "single_output_file_ceiling": "one job writes one Matroska file: its page allocation runs at ~13 GB/s on tmpfs = ~265 4K frames/s whatever the GPU count (DESIGN.md)",
+                "trace": pl[-1].split("pipeline: ", 1)[1] if pl else None,
                 "phases": [ln.split("rcgpu trace:", 1)[1].strip() for ln in r.stderr.splitlines() if "rcgpu trace:" in ln and "pipeline:" not in ln],
-                "what": f"process start to exit of rcgpu-ffmpeg: {n_frames} x {width}x{height} RGB16 DPX on tmpfs ({R} distinct, hard-linked) -> FFV1 slices={slices} -> MKV on tmpfs; started after the device had been idle for {os.environ.get('RCGPU_BENCH_E2E_IDLE', '4')} s (the driver wipes the memory the previous leg freed)"}, ok is not False
+                "what": f"BASELINE config 3 (config 2 + audio): process start to exit of rcgpu-ffmpeg: {n_frames} x {width}x{height} RGB16 DPX on tmpfs ({R} distinct, hard-linked){audio_note} -> FFV1 slices={slices} -> MKV on tmpfs; started after the device had been idle for {os.environ.get('RCGPU_BENCH_E2E_IDLE', '4')} s (the driver wipes the memory the previous leg freed)"}, ok is not False
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def cfg1_leg(api, synth, device):
+    """BASELINE config 1's shape on the device: 24 x 2048x1556 RGB 10-bit FilledA BE DPX payloads, host memory in, host memory out,
+    through rcgpu_ffv1_encode_sequence_memory (what the ffmpeg subprocess does for such a package), slice count = the reference's."""
+    import numpy as np
+    import oracle_binding as ob
+    w, h, n, pixfmt = 2048, 1556, 24, synth.PIX_RGB10_FILLEDA_BE
+    payloads = []
+    for i in range(n):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 10, "film", seed=i), pixfmt, True)
+        payloads.append(np.frombuffer(pl, dtype=np.uint8).copy())
+    slices = api.lib().rcgpu_reference_slices(w, h, 10, 1)
+    nh, nv = api.slices_to_grid(slices)
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, nh, nv, 1, 1, 0, device, 0, 0, 1, 3)
+    out_cap = int(payloads[0].nbytes * 1.3) + (1 << 20)
+    outs = [np.empty(out_cap, dtype=np.uint8) for _ in range(n)]
+    best = None
+    for _ in range(2):                                   # the second call finds the runtime warm
+        t0 = time.perf_counter()
+        st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in payloads], n, [a.ctypes.data for a in outs], out_cap, batch=n, device_first=device, device_count=1)
+        wall = time.perf_counter() - t0
+        if best is None or wall < best[0]:
+            best = (wall, st)
+    wall, st = best
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    ok = all(bytes(outs[i][:sizes[i]]) == ob.encode_payload(p, payloads[i].tobytes(), line_bytes) for i in (0, n - 1))
+    return {"workload": f"config 1 shape: {n} x {w}x{h} RGB 10-bit FilledA BE, slices={slices} ({nh}x{nv}), host buffers in and out (rcgpu_ffv1_encode_sequence_memory)",
+            "value": round(n / wall, 2), "unit": "frames/s", "call_seconds": round(wall, 3), "pipeline_seconds": round(st.seconds, 3), "prepare_seconds": round(st.prepare_seconds, 3),
+            "first_packet_seconds": round(st.first_packet_seconds, 3), "packet_bytes_avg": int(sum(sizes) / n),
+            "compression_ratio": round(sum(sizes) / n / payloads[0].nbytes, 4), "packets_equal_to_oracle": {"frames_checked": 2, "ok": bool(ok)},
+            "note": "24 frames are one short batch: the number is start-up (encoder buffers, pinned slots) plus one batch's latency, not a rate"}, ok
+
+
+def cfg4_leg(torch, api, synth, dev, device, steps=2, F=80):
+    """BASELINE config 4's shape on one device: 8192x4320 RGB 16-bit LE (the payload of a single-strip TIFF), the reference's 576 slices,
+    device-resident like the headline; the dominant kernel's roofline from this run's HIP events."""
+    import numpy as np
+    w, h, pixfmt = 8192, 4320, synth.PIX_RGB16_LE
+    line_bytes = w * 6
+    slices = api.lib().rcgpu_reference_slices(w, h, 16, 1)
+    nh, nv = api.slices_to_grid(slices)
+    base = make_frames(torch, 8, w, h, "film", 77, dev)                   # 8 distinct 212 MB pictures (big endian as generated) ...
+    base = base.view(8, -1, 2).flip(-1).reshape(8, -1).contiguous()     # ... byte-swapped: little endian, as TIFF stores them
+    frames = base.repeat((F + 7) // 8, 1)[:F].contiguous()
+    del base
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=F, device=device)
+    stride = (enc.max_packet + 255) & ~255
+    d_packets = torch.empty(F * stride, dtype=torch.uint8, device=dev)
+    d_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
+    ptrs = [frames[i].data_ptr() for i in range(F)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
+    step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = enc.kernel_times(); launches = enc.kernel_launches(); flags = enc.error_flags()
+    sizes = d_sizes.cpu().tolist()
+    # parity at this shape: the device decoder (itself checked against the oracle and the reference in tests/) rebuilds the first 8 payloads
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=8, device=device)
+    outs = torch.empty((8, line_bytes * h), dtype=torch.uint8, device=dev)
+    dec.decode_device([d_packets.data_ptr() + i * stride for i in range(8)], sizes[:8], [outs[i].data_ptr() for i in range(8)], stream)
+    ok = api.compare_device_batch([outs[i].data_ptr() for i in range(8)], ptrs[:8], [line_bytes * h] * 8, stream) == [-1] * 8
+    dec.close()
+    payload = line_bytes * h
+    packet_avg = sum(sizes) / F
+    dom = max(kt, key=lambda k: kt[k])
+    nl = max(1, launches.get(dom, 1))
+    alg = F * (payload + packet_avg) / nl
+    ach = alg / (kt[dom] / nl * 1e-3) / 1e9
+    rec = {"workload": f"config 4 shape on one GPU: {w}x{h} RGB 16-bit LE (TIFF payload), slices={slices} ({nh}x{nv}), {F} frames per step resident in HBM, content=film",
+           "value": round(F * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "packet_bytes_avg": int(packet_avg),
+           "compression_ratio": round(packet_avg / payload, 4), "device_error_flags": flags, "decodes_to_source_on_device": bool(ok),
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(kt[dom] / nl, 3), "launches_per_step": nl,
+                        "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0}}}
+    enc.close()
+    del frames, d_packets, outs
+    torch.cuda.empty_cache()
+    return rec, bool(ok) and flags == 0
+
+
+def check576_leg(args, torch, api, synth, dev, device, width, height):
+    """The check half at the slice count the reference itself picks for 4K 16-bit (576): nine times the chains per frame, so a ninth of
+    the frames in flight gives the decoder the same number of chains."""
+    pixfmt = synth.PIX_RGB16_BE
+    line_bytes = width * 6
+    slices = api.lib().rcgpu_reference_slices(width, height, 16, 1)
+    nh, nv = api.slices_to_grid(slices)
+    F = 64
+    frames = make_frames(torch, F, width, height, "film", 5, dev)
+    enc = api.Ffv1Encoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=F, device=device)
+    stride = (enc.max_packet + 255) & ~255
+    d_packets = torch.empty(F * stride, dtype=torch.uint8, device=dev)
+    d_sizes = torch.zeros(F, dtype=torch.int64, device=dev)
+    ptrs = [frames[i].data_ptr() for i in range(F)]
+    stream = torch.cuda.current_stream().cuda_stream
+    enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
+    torch.cuda.synchronize()
+    flags = enc.error_flags()
+    sizes = d_sizes.cpu().tolist(); record = enc.config_record(); enc.close()
+    rec, ok = check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device,
+                        steps=2, warmup=1, cpu=False, check_batch=256)
+    del frames, d_packets
+    torch.cuda.empty_cache()
+    return {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline") if k in rec}, ok and flags == 0
 
 
 def bind_to_numa_node(node: int) -> None:
@@ -345,7 +567,8 @@ def main():
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--legs", default="host,e2e,check,cpu", help="comma list of the extra records: host (host_pipeline), e2e, check, cpu (cpu_baseline); '' = none")
+    ap.add_argument("--legs", default="host,e2e,check,cpu,configs",
+                    help="comma list of the extra records: host (host_pipeline), e2e (config 3), check (config 5), cpu (cpu_baseline), configs (config 1 and 4 shapes, check at 576 slices); '' = none")
     ap.add_argument("--host-frames", type=int, default=3840, help="host_pipeline: frames per GPU")
     ap.add_argument("--host-lanes", type=int, default=1, help="host_pipeline: encoder instances per GPU, batches staggered")
     ap.add_argument("--host-readers", type=int, default=0)
@@ -515,6 +738,7 @@ def main():
             launch_ms = kt[dom] / nl
             achieved = alg_bytes_launch / (launch_ms * 1e-3) / 1e9
             traffic = note = None
+            tjd = {}
             tj = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tj):
                 try:
@@ -524,8 +748,18 @@ def main():
                     note = tjd.get("note")
                 except Exception:
                     traffic = None
+            issue = None
+            try:      # VALU wave-instructions per frame (SQ_INSTS_VALU, profiles/) against the issue rates tools/valu_peak measured on this chip
+                v = tjd.get("valu", {})
+                per_frame = v.get("wave_instr_per_frame_split" if enc.kernel_launches().get("k_rc_range") else "wave_instr_per_frame_whole")
+                if per_frame:
+                    rate = per_frame * fps / world
+                    issue = {"valu_wave_instr_per_frame": per_frame, "frac_of_half_rate_peak": round(rate / (1024 * v["half_rate_per_simd"]), 4),
+                             "frac_of_full_rate_peak": round(rate / (1024 * v["full_rate_per_simd"]), 4), "note": v.get("note")}
+            except Exception:
+                issue = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "issue_frac": issue,
                     "algorithmic_bytes_per_launch": int(alg_bytes_launch), "launch_ms": round(launch_ms, 3), "launches_per_step": nl,
                     "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0},
                     "note": note or "entropy coding: serial per slice and per context, bound by instruction issue rather than bytes (DESIGN.md section 5)"}
@@ -533,8 +767,12 @@ def main():
             "metric": "4K-DCI 16-bit DPX->FFV1 frames/sec", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": f"{width}x{height} RGB 16-bit BE DPX payload -> FFV1 v3 intra, slices={args.slices} ({nh}x{nv}), "
-                                   f"coder=1 context=1 ({args.context_model} level maps) slicecrc=1, content={args.kind}",
+            "h2d_included": False,      # `value`: payloads resident in HBM when the clock starts; `kernel_metric` below is SURVEY.md 8d's H2D-inclusive figure
+            "config": {"workload": f"BASELINE config 2: {width}x{height} RGB 16-bit BE DPX payload -> FFV1 v3 intra, slices={args.slices} ({nh}x{nv}), "
+                                   f"coder=1 context=1 ({args.context_model} level maps) slicecrc=1, content={args.kind}; the other configs of BASELINE.json: "
+                                   f"config 1 shape -> `configs.cfg1`, config 3 (config 2 + 6-ch WAV, files to MKV) -> `e2e`, config 4 shape on one GPU -> `configs.cfg4`, "
+                                   f"config 5 (--check: decode + compare + MD5 on the device) -> `check` (64 slices) and `configs.check_576_slices`",
+                       "range_coder": "split (k_rc_range + k_rangecode<true> + k_rc_tails)" if launches.get("k_rc_range") else "one lane per slice",
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective",
                        "packet_bytes_avg": int(packet_avg), "compression_ratio": round(packet_avg / payload_bytes, 4),
                        "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified, "verified_by_reference": verified_ref,
@@ -544,8 +782,9 @@ def main():
 
     # ---- the extra legs.  What they need of the headline run is kept on the host; the encoder's 170 GB go back first.
     record = enc.config_record()
-    host_ring = [frames[i].cpu().numpy() for i in range(R)] if (legs & {"host", "e2e"}) else []
-    expect = [bytes(d_packets[i * stride:i * stride + sizes[i]].cpu().numpy()) for i in range(R)] if (legs & {"host", "e2e"}) else []
+    host_ring = [frames[i].cpu().numpy() for i in range(R)] if (legs & {"host", "e2e", "cpu"}) else []
+    expect = [bytes(d_packets[i * stride:i * stride + sizes[i]].cpu().numpy()) for i in range(R)] if (legs & {"host", "e2e", "cpu"}) else []
+    src0 = bytes(frames[0].cpu().numpy()) if "cpu" in legs and not host_ring else None
     cfg = api.Ffv1Config(width, height, pixfmt, line_bytes, nh, nv, 1, ctx, 0, local_rank, args.segments, 0, 1, 3)
     ok_all = True
     if "check" in legs and world == 1:
@@ -566,14 +805,28 @@ def main():
         if os.environ.get("RCGPU_DMA_NOISE_HOST"):
             stop.set(); noise.join()
             print("bench: dma noise beside the host pipeline: %.0f GB = %.1f GB/s" % (moved[0] / 1e9, moved[0] / 1e9 / max(1e-9, time.perf_counter() - t_noise)), file=sys.stderr)
-        n_loc, _, dt_all = hp.pop("_local")
+        n_loc, dt_loc, dt_all = hp.pop("_local")
+        rows = rdist.gather_floats(dist, [n_loc, dt_loc, hp["h2d_GBps"], hp["d2h_GBps"], hp["first_packet_seconds"], hp["steady_frames_per_second"]], dev)
         if result is not None:
+            # per rank, so that a multi-GPU run shows WHERE the GPUs contend: every payload and packet crosses host memory about four times
+            # (reader copy in, DMA out, DMA in, writer copy out)
+            hp["per_rank"] = [{"rank": r, "frames": int(v[0]), "seconds": round(v[1], 3), "frames_per_second": round(v[0] / v[1], 2), "h2d_GBps": v[2], "d2h_GBps": v[3],
+                               "first_packet_seconds": v[4], "steady_frames_per_second": v[5]} for r, v in enumerate(rows)]
+            hp["host_memory_GBps_all_ranks"] = round(sum(2 * (v[2] + v[3]) for v in rows), 1)
             hp["value"] = round(world * n_loc / dt_all, 2); hp["unit"] = "frames/s"; hp["n_gpus"] = world
             hp["fraction_of_device_resident"] = round(hp["value"] / fps, 3)
             result["host_pipeline"] = hp
+        if result is not None and "host_pipeline" in result:
+            hp = result["host_pipeline"]
+            result["kernel_metric"] = {"value": hp["value"], "unit": "frames/s", "h2d_included": True,
+                                       "what": "SURVEY.md 8d 'kernel-only fps (inputs resident in pinned host memory, H2D included)': payloads start and packets end in host memory, "
+                                               "uploads / coding / downloads overlapped (the host_pipeline record)"}
+    if rank == 0 and world > 1 and result is not None:
+        result["single_job_note"] = ("frames shard over the GPUs with no collective; a single JOB, though, writes ONE Matroska file, whose page allocation runs at "
+                                     "~13 GB/s = ~265 4K frames/s whatever the GPU count (e2e record at N = 1): N GPUs pay off for N jobs side by side or for a caller that keeps packets in memory")
     if rank == 0 and world == 1:
         if "e2e" in legs:
-            rec, ok = e2e_leg(synth, host_ring, width, height, args.e2e_frames, args.slices, expect[0] if expect else None)
+            rec, ok = e2e_leg(synth, host_ring, width, height, args.e2e_frames, args.slices, expect)
             ok_all &= ok
             result["e2e"] = rec
         if "check" in legs:
@@ -581,8 +834,28 @@ def main():
                                 steps=2, warmup=1, cpu="cpu" in legs)
             ok_all &= ok
             result["check"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline") if k in rec}
+            if result["check"].get("config", {}).get("all_frames_identical_to_source"):
+                result["config"]["packets_verified"] = (f"all {F} packets of the last timed step decode to their sources on the device (check record: byte compare + MD5); "
+                                                        "the first ones also through the oracle and the reference binary (verified_vs_oracle, verified_by_reference), "
+                                                        "and the CPU baseline's oracle packets are compared with the device's by MD5 (cpu_baseline.gpu_packets_equal_to_oracle)")
+        del frames, keep_pk
+        torch.cuda.empty_cache()
+        if "configs" in legs:
+            cfgs = {}
+            for name, fn in (("cfg1", lambda: cfg1_leg(api, synth, local_rank)), ("cfg4", lambda: cfg4_leg(torch, api, synth, dev, local_rank)),
+                             ("check_576_slices", lambda: check576_leg(args, torch, api, synth, dev, local_rank, width, height))):
+                try:
+                    cfgs[name], ok = fn()
+                    ok_all &= ok
+                except Exception as e:          # a sub-record is a report: its failure is shown, the headline stays
+                    cfgs[name] = {"error": str(e)[-300:]}
+                    ok_all = False
+            result["configs"] = cfgs
         if "cpu" in legs:
-            result["cpu_baseline"] = cpu_baseline(host_ring[0].tobytes() if host_ring else bytes(frames[0].cpu().numpy()), line_bytes, width, height)
+            import hashlib
+            cb, ok = cpu_baseline([a.tobytes() for a in host_ring] if host_ring else [src0], line_bytes, width, height, [hashlib.md5(e).hexdigest() for e in expect] if expect else [])
+            ok_all &= ok
+            result["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(result))
     rdist.finish(dist)

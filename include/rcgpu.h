@@ -281,6 +281,9 @@ int  rcgpu_ffv1_config_from_stream(const uint8_t* record, size_t size, const uin
 int  rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* dec, float ms[3]);   /* split+crc, slices, pack */
 /* First differing byte of two device buffers; *first_diff = UINT64_MAX when they are equal (FileWriter.cpp:448-463). */
 int  rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t* first_diff, void* hip_stream);
+/* The same for n pairs of device buffers in one launch: first_diff[i] (host) for pair i.  Ordered on hip_stream alone, like rcgpu_md5_device:
+ * a --check binding compares batch k-1 on a side stream while batch k is decoded. */
+int  rcgpu_compare_device_batch(const void* const* d_a, const void* const* d_b, const uint64_t* sizes, uint32_t n, uint64_t* first_diff, void* hip_stream);
 /* MD5 of n device buffers, one lane per buffer; out_md5 = n x 16 bytes on the host (FileWriter.cpp:596-727). */
 int  rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, void* hip_stream);
 /* The same for n host buffers, e.g. memory-mapped source files during analysis (input_base::Hash, Lib/Uncompressed/../Input_Base.cpp:54-81

@@ -122,6 +122,7 @@ SYMBOLS = {
     "rcgpu_ffv1_config_from_stream": (C.c_int, [_U8P, _SZ, _U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rcgpu_compare_device": (C.c_int, [_VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
+    "rcgpu_compare_device_batch": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _VP, _VP]),
     "rcgpu_md5_device": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _VP, _VP]),
     "rcgpu_flac_create": (C.c_int, [C.POINTER(FlacConfig), C.POINTER(_VP)]),
     "rcgpu_flac_destroy": (None, [_VP]),
@@ -373,6 +374,14 @@ def compare_device(a: int, b: int, n: int, stream: int = 0) -> int:
     r = C.c_uint64()
     _check(lib().rcgpu_compare_device(a, b, n, C.byref(r), stream), "rcgpu_compare_device")
     return -1 if r.value == 0xFFFFFFFFFFFFFFFF else r.value
+
+
+def compare_device_batch(a: list[int], b: list[int], sizes: list[int], stream: int = 0) -> list[int]:
+    """-> per pair the index of the first differing byte, or -1."""
+    n = len(a)
+    out = (C.c_uint64 * n)()
+    _check(lib().rcgpu_compare_device_batch((_VP * n)(*a), (_VP * n)(*b), (C.c_uint64 * n)(*sizes), n, out, stream), "rcgpu_compare_device_batch")
+    return [-1 if v == 0xFFFFFFFFFFFFFFFF else v for v in out]
 
 
 def dpx_padding_scan_device(ptrs: list[int], pixfmt: int, width: int, height: int, flags: int = 0, stream: int = 0) -> list[int]:

@@ -402,6 +402,29 @@ __global__ __launch_bounds__(256) void k_compare(const uint8_t* __restrict__ a, 
     if (best != ~0ull) atomicMin(first_diff, best);
 }
 
+// The same for n pairs of buffers in one launch (grid.y = pair), 16 bytes per thread and turn where both pointers allow it: what
+// frame_writer's compare (FileWriter.cpp:448-463) does for every decoded frame of a batch.  first_diff[pair] starts at ~0.
+__global__ __launch_bounds__(256) void k_compare_batch(const uint8_t* const* __restrict__ as, const uint8_t* const* __restrict__ bs,
+                                                       const unsigned long long* __restrict__ sizes, unsigned long long* __restrict__ first_diff)
+{
+    const uint8_t* a = as[blockIdx.y]; const uint8_t* b = bs[blockIdx.y];
+    const unsigned long long n = sizes[blockIdx.y];
+    unsigned long long best = ~0ull;
+    const bool wide = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    const unsigned long long nw = wide ? n / 16 : 0;
+    const uint4* a4 = reinterpret_cast<const uint4*>(a); const uint4* b4 = reinterpret_cast<const uint4*>(b);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < nw; i += (unsigned long long)gridDim.x * 256) {
+        const uint4 x = a4[i], y = b4[i];
+        if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) {
+            for (unsigned long long k = i * 16; k < i * 16 + 16; k++) if (a[k] != b[k]) { best = k; break; }
+            break;
+        }
+    }
+    for (unsigned long long i = nw * 16 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n && best == ~0ull; i += (unsigned long long)gridDim.x * 256)
+        if (a[i] != b[i]) best = i;
+    if (best != ~0ull) atomicMin(&first_diff[blockIdx.y], best);
+}
+
 // RFC 1321, one buffer per lane (the hash is serial per buffer; many buffers are in flight)
 __device__ __forceinline__ uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
 __global__ __launch_bounds__(64) void k_md5(const uint8_t* const* __restrict__ bufs, const unsigned long long* __restrict__ sizes, uint32_t n,
@@ -755,6 +778,30 @@ extern "C" int rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n
     (void)hipFree(d_res);
     if (he != hipSuccess) return fail(100, "compare: %s", hipGetErrorString(he));
     *first_diff = r;
+    return 0;
+}
+
+// n pairs of device buffers at once; everything is ordered on `st` alone (see rcgpu_md5_device), first_diff = n values on the host.
+extern "C" int rcgpu_compare_device_batch(const void* const* d_a, const void* const* d_b, const uint64_t* sizes, uint32_t n, uint64_t* first_diff, void* hip_stream)
+{
+    clear_error();
+    if (!d_a || !d_b || !sizes || !first_diff || !n) return fail(1, "compare: null argument");
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    const uint8_t** d_pa = nullptr; const uint8_t** d_pb = nullptr; unsigned long long* d_s = nullptr; unsigned long long* d_r = nullptr;
+    hipError_t he = hipMallocAsync(reinterpret_cast<void**>(&d_pa), sizeof(void*) * n, st);
+    if (he == hipSuccess) he = hipMallocAsync(reinterpret_cast<void**>(&d_pb), sizeof(void*) * n, st);
+    if (he == hipSuccess) he = hipMallocAsync(reinterpret_cast<void**>(&d_s), 8 * size_t(n), st);
+    if (he == hipSuccess) he = hipMallocAsync(reinterpret_cast<void**>(&d_r), 8 * size_t(n), st);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_pa, d_a, sizeof(void*) * n, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_pb, d_b, sizeof(void*) * n, hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_s, sizes, 8 * size_t(n), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) he = hipMemsetAsync(d_r, 0xFF, 8 * size_t(n), st);
+    if (he == hipSuccess) { hipLaunchKernelGGL(k_compare_batch, dim3(64, n), dim3(256), 0, st, d_pa, d_pb, d_s, d_r); he = hipGetLastError(); }
+    if (he == hipSuccess) he = hipMemcpyAsync(first_diff, d_r, 8 * size_t(n), hipMemcpyDeviceToHost, st);
+    for (void* p : { (void*)d_pa, (void*)d_pb, (void*)d_s, (void*)d_r }) if (p) (void)hipFreeAsync(p, st);
+    const hipError_t hs = hipStreamSynchronize(st);
+    if (he == hipSuccess) he = hs;
+    if (he != hipSuccess) return fail(100, "compare: %s", hipGetErrorString(he));
     return 0;
 }
 

@@ -147,6 +147,11 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
     if (videos.empty()) return fail(1, "pipeline: no video");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(4, "no HIP device available -- rcgpu has no CPU encode path");
+    // Test hook (tests/test_gpu_pipeline.py): RCGPU_TEST_DEVICE_ALIASES=k presents every physical device k times, so that the lane-per-device
+    // path -- a lane with its own encoder, copy streams, events and ring per entry of device_first/device_count, one placer across them --
+    // runs on a box with a single GPU.  The lanes then share that GPU's memory: the test passes its own batch size.
+    const int ndev_phys = ndev;
+    if (const char* x = getenv("RCGPU_TEST_DEVICE_ALIASES")) ndev *= std::max(1, std::min(8, atoi(x)));
     const int dev0 = std::max(0, opt.device_first);
     int cnt = opt.device_count > 0 ? opt.device_count : ndev - dev0;
     if (dev0 >= ndev || cnt <= 0) return fail(4, "device selection %d+%d is outside the %d visible devices", dev0, opt.device_count, ndev);
@@ -162,7 +167,7 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
     s.F.assign(videos.size(), 1); s.payload.assign(videos.size(), 0); s.max_packet.assign(videos.size(), 0);
     for (int li = 0; li < cnt; li++) {
         lane_t& L = s.lanes[size_t(li)];
-        L.id = li; L.device = dev0 + li % ndev_used;
+        L.id = li; L.device = (dev0 + li % ndev_used) % ndev_phys;
         if (hipSetDevice(L.device) != hipSuccess) return fail(4, "pipeline: cannot select device %d", L.device);
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail(100, "pipeline: hipMemGetInfo failed");

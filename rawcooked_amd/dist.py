@@ -42,6 +42,18 @@ def barrier(dist) -> None:
         dist.barrier()
 
 
+def gather_floats(dist, values, device):
+    """Every rank's list of floats on every rank: [[rank 0's], [rank 1's], ...] (the per-rank rows of a multi-GPU report).  All ranks call it."""
+    vals = [float(v) for v in values]
+    if dist is None:
+        return [vals]
+    import torch
+    t = torch.tensor(vals, dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.tolist()] for o in out]
+
+
 def timed_steps(dist, device, step, steps: int, warmup: int, synchronize) -> float:
     """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by barrier + device synchronize on
     both sides; the result is the slowest rank's wall time."""

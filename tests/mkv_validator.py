@@ -120,7 +120,8 @@ def _parse(f, pos, end, level, max_value_bytes=1 << 16):
     return out
 
 
-def validate(path: str) -> dict:
+def validate(path: str, on_block=None) -> dict:
+    """on_block(track, absolute_time, payload_offset, payload_end): called for every SimpleBlock, with where its payload lies in the file."""
     import os
     fsize = os.path.getsize(path)
     with open(path, "rb") as f:
@@ -207,6 +208,8 @@ def validate(path: str) -> dict:
                 held.add((trk, t_abs))
                 end_time = max(end_time, t_abs)
                 assert blk.end - blk.data > 4, "empty SimpleBlock"
+                if on_block is not None:
+                    on_block(trk, t_abs, blk.data + 4, blk.end)
             clusters[c.pos - seg.data] = (ts, held)
         dur = info.opt("Duration")
         if dur is not None and clusters:

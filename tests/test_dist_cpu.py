@@ -40,6 +40,9 @@ def test_two_ranks_gloo(tmp_path):
         assert len(calls) == 5 and dt >= 0.29, (calls, dt)          # 2 warm-up + 3 timed steps; the slower rank's 3 x 0.1 s
         n = torch.tensor([len(mine)]); dist.all_reduce(n)          # test-side bookkeeping only: the encode path has no collective
         assert t == 2.0 and int(n) == 10, (t, int(n))
+        rows = rdist.gather_floats(dist, [r, 2.5 * r], torch.device("cpu"))      # bench.py's per-rank host_pipeline rows
+        assert rows == [[0.0, 0.0], [1.0, 2.5]], rows
+        assert rdist.gather_floats(None, [3, 4], torch.device("cpu")) == [[3.0, 4.0]]
         rdist.finish(dist)
         print("rank", r, "ok", mine)
     """))

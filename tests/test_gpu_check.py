@@ -58,8 +58,14 @@ def test_encode_then_decode_on_device_and_verify(built):
     md5s = api.md5_device([t.data_ptr() for t in dout], [len(s) for s in srcs])
     assert md5s == [hashlib.md5(s).digest() for s in srcs]                                            # FileWriter.cpp:596-727
     # negative controls: a flipped payload byte is located, a flipped packet byte is refused
+    assert api.compare_device_batch([t.data_ptr() for t in dout], [t.data_ptr() for t in dsrc], [len(s) for s in srcs]) == [-1] * n
     dout[2][12345] ^= 1
     assert api.compare_device(dout[2].data_ptr(), dsrc[2].data_ptr(), len(srcs[2])) == 12345
+    dout[0][len(srcs[0]) - 1] ^= 0x80                      # the last byte, and views that start at odd addresses (byte-wise path)
+    want = [len(srcs[0]) - 1, -1, 12345] + [-1] * (n - 3)
+    assert api.compare_device_batch([t.data_ptr() for t in dout], [t.data_ptr() for t in dsrc], [len(s) for s in srcs]) == want[:n]
+    assert api.compare_device_batch([dout[2].data_ptr() + 1], [dsrc[2].data_ptr() + 1], [len(srcs[2]) - 1]) == [12344]
+    dout[0][len(srcs[0]) - 1] ^= 0x80
     dpk[stride + sizes[1] // 2] ^= 0x10
     with pytest.raises(api.RcgpuError, match="undecodable"):
         dec.decode_device([dpk.data_ptr() + i * stride for i in range(n)], sizes, [t.data_ptr() for t in dout])

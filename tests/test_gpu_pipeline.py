@@ -157,6 +157,30 @@ def test_several_lanes_return_packets_in_frame_order(lanes, n, batch):
         assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
 
 
+@pytest.mark.parametrize("aliases,first,count,n,batch", [(2, 0, 2, 41, 6), (4, 1, 3, 50, 4), (3, 0, 0, 37, 5)])
+def test_a_lane_per_device_through_device_first_and_count(monkeypatch, aliases, first, count, n, batch):
+    """The multi-GPU path proper -- a lane per entry of device_first / device_count, each with its own encoder, pinned ring, copy streams and
+    events, one placer across them -- on a box with one GPU: RCGPU_TEST_DEVICE_ALIASES presents the device several times (the lanes share
+    its memory, hence the explicit batch).  No 8-GPU node has run this code yet; this is the closest one GPU gets."""
+    import numpy as np
+    monkeypatch.setenv("RCGPU_TEST_DEVICE_ALIASES", str(aliases))
+    w, h, pixfmt, n_in = 128, 72, synth.PIX_RGB16_BE, 7
+    payloads, line_bytes = _sequence(w, h, pixfmt, n_in)
+    src = [np.frombuffer(p, dtype=np.uint8).copy() for p in payloads]
+    out_cap = len(payloads[0]) * 2
+    outs = [np.zeros(out_cap, dtype=np.uint8) for _ in range(n)]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 2, 2, 1, 1, 0, 0, 0, 0, 1, 3)
+    st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], n, [a.ctypes.data for a in outs], out_cap, batch=batch, device_first=first, device_count=count)
+    usable = (aliases - first) if count == 0 else min(count, aliases - first)
+    assert st.frames == n and st.devices == min(usable, (n + 7) // 8), (st.devices, usable)
+    p = ob.Params(w, h, pixfmt, 2, 2, 1, 1)
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
+    for i in range(n):
+        assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
+    with pytest.raises(api.RcgpuError, match="outside"):
+        api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], 4, [a.ctypes.data for a in outs], out_cap, batch=2, device_first=aliases, device_count=1)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RCGPU_SOAK_PIPE", "6"))))      # soak: RCGPU_SOAK_PIPE=200
 def test_random_pipeline_shapes_equal_the_oracle(seed, monkeypatch):
     """Sequence lengths, batch sizes, slot and ring sizes, thread counts, lanes and copy streams drawn at random: the packets are the
