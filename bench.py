@@ -149,6 +149,62 @@ def cpu_baseline(payloads: list, line_bytes: int, width: int, height: int, gpu_p
                       f"absent here)"}, not bad
 
 
+def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=64):
+    """The product-level number of BASELINE config 5: `rawcooked_linked --check` -- the REAL reference with this library linked in
+    (INTEGRATION.md route C: oracle/route_c_*.patch, built by oracle/Makefile.ref) -- on an MKV of this run's packets, with the device
+    decoder taking the frames the demuxer announces in batches (RCGPU_CHECK_BATCH), beside the same binary with RCGPU_CHECK=0 (its own
+    CPU slice pool).  Everything around the decoder is the reference's: demux, reversibility data, MergeIn, MD5 of every rebuilt file."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "rawcooked_linked")
+    if not os.path.exists(exe):
+        return None
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    work = tempfile.mkdtemp(prefix="rcgpu_linked_", dir=base)
+    try:
+        os.makedirs(os.path.join(work, "seq"))
+        n = min(nframes, len(sizes))
+        for i in range(n):
+            with open(os.path.join(work, "seq", "f_%06d.dpx" % i), "wb") as f:
+                f.write(synth.dpx_file(None, pixfmt, frame_index=i, payload=bytes(frames[i].cpu().numpy()), size=(width, height)))
+        def run(cmd, env=None, timeout=90):      # the reference occasionally dead-locks in its own analysis thread pool on many-core hosts: bounded, retried
+            for attempt in range(3):
+                try:
+                    t0 = time.perf_counter()
+                    r_ = subprocess.run(cmd, cwd=work, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=timeout, env=env)
+                    r_.seconds = time.perf_counter() - t0
+                    return r_
+                except subprocess.TimeoutExpired:
+                    if attempt == 2:
+                        raise
+        r = run([exe, "--hash", "--no-check-padding", "-d", "-y", "seq"], timeout=60)      # analysis only: the reversibility data with the MD5 of every file
+        if r.returncode != 0:
+            return {"error": "analysis failed: " + (r.stderr or r.stdout)[-200:]}
+        mux = api.MkvMuxer(os.path.join(work, "seq.mkv"))
+        t = mux.add_video(record, width, height, 24, 1)
+        mux.add_attachment("RAWcooked reversibility data", open(os.path.join(work, "seq.rawcooked_reversibility_data"), "rb").read())
+        mux.begin()
+        for i in range(n):
+            mux.write_block(t, i * 1000000000 // 24, bytes(d_packets[i * stride:i * stride + sizes[i]].cpu().numpy()))
+        mux.close()
+        out = {"frames": n, "unit": "frames/s"}
+        for name, env in (("device_decoder", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": str(n)}), ("reference_cpu_pool", {"RCGPU_CHECK": "0"})):
+            r = run([exe, "--check", "seq.mkv"], env=dict(os.environ, **env), timeout=120)
+            dt = r.seconds
+            ok = r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout
+            out[name] = {"value": round(n / dt, 2), "seconds": round(dt, 2), "verdict": "Reversibility was checked, no issue detected." if ok else (r.stdout + r.stderr)[-200:]}
+        if out["reference_cpu_pool"]["value"]:
+            out["speedup"] = round(out["device_decoder"]["value"] / out["reference_cpu_pool"]["value"], 2)
+        out["what"] = (f"oracle/_ref/rawcooked_linked --check on an MKV of {n} of this run's {width}x{height} packets (tmpfs): process start to exit, the reference's own demuxer, MergeIn and "
+                       f"MD5 of every rebuilt file (one core, ~0.6 GB/s: ~12 frames/s at 4K whatever decodes) around the decoder; {usable_cores()} usable cores")
+        return out
+    except Exception as e:
+        return {"error": str(e)[-300:]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def reference_check_baseline(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=16, parallel=1):
     """cpu_baseline of the check path, kind "reference": the REAL reference binary (oracle/_ref/rawcooked, built from the reference's
     own sources by oracle/Makefile.ref) decodes and verifies an MKV holding `nframes` of this run's packets, on the host's cores."""
@@ -221,9 +277,10 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     """Config 5: decode the packets back and verify them -- everything resident in HBM (single GPU).  The caller has released the
     encoder: the decoder is latency-bound per slice chain, its rate is chains in flight / chain latency, so D >= F frames are decoded per
     step (the F encoded packets, reused round-robin -- SURVEY.md 8d "ring reuse")."""
-    cpu_rec = None
+    cpu_rec = linked_rec = None
     if cpu:
         from rawcooked_amd import synth as _synth
+        linked_rec = linked_check_record(api, _synth, record, frames, d_packets, stride, sizes, width, height, pixfmt)
         cpu_rec = reference_check_baseline(api, _synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, parallel=max(1, min(8, usable_cores() // 32)))
     torch.cuda.empty_cache()
     D = max(F, check_batch or args.check_batch)
@@ -302,7 +359,7 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
                    "compared_inside_timed_region": state["compared"], "verify_seconds_last_batch": round(t_verify, 3)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                      "traffic": traffic, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}},
-        **({"cpu_baseline": cpu_rec} if cpu_rec else {})}
+        **({"cpu_baseline": cpu_rec} if cpu_rec else {}), **({"linked_check": linked_rec} if linked_rec else {})}
     dec.close()
     del outs
     torch.cuda.empty_cache()
@@ -833,7 +890,7 @@ def main():
             rec, ok = check_leg(args, torch, api, record, frames, keep_pk, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, local_rank,
                                 steps=2, warmup=1, cpu="cpu" in legs)
             ok_all &= ok
-            result["check"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline") if k in rec}
+            result["check"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline", "linked_check") if k in rec}
             if result["check"].get("config", {}).get("all_frames_identical_to_source"):
                 result["config"]["packets_verified"] = (f"all {F} packets of the last timed step decode to their sources on the device (check record: byte compare + MD5); "
                                                         "the first ones also through the oracle and the reference binary (verified_vs_oracle, verified_by_reference), "

@@ -418,3 +418,34 @@ def test_linked_reference_encodes_and_checks_on_the_device(built, linkedbin, ref
     open(p, "wb").write(data)
     r = run([linkedbin, "--check", "pkg.mkv"], work, timeout=60)
     assert r.returncode != 0 or "Error" in (r.stdout + r.stderr) or OK_LINE not in r.stdout
+
+
+@pytest.mark.parametrize("batch", ["1", "5", "64"])
+def test_linked_reference_checks_in_batches(built, linkedbin, refbin, tmp_path, monkeypatch, batch):
+    """Route C batches: the demuxer (oracle/route_c_matroska_cpp.patch, Matroska.cpp:934-953) announces the blocks of the track that follow
+    the one it hands over, ffv1_frame::Process (oracle/route_c_ffv1_frame_cpp.patch) decodes up to RCGPU_CHECK_BATCH of them in one device call
+    and keeps the payloads until their turn.  Audio blocks lie between the video blocks; 13 frames do not divide by 5; one corrupt frame in
+    the middle is reported as that frame's error and the frames around it still check."""
+    work = str(tmp_path)
+    make_package(work, 96, 64, synth.PIX_RGB16_BE, 13, "film", audio=(2, 16, 48000, 26000))
+    monkeypatch.setenv("RCGPU_CHECK_BATCH", batch)
+    r = run([linkedbin, "--no-check-padding", "--check", "--hash", "-y", "pkg"], work, timeout=60)        # encode (route B) + check (route C)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+    r = run([linkedbin, "-y", "pkg.mkv"], work, timeout=60)                                                # every file rebuilt through the batches
+    assert r.returncode == 0, r.stdout + r.stderr
+    for i in range(13):
+        fn = os.path.join("pkg", "img", "f_%06d.dpx" % i)
+        assert open(os.path.join(work, fn), "rb").read() == open(os.path.join(work, "pkg.mkv.RAWcooked", fn), "rb").read(), fn
+    # flip a bit inside the 7th video block: that frame is undecodable, the verdict says so, nothing crashes
+    import mkv_validator
+    blocks = []
+    mkv_validator.validate(os.path.join(work, "pkg.mkv"), on_block=lambda trk, t, a, b: blocks.append((trk, a, b)))
+    video = [(a, b) for trk, a, b in blocks if trk == 1]
+    assert len(video) == 13 and any(trk != 1 for trk, _, _ in blocks)
+    data = bytearray(open(os.path.join(work, "pkg.mkv"), "rb").read())
+    a, b = video[6]
+    data[(a + b) // 2] ^= 0x04
+    open(os.path.join(work, "pkg.mkv"), "wb").write(data)
+    r = run([linkedbin, "--check", "pkg.mkv"], work, timeout=60)
+    assert OK_LINE not in r.stdout and ("Error" in (r.stdout + r.stderr) or r.returncode != 0), r.stdout + r.stderr
+    assert "f_000006" in (r.stdout + r.stderr), r.stdout + r.stderr
