@@ -365,6 +365,11 @@ __device__ unsigned long long g_prof[16];
 #else
 #define PROF_T(i)
 #endif
+#ifdef RCGPU_EXP_SLOTMAJOR
+#define OPI(k) (((k) & 31) * 64)
+#else
+#define OPI(k) (k)
+#endif
 template <bool LDS_STATES>
 __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
@@ -606,7 +611,11 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         unsigned long long done = 0;
         bool pending = valid;
         uint8_t* sl = LDS_STATES ? lstates + size_t(key) * 32 : slot + leader * 32;
+        #ifdef RCGPU_EXP_SLOTMAJOR
+        uint8_t* op = stage + lane;                     // timing build: decision slot k of lane l at k * 64 + l -- no two lanes of a store share a bank
+#else
         uint8_t* op = stage + stage_count + excl;
+#endif
         {   // the coded bits of this lane's decisions do not depend on any state: zero flag | e ones, a zero | mantissa from the top | sign.
             // 2e + 3 bits: one dword unless some lane of the chunk has e >= 15 (emax is uniform)
             const uint32_t o = stage_count + excl, w = o >> 5, sh = o & 31;
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                 for (uint32_t r = rank & 3; r; r--) st = trans[256 + st];          // rank = 16 a + 4 b + c: at most 3 + 3 + 3 look-ups
                 for (uint32_t r = (rank >> 2) & 3; r; r--) st = pw[st];
                 for (uint32_t r = rank >> 4; r; r--) st = pw[256 + st];
-                op[0] = uint8_t(st);                                   // a coded 1: t = state
+                op[OPI(0)] = uint8_t(st);                                   // a coded 1: t = state
                 if (last) sl[0] = trans[256 + st];
             }
             done |= __ballot(zrun);
@@ -665,8 +674,8 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 #define ST_GET(k) ((S[(k) >> 2] >> (8 * ((k) & 3))) & 0xFFu)
 #define ST_PUT_IF(c, k, v) (S[(k) >> 2] = (c) ? ((S[(k) >> 2] & ~(0xFFu << (8 * ((k) & 3)))) | ((v) << (8 * ((k) & 3)))) : S[(k) >> 2])
 #define NEXT(en) uint32_t(trans[256 + (en)])                            /* en = +state for bit 1, -state for bit 0 */
-#define EXP_SLOT(t) { const int en = __mul24(int(ST_GET(1 + (t))), sg_e[t]); nxe[t] = NEXT(en); if (nz && (t) <= e) op[1 + (t)] = uint8_t(en); }
-#define MAN_SLOT(t) { const int en = __mul24(int(ST_GET(22 + (t))), sg_m[t]); nxm[t] = NEXT(en); if (nz && (t) < e) op[2 * e + 1 - (t)] = uint8_t(en); }
+#define EXP_SLOT(t) { const int en = __mul24(int(ST_GET(1 + (t))), sg_e[t]); nxe[t] = NEXT(en); if (nz && (t) <= e) op[OPI(1 + (t))] = uint8_t(en); }
+#define MAN_SLOT(t) { const int en = __mul24(int(ST_GET(22 + (t))), sg_m[t]); nxm[t] = NEXT(en); if (nz && (t) < e) op[OPI(2 * e + 1 - (t))] = uint8_t(en); }
 #define MERGE(x, n, m) x = ((n) & (m)) | ((x) & ~(m))
                     const bool nz = a != 0;
                     const int ks = 11 + (e < 10 ? e : 10);              // sign state: the only index that depends on the symbol
@@ -675,7 +684,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                     // number indexes the transition table.  (The coded bits went into the bit stage before the rounds.)
                     const int en_z = nz ? -int(ST_GET(0)) : int(ST_GET(0));
                     const uint32_t nx_z = NEXT(en_z);
-                    op[0] = uint8_t(en_z);
+                    op[OPI(0)] = uint8_t(en_z);
                     uint32_t nxe[9] = {}, nxm[9] = {}, nx_s = 0;
                     if constexpr (L >= 1) {
                         const int st_s = nz ? int(sl[ks]) : 128;       // sign states 11..21 are touched by nothing else: straight from LDS
@@ -684,7 +693,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                         if constexpr (L >= 3) { EXP_SLOT(7) EXP_SLOT(8) MAN_SLOT(6) MAN_SLOT(7) MAN_SLOT(8) }
                         const int en_s = d < 0 ? st_s : -st_s;
                         nx_s = NEXT(en_s);
-                        if (nz) op[2 * e + 2] = uint8_t(en_s);
+                        if (nz) op[OPI(2 * e + 2)] = uint8_t(en_s);
                     }
                     PROF_T(9)
                     // ---- the two chains: state 10 for exponent bits 9.., state 31 for mantissa bits e-1 .. 9
@@ -693,7 +702,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                         for (int t = 9; t <= emax; t++) {
                             const bool act = nz && t <= e;
                             const int en = t < e ? int(ST_GET(10)) : -int(ST_GET(10));
-                            if (act) op[1 + t] = uint8_t(en);
+                            if (act) op[OPI(1 + t)] = uint8_t(en);
                             const uint32_t nx = NEXT(en);
                             ST_PUT_IF(act, 10, nx);
                         }
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                         for (int t = emax - 1; t >= 9; t--) {
                             const bool act = nz && t < e;
                             const int en = (a >> t) & 1u ? int(ST_GET(31)) : -int(ST_GET(31));
-                            if (act) op[2 * e + 1 - t] = uint8_t(en);
+                            if (act) op[OPI(2 * e + 1 - t)] = uint8_t(en);
                             const uint32_t nx = NEXT(en);
                             ST_PUT_IF(act, 31, nx);
                         }
