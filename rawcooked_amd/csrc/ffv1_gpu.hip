@@ -753,11 +753,20 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         }
 
         PROF_T(5)
-        // --- last lane of each group writes the states back
-        if (!LDS_STATES && valid && last) {
-            const uint4* sp = reinterpret_cast<const uint4*>(sl);
-            uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
-            gp[0] = sp[0]; gp[1] = sp[1];
+        // --- the states go back to HBM, once per group.  A record is 32 bytes and a store carries 16 per lane: written by its own lane in two
+        // stores, every record costs two write requests to the L2 -- and k_resolve is bound by the requests its CU's L1 has in flight
+        // (TCP_PENDING_STALL_CYCLES 85 % of the L1's cycles; 0.98 read + 2.29 write requests per sample, profiles/r03_tcp_counters.txt).
+        // So a PAIR of lanes writes one record, its halves side by side in one store instruction: one request per record.
+        if (!LDS_STATES) {
+            const uint32_t wb = (valid && last) ? (key | uint32_t(leader) << 16) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t info = uint32_t(__shfl(int(wb), h * 32 + (lane >> 1)));
+                if (info != 0xFFFFFFFFu) {
+                    const uint32_t half = uint32_t(lane & 1) * 16u;
+                    *reinterpret_cast<uint4*>(st_base + size_t(info & 0xFFFFu) * 32 + half) = *reinterpret_cast<const uint4*>(slot + (info >> 16) * 32 + half);
+                }
+            }
         }
         PROF_T(6)
         stage_count += total;
@@ -810,19 +819,23 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 //     event, which ripples it through the bytes already in HBM.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kMaxCarryEvents = 4096;
-// Parked dwords between two drains: the decisions renormalise at most once each, a flush per four bytes (+1 carried in).  The whole-slice
-// coder drains once per piece (kDrainWhole decisions), always before the next prefetch is issued; the span coder of the split mapping is a
-// throughput kernel that must fit beside k_resolve's LDS, and drains every kDrainSpan decisions into a quarter of the rows.
+// Finished dwords are parked in a per-lane ring in LDS and leave for HBM SIXTEEN BYTES at a time: a dword per lane and store instruction is
+// a write request per four bytes of output -- as many requests as the coder's stream reads cause, on CUs whose L1 request queues are what
+// k_resolve waits for (profiles/r03_tcp_counters.txt).  Between two drains the decisions renormalise at most once each, a flush per four
+// bytes (+1 carried in), and up to three rows stay behind for the next group: the whole-slice coder drains twice per piece (always before
+// a prefetch is issued or in the middle of a piece), the span coder of the split mapping every 14 decisions into half the rows.
+// The whole-slice coder keeps the one-dword stores of its first version, all of them at the piece boundary before the next prefetch is
+// issued: its wavefronts are serial chains, and stores in the middle of a piece made them 7 % longer (measured, round 3).
 constexpr int kDrainWhole = kPieceEntries, kDrainSpan = 14;
-constexpr int out_rows(int drain_every) { return drain_every / 4 + 1 + (drain_every % 4 ? 1 : 0); }
-constexpr int kOutRows = out_rows(kDrainWhole);
+constexpr int ring_rows(int drain_every) { return drain_every / 4 + 1 + (drain_every % 4 ? 1 : 0) + 3 <= 8 ? 8 : drain_every / 4 + 1 <= 16 ? 16 : 32; }
+static_assert(kDrainWhole / 4 + 1 <= 16 && kDrainSpan / 4 + 2 + 3 <= 8, "the ring holds what two drains leave and add");
 
 struct rc_resume { uint32_t range, nb, pd; int pos; unsigned long long low; unsigned long long pad; };   // per chain, between segments
 
 struct rc_lane {
     uint32_t range; unsigned long long low; uint32_t nb; uint32_t pd;
-    uint32_t ocnt;                    // dwords parked during this piece
-    uint32_t* obuf;                   // LDS [kOutRows + 1][64], this lane's column
+    uint32_t wr, rd;                  // dwords parked / drained so far (ring positions modulo its size)
+    uint32_t* obuf;                   // LDS [rows][64], this lane's column
     int pos; uint8_t* out; int cap; uint32_t chain;
     int lo;                           // first byte position this lane codes (0 for a whole slice, the checkpoint's for a span)
 };
@@ -842,6 +855,7 @@ __device__ __forceinline__ void rc_step(rc_lane& r, uint32_t t, uint32_t m)
 // Predicated flush: when >= 4 finished bytes are pending, the four oldest move to pd and the old pd is parked.  The parked slot is
 // written unconditionally (a lane that does not flush rewrites it at its next real flush), and the ~2^-32 carry out of pd is the
 // only branch: taken by a whole wavefront almost never.
+template <int R>
 __device__ __forceinline__ void rc_check(rc_lane& r, uint32_t* ev_count, uint2* ev)
 {
     const bool f = r.nb >= 32;                                // nb <= 40 here
@@ -849,36 +863,51 @@ __device__ __forceinline__ void rc_check(rc_lane& r, uint32_t* ev_count, uint2* 
     const uint32_t four = uint32_t(r.low >> (sh16 & 63));
     const uint32_t carry = f ? uint32_t(r.low >> 32) >> (sh16 & 31) : 0u;   // whatever sits above those four bytes
     const uint32_t npd = r.pd + carry;
-    r.obuf[r.ocnt * 64] = __builtin_bswap32(npd);
+    r.obuf[(r.wr & uint32_t(R - 1)) * 64] = __builtin_bswap32(npd);
     if (__builtin_expect(__ballot(npd < carry) != 0, 0)) {    // pd wrapped: +1 belongs to the bytes below that dword, already in HBM
         if (npd < carry) {
             const uint32_t slot = atomicAdd(ev_count, 1u);
-            if (slot < kMaxCarryEvents) ev[slot] = make_uint2(r.chain, uint32_t(r.pos + 4 * int(r.ocnt)));
+            if (slot < kMaxCarryEvents) ev[slot] = make_uint2(r.chain, uint32_t(r.pos + 4 * int(r.wr - r.rd)));
         }
     }
-    r.ocnt += r.nb >> 5;                                      // bit 5 of nb <=> f
+    r.wr += r.nb >> 5;                                        // bit 5 of nb <=> f
     r.pd = f ? four : r.pd;
     r.low = f ? (unsigned long long)__builtin_amdgcn_ubfe(uint32_t(r.low), 0u, sh16) : r.low;
     r.nb &= 31;                                               // -32 when f
 }
 
-template <int ROWS = kOutRows>
+// Groups of four parked dwords leave as one 16-byte store (WIDE); ALL = everything goes, dword by dword: at the end of a launch or span the
+// one to three rows the groups left, in the whole-slice coder every row.
+template <int R, bool WIDE, bool ALL = false>
 __device__ __forceinline__ void rc_drain(rc_lane& r)
 {
+    // the first dword a lane parks is its still empty second stage (r.pos == r.lo - 4): it is never stored
+    if (r.pos < r.lo && r.wr != r.rd) { r.rd++; r.pos += 4; }
+    if (WIDE)
 #pragma unroll
-    for (int k = 0; k < ROWS; k++) {
-        if (uint32_t(k) < r.ocnt) {
-            // the first dword a lane parks is its still empty second stage (r.pos == r.lo - 4): it lands in the slack in front of the slice
-            int at = r.pos + 4 <= r.cap ? r.pos : r.cap - 4;
-            if (k == 0) at = r.pos < r.lo ? -4 : at;
-            *reinterpret_cast<uint32_t*>(r.out + at) = r.obuf[k * 64];
-            r.pos += 4;
+    for (int g = 0; g < R / 4; g++) {
+        if (r.wr - r.rd >= 4u) {
+            uint4 v;
+            v.x = r.obuf[(r.rd & uint32_t(R - 1)) * 64]; v.y = r.obuf[((r.rd + 1) & uint32_t(R - 1)) * 64];
+            v.z = r.obuf[((r.rd + 2) & uint32_t(R - 1)) * 64]; v.w = r.obuf[((r.rd + 3) & uint32_t(R - 1)) * 64];
+            const int at = r.pos + 16 <= r.cap ? r.pos : r.cap - 16;       // an overflowing slice is reported at its end, its stores stay inside
+            *reinterpret_cast<uint4*>(r.out + at) = v;
+            r.pos += 16; r.rd += 4;
         }
     }
-    r.ocnt = 0;
+    if (ALL) {
+#pragma unroll
+        for (int k = 0; k < (WIDE ? 3 : R); k++) {
+            if (r.wr != r.rd) {
+                const int at = r.pos + 4 <= r.cap ? r.pos : r.cap - 4;
+                *reinterpret_cast<uint32_t*>(r.out + at) = r.obuf[(r.rd & uint32_t(R - 1)) * 64];
+                r.pos += 4; r.rd++;
+            }
+        }
+    }
 }
 
-template <int DRAIN = kDrainWhole>
+template <int DRAIN>
 __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32_t cnt, uint32_t* ev_count, uint2* ev)
 {
     const uint32_t w[16] = { q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
@@ -889,8 +918,8 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
             const uint32_t t = (w[j >> 2] >> (8 * (j & 3))) & 0xFF;
             const uint32_t m = uint32_t(__builtin_amdgcn_sbfe(int(w[14 + (j >> 5)]), uint32_t(j & 31), 1u));
             rc_step(r, t, m);
-            if (j & 1) rc_check(r, ev_count, ev);
-            if (DRAIN < kPieceEntries && (j + 1) % DRAIN == 0 && j + 1 < kPieceEntries) rc_drain<out_rows(DRAIN)>(r);
+            if (j & 1) rc_check<ring_rows(DRAIN)>(r, ev_count, ev);
+            if (DRAIN < kPieceEntries && (j + 1) % DRAIN == 0 && j + 1 < kPieceEntries) rc_drain<ring_rows(DRAIN), true>(r);
         }
     } else {
 #pragma unroll 1
@@ -900,8 +929,8 @@ __device__ __forceinline__ void rc_piece(rc_lane& r, const uint4 (&q)[4], uint32
             for (int k = 0; k < 14; k++) ww = (j >> 2) == uint32_t(k) ? w[k] : ww;
             const uint32_t bw = j < 32 ? w[14] : w[15];
             rc_step(r, (ww >> (8 * (j & 3))) & 0xFF, 0u - ((bw >> (j & 31)) & 1u));
-            rc_check(r, ev_count, ev);
-            if (DRAIN < kPieceEntries && (j & 3) == 3) rc_drain<out_rows(DRAIN)>(r);       // a check per decision here: at most four rows between drains
+            rc_check<ring_rows(DRAIN)>(r, ev_count, ev);
+            if ((j & 3) == 3) rc_drain<ring_rows(DRAIN), DRAIN < kPieceEntries, DRAIN == kPieceEntries>(r);       // a check per decision here: at most four rows between drains
         }
     }
 }
@@ -925,8 +954,8 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
                                                   uint32_t* __restrict__ out_len, uint32_t* __restrict__ err, uint2* __restrict__ events,
                                                   rc_ckpt* __restrict__ ckpt, uint32_t span_pieces)
 {
-    constexpr int kDrain = SPAN ? kDrainSpan : kDrainWhole, kRows = out_rows(kDrain);
-    __shared__ uint32_t obuf[(kRows + 1) * 64];
+    constexpr int kDrain = SPAN ? kDrainSpan : kDrainWhole, kRows = ring_rows(kDrain);
+    __shared__ uint32_t obuf[kRows * 64];
     // The whole-slice coder is latency-bound and shares SIMDs with throughput-bound k_resolve wavefronts: take issue priority.
     if (!SPAN) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
@@ -949,7 +978,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
     rc_ckpt* const ck = SPAN ? ckpt + size_t(blockIdx.y) * nchains + cc : nullptr;
 
     rc_lane r;
-    r.obuf = obuf + lane; r.ocnt = 0;
+    r.obuf = obuf + lane; r.wr = r.rd = 0;
     r.range = 0xFF00; r.low = 0; r.nb = 0; r.pd = 0; r.pos = -4; r.chain = cc; r.lo = 0;
     if (SPAN) { const rc_ckpt v = *ck; r.range = v.v; r.lo = int(v.pos); r.pos = r.lo - 4; }
     else if (seg) { const rc_resume v = resume[cc]; r.range = v.range; r.low = v.low; r.nb = v.nb; r.pd = v.pd; r.pos = v.pos; }   // nb in bits
@@ -972,7 +1001,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
             const uint4* p = src + pi * (kGroupPieceBytes / 16);
 #pragma unroll
             for (int k = 0; k < 4; k++) cur[k] = p[k];
-            rc_drain<kRows>(r);
+            rc_drain<kRows, SPAN, !SPAN>(r);
             if (pc < npieces) {
                 const unsigned long long left = n - (p0 + pc) * kPieceEntries;
                 rc_piece<kDrain>(r, cur, left < kPieceEntries ? uint32_t(left) : uint32_t(kPieceEntries), err + 1, events);
@@ -986,7 +1015,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
         // sits here (covering only loads issued a whole piece ago), not behind the next prefetch.
 #pragma unroll
         for (int k = 0; k < 4; k++) { asm volatile("" : "+v"(cur[k].x), "+v"(cur[k].y), "+v"(cur[k].z), "+v"(cur[k].w)); }
-        rc_drain<kRows>(r);
+        rc_drain<kRows, SPAN, !SPAN>(r);
         const unsigned long long pn = pc + 1 < npieces ? pc + 1 : (npieces ? npieces - 1 : 0);
         const uint4* p = src + pn * (kGroupPieceBytes / 16);
 #pragma unroll
@@ -999,7 +1028,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
         for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
     }
-    rc_drain<kRows>(r);
+    rc_drain<kRows, SPAN, true>(r);
     if (!SPAN && active && !last_seg) { rc_resume v; v.range = r.range; v.low = r.low; v.nb = r.nb; v.pd = r.pd; v.pos = r.pos; v.pad = 0; resume[cc] = v; }
     if (SPAN && active && !ends_chain) {
         // End of a span: the second stage and the finished bytes leave one by one (the next span's first byte follows directly), the 16
