@@ -1501,13 +1501,13 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     e->lds_states = size_t(e->nkeys) * 32 <= (48u << 10);                        // 338 contexts x 2 (3) sets x 32 B = 21.6 (32.4) KB
     // Workgroup LDS = kResolveFixedLds + two bitmaps: 9.4 KB with the 10 126 contexts of the default model, so that the registers (four
     // wavefronts per SIMD) and not the LDS bound k_resolve's occupancy.  A total can be forced to re-measure what occupancy is worth.
-    // Range coder mapping.  One lane per slice is a serial chain of 21 VALU instructions per decision; a batch holds max_batch x S of them,
-    // 64 to a wavefront.  With fewer wavefronts than the chip has SIMDs (1024) the chains, not the chip, set the batch time: then the
-    // coder is split (k_rc_range / k_rangecode<true> / k_rc_tails).  With thousands of slices in flight the whole-slice coder is already a
-    // throughput kernel and the first pass would only add its nine instructions per decision.
+    // Range coder mapping.  One lane per slice is a serial chain of 21 VALU instructions per decision, 64 chains to a wavefront, each
+    // wavefront alone on its SIMD's issue port: 0.41 s for a 4K slice whatever the batch.  With 300 and more such wavefronts in flight that
+    // chain hides behind k_resolve (4096x2160 x 336 frames: 684-696 frames/s either way); with fewer, the chain sets the batch time and
+    // the coder is split (k_rc_range / k_rangecode<true> / k_rc_tails: 168 frames per step 565 instead of 376 frames/s, 112: 459 / 259).
     {
         const size_t waves = (size_t(cfg->max_batch) * S + 63) / 64;
-        e->span_pieces = cfg->rc_span == RCGPU_RC_WHOLE ? 0u : cfg->rc_span ? cfg->rc_span : (waves < 1024 && e->sp.version != 1 ? 64u : 0u);
+        e->span_pieces = cfg->rc_span == RCGPU_RC_WHOLE ? 0u : cfg->rc_span ? cfg->rc_span : (waves < 300 && e->sp.version != 1 ? 64u : 0u);
         e->exp_skip_rc = getenv("RCGPU_EXP_SKIP_RC") != nullptr;
         if (const char* x = getenv("RCGPU_RESOLVE_PRIO")) e->resolve_prio = uint32_t(atoi(x));        // for measuring
         if (const char* x = getenv("RCGPU_RC_SPAN")) { const int v = atoi(x); e->span_pieces = v >= 8 ? uint32_t(v) : 0u; }      // for measuring
