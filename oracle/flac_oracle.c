@@ -277,10 +277,10 @@ static int quantize(const double* c, int order, int32_t* q, int* shift_out)
     return 1;
 }
 
-static void plan_subframe(const flaco_params* P, const int32_t* x, uint32_t n, subframe_plan* best, int32_t* best_res,
+/* bps: width of THIS subframe's samples -- the side channel of a stereo pair has one bit more (stream_decoder.c:2036-2062) */
+static void plan_subframe(const flaco_params* P, uint32_t bps, const int32_t* x, uint32_t n, subframe_plan* best, int32_t* best_res,
                           int32_t* tmp_res, int64_t* xs)
 {
-    const uint32_t bps = P->bits_per_sample;
     const int param_bits = bps > 16 ? 5 : 4, kmax = bps > 16 ? 30 : 14;
     memset(best, 0, sizeof *best);
     /* constant */
@@ -322,9 +322,8 @@ static void plan_subframe(const flaco_params* P, const int32_t* x, uint32_t n, s
     }
 }
 
-static void write_subframe(bitw* w, const flaco_params* P, const int32_t* x, uint32_t n, const subframe_plan* sp, const int32_t* res)
+static void write_subframe(bitw* w, int bps, const int32_t* x, uint32_t n, const subframe_plan* sp, const int32_t* res)
 {
-    const int bps = (int)P->bits_per_sample;
     const int param_bits = bps > 16 ? 5 : 4;
     switch (sp->type) {
     case 0: bw_put(w, 0x00, 8); bw_put_signed(w, x[0], bps); return;
@@ -370,11 +369,15 @@ long flaco_encode(const flaco_params* P, const uint8_t* pcm, uint64_t pcm_bytes,
     const uint64_t total = pcm_bytes / ((uint64_t)bytes_ps * ch);
     const uint64_t nframes = (total + B - 1) / B;
     if (nframes > frame_cap) return -1;
-    int32_t* x = malloc((size_t)B * ch * sizeof(int32_t));
-    int32_t* res = malloc((size_t)B * ch * sizeof(int32_t));
+    /* Two channels are also tried as left/side, side/right and mid/side (channel assignments 8, 9, 10; stream_decoder.c:2299-2321 reads
+       them, :2036-2062 undoes them): four candidate signals L, R, M = (L + R) >> 1, S = L - R, the pair with the fewest bits wins, the
+       plain pair on a tie. */
+    const uint32_t nsig = ch == 2 ? 4 : ch;
+    int32_t* x = malloc((size_t)B * nsig * sizeof(int32_t));
+    int32_t* res = malloc((size_t)B * nsig * sizeof(int32_t));
     int32_t* tmp = malloc((size_t)B * sizeof(int32_t));
     int64_t* xs = malloc((size_t)B * sizeof(int64_t));
-    subframe_plan* plans = malloc(sizeof(subframe_plan) * ch);
+    subframe_plan* plans = malloc(sizeof(subframe_plan) * nsig);
     size_t pos = 0; long ret = (long)nframes;
     for (uint64_t fi = 0; fi < nframes; fi++) {
         const uint32_t n = (uint32_t)((fi + 1) * B <= total ? B : total - fi * B);
@@ -382,14 +385,34 @@ long flaco_encode(const flaco_params* P, const uint8_t* pcm, uint64_t pcm_bytes,
             for (uint32_t c = 0; c < ch; c++)
                 x[(size_t)c * B + i] = load_sample(pcm + ((fi * B + i) * ch + c) * bytes_ps, bps);
         uint64_t bits = 0;
-        for (uint32_t c = 0; c < ch; c++) { plan_subframe(P, x + (size_t)c * B, n, &plans[c], res + (size_t)c * B, tmp, xs); bits += plans[c].bits; }
+        uint32_t sig[8], sig_bps[8], assignment = ch - 1;
+        for (uint32_t c = 0; c < ch; c++) { sig[c] = c; sig_bps[c] = bps; }
+        if (ch == 2) {
+            for (uint32_t i = 0; i < n; i++) {
+                const int32_t l = x[i], r = x[(size_t)B + i];
+                x[(size_t)2 * B + i] = (l + r) >> 1;
+                x[(size_t)3 * B + i] = l - r;
+            }
+        }
+        for (uint32_t c = 0; c < nsig; c++) plan_subframe(P, c == 3 && ch == 2 ? bps + 1 : bps, x + (size_t)c * B, n, &plans[c], res + (size_t)c * B, tmp, xs);
+        if (ch == 2) {
+            const uint64_t lr = plans[0].bits + plans[1].bits, ls = plans[0].bits + plans[3].bits, rs = plans[3].bits + plans[1].bits, ms = plans[2].bits + plans[3].bits;
+            uint64_t best = lr; assignment = 1;
+            if (ls < best) { best = ls; assignment = 8; }
+            if (rs < best) { best = rs; assignment = 9; }
+            if (ms < best) { best = ms; assignment = 10; }
+            if (assignment == 8) { sig[1] = 3; sig_bps[1] = bps + 1; }
+            else if (assignment == 9) { sig[0] = 3; sig_bps[0] = bps + 1; }
+            else if (assignment == 10) { sig[0] = 2; sig[1] = 3; sig_bps[1] = bps + 1; }
+        }
+        for (uint32_t c = 0; c < ch; c++) bits += plans[sig[c]].bits;
         /* frame header (stream_decoder.c:2159-2466), fixed blocking strategy */
         uint8_t hdr[16]; int h = 0;
         hdr[h++] = 0xFF; hdr[h++] = 0xF8;
         const int bsc = blocksize_code(n);
         const int src = P->sample_rate == 44100 ? 9 : P->sample_rate == 48000 ? 10 : P->sample_rate == 96000 ? 11 : 0;
         hdr[h++] = (uint8_t)((bsc << 4) | src);
-        hdr[h++] = (uint8_t)(((ch - 1) << 4) | ((bps == 8 ? 1 : bps == 16 ? 4 : 6) << 1));
+        hdr[h++] = (uint8_t)((assignment << 4) | ((bps == 8 ? 1 : bps == 16 ? 4 : 6) << 1));
         h += utf8_put(hdr + h, fi);
         if (bsc == 6) hdr[h++] = (uint8_t)(n - 1);
         else if (bsc == 7) { hdr[h++] = (uint8_t)((n - 1) >> 8); hdr[h++] = (uint8_t)(n - 1); }
@@ -398,7 +421,7 @@ long flaco_encode(const flaco_params* P, const uint8_t* pcm, uint64_t pcm_bytes,
         if (pos + fsize > cap) { ret = -1; break; }
         memcpy(out + pos, hdr, (size_t)h);
         bitw w = { out + pos + h, fsize - (size_t)h - 2, 0, 0 };
-        for (uint32_t c = 0; c < ch; c++) write_subframe(&w, P, x + (size_t)c * B, n, &plans[c], res + (size_t)c * B);
+        for (uint32_t c = 0; c < ch; c++) write_subframe(&w, (int)sig_bps[c], x + (size_t)sig[c] * B, n, &plans[sig[c]], res + (size_t)sig[c] * B);
         if (w.overflow || w.bitpos != bits) { ret = -2; break; }
         const uint16_t crc = flaco_crc16(out + pos, fsize - 2);
         out[pos + fsize - 2] = (uint8_t)(crc >> 8); out[pos + fsize - 1] = (uint8_t)crc;
@@ -460,7 +483,7 @@ long long flaco_decode(const flaco_params* P, const uint8_t* frames, size_t size
         else if (bsc == 6) n = br_get(&r, 8) + 1; else if (bsc == 7) n = br_get(&r, 16) + 1;
         else if (bsc >= 8) n = 256u << (bsc - 8); else { ret = -13; break; }
         if (src == 12) br_get(&r, 8); else if (src == 13 || src == 14) br_get(&r, 16); else if (src == 15) { ret = -14; break; }
-        if (ca != ch - 1) { ret = -15; break; }
+        if (ca != ch - 1 && !(ch == 2 && ca >= 8 && ca <= 10)) { ret = -15; break; }
         const uint32_t want_ssc = bps == 8 ? 1 : bps == 16 ? 4 : 6;
         if (ssc != want_ssc && ssc != 0) { ret = -16; break; }
         const size_t hbytes = (size_t)(r.bitpos >> 3);
@@ -472,7 +495,8 @@ long long flaco_decode(const flaco_params* P, const uint8_t* frames, size_t size
             const uint32_t type = br_get(&r, 6);
             uint32_t wasted = 0;
             if (br_get(&r, 1)) wasted = br_unary(&r) + 1;
-            const int sb = (int)bps - (int)wasted;
+            const int side = (ca == 8 && c == 1) || (ca == 9 && c == 0) || (ca == 10 && c == 1);      /* the difference channel: one bit more */
+            const int sb = (int)bps + side - (int)wasted;
             if (type == 0) { const int32_t v = br_get_signed(&r, sb); for (uint32_t i = 0; i < n; i++) d[i] = v; }
             else if (type == 1) { for (uint32_t i = 0; i < n; i++) d[i] = br_get_signed(&r, sb); }
             else {
@@ -516,6 +540,14 @@ long long flaco_decode(const flaco_params* P, const uint8_t* frames, size_t size
             if (wasted) for (uint32_t i = 0; i < n; i++) d[i] = (int32_t)((uint32_t)d[i] << wasted);
         }
         if (ret) break;
+        if (ca >= 8) {                                                     /* stream_decoder.c:2036-2062 */
+            int32_t* a = x; int32_t* b = x + 65536;
+            for (uint32_t i = 0; i < n; i++) {
+                if (ca == 8) b[i] = a[i] - b[i];                           /* left, side -> right */
+                else if (ca == 9) a[i] = a[i] + b[i];                      /* side, right -> left */
+                else { const int32_t m2 = (int32_t)(((uint32_t)a[i] << 1) | ((uint32_t)b[i] & 1u)), sd = b[i]; a[i] = (m2 + sd) >> 1; b[i] = (m2 - sd) >> 1; }
+            }
+        }
         if (r.err) { ret = -30; break; }
         while (r.bitpos & 7) if (br_get(&r, 1)) { ret = -31; break; }
         if (ret) break;

@@ -4,7 +4,9 @@
 // (Lib/CoDec/Wrapper.cpp:131-373).  No CPU fallback: without a HIP device rcgpu_flac_create() fails.
 //
 // Two kernels, one wavefront per work item:
-//   k_flac_plan   (block, channel): constant / verbatim / fixed 0-4 / LPC 1..max search.  Integer-exact Welch-windowed
+//   k_flac_plan   (block, signal): a signal is a channel -- or, for two channels, one of left, right, mid = (l + r) >> 1, side = l - r (one
+//                 bit wider), so that k_flac_write can choose between the plain pair and left/side, side/right, mid/side (channel
+//                 assignments 8, 9, 10; stream_decoder.c:2299-2321 reads them, :2036-2062 undoes them).  Per signal: constant / verbatim / fixed 0-4 / LPC 1..max search.  Integer-exact Welch-windowed
 //                 autocorrelation (wave reduction of int64), Levinson-Durbin + coefficient quantiser in IEEE double with a
 //                 fixed operation order (-ffp-contract=off), exhaustive order search by exact Rice bit counts,
 //                 partition-order search by the integer cost m*(k+1) + (U >> k).
@@ -47,6 +49,14 @@ __device__ __forceinline__ int32_t load_pcm(const uint8_t* p, uint32_t bps)
     if (bps == 8) return int32_t(p[0]) - 128;
     if (bps == 16) return int16_t(uint16_t(p[0]) | (uint16_t(p[1]) << 8));
     return int32_t((uint32_t(p[0]) << 8) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 24)) >> 8;
+}
+// Signal `sg` of a frame: channel sg, or for two channels 0 left, 1 right, 2 mid, 3 side.
+__device__ __forceinline__ int32_t load_signal(const uint8_t* pcm, unsigned long long sample, uint32_t nch, uint32_t sg, uint32_t bps)
+{
+    const uint32_t bytes_ps = bps / 8;
+    if (nch != 2) return load_pcm(pcm + (sample * nch + sg) * bytes_ps, bps);
+    const int32_t l = load_pcm(pcm + sample * 2 * bytes_ps, bps), r = load_pcm(pcm + (sample * 2 + 1) * bytes_ps, bps);
+    return sg == 0 ? l : sg == 1 ? r : sg == 2 ? (l + r) >> 1 : l - r;
 }
 __device__ __forceinline__ uint32_t zigzag(int32_t r) { return r >= 0 ? uint32_t(r) << 1 : ((uint32_t(-(r + 1))) << 1) | 1u; }
 
@@ -150,12 +160,13 @@ __global__ __launch_bounds__(64) void k_flac_plan(const flac_const* __restrict__
     __shared__ int s_shift, s_ok, s_usable;
 
     const int lane = threadIdx.x;
-    const uint32_t blk = blockIdx.x, ch = blockIdx.y, nch = C->channels, bps = C->bps, bytes_ps = bps / 8;
+    const uint32_t blk = blockIdx.x, sg = blockIdx.y, nch = C->channels, nsig = gridDim.y;
+    const uint32_t bps = C->bps + (nch == 2 && sg == 3 ? 1u : 0u);          // the side signal has one bit more
     const unsigned long long first = (unsigned long long)blk * B;
     const uint32_t n = uint32_t(first + B <= C->total_samples ? B : C->total_samples - first);
     const int param_bits = bps > 16 ? 5 : 4, kmax = bps > 16 ? 30 : 14;
 
-    for (uint32_t i = lane; i < n; i += 64) x[i] = load_pcm(pcm + ((first + i) * nch + ch) * bytes_ps, bps);
+    for (uint32_t i = lane; i < n; i += 64) x[i] = load_signal(pcm, first + i, nch, sg, C->bps);
     __syncthreads();
 
     bool differs = false;
@@ -166,8 +177,8 @@ __global__ __launch_bounds__(64) void k_flac_plan(const flac_const* __restrict__
         best.bits = constant ? 8 + bps : 8 + (unsigned long long)n * bps;
     }
     __syncthreads();
-    sub_plan* out = plans + size_t(blk) * nch + ch;
-    int32_t* rout = residuals + (size_t(blk) * nch + ch) * B;
+    sub_plan* out = plans + size_t(blk) * nsig + sg;
+    int32_t* rout = residuals + (size_t(blk) * nsig + sg) * B;
 
     if (!constant) {
         int maxorder = int(C->max_order);
@@ -313,10 +324,20 @@ __global__ __launch_bounds__(64) void k_flac_write(const flac_const* __restrict_
     __shared__ uint16_t T16[256];
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) { uint16_t c = uint16_t(i << 8); for (int k = 0; k < 8; k++) c = uint16_t((c & 0x8000) ? (c << 1) ^ 0x8005 : c << 1); T16[i] = c; }
-    const uint32_t blk = blockIdx.x, B = C->block_size, nch = C->channels, bps = C->bps, bytes_ps = bps / 8;
+    const uint32_t blk = blockIdx.x, B = C->block_size, nch = C->channels, nsig = nch == 2 ? 4u : nch;
     const unsigned long long first = (unsigned long long)blk * B;
     const uint32_t n = uint32_t(first + B <= C->total_samples ? B : C->total_samples - first);
-    const int param_bits = bps > 16 ? 5 : 4;
+    // two channels: the pair of signals with the fewest bits, the plain pair on a tie (the rule oracle/flac_oracle.c states)
+    uint32_t assignment = nch - 1, sig0 = 0, sig1 = 1;
+    if (nch == 2) {
+        const sub_plan* q = plans + size_t(blk) * 4;
+        const unsigned long long lr = q[0].bits + q[1].bits, ls = q[0].bits + q[3].bits, rs = q[3].bits + q[1].bits, ms = q[2].bits + q[3].bits;
+        unsigned long long best = lr; assignment = 1;
+        if (ls < best) { best = ls; assignment = 8; }
+        if (rs < best) { best = rs; assignment = 9; }
+        if (ms < best) { best = ms; assignment = 10; }
+        if (assignment == 8) sig1 = 3; else if (assignment == 9) sig0 = 3; else if (assignment == 10) { sig0 = 2; sig1 = 3; }
+    }
     uint32_t* words = work + size_t(blk) * (C->frame_slot / 4);
     uint8_t* fout = frames + size_t(blk) * C->frame_slot;
 
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(64) void k_flac_write(const flac_const* __restrict_
         const int bsc = blocksize_code(n);
         const int src = C->sample_rate == 44100 ? 9 : C->sample_rate == 48000 ? 10 : C->sample_rate == 96000 ? 11 : 0;
         hdr[h++] = uint8_t((bsc << 4) | src);
-        hdr[h++] = uint8_t(((nch - 1) << 4) | ((bps == 8 ? 1 : bps == 16 ? 4 : 6) << 1));
+        hdr[h++] = uint8_t((assignment << 4) | ((C->bps == 8 ? 1 : C->bps == 16 ? 4 : 6) << 1));
         unsigned long long v = blk;                                 // UTF-8 coded frame number
         if (v < 0x80) hdr[h++] = uint8_t(v);
         else {
@@ -348,10 +369,13 @@ __global__ __launch_bounds__(64) void k_flac_write(const flac_const* __restrict_
     for (int i = lane; i < hlen; i += 64) put_bits(words, (unsigned long long)i * 8, hdr[i], 8);
 
     for (uint32_t ch = 0; ch < nch; ch++) {
-        const sub_plan* sp = plans + size_t(blk) * nch + ch;
-        const int32_t* res = residuals + (size_t(blk) * nch + ch) * B;
+        const uint32_t sg = nch == 2 ? (ch ? sig1 : sig0) : ch;
+        const uint32_t bps = C->bps + (nch == 2 && sg == 3 ? 1u : 0u);
+        const int param_bits = bps > 16 ? 5 : 4;
+        const sub_plan* sp = plans + size_t(blk) * nsig + sg;
+        const int32_t* res = residuals + (size_t(blk) * nsig + sg) * B;
         const int type = sp->type, order = sp->order;
-        auto sample = [&](uint32_t i) { return load_pcm(pcm + ((first + i) * nch + ch) * bytes_ps, bps); };
+        auto sample = [&](uint32_t i) { return load_signal(pcm, first + i, nch, sg, C->bps); };
         if (type == 0) {
             if (lane == 0) { put_bits(words, pos, 0x00, 8); put_bits(words, pos + 8, uint32_t(sample(0)), int(bps)); }
         } else if (type == 1) {
@@ -479,7 +503,8 @@ extern "C" int rcgpu_flac_encode_host(rcgpu_flac* e, const uint8_t* pcm, uint64_
     hipError_t he = hipSuccess;
     const size_t slots = size_t(nblocks) * hc.frame_slot;
 #define DM(p, b) if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&(p)), (b))
-    DM(d_c, sizeof hc); DM(d_pcm, pcm_bytes + 16); DM(d_plans, sizeof(sub_plan) * nblocks * ch); DM(d_res, size_t(nblocks) * ch * B * 4);
+    const uint32_t nsig = ch == 2 ? 4u : ch;              // two channels: left, right, mid, side
+    DM(d_c, sizeof hc); DM(d_pcm, pcm_bytes + 16); DM(d_plans, sizeof(sub_plan) * nblocks * nsig); DM(d_res, size_t(nblocks) * nsig * B * 4);
     DM(d_work, slots + 16); DM(d_frames, slots + 16); DM(d_sizes, nblocks * 4);
 #undef DM
     if (he == hipSuccess) he = hipMemcpy(d_c, &hc, sizeof hc, hipMemcpyHostToDevice);
@@ -489,7 +514,7 @@ extern "C" int rcgpu_flac_encode_host(rcgpu_flac* e, const uint8_t* pcm, uint64_
     const size_t lds = size_t(B) * 4 * 2 + kMaxParts * 8 + size_t(B) * 8 + 2 * kMaxParts;
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(k_flac_plan), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (he == hipSuccess) {
-        hipLaunchKernelGGL(k_flac_plan, dim3(uint32_t(nblocks), ch), dim3(64), lds, 0, d_c, d_pcm, d_plans, d_res);
+        hipLaunchKernelGGL(k_flac_plan, dim3(uint32_t(nblocks), nsig), dim3(64), lds, 0, d_c, d_pcm, d_plans, d_res);
         hipLaunchKernelGGL(k_flac_write, dim3(uint32_t(nblocks)), dim3(64), 0, 0, d_c, d_pcm, d_plans, d_res, d_work, d_frames, d_sizes);
         he = hipGetLastError();
     }

@@ -257,6 +257,16 @@ def pcm_samples(n: int, channels: int, bits: int, rate: int = 48000, kind: str =
         return rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(n, channels)).astype(np.int32)
     t = np.arange(n, dtype=np.float64) / rate
     out = np.empty((n, channels), dtype=np.int32)
+    if kind in ("stereo", "stereo_left", "stereo_right"):
+        # a centre signal in both channels plus a little of something else: what left/side, side/right and mid/side coding are for.
+        # "stereo": both channels busy (mid/side wins); "stereo_left" / "stereo_right": one channel is the clean one (left/side, side/right)
+        centre = 0.3 * np.sin(2 * np.pi * 330.0 * t) + 0.1 * np.sin(2 * np.pi * 1234.5 * t + 0.3) + 0.05 * np.sin(2 * np.pi * 4321.0 * t)
+        wide = 0.004 * np.sin(2 * np.pi * 97.0 * t)
+        for c in range(channels):
+            own = (rng.random(n) - rng.random(n)) * (0.002 if kind == "stereo" or (kind == "stereo_left") == (c != 0) else 0.0)
+            sig = centre + (wide if c % 2 == 0 else -wide) + own + (rng.random(n) - rng.random(n)) / full * 2.0
+            out[:, c] = np.clip(np.round(sig * full), -full - 1, full).astype(np.int32)
+        return out
     for c in range(channels):
         f0 = 220.0 * (1.0 + 0.37 * c)
         sig = 0.25 * np.sin(2 * np.pi * f0 * t) + 0.08 * np.sin(2 * np.pi * 3.01 * f0 * t + c)

@@ -68,6 +68,9 @@ FLAC = [  # name, ch, bits, rate, samples, kind
     ("wav_6ch24_48k", 6, 24, 48000, 6000, "music"),
     ("wav_1ch8_44k", 1, 8, 44100, 5000, "music"),
     ("wav_2ch24_noise", 2, 24, 96000, 9000, "noise"),
+    ("wav_2ch16_midside", 2, 16, 48000, 10000, "stereo"),          # channel assignment 10
+    ("wav_2ch24_leftside", 2, 24, 48000, 7000, "stereo_left"),     # 8: the side subframe is 25 bits wide
+    ("wav_2ch16_sideright", 2, 16, 44100, 6000, "stereo_right"),   # 9
 ]
 
 

@@ -19,6 +19,10 @@ CASES = [
     (2, 16, 44100, 5000, "silence"),
     (1, 16, 48000, 4608 * 2 + 1, "music"),   # last block of one sample
     (2, 16, 48000, 17, "music"),             # shorter than every LPC order
+    (2, 16, 48000, 20000, "stereo"),         # correlated channels: mid/side frames (channel assignment 10)
+    (2, 24, 48000, 14000, "stereo_left"),    # left/side (8): the side signal is 25 bits wide
+    (2, 16, 44100, 9000, "stereo_right"),    # side/right (9)
+    (2, 8, 44100, 9000, "stereo"),
 ]
 
 
@@ -35,6 +39,9 @@ def test_flac_frames_match_oracle(built, ch, bits, rate, n, kind):
         assert a == b, f"frame {i}: device {len(a)} bytes, oracle {len(b)} bytes, first diff at {next((k for k in range(min(len(a), len(b))) if a[k] != b[k]), -1)}"
     assert cp == ocp
     assert ob.flac_decode(ch, rate, bits, b"".join(frames), len(pcm)) == pcm
+    if kind.startswith("stereo") and bits > 8:
+        want = {"stereo": 10, "stereo_left": 8, "stereo_right": 9}[kind]
+        assert [f[3] >> 4 for f in frames[:-1]] == [want] * (len(frames) - 1), [f[3] >> 4 for f in frames]
     enc.close()
 
 
@@ -61,6 +68,9 @@ def test_flac_random_signals_match_oracle(built, seed):
         else:
             sig = 0.3 * np.sin(2 * np.pi * 440 * t); a = int(rng.integers(0, n)); sig[a:a + int(rng.integers(1, 600))] = rng.uniform(-1, 1)
         pcm_i[:, c] = np.clip(np.round(sig * full), -full - 1, full)
+    if ch == 2 and seed % 2:           # a correlated pair: the stereo assignments (left/side, side/right, mid/side) get their turn
+        w = rng.uniform(0.0, 0.2)
+        pcm_i[:, 1] = np.clip(pcm_i[:, 0] * rng.choice([1.0, -1.0, 0.5]) + np.round(w * pcm_i[:, 1]), -full - 1, full)
     wav = synth.wav_file(pcm_i.astype(np.int32), bits, rate)
     info = api.wav_probe(wav)
     pcm = wav[info.data_offset:info.data_offset + info.data_size]
