@@ -449,3 +449,30 @@ def test_linked_reference_checks_in_batches(built, linkedbin, refbin, tmp_path, 
     r = run([linkedbin, "--check", "pkg.mkv"], work, timeout=60)
     assert OK_LINE not in r.stdout and ("Error" in (r.stdout + r.stderr) or r.returncode != 0), r.stdout + r.stderr
     assert "f_000006" in (r.stdout + r.stderr), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("batch", ["3", "256"])
+def test_linked_reference_hashes_the_sources_on_the_device(built, linkedbin, refbin, tmp_path, monkeypatch, batch):
+    """Route D: the analysis loop (CLI/Main.cpp:280-292) announces the files it is about to open (oracle/route_d_main_cpp.patch) and
+    input_base::Hash (Lib/Utils/FileIO/Input_Base.cpp:54-81, oracle/route_d_input_base_cpp.patch) takes their whole-file MD5s from
+    rcgpu_md5_host_batch -- many files side by side on the device -- instead of hashing one after the other on one core.  The
+    reversibility data the patched binary writes (it holds every file's MD5) must be the unmodified reference's, byte for byte; files of
+    different sizes, a batch size that does not divide the sequence, and the reference's own MD5 under RCGPU_HASH=0."""
+    work = str(tmp_path)
+    make_package(work, 80, 48, synth.PIX_RGB16_BE, 11, "film", audio=(2, 16, 48000, 9000))
+    r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = open(os.path.join(work, "pkg.rawcooked_reversibility_data"), "rb").read()
+    os.unlink(os.path.join(work, "pkg.rawcooked_reversibility_data"))
+    for env_hash in ("1", "0"):
+        monkeypatch.setenv("RCGPU_HASH", env_hash)
+        monkeypatch.setenv("RCGPU_HASH_BATCH", batch)
+        r = run([linkedbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = open(os.path.join(work, "pkg.rawcooked_reversibility_data"), "rb").read()
+        os.unlink(os.path.join(work, "pkg.rawcooked_reversibility_data"))
+        assert got == want, f"RCGPU_HASH={env_hash}: the reversibility data differs"
+    # and the whole round trip with device hashes: encode, then check against them
+    monkeypatch.setenv("RCGPU_HASH", "1")
+    r = run([linkedbin, "--no-check-padding", "--check", "--hash", "-y", "pkg"], work, timeout=60)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
