@@ -149,11 +149,14 @@ def cpu_baseline(payloads: list, line_bytes: int, width: int, height: int, gpu_p
                       f"absent here)"}, not bad
 
 
-def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=64):
+def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=256, cpu_frames=48, variants=None):
     """The product-level number of BASELINE config 5: `rawcooked_linked --check` -- the REAL reference with this library linked in
-    (INTEGRATION.md route C: oracle/route_c_*.patch, built by oracle/Makefile.ref) -- on an MKV of this run's packets, with the device
-    decoder taking the frames the demuxer announces in batches (RCGPU_CHECK_BATCH), beside the same binary with RCGPU_CHECK=0 (its own
-    CPU slice pool).  Everything around the decoder is the reference's: demux, reversibility data, MergeIn, MD5 of every rebuilt file."""
+    (INTEGRATION.md route C: oracle/route_c_*.patch, built by oracle/Makefile.ref) -- on an MKV of this run's packets.  The demuxer
+    announces the frames that follow, the device decoder takes them in batches (RCGPU_CHECK_BATCH) and keeps the payloads; frame_writer
+    lets every rebuilt file wait for its batch, and the batch is hashed (MD5) and compared with the files on disk on the device
+    (rcgpu_ffv1_decoder_verify_kept).  Beside it: the same binary with the payloads coming back to the reference's own per-file MD5 and
+    memcmp (RCGPU_CHECK_DEFER=0), and with its own CPU slice pool (RCGPU_CHECK=0; a shorter MKV of the same packets, it is a steady
+    per-frame rate).  Everything else is the reference's: demux, reversibility data, MergeIn, the verdict."""
     import shutil
     import subprocess
     import tempfile
@@ -163,41 +166,65 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     work = tempfile.mkdtemp(prefix="rcgpu_linked_", dir=base)
     try:
-        os.makedirs(os.path.join(work, "seq"))
-        n = min(nframes, len(sizes))
-        for i in range(n):
-            with open(os.path.join(work, "seq", "f_%06d.dpx" % i), "wb") as f:
-                f.write(synth.dpx_file(None, pixfmt, frame_index=i, payload=bytes(frames[i].cpu().numpy()), size=(width, height)))
-        def run(cmd, env=None, timeout=90):      # the reference occasionally dead-locks in its own analysis thread pool on many-core hosts: bounded, retried
+        F = len(sizes)
+        n = max(1, nframes)
+        m = min(n, max(1, cpu_frames))
+
+        def run(cmd, cwd, env=None, timeout=90):      # the reference occasionally dead-locks in its own analysis thread pool on many-core hosts: bounded, retried
             for attempt in range(3):
                 try:
                     t0 = time.perf_counter()
-                    r_ = subprocess.run(cmd, cwd=work, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=timeout, env=env)
+                    r_ = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=timeout, env=env)
                     r_.seconds = time.perf_counter() - t0
                     return r_
                 except subprocess.TimeoutExpired:
                     if attempt == 2:
                         raise
-        r = run([exe, "--hash", "--no-check-padding", "-d", "-y", "seq"], timeout=60)      # analysis only: the reversibility data with the MD5 of every file
-        if r.returncode != 0:
-            return {"error": "analysis failed: " + (r.stderr or r.stdout)[-200:]}
-        mux = api.MkvMuxer(os.path.join(work, "seq.mkv"))
-        t = mux.add_video(record, width, height, 24, 1)
-        mux.add_attachment("RAWcooked reversibility data", open(os.path.join(work, "seq.rawcooked_reversibility_data"), "rb").read())
-        mux.begin()
-        for i in range(n):
-            mux.write_block(t, i * 1000000000 // 24, bytes(d_packets[i * stride:i * stride + sizes[i]].cpu().numpy()))
-        mux.close()
-        out = {"frames": n, "unit": "frames/s"}
-        for name, env in (("device_decoder", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": str(n)}), ("reference_cpu_pool", {"RCGPU_CHECK": "0"})):
-            r = run([exe, "--check", "seq.mkv"], env=dict(os.environ, **env), timeout=120)
-            dt = r.seconds
-            ok = r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout
-            out[name] = {"value": round(n / dt, 2), "seconds": round(dt, 2), "verdict": "Reversibility was checked, no issue detected." if ok else (r.stdout + r.stderr)[-200:]}
-        if out["reference_cpu_pool"]["value"]:
+
+        def package(name, count):
+            d = os.path.join(work, name)
+            os.makedirs(os.path.join(d, "seq"))
+            host = {}
+            for i in range(count):
+                k = i % F
+                if k not in host:
+                    host[k] = (bytes(frames[k].cpu().numpy()), bytes(d_packets[k * stride:k * stride + sizes[k]].cpu().numpy()))
+                with open(os.path.join(d, "seq", "f_%06d.dpx" % i), "wb") as f:
+                    f.write(synth.dpx_file(None, pixfmt, frame_index=i, payload=host[k][0], size=(width, height)))
+            r = run([exe, "--hash", "--no-check-padding", "-d", "-y", "seq"], d, timeout=120)      # analysis only: the reversibility data with the MD5 of every file (route D)
+            if r.returncode != 0:
+                raise RuntimeError("analysis failed: " + (r.stderr or r.stdout)[-200:])
+            mux = api.MkvMuxer(os.path.join(d, "seq.mkv"))
+            t = mux.add_video(record, width, height, 24, 1)
+            mux.add_attachment("RAWcooked reversibility data", open(os.path.join(d, "seq.rawcooked_reversibility_data"), "rb").read())
+            mux.begin()
+            for i in range(count):
+                mux.write_block(t, i * 1000000000 // 24, host[i % F][1])
+            mux.close()
+            return d, r.seconds
+        big, analysis_s = package("big", n)
+        small = big if m == n else package("small", m)[0]
+        out = {"frames": n, "unit": "frames/s", "analysis_seconds": round(analysis_s, 2)}
+        OKL = "Reversibility was checked, no issue detected."
+        # `--check x.mkv` judges by the MD5s in the reversibility data; with `-o .` the rebuilt files are also compared with the sources on disk
+        todo = (("device_decoder", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": str(n)}, big, n, []),
+                ("device_decoder_and_sources", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": str(n)}, big, n, ["-o", "."]),
+                ("device_decoder_payloads_to_host", {"RCGPU_CHECK": "1", "RCGPU_CHECK_DEFER": "0", "RCGPU_CHECK_BATCH": "128"}, small, m, []),
+                ("reference_cpu_pool", {"RCGPU_CHECK": "0"}, small, m, []),
+                ("reference_cpu_pool_and_sources", {"RCGPU_CHECK": "0"}, small, m, ["-o", "."]))
+        for name, env, d, count, extra in todo:
+            if (variants and name not in variants) or (not variants and name == "reference_cpu_pool_and_sources"):
+                continue
+            r = run([exe, "--check", "seq.mkv"] + extra, d, env=dict(os.environ, **env), timeout=180)
+            ok = r.returncode == 0 and OKL in r.stdout
+            out[name] = {"value": round(count / r.seconds, 2), "frames": count, "seconds": round(r.seconds, 2), "verdict": OKL if ok else (r.stdout + r.stderr)[-200:]}
+            if os.environ.get("RCGPU_TRACE_KEPT"):
+                out[name]["trace"] = [ln for ln in r.stderr.split("\n") if ln.startswith("rcgpu kept:")]
+        if out.get("reference_cpu_pool", {}).get("value") and "device_decoder" in out:
             out["speedup"] = round(out["device_decoder"]["value"] / out["reference_cpu_pool"]["value"], 2)
-        out["what"] = (f"oracle/_ref/rawcooked_linked --check on an MKV of {n} of this run's {width}x{height} packets (tmpfs): process start to exit, the reference's own demuxer, MergeIn and "
-                       f"MD5 of every rebuilt file (one core, ~0.6 GB/s: ~12 frames/s at 4K whatever decodes) around the decoder; {usable_cores()} usable cores")
+        out["what"] = (f"oracle/_ref/rawcooked_linked --check on an MKV of {n} {width}x{height} frames (this run's packets, tmpfs), process start to exit: the reference's own demuxer, "
+                       f"reversibility data and verdict around the device decoder, the files hashed and compared with the sources on the device a batch at a time; "
+                       f"reference_cpu_pool = the same binary with RCGPU_CHECK=0 on {m} of the frames; {usable_cores()} usable cores")
         return out
     except Exception as e:
         return {"error": str(e)[-300:]}

@@ -270,6 +270,31 @@ int  rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* dec, const void* const
  * Synchronous; returns an error if any slice of the batch is undecodable. */
 int  rcgpu_ffv1_decoder_decode_host(rcgpu_ffv1_decoder* dec, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n,
                                     uint8_t* const* payloads);
+/* `--check` with nothing but verdicts coming back.  frame_writer::FrameCall (FileWriter.cpp:73-300) receives every rebuilt file on the
+ * host, hashes it (CheckMD5, :596-727, one core) and compares it with the file on disk (CheckFile / CheckFile_Compare, :448-463,
+ * :464-594).  These three calls keep the decoded payloads on the device and do both there, for a whole batch of files at once:
+ *   decode_keep   decodes n (<= max_batch) packets held by the host (the Matroska blocks); payload i stays on the device as slot i
+ *                 until the next decode_keep / decode_host of this decoder;
+ *   kept_to_host  one kept payload after all (a caller that has `InData` to merge, RawFrame.cpp:184-206, or a file to write);
+ *   verify_kept   for n files, each = `before` + the payload of `slot` + `after` (raw_frame's Pre / plane / Post): its MD5 when
+ *                 RCGPU_KEPT_MD5 is set, and, when `on_disk` is not NULL, the offset of the first byte at which it differs from the
+ *                 on_disk_size bytes at on_disk (e.g. the mapped source file): UINT64_MAX when they are the same, the shorter length when
+ *                 one is the beginning of the other.  `before` and `after` are at most RCGPU_KEPT_ROOM bytes each. */
+#define RCGPU_KEPT_MD5  1u
+#define RCGPU_KEPT_ROOM 65536u
+typedef struct rcgpu_kept_file {
+    uint32_t slot, flags;
+    const uint8_t* before;  uint64_t before_size;
+    const uint8_t* after;   uint64_t after_size;
+    const uint8_t* on_disk; uint64_t on_disk_size;
+} rcgpu_kept_file;
+typedef struct rcgpu_kept_verdict {
+    uint8_t  md5[16];
+    uint64_t first_diff;
+} rcgpu_kept_verdict;
+int  rcgpu_ffv1_decoder_decode_keep(rcgpu_ffv1_decoder* dec, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n);
+int  rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* dec, uint32_t slot, uint8_t* payload);
+int  rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* dec, const rcgpu_kept_file* files, uint32_t n, rcgpu_kept_verdict* verdicts);
 /* Fill the stream-dependent fields of `cfg` (num_h_slices, num_v_slices, slicecrc, context, coder) from a Matroska CodecPrivate =
  * FFV1 configuration record, the way parameters::Parse reads it (FFV1_Parameters.cpp:23-183); width, height, pixfmt, line_bytes
  * and flags describe the files and are the caller's (they come from the reversibility data / the probes).  Fails when the record

@@ -118,6 +118,9 @@ SYMBOLS = {
     "rcgpu_ffv1_decoder_decode_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP), C.POINTER(C.c_uint32), _VP]),
     "rcgpu_md5_host_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _U8P, C.c_int]),
     "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
+    "rcgpu_ffv1_decoder_decode_keep": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32]),
+    "rcgpu_ffv1_decoder_kept_to_host": (C.c_int, [_VP, C.c_uint32, _VP]),
+    "rcgpu_ffv1_decoder_verify_kept": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
     "rcgpu_ffv1_config_from_record": (C.c_int, [_U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_config_from_stream": (C.c_int, [_U8P, _SZ, _U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
@@ -329,6 +332,17 @@ def encode_sequence_memory(cfg: Ffv1Config, frame_addrs: list[int], n_frames: in
     return st, list(sizes)
 
 
+class KeptFile(C.Structure):
+    """rcgpu_kept_file (include/rcgpu.h)."""
+    _fields_ = [("slot", C.c_uint32), ("flags", C.c_uint32), ("before", C.c_void_p), ("before_size", C.c_uint64),
+                ("after", C.c_void_p), ("after_size", C.c_uint64), ("on_disk", C.c_void_p), ("on_disk_size", C.c_uint64)]
+
+
+class KeptVerdict(C.Structure):
+    """rcgpu_kept_verdict (include/rcgpu.h)."""
+    _fields_ = [("md5", C.c_uint8 * 16), ("first_diff", C.c_uint64)]
+
+
 class Ffv1Decoder:
     """Device FFV1 decoder + pack (the --check half).  Buffers are device pointers (ints)."""
 
@@ -362,6 +376,40 @@ class Ffv1Decoder:
         op = (_VP * n)(*[C.cast(o, _VP) for o in outs])
         _check(lib().rcgpu_ffv1_decoder_decode_host(self.h, pk, sz, n, op), "rcgpu_ffv1_decoder_decode_host")
         return [o.raw for o in outs]
+
+    def decode_keep(self, packets: list[bytes]) -> None:
+        """Decodes the packets; payload i stays on the device as slot i (rcgpu_ffv1_decoder_decode_keep)."""
+        n = len(packets)
+        keep = [C.create_string_buffer(p, len(p)) for p in packets]
+        pk = (_VP * n)(*[C.cast(k, _VP) for k in keep])
+        sz = (C.c_uint64 * n)(*[len(p) for p in packets])
+        _check(lib().rcgpu_ffv1_decoder_decode_keep(self.h, pk, sz, n), "rcgpu_ffv1_decoder_decode_keep")
+
+    def kept_to_host(self, slot: int, payload_bytes: int) -> bytes:
+        out = C.create_string_buffer(payload_bytes)
+        _check(lib().rcgpu_ffv1_decoder_kept_to_host(self.h, slot, out), "rcgpu_ffv1_decoder_kept_to_host")
+        return out.raw
+
+    def verify_kept(self, files: list[dict]) -> list[tuple[bytes, int]]:
+        """files: dicts with slot, before, after (bytes), on_disk (bytes or None), md5 (bool) -> per file (md5, first differing offset or -1):
+        frame_writer's CheckMD5 and CheckFile (FileWriter.cpp:464-727) for a batch of rebuilt files, on the device."""
+        n = len(files)
+        arr = (KeptFile * n)()
+        keep = []
+        for i, f in enumerate(files):
+            arr[i].slot = f["slot"]
+            arr[i].flags = 1 if f.get("md5", True) else 0
+            for name in ("before", "after", "on_disk"):
+                v = f.get(name)
+                if v is None:
+                    continue
+                b = C.create_string_buffer(bytes(v), len(v)) if len(v) else C.create_string_buffer(1)
+                keep.append(b)
+                setattr(arr[i], name, C.cast(b, _VP))
+                setattr(arr[i], name + "_size", len(v))
+        out = (KeptVerdict * n)()
+        _check(lib().rcgpu_ffv1_decoder_verify_kept(self.h, arr, n, out), "rcgpu_ffv1_decoder_verify_kept")
+        return [(bytes(bytearray(o.md5)), -1 if o.first_diff == 0xFFFFFFFFFFFFFFFF else o.first_diff) for o in out]
 
     def kernel_times(self) -> dict[str, float]:
         ms = (C.c_float * 3)()

@@ -19,6 +19,12 @@
 //   k_md5         LANE   / buffer   RFC 1321, one buffer per lane
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
 #include <vector>
 #include "ffv1_host.h"
 #include "rc_common.h"
@@ -425,10 +431,11 @@ __global__ __launch_bounds__(256) void k_compare_batch(const uint8_t* const* __r
     if (best != ~0ull) atomicMin(&first_diff[blockIdx.y], best);
 }
 
-// RFC 1321, one buffer per lane (the hash is serial per buffer; many buffers are in flight)
-__device__ __forceinline__ uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
-__global__ __launch_bounds__(64) void k_md5(const uint8_t* const* __restrict__ bufs, const unsigned long long* __restrict__ sizes, uint32_t n,
-                                            uint8_t* __restrict__ out)
+// RFC 1321, one buffer per lane (the hash is serial per buffer; many buffers are in flight).  A lane's chain is 64 steps of four
+// dependent instructions per 64-byte block and nothing else shares its wavefront's issue slot, so what the kernel can hide is the
+// latency of the block's own load: the next block is fetched while this one is hashed.
+__device__ __forceinline__ uint32_t rol(uint32_t x, int s) { return __builtin_amdgcn_alignbit(x, x, 32 - s); }
+__device__ __forceinline__ void md5_block(const uint32_t (&m)[16], uint32_t& h0, uint32_t& h1, uint32_t& h2, uint32_t& h3)
 {
     const uint32_t K[64] = {
         0xd76aa478,0xe8c7b756,0x242070db,0xc1bdceee,0xf57c0faf,0x4787c62a,0xa8304613,0xfd469501,0x698098d8,0x8b44f7af,0xffff5bb1,0x895cd7be,0x6b901122,0xfd987193,0xa679438e,0x49b40821,
@@ -436,42 +443,78 @@ __global__ __launch_bounds__(64) void k_md5(const uint8_t* const* __restrict__ b
         0xfffa3942,0x8771f681,0x6d9d6122,0xfde5380c,0xa4beea44,0x4bdecfa9,0xf6bb4b60,0xbebfbc70,0x289b7ec6,0xeaa127fa,0xd4ef3085,0x04881d05,0xd9d4d039,0xe6db99e5,0x1fa27cf8,0xc4ac5665,
         0xf4292244,0x432aff97,0xab9423a7,0xfc93a039,0x655b59c3,0x8f0ccc92,0xffeff47d,0x85845dd1,0x6fa87e4f,0xfe2ce6e0,0xa3014314,0x4e0811a1,0xf7537e82,0xbd3af235,0x2ad7d2bb,0xeb86d391 };
     const int S[16] = { 7, 12, 17, 22, 5, 9, 14, 20, 4, 11, 16, 23, 6, 10, 15, 21 };
+    uint32_t a = h0, b = h1, c = h2, d = h3;
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        uint32_t fn; int g;
+        if (r < 16) { fn = (b & c) | (~b & d); g = r; }
+        else if (r < 32) { fn = (d & b) | (~d & c); g = (5 * r + 1) & 15; }
+        else if (r < 48) { fn = b ^ c ^ d; g = (3 * r + 5) & 15; }
+        else { fn = c ^ (b | ~d); g = (7 * r) & 15; }
+        const uint32_t t = d; d = c; c = b; b = b + rol(a + fn + (K[r] + m[g]), S[(r >> 4) * 4 + (r & 3)]); a = t;
+    }
+    h0 += a; h1 += b; h2 += c; h3 += d;
+}
+// MODE 0: 16-byte aligned, 1: 4-byte aligned, 2: any address -- aligned words, funnel-shifted by `sh` bits (reads the word after the block)
+template <int MODE> __device__ __forceinline__ void md5_load(uint32_t (&m)[16], const uint8_t* p, uint32_t sh)
+{
+    if (MODE == 0) {
+        const uint4* w = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint4 v = w[k]; m[4 * k] = v.x; m[4 * k + 1] = v.y; m[4 * k + 2] = v.z; m[4 * k + 3] = v.w; }
+    } else if (MODE == 1) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+        for (int k = 0; k < 16; k++) m[k] = w[k];
+    } else {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+        uint32_t lo = w[0];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const uint32_t hi = w[k + 1]; m[k] = __builtin_amdgcn_alignbit(hi, lo, sh); lo = hi; }
+    }
+}
+template <int MODE> __device__ __forceinline__ void md5_whole_blocks(const uint8_t* p, uint32_t sh, unsigned long long nblk, uint32_t& h0, uint32_t& h1, uint32_t& h2, uint32_t& h3)
+{
+    uint32_t m[16], x[16];
+    if (nblk) md5_load<MODE>(m, p, sh);
+    unsigned long long k = 0;
+    for (; k + 2 <= nblk; k += 2) {                             // m holds block k
+        md5_load<MODE>(x, p + (k + 1) * 64, sh);
+        md5_block(m, h0, h1, h2, h3);
+        if (k + 2 < nblk) md5_load<MODE>(m, p + (k + 2) * 64, sh);
+        md5_block(x, h0, h1, h2, h3);
+    }
+    if (k < nblk) md5_block(m, h0, h1, h2, h3);
+}
+__global__ __launch_bounds__(64) void k_md5(const uint8_t* const* __restrict__ bufs, const unsigned long long* __restrict__ sizes, uint32_t n,
+                                            uint8_t* __restrict__ out)
+{
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const uint8_t* p = bufs[i];
     const unsigned long long size = sizes[i];
     uint32_t h0 = 0x67452301, h1 = 0xefcdab89, h2 = 0x98badcfe, h3 = 0x10325476;
     const unsigned long long total = ((size + 8) / 64 + 1) * 64;
-    for (unsigned long long off = 0; off < total; off += 64) {
+    const uintptr_t mis = reinterpret_cast<uintptr_t>(p) & 15;
+    // blocks that are read as words; the rest, and the padding, byte by byte
+    const unsigned long long whole = (mis & 3) ? (size >= 68 ? (size - 4) / 64 : 0) : size / 64;
+    if (mis == 0) md5_whole_blocks<0>(p, 0, whole, h0, h1, h2, h3);
+    else if (!(mis & 3)) md5_whole_blocks<1>(p, 0, whole, h0, h1, h2, h3);
+    else md5_whole_blocks<2>(p - (mis & 3), uint32_t(mis & 3) * 8, whole, h0, h1, h2, h3);
+    for (unsigned long long off = whole * 64; off < total; off += 64) {
         uint32_t m[16];
-        if (off + 64 <= size && !(reinterpret_cast<uintptr_t>(p) & 3)) {
-            const uint32_t* w = reinterpret_cast<const uint32_t*>(p + off);
 #pragma unroll
-            for (int k = 0; k < 16; k++) m[k] = w[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                uint32_t v = 0;
-                for (int b = 0; b < 4; b++) {
-                    const unsigned long long q = off + 4 * k + b;
-                    uint32_t byte = q < size ? p[q] : (q == size ? 0x80u : 0u);
-                    if (off + 64 == total && 4 * k + b >= 56) byte = uint32_t(((size * 8) >> (8 * (4 * k + b - 56))) & 0xFF);
-                    v |= byte << (8 * b);
-                }
-                m[k] = v;
+        for (int k = 0; k < 16; k++) {
+            uint32_t v = 0;
+            for (int b = 0; b < 4; b++) {
+                const unsigned long long q = off + 4 * k + b;
+                uint32_t byte = q < size ? p[q] : (q == size ? 0x80u : 0u);
+                if (off + 64 == total && 4 * k + b >= 56) byte = uint32_t(((size * 8) >> (8 * (4 * k + b - 56))) & 0xFF);
+                v |= byte << (8 * b);
             }
+            m[k] = v;
         }
-        uint32_t a = h0, b = h1, c = h2, d = h3;
-#pragma unroll
-        for (int r = 0; r < 64; r++) {
-            uint32_t fn; int g;
-            if (r < 16) { fn = (b & c) | (~b & d); g = r; }
-            else if (r < 32) { fn = (d & b) | (~d & c); g = (5 * r + 1) & 15; }
-            else if (r < 48) { fn = b ^ c ^ d; g = (3 * r + 5) & 15; }
-            else { fn = c ^ (b | ~d); g = (7 * r) & 15; }
-            const uint32_t t = d; d = c; c = b; b = b + rol(a + fn + K[r] + m[g], S[(r >> 4) * 4 + (r & 3)]); a = t;
-        }
-        h0 += a; h1 += b; h2 += c; h3 += d;
+        md5_block(m, h0, h1, h2, h3);
     }
     const uint32_t hh[4] = { h0, h1, h2, h3 };
     for (int k = 0; k < 16; k++) out[size_t(i) * 16 + k] = uint8_t(hh[k / 4] >> (8 * (k % 4)));
@@ -494,6 +537,15 @@ struct rcgpu_ffv1_decoder {
     hipStream_t own_stream = nullptr;
     hipEvent_t ev[8]{};
     bool ev_valid = false;
+    // the payloads of the last decode_keep: slot i = d_kept + i * kept_stride, [room | payload | room] so that the bytes a file has
+    // before and after its payload can be put next to it and the file hashed as one buffer
+    uint8_t* d_kept_in = nullptr; size_t kept_in_cap = 0;
+    uint8_t* d_kept = nullptr; size_t kept_cap = 0, kept_stride = 0; uint32_t kept_n = 0;
+    uint8_t* d_disk = nullptr; size_t disk_cap = 0;
+    hipStream_t side_stream = nullptr; hipEvent_t ev_tab = nullptr;
+    uint64_t* h_tab = nullptr; uint64_t* d_tab = nullptr; uint32_t tab_cap = 0;
+    static constexpr unsigned kLanes = 8; static constexpr size_t kStage = size_t(8) << 20;
+    struct lane { hipStream_t st = nullptr; uint8_t* stage[2] = { nullptr, nullptr }; hipEvent_t ev[2] = { nullptr, nullptr }; } lanes[kLanes];
 };
 
 extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
@@ -506,6 +558,16 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     if (d->h_sizes) (void)hipHostFree(d->h_sizes);
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+    for (void* b : { (void*)d->d_kept_in, (void*)d->d_kept, (void*)d->d_disk }) if (b) (void)hipFree(b);
+    if (d->side_stream) (void)hipStreamDestroy(d->side_stream);
+    if (d->ev_tab) (void)hipEventDestroy(d->ev_tab);
+    if (d->h_tab) (void)hipHostFree(d->h_tab);
+    if (d->d_tab) (void)hipFree(d->d_tab);
+    for (auto& l : d->lanes) {
+        for (auto& p : l.stage) if (p) (void)hipHostFree(p);
+        for (auto& e : l.ev) if (e) (void)hipEventDestroy(e);
+        if (l.st) (void)hipStreamDestroy(l.st);
+    }
     delete d;
 }
 
@@ -657,6 +719,229 @@ extern "C" int rcgpu_ffv1_decoder_decode_host(rcgpu_ffv1_decoder* d, const uint8
     if (d_out) (void)hipFree(d_out);
     if (he != hipSuccess) return fail(100, "ffv1 decoder: %s", hipGetErrorString(he));
     return rc;
+}
+
+// ---- `--check` with the payloads staying on the device (rcgpu.h: decode_keep / kept_to_host / verify_kept)
+namespace {
+
+struct up_item { uint8_t* dst; const uint8_t* src; size_t size; };
+
+// Host memory that is not pinned -- the mapped MKV, the mapped source files -- goes up through pinned staging buffers, several threads
+// side by side: one thread is bound by the page faults of the mapping and by its own copy into the staging buffer.
+hipError_t upload_side_by_side(rcgpu_ffv1_decoder* d, const std::vector<up_item>& items)
+{
+    std::vector<up_item> chunks;
+    for (const up_item& it : items)
+        for (size_t o = 0; o < it.size; o += rcgpu_ffv1_decoder::kStage)
+            chunks.push_back({ it.dst + o, it.src + o, std::min(rcgpu_ffv1_decoder::kStage, it.size - o) });
+    if (chunks.empty()) return hipSuccess;
+    unsigned nt = rcgpu_ffv1_decoder::kLanes;
+    if (const char* e = getenv("RCGPU_UPLOAD_THREADS")) nt = unsigned(std::max(1, std::min(int(rcgpu_ffv1_decoder::kLanes), atoi(e))));
+    nt = unsigned(std::min<size_t>(nt, chunks.size()));
+    for (unsigned t = 0; t < nt; t++) {
+        auto& l = d->lanes[t];
+        hipError_t he = hipSuccess;
+        if (!l.st) he = hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && he == hipSuccess; k++) {
+            if (!l.stage[k]) he = hipHostMalloc(reinterpret_cast<void**>(&l.stage[k]), rcgpu_ffv1_decoder::kStage);
+            if (he == hipSuccess && !l.ev[k]) he = hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming);
+        }
+        if (he != hipSuccess) return he;
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{int(hipSuccess)};
+    auto work = [&](unsigned t) {
+        auto& l = d->lanes[t];
+        hipError_t he = hipSetDevice(d->cfg.device);
+        bool used[2] = { false, false };
+        for (int k = 0; he == hipSuccess; k ^= 1) {
+            const size_t i = next.fetch_add(1);
+            if (i >= chunks.size()) break;
+            if (used[k]) he = hipEventSynchronize(l.ev[k]);
+            if (he != hipSuccess) break;
+            memcpy(l.stage[k], chunks[i].src, chunks[i].size);
+            he = hipMemcpyAsync(chunks[i].dst, l.stage[k], chunks[i].size, hipMemcpyHostToDevice, l.st);
+            if (he == hipSuccess) he = hipEventRecord(l.ev[k], l.st);
+            used[k] = true;
+        }
+        const hipError_t hs = hipStreamSynchronize(l.st);
+        if (he == hipSuccess) he = hs;
+        if (he != hipSuccess) err.store(int(he));
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    return hipError_t(err.load());
+}
+
+// RCGPU_TRACE_KEPT=1: where the time of a batch goes, on stderr
+struct kept_clock {
+    const bool on = getenv("RCGPU_TRACE_KEPT") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what, uint32_t n) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "rcgpu kept: %-28s %4u files %8.1f ms\n", what, n, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
+hipError_t grow(uint8_t*& p, size_t& cap, size_t need)
+{
+    if (need <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const hipError_t he = hipMalloc(reinterpret_cast<void**>(&p), need);
+    if (he == hipSuccess) cap = need;
+    return he;
+}
+
+}  // namespace
+
+extern "C" int rcgpu_ffv1_decoder_decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n)
+{
+    clear_error();
+    if (!d || !packets || !packet_sizes) return fail(1, "ffv1 decoder: null argument");
+    if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    d->kept_n = 0;
+    const size_t out_bytes = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
+    d->kept_stride = (size_t(RCGPU_KEPT_ROOM) * 2 + out_bytes + 255) & ~size_t(255);
+    uint64_t in_total = 0;
+    for (uint32_t i = 0; i < n; i++) in_total += (packet_sizes[i] + 255) & ~uint64_t(255);
+    kept_clock clk;
+    HIP_TRY(grow(d->d_kept_in, d->kept_in_cap, size_t(in_total) + 256));
+    HIP_TRY(grow(d->d_kept, d->kept_cap, d->kept_stride * n));
+    clk.lap("decode_keep: device buffers", n);
+    std::vector<up_item> up(n);
+    std::vector<const void*> pk(n); std::vector<void*> out(n);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        up[i] = { d->d_kept_in + off, packets[i], size_t(packet_sizes[i]) };
+        pk[i] = d->d_kept_in + off; out[i] = d->d_kept + size_t(i) * d->kept_stride + RCGPU_KEPT_ROOM;
+        off += (packet_sizes[i] + 255) & ~uint64_t(255);
+    }
+    HIP_TRY(upload_side_by_side(d, up));
+    clk.lap("decode_keep: packets up", n);
+    uint32_t flags = 0;
+    const int rc = rcgpu_ffv1_decoder_decode_device(d, pk.data(), packet_sizes, n, out.data(), &flags, d->own_stream);
+    clk.lap("decode_keep: decoded", n);
+    if (!rc) d->kept_n = n;
+    return rc;
+}
+
+extern "C" int rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* d, uint32_t slot, uint8_t* payload)
+{
+    clear_error();
+    if (!d || !payload) return fail(1, "ffv1 decoder: null argument");
+    if (slot >= d->kept_n) return fail(2, "ffv1 decoder: slot %u of %u kept payloads", slot, d->kept_n);
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    const size_t out_bytes = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
+    HIP_TRY(hipMemcpy(payload, d->d_kept + size_t(slot) * d->kept_stride + RCGPU_KEPT_ROOM, out_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* d, const rcgpu_kept_file* files, uint32_t n, rcgpu_kept_verdict* verdicts)
+{
+    clear_error();
+    if (!d || !files || !verdicts || !n) return fail(1, "ffv1 decoder: null argument");
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    const size_t P = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
+    const size_t disk_stride = (P + 255) & ~size_t(255);
+    uint32_t n_md5 = 0, n_cmp = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const rcgpu_kept_file& f = files[i];
+        if (f.slot >= d->kept_n) return fail(2, "ffv1 decoder: slot %u of %u kept payloads", f.slot, d->kept_n);
+        if (f.before_size > RCGPU_KEPT_ROOM || f.after_size > RCGPU_KEPT_ROOM || (f.before_size && !f.before) || (f.after_size && !f.after))
+            return fail(2, "ffv1 decoder: %llu bytes before and %llu after the payload (at most %u each)", (unsigned long long)f.before_size, (unsigned long long)f.after_size, RCGPU_KEPT_ROOM);
+        for (uint32_t j = 0; j < i; j++) if (files[j].slot == f.slot) return fail(2, "ffv1 decoder: slot %u named twice", f.slot);
+        n_md5 += (f.flags & RCGPU_KEPT_MD5) != 0; n_cmp += f.on_disk != nullptr;
+        memset(verdicts[i].md5, 0, 16); verdicts[i].first_diff = ~uint64_t(0);
+    }
+    if (!d->side_stream) HIP_TRY(hipStreamCreateWithFlags(&d->side_stream, hipStreamNonBlocking));
+    if (!d->ev_tab) HIP_TRY(hipEventCreateWithFlags(&d->ev_tab, hipEventDisableTiming));
+    kept_clock clk;
+    // the tables of both kernels -- pointers, lengths, results -- in one pinned block and its mirror on the device, 8 words per file:
+    // [image, image bytes, payload, file's bytes, bytes to compare, first difference, md5 (2 words)] x n, array after array
+    if (d->tab_cap < n) {
+        if (d->h_tab) (void)hipHostFree(d->h_tab);
+        if (d->d_tab) (void)hipFree(d->d_tab);
+        d->h_tab = nullptr; d->d_tab = nullptr; d->tab_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_tab), size_t(n) * 64));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_tab), size_t(n) * 64));
+        d->tab_cap = n;
+    }
+    uint64_t* h = d->h_tab; uint64_t* g = d->d_tab;
+    std::vector<uint32_t> img_of, cmp_of;
+    hipError_t he = hipSuccess;
+    // 1. the hashes: the bytes around the payload go next to it, one lane hashes one file; this runs beside everything below
+    for (uint32_t i = 0; i < n && he == hipSuccess; i++) {
+        const rcgpu_kept_file& f = files[i];
+        if (!(f.flags & RCGPU_KEPT_MD5)) continue;
+        uint8_t* pay = d->d_kept + size_t(f.slot) * d->kept_stride + RCGPU_KEPT_ROOM;
+        if (f.before_size) he = hipMemcpyAsync(pay - f.before_size, f.before, f.before_size, hipMemcpyHostToDevice, d->own_stream);
+        if (f.after_size && he == hipSuccess) he = hipMemcpyAsync(pay + P, f.after, f.after_size, hipMemcpyHostToDevice, d->own_stream);
+        h[img_of.size()] = reinterpret_cast<uintptr_t>(pay - f.before_size); h[n + img_of.size()] = f.before_size + P + f.after_size;
+        img_of.push_back(i);
+    }
+    // 2. the comparison (CheckFile_Compare over Pre, plane, Post, FileWriter.cpp:448-463,581-589, then the length, :200): the bytes
+    // around the payload are compared here, the payload with the file's bytes on the device
+    std::vector<up_item> up;
+    if (n_cmp && he == hipSuccess) he = grow(d->d_disk, d->disk_cap, disk_stride * n_cmp);
+    for (uint32_t i = 0; i < n && he == hipSuccess; i++) {
+        const rcgpu_kept_file& f = files[i];
+        if (!f.on_disk) continue;
+        const uint64_t have = f.on_disk_size > f.before_size ? std::min<uint64_t>(f.on_disk_size - f.before_size, P) : 0;
+        uint8_t* dst = d->d_disk + cmp_of.size() * disk_stride;
+        if (have) up.push_back({ dst, f.on_disk + f.before_size, size_t(have) });
+        const size_t k = cmp_of.size();
+        h[2 * n + k] = reinterpret_cast<uintptr_t>(d->d_kept + size_t(f.slot) * d->kept_stride + RCGPU_KEPT_ROOM); h[3 * n + k] = reinterpret_cast<uintptr_t>(dst);
+        h[4 * n + k] = have; h[5 * n + k] = ~uint64_t(0);
+        cmp_of.push_back(i);
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(g, h, size_t(n) * 48, hipMemcpyHostToDevice, d->own_stream);
+    if (he == hipSuccess) he = hipEventRecord(d->ev_tab, d->own_stream);
+    if (n_md5 && he == hipSuccess) {
+        hipLaunchKernelGGL(k_md5, dim3((n_md5 + 63) / 64), dim3(64), 0, d->own_stream, reinterpret_cast<const uint8_t* const*>(g), reinterpret_cast<const unsigned long long*>(g + n), n_md5,
+                           reinterpret_cast<uint8_t*>(g + 6 * size_t(n)));
+        he = hipGetLastError();
+        if (he == hipSuccess) he = hipMemcpyAsync(h + 6 * size_t(n), g + 6 * size_t(n), size_t(n_md5) * 16, hipMemcpyDeviceToHost, d->own_stream);
+    }
+    clk.lap("verify_kept: md5 launched", n_md5);
+    if (n_cmp && he == hipSuccess) {
+        he = upload_side_by_side(d, up);
+        clk.lap("verify_kept: files up", n_cmp);
+        if (he == hipSuccess) he = hipStreamWaitEvent(d->side_stream, d->ev_tab, 0);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_compare_batch, dim3(64, n_cmp), dim3(256), 0, d->side_stream, reinterpret_cast<const uint8_t* const*>(g + 2 * size_t(n)), reinterpret_cast<const uint8_t* const*>(g + 3 * size_t(n)),
+                               reinterpret_cast<const unsigned long long*>(g + 4 * size_t(n)), reinterpret_cast<unsigned long long*>(g + 5 * size_t(n)));
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipMemcpyAsync(h + 5 * size_t(n), g + 5 * size_t(n), size_t(n_cmp) * 8, hipMemcpyDeviceToHost, d->side_stream);
+        const hipError_t hs = hipStreamSynchronize(d->side_stream);
+        if (he == hipSuccess) he = hs;
+    }
+    clk.lap("verify_kept: compared", n_cmp);
+    const hipError_t hs = hipStreamSynchronize(d->own_stream);
+    if (he == hipSuccess) he = hs;
+    clk.lap("verify_kept: md5 done", n_md5);
+    if (he != hipSuccess) return fail(100, "ffv1 decoder: verify: %s", hipGetErrorString(he));
+    const uint8_t* md5s = reinterpret_cast<const uint8_t*>(h + 6 * size_t(n));
+    const uint64_t* diffs = h + 5 * size_t(n);
+    for (uint32_t k = 0; k < n_md5; k++) memcpy(verdicts[img_of[k]].md5, &md5s[size_t(k) * 16], 16);
+    for (uint32_t k = 0; k < n_cmp; k++) {
+        const rcgpu_kept_file& f = files[cmp_of[k]];
+        const uint64_t mine = f.before_size + P + f.after_size, common = std::min<uint64_t>(mine, f.on_disk_size);
+        uint64_t at = ~uint64_t(0);
+        const uint64_t nb = std::min<uint64_t>(f.before_size, common);
+        for (uint64_t q = 0; q < nb && at == ~uint64_t(0); q++) if (f.before[q] != f.on_disk[q]) at = q;
+        if (at == ~uint64_t(0) && diffs[k] != ~uint64_t(0)) at = f.before_size + diffs[k];
+        for (uint64_t q = f.before_size + P; q < common && at == ~uint64_t(0); q++) if (f.after[q - f.before_size - P] != f.on_disk[q]) at = q;
+        if (at == ~uint64_t(0) && mine != f.on_disk_size) at = common;
+        verdicts[cmp_of[k]].first_diff = at;
+    }
+    return 0;
 }
 
 extern "C" int rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* d, float ms[3])

@@ -79,6 +79,74 @@ def test_md5_device_edges(built):
     assert got == [hashlib.md5(m).digest() for m in msgs]
 
 
+def test_many_small_verification_calls_on_a_side_stream(built):
+    """A --check binding calls the compare and the MD5 once per small batch, hundreds of times, on its own stream."""
+    st = torch.cuda.Stream()
+    a = dev(os.urandom(40000)); b = a.clone()
+    b[777] ^= 1
+    want = hashlib.md5(bytes(a.cpu().numpy())).digest()
+    for k in range(300):
+        assert api.compare_device_batch([a.data_ptr()], [b.data_ptr()], [40000], st.cuda_stream) == [777]
+        assert api.compare_device_batch([a.data_ptr(), a.data_ptr()], [a.data_ptr(), b.data_ptr() + 1000], [40000, 39000], st.cuda_stream) == [-1, 0 if a[0] != b[1000] else 1]
+        if k % 10 == 0:
+            assert api.md5_device([a.data_ptr()], [40000], st.cuda_stream) == [want]
+
+
+def test_md5_device_at_any_address(built):
+    """Views that start at every offset modulo 16 (whole 16-byte reads, word reads, funnel-shifted words) and lengths around the
+    block, the padding and the extra word the shifted path reads."""
+    blob = os.urandom(70000)
+    t = dev(blob)
+    views = [(o, n) for o in range(17) for n in (0, 1, 63, 64, 67, 68, 69, 127, 128, 131, 132, 4096, 4099, 65000)]
+    got = api.md5_device([t.data_ptr() + o for o, _ in views], [n for _, n in views])
+    assert got == [hashlib.md5(blob[o:o + n]).digest() for o, n in views]
+
+
+def test_check_with_the_payloads_kept_on_the_device(built):
+    """decode_keep / kept_to_host / verify_kept: what frame_writer does with every rebuilt file -- MD5 of Pre + plane + Post
+    (FileWriter.cpp:709-724) and the comparison with the file on disk (:581-589, length :200) -- for a batch, without the payloads
+    coming back."""
+    w, h, pixfmt, nh, nv, n = 320, 180, synth.PIX_RGB16_BE, 4, 4, 7
+    srcs = []
+    for i in range(n):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 16, "film", seed=40 + i), pixfmt, True)
+        srcs.append(pl)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=n)
+    packets = enc.encode_host(srcs)
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=n)
+    dec.decode_keep(packets)
+    assert [dec.kept_to_host(i, len(srcs[i])) for i in range(n)] == srcs
+    before = [os.urandom(k) for k in (2048, 0, 7, 8192, 65536, 1, 2050)]
+    after = [os.urandom(k) for k in (0, 33, 0, 65536, 5, 0, 100)]
+    files = [before[i] + srcs[i] + after[i] for i in range(n)]
+    disk = list(files)
+    disk[1] = files[1][:-1] + bytes([files[1][-1] ^ 1])                 # last byte of the bytes after the payload
+    disk[2] = bytes([files[2][0] ^ 0x40]) + files[2][1:]                # first byte of the bytes before it
+    disk[3] = files[3][:8192 + 4321] + bytes([files[3][8192 + 4321] ^ 2]) + files[3][8192 + 4322:]   # inside the payload
+    disk[4] = files[4][:-3]                                             # the file on disk is shorter
+    disk[5] = files[5] + b"\0"                                          # ... longer
+    disk[6] = None                                                      # nothing to compare with: hash only
+    order = [3, 0, 6, 1, 5, 2, 4]
+    got = dec.verify_kept([{"slot": i, "before": before[i], "after": after[i], "on_disk": disk[i]} for i in order])
+    want_diff = {0: -1, 1: len(files[1]) - 1, 2: 0, 3: 8192 + 4321, 4: len(files[4]) - 3, 5: len(files[5]), 6: -1}
+    for k, i in enumerate(order):
+        assert got[k] == (hashlib.md5(files[i]).digest(), want_diff[i]), i
+    # compare only; a second batch replaces the slots; bad arguments are refused
+    got = dec.verify_kept([{"slot": 0, "before": b"", "after": b"", "on_disk": srcs[0], "md5": False}])
+    assert got == [(bytes(16), -1)]
+    dec.decode_keep(packets[4:6])
+    assert dec.verify_kept([{"slot": 1, "before": b"ab", "after": b"c", "on_disk": b"ab" + srcs[5] + b"c"}]) == [(hashlib.md5(b"ab" + srcs[5] + b"c").digest(), -1)]
+    for bad in ([{"slot": 2, "before": b"", "after": b""}], [{"slot": 0, "before": bytes(65537), "after": b""}],
+                [{"slot": 0, "before": b"", "after": b""}, {"slot": 0, "before": b"", "after": b""}]):
+        with pytest.raises(api.RcgpuError):
+            dec.verify_kept(bad)
+    with pytest.raises(api.RcgpuError, match="undecodable"):
+        dec.decode_keep([packets[0], packets[1][:100] + bytes([packets[1][100] ^ 8]) + packets[1][101:]])
+    with pytest.raises(api.RcgpuError):
+        dec.kept_to_host(0, len(srcs[0]))                               # nothing is kept after a failed batch
+    enc.close(); dec.close()
+
+
 @pytest.mark.parametrize("name", ["dpx_rgb16be_64x48", "dpx_rgb10be_50x38", "dpx_rgba12packed_50x38", "exr_rgb16_72x40"])
 def test_corrupted_packets_never_hang_or_fault(built, name):
     """Robustness of the device decoder: random byte flips, truncations and garbage tails in reference-blessed packets.  With slice

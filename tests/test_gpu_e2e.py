@@ -451,6 +451,57 @@ def test_linked_reference_checks_in_batches(built, linkedbin, refbin, tmp_path, 
     assert "f_000006" in (r.stdout + r.stderr), r.stdout + r.stderr
 
 
+def test_linked_reference_judges_whole_batches_on_the_device(built, linkedbin, refbin, tmp_path, monkeypatch):
+    """Route C with the payloads staying on the device (oracle/route_c_filewriter_cpp.patch): frame_writer::FrameCall lets every rebuilt
+    file wait for the rest of its batch, and the batch is hashed and compared with the files on disk by rcgpu_ffv1_decoder_verify_kept.
+    What the user reads must be what the unmodified reference prints -- for a package that checks, and for sources that were changed
+    after the encoding: a byte of a payload, a byte of a header, a byte after the payload, a shorter file, a longer file, a file that is
+    gone.  RCGPU_CHECK_DEFER=0 (payloads back to the host, the reference's own MD5 and memcmp) must say the same."""
+    work = str(tmp_path)
+    n = 13
+    make_package(work, 96, 64, synth.PIX_RGB16_BE, n, "film", audio=(2, 16, 48000, 26000))
+    monkeypatch.setenv("RCGPU_CHECK_BATCH", "5")
+    r = run([linkedbin, "--no-check-padding", "--check", "--hash", "-y", "pkg"], work, timeout=60)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+
+    def verdict(r):
+        return r.returncode, sorted(set(ln.strip() for ln in (r.stdout + r.stderr).replace("\r", "\n").split("\n")
+                                        if "rror" in ln or "ndecodable" in ln or "f_0000" in ln or OK_LINE in ln))
+
+    def files(i):
+        return os.path.join(work, "pkg", "img", "f_%06d.dpx" % i)
+
+    def change(i, fn):
+        d = bytearray(open(files(i), "rb").read())
+        d = fn(d, int.from_bytes(d[4:8], "big"))
+        open(files(i), "wb").write(d)
+
+    def flip(at):
+        def f(d, off):
+            d[at(d, off)] ^= 0x10
+            return d
+        return f
+    change(2, flip(lambda d, off: off + 1234))                # inside the payload
+    change(5, flip(lambda d, off: 40))                        # inside the header (the bytes before the payload)
+    change(6, flip(lambda d, off: len(d) - 1))                # the last byte
+    change(8, lambda d, off: d[:-7])                          # shorter
+    change(9, lambda d, off: d + b"\0\0\0")                  # longer
+    os.unlink(files(11))                                      # gone
+    # `--check x.mkv` alone judges by the hashes in the reversibility data; with `-o` the rebuilt files are compared with the ones there too
+    # (CLI/Main.cpp:505, frame_writer::NoOutputCheck)
+    assert verdict(run([refbin, "--check", "pkg.mkv"], work))[0] == 0
+    want = verdict(run([refbin, "--check", "pkg.mkv", "-o", "."], work))
+    assert OK_LINE not in " ".join(want[1]) and all(any("f_%06d" % i in ln for ln in want[1]) for i in (2, 5, 6, 8, 9, 11)), want
+    for defer in ("1", "0"):
+        monkeypatch.setenv("RCGPU_CHECK_DEFER", defer)
+        for batch in ("5", "64"):
+            monkeypatch.setenv("RCGPU_CHECK_BATCH", batch)
+            got = verdict(run([linkedbin, "--check", "pkg.mkv", "-o", "."], work, timeout=60))
+            assert got == want, (defer, batch, got, want)
+            r = run([linkedbin, "--check", "pkg.mkv"], work, timeout=60)
+            assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("batch", ["3", "256"])
 def test_linked_reference_hashes_the_sources_on_the_device(built, linkedbin, refbin, tmp_path, monkeypatch, batch):
     """Route D: the analysis loop (CLI/Main.cpp:280-292) announces the files it is about to open (oracle/route_d_main_cpp.patch) and
