@@ -149,7 +149,7 @@ def cpu_baseline(payloads: list, line_bytes: int, width: int, height: int, gpu_p
                       f"absent here)"}, not bad
 
 
-def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=256, cpu_frames=48, variants=None):
+def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=256, cpu_frames=32, variants=None):
     """The product-level number of BASELINE config 5: `rawcooked_linked --check` -- the REAL reference with this library linked in
     (INTEGRATION.md route C: oracle/route_c_*.patch, built by oracle/Makefile.ref) -- on an MKV of this run's packets.  The demuxer
     announces the frames that follow, the device decoder takes them in batches (RCGPU_CHECK_BATCH) and keeps the payloads; frame_writer
