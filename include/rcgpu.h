@@ -314,6 +314,11 @@ int  rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes, uint32_t
 /* The same for n host buffers, e.g. memory-mapped source files during analysis (input_base::Hash, Lib/Uncompressed/../Input_Base.cpp:54-81
  * hashes them one at a time on one core): uploaded once, hashed side by side. */
 int  rcgpu_md5_host_batch(const uint8_t* const* bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, int device);
+/* Both passes the analysis makes over every byte of a source file, for n mapped files that go up once: the whole-file MD5 (out_md5, n x 16;
+ * may be NULL) and, for the files rcgpu_dpx_probe recognises, the padding-bit test of dpx::ParseBuffer (DPX.cpp:501-608): scanned[i] = 1
+ * and first_nonzero[i] = the reference's In_FirstNonZero relative to the payload, or UINT64_MAX when every padding bit is zero -- then the
+ * reference's loop has nothing to find (first_nonzero and scanned may both be NULL). */
+int  rcgpu_analysis_host_batch(const uint8_t* const* files, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, uint64_t* first_nonzero, uint8_t* scanned, int device);
 /* The padding-bit test of the DPX analysis (dpx::ParseBuffer, Lib/Uncompressed/DPX/DPX.cpp:501-608) for n device payloads of one
  * layout -- e.g. the frames just uploaded for encoding: first_nonzero[i] (host) = the reference's In_FirstNonZero relative to the
  * payload, or UINT64_MAX when every padding bit is zero (then no "In" block is needed in the reversibility data). */

@@ -117,6 +117,7 @@ SYMBOLS = {
     "rcgpu_ffv1_decoder_destroy": (None, [_VP]),
     "rcgpu_ffv1_decoder_decode_device": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP), C.POINTER(C.c_uint32), _VP]),
     "rcgpu_md5_host_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _U8P, C.c_int]),
+    "rcgpu_analysis_host_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _VP, _VP, _VP, C.c_int]),
     "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_decode_keep": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32]),
     "rcgpu_ffv1_decoder_kept_to_host": (C.c_int, [_VP, C.c_uint32, _VP]),
@@ -195,6 +196,20 @@ def md5_host_batch(bufs: list[bytes], device: int = 0) -> list[bytes]:
     _check(lib().rcgpu_md5_host_batch(ptrs, sz, n, out, device), "rcgpu_md5_host_batch")
     raw = out.raw
     return [raw[16 * i:16 * i + 16] for i in range(n)]
+
+
+def analysis_host_batch(files: list[bytes], device: int = 0) -> list[tuple[bytes, bool, int]]:
+    """Per file (MD5, scanned, first non-zero padding offset relative to the payload or -1): Input_Base.cpp:54-81 + DPX.cpp:501-608."""
+    n = len(files)
+    keep = [C.create_string_buffer(b, len(b)) for b in files]
+    ptrs = (_VP * n)(*[C.cast(k, _VP) for k in keep])
+    sz = (C.c_uint64 * n)(*[len(b) for b in files])
+    out = C.create_string_buffer(16 * n)
+    first = (C.c_uint64 * n)()
+    scanned = C.create_string_buffer(n)
+    _check(lib().rcgpu_analysis_host_batch(ptrs, sz, n, out, first, scanned, device), "rcgpu_analysis_host_batch")
+    raw = out.raw
+    return [(raw[16 * i:16 * i + 16], scanned.raw[i] != 0, -1 if first[i] == 0xFFFFFFFFFFFFFFFF else first[i]) for i in range(n)]
 
 
 def config_from_record(record: bytes, width: int, height: int, pixfmt: int, line_bytes: int, flags: int = 0, context: int = 1) -> Ffv1Config:

@@ -220,6 +220,34 @@ def test_md5_of_host_buffers(built):
 DPX_LAYOUTS = [p for p in range(23) if p != synth.PIX_EXR_RGB16]
 
 
+def test_analysis_of_a_batch_of_files(built):
+    """rcgpu_analysis_host_batch: whole files of several layouts and sizes in one call -> hashlib's MD5 of every file and, for the DPX
+    files, the padding verdict of oracle/dpx_oracle.c (DPX.cpp:501-608); a WAV file and junk are hashed and not scanned."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    files, want = [], []
+    for k, (pixfmt, w, h) in enumerate([(synth.PIX_RGB10_FILLEDA_BE, 37, 9), (synth.PIX_RGB10_FILLEDA_BE, 37, 9), (synth.PIX_RGB10_FILLEDA_BE, 37, 9),
+                                        (synth.PIX_RGB16_BE, 21, 6), (synth.PIX_RGB12_PACKED_BE, 50, 7), (synth.PIX_Y10_FILLEDA_BE, 64, 5),
+                                        (synth.PIX_RGBA12_FILLEDA_LE, 16, 4), (synth.PIX_RGB10_FILLEDA_BE, 40, 9)]):
+        bits, nc, _, be = synth.PIX_INFO[pixfmt]
+        packing = synth.DPX_PACKING.get(pixfmt, 1 if bits in (10, 12) else 0)
+        payload, _ = synth.pack_payload(synth.components(w, h, nc, bits, "noise", seed=k), pixfmt, True)
+        payload = bytearray(payload)
+        if k in (1, 4, 6):                                                  # a few bits anywhere: some land in padding, some do not
+            for _ in range(3):
+                payload[int(rng.integers(0, len(payload)))] ^= 1 << int(rng.integers(0, 8))
+        if k == 2:
+            payload[len(payload) - 1] |= 1
+        files.append(synth.dpx_file(None, pixfmt, frame_index=k, payload=bytes(payload), size=(w, h)))
+        first = ob.dpx_padding_first_nonzero(bytes(payload), w, h, bits, nc, be, packing, False)
+        want.append((hashlib.md5(files[-1]).digest(), True, -1 if first == 2 ** 64 - 1 else first))
+    files.append(synth.wav_file(synth.pcm_samples(500, 2, 16), 16)); want.append((hashlib.md5(files[-1]).digest(), False, -1))
+    files.append(os.urandom(5000)); want.append((hashlib.md5(files[-1]).digest(), False, -1))
+    files.append(files[0][:3000]); want.append((hashlib.md5(files[-1]).digest(), False, -1))      # a truncated DPX file is not scanned
+    assert api.analysis_host_batch(files) == want
+    assert any(w[2] >= 0 for w in want) and any(w[1] and w[2] < 0 for w in want)
+
+
 @pytest.mark.parametrize("pixfmt", DPX_LAYOUTS)
 def test_padding_scan_matches_the_reference_rule(built, pixfmt):
     """rcgpu_dpx_padding_scan_device against oracle/dpx_oracle.c (DPX.cpp:501-608 restated from the header facts): clean payloads,

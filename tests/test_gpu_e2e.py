@@ -527,3 +527,44 @@ def test_linked_reference_hashes_the_sources_on_the_device(built, linkedbin, ref
     monkeypatch.setenv("RCGPU_HASH", "1")
     r = run([linkedbin, "--no-check-padding", "--check", "--hash", "-y", "pkg"], work, timeout=60)
     assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("hash_too", [True, False])
+def test_linked_reference_tests_the_padding_bits_on_the_device(built, linkedbin, refbin, tmp_path, monkeypatch, hash_too):
+    """Route D, second half: with --check-padding dpx::ParseBuffer walks every payload looking for non-zero padding bits
+    (Lib/Uncompressed/DPX/DPX.cpp:501-608).  The files the analysis loop announces are scanned on the device while they are there for their
+    MD5 (rcgpu_analysis_host_batch); the loop is skipped for the clean ones (oracle/route_d_dpx_cpp.patch) and runs as ever for the others.
+    The reversibility data -- it holds the padding bits of the frames that have any -- must be the unmodified reference's, byte for byte."""
+    work = str(tmp_path)
+    n = 11
+    make_package(work, 80, 48, synth.PIX_RGB10_FILLEDA_BE, n, "film")
+    dirty = (3, 7, 8)
+    for i in dirty:
+        p = os.path.join(work, "pkg", "img", "f_%06d.dpx" % i)
+        d = bytearray(open(p, "rb").read())
+        off = int.from_bytes(d[4:8], "big")
+        for k in range(off + 3 + 4 * 100 * i, len(d), 4 * (50 + i)):
+            d[k] |= 1 + (k % 3 == 0)
+        open(p, "wb").write(d)
+    args = (["--hash"] if hash_too else []) + ["--check-padding", "-d", "-y", "pkg"]
+    r = run([refbin] + args, work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = open(os.path.join(work, "pkg.rawcooked_reversibility_data"), "rb").read()
+    os.unlink(os.path.join(work, "pkg.rawcooked_reversibility_data"))
+    monkeypatch.setenv("RCGPU_TRACE_ROUTE_D", "1")
+    for env_hash, batch in (("1", "4"), ("1", "256"), ("0", "256")):
+        monkeypatch.setenv("RCGPU_HASH", env_hash)
+        monkeypatch.setenv("RCGPU_HASH_BATCH", batch)
+        r = run([linkedbin] + args, work, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = open(os.path.join(work, "pkg.rawcooked_reversibility_data"), "rb").read()
+        os.unlink(os.path.join(work, "pkg.rawcooked_reversibility_data"))
+        assert got == want, f"RCGPU_HASH={env_hash} batch {batch}: the reversibility data differs"
+        skipped = [ln for ln in r.stderr.replace("\r", "\n").split("\n") if "rcgpu route D: no padding bit set" in ln]      # the progress indicator shares the line
+        # the first file is parsed before the loop that announces the others
+        assert len(skipped) == (n - 1 - len(dirty) if env_hash == "1" else 0), r.stderr[-600:]
+        assert not any("f_%06d" % i in ln for i in dirty for ln in skipped)
+    # and the package made from it checks
+    monkeypatch.setenv("RCGPU_HASH", "1")
+    r = run([linkedbin, "--check-padding", "--check", "-y", "pkg"] + (["--hash"] if hash_too else []), work, timeout=60)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
