@@ -165,7 +165,8 @@ __device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* base, int k, con
     ST_AT(base, k) = trans[(bit ? 256u : 0u) + s];
     return bit ? 1u : 0u;
 }
-__device__ uint32_t rd_u(rd_lane& r, uint8_t* st, const uint8_t* trans)
+// (slice header only; inlined so that the lane's coder state never has its address taken and stays in registers)
+__device__ __forceinline__ uint32_t rd_u(rd_lane& r, uint8_t* st, const uint8_t* trans)
 {
     if (rd_bit(r, st, 0, trans)) return 0;
     int e = 0;
@@ -174,15 +175,103 @@ __device__ uint32_t rd_u(rd_lane& r, uint8_t* st, const uint8_t* trans)
     for (int i = e - 1; i >= 0; i--) a = (a << 1) | rd_bit(r, st, 22 + (i < 9 ? i : 9), trans);
     return a;
 }
-__device__ int32_t rd_s(rd_lane& r, uint8_t* st, const uint8_t* trans)
+// ---- the same symbol decoder for the samples, with the context's 32 states in eight REGISTERS (state k = byte k & 3 of w[k >> 2], the
+// record as it lies in HBM).  A chain's time is its latency: ~32 decision slots per sample (the wavefront walks the longest lane's
+// exponent), and with the states in LDS a slot was two dependent LDS round trips (state, then the transition table) plus the arithmetic.
+// Here every state index is a compile-time constant -- the exponent loop and the mantissa loop are unrolled over their whole range
+// (FFV1_RangeCoder.cpp:206-236 allows e up to 31) and the lanes a step does not concern are masked, a step that concerns no lane is
+// skipped by a uniform branch -- so a state is a bit-field extract, and the one LDS access left, the transition pair of that state
+// (t16[s] = zero_state[s] | one_state[s] << 8), is issued before the arithmetic that decides which half is wanted.
+template <int K> __device__ __forceinline__ uint32_t st_get(const uint32_t (&w)[8]) { return (w[K >> 2] >> (8 * (K & 3))) & 0xFFu; }
+template <int K> __device__ __forceinline__ void st_put(uint32_t (&w)[8], uint32_t v)
 {
-    if (rd_bit(r, st, 0, trans)) return 0;
-    int e = 0;
-    while (rd_bit(r, st, 1 + (e < 9 ? e : 9), trans)) { if (++e > 31) return 0; }
-    int32_t a = 1;
-    for (int i = e - 1; i >= 0; i--) a = (a << 1) | int32_t(rd_bit(r, st, 22 + (i < 9 ? i : 9), trans));
-    return rd_bit(r, st, 11 + (e < 10 ? e : 10), trans) ? -a : a;
+    w[K >> 2] = (w[K >> 2] & ~(0xFFu << (8 * (K & 3)))) | (v << (8 * (K & 3)));
 }
+// one decision of the lanes in `active` against state s; ns = the state afterwards (s itself for the other lanes)
+__device__ __forceinline__ uint32_t rd_core(rd_lane& r, uint32_t s, const uint16_t* t16, bool active, uint32_t& ns)
+{
+    const uint32_t t2 = t16[s];
+    uint32_t bit = 0;
+    ns = s;
+    if (active) {
+        const bool need = r.mask < 0x100;
+        if (__builtin_expect(__ballot(need && !r.nwin) != 0, 0)) {    // a sample used more than the window held: refill on the spot (rare)
+            if (need && !r.nwin) { rd_refill(r); rd_refill(r); }
+        }
+        const uint32_t b = r.win_hi >> 24;
+        r.current = need ? (r.current << 8) | b : r.current;
+        r.mask = need ? r.mask << 8 : r.mask;
+        const uint32_t nhi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24);      // (hi:lo) << 8
+        r.win_hi = need ? nhi : r.win_hi;
+        r.win_lo = need ? r.win_lo << 8 : r.win_lo;
+        r.nwin -= need ? 1u : 0u;
+        r.pos += need ? 1u : 0u;
+        const uint32_t m2 = __umul24(r.mask, s) >> 8;                 // mask < 2^16 after the renormalisation, s < 2^8
+        const uint32_t nm = r.mask - m2;
+        const bool one = r.current >= nm;
+        r.current -= one ? nm : 0u;
+        r.mask = one ? m2 : nm;
+        ns = one ? t2 >> 8 : t2 & 0xFFu;
+        bit = one ? 1u : 0u;
+    }
+    return bit;
+}
+template <int K> __device__ __forceinline__ uint32_t rd_bit_k(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16, bool active)
+{
+    uint32_t ns;
+    const uint32_t bit = rd_core(r, st_get<K>(w), t16, active, ns);
+    st_put<K>(w, ns);
+    return bit;
+}
+template <int J> struct rd_steps {
+    // exponent: step J reads state 1 + min(J, 9); `going` = the lanes whose ones have not ended yet
+    static __device__ __forceinline__ void unary(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16, bool& going, uint32_t& e, bool& over)
+    {
+        if (__ballot(going) == 0) return;
+        const uint32_t b = rd_bit_k<1 + (J < 9 ? J : 9)>(r, w, t16, going);
+        going = going && b != 0;
+        e += going ? 1u : 0u;
+        if (J == 31) { over = going; going = false; }                // a 32nd one: the value is 0 (`if (++e > 31) return 0`)
+        else rd_steps<J + 1>::unary(r, w, t16, going, e, over);
+    }
+    // mantissa: bit I (from e - 1 down to 0) reads state 22 + min(I, 9)
+    static __device__ __forceinline__ void mantissa(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16, bool live, uint32_t e, int32_t& a)
+    {
+        constexpr int I = 31 - J;
+        const bool act = live && uint32_t(I) < e;
+        if (__ballot(act) != 0) {
+            const uint32_t b = rd_bit_k<22 + (I < 9 ? I : 9)>(r, w, t16, act);
+            a = act ? (a << 1) | int32_t(b) : a;
+        }
+        rd_steps<J + 1>::mantissa(r, w, t16, live, e, a);
+    }
+};
+template <> struct rd_steps<32> {
+    static __device__ __forceinline__ void unary(rd_lane&, uint32_t (&)[8], const uint16_t*, bool&, uint32_t&, bool&) {}
+    static __device__ __forceinline__ void mantissa(rd_lane&, uint32_t (&)[8], const uint16_t*, bool, uint32_t, int32_t&) {}
+};
+// rangecoder::s (FFV1_RangeCoder.cpp:206-236) for all lanes of the wavefront
+__device__ __forceinline__ int32_t rd_s_regs(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16)
+{
+    const bool zero = rd_bit_k<0>(r, w, t16, true) != 0;
+    bool going = !zero, over = false;
+    uint32_t e = 0;
+    rd_steps<0>::unary(r, w, t16, going, e, over);
+    const bool live = !zero && !over;
+    int32_t a = 1;
+    rd_steps<0>::mantissa(r, w, t16, live, e, a);
+    // sign: state 11 + min(e, 10) -- the one index that differs from lane to lane: its dword is picked by selects, its byte by a shift
+    const uint32_t k = 11 + (e < 10 ? e : 10), d = k >> 2, sh = (k & 3) * 8;
+    uint32_t c2 = w[2], c3 = w[3], c4 = w[4], c5 = w[5];
+    asm("" : "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5));                 // opaque copies: left alone, the selects below become an indexed load of a stack copy of w
+    const uint32_t word = d == 2 ? c2 : d == 3 ? c3 : d == 4 ? c4 : c5;
+    uint32_t ns;
+    const bool neg = rd_core(r, (word >> sh) & 0xFFu, t16, live, ns) != 0;
+    const uint32_t put = (word & ~(0xFFu << sh)) | (ns << sh);
+    w[2] = d == 2 ? put : w[2]; w[3] = d == 3 ? put : w[3]; w[4] = d == 4 ? put : w[4]; w[5] = d == 5 ? put : w[5];
+    return live ? (neg ? -a : a) : 0;
+}
+
 __device__ __forceinline__ int32_t med3(int32_t a, int32_t b, int32_t c) { return max(min(a, b), min(max(a, b), c)); }
 
 // inverse of k_unpack: JPEG2000RCT (Transform.cpp:29-37) + packers; whole lines incl. DPX padding are written
@@ -240,10 +329,11 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                                                    uint32_t* __restrict__ err, const uint16_t* __restrict__ hdr)
 {
     __shared__ uint8_t trans[512];
+    __shared__ uint16_t t16[256];
     __shared__ int16_t q[5][256];
     __shared__ __attribute__((aligned(16))) uint8_t slot[64 * 32];
     const int lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; }
+    for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; t16[i] = uint16_t(C->zero_state[i] | C->one_state[i] << 8); }
     for (int i = lane; i < 5 * 256; i += 64) (&q[0][0])[i] = (&C->q[0][0])[i];
     __syncthreads();
     const uint32_t chain = blockIdx.x * 64 + lane;
@@ -318,10 +408,11 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                 int32_t v = ov16 ? med3(int16_t(L), int16_t(L) + int16_t(T) - int16_t(LT), int16_t(T)) : med3(L, L + T - LT, T);
                 const uint32_t key = set * nctx + uint32_t(ctx < 0 ? -ctx : ctx);
                 uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
+                uint32_t sw[8];
                 { const uint4 a0 = gp[0], a1 = gp[1];
-                  myw[0] = a0.x; myw[64] = a0.y; myw[128] = a0.z; myw[192] = a0.w; myw[256] = a1.x; myw[320] = a1.y; myw[384] = a1.z; myw[448] = a1.w; }
-                const int32_t delta = rd_s(r, my, trans);
-                gp[0] = make_uint4(myw[0], myw[64], myw[128], myw[192]); gp[1] = make_uint4(myw[256], myw[320], myw[384], myw[448]);
+                  sw[0] = a0.x; sw[1] = a0.y; sw[2] = a0.z; sw[3] = a0.w; sw[4] = a1.x; sw[5] = a1.y; sw[6] = a1.z; sw[7] = a1.w; }
+                const int32_t delta = rd_s_regs(r, sw, t16);
+                gp[0] = make_uint4(sw[0], sw[1], sw[2], sw[3]); gp[1] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
                 v = (ctx >= 0 ? v + delta : v - delta) & bitmask;
                 cur[x] = v;
                 LL = L; L = v; LT = T; T = RT;
