@@ -160,7 +160,7 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
     import shutil
     import subprocess
     import tempfile
-    exe = os.path.join(ROOT, "oracle", "_ref", "rawcooked_linked")
+    exe = os.environ.get("RCGPU_LINKED_EXE") or os.path.join(ROOT, "oracle", "_ref", "rawcooked_linked")       # e.g. a build with -pg
     if not os.path.exists(exe):
         return None
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
@@ -207,8 +207,9 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
         out = {"frames": n, "unit": "frames/s", "analysis_seconds": round(analysis_s, 2)}
         OKL = "Reversibility was checked, no issue detected."
         # `--check x.mkv` judges by the MD5s in the reversibility data; with `-o .` the rebuilt files are also compared with the sources on disk
-        todo = (("device_decoder", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": str(n)}, big, n, []),
-                ("device_decoder_and_sources", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": str(n)}, big, n, ["-o", "."]),
+        batch = os.environ.get("RCGPU_LINKED_BATCH", str(n))       # frames per device call; by default the whole MKV is one batch
+        todo = (("device_decoder", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": batch}, big, n, []),
+                ("device_decoder_and_sources", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": batch}, big, n, ["-o", "."]),
                 ("device_decoder_payloads_to_host", {"RCGPU_CHECK": "1", "RCGPU_CHECK_DEFER": "0", "RCGPU_CHECK_BATCH": "128"}, small, m, []),
                 ("reference_cpu_pool", {"RCGPU_CHECK": "0"}, small, m, []),
                 ("reference_cpu_pool_and_sources", {"RCGPU_CHECK": "0"}, small, m, ["-o", "."]))
@@ -219,7 +220,10 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
             ok = r.returncode == 0 and OKL in r.stdout
             out[name] = {"value": round(count / r.seconds, 2), "frames": count, "seconds": round(r.seconds, 2), "verdict": OKL if ok else (r.stdout + r.stderr)[-200:]}
             if os.environ.get("RCGPU_TRACE_KEPT"):
-                out[name]["trace"] = [ln for ln in r.stderr.split("\n") if ln.startswith("rcgpu kept:")]
+                import resource
+                ru = resource.getrusage(resource.RUSAGE_CHILDREN)
+                out[name]["children_cpu_seconds_so_far"] = {"user": round(ru.ru_utime, 2), "system": round(ru.ru_stime, 2), "minor_faults": ru.ru_minflt}
+                out[name]["trace"] = [ln[ln.index("rcgpu "):] for ln in r.stderr.replace("\r", "\n").split("\n") if "rcgpu " in ln]
         if out.get("reference_cpu_pool", {}).get("value") and "device_decoder" in out:
             out["speedup"] = round(out["device_decoder"]["value"] / out["reference_cpu_pool"]["value"], 2)
         out["what"] = (f"oracle/_ref/rawcooked_linked --check on an MKV of {n} {width}x{height} frames (this run's packets, tmpfs), process start to exit: the reference's own demuxer, "

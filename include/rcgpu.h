@@ -287,14 +287,27 @@ typedef struct rcgpu_kept_file {
     const uint8_t* before;  uint64_t before_size;
     const uint8_t* after;   uint64_t after_size;
     const uint8_t* on_disk; uint64_t on_disk_size;
+    const char* on_disk_path;   /* when on_disk is NULL: the file to compare with, by name -- read with pread() straight into the staging buffers
+                                   (256 4K files: 0.5-0.8 s; mapped by the caller and passed as on_disk: 0.25 s plus the unmapping) */
 } rcgpu_kept_file;
 typedef struct rcgpu_kept_verdict {
     uint8_t  md5[16];
     uint64_t first_diff;
 } rcgpu_kept_verdict;
 int  rcgpu_ffv1_decoder_decode_keep(rcgpu_ffv1_decoder* dec, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n);
+/* The same with the packets named by their place in an open file -- the Matroska file the blocks lie in -- instead of by address, for a caller
+ * that has not mapped it: they are read with pread() straight into the staging buffers.  (From a mapping the bytes go up faster -- 6 GB in 0.3 s
+ * against 0.35-0.7 s -- at the price of ~0.4 s when the mapping with all its pages touched is torn down, as matroska::ParseBuffer does after
+ * every MiB, Matroska.cpp:394-419: about even.) */
+int  rcgpu_ffv1_decoder_decode_keep_fd(rcgpu_ffv1_decoder* dec, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n);
 int  rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* dec, uint32_t slot, uint8_t* payload);
 int  rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* dec, const rcgpu_kept_file* files, uint32_t n, rcgpu_kept_verdict* verdicts);
+/* The same in two calls, for a caller with more than one batch: _begin takes what it needs of the caller's memory (it may be released when
+ * the call returns), compares, and starts the hashes -- MD5 is serial per file, 0.8 s for a 53 MB file however many there are; the next
+ * rcgpu_ffv1_decoder_decode_keep then fills a second set of slots while they run, and _end (before the decode_keep after that) hands out the n
+ * verdicts.  One verification at a time. */
+int  rcgpu_ffv1_decoder_verify_kept_begin(rcgpu_ffv1_decoder* dec, const rcgpu_kept_file* files, uint32_t n);
+int  rcgpu_ffv1_decoder_verify_kept_end(rcgpu_ffv1_decoder* dec, rcgpu_kept_verdict* verdicts);
 /* Fill the stream-dependent fields of `cfg` (num_h_slices, num_v_slices, slicecrc, context, coder) from a Matroska CodecPrivate =
  * FFV1 configuration record, the way parameters::Parse reads it (FFV1_Parameters.cpp:23-183); width, height, pixfmt, line_bytes
  * and flags describe the files and are the caller's (they come from the reversibility data / the probes).  Fails when the record

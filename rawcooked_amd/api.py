@@ -120,8 +120,11 @@ SYMBOLS = {
     "rcgpu_analysis_host_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _VP, _VP, _VP, C.c_int]),
     "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_decode_keep": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32]),
+    "rcgpu_ffv1_decoder_decode_keep_fd": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32]),
     "rcgpu_ffv1_decoder_kept_to_host": (C.c_int, [_VP, C.c_uint32, _VP]),
     "rcgpu_ffv1_decoder_verify_kept": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
+    "rcgpu_ffv1_decoder_verify_kept_begin": (C.c_int, [_VP, _VP, C.c_uint32]),
+    "rcgpu_ffv1_decoder_verify_kept_end": (C.c_int, [_VP, _VP]),
     "rcgpu_ffv1_config_from_record": (C.c_int, [_U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_config_from_stream": (C.c_int, [_U8P, _SZ, _U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
@@ -350,7 +353,7 @@ def encode_sequence_memory(cfg: Ffv1Config, frame_addrs: list[int], n_frames: in
 class KeptFile(C.Structure):
     """rcgpu_kept_file (include/rcgpu.h)."""
     _fields_ = [("slot", C.c_uint32), ("flags", C.c_uint32), ("before", C.c_void_p), ("before_size", C.c_uint64),
-                ("after", C.c_void_p), ("after_size", C.c_uint64), ("on_disk", C.c_void_p), ("on_disk_size", C.c_uint64)]
+                ("after", C.c_void_p), ("after_size", C.c_uint64), ("on_disk", C.c_void_p), ("on_disk_size", C.c_uint64), ("on_disk_path", C.c_char_p)]
 
 
 class KeptVerdict(C.Structure):
@@ -400,12 +403,17 @@ class Ffv1Decoder:
         sz = (C.c_uint64 * n)(*[len(p) for p in packets])
         _check(lib().rcgpu_ffv1_decoder_decode_keep(self.h, pk, sz, n), "rcgpu_ffv1_decoder_decode_keep")
 
+    def decode_keep_fd(self, fd: int, offsets: list[int], sizes: list[int]) -> None:
+        """The same with the packets at `offsets` of the open file `fd` (rcgpu_ffv1_decoder_decode_keep_fd)."""
+        n = len(offsets)
+        _check(lib().rcgpu_ffv1_decoder_decode_keep_fd(self.h, fd, (C.c_uint64 * n)(*offsets), (C.c_uint64 * n)(*sizes), n), "rcgpu_ffv1_decoder_decode_keep_fd")
+
     def kept_to_host(self, slot: int, payload_bytes: int) -> bytes:
         out = C.create_string_buffer(payload_bytes)
         _check(lib().rcgpu_ffv1_decoder_kept_to_host(self.h, slot, out), "rcgpu_ffv1_decoder_kept_to_host")
         return out.raw
 
-    def verify_kept(self, files: list[dict]) -> list[tuple[bytes, int]]:
+    def verify_kept(self, files: list[dict], begin_only: bool = False) -> list[tuple[bytes, int]]:
         """files: dicts with slot, before, after (bytes), on_disk (bytes or None), md5 (bool) -> per file (md5, first differing offset or -1):
         frame_writer's CheckMD5 and CheckFile (FileWriter.cpp:464-727) for a batch of rebuilt files, on the device."""
         n = len(files)
@@ -414,6 +422,8 @@ class Ffv1Decoder:
         for i, f in enumerate(files):
             arr[i].slot = f["slot"]
             arr[i].flags = 1 if f.get("md5", True) else 0
+            if f.get("on_disk_path"):
+                arr[i].on_disk_path = os.fsencode(f["on_disk_path"])
             for name in ("before", "after", "on_disk"):
                 v = f.get(name)
                 if v is None:
@@ -422,8 +432,20 @@ class Ffv1Decoder:
                 keep.append(b)
                 setattr(arr[i], name, C.cast(b, _VP))
                 setattr(arr[i], name + "_size", len(v))
+        if begin_only:
+            _check(lib().rcgpu_ffv1_decoder_verify_kept_begin(self.h, arr, n), "rcgpu_ffv1_decoder_verify_kept_begin")
+            self._begun = n
+            return []
         out = (KeptVerdict * n)()
         _check(lib().rcgpu_ffv1_decoder_verify_kept(self.h, arr, n, out), "rcgpu_ffv1_decoder_verify_kept")
+        return [(bytes(bytearray(o.md5)), -1 if o.first_diff == 0xFFFFFFFFFFFFFFFF else o.first_diff) for o in out]
+
+    def verify_kept_end(self) -> list[tuple[bytes, int]]:
+        """The verdicts of the verification begun with verify_kept(..., begin_only=True)."""
+        n = getattr(self, "_begun", 0) or 1
+        out = (KeptVerdict * n)()
+        _check(lib().rcgpu_ffv1_decoder_verify_kept_end(self.h, out), "rcgpu_ffv1_decoder_verify_kept_end")
+        self._begun = 0
         return [(bytes(bytearray(o.md5)), -1 if o.first_diff == 0xFFFFFFFFFFFFFFFF else o.first_diff) for o in out]
 
     def kernel_times(self) -> dict[str, float]:

@@ -26,6 +26,10 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "ffv1_host.h"
 #include "rc_common.h"
 #include "crc_dev.h"
@@ -644,11 +648,22 @@ struct rcgpu_ffv1_decoder {
     bool ev_valid = false;
     // the payloads of the last decode_keep: slot i = d_kept + i * kept_stride, [room | payload | room] so that the bytes a file has
     // before and after its payload can be put next to it and the file hashed as one buffer
+    // Two such sets: while the files of one batch are being hashed (verify_kept_begin ... _end) the next batch is decoded into the other.
+    struct kept_set {
+        uint8_t* d = nullptr; size_t cap = 0; uint32_t n = 0;
+        uint64_t* h_tab = nullptr; uint64_t* d_tab = nullptr; uint32_t tab_cap = 0;     // tables of the verification kernels, pinned + device
+        bool pending = false;                                                            // begun, not ended
+        uint32_t pn = 0, pn_md5 = 0, pn_cmp = 0;
+        std::vector<uint32_t> img_of, cmp_of;
+        struct host_part { uint64_t mine, on_disk_size, before_size, head_diff, tail_diff; };   // what the host already knows of a comparison
+        std::vector<host_part> part;
+    } kept[2];
+    int kept_cur = 0;
+    size_t kept_stride = 0;
     uint8_t* d_kept_in = nullptr; size_t kept_in_cap = 0;
-    uint8_t* d_kept = nullptr; size_t kept_cap = 0, kept_stride = 0; uint32_t kept_n = 0;
     uint8_t* d_disk = nullptr; size_t disk_cap = 0;
-    hipStream_t side_stream = nullptr; hipEvent_t ev_tab = nullptr;
-    uint64_t* h_tab = nullptr; uint64_t* d_tab = nullptr; uint32_t tab_cap = 0;
+    hipStream_t side_stream = nullptr, md5_stream = nullptr; hipEvent_t ev_tab = nullptr, ev_side = nullptr;
+    uint8_t* h_edges = nullptr; size_t edges_cap = 0;          // pinned: the bytes before and after the payloads of a batch on their way up
     stager up;
 };
 
@@ -662,11 +677,14 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     if (d->h_sizes) (void)hipHostFree(d->h_sizes);
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
-    for (void* b : { (void*)d->d_kept_in, (void*)d->d_kept, (void*)d->d_disk }) if (b) (void)hipFree(b);
+    if (d->md5_stream) (void)hipStreamSynchronize(d->md5_stream);     // a verification begun and never ended
+    for (void* b : { (void*)d->d_kept_in, (void*)d->kept[0].d, (void*)d->kept[1].d, (void*)d->d_disk, (void*)d->kept[0].d_tab, (void*)d->kept[1].d_tab }) if (b) (void)hipFree(b);
+    for (auto& k : d->kept) if (k.h_tab) (void)hipHostFree(k.h_tab);
+    if (d->h_edges) (void)hipHostFree(d->h_edges);
     if (d->side_stream) (void)hipStreamDestroy(d->side_stream);
+    if (d->md5_stream) (void)hipStreamDestroy(d->md5_stream);
     if (d->ev_tab) (void)hipEventDestroy(d->ev_tab);
-    if (d->h_tab) (void)hipHostFree(d->h_tab);
-    if (d->d_tab) (void)hipFree(d->d_tab);
+    if (d->ev_side) (void)hipEventDestroy(d->ev_side);
     d->up.release();
     delete d;
 }
@@ -824,7 +842,10 @@ extern "C" int rcgpu_ffv1_decoder_decode_host(rcgpu_ffv1_decoder* d, const uint8
 // ---- `--check` with the payloads staying on the device (rcgpu.h: decode_keep / kept_to_host / verify_kept)
 namespace {
 
-struct up_item { uint8_t* dst; const uint8_t* src; size_t size; };
+// what goes up: `size` bytes at `src`, or -- when src is NULL -- at offset `off` of the open file `fd`, read with pread() straight into the
+// staging buffer.  For a caller that has the file mapped anyway the address is the faster of the two (6 GB of packets: 0.3 s from the mapping,
+// 0.35-0.7 s with pread(), and no better through private windows mapped per chunk); the mapping then costs ~0.4 s to tear down, once.
+struct up_item { uint8_t* dst; const uint8_t* src; size_t size; int fd = -1; uint64_t off = 0; };
 
 // One thread is bound by the page faults of a mapping and by its own copy into the staging buffer; eight of them reach the link's rate
 // (13.6 GB of mapped files in 0.25 s).
@@ -833,7 +854,7 @@ hipError_t upload_side_by_side(stager& up, int device, const std::vector<up_item
     std::vector<up_item> chunks;
     for (const up_item& it : items)
         for (size_t o = 0; o < it.size; o += stager::kStage)
-            chunks.push_back({ it.dst + o, it.src + o, std::min(stager::kStage, it.size - o) });
+            chunks.push_back({ it.dst + o, it.src ? it.src + o : nullptr, std::min(stager::kStage, it.size - o), it.fd, it.off + o });
     if (chunks.empty()) return hipSuccess;
     unsigned nt = stager::kLanes;
     if (const char* e = getenv("RCGPU_UPLOAD_THREADS")) nt = unsigned(std::max(1, std::min(int(stager::kLanes), atoi(e))));
@@ -849,7 +870,7 @@ hipError_t upload_side_by_side(stager& up, int device, const std::vector<up_item
         if (he != hipSuccess) return he;
     }
     std::atomic<size_t> next{0};
-    std::atomic<int> err{int(hipSuccess)};
+    std::atomic<int> err{int(hipSuccess)}, short_read{0};
     auto work = [&](unsigned t) {
         auto& l = up.lanes[t];
         hipError_t he = hipSetDevice(device);
@@ -859,7 +880,17 @@ hipError_t upload_side_by_side(stager& up, int device, const std::vector<up_item
             if (i >= chunks.size()) break;
             if (used[k]) he = hipEventSynchronize(l.ev[k]);
             if (he != hipSuccess) break;
-            memcpy(l.stage[k], chunks[i].src, chunks[i].size);
+            if (chunks[i].src) memcpy(l.stage[k], chunks[i].src, chunks[i].size);
+            else {
+                size_t got = 0;
+                while (got < chunks[i].size) {
+                    const ssize_t r = pread(chunks[i].fd, l.stage[k] + got, chunks[i].size - got, off_t(chunks[i].off + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) break;
+                    got += size_t(r);
+                }
+                if (got < chunks[i].size) { short_read.store(1); memset(l.stage[k] + got, 0, chunks[i].size - got); }
+            }
             he = hipMemcpyAsync(chunks[i].dst, l.stage[k], chunks[i].size, hipMemcpyHostToDevice, l.st);
             if (he == hipSuccess) he = hipEventRecord(l.ev[k], l.st);
             used[k] = true;
@@ -872,17 +903,20 @@ hipError_t upload_side_by_side(stager& up, int device, const std::vector<up_item
     for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
+    if (short_read.load() && err.load() == int(hipSuccess)) return hipErrorFileNotFound;      // a file ended before the bytes asked for
     return hipError_t(err.load());
 }
 
 // RCGPU_TRACE_KEPT=1: where the time of a batch goes, on stderr
+const std::chrono::steady_clock::time_point g_loaded = std::chrono::steady_clock::now();      // when the library was loaded: the traces say where in the run they are
 struct kept_clock {
     const bool on = getenv("RCGPU_TRACE_KEPT") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void lap(const char* what, uint32_t n) {
         if (!on) return;
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "rcgpu kept: %-28s %4u files %8.1f ms\n", what, n, std::chrono::duration<double, std::milli>(now - t).count());
+        fprintf(stderr, "rcgpu kept: %-28s %4u files %8.1f ms   (at %.2f s)\n", what, n, std::chrono::duration<double, std::milli>(now - t).count(),
+                std::chrono::duration<double>(now - g_loaded).count());
         t = now;
     }
 };
@@ -899,149 +933,256 @@ hipError_t grow(uint8_t*& p, size_t& cap, size_t need)
 
 }  // namespace
 
-extern "C" int rcgpu_ffv1_decoder_decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n)
+static int decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n)
 {
-    clear_error();
-    if (!d || !packets || !packet_sizes) return fail(1, "ffv1 decoder: null argument");
     if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
     HIP_TRY(hipSetDevice(d->cfg.device));
-    d->kept_n = 0;
+    if (d->kept[d->kept_cur].pending) {                              // its files are still being hashed: this batch goes into the other set
+        if (d->kept[d->kept_cur ^ 1].pending) return fail(2, "ffv1 decoder: two batches wait for rcgpu_ffv1_decoder_verify_kept_end");
+        d->kept_cur ^= 1;
+    }
+    rcgpu_ffv1_decoder::kept_set& K = d->kept[d->kept_cur];
+    K.n = 0;
     const size_t out_bytes = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
     d->kept_stride = (size_t(RCGPU_KEPT_ROOM) * 2 + out_bytes + 255) & ~size_t(255);
     uint64_t in_total = 0;
     for (uint32_t i = 0; i < n; i++) in_total += (packet_sizes[i] + 255) & ~uint64_t(255);
     kept_clock clk;
     HIP_TRY(grow(d->d_kept_in, d->kept_in_cap, size_t(in_total) + 256));
-    HIP_TRY(grow(d->d_kept, d->kept_cap, d->kept_stride * n));
+    HIP_TRY(grow(K.d, K.cap, d->kept_stride * n));
     clk.lap("decode_keep: device buffers", n);
     std::vector<up_item> up(n);
     std::vector<const void*> pk(n); std::vector<void*> out(n);
     uint64_t off = 0;
     for (uint32_t i = 0; i < n; i++) {
-        up[i] = { d->d_kept_in + off, packets[i], size_t(packet_sizes[i]) };
-        pk[i] = d->d_kept_in + off; out[i] = d->d_kept + size_t(i) * d->kept_stride + RCGPU_KEPT_ROOM;
+        up[i].dst = d->d_kept_in + off; up[i].size = size_t(packet_sizes[i]);
+        if (packets) up[i].src = packets[i];
+        else { up[i].src = nullptr; up[i].fd = fd; up[i].off = offsets[i]; }
+        pk[i] = d->d_kept_in + off; out[i] = K.d + size_t(i) * d->kept_stride + RCGPU_KEPT_ROOM;
         off += (packet_sizes[i] + 255) & ~uint64_t(255);
     }
-    HIP_TRY(upload_side_by_side(d->up, d->cfg.device, up));
+    const hipError_t he = upload_side_by_side(d->up, d->cfg.device, up);
+    if (he == hipErrorFileNotFound) return fail(20, "ffv1 decoder: the file ends before a packet does");
+    HIP_TRY(he);
     clk.lap("decode_keep: packets up", n);
     uint32_t flags = 0;
     const int rc = rcgpu_ffv1_decoder_decode_device(d, pk.data(), packet_sizes, n, out.data(), &flags, d->own_stream);
     clk.lap("decode_keep: decoded", n);
-    if (!rc) d->kept_n = n;
+    if (!rc) K.n = n;
     return rc;
+}
+
+extern "C" int rcgpu_ffv1_decoder_decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n)
+{
+    clear_error();
+    if (!d || !packets || !packet_sizes) return fail(1, "ffv1 decoder: null argument");
+    return decode_keep(d, packets, -1, nullptr, packet_sizes, n);
+}
+
+extern "C" int rcgpu_ffv1_decoder_decode_keep_fd(rcgpu_ffv1_decoder* d, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n)
+{
+    clear_error();
+    if (!d || fd < 0 || !offsets || !packet_sizes) return fail(1, "ffv1 decoder: null argument");
+    return decode_keep(d, nullptr, fd, offsets, packet_sizes, n);
 }
 
 extern "C" int rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* d, uint32_t slot, uint8_t* payload)
 {
     clear_error();
     if (!d || !payload) return fail(1, "ffv1 decoder: null argument");
-    if (slot >= d->kept_n) return fail(2, "ffv1 decoder: slot %u of %u kept payloads", slot, d->kept_n);
+    const rcgpu_ffv1_decoder::kept_set& K = d->kept[d->kept_cur];
+    if (slot >= K.n) return fail(2, "ffv1 decoder: slot %u of %u kept payloads", slot, K.n);
     HIP_TRY(hipSetDevice(d->cfg.device));
     const size_t out_bytes = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
-    HIP_TRY(hipMemcpy(payload, d->d_kept + size_t(slot) * d->kept_stride + RCGPU_KEPT_ROOM, out_bytes, hipMemcpyDeviceToHost));
+    kept_clock clk;
+    HIP_TRY(hipMemcpy(payload, K.d + size_t(slot) * d->kept_stride + RCGPU_KEPT_ROOM, out_bytes, hipMemcpyDeviceToHost));
+    clk.lap("kept_to_host: slot", slot);
     return 0;
 }
 
-extern "C" int rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* d, const rcgpu_kept_file* files, uint32_t n, rcgpu_kept_verdict* verdicts)
+// The verification of a batch in two calls, so that the next batch can be decoded while this one is hashed (one lane per file: 0.8 s for
+// 53 MB files however many).  _begin copies what it needs of the caller's memory, uploads and compares the files on disk and starts the
+// hashes; _end waits for them.  Between the two, decode_keep fills the other set of slots.
+extern "C" int rcgpu_ffv1_decoder_verify_kept_begin(rcgpu_ffv1_decoder* d, const rcgpu_kept_file* files, uint32_t n)
 {
     clear_error();
-    if (!d || !files || !verdicts || !n) return fail(1, "ffv1 decoder: null argument");
+    if (!d || !files || !n) return fail(1, "ffv1 decoder: null argument");
+    if (d->kept[0].pending || d->kept[1].pending) return fail(2, "ffv1 decoder: a verification is waiting for rcgpu_ffv1_decoder_verify_kept_end");
     HIP_TRY(hipSetDevice(d->cfg.device));
+    rcgpu_ffv1_decoder::kept_set& K = d->kept[d->kept_cur];
     const size_t P = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
     const size_t disk_stride = (P + 255) & ~size_t(255);
     uint32_t n_md5 = 0, n_cmp = 0;
     for (uint32_t i = 0; i < n; i++) {
         const rcgpu_kept_file& f = files[i];
-        if (f.slot >= d->kept_n) return fail(2, "ffv1 decoder: slot %u of %u kept payloads", f.slot, d->kept_n);
+        if (f.slot >= K.n) return fail(2, "ffv1 decoder: slot %u of %u kept payloads", f.slot, K.n);
         if (f.before_size > RCGPU_KEPT_ROOM || f.after_size > RCGPU_KEPT_ROOM || (f.before_size && !f.before) || (f.after_size && !f.after))
             return fail(2, "ffv1 decoder: %llu bytes before and %llu after the payload (at most %u each)", (unsigned long long)f.before_size, (unsigned long long)f.after_size, RCGPU_KEPT_ROOM);
         for (uint32_t j = 0; j < i; j++) if (files[j].slot == f.slot) return fail(2, "ffv1 decoder: slot %u named twice", f.slot);
-        n_md5 += (f.flags & RCGPU_KEPT_MD5) != 0; n_cmp += f.on_disk != nullptr;
-        memset(verdicts[i].md5, 0, 16); verdicts[i].first_diff = ~uint64_t(0);
+        n_md5 += (f.flags & RCGPU_KEPT_MD5) != 0; n_cmp += f.on_disk != nullptr || f.on_disk_path != nullptr;
     }
     if (!d->side_stream) HIP_TRY(hipStreamCreateWithFlags(&d->side_stream, hipStreamNonBlocking));
+    if (!d->md5_stream) {
+        // the hashes are the background work of the next batch's decoding: lowest priority, which also gives the stream a hardware queue of
+        // its own (streams of one priority share a few queues, and whatever is queued behind the 0.8 s hash kernel there waits for it)
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&d->md5_stream, hipStreamNonBlocking, lo));
+    }
     if (!d->ev_tab) HIP_TRY(hipEventCreateWithFlags(&d->ev_tab, hipEventDisableTiming));
+    if (!d->ev_side) HIP_TRY(hipEventCreateWithFlags(&d->ev_side, hipEventDisableTiming));
     kept_clock clk;
     // the tables of both kernels -- pointers, lengths, results -- in one pinned block and its mirror on the device, 8 words per file:
     // [image, image bytes, payload, file's bytes, bytes to compare, first difference, md5 (2 words)] x n, array after array
-    if (d->tab_cap < n) {
-        if (d->h_tab) (void)hipHostFree(d->h_tab);
-        if (d->d_tab) (void)hipFree(d->d_tab);
-        d->h_tab = nullptr; d->d_tab = nullptr; d->tab_cap = 0;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_tab), size_t(n) * 64));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d->d_tab), size_t(n) * 64));
-        d->tab_cap = n;
+    if (K.tab_cap < n) {
+        if (K.h_tab) (void)hipHostFree(K.h_tab);
+        if (K.d_tab) (void)hipFree(K.d_tab);
+        K.h_tab = nullptr; K.d_tab = nullptr; K.tab_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&K.h_tab), size_t(n) * 64));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&K.d_tab), size_t(n) * 64));
+        K.tab_cap = n;
     }
-    uint64_t* h = d->h_tab; uint64_t* g = d->d_tab;
-    std::vector<uint32_t> img_of, cmp_of;
+    uint64_t* h = K.h_tab; uint64_t* g = K.d_tab;
+    K.img_of.clear(); K.cmp_of.clear(); K.part.clear();
     hipError_t he = hipSuccess;
-    // 1. the hashes: the bytes around the payload go next to it, one lane hashes one file; this runs beside everything below
+    // 1. the hashes: the bytes around the payload go next to it (on the side stream, which this call waits for: the caller's buffers are
+    // free when it returns), one lane hashes one file
+    // (through one pinned block: a copy from pageable memory waits for the stream every time, ~1 ms each, two per file)
+    size_t edge_bytes = 0;
+    for (uint32_t i = 0; i < n; i++) if (files[i].flags & RCGPU_KEPT_MD5) edge_bytes += size_t(files[i].before_size + files[i].after_size);
+    if (edge_bytes > d->edges_cap) {
+        if (d->h_edges) (void)hipHostFree(d->h_edges);
+        d->h_edges = nullptr; d->edges_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_edges), edge_bytes + (edge_bytes >> 2)));
+        d->edges_cap = edge_bytes + (edge_bytes >> 2);
+    }
+    size_t eo = 0;
     for (uint32_t i = 0; i < n && he == hipSuccess; i++) {
         const rcgpu_kept_file& f = files[i];
         if (!(f.flags & RCGPU_KEPT_MD5)) continue;
-        uint8_t* pay = d->d_kept + size_t(f.slot) * d->kept_stride + RCGPU_KEPT_ROOM;
-        if (f.before_size) he = hipMemcpyAsync(pay - f.before_size, f.before, f.before_size, hipMemcpyHostToDevice, d->own_stream);
-        if (f.after_size && he == hipSuccess) he = hipMemcpyAsync(pay + P, f.after, f.after_size, hipMemcpyHostToDevice, d->own_stream);
-        h[img_of.size()] = reinterpret_cast<uintptr_t>(pay - f.before_size); h[n + img_of.size()] = f.before_size + P + f.after_size;
-        img_of.push_back(i);
+        uint8_t* pay = K.d + size_t(f.slot) * d->kept_stride + RCGPU_KEPT_ROOM;
+        if (f.before_size) { memcpy(d->h_edges + eo, f.before, f.before_size); he = hipMemcpyAsync(pay - f.before_size, d->h_edges + eo, f.before_size, hipMemcpyHostToDevice, d->side_stream); eo += f.before_size; }
+        if (f.after_size && he == hipSuccess) { memcpy(d->h_edges + eo, f.after, f.after_size); he = hipMemcpyAsync(pay + P, d->h_edges + eo, f.after_size, hipMemcpyHostToDevice, d->side_stream); eo += f.after_size; }
+        h[K.img_of.size()] = reinterpret_cast<uintptr_t>(pay - f.before_size); h[n + K.img_of.size()] = f.before_size + P + f.after_size;
+        K.img_of.push_back(i);
     }
     // 2. the comparison (CheckFile_Compare over Pre, plane, Post, FileWriter.cpp:448-463,581-589, then the length, :200): the bytes
     // around the payload are compared here, the payload with the file's bytes on the device
+    // A file named by its path is read with pread(): its few bytes around the payload here, the rest straight into the staging buffers.
     std::vector<up_item> up;
+    std::vector<int> fds;                                   // open while their bytes go up; closed group by group (hundreds of files)
     if (n_cmp && he == hipSuccess) he = grow(d->d_disk, d->disk_cap, disk_stride * n_cmp);
     for (uint32_t i = 0; i < n && he == hipSuccess; i++) {
         const rcgpu_kept_file& f = files[i];
-        if (!f.on_disk) continue;
-        const uint64_t have = f.on_disk_size > f.before_size ? std::min<uint64_t>(f.on_disk_size - f.before_size, P) : 0;
-        uint8_t* dst = d->d_disk + cmp_of.size() * disk_stride;
-        if (have) up.push_back({ dst, f.on_disk + f.before_size, size_t(have) });
-        const size_t k = cmp_of.size();
-        h[2 * n + k] = reinterpret_cast<uintptr_t>(d->d_kept + size_t(f.slot) * d->kept_stride + RCGPU_KEPT_ROOM); h[3 * n + k] = reinterpret_cast<uintptr_t>(dst);
+        if (!f.on_disk && !f.on_disk_path) continue;
+        uint64_t disk_size = f.on_disk_size;
+        int fd = -1;
+        std::vector<uint8_t> head, tail;                    // what the file has where this file has `before` and `after`
+        if (!f.on_disk) {
+            struct stat st;
+            fd = open(f.on_disk_path, O_RDONLY);
+            if (fd < 0 || fstat(fd, &st) != 0) { if (fd >= 0) close(fd); for (int x : fds) close(x); return fail(20, "ffv1 decoder: cannot open %s: %s", f.on_disk_path, strerror(errno)); }
+            disk_size = uint64_t(st.st_size);
+            head.resize(size_t(std::min<uint64_t>(f.before_size, disk_size)));
+            const uint64_t t0 = f.before_size + P, t1 = std::min<uint64_t>(t0 + f.after_size, disk_size);
+            if (t1 > t0) tail.resize(size_t(t1 - t0));
+            if ((!head.empty() && pread(fd, head.data(), head.size(), 0) != ssize_t(head.size())) || (!tail.empty() && pread(fd, tail.data(), tail.size(), off_t(t0)) != ssize_t(tail.size()))) {
+                close(fd); for (int x : fds) close(x);
+                return fail(20, "ffv1 decoder: cannot read %s", f.on_disk_path);
+            }
+            fds.push_back(fd);
+        }
+        const uint64_t have = disk_size > f.before_size ? std::min<uint64_t>(disk_size - f.before_size, P) : 0;
+        uint8_t* dst = d->d_disk + K.cmp_of.size() * disk_stride;
+        if (have) { up_item it{ dst, f.on_disk ? f.on_disk + f.before_size : nullptr, size_t(have) }; it.fd = fd; it.off = f.before_size; up.push_back(it); }
+        const size_t k = K.cmp_of.size();
+        h[2 * n + k] = reinterpret_cast<uintptr_t>(K.d + size_t(f.slot) * d->kept_stride + RCGPU_KEPT_ROOM); h[3 * n + k] = reinterpret_cast<uintptr_t>(dst);
         h[4 * n + k] = have; h[5 * n + k] = ~uint64_t(0);
-        cmp_of.push_back(i);
+        rcgpu_ffv1_decoder::kept_set::host_part hp{ f.before_size + P + f.after_size, disk_size, f.before_size, ~uint64_t(0), ~uint64_t(0) };
+        const uint64_t common = std::min<uint64_t>(hp.mine, disk_size), nb = std::min<uint64_t>(f.before_size, common);
+        const uint8_t* dh = f.on_disk ? f.on_disk : head.data();
+        for (uint64_t q = 0; q < nb && hp.head_diff == ~uint64_t(0); q++) if (f.before[q] != dh[q]) hp.head_diff = q;
+        for (uint64_t q = f.before_size + P; q < common && hp.tail_diff == ~uint64_t(0); q++)
+            if (f.after[q - f.before_size - P] != (f.on_disk ? f.on_disk[q] : tail[size_t(q - f.before_size - P)])) hp.tail_diff = q;
+        K.part.push_back(hp);
+        K.cmp_of.push_back(i);
+        if (fds.size() >= 128 && he == hipSuccess) {       // this group's bytes go up now
+            he = upload_side_by_side(d->up, d->cfg.device, up);
+            up.clear();
+            for (int x : fds) close(x);
+            fds.clear();
+        }
     }
-    if (he == hipSuccess) he = hipMemcpyAsync(g, h, size_t(n) * 48, hipMemcpyHostToDevice, d->own_stream);
-    if (he == hipSuccess) he = hipEventRecord(d->ev_tab, d->own_stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(g, h, size_t(n) * 48, hipMemcpyHostToDevice, d->side_stream);
+    if (he == hipSuccess) he = hipEventRecord(d->ev_tab, d->side_stream);
+    // the hashes start now, on their own low-priority stream (a hardware queue of its own: the comparison queued below does not wait behind them)
     if (n_md5 && he == hipSuccess) {
-        hipLaunchKernelGGL(k_md5, dim3((n_md5 + 63) / 64), dim3(64), 0, d->own_stream, reinterpret_cast<const uint8_t* const*>(g), reinterpret_cast<const unsigned long long*>(g + n), n_md5,
-                           reinterpret_cast<uint8_t*>(g + 6 * size_t(n)));
-        he = hipGetLastError();
-        if (he == hipSuccess) he = hipMemcpyAsync(h + 6 * size_t(n), g + 6 * size_t(n), size_t(n_md5) * 16, hipMemcpyDeviceToHost, d->own_stream);
+        he = hipStreamWaitEvent(d->md5_stream, d->ev_tab, 0);
+        if (he == hipSuccess) {
+            hipLaunchKernelGGL(k_md5, dim3((n_md5 + 63) / 64), dim3(64), 0, d->md5_stream, reinterpret_cast<const uint8_t* const*>(g), reinterpret_cast<const unsigned long long*>(g + n), n_md5,
+                               reinterpret_cast<uint8_t*>(g + 6 * size_t(n)));
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipMemcpyAsync(h + 6 * size_t(n), g + 6 * size_t(n), size_t(n_md5) * 16, hipMemcpyDeviceToHost, d->md5_stream);
     }
     clk.lap("verify_kept: md5 launched", n_md5);
     if (n_cmp && he == hipSuccess) {
         he = upload_side_by_side(d->up, d->cfg.device, up);
+        for (int x : fds) close(x);
+        fds.clear();
+        if (he == hipErrorFileNotFound) return fail(20, "ffv1 decoder: a file on disk ended while it was read");
         clk.lap("verify_kept: files up", n_cmp);
-        if (he == hipSuccess) he = hipStreamWaitEvent(d->side_stream, d->ev_tab, 0);
         if (he == hipSuccess) {
             hipLaunchKernelGGL(k_compare_batch, dim3(64, n_cmp), dim3(256), 0, d->side_stream, reinterpret_cast<const uint8_t* const*>(g + 2 * size_t(n)), reinterpret_cast<const uint8_t* const*>(g + 3 * size_t(n)),
                                reinterpret_cast<const unsigned long long*>(g + 4 * size_t(n)), reinterpret_cast<unsigned long long*>(g + 5 * size_t(n)));
             he = hipGetLastError();
         }
         if (he == hipSuccess) he = hipMemcpyAsync(h + 5 * size_t(n), g + 5 * size_t(n), size_t(n_cmp) * 8, hipMemcpyDeviceToHost, d->side_stream);
-        const hipError_t hs = hipStreamSynchronize(d->side_stream);
-        if (he == hipSuccess) he = hs;
     }
-    clk.lap("verify_kept: compared", n_cmp);
-    const hipError_t hs = hipStreamSynchronize(d->own_stream);
+    // everything that reads the caller's memory is queued on the side stream: mark it and wait for the mark
+    if (he == hipSuccess) he = hipEventRecord(d->ev_side, d->side_stream);
+    const hipError_t hs = he == hipSuccess ? hipEventSynchronize(d->ev_side) : hipStreamSynchronize(d->side_stream);
     if (he == hipSuccess) he = hs;
-    clk.lap("verify_kept: md5 done", n_md5);
+    clk.lap("verify_kept: compared", n_cmp);
+    if (he != hipSuccess) { (void)hipStreamSynchronize(d->md5_stream); return fail(100, "ffv1 decoder: verify: %s", hipGetErrorString(he)); }
+    K.pending = true; K.pn = n; K.pn_md5 = n_md5; K.pn_cmp = n_cmp;
+    return 0;
+}
+
+extern "C" int rcgpu_ffv1_decoder_verify_kept_end(rcgpu_ffv1_decoder* d, rcgpu_kept_verdict* verdicts)
+{
+    clear_error();
+    if (!d || !verdicts) return fail(1, "ffv1 decoder: null argument");
+    rcgpu_ffv1_decoder::kept_set* Kp = d->kept[0].pending ? &d->kept[0] : d->kept[1].pending ? &d->kept[1] : nullptr;
+    if (!Kp) return fail(2, "ffv1 decoder: no verification was begun");
+    rcgpu_ffv1_decoder::kept_set& K = *Kp;
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    kept_clock clk;
+    K.pending = false;
+    const hipError_t he = hipStreamSynchronize(d->md5_stream);
+    clk.lap("verify_kept: md5 done", K.pn_md5);
     if (he != hipSuccess) return fail(100, "ffv1 decoder: verify: %s", hipGetErrorString(he));
-    const uint8_t* md5s = reinterpret_cast<const uint8_t*>(h + 6 * size_t(n));
-    const uint64_t* diffs = h + 5 * size_t(n);
-    for (uint32_t k = 0; k < n_md5; k++) memcpy(verdicts[img_of[k]].md5, &md5s[size_t(k) * 16], 16);
-    for (uint32_t k = 0; k < n_cmp; k++) {
-        const rcgpu_kept_file& f = files[cmp_of[k]];
-        const uint64_t mine = f.before_size + P + f.after_size, common = std::min<uint64_t>(mine, f.on_disk_size);
-        uint64_t at = ~uint64_t(0);
-        const uint64_t nb = std::min<uint64_t>(f.before_size, common);
-        for (uint64_t q = 0; q < nb && at == ~uint64_t(0); q++) if (f.before[q] != f.on_disk[q]) at = q;
-        if (at == ~uint64_t(0) && diffs[k] != ~uint64_t(0)) at = f.before_size + diffs[k];
-        for (uint64_t q = f.before_size + P; q < common && at == ~uint64_t(0); q++) if (f.after[q - f.before_size - P] != f.on_disk[q]) at = q;
-        if (at == ~uint64_t(0) && mine != f.on_disk_size) at = common;
-        verdicts[cmp_of[k]].first_diff = at;
+    const size_t n = K.pn;
+    const uint8_t* md5s = reinterpret_cast<const uint8_t*>(K.h_tab + 6 * n);
+    const uint64_t* diffs = K.h_tab + 5 * n;
+    for (size_t i = 0; i < n; i++) { memset(verdicts[i].md5, 0, 16); verdicts[i].first_diff = ~uint64_t(0); }
+    for (uint32_t k = 0; k < K.pn_md5; k++) memcpy(verdicts[K.img_of[k]].md5, &md5s[size_t(k) * 16], 16);
+    for (uint32_t k = 0; k < K.pn_cmp; k++) {
+        const auto& hp = K.part[k];
+        uint64_t at = hp.head_diff;
+        if (at == ~uint64_t(0) && diffs[k] != ~uint64_t(0)) at = hp.before_size + diffs[k];
+        if (at == ~uint64_t(0)) at = hp.tail_diff;
+        if (at == ~uint64_t(0) && hp.mine != hp.on_disk_size) at = std::min<uint64_t>(hp.mine, hp.on_disk_size);
+        verdicts[K.cmp_of[k]].first_diff = at;
     }
     return 0;
+}
+
+extern "C" int rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* d, const rcgpu_kept_file* files, uint32_t n, rcgpu_kept_verdict* verdicts)
+{
+    if (!verdicts) { clear_error(); return fail(1, "ffv1 decoder: null argument"); }
+    if (const int rc = rcgpu_ffv1_decoder_verify_kept_begin(d, files, n)) return rc;
+    return rcgpu_ffv1_decoder_verify_kept_end(d, verdicts);
 }
 
 extern "C" int rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* d, float ms[3])

@@ -138,6 +138,42 @@ def test_check_with_the_payloads_kept_on_the_device(built):
     assert got == [(bytes(16), -1)]
     dec.decode_keep(packets[4:6])
     assert dec.verify_kept([{"slot": 1, "before": b"ab", "after": b"c", "on_disk": b"ab" + srcs[5] + b"c"}]) == [(hashlib.md5(b"ab" + srcs[5] + b"c").digest(), -1)]
+    # the packets by their place in a file, the files on disk by their names (read with pread() instead of through mappings)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        blob, offs = b"head", []
+        for pk in packets:
+            offs.append(len(blob)); blob += pk + b"--"
+        open(os.path.join(tmp, "all.bin"), "wb").write(blob)
+        fd = os.open(os.path.join(tmp, "all.bin"), os.O_RDONLY)
+        dec.decode_keep_fd(fd, offs, [len(pk) for pk in packets])
+        assert [dec.kept_to_host(i, len(srcs[i])) for i in range(n)] == srcs
+        with pytest.raises(api.RcgpuError, match="file ends"):
+            dec.decode_keep_fd(fd, [offs[0], len(blob) - 10], [len(packets[0]), len(packets[1])])
+        os.close(fd)
+        dec.decode_keep(packets)
+        named = []
+        for i in range(n):
+            if disk[i] is not None:
+                open(os.path.join(tmp, "f%d" % i), "wb").write(disk[i])
+                named.append(i)
+        got = dec.verify_kept([{"slot": i, "before": before[i], "after": after[i], "on_disk_path": os.path.join(tmp, "f%d" % i)} for i in named])
+        assert got == [(hashlib.md5(files[i]).digest(), want_diff[i]) for i in named]
+        with pytest.raises(api.RcgpuError, match="cannot open"):
+            dec.verify_kept([{"slot": 0, "before": b"", "after": b"", "on_disk_path": os.path.join(tmp, "nothing")}])
+    # in two calls: the next batch is decoded (into a second set of slots) while the files of this one are hashed
+    dec.decode_keep(packets[:4])
+    dec.verify_kept([{"slot": i, "before": before[i], "after": after[i], "on_disk": disk[i]} for i in (2, 0, 3)], begin_only=True)
+    with pytest.raises(api.RcgpuError, match="waiting"):
+        dec.verify_kept([{"slot": 1, "before": b"", "after": b""}])
+    dec.decode_keep(packets[5:7])
+    assert dec.kept_to_host(1, len(srcs[6])) == srcs[6]
+    dec.decode_keep(packets[5:7])                                       # ... and once more: the waiting set is left alone
+    assert dec.verify_kept_end() == [(hashlib.md5(files[i]).digest(), want_diff[i]) for i in (2, 0, 3)]
+    with pytest.raises(api.RcgpuError, match="no verification"):
+        dec.verify_kept_end()
+    assert dec.verify_kept([{"slot": 0, "before": b"x", "after": b"", "on_disk": b"x" + srcs[5]}]) == [(hashlib.md5(b"x" + srcs[5]).digest(), -1)]
+    dec.decode_keep(packets[4:6])
     for bad in ([{"slot": 2, "before": b"", "after": b""}], [{"slot": 0, "before": bytes(65537), "after": b""}],
                 [{"slot": 0, "before": b"", "after": b""}, {"slot": 0, "before": b"", "after": b""}]):
         with pytest.raises(api.RcgpuError):
