@@ -224,6 +224,17 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
                 ru = resource.getrusage(resource.RUSAGE_CHILDREN)
                 out[name]["children_cpu_seconds_so_far"] = {"user": round(ru.ru_utime, 2), "system": round(ru.ru_stime, 2), "minor_faults": ru.ru_minflt}
                 out[name]["trace"] = [ln[ln.index("rcgpu "):] for ln in r.stderr.replace("\r", "\n").split("\n") if "rcgpu " in ln]
+        if not variants or "whole_product" in variants:
+            # and the product as a user runs it: one process analyses the sources (route D), encodes them (route B), and checks the MKV it wrote (route C)
+            os.rename(os.path.join(big, "seq.mkv"), os.path.join(big, "muxed_by_the_bench.mkv"))
+            r = run([exe, "--no-check-padding", "--check", "--hash", "-y", "seq"], big, env=dict(os.environ, RCGPU_CHECK="1", RCGPU_CHECK_BATCH=batch), timeout=300)
+            ok = r.returncode == 0 and OKL in r.stdout
+            same = ok and os.path.getsize(os.path.join(big, "seq.mkv")) > 0
+            if os.environ.get("RCGPU_TRACE_KEPT"):
+                out["whole_product_trace"] = [ln[ln.index("rcgpu"):] for ln in r.stderr.replace("\r", "\n").split("\n") if "rcgpu" in ln][:60]
+            out["whole_product"] = {"value": round(n / r.seconds, 2), "frames": n, "seconds": round(r.seconds, 2), "verdict": OKL if ok else (r.stdout + r.stderr)[-200:],
+                                    "what": "rawcooked_linked --check --hash -y <folder>: analysis with the MD5 of every source, FFV1 encoding into a Matroska file, and the check of that file, "
+                                            "process start to exit", "mkv_bytes": os.path.getsize(os.path.join(big, "seq.mkv")) if same else 0}
         if out.get("reference_cpu_pool", {}).get("value") and "device_decoder" in out:
             out["speedup"] = round(out["device_decoder"]["value"] / out["reference_cpu_pool"]["value"], 2)
         out["what"] = (f"oracle/_ref/rawcooked_linked --check on an MKV of {n} {width}x{height} frames (this run's packets, tmpfs), process start to exit: the reference's own demuxer, "

@@ -176,12 +176,16 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
             rcgpu_ffv1_config c = videos[vi].cfg;
             c.device = L.device;
             if (li == 0) {
-                // frames in flight: what the device holds (85 % of its free memory, shared by the job's tracks), at most 336 -- where
-                // k_resolve's time, which grows with the batch, meets the serial range-coder chain of a slice, which does not
-                //  --, and evened out over the batches of the sequence
+                // frames in flight: what the device holds (85 % of its free memory, shared by the job's tracks), at most 336 frames of 64 slices
+                // = 21504 slice chains -- where k_resolve's time, which grows with the batch, meets the serial range-coder chain of a slice,
+                // which does not --, and evened out over the batches of the sequence.  The bound is in CHAINS: the 576
+                // slices RAWcooked asks for at 4K (DPX.cpp:428-458) fill the device with 40 frames (571 frames/s; 546 with 256, whose 71 GB of
+                // context states alone take 4.3 s to allocate).
                 const uint64_t per = std::max<uint64_t>(1, ffv1_device_bytes_per_frame(c));
                 const uint64_t share = videos.size() * uint64_t((cnt + ndev_used - 1) / ndev_used);      // encoders that will live on this device
-                uint64_t f = opt.batch ? opt.batch : std::min<uint64_t>(336 / uint64_t((cnt + ndev_used - 1) / ndev_used), uint64_t(double(free_b) * 0.85 / double(share)) / per);
+                const uint64_t slices = std::max<uint64_t>(1, uint64_t(c.num_h_slices) * c.num_v_slices);
+                const uint64_t by_chains = std::min<uint64_t>(336, std::max<uint64_t>(8, (336 * 64 + slices - 1) / slices));
+                uint64_t f = opt.batch ? opt.batch : std::min<uint64_t>(std::max<uint64_t>(1, by_chains / uint64_t((cnt + ndev_used - 1) / ndev_used)), uint64_t(double(free_b) * 0.85 / double(share)) / per);
                 f = std::max<uint64_t>(1, f);
                 const uint64_t n = std::max<uint64_t>(1, videos[vi].frames);
                 const uint64_t per_lane = (n + uint64_t(cnt) - 1) / uint64_t(cnt);
