@@ -1139,6 +1139,8 @@ extern "C" int rcgpu_ffv1_decoder_verify_kept_begin(rcgpu_ffv1_decoder* d, const
         }
         if (he == hipSuccess) he = hipMemcpyAsync(h + 5 * size_t(n), g + 5 * size_t(n), size_t(n_cmp) * 8, hipMemcpyDeviceToHost, d->side_stream);
     }
+    for (int x : fds) close(x);                              // (an error on the way here skipped the upload that closes them)
+    fds.clear();
     // everything that reads the caller's memory is queued on the side stream: mark it and wait for the mark
     if (he == hipSuccess) he = hipEventRecord(d->ev_side, d->side_stream);
     const hipError_t hs = he == hipSuccess ? hipEventSynchronize(d->ev_side) : hipStreamSynchronize(d->side_stream);
