@@ -215,6 +215,10 @@ typedef struct {
     uint32_t in_ring_frames;            /* pinned upload slots; 0 = automatic */
     uint64_t out_ring_bytes;            /* pinned download ring per device; 0 = automatic */
     uint32_t lanes_per_device;          /* encoder instances per device, their batches staggered (shorter head and tail of a job); 0 = 1 */
+    uint32_t copy_streams;              /* copy streams per direction and lane; 0 = automatic (two: one stream's copies run strictly one after the other) */
+    uint32_t device_aliases;            /* test hook, 0 or 1 = off: k > 1 presents every physical device k times to device_first / device_count, so
+                                           that the lane-per-device path (one encoder, ring and set of copy streams per device, one placer across
+                                           them) runs on a box with a single GPU; the lanes then share its memory -- pass `batch` */
 } rcgpu_sequence_options;
 typedef struct {
     double   seconds;                   /* first read_frame .. last packet_done */

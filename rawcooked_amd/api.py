@@ -14,6 +14,8 @@ from dataclasses import dataclass, field
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librcgpu.so")
+if os.environ.get("RCGPU_LIB"):      # the measuring tools load the timing build (make -C rawcooked_amd/csrc timing) this way; nothing else does
+    LIB_PATH = os.path.abspath(os.environ["RCGPU_LIB"])
 
 
 class RcgpuError(RuntimeError):
@@ -49,7 +51,8 @@ class SequenceIo(C.Structure):
 
 class SequenceOptions(C.Structure):
     _fields_ = [("device_first", C.c_int), ("device_count", C.c_int), ("batch", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
-                ("in_ring_frames", C.c_uint32), ("out_ring_bytes", C.c_uint64), ("lanes_per_device", C.c_uint32)]
+                ("in_ring_frames", C.c_uint32), ("out_ring_bytes", C.c_uint64), ("lanes_per_device", C.c_uint32),
+                ("copy_streams", C.c_uint32), ("device_aliases", C.c_uint32)]
 
 
 class SequenceStats(C.Structure):
@@ -322,7 +325,7 @@ class Ffv1Encoder:
 
 
 def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, place_packet=None, batch=0, readers=0, writers=0,
-                    in_ring_frames=0, out_ring_bytes=0, device_first=0, device_count=0, lanes_per_device=0):
+                    in_ring_frames=0, out_ring_bytes=0, device_first=0, device_count=0, lanes_per_device=0, copy_streams=0, device_aliases=0):
     """rcgpu_ffv1_encode_sequence: `read_frame(frame, dst_address, nbytes) -> int` fills a pinned upload slot, `packet_done(frame,
     address, size) -> int` receives each packet (writer threads), `place_packet(frame, size) -> address or None` is optional.
     Returns (SequenceStats, configuration record)."""
@@ -330,7 +333,7 @@ def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, pla
     pd = PACKET_DONE_FN(lambda user, frame, data, n: int(packet_done(frame, data, n) or 0))
     pp = PLACE_PACKET_FN(lambda user, frame, n: place_packet(frame, n) or 0) if place_packet else PLACE_PACKET_FN()
     io = SequenceIo(rf, pp, pd, None)
-    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes, lanes_per_device)
+    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes, lanes_per_device, copy_streams, device_aliases)
     st = SequenceStats()
     rec = C.create_string_buffer(8192)
     rs = _SZ(8192)
@@ -339,12 +342,12 @@ def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, pla
 
 
 def encode_sequence_memory(cfg: Ffv1Config, frame_addrs: list[int], n_frames: int, out_addrs: list[int], out_cap: int, batch=0, readers=0, writers=0,
-                           device_first=0, device_count=0, lanes_per_device=0, in_ring_frames=0):
+                           device_first=0, device_count=0, lanes_per_device=0, in_ring_frames=0, copy_streams=0, device_aliases=0):
     """rcgpu_ffv1_encode_sequence_memory: frame i = frame_addrs[i % len], packet i -> out_addrs[i % len].  Returns (stats, sizes)."""
     fin = (_VP * len(frame_addrs))(*frame_addrs)
     fout = (_VP * len(out_addrs))(*out_addrs) if out_addrs else None
     sizes = (C.c_uint64 * n_frames)()
-    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, 0, lanes_per_device)
+    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, 0, lanes_per_device, copy_streams, device_aliases)
     st = SequenceStats()
     _check(lib().rcgpu_ffv1_encode_sequence_memory(C.byref(cfg), fin, len(frame_addrs), n_frames, fout, len(out_addrs), out_cap, sizes, C.byref(opt), C.byref(st), None, None),
            "rcgpu_ffv1_encode_sequence_memory")

@@ -358,18 +358,16 @@ __device__ const act_masks kActMasks = make_act_masks();
 // through LDS need no barrier and, above all, no s_waitcnt vmcnt(0) -- which __syncthreads() implies and which would put the HBM
 // latency of every prefetch and store on the critical path.  Only the compiler must keep the order.
 #define WAVE_SYNC() asm volatile("" ::: "memory")
-// Timing build (-DRCGPU_EXP_PROF, tools/prof_resolve.py): the shader clock around the phases of a chunk, summed over all wavefronts.
-#ifdef RCGPU_EXP_PROF
+// Timing build only (make timing PROF=1: -DRCGPU_TIMING_BUILD -DRCGPU_TIMING_PROF, tools/prof_resolve.py): the shader clock around the phases
+// of a chunk, summed over all wavefronts.  The shipped library holds none of it.
+#if defined(RCGPU_TIMING_BUILD) && defined(RCGPU_TIMING_PROF)
+#define RCGPU_PROF 1
 __device__ unsigned long long g_prof[16];
 #define PROF_T(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); prof[i] += now_ - tlast; tlast = now_; }
 #else
 #define PROF_T(i)
 #endif
-#ifdef RCGPU_EXP_SLOTMAJOR
-#define OPI(k) (((k) & 31) * 64)
-#else
 #define OPI(k) (k)
-#endif
 template <bool LDS_STATES>
 __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(const enc_const* __restrict__ C, const slice_geom* __restrict__ geom,
                                                 const uint16_t* __restrict__ hdr, const uint32_t* __restrict__ sym,
@@ -492,7 +490,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     flush_full();
 
     const unsigned long long lane_bit = 1ull << lane;
-#ifdef RCGPU_EXP_PROF
+#ifdef RCGPU_PROF
     unsigned long long prof[12] = {}; unsigned long long tlast = __builtin_readcyclecounter();
 #endif
     // Software pipeline over chunks of 64 symbols.  While chunk k is binarised, the symbols of chunk k+2 and the context states of
@@ -611,11 +609,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         unsigned long long done = 0;
         bool pending = valid;
         uint8_t* sl = LDS_STATES ? lstates + size_t(key) * 32 : slot + leader * 32;
-        #ifdef RCGPU_EXP_SLOTMAJOR
-        uint8_t* op = stage + lane;                     // timing build: decision slot k of lane l at k * 64 + l -- no two lanes of a store share a bank
-#else
         uint8_t* op = stage + stage_count + excl;
-#endif
         {   // the coded bits of this lane's decisions do not depend on any state: zero flag | e ones, a zero | mantissa from the top | sign.
             // 2e + 3 bits: one dword unless some lane of the chunk has e >= 15 (emax is uniform)
             const uint32_t o = stage_count + excl, w = o >> 5, sh = o & 31;
@@ -772,12 +766,12 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         stage_count += total;
         flush_full();
         PROF_T(7)
-#ifdef RCGPU_EXP_PROF
+#ifdef RCGPU_PROF
         prof[8] += 1;
 #endif
         ppack = (valid ? key : 0xFFFFu) | uint32_t(leader) << 16;
     }
-#ifdef RCGPU_EXP_PROF
+#ifdef RCGPU_PROF
     if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_prof[i], prof[i]);
 #endif
     if (!last_seg) {      // park the unfinished piece and the bitmap (or the state table) for the next segment
@@ -1376,7 +1370,7 @@ struct rcgpu_ffv1 {
     hipStream_t rr_stream = nullptr;                            // split coder: k_rc_range's stream (the spans are coded on rc_stream)
     uint32_t span_pieces = 0;                                   // split coder: pieces per span; 0 = one lane codes a whole slice
     uint32_t resolve_prio = 0;                                  // k_resolve's s_setprio
-    bool exp_skip_rc = false;                                   // RCGPU_EXP_SKIP_RC: no range coder at all (timing runs of k_resolve alone; no valid output)
+    bool exp_skip_rc = false;                                   // timing build only: no range coder at all (k_resolve alone; no valid output)
     rc_ckpt* d_ckpt = nullptr; size_t ckpt_cap = 0;             // [span of the batch][chain]
     std::vector<uint32_t> seg_spans, seg_span_off;
     // device buffers
@@ -1508,9 +1502,9 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     {
         const size_t waves = (size_t(cfg->max_batch) * S + 63) / 64;
         e->span_pieces = cfg->rc_span == RCGPU_RC_WHOLE ? 0u : cfg->rc_span ? cfg->rc_span : (waves < 300 && e->sp.version != 1 ? 64u : 0u);
-        e->exp_skip_rc = getenv("RCGPU_EXP_SKIP_RC") != nullptr;
-        if (const char* x = getenv("RCGPU_RESOLVE_PRIO")) e->resolve_prio = uint32_t(atoi(x));        // for measuring
-        if (const char* x = getenv("RCGPU_RC_SPAN")) { const int v = atoi(x); e->span_pieces = v >= 8 ? uint32_t(v) : 0u; }      // for measuring
+        e->exp_skip_rc = TIMING_ENV("RCGPU_EXP_SKIP_RC") != nullptr;
+        if (const char* x = TIMING_ENV("RCGPU_RESOLVE_PRIO")) e->resolve_prio = uint32_t(atoi(x));        // for measuring
+        if (const char* x = TIMING_ENV("RCGPU_RC_SPAN")) { const int v = atoi(x); e->span_pieces = v >= 8 ? uint32_t(v) : 0u; }      // for measuring
     }
     // Measured (4096x2160, 336 frames, round 3): k_resolve alone 390 / 372 / 408 / 431 / 509 / 617 ms per step at 16 / 12 / 10 / 8 / 6 / 4
     // wavefronts per CU; beside the whole-slice range coder 10 per CU (16 000 B) is best, beside the split coder 11-12 (13 600 B): the
@@ -1518,7 +1512,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     {
         const size_t have = size_t(kResolveFixedLds) + e->resolve_lds;
         size_t want = e->lds_states ? 0 : e->span_pieces ? 13600 : 16000;
-        if (const char* x = getenv("RCGPU_RESOLVE_LDS_TOTAL")) want = size_t(atoi(x));
+        if (const char* x = TIMING_ENV("RCGPU_RESOLVE_LDS_TOTAL")) want = size_t(atoi(x));
         if (want > have) e->resolve_lds += want - have;
     }
     if (e->lds_states) { e->resolve_lds += size_t(e->nkeys) * 32; e->resume_stride = uint32_t(80 + e->nkeys * 32); }
@@ -1539,7 +1533,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     // the split coder keeps a window until its spans are coded, two kernels behind k_resolve: a third window keeps k_resolve from waiting
     // (4096x2160, 168 frames per step: 476 frames/s with two windows, 565 with three or four)
     e->nwin = e->span_pieces ? kWindows + 1 : kWindows;
-    if (const char* x = getenv("RCGPU_WINDOWS")) e->nwin = uint32_t(std::min<int>(kMaxWindows, std::max(2, atoi(x))));       // for measuring
+    if (const char* x = TIMING_ENV("RCGPU_WINDOWS")) e->nwin = uint32_t(std::min<int>(kMaxWindows, std::max(2, atoi(x))));       // for measuring
 
     // slice geometry (FFV1_Slice.cpp:153-156), header decisions, raw-byte buffers
     std::vector<uint16_t> hdr;
@@ -1629,7 +1623,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(hip_stream);       // NULL = the default stream: ordered after the caller's earlier work
     hipStream_t s2 = e->rc_stream;
-    static const bool exp_serial = getenv("RCGPU_EXP_SERIAL") != nullptr;      // timing runs: every kernel alone on the device, one after the other
+    static const bool exp_serial = TIMING_ENV("RCGPU_EXP_SERIAL") != nullptr;      // timing runs: every kernel alone on the device, one after the other
     if (exp_serial) s2 = st;
     const enc_const& c = e->hc;
     const uint32_t S = c.S, nchains = n * S, ngroups = (nchains + 63) / 64, nseg = e->nseg;
@@ -1739,7 +1733,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
                                                           j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, nchains, ck, e->span_pieces, nsp); }));
             HIP_TRY(hipEventRecord(e->ev_rr[j], s3));
             HIP_TRY(hipStreamWaitEvent(s2, e->ev_rr[j], 0));
-            static const bool exp_skip_b = getenv("RCGPU_EXP_SKIP_B") != nullptr;        // timing runs: no span coder (no valid output)
+            static const bool exp_skip_b = TIMING_ENV("RCGPU_EXP_SKIP_B") != nullptr;        // timing runs: no span coder (no valid output)
             if (!exp_skip_b)
             HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<true>, dim3(ngroups, nsp), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
                                                           j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
@@ -1764,6 +1758,10 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         HIP_TRY(timed(6, s2, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                       e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
     }
+#ifdef RCGPU_TIMING_BUILD
+    // a timing run that skipped a coder has no valid packets: the batch says so in its error word, whoever reads it
+    if (e->exp_skip_rc || TIMING_ENV("RCGPU_EXP_SKIP_B")) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_err), 8, 1, s2));
+#endif
     HIP_TRY(hipEventRecord(e->ev_fork, s2));
     HIP_TRY(hipStreamWaitEvent(st, e->ev_fork, 0));
     HIP_TRY(hipGetLastError());
@@ -1869,6 +1867,7 @@ const char* ffv1_error_flags_text(uint32_t flags)
     if (flags & 1u) return "a slice outgrew its byte buffer (content expands beyond 1.5x raw)";
     if (flags & 2u) return "a slice does not fit its footer / the 24-bit slice size field";
     if (flags & 4u) return "more late carries than the event table holds";
+    if (flags & 8u) return "timing build: a coder was switched off, the packets are not FFV1";
     return "unknown device error";
 }
 
@@ -2023,7 +2022,7 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
     }
 }
 
-#ifdef RCGPU_EXP_PROF
+#ifdef RCGPU_PROF
 extern "C" int rcgpu_debug_prof(unsigned long long* out)      // timing build only: see PROF_T
 {
     unsigned long long z[16] = {};

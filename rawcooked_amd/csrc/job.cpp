@@ -180,10 +180,10 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     const bool vflip_all = opt.has("vf");
     uint32_t context = uint32_t(opt.num("context", 0));
     const uint32_t slicecrc = uint32_t(opt.num("slicecrc", 1));
-    // -context 1 uses FFmpeg's level maps unless the compact 5-input model is asked for (RCGPU_CONTEXT_MODEL=compact or
-    // the option rcgpu_context_model=compact): same bitstream syntax, tables in the configuration record, states in LDS
+    // -context 1 uses FFmpeg's level maps unless the compact 5-input model is asked for (the option rcgpu_context_model=compact; on the
+    // shim's command line `-rcgpu_context_model compact`): same bitstream syntax, tables in the configuration record, states in LDS.
+    // An option like every other that changes bytes -- never the environment.
     const char* model = opt.get("rcgpu_context_model");
-    if (!model) model = getenv("RCGPU_CONTEXT_MODEL");
     if (context == 1 && model && !strcmp(model, "compact")) context = 2;
     const bool overwrite = opt.has("y") && !opt.has("n");
     if (!overwrite && file_exists(job->output_path)) return bail(fail(3, "output file %s already exists (use -y)", job->output_path));

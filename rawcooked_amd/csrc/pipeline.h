@@ -47,6 +47,8 @@ struct pipe_options {
     uint32_t readers = 0, writers = 0;           // host threads; 0 = automatic
     uint32_t in_slots = 0;                       // pinned upload slots; 0 = automatic
     uint64_t out_ring_bytes = 0;                 // pinned download ring per lane; 0 = automatic
+    uint32_t device_aliases = 0;                 // test hook: every physical device presented this many times (0, 1 = as they are)
+    uint32_t copy_streams = 0;                   // copy streams per direction and lane; 0 = automatic (two)
     bool trace = false;
 };
 

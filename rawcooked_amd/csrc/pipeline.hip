@@ -147,11 +147,12 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
     if (videos.empty()) return fail(1, "pipeline: no video");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(4, "no HIP device available -- rcgpu has no CPU encode path");
-    // Test hook (tests/test_gpu_pipeline.py): RCGPU_TEST_DEVICE_ALIASES=k presents every physical device k times, so that the lane-per-device
-    // path -- a lane with its own encoder, copy streams, events and ring per entry of device_first/device_count, one placer across them --
-    // runs on a box with a single GPU.  The lanes then share that GPU's memory: the test passes its own batch size.
+    // Test hook (rcgpu_sequence_options::device_aliases; tests/test_gpu_pipeline.py, bench.py --gpus N on a one-GPU box): every physical
+    // device is presented k times, so that the lane-per-device path -- a lane with its own encoder, copy streams, events and ring per entry
+    // of device_first/device_count, one placer across them -- runs on a box with a single GPU.  The lanes then share that GPU's memory:
+    // the caller passes its own batch size.
     const int ndev_phys = ndev;
-    if (const char* x = getenv("RCGPU_TEST_DEVICE_ALIASES")) ndev *= std::max(1, std::min(8, atoi(x)));
+    if (opt.device_aliases > 1) ndev *= int(std::min(8u, opt.device_aliases));
     const int dev0 = std::max(0, opt.device_first);
     int cnt = opt.device_count > 0 ? opt.device_count : ndev - dev0;
     if (dev0 >= ndev || cnt <= 0) return fail(4, "device selection %d+%d is outside the %d visible devices", dev0, opt.device_count, ndev);
@@ -212,7 +213,7 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
         // the pipeline itself got faster).  Measured, frames/s between the first and the last batch: 529 with one stream per direction,
         // 643 with two (= the device-resident rate), 649 with three, 460 with four.
         uint32_t ncopy = cnt > ndev_used ? 1 : kCopyStreams;         // several lanes on a device: their streams add up, and four per direction were worse
-        if (const char* x = getenv("RCGPU_COPY_STREAMS")) ncopy = uint32_t(std::max(1, std::min(8, atoi(x))));
+        if (opt.copy_streams) ncopy = std::min(8u, opt.copy_streams);
         L.cin.assign(ncopy, nullptr); L.cout.assign(ncopy, nullptr); L.join_ev.assign(2 * ncopy, nullptr);
         for (uint32_t k = 0; k < ncopy; k++)
             if (hipStreamCreateWithPriority(&L.cin[k], hipStreamNonBlocking, prio_greatest) != hipSuccess ||
@@ -252,7 +253,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     // takes 8.1 s instead of 7.1 s, host to host 550 instead of 573 frames/s.  For callers that want the first packet early, not the last.
     std::vector<batch_t> batches; std::vector<uint32_t> batch_of(N);
     std::vector<uint32_t> made(s.videos.size(), 0);
-    static const bool ramp = getenv("RCGPU_RAMP") != nullptr;
+    static const bool ramp = TIMING_ENV("RCGPU_RAMP") != nullptr;
     for (size_t i = 0; i < N;) {
         const uint32_t v = frames[i].video;
         size_t cap = s.F[v];
@@ -284,7 +285,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         // (chunks of an earlier run() on this pipeline are kept, and their size with them)
         if (L.chunks.empty()) L.chunk_bytes = std::max<size_t>(2 * max_pkt, size_t(std::min<uint64_t>(uint64_t(256) << 20, ((total_need / 2 + 4095) & ~uint64_t(4095)))));
         uint64_t want = s.opt.out_ring_bytes ? s.opt.out_ring_bytes : std::min<uint64_t>(uint64_t(4) << 30, std::max<uint64_t>(uint64_t(1) << 30, uint64_t(maxF) * max_payload));
-        if (const char* x = getenv("RCGPU_OUT_RING_MB")) if (!s.opt.out_ring_bytes && atoll(x) > 0) want = uint64_t(atoll(x)) << 20;        // for sizing experiments
+        if (const char* x = TIMING_ENV("RCGPU_OUT_RING_MB")) if (!s.opt.out_ring_bytes && atoll(x) > 0) want = uint64_t(atoll(x)) << 20;        // for sizing experiments
         want = std::min<uint64_t>(want, std::max<uint64_t>(total_need, L.chunk_bytes));
         L.max_chunks = total_need ? std::max<size_t>(2, size_t((want + L.chunk_bytes - 1) / L.chunk_bytes)) : 0;      // a lane without batches pins nothing
         L.cur = -1; L.cur_off = 0; L.outq.clear(); std::fill(L.outstanding.begin(), L.outstanding.end(), 0); L.up_span_valid = false; L.upload_wait = 0; L.h2d_span = 0; L.copy_calls = L.dl_calls = L.dl_wait = 0;
@@ -727,7 +728,8 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
     pipe_video v; v.cfg = *cfg; v.frames = n_frames;
     pipe_options po;
     if (opt) { po.device_first = opt->device_first; po.device_count = opt->device_count; po.readers = opt->readers; po.writers = opt->writers;
-               po.in_slots = opt->in_ring_frames; po.out_ring_bytes = opt->out_ring_bytes; po.batch = opt->batch; po.lanes_per_device = opt->lanes_per_device; }
+               po.in_slots = opt->in_ring_frames; po.out_ring_bytes = opt->out_ring_bytes; po.batch = opt->batch; po.lanes_per_device = opt->lanes_per_device;
+               po.device_aliases = opt->device_aliases; po.copy_streams = opt->copy_streams; }
     if (const char* e = getenv("RCGPU_LANES")) if (!po.lanes_per_device) po.lanes_per_device = uint32_t(std::max(1, atoi(e)));
     if (!po.batch) po.batch = cfg->max_batch > 1 ? cfg->max_batch : 0;
     po.trace = getenv("RCGPU_TRACE") != nullptr;

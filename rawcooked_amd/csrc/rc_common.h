@@ -8,6 +8,17 @@
 #include <vector>
 #include "rcgpu.h"
 
+// Measuring switches -- kernels skipped, mappings forced, copy-stream counts -- exist in the TIMING build only (`make timing`:
+// librcgpu_timing.so, -DRCGPU_TIMING_BUILD; tools/sweep_*.sh and tools/ab.sh load it through RCGPU_LIB).  The shipped library reads none of
+// them: the only inputs that change its bytes are the fields of its configuration structs, as the reference's only ones are its
+// command line's (CLI/Global.cpp:938-989).
+#ifdef RCGPU_TIMING_BUILD
+#include <cstdlib>
+#define TIMING_ENV(name) getenv(name)
+#else
+#define TIMING_ENV(name) static_cast<const char*>(nullptr)
+#endif
+
 namespace rc {
 
 // Thread-local error text behind rcgpu_last_error().  Returns `code` so callers can `return fail(...)`.

@@ -168,14 +168,15 @@ def test_flipped_byte_is_detected(built, refbin, tmp_path):
 
 
 def test_reference_accepts_compact_context_model(built, refbin, tmp_path):
-    """RCGPU_CONTEXT_MODEL=compact: custom quantisation tables travel in the configuration record; the reference's decoder must
+    """`-rcgpu_context_model compact` (an output option of the shim, rcgpu_job::options): custom quantisation tables travel in the configuration record; the reference's decoder must
     rebuild the sources from them (FFV1_Parameters.cpp:206-253 parses any monotone table)."""
     work = str(tmp_path)
     make_package(work, 160, 90, synth.PIX_RGB16_BE, 3, "film", audio=(2, 24, 48000, 5000))
     r = run([refbin, "--hash", "--no-check-padding", "-d", "-y", "pkg"], work)
     assert r.returncode == 0, r.stdout + r.stderr
     argv = shlex.split(r.stdout.strip())
-    r = subprocess.run([SHIM] + argv[1:], cwd=work, capture_output=True, text=True, env=dict(os.environ, RCGPU_CONTEXT_MODEL="compact"))
+    at = argv.index("-coder")          # among the output options (CLI/Output.cpp:273-278)
+    r = run([SHIM] + argv[1:at] + ["-rcgpu_context_model", "compact"] + argv[at:], work)
     assert r.returncode == 0, r.stdout + r.stderr
     compact_size = os.path.getsize(os.path.join(work, "pkg.mkv"))
     r = run([refbin, "--check", "pkg.mkv"], work)

@@ -160,17 +160,16 @@ def test_several_lanes_return_packets_in_frame_order(lanes, n, batch):
 @pytest.mark.parametrize("aliases,first,count,n,batch", [(2, 0, 2, 41, 6), (4, 1, 3, 50, 4), (3, 0, 0, 37, 5)])
 def test_a_lane_per_device_through_device_first_and_count(monkeypatch, aliases, first, count, n, batch):
     """The multi-GPU path proper -- a lane per entry of device_first / device_count, each with its own encoder, pinned ring, copy streams and
-    events, one placer across them -- on a box with one GPU: RCGPU_TEST_DEVICE_ALIASES presents the device several times (the lanes share
-    its memory, hence the explicit batch).  No 8-GPU node has run this code yet; this is the closest one GPU gets."""
+    events, one placer across them -- on a box with one GPU: rcgpu_sequence_options::device_aliases presents the device several times (the
+    lanes share its memory, hence the explicit batch).  No 8-GPU node has run this code yet; this is the closest one GPU gets."""
     import numpy as np
-    monkeypatch.setenv("RCGPU_TEST_DEVICE_ALIASES", str(aliases))
     w, h, pixfmt, n_in = 128, 72, synth.PIX_RGB16_BE, 7
     payloads, line_bytes = _sequence(w, h, pixfmt, n_in)
     src = [np.frombuffer(p, dtype=np.uint8).copy() for p in payloads]
     out_cap = len(payloads[0]) * 2
     outs = [np.zeros(out_cap, dtype=np.uint8) for _ in range(n)]
     cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 2, 2, 1, 1, 0, 0, 0, 0, 1, 3)
-    st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], n, [a.ctypes.data for a in outs], out_cap, batch=batch, device_first=first, device_count=count)
+    st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], n, [a.ctypes.data for a in outs], out_cap, batch=batch, device_first=first, device_count=count, device_aliases=aliases)
     usable = (aliases - first) if count == 0 else min(count, aliases - first)
     assert st.frames == n and st.devices == min(usable, (n + 7) // 8), (st.devices, usable)
     p = ob.Params(w, h, pixfmt, 2, 2, 1, 1)
@@ -178,7 +177,7 @@ def test_a_lane_per_device_through_device_first_and_count(monkeypatch, aliases, 
     for i in range(n):
         assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
     with pytest.raises(api.RcgpuError, match="outside"):
-        api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], 4, [a.ctypes.data for a in outs], out_cap, batch=2, device_first=aliases, device_count=1)
+        api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], 4, [a.ctypes.data for a in outs], out_cap, batch=2, device_first=aliases, device_count=1, device_aliases=aliases)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RCGPU_SOAK_PIPE", "6"))))      # soak: RCGPU_SOAK_PIPE=200
@@ -191,7 +190,7 @@ def test_random_pipeline_shapes_equal_the_oracle(seed, monkeypatch):
     pixfmt = r.choice([synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGB8])
     n = r.choice([1, 2, 7, 19, 33, 50, 77])
     nh, nv = r.choice([(1, 1), (2, 2), (3, 2)])
-    monkeypatch.setenv("RCGPU_COPY_STREAMS", str(r.choice([1, 2, 3])))
+    copy_streams = r.choice([1, 2, 3])
     payloads, line_bytes = _sequence(w, h, pixfmt, min(n, 12), kind=r.choice(["film", "noise", "flat"]))
     keep = [C.create_string_buffer(p, len(p)) for p in payloads]
     cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, nh, nv, 1, 1, 0, 0, 0, 0, 1, 3)
@@ -210,7 +209,7 @@ def test_random_pipeline_shapes_equal_the_oracle(seed, monkeypatch):
 
     st, _ = api.encode_sequence(cfg, n, read_frame, packet_done, batch=r.choice([0, 1, 3, 8, 16]), in_ring_frames=r.choice([0, 2, 3, 9]),
                                 out_ring_bytes=r.choice([0, 1 << 16, 1 << 20]), readers=r.choice([1, 2, 5]), writers=r.choice([1, 3]),
-                                lanes_per_device=r.choice([0, 1, 2]))
+                                lanes_per_device=r.choice([0, 1, 2]), copy_streams=copy_streams)
     assert st.frames == n and sorted(got) == list(range(n))
     p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
     want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
@@ -222,7 +221,6 @@ def test_random_pipeline_shapes_equal_the_oracle(seed, monkeypatch):
 def test_hd_sequence_with_real_transfers_equals_the_oracle(copy_streams, lanes, monkeypatch):
     """1920x1080 frames (12 MB payloads, ~11 MB packets): uploads, kernels and downloads really overlap here; a download ring of two
     chunks and eight upload slots keep every recycling path busy.  Packets are the oracle's, in any stream / lane arrangement."""
-    monkeypatch.setenv("RCGPU_COPY_STREAMS", str(copy_streams))
     w, h, pixfmt, n, distinct = 1920, 1080, synth.PIX_RGB16_BE, 60, 6
     payloads, line_bytes = _sequence(w, h, pixfmt, distinct)
     keep = [C.create_string_buffer(p, len(p)) for p in payloads]
@@ -239,7 +237,7 @@ def test_hd_sequence_with_real_transfers_equals_the_oracle(copy_streams, lanes, 
             got[frame] = b
         return 0
 
-    st, _ = api.encode_sequence(cfg, n, read_frame, packet_done, batch=7, in_ring_frames=8, out_ring_bytes=1 << 20, readers=4, writers=3, lanes_per_device=lanes)
+    st, _ = api.encode_sequence(cfg, n, read_frame, packet_done, batch=7, in_ring_frames=8, out_ring_bytes=1 << 20, readers=4, writers=3, lanes_per_device=lanes, copy_streams=copy_streams)
     assert st.frames == n and sorted(got) == list(range(n))
     p = ob.Params(w, h, pixfmt, 4, 4, 1, 1)
     want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]

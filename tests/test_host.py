@@ -39,6 +39,25 @@ def test_product_does_not_link_the_oracle(built):
             assert "oracle" not in open(os.path.join(ROOT, "rawcooked_amd", "csrc", fn)).read().replace("oracle/flac_oracle.c", "").replace("scalar oracle", "").replace("the oracle", "").replace("oracle's", "").replace("oracle ", "")
 
 
+def test_shipped_library_has_no_switch_that_changes_bytes(built):
+    """The measuring switches -- kernels skipped, coder mappings forced, device aliases -- exist in the timing build only (`make timing`,
+    -DRCGPU_TIMING_BUILD).  The shipped library and shim read no environment variable that can change a byte of the output: the
+    reference's only such switches are its command line's (CLI/Global.cpp:938-989)."""
+    csrc = os.path.join(ROOT, "rawcooked_amd", "csrc")
+    allowed = {"RCGPU_BATCH", "RCGPU_DEVICES", "RCGPU_LANES", "RCGPU_MKV_MMAP", "RCGPU_MKV_NO_MMAP", "RCGPU_READERS", "RCGPU_WRITERS",
+               "RCGPU_RELEASE_AT_EXIT", "RCGPU_TRACE", "RCGPU_TRACE_KEPT", "RCGPU_UPLOAD_THREADS"}      # sizing and tracing: same bytes
+    for path in (api.LIB_PATH, os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")):
+        names = set(re.findall(rb"RCGPU_[A-Z0-9_]+", open(path, "rb").read()))
+        names = {n.decode() for n in names if not n.startswith((b"RCGPU_PIX_", b"RCGPU_FLAG_", b"RCGPU_RC_WHOLE", b"RCGPU_KEPT_"))}
+        assert names <= allowed, names - allowed
+    for fn in os.listdir(csrc):
+        if fn.endswith((".cpp", ".hip", ".h")):
+            text = open(os.path.join(csrc, fn)).read()
+            assert "#ifdef RCGPU_EXP" not in text, fn
+            for m in re.finditer(r'[^_A-Z]getenv\("(RCGPU_[A-Z0-9_]+)"\)', text):
+                assert m.group(1) in allowed, (fn, m.group(1))
+
+
 @pytest.mark.skipif(api.lib().rcgpu_device_count() > 0, reason="GPU present")
 def test_no_gpu_means_loud_failure_not_fallback(built, tmp_path):
     with pytest.raises(api.RcgpuError, match="no HIP device"):
