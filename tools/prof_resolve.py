@@ -1,4 +1,5 @@
-"""Where do k_resolve's cycles go?  Needs a library built with -DRCGPU_EXP_PROF (timing build: s_memtime around the phases of a chunk,
+"""Where do k_resolve's cycles go?  Needs the timing build with the probes: `make -C rawcooked_amd/csrc timing PROF=1`,
+then RCGPU_LIB=rawcooked_amd/librcgpu_timing.so (s_memtime around s_memtime around the phases of a chunk,
 summed over all wavefronts).  Usage on the GPU box:  python tools/prof_resolve.py [bench.py arguments]"""
 import ctypes as C
 import io
