@@ -109,20 +109,31 @@ struct rd_lane {
     uint32_t pos, n;                  // bytes consumed so far (Buffer_Cur - Buffer) and size of the slice's coded data
     uint32_t win_hi, win_lo, nwin;    // window: the next nwin bytes, left aligned in win_hi:win_lo; zeros stand in once the data is used up
     unsigned long long pend; uint32_t npend;
+    unsigned long long pend2; uint32_t have2;     // the second half of a 16-byte load, waiting to become `pend`
     const uint8_t* next; const uint8_t* end;      // first byte not yet loaded, end of the coded data
 };
 
-__device__ __forceinline__ unsigned long long rd_load(const uint8_t* p, uint32_t avail, uint32_t& got)
+// The slice's bytes come 16 at a time (one request per lane and 16 bytes: every lane reads a line of its own, and a line that is asked
+// for eight bytes at a time is fetched eight times once thousands of wavefronts share the caches); the last bytes one by one.
+__device__ __forceinline__ void rd_load(rd_lane& r)
 {
-    if (avail >= 8) {
-        const uint32_t lo = *reinterpret_cast<const uint32_t*>(p), hi = *reinterpret_cast<const uint32_t*>(p + 4);   // unaligned loads are fine in global memory
-        got = 8;
-        return (unsigned long long)__builtin_bswap32(lo) << 32 | __builtin_bswap32(hi);
+    const uint32_t avail = r.next < r.end ? uint32_t(r.end - r.next) : 0u;
+    if (avail >= 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(r.next);                              // unaligned loads are fine in global memory
+        r.pend = (unsigned long long)__builtin_bswap32(v.x) << 32 | __builtin_bswap32(v.y);
+        r.pend2 = (unsigned long long)__builtin_bswap32(v.z) << 32 | __builtin_bswap32(v.w);
+        r.have2 = 1; r.next += 16;
+    } else if (avail >= 8) {
+        const uint32_t lo = *reinterpret_cast<const uint32_t*>(r.next), hi = *reinterpret_cast<const uint32_t*>(r.next + 4);
+        r.pend = (unsigned long long)__builtin_bswap32(lo) << 32 | __builtin_bswap32(hi);
+        r.next += 8;
+    } else {
+        unsigned long long v = 0;
+        for (uint32_t i = 0; i < avail; i++) v |= (unsigned long long)r.next[i] << (56 - 8 * i);     // last bytes of the slice: never read past them
+        r.pend = v;                                                                                   // ... and zeros after them (FFV1_RangeCoder.cpp:79-85)
+        r.next += avail;
     }
-    unsigned long long v = 0;
-    for (uint32_t i = 0; i < avail; i++) v |= (unsigned long long)p[i] << (56 - 8 * i);     // last bytes of the slice: never read past them
-    got = 8;                                                                                 // ... and zeros after them (FFV1_RangeCoder.cpp:79-85)
-    return v;
+    r.npend = 8;
 }
 // At a sample boundary (all lanes converged): move arrived bytes into the window, then put the next load in flight.
 __device__ __forceinline__ void rd_refill(rd_lane& r)
@@ -135,9 +146,8 @@ __device__ __forceinline__ void rd_refill(rd_lane& r)
         r.npend -= k; r.nwin += k;
     }
     if (!r.npend) {
-        uint32_t got = 8;
-        r.pend = r.next < r.end ? rd_load(r.next, uint32_t(r.end - r.next), got) : 0ull;       // past the end: zeros
-        r.npend = got; r.next += r.next < r.end ? min(got, uint32_t(r.end - r.next)) : 0u;
+        if (r.have2) { r.pend = r.pend2; r.npend = 8; r.have2 = 0; }
+        else rd_load(r);
     }
 }
 
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     if (len < tail) { atomicOr(err, 8u); return; }
     const uint8_t* buf = packets[f] + slice_start[chain];
     rd_lane r;
-    r.n = len - tail; r.pos = 1; r.win_hi = r.win_lo = 0; r.pend = 0; r.nwin = r.npend = 0; r.next = buf; r.end = buf + r.n;
+    r.n = len - tail; r.pos = 1; r.win_hi = r.win_lo = 0; r.pend = r.pend2 = 0; r.nwin = r.npend = r.have2 = 0; r.next = buf; r.end = buf + r.n;
     rd_refill(r); rd_refill(r);
     r.current = r.win_hi >> 24; r.win_hi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24); r.win_lo <<= 8; r.nwin--;   // AssignBuffer, FFV1_RangeCoder.cpp:22-33
     r.mask = 0xFF;
@@ -380,20 +390,26 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     const uint32_t W = C->W, H = C->H, np = C->planes;
     const uint32_t x0 = uint32_t((unsigned long long)sx * W / C->num_h), y0 = uint32_t((unsigned long long)sy * H / C->num_v);
     const uint32_t w = uint32_t((unsigned long long)(sx + 1) * W / C->num_h) - x0, h = uint32_t((unsigned long long)(sy + 1) * H / C->num_v) - y0;
-    // RING: no picture-sized planes.  A lane keeps the last three lines of each plane of its slice ([plane][y % 3][ring_w]) and
-    // packs a picture line into the payload as soon as its last plane is decoded: 125 instead of 230 MB per frame in flight.
-    const size_t plane_sz = RING ? size_t(3) * ring_w : size_t(W) * H;
+    // RING: no picture-sized planes.  A lane keeps the last three lines of each plane of its slice and packs a picture line into the
+    // payload as soon as its last plane is decoded: 125 instead of 230 MB per frame in flight.  The rings of the 64 slices of a wavefront
+    // are INTERLEAVED: element (plane p, ring row r, column x) of lane l lies at ((p * 3 + r) * ring_w + x) * 64 + l of the wavefront's
+    // block.  All lanes of a wavefront are at the same p, y and x (one instruction stream), so the store of cur[x], the fetches of
+    // prev[x + 2] and pp[x + 1] and the packer's reads are ONE 256-byte access per wave instruction; with a ring of its own per lane each of
+    // them touched 64 lines for 4 bytes apiece -- 5.5 of the kernel's 7.4 GB of HBM traffic per 4K frame (profiles/r03g_check_pmc_*).
+    const size_t plane_sz = RING ? size_t(3) * ring_w : size_t(W) * H;          // elements of one plane of one lane / of one picture plane
     const uint32_t pitch = RING ? ring_w : W;
-    int32_t* fp = RING ? planes + size_t(chain) * np * plane_sz : planes + size_t(f) * np * plane_sz + size_t(y0) * W + x0;
+    constexpr size_t xs = RING ? 64 : 1;                                         // distance between neighbouring columns, in elements
+    const size_t pstride = plane_sz * xs;                                        // distance between planes
+    int32_t* fp = RING ? planes + size_t(blockIdx.x) * 64 * np * plane_sz + lane : planes + size_t(f) * np * plane_sz + size_t(y0) * W + x0;
     uint8_t* st_base = states + size_t(chain) * nkeys * 32;          // pre-set to 128 by the host (states_coded = 0)
     const bool is5 = C->is5, ov16 = C->overflow16, rgb = C->rgb;
     const int32_t bitmask = int32_t((1u << C->bits) - 1);
     const uint32_t nctx = C->nctx;
     for (uint32_t y = 0; y < h; y++)
         for (uint32_t p = 0; p < np; p++) {
-            int32_t* cur = fp + p * plane_sz + size_t(RING ? y % 3 : y) * pitch;
-            const int32_t* prev = RING ? fp + p * plane_sz + size_t((y + 2) % 3) * pitch : cur - W;                  // valid when y >= 1
-            const int32_t* pp = RING ? fp + p * plane_sz + size_t((y + 1) % 3) * pitch : cur - 2 * size_t(W);        // valid when y >= 2
+            int32_t* cur = fp + p * pstride + size_t(RING ? y % 3 : y) * pitch * xs;
+            const int32_t* prev = RING ? fp + p * pstride + size_t((y + 2) % 3) * pitch * xs : cur - W;                  // valid when y >= 1
+            const int32_t* pp = RING ? fp + p * pstride + size_t((y + 1) % 3) * pitch * xs : cur - 2 * size_t(W);        // valid when y >= 2
             const uint32_t set = rgb ? (p + 1) >> 1 : 0;
             // edge rules of SliceContent_LineThenPlane (FFV1_Slice.cpp:427-441): cur[-1] = prev[0], prev[w] = prev[w-1],
             // everything above the slice is 0, cur[-2] is 0
@@ -401,12 +417,12 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
             int32_t LT = y >= 2 ? pp[0] : 0;
             int32_t T = y ? prev[0] : 0;
             // the two neighbours that come from memory are fetched one sample ahead
-            int32_t RTn = y ? (1 < w ? prev[1] : T) : 0, TTn = y >= 2 ? pp[0] : 0;
+            int32_t RTn = y ? (1 < w ? prev[xs] : T) : 0, TTn = y >= 2 ? pp[0] : 0;
             for (uint32_t x = 0; x < w; x++) {
                 rd_refill(r);
                 const int32_t RT = RTn, TT = TTn;
-                RTn = y ? (x + 2 < w ? prev[x + 2] : RT) : 0;
-                TTn = y >= 2 && x + 1 < w ? pp[x + 1] : 0;
+                RTn = y ? (x + 2 < w ? prev[size_t(x + 2) * xs] : RT) : 0;
+                TTn = y >= 2 && x + 1 < w ? pp[size_t(x + 1) * xs] : 0;
                 int32_t ctx = q[0][(L - LT) & 0xFF] + q[1][(LT - T) & 0xFF] + q[2][(T - RT) & 0xFF];
                 if (is5) ctx += q[3][(LL - L) & 0xFF] + q[4][(TT - T) & 0xFF];
                 int32_t v = ov16 ? med3(int16_t(L), int16_t(L) + int16_t(T) - int16_t(LT), int16_t(T)) : med3(L, L + T - LT, T);
@@ -418,19 +434,19 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                 const int32_t delta = rd_s_regs(r, sw, t16);
                 gp[0] = make_uint4(sw[0], sw[1], sw[2], sw[3]); gp[1] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
                 v = (ctx >= 0 ? v + delta : v - delta) & bitmask;
-                cur[x] = v;
+                cur[size_t(x) * xs] = v;
                 LL = L; L = v; LT = T; T = RT;
             }
             if (RING && p + 1 == np) {                                // the picture line is complete: inverse RCT + pack, Transform.cpp From()
                 const uint32_t gy = y0 + y;
                 uint8_t* line = payloads[f] + size_t(C->vflip ? H - 1 - gy : gy) * C->line_bytes;
-                const int32_t* r0 = fp + size_t(y % 3) * pitch;
+                const int32_t* r0 = fp + size_t(y % 3) * pitch * xs;
                 for (uint32_t xb = 0; xb < w; xb += 8) {               // eight pixels' loads in flight together, then their stores
                     int32_t a0[8], a1[8], a2[8], a3[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        const uint32_t x = min(xb + uint32_t(j), w - 1);
-                        a0[j] = r0[x]; a1[j] = np > 1 ? r0[plane_sz + x] : 0; a2[j] = np > 1 ? r0[2 * plane_sz + x] : 0; a3[j] = np > 3 ? r0[3 * plane_sz + x] : 0;
+                        const size_t x = size_t(min(xb + uint32_t(j), w - 1)) * xs;
+                        a0[j] = r0[x]; a1[j] = np > 1 ? r0[pstride + x] : 0; a2[j] = np > 1 ? r0[2 * pstride + x] : 0; a3[j] = np > 3 ? r0[3 * pstride + x] : 0;
                     }
 #pragma unroll
                     for (int j = 0; j < 8; j++)
@@ -754,7 +770,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     // the word-stream layouts share words between neighbouring slices and keep the planes + k_pack_words route
     d->ring = c.fields == kFieldsBytes || c.fields == kFieldsExr;
     d->ring_w = (c.W + c.num_h - 1) / c.num_h + 1;
-    DM(d->d_planes, d->ring ? nchains * c.planes * 3 * d->ring_w * 4 : size_t(F) * c.planes * c.W * c.H * 4); DM(d->d_err, 16);
+    DM(d->d_planes, d->ring ? (nchains + 63) / 64 * 64 * c.planes * 3 * d->ring_w * 4 : size_t(F) * c.planes * c.W * c.H * 4); DM(d->d_err, 16);      // rings: interleaved per wavefront of 64 chains
 #undef DM
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_ptrs), sizeof(void*) * F * 2);
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_sizes), 8 * F);

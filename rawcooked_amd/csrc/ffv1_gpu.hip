@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                                                 uint8_t* __restrict__ resume, uint32_t resume_stride, uint32_t prio)
 {
     // Issue priority against the range coder's wavefronts on the same SIMD (the split coder's spans run at 0, its serial pass at 3).
-    if (prio == 1) __builtin_amdgcn_s_setprio(1); else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    if ((prio & 0xFF) == 1) __builtin_amdgcn_s_setprio(1); else if ((prio & 0xFF) == 2) __builtin_amdgcn_s_setprio(2);
     // One launch handles segment `seg` of every slice.  What must survive between launches -- the < 56 decisions that
     // did not fill a piece -- lives in `resume` (per chain: count, entries, their bits).  The context states of a batch are preset
     // to 128 in HBM by the host (states_coded = 0): 20 MB per 4K frame, against 3 GB of traffic the kernel itself causes.
@@ -404,7 +404,16 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     const slice_geom G = geom[s];
     const uint32_t nctx = C->nctx;
     const uint32_t* in = sym + size_t(f) * C->samples_per_frame + G.sym_off;
+#ifdef RCGPU_TIMING_BUILD
+    // RCGPU_EXP_STATES_L2 (timing build only; wrong bytes, right work): every state record this wavefront gathers and writes back lies in
+    // a 1 MB region that stays in the L2 -- the kernel with everything but the HBM latency of its state traffic: its floor
+    const bool l2res = (prio & 0x100) != 0;
+    uint8_t* st_base = l2res ? states + size_t(chain & 1023) * 1024 : states + size_t(chain) * nkeys * 32;
+#define ST_KEY(k) (l2res ? ((k) & 31u) : (k))
+#else
     uint8_t* st_base = states + size_t(chain) * nkeys * 32;
+#define ST_KEY(k) (k)
+#endif
     // interleaved decision stream: piece k of this chain lives at group base + (k*64 + lane_of_chain)*64
     uint32_t* out32 = reinterpret_cast<uint32_t*>(stream + group_off[chain >> 6]) + (chain & 63) * 16;
 
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
     uint32_t sv_nxt = sym_begin + 64 + lane < sym_end ? in[sym_begin + 64 + lane] : 0;
     uint4 P0 = make_uint4(0, 0, 0, 0), P1 = P0;
     if (!LDS_STATES && sym_begin + lane < sym_end) {
-        const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(key_of(sv_cur)) * 32);
+        const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(ST_KEY(key_of(sv_cur))) * 32);
         P0 = gp[0]; P1 = gp[1];
     }
     uint32_t ppack = 0xFFFFu;             // previous chunk: this lane's key (keys stay below 2^14; 0xFFFF = none yet) | its group's slot << 16
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
         // --- next chunk's states and the symbols after it leave for HBM now
         sv_cur = sv_nxt;
         if (!LDS_STATES && i + 64 < sym_end) {
-            const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(key_of(sv_nxt)) * 32);
+            const uint4* gp = reinterpret_cast<const uint4*>(st_base + size_t(ST_KEY(key_of(sv_nxt))) * 32);
             P0 = gp[0]; P1 = gp[1];
         }
         sv_nxt = i + 128 < sym_end ? in[i + 128] : 0;
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
                 const uint32_t info = uint32_t(__shfl(int(wb), h * 32 + (lane >> 1)));
                 if (info != 0xFFFFFFFFu) {
                     const uint32_t half = uint32_t(lane & 1) * 16u;
-                    *reinterpret_cast<uint4*>(st_base + size_t(info & 0xFFFFu) * 32 + half) = *reinterpret_cast<const uint4*>(slot + (info >> 16) * 32 + half);
+                    *reinterpret_cast<uint4*>(st_base + size_t(ST_KEY(info & 0xFFFFu)) * 32 + half) = *reinterpret_cast<const uint4*>(slot + (info >> 16) * 32 + half);
                 }
             }
         }
@@ -793,6 +802,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_resolve(c
 
 // ---------------------------------------------------------------------------------------------------------
 #undef WAVE_SYNC
+#undef ST_KEY
 
 // K4: range coder, one LANE per slice (chain).  The 64 chains of a wavefront read the same piece index of their
 // interleaved streams each iteration and run the low/range recurrence of RFC 9043 3.8.1 in lock-step.
@@ -1504,6 +1514,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         e->span_pieces = cfg->rc_span == RCGPU_RC_WHOLE ? 0u : cfg->rc_span ? cfg->rc_span : (waves < 300 && e->sp.version != 1 ? 64u : 0u);
         e->exp_skip_rc = TIMING_ENV("RCGPU_EXP_SKIP_RC") != nullptr;
         if (const char* x = TIMING_ENV("RCGPU_RESOLVE_PRIO")) e->resolve_prio = uint32_t(atoi(x));        // for measuring
+        if (TIMING_ENV("RCGPU_EXP_STATES_L2")) e->resolve_prio |= 0x100;                                  // k_resolve's floor without HBM latency (wrong bytes)
         if (const char* x = TIMING_ENV("RCGPU_RC_SPAN")) { const int v = atoi(x); e->span_pieces = v >= 8 ? uint32_t(v) : 0u; }      // for measuring
     }
     // Measured (4096x2160, 336 frames, round 3): k_resolve alone 390 / 372 / 408 / 431 / 509 / 617 ms per step at 16 / 12 / 10 / 8 / 6 / 4
@@ -1760,7 +1771,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     }
 #ifdef RCGPU_TIMING_BUILD
     // a timing run that skipped a coder has no valid packets: the batch says so in its error word, whoever reads it
-    if (e->exp_skip_rc || TIMING_ENV("RCGPU_EXP_SKIP_B")) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_err), 8, 1, s2));
+    if (e->exp_skip_rc || TIMING_ENV("RCGPU_EXP_SKIP_B") || TIMING_ENV("RCGPU_EXP_STATES_L2")) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_err), 8, 1, s2));
 #endif
     HIP_TRY(hipEventRecord(e->ev_fork, s2));
     HIP_TRY(hipStreamWaitEvent(st, e->ev_fork, 0));
