@@ -13,6 +13,14 @@ TEST INFRASTRUCTURE.  Checks, with the RFC section each comes from:
     present exactly once, slice_width_minus1 / slice_height_minus1 keep the rectangle inside the grid, quant_table_set_index <
     quant_table_set_count per plane group, picture_structure in 0..3, no sar_num without a sar_den
 The range decoder below is the one of RFC 9043 section 3.8.1 (binary arithmetic coder, 3.8.1.2 "unsigned/signed integer symbols").
+
+`decode_frame` goes further than structure: it decodes every SAMPLE of a frame with code written from the RFC's text alone -- border
+(3.1), sample positions (3.2), median predictor and its 16-bit exception (3.3), quantisation table sets and the context (3.4, 3.5, 4.9),
+JPEG 2000 RCT with the offset and the BGR exception for 9..15 bits without alpha (3.7.2), sample differences folded to `bits` (3.8),
+signed symbols (3.8.1.2), line-interleaved planes of an RGB slice (3.7.2 / 4.6), sentinel-mode termination (3.8.1.1.1) -- so that three
+independent decoders (the reference's, the oracle's restatement of it, and this one) must agree on every golden packet.  There is no
+network in this environment: "from the RFC" means from the published text as its author of this file knows it, not from a copy at hand;
+what stays unpinned is FFmpeg itself.
 """
 from __future__ import annotations
 
@@ -243,6 +251,139 @@ def validate_frame(r: Record, packet: bytes, width: int, height: int) -> dict:
         assert x1 > x0 and y1 > y0, "empty slice"
     assert len(seen) == r.num_h_slices * r.num_v_slices, "some grid positions are not covered by any slice"
     return {"slices": len(slices), "bytes": len(packet)}
+
+
+def _quant_full(levels128: list[int]) -> list[int]:
+    """4.9: a table covers the differences 0..127 as coded; -1..-127 are the negated values, 128 (= -128) mirrors 127."""
+    t = list(levels128) + [0] * 128
+    for i in range(1, 128):
+        t[256 - i] = -t[i]
+    t[128] = -t[127]
+    return t
+
+
+def decode_frame(r: Record, packet: bytes, width: int, height: int, only=None):
+    """All samples of one version-3 intra frame, decoded from the RFC: returns a list of rows, each a list of pixels, each a tuple of
+    components in picture order -- (R, G, B[, A]) for colorspace_type 1, (Y,) for a single plane.  `only`: a set of slice numbers (in
+    bitstream order) to decode; the pixels of the others stay None (a 4K slice takes this pure-Python loop a quarter of a minute)."""
+    rgb = r.colorspace_type == 1
+    assert rgb or not r.chroma_planes, "decode_frame: YCbCr with chroma planes is outside this repository's formats"
+    nplanes = (3 + r.alpha_plane) if rgb else 1
+    bps = r.bits_per_raw_sample
+    bits = bps + 1 if rgb else bps                               # 3.8: RGB differences have one more bit (the RCT widens Cb, Cr)
+    mask = (1 << bits) - 1
+    cast16 = (not rgb) and bps == 16                             # 3.3 exception: l, t, tl as int16 for 16-bit YCbCr with the range coder
+    swap_gb = rgb and not r.alpha_plane and 9 <= bps <= 15       # 3.7.2 exception: B and G trade places
+    one, zero = r.one_state, [0] * 256
+    for i in range(1, 256):
+        zero[i] = (256 - one[256 - i]) & 0xFF                    # 3.8.1.5 zero_state_i = 256 - one_state_(256 - i)
+    out = [[None] * width for _ in range(height)]
+    for n, (a, b) in enumerate(split_slices(r, packet)):
+        if only is not None and n not in only:
+            continue
+        tail = 8 if r.ec else 3
+        rd = RangeDecoder(packet[a:b - tail], one)
+        if n == 0:
+            assert rd.bit([128] * 32, 0) == 1                    # 4.4 keyframe
+        st = [128] * 32
+        sx, sy = rd.symbol(st, False), rd.symbol(st, False)
+        sw, sh = rd.symbol(st, False) + 1, rd.symbol(st, False) + 1
+        nidx = 2 + (1 if r.alpha_plane else 0)
+        qidx = [rd.symbol(st, False) for _ in range(nidx)]
+        rd.symbol(st, False); rd.symbol(st, False); rd.symbol(st, False)        # picture_structure, sar_num, sar_den
+        x0, x1 = sx * width // r.num_h_slices, (sx + sw) * width // r.num_h_slices      # 4.5.x slice_pixel_*
+        y0, y1 = sy * height // r.num_v_slices, (sy + sh) * height // r.num_v_slices
+        w, h = x1 - x0, y1 - y0
+        # per plane group: the five tables of its set, and 32 states of 128 per context (states_coded == 0, keyframe)
+        group_of = [0, 1, 1, 2][:nplanes]
+        Q = [[_quant_full(t) for t in r.tables[qidx[g]]] for g in range(len(qidx))]
+        states = [[[128] * 32 for _ in range(r.context_count[qidx[g]])] for g in range(len(qidx))]
+        assert not any(r.states_coded), "decode_frame: initial states in the record are not used by this repository"
+        # three rows per plane with the 3.1 border: two columns to the left, one to the right
+        rows = [[[0] * (w + 3) for _ in range(3)] for _ in range(nplanes)]
+        d, dlen = rd.d, len(rd.d)
+        low, rng, pos = rd.low, rd.range, rd.pos
+        for y in range(h):
+            for p in range(nplanes):
+                g = group_of[p]
+                q0, q1, q2, q3, q4 = Q[g]
+                five = q3[127] != 0 or q4[127] != 0
+                stp = states[g]
+                cur, prev, pprev = rows[p][y % 3], rows[p][(y + 2) % 3], rows[p][(y + 1) % 3]
+                if y == 0:
+                    for i in range(w + 3): prev[i] = 0
+                if y <= 1:
+                    for i in range(w + 3): pprev[i] = 0
+                # column index = x + 2.  3.1: the column left of the slice is the leftmost column shifted down by one row (0 on top),
+                # the one right of it repeats the rightmost, the second column to the left and everything above are 0
+                cur[0] = 0
+                cur[1] = prev[2] if y else 0
+                prev[w + 2] = prev[w + 1]
+                for x in range(w):
+                    i = x + 2
+                    L2, l = cur[i - 2], cur[i - 1]
+                    tl, t, tr, T2 = prev[i - 1], prev[i], prev[i + 1], pprev[i]
+                    ctx = q0[(l - tl) & 255] + q1[(tl - t) & 255] + q2[(t - tr) & 255]
+                    if five:
+                        ctx += q3[(L2 - l) & 255] + q4[(T2 - t) & 255]
+                    if cast16:
+                        ls = ((l & 0xFFFF) ^ 0x8000) - 0x8000; ts = ((t & 0xFFFF) ^ 0x8000) - 0x8000; tls = ((tl & 0xFFFF) ^ 0x8000) - 0x8000
+                        grad = ls + ts - tls
+                        pred = sorted((ls, ts, grad))[1]
+                    else:
+                        grad = l + t - tl
+                        pred = l if (t <= l <= grad or grad <= l <= t) else t if (l <= t <= grad or grad <= t <= l) else grad
+                    neg = ctx < 0
+                    if neg:
+                        ctx = -ctx
+                    s32 = stp[ctx]
+                    # ---- 3.8.1.2 get_symbol(signed), the range decoder of 3.8.1.1 inlined (this loop is the whole cost of the test)
+                    def getbit(k):
+                        nonlocal low, rng, pos
+                        sv = s32[k]
+                        rr = (rng * sv) >> 8
+                        rng -= rr
+                        if low < rng:
+                            s32[k] = zero[sv]; bitv = 0
+                        else:
+                            low -= rng; rng = rr; s32[k] = one[sv]; bitv = 1
+                        if rng < 0x100:
+                            rng <<= 8; low <<= 8
+                            if pos < dlen: low += d[pos]
+                            pos += 1
+                        return bitv
+                    if getbit(0):
+                        diff = 0
+                    else:
+                        e = 0
+                        while getbit(1 + (e if e < 9 else 9)):
+                            e += 1
+                            assert e <= 31
+                        aa = 1
+                        for k in range(e - 1, -1, -1):
+                            aa = aa * 2 + getbit(22 + (k if k < 9 else 9))
+                        diff = -aa if getbit(11 + (e if e < 10 else 10)) else aa
+                    if neg:
+                        diff = -diff
+                    cur[i] = (pred + diff) & mask
+            # the picture line is complete: 3.7.2 inverse RCT
+            for x in range(w):
+                if rgb:
+                    Y, Cb, Cr = rows[0][y % 3][x + 2], rows[1][y % 3][x + 2] - (1 << bps), rows[2][y % 3][x + 2] - (1 << bps)
+                    gg = Y - ((Cb + Cr) >> 2)
+                    rr_, bb = Cr + gg, Cb + gg
+                    if swap_gb:
+                        gg, bb = bb, gg
+                    px = (rr_, gg, bb) + ((rows[3][y % 3][x + 2],) if r.alpha_plane else ())
+                else:
+                    px = (rows[0][y % 3][x + 2],)
+                out[y0 + y][x0 + x] = px
+        # 3.8.1.1.1 sentinel mode: one more binary symbol with state 129, its value discarded; the bytes must not have run out before
+        rd.low, rd.range, rd.pos = low, rng, pos
+        rd.bit([129], 0)
+        assert rd.pos - 1 <= dlen + 1, "slice data ran out before its last symbol"
+    assert only is not None or all(px is not None for row in out for px in row), "some pixels are covered by no slice"
+    return out
 
 
 def validate_stream(record: bytes, packets: list[bytes], width: int, height: int) -> Record:

@@ -48,6 +48,28 @@ def test_config2_4k_16bit_64_slices(built):
     roundtrip(4096, 2160, synth.PIX_RGB16_BE, 64, 2, "film")
 
 
+def test_a_4k_slice_of_the_device_decodes_by_the_rfc_alone(built):
+    """One 512x270 slice of a 4K frame the device coded (config 2's shape: 64 slices, 5063 contexts, 17-bit differences), decoded by
+    tests/rfc9043_validator.py -- code written from RFC 9043's text, none of this repository's codec -- gives the source's pixels: the
+    sample-level conformance evidence for the GPU bitstream that does not go through the reference's decoder or its restatement."""
+    import numpy as np
+    import rfc9043_validator as rfc
+    w, h, pixfmt = 4096, 2160, synth.PIX_RGB16_BE
+    comp = synth.components(w, h, 3, 16, "film", seed=77)
+    pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 8, 8, 1, 1, max_batch=1)
+    packet = enc.encode_host([pl])[0]
+    record = enc.config_record()
+    enc.close()
+    r = rfc.parse_record(record)
+    rfc.validate_frame(r, packet, w, h)
+    k = 27                                                     # slice (3, 3)
+    px = rfc.decode_frame(r, packet, w, h, only={k})
+    y0, x0 = 3 * 270, 3 * 512
+    got = np.array([row[x0:x0 + 512] for row in px[y0:y0 + 270]], dtype=np.int64)
+    assert got.shape == (270, 512, 3) and np.array_equal(got, comp[y0:y0 + 270, x0:x0 + 512].astype(np.int64))
+
+
 def test_config2_4k_16bit_576_slices_default(built):
     """the slice count the reference itself would pass for this picture (DPX.cpp:428-441): 576 = 32 x 18"""
     assert api.lib().rcgpu_reference_slices(4096, 2160, 16, 1) == 576

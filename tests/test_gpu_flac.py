@@ -45,6 +45,27 @@ def test_flac_frames_match_oracle(built, ch, bits, rate, n, kind):
     enc.close()
 
 
+@pytest.mark.parametrize("name", ["wav_2ch16_48k", "wav_6ch24_48k", "wav_1ch8_44k", "wav_2ch24_noise", "wav_2ch16_midside", "wav_2ch24_leftside", "wav_2ch16_sideright"])
+def test_device_predictor_words_are_the_pinned_ones(built, name):
+    """The device's Levinson-Durbin and quantiser (IEEE double, fixed operation order, -ffp-contract=off) choose the coefficient words
+    pinned in tests/golden/flac_coefficients.json, read back out of the device's own frames by the specification-level decoder
+    (tests/flac_validator.py): a rounding that moved is reported as the block, channel and coefficient it moved in.  Reference maths:
+    Lib/ThirdParty/flac/src/libFLAC/lpc.c:122-259."""
+    import json
+    import flac_validator
+    from test_validators import words_diff
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    v = next(x for x in json.load(open(os.path.join(G, "vectors.json")))["flac"] if x["name"] == name)
+    pcm = open(os.path.join(G, v["pcm"]), "rb").read()
+    enc = api.FlacEncoder(v["channels"], v["rate"], v["bits"], 0, 8)
+    frames, cp = enc.encode(pcm)
+    enc.close()
+    got, infos = flac_validator.parse_stream(b"".join(frames), v["channels"], v["bits"], v["rate"])
+    assert got == pcm
+    words_diff(name, flac_validator.predictor_words(infos), json.load(open(os.path.join(G, "flac_coefficients.json")))[name])
+    assert b"".join(frames) == open(os.path.join(G, v["frames"]), "rb").read() and cp.hex() == v["codec_private"]
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RCGPU_SOAK_FLAC", "8"))))      # soak: RCGPU_SOAK_FLAC=400
 def test_flac_random_signals_match_oracle(built, seed):
     """Random channel counts, depths, lengths and signals (tones + dither at random levels, steps, bursts of full-scale noise,

@@ -62,6 +62,45 @@ __global__ __launch_bounds__(64) void k_gather(uint4* __restrict__ region, uint3
     if (acc == 0x12345678u) sink[0] = acc;                               // keeps the loads alive
 }
 
+// The same with records that own a whole 64-byte line (the 32 state bytes + 32 of padding): does a write-back of the FULL line cost the
+// memory less than the 32-byte half (no read-modify-write of a 64-byte ECC word)?  FULL = 0: 32 bytes read, 32 written (a pair of lanes),
+// at a 64-byte stride; FULL = 1: 32 bytes read, the whole 64-byte line written (a quad of lanes); FULL = 2: 64 read, 64 written.
+template <int FULL>
+__global__ __launch_bounds__(64) void k_gather64(uint4* __restrict__ region, uint32_t nrec_mask, uint32_t iters, uint32_t seed, unsigned long long* __restrict__ sink)
+{
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    uint32_t s = mix(seed + wave * 64u + lane);
+    s = mix(s + 0x9e3779b9u);
+    uint32_t idx = s & nrec_mask;
+    uint4 a = region[size_t(idx) * 4], b = region[size_t(idx) * 4 + 1], c = make_uint4(0, 0, 0, 0), d = c;
+    if (FULL == 2) { c = region[size_t(idx) * 4 + 2]; d = region[size_t(idx) * 4 + 3]; }
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; it++) {
+        uint4 va = a, vb = b, vc = c, vd = d;
+        const uint32_t at = idx;
+        acc += va.x ^ vb.w ^ vc.y ^ vd.z;
+        va.x += 1; vb.w += 1;
+        s = mix(s + 0x9e3779b9u); idx = s & nrec_mask;
+        a = region[size_t(idx) * 4]; b = region[size_t(idx) * 4 + 1];
+        if (FULL == 2) { c = region[size_t(idx) * 4 + 2]; d = region[size_t(idx) * 4 + 3]; }
+        if (FULL == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t rec = uint32_t(__shfl(int(at), h * 32 + int(lane >> 1)));
+                region[size_t(rec) * 4 + (lane & 1)] = (lane & 1) ? vb : va;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 4; h++) {                               // records of lanes h * 16 .. h * 16 + 15, four lanes each
+                const uint32_t rec = uint32_t(__shfl(int(at), h * 16 + int(lane >> 2)));
+                region[size_t(rec) * 4 + (lane & 3)] = (lane & 3) == 0 ? va : (lane & 3) == 1 ? vb : (lane & 3) == 2 ? vc : vd;
+            }
+        }
+    }
+    acc += a.y ^ b.z ^ c.x ^ d.w;
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // one dependent chain per lane: the next address comes out of the record just read
 __global__ __launch_bounds__(64) void k_chase(const uint4* __restrict__ region, uint32_t nrec_mask, uint32_t iters, uint32_t seed, unsigned long long* __restrict__ cycles)
 {
@@ -123,6 +162,55 @@ int main(int argc, char** argv)
                        (rd_bytes + wr_bytes) / t * 1e-12, recs * (mode ? 64 : 32) / t * 1e-12);
                 fflush(stdout);
             }
+    // ---- how the ceiling moves with the REGION (does the 256 MB Infinity Cache serve such records faster than HBM?) and with the number
+    // of CUs that ask (is it a per-CU queue or the memory's own limit?): pair write-back and gather only, 12 wavefronts per CU, depth 1
+    for (double rgb : { 0.03125, 0.0625, 0.125, 0.1875, 0.25, 0.5, 1.0, 2.0 }) {
+        uint64_t n = 1; while (n * 2 * 32 <= uint64_t(rgb * (1ull << 30))) n *= 2;
+        if (rgb == 0.1875) n = (uint64_t(192) << 20) / 32;                      // not a power of two: the kernel masks, so use 128 MB + a second run below
+        if (n > nrec) continue;
+        const uint32_t m = uint32_t((rgb == 0.1875 ? (uint64_t(128) << 20) / 32 : n) - 1);
+        const uint32_t waves = ncu * 12;
+        const uint32_t iters = uint32_t((uint64_t(1) << 31) / (uint64_t(waves) * 64));
+        for (int mode : { 0, 2 }) {
+            const double t = mode == 0 ? run<0, 1>(region, m, waves, iters, sink, st) : run<2, 1>(region, m, waves, iters, sink, st);
+            const double recs = double(waves) * 64 * iters;
+            printf("{\"region_sweep_mb\": %.0f, \"mode\": %d, \"waves_per_cu\": 12, \"G_records_per_s\": %.2f}\n", double(uint64_t(m) + 1) * 32 / double(1 << 20), mode, recs / t * 1e-9);
+            fflush(stdout);
+        }
+    }
+    {   // 64-byte records over the same region (half as many records)
+        const uint32_t m64 = uint32_t(nrec / 2 - 1);
+        const uint32_t waves = ncu * 12;
+        const uint32_t iters = uint32_t((uint64_t(1) << 31) / (uint64_t(waves) * 64));
+        const char* what[3] = { "64-byte stride: 32 B read, 32 B written (pair of lanes)", "64-byte records: 32 B read, the whole 64 B line written (quad of lanes)", "64-byte records: 64 B read, 64 B written" };
+        for (int full = 0; full < 3; full++) {
+            hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            auto launch = [&](uint32_t it, uint32_t seed) {
+                if (full == 0) hipLaunchKernelGGL(k_gather64<0>, dim3(waves), dim3(64), 0, st, region, m64, it, seed, sink);
+                else if (full == 1) hipLaunchKernelGGL(k_gather64<1>, dim3(waves), dim3(64), 0, st, region, m64, it, seed, sink);
+                else hipLaunchKernelGGL(k_gather64<2>, dim3(waves), dim3(64), 0, st, region, m64, it, seed, sink);
+            };
+            launch(iters / 8, 1u);
+            CHECK(hipEventRecord(e0, st)); launch(iters, 7u); CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+            float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("{\"records64\": \"%s\", \"waves_per_cu\": 12, \"G_records_per_s\": %.2f}\n", what[full], double(waves) * 64 * iters / (double(ms) * 1e-3) * 1e-9);
+            CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+        }
+    }
+    {   // half of the CUs (every second one) through a CU-masked stream
+        hipStream_t sm = nullptr;
+        std::vector<uint32_t> cumask((ncu + 31) / 32, 0x55555555u);
+        if (hipExtStreamCreateWithCUMask(&sm, uint32_t(cumask.size()), cumask.data()) == hipSuccess) {
+            const uint32_t waves = ncu / 2 * 12;
+            const uint32_t iters = uint32_t((uint64_t(1) << 30) / (uint64_t(waves) * 64));
+            for (int mode : { 0, 2 }) {
+                const double t = mode == 0 ? run<0, 1>(region, mask, waves, iters, sink, sm) : run<2, 1>(region, mask, waves, iters, sink, sm);
+                const double recs = double(waves) * 64 * iters;
+                printf("{\"half_of_the_cus\": true, \"mode\": %d, \"waves_per_cu\": 12, \"G_records_per_s\": %.2f}\n", mode, recs / t * 1e-9);
+            }
+            CHECK(hipStreamDestroy(sm));
+        }
+    }
     // latency of one dependent random read: alone on the chip, then with every CU busy gathering
     unsigned long long* cyc = nullptr; CHECK(hipMalloc(reinterpret_cast<void**>(&cyc), 8 * 4096));
     for (int loaded = 0; loaded < 2; loaded++) {
