@@ -1467,6 +1467,9 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (cfg->level != 0 && cfg->level != 1 && cfg->level != 3) return fail(2, "ffv1: level %u (1 or 3)", cfg->level);
     if (cfg->level == 1 && (S != 1 || cfg->slicecrc)) return fail(2, "ffv1: level 1 (FFV1 version 1) means one slice and no slice CRC");
     if (cfg->rc_span > RCGPU_RC_WHOLE && cfg->rc_span < 8) return fail(2, "ffv1: rc_span %u (0 automatic, %u whole slices, or at least 8 pieces per span)", cfg->rc_span, RCGPU_RC_WHOLE);
+    // version 1 frames are one slice with no footer and a header replayed in front of the samples: coded by the whole-slice mapping only
+    // (the automatic choice never splits them; the split mapping has no bit-exactness test at level 1)
+    if (cfg->level == 1 && cfg->rc_span > RCGPU_RC_WHOLE) return fail(2, "ffv1: rc_span %u with level 1: FFV1 version 1 frames are coded by the whole-slice mapping", cfg->rc_span);
     const pix_desc& d = pix(cfg->pixfmt);
     const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
     if (altern && d.fields != kFieldsLow) return fail(2, "ffv1: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only (DPX.cpp:363-368)");
@@ -1695,6 +1698,8 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
             for (uint32_t chain = 0; chain < nchains; chain++) mx = std::max(mx, e->h_seg_pieces[size_t(j) * nchains + chain]);
             e->seg_span_off[j] = total_spans;
             e->seg_spans[j] = std::max(1u, (mx + e->span_pieces - 1) / e->span_pieces);
+            if (e->seg_spans[j] > 65535u)      // the spans of a segment are the launch's grid.y
+                return fail(2, "ffv1: rc_span %u cuts a segment of %u pieces into %u spans (at most 65535): raise rc_span or segments", e->span_pieces, mx, e->seg_spans[j]);
             total_spans += e->seg_spans[j];
         }
         const size_t need = size_t(total_spans) * nchains * sizeof(rc_ckpt);

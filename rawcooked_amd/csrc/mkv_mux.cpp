@@ -94,8 +94,10 @@ struct rcgpu_mkv {
     {
         const uint8_t* s = static_cast<const uint8_t*>(p);
         // inside the mapped part of the file the bytes go through the mapping: a pwrite() there would queue behind the thread that
-        // allocates pages ahead (fallocate holds the file's lock for a whole chunk) -- 7 ms per block head, measured
-        if (map && pos >= map_base && pos + n <= map_base + map_len && !(alloc_failed.load() && pos + n > prealloc_to.load())) { memcpy(map + (pos - map_base), p, n); pos += n; return 0; }
+        // allocates pages ahead (fallocate holds the file's lock for a whole chunk) -- 7 ms per block head, measured.  But only where the
+        // pages EXIST (pos + n <= prealloc_to): a head written beyond them faults a tmpfs page in, and if the file system fills at that
+        // moment the fault is a SIGBUS, where the pwrite() below returns an error.  Heads are a few bytes; the allocation runs 2 GB ahead.
+        if (map && pos >= map_base && pos + n <= map_base + map_len && pos + n <= prealloc_to.load()) { memcpy(map + (pos - map_base), p, n); pos += n; return 0; }
         while (n) {
             ssize_t w = ::pwrite(fd, s, n, off_t(pos));     // positional: other threads fill reserved blocks through the same descriptor
             if (w < 0) { if (errno == EINTR) continue; return fail(20, "mkv: write to %s failed: %s", path.c_str(), strerror(errno)); }

@@ -280,6 +280,8 @@ def test_level_1_single_slice_frames(built, pixfmt, coder, ctx):
         api.Ffv1Encoder(w, h, pixfmt, line_bytes, 2, 2, 0, ctx, level=1)
     with pytest.raises(RuntimeError):
         api.Ffv1Decoder(w, h, pixfmt, line_bytes, 2, 2, 0, ctx, level=1)
+    with pytest.raises(RuntimeError, match="whole-slice"):          # the split coder is not offered for version 1 frames
+        api.Ffv1Encoder(w, h, pixfmt, line_bytes, 1, 1, 0, ctx, level=1, rc_span=8)
 
 
 def test_configurations_the_device_path_cannot_hold_are_refused(built):
