@@ -219,6 +219,11 @@ typedef struct {
     uint32_t device_aliases;            /* test hook, 0 or 1 = off: k > 1 presents every physical device k times to device_first / device_count, so
                                            that the lane-per-device path (one encoder, ring and set of copy streams per device, one placer across
                                            them) runs on a box with a single GPU; the lanes then share its memory -- pass `batch` */
+    uint32_t numa;                      /* 0 = automatic: lanes are grouped by the NUMA node their device hangs on (hipDeviceGetPCIBusId ->
+                                           /sys/bus/pci/devices/<id>/numa_node); each group has its own pinned upload slots, reader and writer threads,
+                                           all bound to the node's CPUs, and every lane's download ring is allocated there -- a lane moves ~118 GB/s
+                                           through host memory, which eight lanes cannot take across a socket link.  1 = off (one group, nothing
+                                           bound).  2 = test hook: lane i is treated as attached to node i mod (nodes of the host) */
 } rcgpu_sequence_options;
 typedef struct {
     double   seconds;                   /* first read_frame .. last packet_done */
@@ -231,6 +236,9 @@ typedef struct {
     double   upload_wait_seconds;       /* device 0: time its host thread waited for the readers */
     double   h2d_span_seconds;          /* device 0: sum over batches of first upload start .. last upload end (device clock, HIP events) */
     double   read_call_seconds, write_call_seconds;   /* average duration of one read_frame call / one packet copy + packet_done call */
+    uint32_t host_groups;               /* NUMA groups the lanes fell into */
+    int32_t  lane_device[16], lane_numa_node[16], lane_pinned_node[16];   /* per lane (first 16): its device, the node that device hangs on, and the node
+                                           the kernel reports for the lane's pinned download ring (move_pages); -1 = unknown / no such lane */
 } rcgpu_sequence_stats;
 /* record/record_size: optional, the FFV1 configuration record (Matroska CodecPrivate), *record_size = capacity in, size out. */
 int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, const rcgpu_sequence_io* io,

@@ -49,6 +49,7 @@ struct pipe_options {
     uint64_t out_ring_bytes = 0;                 // pinned download ring per lane; 0 = automatic
     uint32_t device_aliases = 0;                 // test hook: every physical device presented this many times (0, 1 = as they are)
     uint32_t copy_streams = 0;                   // copy streams per direction and lane; 0 = automatic (two)
+    uint32_t numa = 0;                           // 0 = lanes grouped by their device's NUMA node, host threads and pinned memory bound to it; 1 = off; 2 = test hook
     bool trace = false;
 };
 
@@ -62,6 +63,9 @@ struct pipe_stats {
     double upload_wait_seconds = 0;             // lane 0: time its thread waited for the readers to fill a slot
     double read_call_seconds = 0, write_call_seconds = 0;   // average duration of one read callback / one packet copy + done callback
     double h2d_span_seconds = 0;                // lane 0: sum over batches of first upload start .. last upload end (device clock)
+    uint32_t groups = 0;                        // host-side groups (NUMA nodes the lanes' devices hang on)
+    int32_t lane_device[16], lane_node[16], lane_pinned_node[16];   // per lane: device, its NUMA node, the node its pinned ring was found on (-1 unknown)
+    pipe_stats() { for (int i = 0; i < 16; i++) lane_device[i] = lane_node[i] = lane_pinned_node[i] = -1; }
 };
 
 class pipeline {

@@ -8,6 +8,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include "pipeline.h"
 #include "ffv1_internal.h"
 #include "ffv1_host.h"
@@ -25,6 +28,71 @@ constexpr uint32_t kCopyStreams = 2;                          // copy streams pe
 
 struct batch_t { uint32_t video; size_t first, n; int lane; };       // frames[first .. first+n) of the output order
 
+// ---- NUMA.  A lane moves ~30 GB/s each way through pinned host memory, and every byte crosses that memory about four times (reader copy
+// in, DMA out, DMA in, writer copy out): ~118 GB/s of DRAM traffic per GPU.  On a two-socket host with eight GPUs
+// that only works when a lane's pinned slots, its download ring and the threads that fill and drain them live on the socket its GPU
+// hangs on; across the inter-socket link eight lanes would meet its limit long before PCIe's.  So lanes are grouped by the NUMA node of
+// their device (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<id>/numa_node), every group has its own slot pool, readers and writers,
+// bound to the node's CPUs, and pinned memory is allocated by a thread that runs there (first touch) with the lane's device current
+// (the runtime then prefers the device's node as well).
+struct node_cpus { cpu_set_t set; int count = 0; };
+
+int device_numa_node(int device)
+{
+    char id[64] = {};
+    if (hipDeviceGetPCIBusId(id, int(sizeof id), device) != hipSuccess) return -1;
+    for (char* c = id; *c; c++) if (*c >= 'A' && *c <= 'F') *c = char(*c - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", id);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+int host_node_count()
+{
+    int n = 0;
+    for (;; n++) { char path[96]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", n); if (access(path, R_OK) != 0) break; }
+    return n;
+}
+
+// the CPUs of a node that this process may run on (its affinity mask at the time of the call: cgroups and taskset are respected)
+node_cpus cpus_of_node(int node, const cpu_set_t& allowed)
+{
+    node_cpus out; CPU_ZERO(&out.set);
+    char path[96]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return out;
+    char text[4096] = {};
+    if (!fgets(text, sizeof text, f)) text[0] = 0;
+    fclose(f);
+    for (char* p = text; *p;) {
+        char* e = nullptr;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (CPU_ISSET(int(c), &allowed)) { CPU_SET(int(c), &out.set); out.count++; }
+        p = *e == ',' ? e + 1 : e;
+        if (*p == '\n') break;
+    }
+    return out;
+}
+
+void bind_this_thread(const node_cpus& c) { if (c.count > 0) (void)sched_setaffinity(0, sizeof c.set, &c.set); }
+
+// the node a page of this process lies on, as the kernel reports it (move_pages with no target nodes only asks); -1 = unknown
+int node_of_page(const void* p)
+{
+    void* page = reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(4095));
+    int status = -1;
+    if (syscall(SYS_move_pages, 0, 1UL, &page, nullptr, &status, 0) != 0) return -1;
+    return status;
+}
+
 struct out_entry {            // one packet on its way down
     size_t frame = 0; uint8_t* src = nullptr; size_t size = 0; int chunk = -1; hipEvent_t ev = nullptr; int device = 0, lane = 0;
     int* ev_users = nullptr;      // the event is shared by a group of packets: the last one done with it returns it
@@ -33,6 +101,8 @@ struct out_entry {            // one packet on its way down
 
 struct lane_t {
     int id = 0, device = 0;
+    int node = -1, group = 0;                     // NUMA node of the device (-1 unknown), index of the host-side group the lane belongs to
+    int pinned_node = -1;                         // where the kernel says the lane's first ring chunk lies
     std::vector<rcgpu_ffv1*> enc;                 // per video
     std::vector<hipStream_t> cin, cout;          // copy streams per direction: groups of copies are dealt to them in turn
     std::vector<hipEvent_t> join_ev;             // one per extra stream: joins it to stream 0 of its direction at the end of a batch
@@ -70,11 +140,18 @@ struct pipeline::impl {
                             cv_out /* placer: a download was issued */, cv_jobs /* writers: a packet was placed */;
     void wake_all() { cv_slots.notify_all(); cv_ready.notify_all(); cv_ring.notify_all(); cv_out.notify_all(); cv_jobs.notify_all(); }
     int error = 0; std::string error_msg;
-    std::vector<uint8_t*> all_slots, free_slots; size_t slots_wanted = 0;
+    // host-side groups: the lanes of one NUMA node share a pool of pinned upload slots, reader threads and writer threads, all of them on
+    // that node.  One group when the host has one node (or the nodes are unknown).
+    struct group_t {
+        int node = -1; node_cpus cpus; int first_lane = 0; uint32_t lanes = 0;
+        std::vector<uint8_t*> all_slots, free_slots; size_t slots_wanted = 0;
+        std::vector<size_t> frames; size_t next_read = 0;      // the output frames its lanes code, in order; the next one a reader takes
+        std::deque<out_entry> jobs;                            // placed packets of its lanes waiting for a writer
+        uint32_t readers = 0, writers = 0; double reads_done = 0;
+    };
+    std::vector<group_t> groups;
     std::vector<uint8_t*> ready;                  // per output frame: the filled slot (nullptr until read)
-    std::deque<out_entry> jobs;                   // placed packets waiting for a writer
     bool placer_finished = false;
-    std::atomic<size_t> next_read{ 0 };
     bool alloc_done = false;
 
     void set_error(int code, const char* msg)
@@ -111,7 +188,7 @@ pipeline::impl::~impl()
         if (L.h_err) (void)hipHostFree(L.h_err);
     }
     for (lane_t& L : lanes) for (uint8_t* c : L.chunks) if (c) (void)hipHostFree(c);
-    for (uint8_t* s : all_slots) (void)hipHostFree(s);
+    for (group_t& g : groups) for (uint8_t* s : g.all_slots) (void)hipHostFree(s);
     if (tr) fprintf(stderr, "rcgpu trace: release: pinned buffers after %.3f s\n", since());
 }
 
@@ -232,6 +309,25 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
             hipHostMalloc(reinterpret_cast<void**>(&L.h_err), 32, hipHostMallocPortable) != hipSuccess) return fail(100, "pipeline: cannot allocate pinned memory");
     }
     for (size_t vi = 0; vi < videos.size(); vi++) s.slot_bytes = std::max(s.slot_bytes, (s.payload[vi] + 4095) & ~size_t(4095));
+    // ---- host-side groups by NUMA node (see the top of this file).  numa: 0 = by the devices' nodes, 1 = one group, nothing bound,
+    // 2 = test hook: lane i is treated as attached to node i mod (nodes of the host), so that the grouped paths run on a one-GPU box.
+    cpu_set_t allowed; CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &allowed);
+    const int host_nodes = host_node_count();
+    s.groups.clear();
+    for (lane_t& L : s.lanes) {
+        L.node = opt.numa == 1 || host_nodes < 1 ? -1 : opt.numa == 2 ? L.id % host_nodes : device_numa_node(L.device);
+        if (L.node >= host_nodes) L.node = -1;
+        int g = -1;
+        for (size_t k = 0; k < s.groups.size(); k++) if (s.groups[k].node == L.node) g = int(k);
+        if (g < 0) {
+            impl::group_t G; G.node = L.node; G.first_lane = L.id;
+            if (L.node >= 0) G.cpus = cpus_of_node(L.node, allowed);
+            s.groups.push_back(G);
+            g = int(s.groups.size()) - 1;
+        }
+        L.group = g; s.groups[size_t(g)].lanes++;
+    }
     s.prepare_seconds = since(t0);
     return 0;
 }
@@ -274,8 +370,17 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     unsigned hw = std::thread::hardware_concurrency(); if (!hw) hw = 8;
     const uint32_t readers = s.opt.readers ? s.opt.readers : uint32_t(std::max(2u, std::min(hw / 2, 8u * unsigned(nl))));
     const uint32_t writers = s.opt.writers ? s.opt.writers : uint32_t(std::max(2u, std::min(hw / 2, 8u * unsigned(nl))));
-    s.slots_wanted = s.opt.in_slots ? s.opt.in_slots : std::min<size_t>(N, std::max<size_t>(2 * readers, std::min<size_t>(64 * size_t(nl), (size_t(8) << 30) / std::max<size_t>(1, s.slot_bytes))));
-    s.slots_wanted = std::max<size_t>(s.slots_wanted, std::min<size_t>(N, 2));
+    size_t slots_total = s.opt.in_slots ? s.opt.in_slots : std::min<size_t>(N, std::max<size_t>(2 * readers, std::min<size_t>(64 * size_t(nl), (size_t(8) << 30) / std::max<size_t>(1, s.slot_bytes))));
+    slots_total = std::max<size_t>(slots_total, std::min<size_t>(N, 2));
+    // every group gets its lanes' share of the threads and of the slots (at least one reader, one writer and two slots), and the list of
+    // the frames its lanes code: its readers fill its slots with the lowest of THOSE frames not yet read
+    for (impl::group_t& G : s.groups) {
+        G.readers = std::max<uint32_t>(1, readers * G.lanes / uint32_t(nl));
+        G.writers = std::max<uint32_t>(1, writers * G.lanes / uint32_t(nl));
+        G.slots_wanted = std::max<size_t>(std::min<size_t>(N, 2), slots_total * G.lanes / size_t(nl));
+        G.frames.clear(); G.next_read = 0; G.jobs.clear(); G.reads_done = 0;
+    }
+    for (const batch_t& b : batches) { impl::group_t& G = s.groups[size_t(s.lanes[size_t(b.lane)].group)]; for (size_t k = 0; k < b.n; k++) G.frames.push_back(b.first + k); }
     for (lane_t& L : s.lanes) {
         // ring: 1..4 GB in chunks that hold at least two worst-case packets.  It only has to cover the writers' reaction time: a ring that
         // held a whole batch of packets (17.8 GB at 4K) gave the same rates (host to host 482 frames/s with 2, 4, 8 or 17.8 GB) and cost
@@ -291,7 +396,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         L.cur = -1; L.cur_off = 0; L.outq.clear(); std::fill(L.outstanding.begin(), L.outstanding.end(), 0); L.up_span_valid = false; L.upload_wait = 0; L.h2d_span = 0; L.copy_calls = L.dl_calls = L.dl_wait = 0;
         std::fill(L.dl_valid.begin(), L.dl_valid.end(), false);
     }
-    s.ready.assign(N, nullptr); s.jobs.clear(); for (lane_t& L : s.lanes) L.pending.clear(); s.placer_finished = false; s.next_read = 0; s.alloc_done = false;
+    s.ready.assign(N, nullptr); for (lane_t& L : s.lanes) L.pending.clear(); s.placer_finished = false; s.alloc_done = false;
     s.error = 0; s.error_msg.clear();
 
     std::vector<double> batch_done(batches.size(), 0.0);
@@ -307,31 +412,36 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
 
     // ---- pinned memory is page-locked at ~13 GB/s: allocated in the background, first users served first
     std::thread allocator([&] {
-        (void)hipSetDevice(s.lanes[0].device);
-        size_t have = s.all_slots.size();
-        { std::lock_guard<std::mutex> l(s.m); s.free_slots = s.all_slots; }
+        // every buffer is allocated from the node it will be used on: by this thread while it runs on that node's CPUs (first touch), with a
+        // device of that node current (the runtime picks the pool next to the current device)
+        for (impl::group_t& G : s.groups) { std::lock_guard<std::mutex> l(s.m); G.free_slots = G.all_slots; }
         bool more = true;
         while (more && !s.failed()) {
             more = false;
-            if (have < s.slots_wanted) {
+            for (impl::group_t& G : s.groups) {
+                if (G.all_slots.size() >= G.slots_wanted) continue;
+                bind_this_thread(G.cpus);
+                (void)hipSetDevice(s.lanes[size_t(G.first_lane)].device);
                 uint8_t* ptr = nullptr;
                 if (hipHostMalloc(reinterpret_cast<void**>(&ptr), s.slot_bytes, hipHostMallocPortable) != hipSuccess) {
-                    if (have < 2) { s.set_error(100, "pipeline: cannot allocate pinned upload slots"); break; }
-                    s.slots_wanted = have;
+                    if (G.all_slots.size() < 2) { s.set_error(100, "pipeline: cannot allocate pinned upload slots"); break; }
+                    std::lock_guard<std::mutex> l(s.m);
+                    G.slots_wanted = G.all_slots.size();
                 } else {
                     std::lock_guard<std::mutex> l(s.m);
-                    s.all_slots.push_back(ptr); s.free_slots.push_back(ptr); have++;
-                    s.cv_slots.notify_one();
+                    G.all_slots.push_back(ptr); G.free_slots.push_back(ptr);
+                    s.cv_slots.notify_all();
                 }
                 more = true;
             }
             for (lane_t& L : s.lanes) {
-                bool need;
-                { std::lock_guard<std::mutex> l(s.m); need = L.chunks.size() < L.max_chunks; }
+                bool need; bool slots_short;
+                { std::lock_guard<std::mutex> l(s.m); need = L.chunks.size() < L.max_chunks; const impl::group_t& G = s.groups[size_t(L.group)]; slots_short = G.all_slots.size() < G.slots_wanted; }
                 if (!need) continue;
                 // the first chunks of every lane come before the bulk of the upload slots
-                if (L.chunks.size() >= 2 && have < s.slots_wanted) continue;
+                if (L.chunks.size() >= 2 && slots_short) continue;
                 uint8_t* ptr = nullptr;
+                bind_this_thread(s.groups[size_t(L.group)].cpus);
                 (void)hipSetDevice(L.device);
                 if (hipHostMalloc(reinterpret_cast<void**>(&ptr), L.chunk_bytes, hipHostMallocPortable) != hipSuccess) {
                     std::lock_guard<std::mutex> l(s.m);
@@ -340,6 +450,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                     s.wake_all();
                 } else {
                     std::lock_guard<std::mutex> l(s.m);
+                    if (L.chunks.empty()) L.pinned_node = node_of_page(ptr);
                     L.chunks.push_back(ptr); L.outstanding.push_back(0);
                     s.cv_ring.notify_all();
                 }
@@ -362,7 +473,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             size_t asked = 0;
             for (auto it = L.pending.begin(); it != L.pending.end() && asked < L.cin.size();) {
                 if (hipEventQuery(it->ev) != hipSuccess) { ++it; ++asked; continue; }
-                for (uint8_t* sl : it->slots) s.free_slots.push_back(sl);
+                for (uint8_t* sl : it->slots) s.groups[size_t(L.group)].free_slots.push_back(sl);
                 L.free_events.push_back(it->ev);
                 it = L.pending.erase(it);
             }
@@ -370,20 +481,21 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     };
 
     // ---- readers
-    auto reader = [&] {
-        (void)hipSetDevice(s.lanes[0].device);
+    auto reader = [&](impl::group_t& G) {
+        bind_this_thread(G.cpus);
+        (void)hipSetDevice(s.lanes[size_t(G.first_lane)].device);
         for (;;) {
-            // slot first, frame second, under one lock: the filled slots then always hold the LOWEST frames not yet uploaded, which are
-            // the ones the lanes wait for (a reader that took its frame number first could be overtaken for the last free slot by
-            // readers of later frames, and the pool would fill up with frames nobody can use yet)
+            // slot first, frame second, under one lock: the filled slots of a group then always hold the LOWEST of its frames not yet
+            // uploaded, which are the ones its lanes wait for (a reader that took its frame number first could be overtaken for the last free
+            // slot by readers of later frames, and the pool would fill up with frames nobody can use yet)
             uint8_t* slot = nullptr; size_t i = 0;
             {
                 std::unique_lock<std::mutex> l(s.m);
                 for (;;) {
                     if (s.error) return;
-                    if (s.next_read >= N) { if (!reads_done) reads_done = since(t0); return; }
+                    if (G.next_read >= G.frames.size()) { if (!G.reads_done) G.reads_done = since(t0); return; }
                     reap();
-                    if (!s.free_slots.empty()) { slot = s.free_slots.back(); s.free_slots.pop_back(); i = s.next_read++; break; }
+                    if (!G.free_slots.empty()) { slot = G.free_slots.back(); G.free_slots.pop_back(); i = G.frames[G.next_read++]; break; }
                     s.cv_slots.wait_for(l, std::chrono::microseconds(200));
                 }
             }
@@ -397,6 +509,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
 
     // ---- lanes
     auto lane_main = [&](lane_t& L) {
+        bind_this_thread(s.groups[size_t(L.group)].cpus);
         if (hipSetDevice(L.device) != hipSuccess) { s.set_error(100, "pipeline: hipSetDevice failed"); return; }
         std::vector<size_t> mine;
         for (size_t b = 0; b < batches.size(); b++) if (batches[b].lane == L.id) mine.push_back(b);
@@ -440,7 +553,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
                 s.cv_ready.wait(l, [&] { return s.error || s.ready[B.first + k]; });
                 if (s.error) return false;
                 slot = s.ready[B.first + k];
-                ugroup_max = std::max<size_t>(1, std::min<size_t>(kUploadGroup, s.slots_wanted / (4 * size_t(nl))));
+                { const impl::group_t& G = s.groups[size_t(L.group)]; ugroup_max = std::max<size_t>(1, std::min<size_t>(kUploadGroup, G.slots_wanted / (4 * size_t(std::max(1u, G.lanes))))); }
                 L.upload_wait += since(tw);
             }
             const auto tc = clk::now();
@@ -623,23 +736,24 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             }
             o.dst = io.place ? io.place(frames[i], o.size) : nullptr;
             if (io.place && !o.dst && *rcgpu_last_error()) { s.set_error(20, rcgpu_last_error()); break; }
-            { std::lock_guard<std::mutex> l(s.m); s.jobs.push_back(o); }
-            s.cv_jobs.notify_one();
+            { std::lock_guard<std::mutex> l(s.m); s.groups[size_t(L.group)].jobs.push_back(o); }
+            s.cv_jobs.notify_all();            // the writers of every group sleep on this condition: the group's own must hear it
         }
         { std::lock_guard<std::mutex> l(s.m); s.placer_finished = true; }
         s.cv_jobs.notify_all();
     };
 
     // ---- writers
-    auto writer = [&] {
+    auto writer = [&](impl::group_t& G) {
+        bind_this_thread(G.cpus);
         int cur_dev = -1;
         for (;;) {
             out_entry o;
             {
                 std::unique_lock<std::mutex> l(s.m);
-                s.cv_jobs.wait(l, [&] { return s.error || !s.jobs.empty() || s.placer_finished; });
-                if (s.jobs.empty()) return;             // error or finished
-                o = s.jobs.front(); s.jobs.pop_front();
+                s.cv_jobs.wait(l, [&] { return s.error || !G.jobs.empty() || s.placer_finished; });
+                if (G.jobs.empty()) return;             // error or finished
+                o = G.jobs.front(); G.jobs.pop_front();
             }
             if (cur_dev != o.device) { (void)hipSetDevice(o.device); cur_dev = o.device; }
             int r = 0;
@@ -664,11 +778,11 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     };
 
     std::vector<std::thread> threads;
-    for (uint32_t i = 0; i < readers; i++) threads.emplace_back(reader);
+    for (impl::group_t& G : s.groups) for (uint32_t i = 0; i < G.readers; i++) threads.emplace_back(reader, std::ref(G));
     for (lane_t& L : s.lanes) threads.emplace_back(lane_main, std::ref(L));
     std::thread placer_thread(placer);
     std::vector<std::thread> wthreads;
-    for (uint32_t i = 0; i < writers; i++) wthreads.emplace_back(writer);
+    for (impl::group_t& G : s.groups) for (uint32_t i = 0; i < G.writers; i++) wthreads.emplace_back(writer, std::ref(G));
     for (auto& t : threads) t.join();
     // a lane that stopped early (error) leaves the placer waiting: the error flag wakes it
     placer_thread.join();
@@ -692,15 +806,17 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             L.pending.clear();
             drop(L.outq);
         }
-        drop(s.jobs);
+        for (impl::group_t& G : s.groups) { drop(G.jobs); G.free_slots.clear(); }
         for (lane_t& L : s.lanes) { std::fill(L.outstanding.begin(), L.outstanding.end(), 0); L.cur = -1; L.cur_off = 0; }
-        s.free_slots.clear();
     }
     if (stats) {
         stats->seconds = since(t0); stats->first_packet_seconds = first_packet_seconds; stats->frames = N;
         for (const pipe_frame& f : frames) stats->payload_bytes += s.payload[f.video];
         stats->packet_bytes = packet_bytes; stats->batches = batches.size(); stats->batch_frames = maxF; stats->lanes = uint32_t(nl);
-        stats->readers = readers; stats->writers = writers; stats->device_busy_seconds = busy0;
+        stats->readers = 0; stats->writers = 0; stats->device_busy_seconds = busy0;
+        for (const impl::group_t& G : s.groups) { stats->readers += G.readers; stats->writers += G.writers; reads_done = std::max(reads_done, G.reads_done); }
+        stats->groups = uint32_t(s.groups.size());
+        for (size_t li = 0; li < s.lanes.size() && li < 16; li++) { stats->lane_device[li] = s.lanes[li].device; stats->lane_node[li] = s.lanes[li].node; stats->lane_pinned_node[li] = s.lanes[li].pinned_node; }
         stats->read_call_seconds = read_busy.load() / double(N); stats->write_call_seconds = write_busy.load() / double(N);
         stats->reads_done_seconds = reads_done; stats->upload_wait_seconds = s.lanes[0].upload_wait; stats->h2d_span_seconds = s.lanes[0].h2d_span;
         if (!batches.empty()) {
@@ -729,7 +845,7 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
     pipe_options po;
     if (opt) { po.device_first = opt->device_first; po.device_count = opt->device_count; po.readers = opt->readers; po.writers = opt->writers;
                po.in_slots = opt->in_ring_frames; po.out_ring_bytes = opt->out_ring_bytes; po.batch = opt->batch; po.lanes_per_device = opt->lanes_per_device;
-               po.device_aliases = opt->device_aliases; po.copy_streams = opt->copy_streams; }
+               po.device_aliases = opt->device_aliases; po.copy_streams = opt->copy_streams; po.numa = opt->numa; }
     if (const char* e = getenv("RCGPU_LANES")) if (!po.lanes_per_device) po.lanes_per_device = uint32_t(std::max(1, atoi(e)));
     if (!po.batch) po.batch = cfg->max_batch > 1 ? cfg->max_batch : 0;
     po.trace = getenv("RCGPU_TRACE") != nullptr;
@@ -756,6 +872,8 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
         stats->reads_done_seconds = ps.reads_done_seconds; stats->last_batch_seconds = ps.last_batch_seconds;
         stats->upload_wait_seconds = ps.upload_wait_seconds; stats->h2d_span_seconds = ps.h2d_span_seconds;
         stats->read_call_seconds = ps.read_call_seconds; stats->write_call_seconds = ps.write_call_seconds;
+        stats->host_groups = ps.groups;
+        for (int i = 0; i < 16; i++) { stats->lane_device[i] = ps.lane_device[i]; stats->lane_numa_node[i] = ps.lane_node[i]; stats->lane_pinned_node[i] = ps.lane_pinned_node[i]; }
     }
     return r;
 }

@@ -157,6 +157,51 @@ def test_several_lanes_return_packets_in_frame_order(lanes, n, batch):
         assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
 
 
+def _numa_node_of_device(device):
+    """What /sys says about the GPU's PCI function (the library reads the same file)."""
+    import torch
+    p = torch.cuda.get_device_properties(device)
+    path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    try:
+        node = int(open(path).read())
+    except OSError:
+        return -1
+    nodes = 0
+    while __import__("os").path.exists(f"/sys/devices/system/node/node{nodes}/cpulist"):
+        nodes += 1
+    return node if 0 <= node < nodes else -1
+
+
+@pytest.mark.parametrize("aliases,n,batch", [(4, 70, 5), (2, 33, 6)])
+def test_lanes_grouped_by_numa_node_keep_the_packets(aliases, n, batch):
+    """numa = 2 (test hook): lane i is treated as attached to host node i mod nodes, so that the per-node pools -- pinned upload slots, reader
+    and writer threads, frame cursors -- run side by side on a one-GPU box: same packets, in order, and every lane reports its node."""
+    import numpy as np
+    w, h, pixfmt, n_in = 128, 72, synth.PIX_RGB16_BE, 7
+    payloads, line_bytes = _sequence(w, h, pixfmt, n_in)
+    src = [np.frombuffer(p, dtype=np.uint8).copy() for p in payloads]
+    out_cap = len(payloads[0]) * 2
+    outs = [np.zeros(out_cap, dtype=np.uint8) for _ in range(n)]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 2, 2, 1, 1, 0, 0, 0, 0, 1, 3)
+    st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], n, [a.ctypes.data for a in outs], out_cap, batch=batch, device_count=aliases, device_aliases=aliases, numa=2,
+                                           readers=5, writers=3, in_ring_frames=6)
+    nodes = 0
+    while __import__("os").path.exists(f"/sys/devices/system/node/node{nodes}/cpulist"):
+        nodes += 1
+    lanes = st.devices
+    assert lanes == min(aliases, (n + 7) // 8)
+    if nodes:
+        assert list(st.lane_numa_node[:lanes]) == [i % nodes for i in range(lanes)] and st.host_groups == min(nodes, lanes)
+    else:
+        assert st.host_groups == 1
+    p = ob.Params(w, h, pixfmt, 2, 2, 1, 1)
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
+    for i in range(n):
+        assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
+    st1, sizes1 = api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], n, [a.ctypes.data for a in outs], out_cap, batch=batch, device_count=aliases, device_aliases=aliases, numa=1)
+    assert st1.host_groups == 1 and list(st1.lane_numa_node[:lanes]) == [-1] * lanes and sizes1 == sizes
+
+
 @pytest.mark.parametrize("aliases,first,count,n,batch", [(2, 0, 2, 41, 6), (4, 1, 3, 50, 4), (3, 0, 0, 37, 5)])
 def test_a_lane_per_device_through_device_first_and_count(monkeypatch, aliases, first, count, n, batch):
     """The multi-GPU path proper -- a lane per entry of device_first / device_count, each with its own encoder, pinned ring, copy streams and
@@ -172,6 +217,11 @@ def test_a_lane_per_device_through_device_first_and_count(monkeypatch, aliases, 
     st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], n, [a.ctypes.data for a in outs], out_cap, batch=batch, device_first=first, device_count=count, device_aliases=aliases)
     usable = (aliases - first) if count == 0 else min(count, aliases - first)
     assert st.frames == n and st.devices == min(usable, (n + 7) // 8), (st.devices, usable)
+    # every lane sits on the NUMA node its device hangs on: one group here (aliases of one GPU), its pinned ring on that node
+    node = _numa_node_of_device(0)
+    assert st.host_groups == 1 and list(st.lane_device[:st.devices]) == [0] * st.devices and list(st.lane_numa_node[:st.devices]) == [node] * st.devices
+    if node >= 0:
+        assert all(pn in (-1, node) for pn in st.lane_pinned_node[:st.devices]), (node, list(st.lane_pinned_node[:st.devices]))
     p = ob.Params(w, h, pixfmt, 2, 2, 1, 1)
     want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
     for i in range(n):
