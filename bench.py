@@ -408,7 +408,8 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     return rec, bool(same and ok_md5)
 
 
-def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barrier, reduce_max, lanes=1, readers=0, writers=0, slots=0):
+def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barrier, reduce_max, lanes=1, readers=0, writers=0, slots=0,
+                      device_first=None, device_count=1, aliases=0):
     """The workload again with payloads starting and packets ending in host memory (pageable, like the page cache the reference's
     mmaps read from): rcgpu_ffv1_encode_sequence -- reader threads copy into pinned slots, upload / code / download overlap, writer
     threads copy every packet out of the pinned ring into host buffers.  expect_packets: device-resident packets of the ring's
@@ -423,7 +424,8 @@ def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barr
     barrier()
     t0 = time.perf_counter()
     st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in host_ring], n_frames, [a.ctypes.data for a in outs], out_cap, batch=batch // lanes,
-                                           device_first=cfg.device, device_count=1, lanes_per_device=lanes, readers=readers, writers=writers, in_ring_frames=slots)
+                                           device_first=cfg.device if device_first is None else device_first, device_count=device_count, lanes_per_device=lanes,
+                                           readers=readers, writers=writers, in_ring_frames=slots, device_aliases=aliases)
     wall = time.perf_counter() - t0
     dt = reduce_max(st.seconds)          # the pipeline's own clock: first read to last packet, encoder creation (prepare_seconds) beside it
     # the last `nout` packets are still in their buffers: byte-compare them with the device-resident run's packets of the same frames
@@ -444,6 +446,8 @@ def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barr
             "upload_wait_seconds": round(st.upload_wait_seconds, 3), "h2d_span_seconds": round(st.h2d_span_seconds, 3),
             "read_call_ms": round(st.read_call_seconds * 1e3, 2), "write_call_ms": round(st.write_call_seconds * 1e3, 2),
             "packets_identical_to_device_resident_run": (not bad) if check_until else None,
+            "lanes": [{"device": st.lane_device[i], "numa_node": st.lane_numa_node[i], "pinned_ring_on_node": st.lane_pinned_node[i]} for i in range(min(16, st.devices))],
+            "host_groups": st.host_groups,
             "source": f"ring of {R} distinct frames in pageable host memory, reused", "_local": (n_frames, st.seconds, dt)}, (not bad)
 
 
@@ -686,7 +690,15 @@ def main():
     if args.no_cpu_baseline:
         legs.discard("cpu")
 
+    alias_n = 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        n_phys = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip() or 0)
+        if 1 <= n_phys < args.gpus:
+            # fewer GPUs than asked for (the 1-GPU boxes this repository is developed on): the headline runs on the one device and the
+            # `single_process_sharding` record drives the product's lane-per-device path over N ALIASES of it (rcgpu_sequence_options::device_aliases)
+            alias_n = args.gpus
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not alias_n:
         # asked for several GPUs without a launcher: start one rank per GPU ourselves, the way the driver does
         import socket
         import subprocess
@@ -699,7 +711,7 @@ def main():
 
     import torch
     from rawcooked_amd import api, synth
-    from rawcooked_amd import dist as rdist
+    import bench_dist as rdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -857,8 +869,20 @@ def main():
                              "frac_of_full_rate_peak": round(rate / (1024 * v["full_rate_per_simd"]), 4), "note": v.get("note")}
             except Exception:
                 issue = None
+            # the roofline that binds: random 32-byte records gathered and written back (one per sample), against what tools/gather_peak
+            # measured the chip to sustain in exactly that pattern; and the kernel's floor with that traffic served by the L2
+            req = None
+            try:
+                rc_, fl_ = tjd.get("request_ceiling", {}), tjd.get("resolve_floor", {})
+                samples = width * height * 3
+                rate = samples * fps / world / 1e9
+                req = {"records_G_per_s": round(rate, 2), "ceiling_G_per_s": rc_["G_records_per_s"], "request_frac": round(rate / rc_["G_records_per_s"], 4),
+                       "floor_ms": round(fl_["ms_per_step_alone"] / fl_["launches_per_step"] * F / fl_["frames_per_step"], 3), "floor_what": fl_.get("what"), "ceiling_what": rc_.get("what")}
+            except Exception:
+                req = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "issue_frac": issue,
+                    "request_frac": req["request_frac"] if req else None, "floor_ms": req["floor_ms"] if req else None, "requests": req,
                     "algorithmic_bytes_per_launch": int(alg_bytes_launch), "launch_ms": round(launch_ms, 3), "launches_per_step": nl,
                     "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0},
                     "note": note or "entropy coding: serial per slice and per context, bound by instruction issue rather than bytes (DESIGN.md section 5)"}
@@ -920,6 +944,25 @@ def main():
             result["kernel_metric"] = {"value": hp["value"], "unit": "frames/s", "h2d_included": True,
                                        "what": "SURVEY.md 8d 'kernel-only fps (inputs resident in pinned host memory, H2D included)': payloads start and packets end in host memory, "
                                                "uploads / coding / downloads overlapped (the host_pipeline record)"}
+    if (world > 1 or alias_n > 1) and "host" in legs:
+        # ---- the PRODUCT's sharding: one process, one sequence, a lane per device (frame i -> GPU by batch, one placer in frame
+        # order; rawcooked_amd/csrc/pipeline.hip), next to the per-rank rows above, which are N independent jobs (the reference's own way to
+        # use a node: GNU parallel, Doc/Case_study.md:81).  Rank 0 drives all N devices while the other ranks wait at the barrier.
+        barrier()
+        if rank == 0:
+            ndv = alias_n if alias_n > 1 else world
+            n_seq = (args.host_frames // 2) * (1 if alias_n > 1 else world)
+            sp, ok = host_pipeline_leg(api, cfg, host_ring, n_seq, (F // ndv) if alias_n > 1 else F, expect, lambda: None, lambda x: x, 1, args.host_readers, args.host_writers, args.host_slots,
+                                       device_first=0, device_count=ndv, aliases=alias_n)
+            ok_all &= ok
+            n_loc, dt_loc, _ = sp.pop("_local")
+            sp["value"] = round(n_loc / dt_loc, 2); sp["unit"] = "frames/s"; sp["devices"] = ndv
+            sp["what"] = (f"ONE process, ONE sequence of {n_seq} frames, a lane per device over {ndv} " + ("aliases of the one GPU of this box (the lanes share its memory and its kernels' time: "
+                          "this checks the path, the number is not a scaling figure)" if alias_n > 1 else "GPUs") + ": batches dealt to the lanes in turn, no collective, packets placed in frame order "
+                          "and compared with the N = 1 run's; lanes grouped by their device's NUMA node")
+            if result is not None:
+                result["single_process_sharding"] = sp
+        barrier()
     if rank == 0 and world > 1 and result is not None:
         result["single_job_note"] = ("frames shard over the GPUs with no collective; a single JOB, though, writes ONE Matroska file, whose page allocation runs at "
                                      "~13 GB/s = ~265 4K frames/s whatever the GPU count (e2e record at N = 1): N GPUs pay off for N jobs side by side or for a caller that keeps packets in memory")

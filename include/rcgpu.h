@@ -244,6 +244,12 @@ typedef struct {
 int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, const rcgpu_sequence_io* io,
                                const rcgpu_sequence_options* options, rcgpu_sequence_stats* stats, uint8_t* record, size_t* record_size);
 
+/* The sharding rcgpu_ffv1_encode_sequence follows, without a device: frames are coded in batches of `batch` consecutive frames, batch b on
+ * lane b mod lanes (a lane = one device of the selection; SURVEY.md 8e: frames shard with no exchange because every frame is a key frame and
+ * every slice resets its contexts, CLI/Global.cpp:959-960).  lane_of_frame / batch_of_frame: n_frames entries each, either may be NULL.  For
+ * callers that want their input staged next to the device that will read it. */
+int rcgpu_sequence_plan(uint64_t n_frames, uint32_t batch, uint32_t lanes, uint32_t* lane_of_frame, uint32_t* batch_of_frame);
+
 /* The same with host memory on both ends: frame i = frames[i % n_in], packet i -> out[i % n_out] (out_cap bytes each, may be NULL to
  * drop the bytes) and sizes[i] (n_frames entries, may be NULL).  n_in == n_out == n_frames: rcgpu_ffv1_encode_host for a whole
  * sequence, pipelined. */

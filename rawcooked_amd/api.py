@@ -106,6 +106,7 @@ SYMBOLS = {
     "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rcgpu_ffv1_last_error_flags": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
+    "rcgpu_sequence_plan": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rcgpu_ffv1_encode_sequence": (C.c_int, [C.POINTER(Ffv1Config), C.c_uint64, C.POINTER(SequenceIo), C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
     "rcgpu_ffv1_encode_sequence_memory": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP), C.c_uint64, C.c_uint64, C.POINTER(_VP), C.c_uint64, _SZ, C.POINTER(C.c_uint64),
                                           C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
@@ -323,6 +324,14 @@ class Ffv1Encoder:
         if n < 0:
             raise RcgpuError(f"rcgpu_ffv1_debug_fetch({what}) -> {n}")
         return buf.raw[:n]
+
+
+def sequence_plan(n_frames: int, batch: int, lanes: int) -> tuple[list[int], list[int]]:
+    """rcgpu_sequence_plan: (lane of every frame, batch of every frame) -- the sharding rcgpu_ffv1_encode_sequence follows; needs no device."""
+    lane = (C.c_uint32 * max(1, n_frames))()
+    bat = (C.c_uint32 * max(1, n_frames))()
+    _check(lib().rcgpu_sequence_plan(n_frames, batch, lanes, lane, bat), "rcgpu_sequence_plan")
+    return list(lane[:n_frames]), list(bat[:n_frames])
 
 
 def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, place_packet=None, batch=0, readers=0, writers=0,

@@ -332,6 +332,32 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
     return 0;
 }
 
+// The sharding of a job: runs of consecutive frames of one video (at most F[video] of them) are the batches, dealt to the lanes -- the
+// devices -- in turn.  Frames are independent (every frame a key frame, every slice resets its contexts: CLI/Global.cpp:959-960,
+// FFV1_Slice.cpp:180-197,274-275), so nothing else is shared: no collective, one placer restores the order.  Also behind
+// rcgpu_sequence_plan, which is how the CPU tests see the plan the devices follow.
+static void plan_batches(const std::vector<uint32_t>& video_of, const std::vector<uint32_t>& F, const std::vector<uint64_t>& video_frames, int nl, bool ramp,
+                         std::vector<batch_t>& batches, std::vector<uint32_t>& batch_of)
+{
+    const size_t N = video_of.size();
+    batches.clear(); batch_of.assign(N, 0);
+    std::vector<uint32_t> made(F.size(), 0);
+    for (size_t i = 0; i < N;) {
+        const uint32_t v = video_of[i];
+        size_t cap = F[v];
+        if (ramp && video_frames[v] > 2 * uint64_t(F[v]) && F[v] >= 40) {
+            const uint32_t k = made[v] / uint32_t(nl);                       // every lane gets a short first and second batch
+            if (k == 0) cap = F[v] / 5; else if (k == 1) cap = F[v] / 2;
+        }
+        made[v]++;
+        size_t n = 1;
+        while (i + n < N && n < cap && video_of[i + n] == v) n++;
+        for (size_t k = 0; k < n; k++) batch_of[i + k] = uint32_t(batches.size());
+        batches.push_back({ v, i, n, int(batches.size() % size_t(nl)) });
+        i += n;
+    }
+}
+
 int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe_stats* stats)
 {
     impl& s = *p;
@@ -344,25 +370,17 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
     const int nl = int(s.lanes.size());
 
     // ---- batches: runs of consecutive frames of one video, dealt round-robin to the lanes
-    // RCGPU_RAMP=1 makes the first two batches of a long sequence short (a fifth and a half).  Measured in round 3 on 1000 4K files:
+    // RCGPU_RAMP=1 (timing build) makes the first two batches of a long sequence short (a fifth and a half).  Measured in round 3 on 1000 4K files:
     // the first packet leaves after 0.8 s instead of 1.3 s, but five batches instead of three have five starts and drains -- the job
     // takes 8.1 s instead of 7.1 s, host to host 550 instead of 573 frames/s.  For callers that want the first packet early, not the last.
     std::vector<batch_t> batches; std::vector<uint32_t> batch_of(N);
-    std::vector<uint32_t> made(s.videos.size(), 0);
     static const bool ramp = TIMING_ENV("RCGPU_RAMP") != nullptr;
-    for (size_t i = 0; i < N;) {
-        const uint32_t v = frames[i].video;
-        size_t cap = s.F[v];
-        if (ramp && s.videos[v].frames > 2 * uint64_t(s.F[v]) && s.F[v] >= 40) {
-            const uint32_t k = made[v] / uint32_t(nl);                       // every lane gets a short first and second batch
-            if (k == 0) cap = s.F[v] / 5; else if (k == 1) cap = s.F[v] / 2;
-        }
-        made[v]++;
-        size_t n = 1;
-        while (i + n < N && n < cap && frames[i + n].video == v) n++;
-        for (size_t k = 0; k < n; k++) batch_of[i + k] = uint32_t(batches.size());
-        batches.push_back({ v, i, n, int(batches.size() % size_t(nl)) });
-        i += n;
+    {
+        std::vector<uint32_t> video_of(N);
+        for (size_t i = 0; i < N; i++) video_of[i] = frames[i].video;
+        std::vector<uint64_t> vframes(s.videos.size());
+        for (size_t vi = 0; vi < s.videos.size(); vi++) vframes[vi] = s.videos[vi].frames;
+        plan_batches(video_of, s.F, vframes, nl, ramp, batches, batch_of);
     }
     uint32_t maxF = 1; size_t max_pkt = 0, max_payload = 0;
     for (size_t vi = 0; vi < s.videos.size(); vi++) { maxF = std::max(maxF, s.F[vi]); max_pkt = std::max(max_pkt, s.max_packet[vi]); max_payload = std::max(max_payload, s.payload[vi]); }
@@ -876,6 +894,22 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
         for (int i = 0; i < 16; i++) { stats->lane_device[i] = ps.lane_device[i]; stats->lane_numa_node[i] = ps.lane_node[i]; stats->lane_pinned_node[i] = ps.lane_pinned_node[i]; }
     }
     return r;
+}
+
+// Which lane -- which device of device_first .. device_first + device_count - 1 -- codes which frame of a sequence of n_frames coded in batches
+// of `batch` frames: lane_of_frame and batch_of_frame receive n_frames entries each (either may be NULL).  No device needed.
+extern "C" int rcgpu_sequence_plan(uint64_t n_frames, uint32_t batch, uint32_t lanes, uint32_t* lane_of_frame, uint32_t* batch_of_frame)
+{
+    rc::clear_error();
+    if (!batch || !lanes) return rc::fail(1, "sequence plan: batch and lanes must be at least 1");
+    std::vector<uint32_t> video_of(size_t(n_frames), 0), batch_of;
+    std::vector<rc::batch_t> batches;
+    rc::plan_batches(video_of, { batch }, { n_frames }, int(lanes), false, batches, batch_of);
+    for (uint64_t i = 0; i < n_frames; i++) {
+        if (lane_of_frame) lane_of_frame[i] = uint32_t(batches[batch_of[size_t(i)]].lane);
+        if (batch_of_frame) batch_of_frame[i] = batch_of[size_t(i)];
+    }
+    return 0;
 }
 
 // Host memory in, host memory out: frame i is frames[i % n_in], packet i lands in out[i % n_out] (out_cap bytes each) and sizes[i].

@@ -1,5 +1,7 @@
-"""CPU, world_size 2 over gloo: the N>1 bench path shards frames with no data-path collective; only the barrier and the
-max-over-ranks timing use the process group (bench.py).  This exercises exactly those two calls plus the shard plan."""
+"""CPU: the sharding of the product and the plumbing of the N>1 bench.  Frames shard with no data-path collective: rcgpu_sequence_plan is the
+plan rcgpu_ffv1_encode_sequence follows inside one process (a lane per device, rawcooked_amd/csrc/pipeline.hip) and needs no device; the
+bench's ranks (one per GPU, as the driver launches them) use the process group for the barrier and the max-over-ranks timing only.  World
+size 2 over gloo exercises exactly those calls, with every rank taking the frames the plan gives "its" lane."""
 import os
 import subprocess
 import sys
@@ -8,16 +10,24 @@ import textwrap
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_shard_plan_covers_every_frame_once():
+def test_the_products_shard_plan_covers_every_frame_once_in_order():
     sys.path.insert(0, ROOT)
-    from rawcooked_amd.dist import shard_frames
-    for n in (0, 1, 7, 64, 1000):
-        for world in (1, 2, 3, 8):
-            seen = []
-            for r in range(world):
-                seen += shard_frames(n, r, world, batch=5)
-            assert sorted(seen) == list(range(n))
-    assert shard_frames(10, 0, 2, batch=2) == [0, 1, 4, 5, 8, 9] and shard_frames(10, 1, 2, batch=2) == [2, 3, 6, 7]
+    from rawcooked_amd import api
+    for n in (0, 1, 7, 64, 1000, 2000):
+        for lanes in (1, 2, 3, 8):
+            for batch in (1, 5, 336):
+                lane, bat = api.sequence_plan(n, batch, lanes)
+                assert len(lane) == n and all(0 <= x < lanes for x in lane)
+                assert bat == [i // batch for i in range(n)]                     # batches are runs of consecutive frames ...
+                assert lane == [(i // batch) % lanes for i in range(n)]         # ... dealt to the lanes in turn (batch b -> lane b mod lanes)
+    lane, _ = api.sequence_plan(10, 2, 2)
+    assert [i for i in range(10) if lane[i] == 0] == [0, 1, 4, 5, 8, 9] and [i for i in range(10) if lane[i] == 1] == [2, 3, 6, 7]
+    # BASELINE config 4: 2000 frames over 8 GPUs in batches of 80 -> 25 batches, lanes 0..7 then 0 again; no lane idles while another has two more
+    lane, bat = api.sequence_plan(2000, 80, 8)
+    per_lane = [sum(1 for x in lane if x == k) for k in range(8)]
+    assert max(per_lane) - min(per_lane) <= 80 and sum(per_lane) == 2000
+    with __import__("pytest").raises(api.RcgpuError):
+        api.sequence_plan(10, 0, 2)
 
 
 def test_two_ranks_gloo(tmp_path):
@@ -26,13 +36,15 @@ def test_two_ranks_gloo(tmp_path):
         import os, sys, time
         sys.path.insert(0, {ROOT!r})
         import torch, torch.distributed as dist
-        from rawcooked_amd import dist as rdist
-        from rawcooked_amd.dist import shard_frames, max_over_ranks
+        import bench_dist as rdist
+        from bench_dist import max_over_ranks
+        from rawcooked_amd import api
         # the same calls bench.py makes at N > 1, with gloo in place of RCCL
         d2 = rdist.init(int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), 0, "gloo", torch.device("cpu"))
         assert d2 is dist
         r = dist.get_rank()
-        mine = shard_frames(10, r, 2, batch=2)
+        lane_of, _ = api.sequence_plan(10, 2, 2)          # the product's plan: this rank plays lane r
+        mine = [i for i in range(10) if lane_of[i] == r]
         rdist.barrier(dist)
         t = max_over_ranks(dist, 1.0 + r, torch.device("cpu"))
         calls = []
