@@ -149,7 +149,7 @@ def cpu_baseline(payloads: list, line_bytes: int, width: int, height: int, gpu_p
                       f"absent here)"}, not bad
 
 
-def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=256, cpu_frames=32, variants=None):
+def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=1000, cpu_frames=32, variants=None):
     """The product-level number of BASELINE config 5: `rawcooked_linked --check` -- the REAL reference with this library linked in
     (INTEGRATION.md route C: oracle/route_c_*.patch, built by oracle/Makefile.ref) -- on an MKV of this run's packets.  The demuxer
     announces the frames that follow, the device decoder takes them in batches (RCGPU_CHECK_BATCH) and keeps the payloads; frame_writer
@@ -168,29 +168,36 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
     try:
         F = len(sizes)
         n = max(1, nframes)
+        payload_b = int(frames[0].numel())
+        if base and shutil.disk_usage(base).free < 1.3 * (n * max(sizes) + min(n, F) * payload_b + (4 << 30)):
+            n = min(n, 256)                       # BASELINE config 2 is 1000 frames; a box whose tmpfs cannot hold their MKV gets a shorter one, and says so
         m = min(n, max(1, cpu_frames))
 
-        def run(cmd, cwd, env=None, timeout=90):      # the reference occasionally dead-locks in its own analysis thread pool on many-core hosts: bounded, retried
-            for attempt in range(3):
+        def run(cmd, cwd, env=None, timeout=90):
+            # bounded, ONE retry: the lost wake-up of the reference's third-party thread pool (Lib/ThirdParty/thread-pool/include/ThreadPool.h:27-33
+            # against :66-68) leaves matroska::Shutdown() in std::thread::join (Matroska.cpp:271-274); stacks in profiles/r04_hang_stacks.txt
+            for attempt in range(2):
                 try:
                     t0 = time.perf_counter()
                     r_ = subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=timeout, env=env)
                     r_.seconds = time.perf_counter() - t0
                     return r_
                 except subprocess.TimeoutExpired:
-                    if attempt == 2:
+                    if attempt == 1:
                         raise
 
         def package(name, count):
             d = os.path.join(work, name)
             os.makedirs(os.path.join(d, "seq"))
+            os.makedirs(os.path.join(d, "uniq"))
             host = {}
-            for i in range(count):
+            for i in range(count):              # the sequence: F distinct pictures, the rest hard links to them (SURVEY.md 8d "ring reuse"; the e2e leg does the same)
                 k = i % F
                 if k not in host:
-                    host[k] = (bytes(frames[k].cpu().numpy()), bytes(d_packets[k * stride:k * stride + sizes[k]].cpu().numpy()))
-                with open(os.path.join(d, "seq", "f_%06d.dpx" % i), "wb") as f:
-                    f.write(synth.dpx_file(None, pixfmt, frame_index=i, payload=host[k][0], size=(width, height)))
+                    host[k] = bytes(d_packets[k * stride:k * stride + sizes[k]].cpu().numpy())
+                    with open(os.path.join(d, "uniq", "u_%06d.dpx" % k), "wb") as f:
+                        f.write(synth.dpx_file(None, pixfmt, frame_index=k, payload=bytes(frames[k].cpu().numpy()), size=(width, height)))
+                os.link(os.path.join(d, "uniq", "u_%06d.dpx" % k), os.path.join(d, "seq", "f_%06d.dpx" % i))
             r = run([exe, "--hash", "--no-check-padding", "-d", "-y", "seq"], d, timeout=120)      # analysis only: the reversibility data with the MD5 of every file (route D)
             if r.returncode != 0:
                 raise RuntimeError("analysis failed: " + (r.stderr or r.stdout)[-200:])
@@ -199,7 +206,7 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
             mux.add_attachment("RAWcooked reversibility data", open(os.path.join(d, "seq.rawcooked_reversibility_data"), "rb").read())
             mux.begin()
             for i in range(count):
-                mux.write_block(t, i * 1000000000 // 24, host[i % F][1])
+                mux.write_block(t, i * 1000000000 // 24, host[i % F])
             mux.close()
             return d, r.seconds
         big, analysis_s = package("big", n)
@@ -207,7 +214,7 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
         out = {"frames": n, "unit": "frames/s", "analysis_seconds": round(analysis_s, 2)}
         OKL = "Reversibility was checked, no issue detected."
         # `--check x.mkv` judges by the MD5s in the reversibility data; with `-o .` the rebuilt files are also compared with the sources on disk
-        batch = os.environ.get("RCGPU_LINKED_BATCH", str(n))       # frames per device call; by default the whole MKV is one batch
+        batch = os.environ.get("RCGPU_LINKED_BATCH", "256")        # frames per device call (the patch's own default)
         todo = (("device_decoder", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": batch}, big, n, []),
                 ("device_decoder_and_sources", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": batch}, big, n, ["-o", "."]),
                 ("device_decoder_payloads_to_host", {"RCGPU_CHECK": "1", "RCGPU_CHECK_DEFER": "0", "RCGPU_CHECK_BATCH": "128"}, small, m, []),
@@ -263,7 +270,7 @@ def reference_check_baseline(api, synth, record, frames, d_packets, stride, size
         for i in range(n):
             with open(os.path.join(work, "seq", "f_%06d.dpx" % i), "wb") as f:
                 f.write(synth.dpx_file(None, pixfmt, frame_index=i, payload=bytes(frames[i].cpu().numpy()), size=(width, height)))
-        def run(cmd):       # the reference occasionally dead-locks in its own thread pool on many-core hosts: bounded, with one retry
+        def run(cmd):       # bounded, one retry: the reference's thread pool can lose its shutdown wake-up (ThreadPool.h:27-33,66-68; profiles/r04_hang_stacks.txt)
             for attempt in (0, 1):
                 try:
                     return subprocess.run(cmd, cwd=work, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=60)
@@ -639,11 +646,18 @@ def check576_leg(args, torch, api, synth, dev, device, width, height):
     torch.cuda.synchronize()
     flags = enc.error_flags()
     sizes = d_sizes.cpu().tolist(); record = enc.config_record(); enc.close()
+    # the product-level figure at the slice count RAWcooked itself asks FFmpeg for: the real reference with the device decoder linked in, 1000 frames
+    linked = None
+    if "cpu" in {x for x in args.legs.split(",") if x}:
+        linked = linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=1000, variants={"device_decoder"})
     rec, ok = check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device,
                         steps=2, warmup=1, cpu=False, check_batch=256)
     del frames, d_packets
     torch.cuda.empty_cache()
-    return {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline") if k in rec}, ok and flags == 0
+    out = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline") if k in rec}
+    if linked:
+        out["linked_check"] = linked
+    return out, ok and flags == 0
 
 
 def bind_to_numa_node(node: int) -> None:

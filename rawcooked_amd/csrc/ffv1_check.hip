@@ -238,42 +238,51 @@ template <int K> __device__ __forceinline__ uint32_t rd_bit_k(rd_lane& r, uint32
     return bit;
 }
 template <int J> struct rd_steps {
-    // exponent: step J reads state 1 + min(J, 9); `going` = the lanes whose ones have not ended yet
-    static __device__ __forceinline__ void unary(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16, bool& going, uint32_t& e, bool& over)
+    // exponent: step J reads state 1 + min(J, 9); `going` = the lanes whose ones have not ended yet.  Returns the number of steps that ran (a
+    // uniform value: every branch here is taken by the whole wavefront)
+    static __device__ __forceinline__ int unary(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16, bool& going, uint32_t& e, bool& over)
     {
-        if (__ballot(going) == 0) return;
+        if (__builtin_amdgcn_ballot_w64(going) == 0) return J;
         const uint32_t b = rd_bit_k<1 + (J < 9 ? J : 9)>(r, w, t16, going);
         going = going && b != 0;
         e += going ? 1u : 0u;
-        if (J == 31) { over = going; going = false; }                // a 32nd one: the value is 0 (`if (++e > 31) return 0`)
-        else rd_steps<J + 1>::unary(r, w, t16, going, e, over);
-    }
-    // mantissa: bit I (from e - 1 down to 0) reads state 22 + min(I, 9)
-    static __device__ __forceinline__ void mantissa(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16, bool live, uint32_t e, int32_t& a)
-    {
-        constexpr int I = 31 - J;
-        const bool act = live && uint32_t(I) < e;
-        if (__ballot(act) != 0) {
-            const uint32_t b = rd_bit_k<22 + (I < 9 ? I : 9)>(r, w, t16, act);
-            a = act ? (a << 1) | int32_t(b) : a;
-        }
-        rd_steps<J + 1>::mantissa(r, w, t16, live, e, a);
+        if (J == 31) { over = going; going = false; return 32; }     // a 32nd one: the value is 0 (`if (++e > 31) return 0`)
+        else return rd_steps<J + 1>::unary(r, w, t16, going, e, over);
     }
 };
 template <> struct rd_steps<32> {
-    static __device__ __forceinline__ void unary(rd_lane&, uint32_t (&)[8], const uint16_t*, bool&, uint32_t&, bool&) {}
-    static __device__ __forceinline__ void mantissa(rd_lane&, uint32_t (&)[8], const uint16_t*, bool, uint32_t, int32_t&) {}
+    static __device__ __forceinline__ int unary(rd_lane&, uint32_t (&)[8], const uint16_t*, bool&, uint32_t&, bool&) { return 32; }
 };
+// mantissa: bit I (from e - 1 down to 0) reads state 22 + min(I, 9).  The exponent chain ran `steps` steps, so the largest exponent of the
+// wavefront is steps - 1 and its first mantissa bit is I = steps - 2: steps above that are skipped on a SCALAR comparison (two SALU
+// instructions; asking the lanes -- compare, ballot, branch -- was five, for each of 32 steps of every sample: a ninth of the kernel's
+// instructions), and from there down every step concerns at least that lane.
+template <int I> struct rd_man {
+    static __device__ __forceinline__ void run(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16, bool live, uint32_t e, int32_t& a, int top)
+    {
+        if (I <= top) {
+            const bool act = live && uint32_t(I) < e;
+            const uint32_t b = rd_bit_k<22 + (I < 9 ? I : 9)>(r, w, t16, act);
+            a = act ? (a << 1) | int32_t(b) : a;
+        }
+        rd_man<I - 1>::run(r, w, t16, live, e, a, top);
+    }
+};
+template <> struct rd_man<-1> { static __device__ __forceinline__ void run(rd_lane&, uint32_t (&)[8], const uint16_t*, bool, uint32_t, int32_t&, int) {} };
+__device__ __forceinline__ void rd_mantissa(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16, bool live, uint32_t e, int32_t& a, int steps)
+{
+    rd_man<30>::run(r, w, t16, live, e, a, steps - 2);
+}
 // rangecoder::s (FFV1_RangeCoder.cpp:206-236) for all lanes of the wavefront
 __device__ __forceinline__ int32_t rd_s_regs(rd_lane& r, uint32_t (&w)[8], const uint16_t* t16)
 {
     const bool zero = rd_bit_k<0>(r, w, t16, true) != 0;
     bool going = !zero, over = false;
     uint32_t e = 0;
-    rd_steps<0>::unary(r, w, t16, going, e, over);
+    const int steps = __builtin_amdgcn_readfirstlane(rd_steps<0>::unary(r, w, t16, going, e, over));
     const bool live = !zero && !over;
     int32_t a = 1;
-    rd_steps<0>::mantissa(r, w, t16, live, e, a);
+    rd_mantissa(r, w, t16, live, e, a, steps);
     // sign: state 11 + min(e, 10) -- the one index that differs from lane to lane: its dword is picked by selects, its byte by a shift
     const uint32_t k = 11 + (e < 10 ? e : 10), d = k >> 2, sh = (k & 3) * 8;
     uint32_t c2 = w[2], c3 = w[3], c4 = w[4], c5 = w[5];

@@ -32,10 +32,14 @@ def make_package(work, w, h, pixfmt, nframes, kind, tiff=False, audio=None, star
             f.write(synth.wav_file(synth.pcm_samples(n, ch, abits, rate), abits, rate))
 
 
-def run(cmd, cwd, timeout=20, attempts=5):
-    """Run one step of the round trip.  The reference binary occasionally dead-locks in its own analysis thread pool on many-core
-    hosts (seen ~1 in 200 invocations of `rawcooked -d` on the GPU box, never with this repo's code involved), so a step that
-    times out is repeated -- every step is idempotent (-y)."""
+def run(cmd, cwd, timeout=20, attempts=2):
+    """Run one step of the round trip.  ONE retry, for one known cause in unpatched reference code: the lost wake-up of its third-party
+    thread pool -- `shutdown()` sets `m_shutdown` and calls `notify_all()` without the mutex (Lib/ThirdParty/thread-pool/include/
+    ThreadPool.h:66-68) while a worker that has just tested `while (!m_pool->m_shutdown)` has not reached its `wait()` yet (:27-33); the
+    worker then sleeps for good and `matroska::Shutdown()` (Lib/Compressed/Matroska/Matroska.cpp:271-274, `FramesPool->shutdown()`) never
+    returns from `std::thread::join`.  tools/hang/hang_hunt.py caught it six times in 750 runs on the GPU box (profiles/r04_hang_stacks.txt:
+    every one of them this picture -- main thread in Shutdown() -> join, one pool worker in condition_variable::wait, the HSA runtime's two
+    event threads idle, no thread inside rcgpu_* or an RCGPU_LINKED block); every step is idempotent (-y)."""
     for attempt in range(attempts):
         try:
             return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, stdin=subprocess.DEVNULL)

@@ -71,8 +71,9 @@ def test_roundtrip_edges(built, w, h, pixfmt, nh, nv, kind):
     assert ob.lib().ffv1o_decode_payload(__import__("ctypes").byref(p), bytes(bad), len(bad), out, lb) != 0   # slice CRC catches it
 
 
-def _run_ref(cmd, cwd, timeout=120, attempts=3):
-    """The reference occasionally dead-locks in its own thread pool on many-core hosts: repeat a step that times out (idempotent, -y)."""
+def _run_ref(cmd, cwd, timeout=120, attempts=2):
+    """One retry (idempotent steps, -y): the reference's third-party thread pool can lose its shutdown wake-up (ThreadPool.h:27-33 against
+    :66-68; matroska::Shutdown() then never returns from std::thread::join, Matroska.cpp:271-274); stacks in profiles/r04_hang_stacks.txt."""
     for attempt in range(attempts):
         try:
             return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, stdin=subprocess.DEVNULL)
