@@ -171,6 +171,8 @@ def lib() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         dbg = L.rcgpu_ffv1_debug_fetch
         dbg.restype, dbg.argtypes = C.c_longlong, [_VP, C.c_int, C.c_uint32, _VP, _SZ]
+        L.rcgpu_ffv1_decoder_debug_window.restype, L.rcgpu_ffv1_decoder_debug_window.argtypes = C.c_int, [_VP, C.c_uint32]
+        L.rcgpu_ffv1_decoder_debug_careful.restype, L.rcgpu_ffv1_decoder_debug_careful.argtypes = C.c_longlong, [_VP]
         _lib = L
     return _lib
 
@@ -389,6 +391,15 @@ class Ffv1Decoder:
             self.h = _VP()
 
     __del__ = close
+
+    def debug_window(self, nbytes: int) -> None:
+        """Test hook: the sample decoder's byte window is filled to `nbytes` (1..7) instead of 7, so that samples outrun it and go through the careful path."""
+        if lib().rcgpu_ffv1_decoder_debug_window(self.h, nbytes) != 0:
+            raise RcgpuError("rcgpu_ffv1_decoder_debug_window failed")
+
+    def debug_careful(self) -> int:
+        """Samples (per wavefront) of the last batch that were decoded a second time, carefully."""
+        return int(lib().rcgpu_ffv1_decoder_debug_careful(self.h))
 
     def decode_device(self, packet_ptrs: list[int], packet_sizes: list[int], payload_ptrs: list[int], stream: int = 0, check: bool = True) -> int:
         n = len(packet_ptrs)

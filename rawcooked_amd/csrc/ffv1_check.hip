@@ -46,6 +46,7 @@ struct dec_const {
     uint32_t fields, fill, vflip, altern;  // payload layout of the bit-packed DPX flavors (rc_common.h kFields*), RCGPU_FLAG_*
     uint32_t num_h, num_v, S, nctx, nsets, ec, is5, index_count, qidx;
     uint32_t v1, hdr_n;                    // FFV1 version 1: one slice = the packet, hdr_n header decisions in front of it, no footer
+    uint32_t win_cap;                      // bytes a lane's window is filled up to (7; rcgpu_ffv1_decoder_debug_window makes it less, for the tests of the careful path)
     int16_t  q[5][256];
     uint8_t  one_state[256], zero_state[256];
 };
@@ -106,9 +107,13 @@ __global__ __launch_bounds__(256) void k_dec_crc(const dec_const* __restrict__ C
 // lock-step some lane renormalises at almost every decision, and a global byte load there stalls the whole wavefront every time.
 struct rd_lane {
     uint32_t current, mask;
-    uint32_t pos, n;                  // bytes consumed so far (Buffer_Cur - Buffer) and size of the slice's coded data
-    uint32_t win_hi, win_lo, nwin;    // window: the next nwin bytes, left aligned in win_hi:win_lo; zeros stand in once the data is used up
-    unsigned long long pend; uint32_t npend;
+    uint32_t pos, n;                  // bytes consumed as of the last refill (Buffer_Cur - Buffer), size of the slice's coded data
+    // The window: the next `have` (<= 7) bytes of the slice, left aligned in win_hi:win_lo, then a SENTINEL byte 0x80, then zeros.  A
+    // renormalisation shifts the whole window left by a byte and keeps no count: how many bytes are left is read off the sentinel -- the
+    // lowest set bit of the window -- when somebody asks (once per sample).  A window of all zeros means the sentinel itself was consumed as
+    // data: the sample read more bytes than the window held (rd_underflow), and is decoded again by the careful decoder below.
+    uint32_t win_hi, win_lo, have, cap;           // cap: the window is filled up to this many bytes (7)
+    unsigned long long pend; uint32_t npend;      // a further load, issued one sample earlier
     unsigned long long pend2; uint32_t have2;     // the second half of a 16-byte load, waiting to become `pend`
     const uint8_t* next; const uint8_t* end;      // first byte not yet loaded, end of the coded data
 };
@@ -135,32 +140,50 @@ __device__ __forceinline__ void rd_load(rd_lane& r)
     }
     r.npend = 8;
 }
-// At a sample boundary (all lanes converged): move arrived bytes into the window, then put the next load in flight.
+__device__ __forceinline__ bool rd_underflow(const rd_lane& r) { return (r.win_hi | r.win_lo) == 0; }
+// valid bytes left in the window: the sentinel's 0x80 is the lowest set bit, at bit 63 - 8 * valid
+__device__ __forceinline__ uint32_t rd_valid(const rd_lane& r)
+{
+    const uint32_t low = r.win_lo ? uint32_t(__builtin_ctz(r.win_lo)) : 32u + uint32_t(__builtin_ctz(r.win_hi | 0x80000000u));
+    return (63u - low) >> 3;
+}
+// At a sample boundary (all lanes converged, no underflow): account for what was consumed, move arrived bytes into the window behind the
+// valid ones, set the sentinel anew, then put the next load in flight.
 __device__ __forceinline__ void rd_refill(rd_lane& r)
 {
-    if (r.npend && r.nwin < 8) {
-        const uint32_t k = min(r.npend, 8 - r.nwin);
-        const unsigned long long add = r.pend >> (8 * r.nwin);
-        r.win_hi |= uint32_t(add >> 32); r.win_lo |= uint32_t(add);
-        r.pend = k < 8 ? r.pend << (8 * k) : 0ull;
-        r.npend -= k; r.nwin += k;
-    }
+    const uint32_t v = rd_valid(r);
+    r.pos += r.have - v;
+    const uint32_t take = min(r.npend, r.cap > v ? r.cap - v : 0u);
+    unsigned long long w = (unsigned long long)r.win_hi << 32 | r.win_lo;
+    w &= w - 1;                                                                   // the sentinel goes
+    const uint32_t nv = v + take;                                                 // <= 7
+    w |= r.pend >> (8 * v);
+    w &= nv ? ~0ull << (8 * (8 - nv)) : 0ull;                                     // only the bytes taken
+    w |= 0x80ull << (8 * (7 - nv));                                               // ... and the sentinel behind them
+    r.win_hi = uint32_t(w >> 32); r.win_lo = uint32_t(w);
+    r.have = nv;
+    r.pend = take < 8 ? r.pend << (8 * take) : 0ull;
+    r.npend -= take;
     if (!r.npend) {
         if (r.have2) { r.pend = r.pend2; r.npend = 8; r.have2 = 0; }
         else rd_load(r);
     }
 }
+// exact count of consumed bytes right now (end of slice)
+__device__ __forceinline__ uint32_t rd_pos(const rd_lane& r) { return r.pos + r.have - rd_valid(r); }
 
 // A lane's 32 context states live in LDS as eight dwords of a [8][64] array (dword k of lane l at (k*64 + l)*4): for a state index
 // that is uniform over the wavefront every lane touches its own dword -- no bank conflicts, where a [lane][32] layout gives 16-way.
 #define ST_AT(base, k) ((base)[(uint32_t(k) >> 2) * 256 + (uint32_t(k) & 3)])
 
-// rangecoder::b (FFV1_RangeCoder.cpp:71-102), without a branch in the common path: the renormalisation is a handful of selects.
+// rangecoder::b (FFV1_RangeCoder.cpp:71-102), the CAREFUL form: before a renormalisation it looks whether the window still holds a byte and
+// refills on the spot if not.  Slice headers, the end-of-slice bit, and the rare sample that outruns its window (rd_s_careful).
 __device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* base, int k, const uint8_t* trans)
 {
     const bool need = r.mask < 0x100;
-    if (__builtin_expect(__ballot(need && !r.nwin) != 0, 0)) {        // a sample used more than the window held: refill on the spot (rare)
-        if (need && !r.nwin) { rd_refill(r); rd_refill(r); }
+    const bool empty = r.win_hi == 0x80000000u && r.win_lo == 0;       // nothing but the sentinel
+    if (__builtin_expect(__ballot(need && empty) != 0, 0)) {
+        if (need && empty) { rd_refill(r); if (r.win_hi == 0x80000000u && r.win_lo == 0) rd_refill(r); }      // (the first call may only have fetched)
     }
     const uint32_t b = r.win_hi >> 24;
     r.current = need ? (r.current << 8) | b : r.current;
@@ -168,8 +191,6 @@ __device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* base, int k, con
     const uint32_t nhi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24);      // (hi:lo) << 8
     r.win_hi = need ? nhi : r.win_hi;
     r.win_lo = need ? r.win_lo << 8 : r.win_lo;
-    r.nwin -= need ? 1u : 0u;
-    r.pos += need ? 1u : 0u;
     const uint32_t s = ST_AT(base, k);
     const uint32_t m2 = (r.mask * s) >> 8;
     const uint32_t nm = r.mask - m2;
@@ -189,6 +210,16 @@ __device__ __forceinline__ uint32_t rd_u(rd_lane& r, uint8_t* st, const uint8_t*
     for (int i = e - 1; i >= 0; i--) a = (a << 1) | rd_bit(r, st, 22 + (i < 9 ? i : 9), trans);
     return a;
 }
+// rangecoder::s (FFV1_RangeCoder.cpp:206-236) in the careful form, states in the lane's LDS slot: for the sample that outran its window
+__device__ __forceinline__ int32_t rd_s_careful(rd_lane& r, uint8_t* st, const uint8_t* trans)
+{
+    if (rd_bit(r, st, 0, trans)) return 0;
+    int e = 0;
+    while (rd_bit(r, st, 1 + (e < 9 ? e : 9), trans)) { if (++e > 31) return 0; }
+    int32_t a = 1;
+    for (int i = e - 1; i >= 0; i--) a = (a << 1) | int32_t(rd_bit(r, st, 22 + (i < 9 ? i : 9), trans));
+    return rd_bit(r, st, 11 + (e < 10 ? e : 10), trans) ? -a : a;
+}
 // ---- the same symbol decoder for the samples, with the context's 32 states in eight REGISTERS (state k = byte k & 3 of w[k >> 2], the
 // record as it lies in HBM).  A chain's time is its latency: ~32 decision slots per sample (the wavefront walks the longest lane's
 // exponent), and with the states in LDS a slot was two dependent LDS round trips (state, then the transition table) plus the arithmetic.
@@ -201,7 +232,11 @@ template <int K> __device__ __forceinline__ void st_put(uint32_t (&w)[8], uint32
 {
     w[K >> 2] = (w[K >> 2] & ~(0xFFu << (8 * (K & 3)))) | (v << (8 * (K & 3)));
 }
-// one decision of the lanes in `active` against state s; ns = the state afterwards (s itself for the other lanes)
+// one decision of the lanes in `active` against state s; ns = the state afterwards (s itself for the other lanes).  The FAST form: a
+// renormalisation takes the window's top byte and shifts the window, whatever is in it -- no look at how much is left, no counters (the
+// sentinel keeps the count).  In lock-step some lane renormalises at almost every decision; the three instructions and the branch the
+// look cost were paid by all 64 slices every time.  A lane that runs dry reads its sentinel and then zeros: rd_underflow() says so
+// after the sample, and the sample is decoded again carefully.
 __device__ __forceinline__ uint32_t rd_core(rd_lane& r, uint32_t s, const uint16_t* t16, bool active, uint32_t& ns)
 {
     const uint32_t t2 = t16[s];
@@ -209,17 +244,12 @@ __device__ __forceinline__ uint32_t rd_core(rd_lane& r, uint32_t s, const uint16
     ns = s;
     if (active) {
         const bool need = r.mask < 0x100;
-        if (__builtin_expect(__ballot(need && !r.nwin) != 0, 0)) {    // a sample used more than the window held: refill on the spot (rare)
-            if (need && !r.nwin) { rd_refill(r); rd_refill(r); }
-        }
-        const uint32_t b = r.win_hi >> 24;
-        r.current = need ? (r.current << 8) | b : r.current;
+        const uint32_t cur2 = __builtin_amdgcn_alignbit(r.current, r.win_hi, 24);     // (current << 8) | top byte of the window
+        r.current = need ? cur2 : r.current;
         r.mask = need ? r.mask << 8 : r.mask;
-        const uint32_t nhi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24);      // (hi:lo) << 8
+        const uint32_t nhi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24);       // (hi:lo) << 8
         r.win_hi = need ? nhi : r.win_hi;
         r.win_lo = need ? r.win_lo << 8 : r.win_lo;
-        r.nwin -= need ? 1u : 0u;
-        r.pos += need ? 1u : 0u;
         const uint32_t m2 = __umul24(r.mask, s) >> 8;                 // mask < 2^16 after the renormalisation, s < 2^8
         const uint32_t nm = r.mask - m2;
         const bool one = r.current >= nm;
@@ -367,9 +397,10 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     if (len < tail) { atomicOr(err, 8u); return; }
     const uint8_t* buf = packets[f] + slice_start[chain];
     rd_lane r;
-    r.n = len - tail; r.pos = 1; r.win_hi = r.win_lo = 0; r.pend = r.pend2 = 0; r.nwin = r.npend = r.have2 = 0; r.next = buf; r.end = buf + r.n;
-    rd_refill(r); rd_refill(r);
-    r.current = r.win_hi >> 24; r.win_hi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24); r.win_lo <<= 8; r.nwin--;   // AssignBuffer, FFV1_RangeCoder.cpp:22-33
+    r.cap = C->win_cap;
+    r.n = len - tail; r.pos = 0; r.win_hi = 0x80000000u; r.win_lo = 0; r.have = 0; r.pend = r.pend2 = 0; r.npend = r.have2 = 0; r.next = buf; r.end = buf + r.n;
+    rd_refill(r); rd_refill(r);                                      // the first call fetches, the second fills the window
+    r.current = r.win_hi >> 24; r.win_hi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24); r.win_lo <<= 8;   // AssignBuffer, FFV1_RangeCoder.cpp:22-33 (the byte is counted at the next refill)
     r.mask = 0xFF;
     uint8_t* my = slot + lane * 4;
     uint32_t* myw = reinterpret_cast<uint32_t*>(my);               // dword k of this lane's states: myw[k * 64]
@@ -440,7 +471,18 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                 uint32_t sw[8];
                 { const uint4 a0 = gp[0], a1 = gp[1];
                   sw[0] = a0.x; sw[1] = a0.y; sw[2] = a0.z; sw[3] = a0.w; sw[4] = a1.x; sw[5] = a1.y; sw[6] = a1.z; sw[7] = a1.w; }
-                const int32_t delta = rd_s_regs(r, sw, t16);
+                const uint32_t c_cur = r.current, c_mask = r.mask, c_hi = r.win_hi, c_lo = r.win_lo;      // what the fast decoder changes
+                int32_t delta = rd_s_regs(r, sw, t16);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(rd_underflow(r)) != 0, 0)) {
+                    // some slice's sample took more bytes than its window held (up to 35 decisions may each take one; a window holds 7):
+                    // everybody back to the start of the sample, and once more with the decoder that looks before it takes
+                    if (lane == 0) atomicAdd(err + 2, 1u);                                        // (counted: rcgpu_ffv1_decoder_debug_careful)
+                    r.current = c_cur; r.mask = c_mask; r.win_hi = c_hi; r.win_lo = c_lo;
+                    { const uint4 a0 = gp[0], a1 = gp[1];
+                      myw[0] = a0.x; myw[64] = a0.y; myw[128] = a0.z; myw[192] = a0.w; myw[256] = a1.x; myw[320] = a1.y; myw[384] = a1.z; myw[448] = a1.w; }
+                    delta = rd_s_careful(r, my, trans);
+                    for (int k = 0; k < 8; k++) sw[k] = myw[k * 64];
+                }
                 gp[0] = make_uint4(sw[0], sw[1], sw[2], sw[3]); gp[1] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
                 v = (ctx >= 0 ? v + delta : v - delta) & bitmask;
                 cur[size_t(x) * xs] = v;
@@ -465,8 +507,9 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
         }
     // end-of-slice bit, underrun and junk checks (FFV1_Slice.cpp:286-299,336-340)
     my[0] = 129; rd_bit(r, my, 0, trans);
-    const bool underrun = r.pos - (r.mask < 0x100 ? 0 : 1) > r.n;
-    const size_t used = r.pos > r.n ? size_t(r.n) : size_t(r.pos) - (r.mask < 0x100 ? 0 : 1);
+    const uint32_t pos = rd_pos(r);
+    const bool underrun = pos - (r.mask < 0x100 ? 0 : 1) > r.n;
+    const size_t used = pos > r.n ? size_t(r.n) : size_t(pos) - (r.mask < 0x100 ? 0 : 1);
     if (underrun) atomicOr(err, 64u);
     if (used < len - tail) atomicOr(err, 128u);
     if (C->ec && buf[len - 5]) atomicOr(err, 256u);                  // error_status
@@ -767,7 +810,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
         sp.context_model = qidx; sp.compact = cfg->context == 2; sp.coder = cfg->coder == 2 ? 2 : 1; sp.version = 1;
         hdr = ffv1::v1_frame_header_decisions(sp);
     }
-    c.v1 = cfg->level == 1; c.hdr_n = uint32_t(hdr.size());
+    c.v1 = cfg->level == 1; c.hdr_n = uint32_t(hdr.size()); c.win_cap = 7;
     d->nkeys = c.nsets * c.nctx;
     d->payload_bytes = size_t(cfg->line_bytes) * cfg->height;
     const uint32_t F = cfg->max_batch; const size_t nchains = size_t(F) * c.S;
@@ -1263,6 +1306,25 @@ extern "C" int rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* d, const rcgpu
     if (!verdicts) { clear_error(); return fail(1, "ffv1 decoder: null argument"); }
     if (const int rc = rcgpu_ffv1_decoder_verify_kept_begin(d, files, n)) return rc;
     return rcgpu_ffv1_decoder_verify_kept_end(d, verdicts);
+}
+
+// Debug taps for the tests (like rcgpu_ffv1_debug_fetch: exported, not part of include/rcgpu.h).  The sample decoder takes bytes out of a
+// 7-byte window without looking and decodes a sample again, carefully, when it outran the window: with real pictures that almost never
+// happens (1.9 bytes per 16-bit sample), so the tests make the window smaller -- same payloads, the careful path on most samples -- and
+// count how often it ran in the last batch.
+extern "C" int rcgpu_ffv1_decoder_debug_window(rcgpu_ffv1_decoder* d, uint32_t bytes)
+{
+    if (!d || bytes < 1 || bytes > 7) return 1;
+    if (hipSetDevice(d->cfg.device) != hipSuccess) return 2;
+    d->hc.win_cap = bytes;
+    return hipMemcpy(d->d_const, &d->hc, sizeof d->hc, hipMemcpyHostToDevice) == hipSuccess ? 0 : 2;
+}
+extern "C" long long rcgpu_ffv1_decoder_debug_careful(rcgpu_ffv1_decoder* d)
+{
+    if (!d || hipSetDevice(d->cfg.device) != hipSuccess) return -1;
+    uint32_t v[4] = {};
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(v, d->d_err, 16, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long long)v[2];
 }
 
 extern "C" int rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* d, float ms[3])

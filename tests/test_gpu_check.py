@@ -35,6 +35,53 @@ def test_decode_golden_packets(built, v):
     dec.close()
 
 
+@pytest.mark.parametrize("window", [1, 2, 3, 5])
+@pytest.mark.parametrize("v", [v for v in VEC["ffv1"] if v["name"] in ("dpx_rgb16be_64x48", "dpx_rgb10be_50x38", "dpx_rgba12packed_50x38", "dpx_y16be_40x24", "tiff_rgb8_40x30",
+                                                                       "exr_rgb16_72x40", "dpx_rgb16be_coder2_72x40")], ids=lambda v: v["name"])
+def test_samples_that_outrun_their_window_are_decoded_again_carefully(built, v, window):
+    """The sample decoder takes bytes out of a 7-byte window without looking; a sample that took more than the window held (the sentinel
+    was consumed: an all-zero window) is decoded again by the decoder that looks before it takes.  Real pictures almost never get there,
+    so the tests shrink the window (rcgpu_ffv1_decoder_debug_window): with one byte nearly every sample of noisy content goes the careful
+    way -- and the payloads must be the same."""
+    n = len(v["frames"])
+    payloads = [open(os.path.join(G, f["payload"]), "rb").read() for f in v["frames"]]
+    packets = [open(os.path.join(G, f["packet"]), "rb").read() for f in v["frames"]]
+    dec = api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], v["num_h"], v["num_v"], 1, 1, max_batch=n, flags=v["flags"], coder=v["coder"])
+    dpk = [dev(p) for p in packets]
+    careful = {}
+    for cap in (7, window):
+        dec.debug_window(cap)
+        dout = [torch.full((len(p),), 0xAA, dtype=torch.uint8, device="cuda") for p in payloads]
+        assert dec.decode_device([t.data_ptr() for t in dpk], [len(p) for p in packets], [t.data_ptr() for t in dout]) == 0
+        for i in range(n):
+            assert bytes(dout[i].cpu().numpy()) == payloads[i], f"window {cap}: frame {i}"
+        careful[cap] = dec.debug_careful()
+    assert careful[7] <= 2 and careful[window] >= careful[7], careful       # with the full window: (almost) never in these small pictures
+    if window <= 2:
+        assert careful[window] > 0, careful           # ... and a window of one or two bytes cannot hold a 10..16-bit sample's decisions
+    dec.close()
+
+
+def test_a_worst_case_sample_outruns_the_full_window(built):
+    """One slice of uniform 16-bit noise after a long flat run: the contexts' states have adapted to "no change", and the first noisy
+    samples cost far more than the seven bytes of a window.  With the FULL window, the careful path runs, and the picture is right."""
+    import numpy as np
+    w, h, pixfmt = 256, 64, synth.PIX_RGB16_BE
+    rng = np.random.default_rng(5)
+    comp = np.full((h, w, 3), 1000, dtype=np.uint16)
+    comp[8:, :, :] = rng.integers(0, 65536, size=(h - 8, w, 3), dtype=np.uint16)        # flat rows train the states, then noise
+    comp[::2, ::7, :] = 65535; comp[1::2, 3::5, :] = 0                                      # and spikes of full amplitude
+    pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
+    p = ob.Params(w, h, pixfmt, 1, 1, 1, 1)
+    pk = ob.encode_payload(p, pl, line_bytes)
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, 1, 1, 1, 1, max_batch=1)
+    assert dec.decode_host([pk], len(pl))[0] == pl
+    n7 = dec.debug_careful()
+    dec.debug_window(4)
+    assert dec.decode_host([pk], len(pl))[0] == pl and dec.debug_careful() >= n7
+    dec.close()
+
+
 def test_encode_then_decode_on_device_and_verify(built):
     """encode -> decode round trip entirely in HBM at a non-trivial size, verified with the device compare and MD5."""
     w, h, pixfmt, nh, nv, n = 640, 360, synth.PIX_RGB16_BE, 4, 4, 5
