@@ -651,7 +651,7 @@ def check576_leg(args, torch, api, synth, dev, device, width, height):
     if "cpu" in {x for x in args.legs.split(",") if x}:
         linked = linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=1000, variants={"device_decoder"})
     rec, ok = check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device,
-                        steps=2, warmup=1, cpu=False, check_batch=256)
+                        steps=2, warmup=1, cpu=False, check_batch=336)
     del frames, d_packets
     torch.cuda.empty_cache()
     out = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline") if k in rec}
