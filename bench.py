@@ -615,10 +615,19 @@ def cfg4_leg(torch, api, synth, dev, device, steps=2, F=80):
     nl = max(1, launches.get(dom, 1))
     alg = F * (payload + packet_avg) / nl
     ach = alg / (kt[dom] / nl * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: the PMC passes were taken at 4K (profiles/traffic.json); state gathers, write-backs and stream bytes
+    # are per sample, so an 8K frame moves four times a 4K frame's bytes
+    traffic = None
+    try:
+        per4k = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(dom, {}).get("per_frame_bytes")
+        traffic = int(per4k * (w * h) / (W4K * H4K) * F / nl) if per4k else None
+    except Exception:
+        traffic = None
     rec = {"workload": f"config 4 shape on one GPU: {w}x{h} RGB 16-bit LE (TIFF payload), slices={slices} ({nh}x{nv}), {F} frames per step resident in HBM, content=film",
            "value": round(F * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "packet_bytes_avg": int(packet_avg),
            "compression_ratio": round(packet_avg / payload, 4), "device_error_flags": flags, "decodes_to_source_on_device": bool(ok),
-           "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
+                        "traffic_note": "scaled by samples per frame from the 4K PMC passes (profiles/traffic.json)",
                         "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(kt[dom] / nl, 3), "launches_per_step": nl,
                         "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0}}}
     enc.close()
