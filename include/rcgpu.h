@@ -318,13 +318,6 @@ int  rcgpu_ffv1_decoder_decode_keep(rcgpu_ffv1_decoder* dec, const uint8_t* cons
  * against 0.35-0.7 s -- at the price of ~0.4 s when the mapping with all its pages touched is torn down, as matroska::ParseBuffer does after
  * every MiB, Matroska.cpp:394-419: about even.) */
 int  rcgpu_ffv1_decoder_decode_keep_fd(rcgpu_ffv1_decoder* dec, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n);
-/* Read-ahead for the call above: names the batch AFTER the one about to be decoded.  The next decode_keep / decode_keep_fd starts a thread that
- * brings these packets onto the device while its own batch is decoded; the decode_keep_fd that then names exactly them finds them there (a
- * batch that names others reads its own and lets these go).  Measured with the Matroska file on tmpfs: eight threads reading ONE file through
- * pread() get 2-6 GB/s out of it (the same threads copying out of a mapping of it: 20 GB/s), so that a 6 GB batch read ahead takes 0.9-2.9 s beside
- * the decoder -- route C therefore still hands over addresses (oracle/route_c_ffv1_frame_cpp.patch); a file system that reads faster than it maps
- * is what this call is for. */
-int  rcgpu_ffv1_decoder_prefetch_fd(rcgpu_ffv1_decoder* dec, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n);
 int  rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* dec, uint32_t slot, uint8_t* payload);
 int  rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* dec, const rcgpu_kept_file* files, uint32_t n, rcgpu_kept_verdict* verdicts);
 /* The same in two calls, for a caller with more than one batch: _begin takes what it needs of the caller's memory (it may be released when

@@ -126,7 +126,6 @@ SYMBOLS = {
     "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_decode_keep": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32]),
     "rcgpu_ffv1_decoder_decode_keep_fd": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32]),
-    "rcgpu_ffv1_decoder_prefetch_fd": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32]),
     "rcgpu_ffv1_decoder_kept_to_host": (C.c_int, [_VP, C.c_uint32, _VP]),
     "rcgpu_ffv1_decoder_verify_kept": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
     "rcgpu_ffv1_decoder_verify_kept_begin": (C.c_int, [_VP, _VP, C.c_uint32]),
@@ -432,11 +431,6 @@ class Ffv1Decoder:
         """The same with the packets at `offsets` of the open file `fd` (rcgpu_ffv1_decoder_decode_keep_fd)."""
         n = len(offsets)
         _check(lib().rcgpu_ffv1_decoder_decode_keep_fd(self.h, fd, (C.c_uint64 * n)(*offsets), (C.c_uint64 * n)(*sizes), n), "rcgpu_ffv1_decoder_decode_keep_fd")
-
-    def prefetch_fd(self, fd: int, offsets: list[int], sizes: list[int]) -> None:
-        """Starts reading these packets ahead (rcgpu_ffv1_decoder_prefetch_fd): the decode_keep_fd that names them finds them on the device."""
-        n = len(offsets)
-        _check(lib().rcgpu_ffv1_decoder_prefetch_fd(self.h, fd, (C.c_uint64 * n)(*offsets), (C.c_uint64 * n)(*sizes), n), "rcgpu_ffv1_decoder_prefetch_fd")
 
     def kept_to_host(self, slot: int, payload_bytes: int) -> bytes:
         out = C.create_string_buffer(payload_bytes)

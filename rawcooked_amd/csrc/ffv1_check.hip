@@ -728,13 +728,7 @@ struct rcgpu_ffv1_decoder {
     } kept[2];
     int kept_cur = 0;
     size_t kept_stride = 0;
-    uint8_t* d_kept_in[2] = { nullptr, nullptr }; size_t kept_in_cap[2] = { 0, 0 }; int in_cur = 0;    // the packets of a batch; two: one may be filling ahead
-    // packets read ahead (rcgpu_ffv1_decoder_prefetch_fd): while a batch is decoded, a thread brings the next one's packets into the other buffer
-    struct prefetch_t {
-        std::thread th; bool active = false; int fd = -1; std::vector<uint64_t> off, sz; int buf = 0; hipError_t err = hipSuccess;   // under way or done
-        bool want = false; int want_fd = -1; std::vector<uint64_t> want_off, want_sz;                                                  // announced: starts with the next decode
-    } pf;
-    stager up_ahead;
+    uint8_t* d_kept_in = nullptr; size_t kept_in_cap = 0;       // the packets of a batch
     uint8_t* d_disk = nullptr; size_t disk_cap = 0;
     hipStream_t side_stream = nullptr, md5_stream = nullptr; hipEvent_t ev_tab = nullptr, ev_side = nullptr;
     uint8_t* h_edges = nullptr; size_t edges_cap = 0;          // pinned: the bytes before and after the payloads of a batch on their way up
@@ -752,9 +746,7 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
     if (d->md5_stream) (void)hipStreamSynchronize(d->md5_stream);     // a verification begun and never ended
-    if (d->pf.th.joinable()) d->pf.th.join();
-    d->up_ahead.release();
-    for (void* b : { (void*)d->d_kept_in[0], (void*)d->d_kept_in[1], (void*)d->kept[0].d, (void*)d->kept[1].d, (void*)d->d_disk, (void*)d->kept[0].d_tab, (void*)d->kept[1].d_tab }) if (b) (void)hipFree(b);
+    for (void* b : { (void*)d->d_kept_in, (void*)d->kept[0].d, (void*)d->kept[1].d, (void*)d->d_disk, (void*)d->kept[0].d_tab, (void*)d->kept[1].d_tab }) if (b) (void)hipFree(b);
     for (auto& k : d->kept) if (k.h_tab) (void)hipHostFree(k.h_tab);
     if (d->h_edges) (void)hipHostFree(d->h_edges);
     if (d->side_stream) (void)hipStreamDestroy(d->side_stream);
@@ -1024,40 +1016,8 @@ static int decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, int
     uint64_t in_total = 0;
     for (uint32_t i = 0; i < n; i++) in_total += (packet_sizes[i] + 255) & ~uint64_t(255);
     kept_clock clk;
-    // were these packets read ahead?
-    bool ahead = false;
-    if (d->pf.active) {
-        if (d->pf.th.joinable()) d->pf.th.join();
-        d->pf.active = false;
-        ahead = !packets && d->pf.err == hipSuccess && d->pf.fd == fd && d->pf.off.size() == n &&
-                std::equal(d->pf.off.begin(), d->pf.off.end(), offsets) && std::equal(d->pf.sz.begin(), d->pf.sz.end(), packet_sizes);
-        if (ahead) d->in_cur = d->pf.buf;
-        clk.lap(ahead ? "decode_keep: packets were ahead" : "decode_keep: read-ahead unused", n);
-    }
-    if (d->pf.want) {                                         // the batch announced for after this one: its packets go up while this one is decoded
-        d->pf.want = false;
-        d->pf.fd = d->pf.want_fd; d->pf.off.swap(d->pf.want_off); d->pf.sz.swap(d->pf.want_sz);
-        d->pf.buf = d->in_cur ^ 1; d->pf.err = hipSuccess; d->pf.active = true;
-        d->pf.th = std::thread([d]() {
-            auto& pf = d->pf;
-            hipError_t he = hipSetDevice(d->cfg.device);
-            uint64_t total = 0;
-            for (uint64_t z : pf.sz) total += (z + 255) & ~uint64_t(255);
-            if (he == hipSuccess) he = grow(d->d_kept_in[pf.buf], d->kept_in_cap[pf.buf], size_t(total) + 256);
-            if (he == hipSuccess) {
-                std::vector<up_item> up(pf.off.size());
-                uint64_t o = 0;
-                for (size_t i = 0; i < up.size(); i++) {
-                    up[i].dst = d->d_kept_in[pf.buf] + o; up[i].src = nullptr; up[i].size = size_t(pf.sz[i]); up[i].fd = pf.fd; up[i].off = pf.off[i];
-                    o += (pf.sz[i] + 255) & ~uint64_t(255);
-                }
-                he = upload_side_by_side(d->up_ahead, d->cfg.device, up);
-            }
-            pf.err = he;
-        });
-    }
-    uint8_t*& d_in = d->d_kept_in[d->in_cur];
-    if (!ahead) HIP_TRY(grow(d_in, d->kept_in_cap[d->in_cur], size_t(in_total) + 256));
+    uint8_t*& d_in = d->d_kept_in;
+    HIP_TRY(grow(d_in, d->kept_in_cap, size_t(in_total) + 256));
     HIP_TRY(grow(K.d, K.cap, d->kept_stride * n));
     clk.lap("decode_keep: device buffers", n);
     std::vector<up_item> up(n);
@@ -1070,7 +1030,7 @@ static int decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, int
         pk[i] = d_in + off; out[i] = K.d + size_t(i) * d->kept_stride + RCGPU_KEPT_ROOM;
         off += (packet_sizes[i] + 255) & ~uint64_t(255);
     }
-    if (!ahead) {
+    {
         const hipError_t he = upload_side_by_side(d->up, d->cfg.device, up);
         if (he == hipErrorFileNotFound) return fail(20, "ffv1 decoder: the file ends before a packet does");
         HIP_TRY(he);
@@ -1095,16 +1055,6 @@ extern "C" int rcgpu_ffv1_decoder_decode_keep_fd(rcgpu_ffv1_decoder* d, int fd, 
     clear_error();
     if (!d || fd < 0 || !offsets || !packet_sizes) return fail(1, "ffv1 decoder: null argument");
     return decode_keep(d, nullptr, fd, offsets, packet_sizes, n);
-}
-
-extern "C" int rcgpu_ffv1_decoder_prefetch_fd(rcgpu_ffv1_decoder* d, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n)
-{
-    clear_error();
-    if (!d || fd < 0 || !offsets || !packet_sizes || !n) return fail(1, "ffv1 decoder: null argument");
-    if (n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
-    d->pf.want = true; d->pf.want_fd = fd;
-    d->pf.want_off.assign(offsets, offsets + n); d->pf.want_sz.assign(packet_sizes, packet_sizes + n);
-    return 0;
 }
 
 extern "C" int rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* d, uint32_t slot, uint8_t* payload)

@@ -195,19 +195,6 @@ def test_check_with_the_payloads_kept_on_the_device(built):
         fd = os.open(os.path.join(tmp, "all.bin"), os.O_RDONLY)
         dec.decode_keep_fd(fd, offs, [len(pk) for pk in packets])
         assert [dec.kept_to_host(i, len(srcs[i])) for i in range(n)] == srcs
-        # read ahead: batch B's packets go up while batch A is decoded; a batch that was not announced ignores them; a repeated announcement is fine
-        A, Bq = list(range(0, 3)), list(range(3, n))
-        dec.prefetch_fd(fd, [offs[i] for i in Bq], [len(packets[i]) for i in Bq])
-        dec.decode_keep_fd(fd, [offs[i] for i in A], [len(packets[i]) for i in A])
-        assert [dec.kept_to_host(k, len(srcs[i])) for k, i in enumerate(A)] == [srcs[i] for i in A]
-        dec.prefetch_fd(fd, [offs[i] for i in Bq], [len(packets[i]) for i in Bq])
-        dec.prefetch_fd(fd, [offs[i] for i in A], [len(packets[i]) for i in A])
-        dec.prefetch_fd(fd, [offs[i] for i in Bq], [len(packets[i]) for i in Bq])
-        dec.decode_keep_fd(fd, [offs[i] for i in Bq], [len(packets[i]) for i in Bq])
-        assert [dec.kept_to_host(k, len(srcs[i])) for k, i in enumerate(Bq)] == [srcs[i] for i in Bq]
-        dec.prefetch_fd(fd, [offs[0], len(blob) - 10], [len(packets[0]), len(packets[1])])       # a read-ahead that fails is a batch that is read again
-        dec.decode_keep_fd(fd, [offs[1]], [len(packets[1])])
-        assert dec.kept_to_host(0, len(srcs[1])) == srcs[1]
         with pytest.raises(api.RcgpuError, match="file ends"):
             dec.decode_keep_fd(fd, [offs[0], len(blob) - 10], [len(packets[0]), len(packets[1])])
         os.close(fd)
