@@ -321,6 +321,17 @@ def reference_check_baseline(api, synth, record, frames, d_packets, stride, size
         shutil.rmtree(work, ignore_errors=True)
 
 
+def request_roofline(records_per_second):
+    """The roofline that binds both halves: one random 32-byte state record gathered and written back per sample, against what tools/gather_peak
+    measured the chip to sustain in exactly that pattern (profiles/traffic.json: request_ceiling)."""
+    try:
+        rc_ = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["request_ceiling"]
+        g = records_per_second / 1e9
+        return {"request_frac": round(g / rc_["G_records_per_s"], 4), "requests": {"records_G_per_s": round(g, 2), "ceiling_G_per_s": rc_["G_records_per_s"], "ceiling_what": rc_["what"]}}
+    except Exception:
+        return {}
+
+
 def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device, steps, warmup, cpu=True,
               check_batch=None):
     """Config 5: decode the packets back and verify them -- everything resident in HBM (single GPU).  The caller has released the
@@ -407,7 +418,7 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
                    "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "md5_inside_timed_region": state["hashed"],
                    "compared_inside_timed_region": state["compared"], "verify_seconds_last_batch": round(t_verify, 3)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": traffic, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}},
+                     "traffic": traffic, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}, **request_roofline(width * height * 3 * D / (kt[dom] * 1e-3) if dom in kt and kt[dom] else 0)},
         **({"cpu_baseline": cpu_rec} if cpu_rec else {}), **({"linked_check": linked_rec} if linked_rec else {})}
     dec.close()
     del outs

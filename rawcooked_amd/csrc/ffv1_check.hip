@@ -113,32 +113,43 @@ struct rd_lane {
     // lowest set bit of the window -- when somebody asks (once per sample).  A window of all zeros means the sentinel itself was consumed as
     // data: the sample read more bytes than the window held (rd_underflow), and is decoded again by the careful decoder below.
     uint32_t win_hi, win_lo, have, cap;           // cap: the window is filled up to this many bytes (7)
-    unsigned long long pend; uint32_t npend;      // a further load, issued one sample earlier
-    unsigned long long pend2; uint32_t have2;     // the second half of a 16-byte load, waiting to become `pend`
+    unsigned long long pend; uint32_t npend;      // the next bytes behind the window, big end first
+    // what the last load brought, AS LOADED (nraw halves of 8 bytes, little-endian dwords): nobody touches it in the sample that issued the
+    // load -- a use right behind the load (the byte swap, say) would put the whole memory latency into that sample
+    uint32_t raw[4]; uint32_t nraw;
     const uint8_t* next; const uint8_t* end;      // first byte not yet loaded, end of the coded data
 };
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) uint8_t* gbytes_t;      // global memory, said so: a generic pointer makes these loads flat_load, which count as LDS traffic too
 
 // The slice's bytes come 16 at a time (one request per lane and 16 bytes: every lane reads a line of its own, and a line that is asked
 // for eight bytes at a time is fetched eight times once thousands of wavefronts share the caches); the last bytes one by one.
 __device__ __forceinline__ void rd_load(rd_lane& r)
 {
     const uint32_t avail = r.next < r.end ? uint32_t(r.end - r.next) : 0u;
+    gbytes_t g = (gbytes_t)r.next;
     if (avail >= 16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(r.next);                              // unaligned loads are fine in global memory
-        r.pend = (unsigned long long)__builtin_bswap32(v.x) << 32 | __builtin_bswap32(v.y);
-        r.pend2 = (unsigned long long)__builtin_bswap32(v.z) << 32 | __builtin_bswap32(v.w);
-        r.have2 = 1; r.next += 16;
+        const u32x4_t v = *reinterpret_cast<const __attribute__((address_space(1), aligned(1))) u32x4_t*>(g);     // unaligned loads are fine in global memory
+        r.raw[0] = v.x; r.raw[1] = v.y; r.raw[2] = v.z; r.raw[3] = v.w;
+        r.nraw = 2; r.next += 16;
     } else if (avail >= 8) {
-        const uint32_t lo = *reinterpret_cast<const uint32_t*>(r.next), hi = *reinterpret_cast<const uint32_t*>(r.next + 4);
-        r.pend = (unsigned long long)__builtin_bswap32(lo) << 32 | __builtin_bswap32(hi);
-        r.next += 8;
+        r.raw[0] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(g);
+        r.raw[1] = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t*>(g + 4);
+        r.nraw = 1; r.next += 8;
     } else {
-        unsigned long long v = 0;
-        for (uint32_t i = 0; i < avail; i++) v |= (unsigned long long)r.next[i] << (56 - 8 * i);     // last bytes of the slice: never read past them
-        r.pend = v;                                                                                   // ... and zeros after them (FFV1_RangeCoder.cpp:79-85)
-        r.next += avail;
+        uint32_t lo = 0, hi = 0;
+        for (uint32_t i = 0; i < avail; i++) { const uint32_t b = g[i]; if (i < 4) lo |= b << (8 * i); else hi |= b << (8 * (i - 4)); }   // last bytes of the slice: never read past them
+        r.raw[0] = lo; r.raw[1] = hi;                                                                 // ... and zeros after them (FFV1_RangeCoder.cpp:79-85)
+        r.nraw = 1; r.next += avail;
     }
-    r.npend = 8;
+}
+// the next 8 loaded bytes become `pend` (this is where loaded data is first looked at: a sample or more after its load was issued)
+__device__ __forceinline__ void rd_promote(rd_lane& r)
+{
+    r.pend = (unsigned long long)__builtin_bswap32(r.raw[0]) << 32 | __builtin_bswap32(r.raw[1]);
+    r.raw[0] = r.raw[2]; r.raw[1] = r.raw[3];
+    r.nraw--; r.npend = 8;
 }
 __device__ __forceinline__ bool rd_underflow(const rd_lane& r) { return (r.win_hi | r.win_lo) == 0; }
 // valid bytes left in the window: the sentinel's 0x80 is the lowest set bit, at bit 63 - 8 * valid
@@ -151,6 +162,7 @@ __device__ __forceinline__ uint32_t rd_valid(const rd_lane& r)
 // valid ones, set the sentinel anew, then put the next load in flight.
 __device__ __forceinline__ void rd_refill(rd_lane& r)
 {
+    if (!r.npend && r.nraw) rd_promote(r);
     const uint32_t v = rd_valid(r);
     r.pos += r.have - v;
     const uint32_t take = min(r.npend, r.cap > v ? r.cap - v : 0u);
@@ -164,10 +176,7 @@ __device__ __forceinline__ void rd_refill(rd_lane& r)
     r.have = nv;
     r.pend = take < 8 ? r.pend << (8 * take) : 0ull;
     r.npend -= take;
-    if (!r.npend) {
-        if (r.have2) { r.pend = r.pend2; r.npend = 8; r.have2 = 0; }
-        else rd_load(r);
-    }
+    if (!r.npend && !r.nraw) rd_load(r);                                          // (issued here, looked at a sample later)
 }
 // exact count of consumed bytes right now (end of slice)
 __device__ __forceinline__ uint32_t rd_pos(const rd_lane& r) { return r.pos + r.have - rd_valid(r); }
@@ -183,7 +192,7 @@ __device__ __forceinline__ uint32_t rd_bit(rd_lane& r, uint8_t* base, int k, con
     const bool need = r.mask < 0x100;
     const bool empty = r.win_hi == 0x80000000u && r.win_lo == 0;       // nothing but the sentinel
     if (__builtin_expect(__ballot(need && empty) != 0, 0)) {
-        if (need && empty) { rd_refill(r); if (r.win_hi == 0x80000000u && r.win_lo == 0) rd_refill(r); }      // (the first call may only have fetched)
+        if (need && empty) { rd_refill(r); if (r.win_hi == 0x80000000u && r.win_lo == 0) rd_refill(r); }      // (the first call may only have fetched; cap >= 1 byte then arrives)
     }
     const uint32_t b = r.win_hi >> 24;
     r.current = need ? (r.current << 8) | b : r.current;
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     const uint8_t* buf = packets[f] + slice_start[chain];
     rd_lane r;
     r.cap = C->win_cap;
-    r.n = len - tail; r.pos = 0; r.win_hi = 0x80000000u; r.win_lo = 0; r.have = 0; r.pend = r.pend2 = 0; r.npend = r.have2 = 0; r.next = buf; r.end = buf + r.n;
+    r.n = len - tail; r.pos = 0; r.win_hi = 0x80000000u; r.win_lo = 0; r.have = 0; r.pend = 0; r.npend = r.nraw = 0; r.raw[0] = r.raw[1] = r.raw[2] = r.raw[3] = 0; r.next = buf; r.end = buf + r.n;
     rd_refill(r); rd_refill(r);                                      // the first call fetches, the second fills the window
     r.current = r.win_hi >> 24; r.win_hi = __builtin_amdgcn_alignbit(r.win_hi, r.win_lo, 24); r.win_lo <<= 8;   // AssignBuffer, FFV1_RangeCoder.cpp:22-33 (the byte is counted at the next refill)
     r.mask = 0xFF;
@@ -458,19 +467,24 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
             int32_t T = y ? prev[0] : 0;
             // the two neighbours that come from memory are fetched one sample ahead
             int32_t RTn = y ? (1 < w ? prev[xs] : T) : 0, TTn = y >= 2 ? pp[0] : 0;
+            asm volatile("" :: "v"(L), "v"(LT), "v"(T), "v"(RTn), "v"(TTn));      // (arrived before the loop is entered: see the end of its body)
             for (uint32_t x = 0; x < w; x++) {
-                rd_refill(r);
+                // The context's state record is what a sample waits for longest (a random 32-byte gather that depends on the sample decoded
+                // just before): its address comes first, and everything that does not need it -- the window's top-up, the next sample's
+                // neighbours, the prediction -- is done while it is on its way.
                 const int32_t RT = RTn, TT = TTn;
-                RTn = y ? (x + 2 < w ? prev[size_t(x + 2) * xs] : RT) : 0;
-                TTn = y >= 2 && x + 1 < w ? pp[size_t(x + 1) * xs] : 0;
                 int32_t ctx = q[0][(L - LT) & 0xFF] + q[1][(LT - T) & 0xFF] + q[2][(T - RT) & 0xFF];
                 if (is5) ctx += q[3][(LL - L) & 0xFF] + q[4][(TT - T) & 0xFF];
-                int32_t v = ov16 ? med3(int16_t(L), int16_t(L) + int16_t(T) - int16_t(LT), int16_t(T)) : med3(L, L + T - LT, T);
                 const uint32_t key = set * nctx + uint32_t(ctx < 0 ? -ctx : ctx);
                 uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
+                const uint4 a0 = gp[0], a1 = gp[1];
+                asm volatile("" ::: "memory");                        // the gather is issued before the loads below, not behind them
+                RTn = y ? (x + 2 < w ? prev[size_t(x + 2) * xs] : RT) : 0;
+                TTn = y >= 2 && x + 1 < w ? pp[size_t(x + 1) * xs] : 0;
+                rd_refill(r);
+                int32_t v = ov16 ? med3(int16_t(L), int16_t(L) + int16_t(T) - int16_t(LT), int16_t(T)) : med3(L, L + T - LT, T);
                 uint32_t sw[8];
-                { const uint4 a0 = gp[0], a1 = gp[1];
-                  sw[0] = a0.x; sw[1] = a0.y; sw[2] = a0.z; sw[3] = a0.w; sw[4] = a1.x; sw[5] = a1.y; sw[6] = a1.z; sw[7] = a1.w; }
+                sw[0] = a0.x; sw[1] = a0.y; sw[2] = a0.z; sw[3] = a0.w; sw[4] = a1.x; sw[5] = a1.y; sw[6] = a1.z; sw[7] = a1.w;
                 const uint32_t c_cur = r.current, c_mask = r.mask, c_hi = r.win_hi, c_lo = r.win_lo;      // what the fast decoder changes
                 int32_t delta = rd_s_regs(r, sw, t16);
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(rd_underflow(r)) != 0, 0)) {
@@ -483,6 +497,10 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                     delta = rd_s_careful(r, my, trans);
                     for (int k = 0; k < 8; k++) sw[k] = myw[k * 64];
                 }
+                // Everything this sample LOADED for the next one (its neighbours, the window's next bytes) is asked for here, before the stores
+                // below are issued: the loop's next turn then finds nothing it has to wait for, where a wait at its top would also wait for
+                // the stores -- a write's acknowledgement under this kernel's load is thousands of cycles (the counter is one for both)
+                asm volatile("" :: "v"(RTn), "v"(TTn), "v"(r.raw[0]), "v"(r.raw[1]), "v"(r.raw[2]), "v"(r.raw[3]));
                 gp[0] = make_uint4(sw[0], sw[1], sw[2], sw[3]); gp[1] = make_uint4(sw[4], sw[5], sw[6], sw[7]);
                 v = (ctx >= 0 ? v + delta : v - delta) & bitmask;
                 cur[size_t(x) * xs] = v;
