@@ -214,9 +214,10 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
         out = {"frames": n, "unit": "frames/s", "analysis_seconds": round(analysis_s, 2)}
         OKL = "Reversibility was checked, no issue detected."
         # `--check x.mkv` judges by the MD5s in the reversibility data; with `-o .` the rebuilt files are also compared with the sources on disk
-        batch = os.environ.get("RCGPU_LINKED_BATCH", "256")        # frames per device call (the patch's own default)
-        todo = (("device_decoder", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": batch}, big, n, []),
-                ("device_decoder_and_sources", {"RCGPU_CHECK": "1", "RCGPU_CHECK_BATCH": batch}, big, n, ["-o", "."]),
+        # frames per device call: the patch's own choice (by slice chains: 768 frames for streams of up to 128 slices, else 256) unless RCGPU_LINKED_BATCH says otherwise
+        benv = {"RCGPU_CHECK_BATCH": os.environ["RCGPU_LINKED_BATCH"]} if os.environ.get("RCGPU_LINKED_BATCH") else {}
+        todo = (("device_decoder", dict({"RCGPU_CHECK": "1"}, **benv), big, n, []),
+                ("device_decoder_and_sources", dict({"RCGPU_CHECK": "1"}, **benv), big, n, ["-o", "."]),
                 ("device_decoder_payloads_to_host", {"RCGPU_CHECK": "1", "RCGPU_CHECK_DEFER": "0", "RCGPU_CHECK_BATCH": "128"}, small, m, []),
                 ("reference_cpu_pool", {"RCGPU_CHECK": "0"}, small, m, []),
                 ("reference_cpu_pool_and_sources", {"RCGPU_CHECK": "0"}, small, m, ["-o", "."]))
@@ -234,7 +235,7 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
         if not variants or "whole_product" in variants:
             # and the product as a user runs it: one process analyses the sources (route D), encodes them (route B), and checks the MKV it wrote (route C)
             os.rename(os.path.join(big, "seq.mkv"), os.path.join(big, "muxed_by_the_bench.mkv"))
-            r = run([exe, "--no-check-padding", "--check", "--hash", "-y", "seq"], big, env=dict(os.environ, RCGPU_CHECK="1", RCGPU_CHECK_BATCH=batch), timeout=300)
+            r = run([exe, "--no-check-padding", "--check", "--hash", "-y", "seq"], big, env=dict(os.environ, RCGPU_CHECK="1", **benv), timeout=300)
             ok = r.returncode == 0 and OKL in r.stdout
             same = ok and os.path.getsize(os.path.join(big, "seq.mkv")) > 0
             if os.environ.get("RCGPU_TRACE_KEPT"):
