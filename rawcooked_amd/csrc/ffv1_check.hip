@@ -9,7 +9,10 @@
 // Decoding is serial per slice in both recurrences AND in the context model (the context of a sample depends on the
 // sample decoded just before it), so there is nothing for a wavefront to share: the mapping is one LANE per slice,
 // 64 slices per wavefront, thousands of slices in flight.  Context states live in HBM (32 bytes per context, one
-// gather + one write-back per sample through a per-lane LDS slot); previous lines are read back from the output planes.
+// gather + one write-back per sample into eight registers); the previous lines of a slice are kept in three-line rings
+// interleaved per wavefront; the slice's bytes come through a register window that is taken from without a look.
+// What bounds it: the memory system's rate of random 32-byte gathers + write-backs (tools/gather_peak: 19.7 G records/s;
+// 1600 4K frames in flight run at 0.8 of it) -- the same ceiling the encoder's k_resolve sits at.
 //   k_dec_split   thread / frame    walk the 24-bit slice sizes from the packet tail
 //   k_dec_crc     block  / slice    CRC-32 over the whole slice must be 0 (ec = 1)
 //   k_dec_slices  LANE   / slice    range decoder + median predictor + contexts; whole-byte layouts: inverse RCT + pack of every
@@ -1035,8 +1038,12 @@ static int decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, int
     for (uint32_t i = 0; i < n; i++) in_total += (packet_sizes[i] + 255) & ~uint64_t(255);
     kept_clock clk;
     uint8_t*& d_in = d->d_kept_in;
-    HIP_TRY(grow(d_in, d->kept_in_cap, size_t(in_total) + 256));
-    HIP_TRY(grow(K.d, K.cap, d->kept_stride * n));
+    // Sized for the decoder's largest batch at the first call: a buffer that grows later is freed and allocated anew, and an allocation that
+    // follows a free of tens of GB waits for the driver to wipe them (measured: 2-3 s for the 39 GB of a 744-frame batch after a 256-frame
+    // one, 1.4 ms for the same bytes on memory that was never used)
+    const uint32_t most = std::max(n, d->cfg.max_batch);
+    HIP_TRY(grow(d_in, d->kept_in_cap, size_t(in_total / n + 1) * most * 17 / 16 + 256));
+    HIP_TRY(grow(K.d, K.cap, d->kept_stride * most));
     clk.lap("decode_keep: device buffers", n);
     std::vector<up_item> up(n);
     std::vector<const void*> pk(n); std::vector<void*> out(n);
@@ -1160,7 +1167,7 @@ extern "C" int rcgpu_ffv1_decoder_verify_kept_begin(rcgpu_ffv1_decoder* d, const
     // A file named by its path is read with pread(): its few bytes around the payload here, the rest straight into the staging buffers.
     std::vector<up_item> up;
     std::vector<int> fds;                                   // open while their bytes go up; closed group by group (hundreds of files)
-    if (n_cmp && he == hipSuccess) he = grow(d->d_disk, d->disk_cap, disk_stride * n_cmp);
+    if (n_cmp && he == hipSuccess) he = grow(d->d_disk, d->disk_cap, disk_stride * std::max(n_cmp, d->cfg.max_batch));
     for (uint32_t i = 0; i < n && he == hipSuccess; i++) {
         const rcgpu_kept_file& f = files[i];
         if (!f.on_disk && !f.on_disk_path) continue;
