@@ -331,9 +331,6 @@ int  rcgpu_ffv1_decoder_verify_kept_end(rcgpu_ffv1_decoder* dec, rcgpu_kept_verd
  * and flags describe the files and are the caller's (they come from the reversibility data / the probes).  Fails when the record
  * does not describe `pixfmt` (colorspace, bit depth, alpha) or uses a feature this decoder lacks. */
 int  rcgpu_ffv1_config_from_record(const uint8_t* record, size_t size, rcgpu_ffv1_config* cfg);
-/* Only the slice grid of a configuration record (all a binding knows of a track before its first frame): the decoder's rate is slice chains in
- * flight, so a --check binding sizes its batches by it (oracle/route_c_ffv1_frame_cpp.patch, ffv1_frame::OutOfBand). */
-int  rcgpu_ffv1_record_slices(const uint8_t* record, size_t size, uint32_t* num_h_slices, uint32_t* num_v_slices);
 /* The same plus the one stream fact the record does not hold: which of its table sets the planes use (quant_table_set_index in every
  * slice header, FFV1_Slice.cpp:159-168), read from the first slice header of `packet` (the first frame of the track). */
 int  rcgpu_ffv1_config_from_stream(const uint8_t* record, size_t size, const uint8_t* packet, size_t packet_size, rcgpu_ffv1_config* cfg);

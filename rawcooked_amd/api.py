@@ -106,7 +106,6 @@ SYMBOLS = {
     "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rcgpu_ffv1_last_error_flags": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
-    "rcgpu_ffv1_record_slices": (C.c_int, [_VP, _SZ, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rcgpu_sequence_plan": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rcgpu_ffv1_encode_sequence": (C.c_int, [C.POINTER(Ffv1Config), C.c_uint64, C.POINTER(SequenceIo), C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
     "rcgpu_ffv1_encode_sequence_memory": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP), C.c_uint64, C.c_uint64, C.POINTER(_VP), C.c_uint64, _SZ, C.POINTER(C.c_uint64),

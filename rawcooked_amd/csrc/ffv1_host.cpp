@@ -234,31 +234,6 @@ struct host_rd {
 };
 }  // namespace
 
-// num_h_slices / num_v_slices of a configuration record, before anything else about the stream is known (FFV1_Parameters.cpp:23-104 reads
-// them the same way): what a --check binding sizes its batches by -- the decoder's rate is slice chains in flight.
-extern "C" int rcgpu_ffv1_record_slices(const uint8_t* rec, size_t size, uint32_t* num_h, uint32_t* num_v)
-{
-    using namespace rc; using namespace rc::ffv1;
-    clear_error();
-    if (!rec || !num_h || !num_v) return fail(1, "ffv1 record: null argument");
-    if (size < 5 || rcgpu_crc32_ffv1(rec, size)) return fail(3, "ffv1 record: CRC mismatch (FFV1_Frame.cpp:116)");
-    host_rd r(rec, size - 4);
-    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
-    if (r.u(st) != 3) return fail(4, "ffv1 record: only version 3 is supported");
-    (void)r.u(st);                                                     // micro_version
-    const uint32_t coder = r.u(st);
-    if (coder > 2) return fail(4, "ffv1 record: coder_type %u", coder);
-    if (coder == 2) for (int i = 1; i < 256; i++) (void)r.s(st);      // state_transition_delta
-    (void)r.u(st); (void)r.u(st);                                      // colorspace_type, bits_per_raw_sample
-    (void)r.bit(st[0]);                                                // chroma_planes
-    (void)r.u(st); (void)r.u(st);                                      // log2 subsampling
-    (void)r.bit(st[0]);                                                // alpha
-    const uint32_t nh1 = r.u(st), nv1 = r.u(st);
-    if (nh1 > 0xFFFF || nv1 > 0xFFFF) return fail(5, "ffv1 record: %u x %u slices", nh1 + 1, nv1 + 1);
-    *num_h = nh1 + 1; *num_v = nv1 + 1;
-    return 0;
-}
-
 extern "C" int rcgpu_ffv1_config_from_record(const uint8_t* rec, size_t size, rcgpu_ffv1_config* cfg)
 {
     using namespace rc; using namespace rc::ffv1;
