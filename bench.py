@@ -445,6 +445,11 @@ def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barr
     nout = 64
     out_cap = int(payload * 1.3) + (1 << 20)
     outs = [np.empty(out_cap, dtype=np.uint8) for _ in range(nout)]       # where packets end: pageable host memory, reused
+    # batches of equal size (what the job level does by itself, pipeline.hip: 3840 frames are 12 x 320, not 11 x 336 + 144 -- a short last
+    # batch costs a whole range-coder chain for a third of the frames)
+    per_lane = -(-n_frames // max(1, device_count))
+    nb = -(-per_lane // max(1, batch))
+    batch = -(-per_lane // nb)
     barrier()
     t0 = time.perf_counter()
     st, sizes = api.encode_sequence_memory(cfg, [a.ctypes.data for a in host_ring], n_frames, [a.ctypes.data for a in outs], out_cap, batch=batch // lanes,
