@@ -328,12 +328,15 @@ def reference_check_baseline(api, synth, record, frames, d_packets, stride, size
 
 
 def request_roofline(records_per_second):
-    """The roofline that binds both halves: one random 32-byte state record gathered and written back per sample, against what tools/gather_peak
-    measured the chip to sustain in exactly that pattern (profiles/traffic.json: request_ceiling)."""
+    """The roofline that binds the check half: one random 32-byte state record gathered and written back per sample, against what
+    tools/gather_region measured the chip to sustain in the decoder's pattern -- every lane in a state array of its own
+    (profiles/traffic.json: request_ceiling)."""
     try:
         rc_ = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["request_ceiling"]
         g = records_per_second / 1e9
-        return {"request_frac": round(g / rc_["G_records_per_s"], 4), "requests": {"records_G_per_s": round(g, 2), "ceiling_G_per_s": rc_["G_records_per_s"], "ceiling_what": rc_["what"]}}
+        return {"request_frac": round(g / rc_["decoder_G_records_per_s"], 4),
+                "requests": {"records_G_per_s": round(g, 2), "ceiling_G_per_s": rc_["decoder_G_records_per_s"], "uniform_address_ceiling_G_per_s": rc_["uniform_G_records_per_s"],
+                             "ceiling_what": rc_["what"]}}
     except Exception:
         return {}
 
@@ -682,7 +685,7 @@ def check576_leg(args, torch, api, synth, dev, device, width, height):
     if "cpu" in {x for x in args.legs.split(",") if x}:
         linked = linked_check_record(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=1000, variants={"device_decoder"})
     rec, ok = check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, device,
-                        steps=2, warmup=1, cpu=False, check_batch=336)
+                        steps=2, warmup=1, cpu=False, check_batch=512)
     del frames, d_packets
     torch.cuda.empty_cache()
     out = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline") if k in rec}
@@ -914,14 +917,15 @@ def main():
                              "frac_of_full_rate_peak": round(rate / (1024 * v["full_rate_per_simd"]), 4), "note": v.get("note")}
             except Exception:
                 issue = None
-            # the roofline that binds: random 32-byte records gathered and written back (one per sample), against what tools/gather_peak
+            # the roofline that binds: random 32-byte records gathered and written back (one per sample), against what tools/gather_region
             # measured the chip to sustain in exactly that pattern; and the kernel's floor with that traffic served by the L2
             req = None
             try:
                 rc_, fl_ = tjd.get("request_ceiling", {}), tjd.get("resolve_floor", {})
                 samples = width * height * 3
                 rate = samples * fps / world / 1e9
-                req = {"records_G_per_s": round(rate, 2), "ceiling_G_per_s": rc_["G_records_per_s"], "request_frac": round(rate / rc_["G_records_per_s"], 4),
+                req = {"records_G_per_s": round(rate, 2), "ceiling_G_per_s": rc_["G_records_per_s"], "uniform_address_ceiling_G_per_s": rc_.get("uniform_G_records_per_s"),
+                       "request_frac": round(rate / rc_["G_records_per_s"], 4),
                        "floor_ms": round(fl_["ms_per_step_alone"] / fl_["launches_per_step"] * F / fl_["frames_per_step"], 3), "floor_what": fl_.get("what"), "ceiling_what": rc_.get("what")}
             except Exception:
                 req = None

@@ -398,6 +398,12 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     __shared__ int16_t q[5][256];
     __shared__ __attribute__((aligned(16))) uint8_t slot[64 * 32];
     const int lane = threadIdx.x;
+    // Every wavefront of this kernel has the same work and the kernel ends with its slowest one.  A wavefront of another kernel on the same
+    // SIMD -- k_md5 hashing the previous batch is one dependent VALU chain per wavefront, issuing all the time -- takes issue slots from
+    // the one or two decoder wavefronts beside it and from nobody else: those few finish late and everybody waits (measured: 2.22 s alone,
+    // 2.64 s beside k_md5 for 1600 frames of 64 slices; 0.46 and 0.76-0.80 s for 336 frames of 576).  With the higher priority the
+    // decoder's instructions go first and the hash takes the slots the decoder leaves while it waits for memory.
+    __builtin_amdgcn_s_setprio(3);
     for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; t16[i] = uint16_t(C->zero_state[i] | C->one_state[i] << 8); }
     for (int i = lane; i < 5 * 256; i += 64) (&q[0][0])[i] = (&C->q[0][0])[i];
     __syncthreads();
