@@ -372,6 +372,11 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     F0 = min(F, 32)                                                                        # distinct sources hashed on the host
     want = {i: hashlib.md5(bytes(frames[i].cpu().numpy())).digest() for i in range(F0)}
     side = torch.cuda.Stream()
+    # The decoding gets a stream of its own too, not torch's current one: that is the legacy default stream, with which every blocking
+    # stream synchronises -- and the library's CU-masked streams (the hash on CUs of its own, ffv1_check.hip partition_streams) can only be
+    # made blocking: a hash launched while the default stream waits for the decoder would itself wait for the decoder.
+    main = torch.cuda.Stream()
+    stream = main.cuda_stream
     state = {"k": 0, "bad": 0, "hashed": 0, "compared": 0, "differing": 0, "ev": None}
 
     def verify(prev, st):
@@ -384,7 +389,7 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     def step():
         k = state["k"]; cur = k & 1 if pipelined else 0
         dec.decode_device(pk, sizes, ops[cur], stream, check=False)
-        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+        ev = torch.cuda.Event(); ev.record(main)
         if pipelined and state["ev"] is not None:         # batch k-1 is verified on the side stream while batch k is decoded
             side.wait_event(state["ev"])
             verify(ops[cur ^ 1], side.cuda_stream)

@@ -29,6 +29,7 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#include <mutex>
 #include <cerrno>
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -713,6 +714,40 @@ __global__ __launch_bounds__(64) void k_md5(const uint8_t* const* __restrict__ b
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
+// CUs of its own for the hash.  k_md5 is one dependent VALU chain per wavefront, ready to issue all the time for the second a batch of 4K
+// files takes; k_dec_slices ends with its slowest wavefront, and the ones that share a SIMD with a hash wavefront are the slowest (2.64 s
+// instead of 2.19 for 1600 frames; 2.41-2.45 with the decoder at the higher wave priority: DESIGN.md section 5).  So the two get
+// disjoint CUs through CU-masked streams: one CU of every XCD for the hash (32 SIMDs: 2048 files a wavefront apiece), the other 248 for
+// the decoder.  What the mask means was measured (tools/cu_mask_probe.hip, profiles/r04_cu_mask_probe.txt): bit i stands for a CU of XCD
+// i % 8, and a mask that leaves an XCD without a CU is ignored as a whole.  Devices that are not 8 x 32 CUs get plain streams.
+constexpr uint32_t kHashCuBits = 0xFFu;                    // bits 0..7: one CU of each XCD
+static bool partition_streams(int device, hipStream_t* decode, hipStream_t* hash)
+{
+    // RCGPU_NO_CU_PARTITION: plain streams (rocprofv3 --kernel-trace of ROCm 7.2 dies of a segmentation fault in a process that has
+    // made a CU-masked stream; tools/profile_check.sh sets it).  Same bytes either way.
+    if (const char* e = getenv("RCGPU_NO_CU_PARTITION")) if (*e && *e != '0') return false;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount != 256) return false;
+    uint32_t mh[8] = { kHashCuBits, 0, 0, 0, 0, 0, 0, 0 };
+    uint32_t md[8] = { ~kHashCuBits, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u };
+    hipStream_t a = nullptr, b = nullptr;
+    if (decode && hipExtStreamCreateWithCUMask(&a, 8, md) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hash && hipExtStreamCreateWithCUMask(&b, 8, mh) != hipSuccess) { (void)hipGetLastError(); if (a) (void)hipStreamDestroy(a); return false; }
+    if (decode) *decode = a;
+    if (hash) *hash = b;
+    return true;
+}
+// the hash stream of the free-standing rcgpu_md5_device, one per device, made on first use and kept
+static hipStream_t device_hash_stream(int device)
+{
+    static std::mutex mu; static hipStream_t st[16]; static bool tried[16];
+    std::lock_guard<std::mutex> g(mu);
+    const int k = device & 15;
+    if (!tried[k]) { tried[k] = true; st[k] = nullptr; if (!partition_streams(device, nullptr, &st[k])) st[k] = nullptr; }
+    return st[k];
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Host memory that is not pinned -- the mapped MKV, mapped source files -- goes up through pinned staging buffers, several threads side
 // by side (upload_side_by_side below): the streams, buffers and events of those threads, made on first use
 struct stager {
@@ -739,6 +774,7 @@ struct rcgpu_ffv1_decoder {
     uint8_t* d_states = nullptr; int32_t* d_planes = nullptr; uint32_t* d_err = nullptr;
     void** h_ptrs = nullptr; unsigned long long* h_sizes = nullptr;
     hipStream_t own_stream = nullptr;
+    hipStream_t dec_stream = nullptr;              // k_dec_slices' stream when the hash has CUs of its own (partition_streams), else null
     hipEvent_t ev[8]{};
     bool ev_valid = false;
     // the payloads of the last decode_keep: slot i = d_kept + i * kept_stride, [room | payload | room] so that the bytes a file has
@@ -772,6 +808,7 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     if (d->h_sizes) (void)hipHostFree(d->h_sizes);
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
+    if (d->dec_stream) { (void)hipStreamSynchronize(d->dec_stream); (void)hipStreamDestroy(d->dec_stream); }
     if (d->md5_stream) (void)hipStreamSynchronize(d->md5_stream);     // a verification begun and never ended
     for (void* b : { (void*)d->d_kept_in, (void*)d->kept[0].d, (void*)d->kept[1].d, (void*)d->d_disk, (void*)d->kept[0].d_tab, (void*)d->kept[1].d_tab }) if (b) (void)hipFree(b);
     for (auto& k : d->kept) if (k.h_tab) (void)hipHostFree(k.h_tab);
@@ -846,6 +883,7 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_ptrs), sizeof(void*) * F * 2);
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_sizes), 8 * F);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking);
+    if (he == hipSuccess && !partition_streams(cfg->device, &d->dec_stream, &d->md5_stream)) d->dec_stream = d->md5_stream = nullptr;
     for (auto& e : d->ev) if (he == hipSuccess) he = hipEventCreate(&e);
     if (he == hipSuccess) he = hipMemcpy(d->d_const, &c, sizeof c, hipMemcpyHostToDevice);
     if (he == hipSuccess && !hdr.empty()) he = hipMemcpy(d->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
@@ -876,13 +914,18 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     hipLaunchKernelGGL(k_dec_split, dim3((n + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_sizes, n, d->d_slice_start, d->d_slice_len, d->d_err);
     if (c.ec) hipLaunchKernelGGL(k_dec_crc, dim3(nchains), dim3(256), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, d->d_err);
     HIP_TRY(hipEventRecord(d->ev[1], st));
+    // the slices are decoded on the CUs the hash does not use (partition_streams): the kernel goes to a stream of the decoder's own, between
+    // two events that keep it where it was in the caller's stream
+    hipStream_t ks = d->dec_stream ? d->dec_stream : st;
+    if (ks != st) HIP_TRY(hipStreamWaitEvent(ks, d->ev[1], 0));
     if (d->ring)
-        hipLaunchKernelGGL(k_dec_slices<true>, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
+        hipLaunchKernelGGL(k_dec_slices<true>, dim3((nchains + 63) / 64), dim3(64), 0, ks, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
                            d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, d->ring_w, d->d_err, d->d_hdr);
     else
-        hipLaunchKernelGGL(k_dec_slices<false>, dim3((nchains + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
+        hipLaunchKernelGGL(k_dec_slices<false>, dim3((nchains + 63) / 64), dim3(64), 0, ks, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
                            d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, 0u, d->d_err, d->d_hdr);
-    HIP_TRY(hipEventRecord(d->ev[2], st));
+    HIP_TRY(hipEventRecord(d->ev[2], ks));
+    if (ks != st) HIP_TRY(hipStreamWaitEvent(st, d->ev[2], 0));
     if (d->ring) { /* packed inline */ }
     else {
         const uint32_t nwords = c.altern ? (c.W * c.H + 2) / 3 : c.H * (c.line_bytes / 4);
@@ -1468,10 +1511,20 @@ extern "C" int rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes
     if (he == hipSuccess) he = hipMallocAsync(reinterpret_cast<void**>(&d_o), 16 * size_t(n), st);
     if (he == hipSuccess) he = hipMemcpyAsync(d_p, d_bufs, sizeof(void*) * n, hipMemcpyHostToDevice, st);
     if (he == hipSuccess) he = hipMemcpyAsync(d_s, sizes, 8 * size_t(n), hipMemcpyHostToDevice, st);
-    if (he == hipSuccess) { hipLaunchKernelGGL(k_md5, dim3((n + 63) / 64), dim3(64), 0, st, d_p, d_s, n, d_o); he = hipGetLastError(); }
+    // the kernel itself runs on the hash's own CUs when the device has them to give (partition_streams; up to 64 wavefronts: beyond that
+    // the 32 SIMDs of the partition would be the slower place), in the caller's order
+    int dev = 0; hipStream_t hs_ = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (he == hipSuccess && n <= 4096 && hipGetDevice(&dev) == hipSuccess) hs_ = device_hash_stream(dev);
+    if (hs_ && (hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess)) hs_ = nullptr;
+    if (he == hipSuccess && hs_) { he = hipEventRecord(e0, st); if (he == hipSuccess) he = hipStreamWaitEvent(hs_, e0, 0); }
+    if (he == hipSuccess) { hipLaunchKernelGGL(k_md5, dim3((n + 63) / 64), dim3(64), 0, hs_ ? hs_ : st, d_p, d_s, n, d_o); he = hipGetLastError(); }
+    if (he == hipSuccess && hs_) { he = hipEventRecord(e1, hs_); if (he == hipSuccess) he = hipStreamWaitEvent(st, e1, 0); }
     if (he == hipSuccess) he = hipMemcpyAsync(out_md5, d_o, 16 * size_t(n), hipMemcpyDeviceToHost, st);
     for (void* p : { (void*)d_p, (void*)d_s, (void*)d_o }) if (p) (void)hipFreeAsync(p, st);
     const hipError_t hs = hipStreamSynchronize(st);
+    if (hs_ && hs != hipSuccess) (void)hipStreamSynchronize(hs_);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
     if (he == hipSuccess) he = hs;
     if (he != hipSuccess) return fail(100, "md5: %s", hipGetErrorString(he));
     return 0;

@@ -45,7 +45,7 @@ def test_shipped_library_has_no_switch_that_changes_bytes(built):
     reference's only such switches are its command line's (CLI/Global.cpp:938-989)."""
     csrc = os.path.join(ROOT, "rawcooked_amd", "csrc")
     allowed = {"RCGPU_BATCH", "RCGPU_DEVICES", "RCGPU_LANES", "RCGPU_MKV_MMAP", "RCGPU_MKV_NO_MMAP", "RCGPU_READERS", "RCGPU_WRITERS",
-               "RCGPU_RELEASE_AT_EXIT", "RCGPU_TRACE", "RCGPU_TRACE_KEPT", "RCGPU_UPLOAD_THREADS"}      # sizing and tracing: same bytes
+               "RCGPU_NO_CU_PARTITION", "RCGPU_RELEASE_AT_EXIT", "RCGPU_TRACE", "RCGPU_TRACE_KEPT", "RCGPU_UPLOAD_THREADS"}      # sizing and tracing: same bytes
     for path in (api.LIB_PATH, os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")):
         names = set(re.findall(rb"RCGPU_[A-Z0-9_]+", open(path, "rb").read()))
         names = {n.decode() for n in names if not n.startswith((b"RCGPU_PIX_", b"RCGPU_FLAG_", b"RCGPU_RC_WHOLE", b"RCGPU_KEPT_"))}

@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <algorithm>
+#include <chrono>
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 __global__ void k_where(uint32_t* out)
 {
@@ -11,6 +13,12 @@ __global__ void k_where(uint32_t* out)
         out[blockIdx.x * 2] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);        // HW_REG_XCC_ID, bits 3:0
         out[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);    // HW_REG_HW_ID
     }
+}
+__global__ void k_spin(uint32_t n, uint32_t* out)
+{
+    uint32_t a = threadIdx.x;
+    for (uint32_t i = 0; i < n; i++) a = a * 1664525u + 1013904223u;
+    if (a == 12345u) out[0] = a;
 }
 int main()
 {
@@ -27,6 +35,44 @@ int main()
         for (int i = 0; i < 16; i++) { xcc_set |= 1u << (h[i * 2] & 15); const uint32_t cu = (h[i * 2 + 1] >> 8) & 15, se = (h[i * 2 + 1] >> 13) & 7; cu_lo = cu < cu_lo ? cu : cu_lo; cu_hi = cu > cu_hi ? cu : cu_hi; se_set |= 1u << se; }
         printf("bit %3u: xcc mask %02x  se mask %02x  cu_id %u..%u  hw_id[0] %08x\n", b, xcc_set, se_set, cu_lo, cu_hi, h[1]);
         CHECK(hipStreamDestroy(st));
+    }
+    // patterns: how many distinct CUs (XCC, shader engine, CU id) do 4096 workgroups of a masked stream land on, and on which XCCs?
+    uint32_t* d2 = nullptr; CHECK(hipMalloc(reinterpret_cast<void**>(&d2), 8 * 4096));
+    struct pat { const char* name; uint32_t word_even, word_odd; uint32_t words_set; };
+    const pat pats[] = { { "all bits", 0xFFFFFFFFu, 0xFFFFFFFFu, words }, { "every second bit", 0x55555555u, 0x55555555u, words }, { "low half of every word", 0x0000FFFFu, 0x0000FFFFu, words },
+                         { "first half of the words", 0xFFFFFFFFu, 0xFFFFFFFFu, words / 2 }, { "even words only", 0xFFFFFFFFu, 0u, words }, { "first word only", 0xFFFFFFFFu, 0xFFFFFFFFu, 1 },
+                         { "low byte of every word", 0x000000FFu, 0x000000FFu, words } };
+    for (const pat& q : pats) {
+        std::vector<uint32_t> mask(words, 0);
+        for (uint32_t w = 0; w < q.words_set; w++) mask[w] = (w & 1) ? q.word_odd : q.word_even;
+        hipStream_t st; const hipError_t e = hipExtStreamCreateWithCUMask(&st, words, mask.data());
+        if (e != hipSuccess) { printf("pattern %-26s: %s\n", q.name, hipGetErrorString(e)); continue; }
+        CHECK(hipMemsetAsync(d2, 0xFF, 8 * 4096, st));
+        hipLaunchKernelGGL(k_where, dim3(4096), dim3(64), 0, st, d2);
+        std::vector<uint32_t> h(8192); CHECK(hipMemcpyAsync(h.data(), d2, 8 * 4096, hipMemcpyDeviceToHost, st)); CHECK(hipStreamSynchronize(st));
+        std::vector<uint32_t> ids; uint32_t per_xcc[16] = { 0 };
+        for (int i = 0; i < 4096; i++) ids.push_back((h[i * 2] & 15) << 16 | ((h[i * 2 + 1] >> 13) & 7) << 8 | ((h[i * 2 + 1] >> 8) & 15));
+        std::sort(ids.begin(), ids.end()); ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+        for (uint32_t id : ids) per_xcc[id >> 16]++;
+        printf("pattern %-26s: %3zu distinct CUs; per XCC", q.name, ids.size());
+        for (int x = 0; x < 8; x++) printf(" %u", per_xcc[x]);
+        printf("\n");
+        CHECK(hipStreamDestroy(st));
+    }
+    // do two kernels on two CU-masked streams with disjoint masks run side by side?  A spin of ~200 ms on each, alone and together.
+    {
+        uint32_t ma[8] = { 0xFFu, 0, 0, 0, 0, 0, 0, 0 }, mb[8] = { ~0xFFu, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u };
+        hipStream_t sa, sb, sp; CHECK(hipExtStreamCreateWithCUMask(&sa, 8, ma)); CHECK(hipExtStreamCreateWithCUMask(&sb, 8, mb)); CHECK(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
+        auto timed = [&](hipStream_t s1, uint32_t g1, hipStream_t s2, uint32_t g2) -> double {
+            hipDeviceSynchronize();
+            const auto t0 = std::chrono::steady_clock::now();
+            if (s1) hipLaunchKernelGGL(k_spin, dim3(g1), dim3(64), 0, s1, 40000000u, d2);
+            if (s2) hipLaunchKernelGGL(k_spin, dim3(g2), dim3(64), 0, s2, 40000000u, d2);
+            hipDeviceSynchronize();
+            return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3;
+        };
+        printf("spin: hash-mask stream alone %.0f ms, decode-mask stream alone %.0f ms, both %.0f ms; plain stream + hash-mask stream %.0f ms; plain + decode-mask %.0f ms\n",
+               timed(sa, 16, nullptr, 0), timed(sb, 1024, nullptr, 0), timed(sa, 16, sb, 1024), timed(sp, 1024, sa, 16), timed(sp, 1024, sb, 1024));
     }
     return 0;
 }

@@ -1,6 +1,7 @@
 # rocprofv3 of the check half (config 5): --stats, then the two PMC passes that give k_dec_slices its HBM bytes.  GPU box: bash tools/profile_check.sh <tag>
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
+export RCGPU_NO_CU_PARTITION=1      # rocprofv3 of ROCm 7.2 crashes in a process with CU-masked streams (the hash then shares the CUs again)
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/pc gpurun_out/summary
 timeout ${PASS_TIMEOUT:-420} rocprofv3 --kernel-trace --stats -d gpurun_out/pc -o chk -- python bench.py --mode check --steps 2 --warmup 1 --legs "" > gpurun_out/pc/log 2>&1
 python tools/rocprof_summary.py stats $(find gpurun_out/pc -name "*.db" | head -1) > gpurun_out/summary/${TAG}_check_kernel_stats.csv

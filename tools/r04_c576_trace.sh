@@ -1,6 +1,7 @@
 # kernel trace of the check half at 576 slices: every launch's start and duration.  bash tools/r04_c576_trace.sh <check batch>
 CFG="$1"; B=$2
 cd /tmp && export TMPDIR=/tmp
+export RCGPU_NO_CU_PARTITION=1      # rocprofv3 of ROCm 7.2 crashes in a process with CU-masked streams (the hash then shares the CUs again)
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/pc gpurun_out/r04
 timeout 420 rocprofv3 --kernel-trace -d gpurun_out/pc -o chk -- python bench.py --mode check --steps ${STEPS:-2} --warmup 1 --legs "" $CFG > gpurun_out/pc/log 2>&1
 python - "$(find gpurun_out/pc -name '*.db' | head -1)" <<'PY' | tee gpurun_out/r04/c576_trace_$B.txt
