@@ -1,5 +1,10 @@
-// cu_mask_probe.hip -- which CU does bit b of hipExtStreamCreateWithCUMask's mask stand for?  One launch per bit with only that bit set;
-// the kernel reports XCC_ID and HW_ID of where it ran.  hipcc --offload-arch=gfx950 -O2 tools/cu_mask_probe.hip -o tools/bin/cu_mask_probe
+// cu_mask_probe.hip -- what does the mask of hipExtStreamCreateWithCUMask mean on an MI355X (8 XCDs x 32 CUs)?
+//   1. one launch per bit with only that bit set; the kernel reports XCC_ID and HW_ID of where it ran (finding: everywhere -- see 2);
+//   2. patterns, 4096 workgroups each, counting the distinct CUs and the CUs per XCD they landed on (finding: bit i is a CU of XCD i % 8, so
+//      32 / 64 / 128 evenly set bits give 4 / 8 / 16 CUs of every XCD; a mask that leaves an XCD without a CU -- one bit, every second bit --
+//      is ignored as a whole);
+//   3. a spin kernel on two streams with disjoint masks, alone and together (finding: they run side by side).
+// What ffv1_check.hip's partition_streams relies on.  hipcc --offload-arch=gfx950 -O2 tools/cu_mask_probe.hip -o tools/bin/cu_mask_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
@@ -64,11 +69,11 @@ int main()
         uint32_t ma[8] = { 0xFFu, 0, 0, 0, 0, 0, 0, 0 }, mb[8] = { ~0xFFu, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u };
         hipStream_t sa, sb, sp; CHECK(hipExtStreamCreateWithCUMask(&sa, 8, ma)); CHECK(hipExtStreamCreateWithCUMask(&sb, 8, mb)); CHECK(hipStreamCreateWithFlags(&sp, hipStreamNonBlocking));
         auto timed = [&](hipStream_t s1, uint32_t g1, hipStream_t s2, uint32_t g2) -> double {
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
             const auto t0 = std::chrono::steady_clock::now();
             if (s1) hipLaunchKernelGGL(k_spin, dim3(g1), dim3(64), 0, s1, 40000000u, d2);
             if (s2) hipLaunchKernelGGL(k_spin, dim3(g2), dim3(64), 0, s2, 40000000u, d2);
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
             return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e3;
         };
         printf("spin: hash-mask stream alone %.0f ms, decode-mask stream alone %.0f ms, both %.0f ms; plain stream + hash-mask stream %.0f ms; plain + decode-mask %.0f ms\n",

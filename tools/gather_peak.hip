@@ -9,8 +9,9 @@
 //     its halves side by side in one store instruction (round 3);
 //   * `depth` independent gathers in flight per wavefront (k_resolve: the prefetch of chunk k+1 is issued while chunk k is binarised: 1);
 //   * W wavefronts per CU (k_resolve runs 10-12), each a workgroup of its own, over a region of R bytes;
-//   * (the run "from half of the CUs" at the end goes through a CU-masked stream, and tools/cu_mask_probe.hip shows this runtime ignoring the
-//     mask: that line of the output says nothing.  tools/gather_region.hip repeats it with one workgroup of 16 wavefronts per CU in use.)
+//   * (the run "from half of the CUs" at the end sets every second bit of a CU mask; tools/cu_mask_probe.hip shows that bit i stands for a CU
+//     of XCD i % 8 and that a mask which leaves an XCD empty is ignored: that run used all CUs and says nothing.  tools/gather_region.hip
+//     repeats it with one workgroup of 16 wavefronts per CU in use.)
 //   * plus the latency of one dependent random read, unloaded (one wavefront on the chip) and beside the loaded chip.
 // Output: one JSON object per line.  Build and run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O2 tools/gather_peak.hip -o tools/bin/gather_peak && tools/bin/gather_peak [region GB]

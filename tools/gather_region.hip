@@ -244,8 +244,8 @@ int main(int argc, char** argv)
         }
     }
     // ---- from half of the CUs, from a quarter: workgroups of 16 wavefronts, one per CU as the dispatcher deals them, as many as there
-    // are to be CUs in use; where they ran is read back (XCC_ID, HW_ID).  (A CU-masked stream is not it: tools/cu_mask_probe shows this
-    // runtime dealing a one-bit mask's workgroups to every XCD and shader engine.)
+    // are to be CUs in use; where they ran is read back (XCC_ID, HW_ID).  (gather_peak's CU-masked stream was not it: its mask, every second bit,
+    // names four of the eight XCDs and such a mask is ignored -- tools/cu_mask_probe.)
     if (argc <= 2) {
         uint32_t* where = nullptr; CHECK(hipMalloc(reinterpret_cast<void**>(&where), 4 * 4096));
         for (uint32_t wgs : { 256u, 128u, 64u }) {
