@@ -280,7 +280,10 @@ void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* dec);
 /* Decode n (<= max_batch) packets resident in device memory into n payload buffers in device memory (data_size bytes
  * each, padding bits zero -- the caller XORs the reversibility `InData`, RawFrame.cpp:184-206).  When h_err_flags is
  * not NULL the call synchronises and returns an error if any slice failed (bad split 1|2, CRC 4, header 32, underrun 64,
- * junk 128, error_status 256); with NULL it is asynchronous on `hip_stream`. */
+ * junk 128, error_status 256); with NULL it is asynchronous on `hip_stream`.
+ * On an MI355X the slices are decoded on 248 of the 256 CUs and rcgpu_md5_device / verify_kept hash on the other eight (CU-masked
+ * streams inside the library, joined to `hip_stream` by events: the order the caller sees is unchanged).  Such streams synchronise
+ * with the legacy default stream: to hash batch k-1 WHILE batch k is decoded, give both calls streams of their own, not NULL. */
 int  rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* dec, const void* const* d_packets, const uint64_t* packet_sizes, uint32_t n,
                                       void* const* d_payloads, uint32_t* h_err_flags, void* hip_stream);
 /* Host-buffer convenience for a caller that holds the Matroska blocks in memory (what ffv1_wrapper::Process receives one at a
