@@ -716,6 +716,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "336")), help="frames in flight per GPU per step")
     ap.add_argument("--segments", type=int, default=0, help="hand-over windows per slice between k_resolve and k_rangecode (0 = library default)")
+    ap.add_argument("--run-on", type=int, default=1, help="1: the timed steps in the encoder's run-on mode (batch k+1 started while batch k is coded); 0: one batch at a time")
     ap.add_argument("--check-batch", type=int, default=1600, help="check leg: frames decoded per step (>= --batch)")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
     ap.add_argument("--width", type=int, default=W4K)
@@ -795,6 +796,11 @@ def main():
     def step():
         enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
 
+    # The timed steps run one behind the other as a caller with a long sequence on the device would issue them: in run-on mode
+    # (rcgpu_ffv1_set_run_on) batch k+1 is modelled while batch k is coded and the range coder's chain runs through.  Every step
+    # still does all of its work inside the timed region (the region ends with a device-wide synchronisation); --run-on 0 times the
+    # steps one at a time, the device idle between them, as the line did until round 4.
+    run_on = bool(args.run_on) and args.mode != "check" and args.context_model != "compact"
     if args.mode == "check":
         step(); torch.cuda.synchronize()
         sizes = d_sizes.cpu().tolist(); record = enc.config_record(); enc.close()
@@ -851,7 +857,29 @@ def main():
         noise = _th.Thread(target=pump); noise.start(); t_noise = time.perf_counter()
 
     # ---- the headline: device-resident steps, timed as the driver's contract says (barrier + synchronize on both sides, max over ranks)
+    mode_probe = None
+    if run_on:
+        try:
+            enc.set_run_on(True)
+        except Exception as ex:      # the second bank does not fit beside this batch: one batch at a time
+            print("bench: run-on mode not available: %s" % ex, file=sys.stderr); run_on = False
+    if run_on:
+        # three steps in either mode before the clock starts: the timed steps use the faster one (run-on mode needs hardware queues of
+        # its own for five streams; where the runtime deals them differently it must not cost the line 40 %)
+        def probe(on):
+            enc.set_run_on(on); torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(3):
+                step()
+            enc.join(stream); torch.cuda.synchronize()
+            return (time.perf_counter() - t) / 3
+        probe(True)
+        mode_probe = {"run_on_ms_per_step": round(probe(True) * 1e3, 1), "one_batch_at_a_time_ms_per_step": round(probe(False) * 1e3, 1)}
+        run_on = mode_probe["run_on_ms_per_step"] <= mode_probe["one_batch_at_a_time_ms_per_step"]
+        enc.set_run_on(run_on)
     dt = rdist.timed_steps(dist, dev, step, args.steps, args.warmup, torch.cuda.synchronize)
+    if run_on:
+        enc.join(stream); torch.cuda.synchronize()
     if noise is not None:
         stop.set(); noise.join()
         print("bench: dma noise moved %.0f GB during warm-up and timed steps = %.1f GB/s beside the kernels" % (moved[0] / 1e9, moved[0] / 1e9 / max(1e-9, time.perf_counter() - t_noise)), file=sys.stderr)
@@ -951,6 +979,8 @@ def main():
                                    f"config 5 (--check: decode + compare + MD5 on the device) -> `check` (64 slices) and `configs.check_576_slices`",
                        "range_coder": "split (k_rc_range + k_rangecode<true> + k_rc_tails)" if launches.get("k_rc_range") else "one lane per slice",
                        "frames_per_step_per_gpu": F, "parallelism": f"frame-sharded x{world}, no collective",
+                       "steps_issued": "run-on: batch k+1 is modelled and started while batch k is coded (rcgpu_ffv1_set_run_on)" if run_on else "one batch at a time",
+                       **({"steps_issued_probe": mode_probe} if mode_probe else {}),
                        "packet_bytes_avg": int(packet_avg), "compression_ratio": round(packet_avg / payload_bytes, 4),
                        "decisions_per_frame": int(decisions / F) if decisions else None, "verified_vs_oracle": verified, "verified_by_reference": verified_ref,
                        "device_error_flags": flags, "hbm_in_use_gb": hbm_in_use},

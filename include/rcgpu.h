@@ -183,6 +183,18 @@ size_t rcgpu_ffv1_max_packet_bytes(const rcgpu_ffv1* enc);
 int rcgpu_ffv1_encode_device(rcgpu_ffv1* enc, const void* const* d_frames, uint32_t n,
                              void* d_packets, size_t packet_stride, uint64_t* d_packet_sizes, void* hip_stream);
 
+/* RUN-ON mode for a caller that encodes batch after batch with the frames already on the device.  A batch is k_model, then 32
+ * segments of k_resolve with the range coder one segment behind, then footer / scan / gather: with one batch at a time the coder's
+ * chain -- the critical path -- stands still for a ninth of a step.  With run-on mode on, rcgpu_ffv1_encode_device(k+1) models batch k+1
+ * while batch k is in flight (the call still blocks until ITS k_model has run), lets its segments follow batch k's without a gap, and
+ * makes `hip_stream` wait for batch k only: packets and sizes of the batch passed to a call are complete, in stream order, after the
+ * NEXT call or after rcgpu_ffv1_join().  A batch's frames may be reused as soon as its call has returned, as before (k_model has
+ * read them); consecutive batches get different d_packets / d_packet_sizes if the caller reads them in between.  Costs a second set
+ * of per-batch buffers (symbols, states, coder output: rcgpu_ffv1_set_run_on fails if they do not fit); same packets, byte for byte. */
+int rcgpu_ffv1_set_run_on(rcgpu_ffv1* enc, int on);
+/* Makes `hip_stream` wait for every batch issued so far (the last one, in run-on mode). */
+int rcgpu_ffv1_join(rcgpu_ffv1* enc, void* hip_stream);
+
 /* Error word of the last batch (the device-pointer call above enqueues work and cannot report it): bit 0 a slice outgrew its byte
  * buffer, bit 1 a slice does not fit its footer or the 24-bit slice size field -- its packet is incomplete --, bit 2 more than 4096
  * late carries.  Synchronises the encoder's streams; returns an error (and the text) when *flags != 0. */

@@ -106,6 +106,8 @@ SYMBOLS = {
     "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rcgpu_ffv1_last_error_flags": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
+    "rcgpu_ffv1_set_run_on": (C.c_int, [_VP, C.c_int]),
+    "rcgpu_ffv1_join": (C.c_int, [_VP, _VP]),
     "rcgpu_sequence_plan": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rcgpu_ffv1_encode_sequence": (C.c_int, [C.POINTER(Ffv1Config), C.c_uint64, C.POINTER(SequenceIo), C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
     "rcgpu_ffv1_encode_sequence_memory": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP), C.c_uint64, C.c_uint64, C.POINTER(_VP), C.c_uint64, _SZ, C.POINTER(C.c_uint64),
@@ -297,6 +299,14 @@ class Ffv1Encoder:
         n = len(frame_ptrs)
         ptrs = (_VP * n)(*frame_ptrs)
         _check(lib().rcgpu_ffv1_encode_device(self.h, ptrs, n, d_packets, packet_stride, d_sizes, stream), "rcgpu_ffv1_encode_device")
+
+    def set_run_on(self, on: bool = True) -> None:
+        """Run-on mode (rcgpu.h): the next batch is modelled and started while this one is in flight; a call joins the batch BEFORE it."""
+        _check(lib().rcgpu_ffv1_set_run_on(self.h, 1 if on else 0), "rcgpu_ffv1_set_run_on")
+
+    def join(self, stream: int = 0) -> None:
+        """Makes `stream` wait for every batch issued so far."""
+        _check(lib().rcgpu_ffv1_join(self.h, stream), "rcgpu_ffv1_join")
 
     def error_flags(self) -> int:
         """Device error word of the last batch (0 = fine); raises with the library's text when it is not."""

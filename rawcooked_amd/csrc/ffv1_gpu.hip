@@ -1406,8 +1406,28 @@ struct rcgpu_ffv1 {
     std::vector<int> ev_kernel;                    // kernel index of each pair
     size_t ev_used = 0;
     std::vector<hipEvent_t> ev_prev; std::vector<int> ev_kernel_prev; size_t ev_used_prev = 0;   // the call before: still readable while the next batch runs
-    hipEvent_t ev_k3[kMaxSeg]{}, ev_k4[kMaxSeg]{}, ev_rr[kMaxSeg]{}, ev_fork = nullptr;
+    hipEvent_t ev_k3[2 * kMaxSeg]{}, ev_k4[2 * kMaxSeg]{}, ev_rr[kMaxSeg]{}, ev_fork = nullptr;     // k3 / k4: a ring over the segments of two batches
+    unsigned long long gseg = 0;                   // segments issued so far: segment G uses window G % nwin and the events G % (2 * nseg)
     bool ev_valid = false;
+    // RUN-ON mode (rcgpu_ffv1_set_run_on): the device does not go idle between two batches.  Today's step is k_model (29 ms, both
+    // entropy kernels waiting), the first k_resolve segment (13 ms, the coder waiting), 32 range-coder segments, and footer / scan / gather
+    // (14 ms, nothing else running): 56 ms of a 490 ms step in which the coder's chain -- the step's critical path -- stands still.  With
+    // two BANKS of everything a batch owns (symbols, states, tables, coder output) batch k+1 is modelled on a stream of its own while
+    // batch k is in flight, its k_resolve segments follow batch k's on the front stream, its coder segments follow batch k's on the coder's
+    // stream, and batch k's footer / scan / gather run beside them on a tail stream.  The windows' ring and its events run through.
+    // The d_* members above are the CURRENT bank (the batch issued last); `alt` is the other one.
+    struct bank_t {
+        const uint8_t** d_frame_ptrs = nullptr; uint32_t* d_sym = nullptr; uint8_t* d_states = nullptr;
+        unsigned long long* d_ndec = nullptr; unsigned long long* d_total_n = nullptr; uint32_t* d_seg_pieces = nullptr; unsigned long long* d_group_off = nullptr;
+        uint8_t* d_k3_resume = nullptr; rc_resume* d_k4_resume = nullptr; uint8_t* d_cbuf = nullptr; uint32_t* d_out_len = nullptr; uint32_t* d_tot_len = nullptr;
+        unsigned long long* d_slice_dst = nullptr; uint32_t* d_err = nullptr; uint2* d_events = nullptr;
+        hipEvent_t ev_done = nullptr;              // behind the last kernel of the bank's batch
+        bool used = false, joined = true;          // a batch has run in it; a caller's stream has been made to wait for it
+    } alt;
+    hipEvent_t ev_done = nullptr; bool used = false, joined = true;       // the current bank's
+    bool run_on = false, alt_allocated = false;
+    hipStream_t model_stream = nullptr, front_stream = nullptr, tail_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_model = nullptr;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
     uint32_t last_n = 0;
     hipEvent_t gather_wait = nullptr;              // pipeline: k_gather of the next batch waits for the previous batch's download
@@ -1432,7 +1452,13 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
     void* bufs[] = { e->d_const, e->d_geom, e->d_hdr, e->d_frame_ptrs, e->d_planes, e->d_sym, e->d_states, e->d_ndec, e->d_total_n, e->d_seg_pieces,
                      e->d_group_off, e->d_k3_resume, e->d_k4_resume, e->d_cbuf, e->d_out_len, e->d_tot_len,
                      e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes, e->d_ckpt };
+    for (hipStream_t q : { e->model_stream, e->front_stream, e->tail_stream, e->rc_stream }) if (q) (void)hipStreamSynchronize(q);
     for (void* b : bufs) if (b) (void)hipFree(b);
+    void* abufs[] = { e->alt.d_frame_ptrs, e->alt.d_sym, e->alt.d_states, e->alt.d_ndec, e->alt.d_total_n, e->alt.d_seg_pieces, e->alt.d_group_off, e->alt.d_k3_resume,
+                      e->alt.d_k4_resume, e->alt.d_cbuf, e->alt.d_out_len, e->alt.d_tot_len, e->alt.d_slice_dst, e->alt.d_err, e->alt.d_events };
+    for (void* b : abufs) if (b) (void)hipFree(b);
+    for (hipEvent_t q : { e->ev_done, e->alt.ev_done, e->ev_in, e->ev_model }) if (q) (void)hipEventDestroy(q);
+    for (hipStream_t q : { e->model_stream, e->tail_stream }) if (q) (void)hipStreamDestroy(q);       // (front_stream is rr_stream)
     for (uint8_t* w : e->d_window) if (w) (void)hipFree(w);
     void* hosts[] = { e->h_psizes, e->h_ndec_pinned, e->h_frame_ptrs, e->h_total_n, e->h_seg_pieces, e->h_group_off, e->h_err };
     for (void* h : hosts) if (h) (void)hipHostFree(h);
@@ -1599,12 +1625,13 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     for (auto& ev : e->ev) if (he == hipSuccess) he = hipEventCreate(&ev);
     e->ev_prev.resize(e->ev.size());
     for (auto& ev : e->ev_prev) if (he == hipSuccess) he = hipEventCreate(&ev);
-    for (uint32_t j = 0; j < nseg; j++) {
+    for (uint32_t j = 0; j < 2 * nseg; j++) {
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k3[j], hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_k4[j], hipEventDisableTiming);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_rr[j], hipEventDisableTiming);
+        if (he == hipSuccess && j < nseg) he = hipEventCreateWithFlags(&e->ev_rr[j], hipEventDisableTiming);
     }
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming);
     if (he == hipSuccess) he = hipMemcpy(e->d_const, &e->hc, sizeof(enc_const), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(e->d_geom, e->geom.data(), sizeof(slice_geom) * S, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(e->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
@@ -1639,6 +1666,22 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     hipStream_t s2 = e->rc_stream;
     static const bool exp_serial = TIMING_ENV("RCGPU_EXP_SERIAL") != nullptr;      // timing runs: every kernel alone on the device, one after the other
     if (exp_serial) s2 = st;
+    // run-on mode: this batch goes into the other bank; modelling, resolving and the batch's tail get streams of their own (see rcgpu_ffv1)
+    const bool ro = e->run_on && !exp_serial && !e->span_pieces && !e->exp_skip_rc;
+    if (ro) {
+#define SW(f) std::swap(e->f, e->alt.f)
+        SW(d_frame_ptrs); SW(d_sym); SW(d_states); SW(d_ndec); SW(d_total_n); SW(d_seg_pieces); SW(d_group_off); SW(d_k3_resume); SW(d_k4_resume);
+        SW(d_cbuf); SW(d_out_len); SW(d_tot_len); SW(d_slice_dst); SW(d_err); SW(d_events); SW(ev_done); SW(used); SW(joined);
+#undef SW
+    }
+    hipStream_t ms = ro ? e->model_stream : st;          // k_model and the tables
+    hipStream_t fr = ro ? e->front_stream : st;          // k_resolve
+    hipStream_t tl = ro ? e->tail_stream : s2;           // footer, scan, gather
+    if (ro) {
+        HIP_TRY(hipEventRecord(e->ev_in, st));                                       // the caller's frames are ready
+        HIP_TRY(hipStreamWaitEvent(ms, e->ev_in, 0));
+        if (e->used) HIP_TRY(hipStreamWaitEvent(ms, e->ev_done, 0));                 // the batch before the last, whose bank this is, is finished
+    }
     const enc_const& c = e->hc;
     const uint32_t S = c.S, nchains = n * S, ngroups = (nchains + 63) / 64, nseg = e->nseg;
     std::swap(e->ev, e->ev_prev); std::swap(e->ev_kernel, e->ev_kernel_prev); e->ev_used_prev = e->ev_used;      // timing events alternate between two sets
@@ -1653,18 +1696,18 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     };
 
     for (uint32_t i = 0; i < n; i++) e->h_frame_ptrs[i] = d_frames[i];
-    HIP_TRY(rc::copy_by_kernel(e->d_frame_ptrs, e->h_frame_ptrs, sizeof(void*) * n, st));
-    HIP_TRY(hipMemsetAsync(e->d_ndec, 0, size_t(nchains) * nseg * 8, st));
-    HIP_TRY(hipMemsetAsync(e->d_err, 0, 16, st));
+    HIP_TRY(rc::copy_by_kernel(e->d_frame_ptrs, e->h_frame_ptrs, sizeof(void*) * n, ms));
+    HIP_TRY(hipMemsetAsync(e->d_ndec, 0, size_t(nchains) * nseg * 8, ms));
+    HIP_TRY(hipMemsetAsync(e->d_err, 0, 16, ms));
     uint32_t max_tiles = 0;
     for (const slice_geom& g : e->geom) max_tiles = std::max(max_tiles, ((g.w + kTileW - 1) / kTileW) * ((g.h + kTileR - 1) / kTileR));
-    HIP_TRY(timed(1, st, [&] { hipLaunchKernelGGL(k_model, dim3(max_tiles, nchains), dim3(256), size_t(c.planes) * kTileRows * kTileCols * 4, st,
+    HIP_TRY(timed(1, ms, [&] { hipLaunchKernelGGL(k_model, dim3(max_tiles, nchains), dim3(256), size_t(c.planes) * kTileRows * kTileCols * 4, ms,
                                                   e->d_const, e->d_geom, e->d_frame_ptrs, e->d_sym, e->d_ndec); }));
     // states_coded = 0: every context starts at 128 (beside the host round trip below)
-    if (!e->lds_states) HIP_TRY(hipMemsetAsync(e->d_states, 0x80, size_t(nchains) * e->nkeys * 32, st));
+    if (!e->lds_states) HIP_TRY(hipMemsetAsync(e->d_states, 0x80, size_t(nchains) * e->nkeys * 32, ms));
     // The exact decision counts size the stream windows: one host round trip per batch.
-    HIP_TRY(rc::copy_by_kernel(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * nseg * 8, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(rc::copy_by_kernel(e->h_ndec_pinned, e->d_ndec, size_t(nchains) * nseg * 8, ms));
+    HIP_TRY(hipStreamSynchronize(ms));
     uint64_t total_dec = 0;
     for (uint32_t chain = 0; chain < nchains; chain++) {
         unsigned long long D = e->geom[chain % S].hdr_n, done = 0;
@@ -1712,6 +1755,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         }
     }
     if (window_need > e->window_cap) {
+        if (ro) for (hipStream_t q : { fr, s2, tl }) HIP_TRY(hipStreamSynchronize(q));       // the batch in flight is using the windows that are about to go
         for (auto& w : e->d_window) { if (w) HIP_TRY(hipFree(w)); w = nullptr; }
         e->window_cap = 0;
         const size_t want = window_need + window_need / 8 + (1u << 20);
@@ -1721,30 +1765,37 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         }
         e->window_cap = want;
     }
-    HIP_TRY(rc::copy_by_kernel(e->d_total_n, e->h_total_n, size_t(nchains) * 8, st));
-    HIP_TRY(rc::copy_by_kernel(e->d_seg_pieces, e->h_seg_pieces, (size_t(nchains) * nseg * 4 + 7) & ~size_t(7), st));
-    HIP_TRY(rc::copy_by_kernel(e->d_group_off, e->h_group_off, size_t(ngroups) * nseg * 8, st));
+    HIP_TRY(rc::copy_by_kernel(e->d_total_n, e->h_total_n, size_t(nchains) * 8, ms));
+    HIP_TRY(rc::copy_by_kernel(e->d_seg_pieces, e->h_seg_pieces, (size_t(nchains) * nseg * 4 + 7) & ~size_t(7), ms));
+    HIP_TRY(rc::copy_by_kernel(e->d_group_off, e->h_group_off, size_t(ngroups) * nseg * 8, ms));
+    if (ro) { HIP_TRY(hipEventRecord(e->ev_model, ms)); HIP_TRY(hipStreamWaitEvent(fr, e->ev_model, 0)); }
     // k_resolve(seg j) on the caller's stream, k_rangecode(seg j) on rc_stream; window j % nwin is reused once k_rangecode(j - nwin) is done.
     // Split coder: k_rc_range(seg j) on rr_stream between the two -- it follows k_resolve(j) and its own previous segment, the spans of
     // segment j follow it and nothing else.
     hipStream_t s3 = exp_serial ? st : e->rr_stream;
-    HIP_TRY(hipEventRecord(e->ev_fork, st));
+    HIP_TRY(hipEventRecord(e->ev_fork, fr));
     HIP_TRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
     if (e->span_pieces) HIP_TRY(hipStreamWaitEvent(s3, e->ev_fork, 0));
+    // Segment G of the encoder's life (gseg + j) hands over through window G % nw, and its two events are G % (2 * nseg) of their rings:
+    // the numbering runs through the batches, so that in run-on mode this batch's first segments wait for the previous batch's last ones
+    // exactly as a batch's later segments wait for its earlier ones.
+    const uint32_t nw = nseg > 1 ? e->nwin : 1u, ring = 2 * nseg;
     for (uint32_t j = 0; j < nseg; j++) {
-        uint8_t* win = e->d_window[j % e->nwin];
-        if (j >= e->nwin) HIP_TRY(hipStreamWaitEvent(st, e->ev_k4[j - e->nwin], 0));
-        HIP_TRY(timed(2, st, [&] {
-            if (e->lds_states) hipLaunchKernelGGL(k_resolve<true>, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
+        const unsigned long long G = e->gseg + j;
+        hipEvent_t k3 = e->ev_k3[G % ring], k4 = e->ev_k4[G % ring];
+        uint8_t* win = e->d_window[G % nw];
+        if (G >= nw) HIP_TRY(hipStreamWaitEvent(fr, e->ev_k4[(G - nw) % ring], 0));
+        HIP_TRY(timed(2, fr, [&] {
+            if (e->lds_states) hipLaunchKernelGGL(k_resolve<true>, dim3(nchains), dim3(64), e->resolve_lds, fr, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
                                                   e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride, e->resolve_prio);
-            else hipLaunchKernelGGL(k_resolve<false>, dim3(nchains), dim3(64), e->resolve_lds, st, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
+            else hipLaunchKernelGGL(k_resolve<false>, dim3(nchains), dim3(64), e->resolve_lds, fr, e->d_const, e->d_geom, e->d_hdr, e->d_sym, e->d_states,
                                     e->d_group_off + size_t(j) * ngroups, win, e->nkeys, j, e->d_k3_resume, e->resume_stride, e->resolve_prio); }));
-        HIP_TRY(hipEventRecord(e->ev_k3[j], st));
-        if (e->exp_skip_rc) { HIP_TRY(hipStreamWaitEvent(s2, e->ev_k3[j], 0)); HIP_TRY(hipEventRecord(e->ev_k4[j], s2)); continue; }    // timing runs: k_resolve alone
+        HIP_TRY(hipEventRecord(k3, fr));
+        if (e->exp_skip_rc) { HIP_TRY(hipStreamWaitEvent(s2, k3, 0)); HIP_TRY(hipEventRecord(k4, s2)); continue; }    // timing runs: k_resolve alone
         if (e->span_pieces) {
             rc_ckpt* ck = e->d_ckpt + size_t(e->seg_span_off[j]) * nchains;
             const uint32_t nsp = e->seg_spans[j];
-            HIP_TRY(hipStreamWaitEvent(s3, e->ev_k3[j], 0));
+            HIP_TRY(hipStreamWaitEvent(s3, k3, 0));
             HIP_TRY(timed(7, s3, [&] { hipLaunchKernelGGL(k_rc_range, dim3(ngroups), dim3(64), 0, s3, e->d_const, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
                                                           j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, nchains, ck, e->span_pieces, nsp); }));
             HIP_TRY(hipEventRecord(e->ev_rr[j], s3));
@@ -1755,33 +1806,94 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
                                                           j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
                                                           (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, ck, e->span_pieces); }));
         } else {
-            HIP_TRY(hipStreamWaitEvent(s2, e->ev_k3[j], 0));
+            HIP_TRY(hipStreamWaitEvent(s2, k3, 0));
             HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<false>, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
                                                           j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
                                                           (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, static_cast<rc_ckpt*>(nullptr), 0u); }));
         }
-        HIP_TRY(hipEventRecord(e->ev_k4[j], s2));
+        HIP_TRY(hipEventRecord(k4, s2));
     }
+    const hipEvent_t k4_last = e->ev_k4[(e->gseg + nseg - 1) % ring];
+    e->gseg += nseg;
     if (e->span_pieces && !e->exp_skip_rc)
         HIP_TRY(timed(8, s2, [&] { hipLaunchKernelGGL(k_rc_tails, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_ckpt, total_spans, nchains,
                                                       e->d_cbuf, (unsigned long long)e->cbuf_frame_stride); }));
-    // footer / scan / gather follow the last range-coder segment on its stream; the caller's stream then joins
-    HIP_TRY(timed(4, s2, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+    // footer / scan / gather follow the last range-coder segment -- on its stream, or in run-on mode on the tail stream, beside the next
+    // batch's first coder segments; then the caller's stream joins: this batch, or in run-on mode the batch before it
+    if (tl != s2) HIP_TRY(hipStreamWaitEvent(tl, k4_last, 0));
+    HIP_TRY(timed(4, tl, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, tl, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));
-    HIP_TRY(timed(5, s2, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, s2, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
+    HIP_TRY(timed(5, tl, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, tl, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
     if (!e->defer_gather) {
-        if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(s2, e->gather_wait, 0)); e->gather_wait = nullptr; }
-        HIP_TRY(timed(6, s2, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, s2, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+        if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(tl, e->gather_wait, 0)); e->gather_wait = nullptr; }
+        HIP_TRY(timed(6, tl, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, tl, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                       e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
     }
 #ifdef RCGPU_TIMING_BUILD
     // a timing run that skipped a coder has no valid packets: the batch says so in its error word, whoever reads it
-    if (e->exp_skip_rc || TIMING_ENV("RCGPU_EXP_SKIP_B") || TIMING_ENV("RCGPU_EXP_STATES_L2")) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_err), 8, 1, s2));
+    if (e->exp_skip_rc || TIMING_ENV("RCGPU_EXP_SKIP_B") || TIMING_ENV("RCGPU_EXP_STATES_L2")) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_err), 8, 1, tl));
 #endif
-    HIP_TRY(hipEventRecord(e->ev_fork, s2));
-    HIP_TRY(hipStreamWaitEvent(st, e->ev_fork, 0));
+    HIP_TRY(hipEventRecord(e->ev_done, tl));
+    e->used = true; e->joined = false;
+    if (!ro) { HIP_TRY(hipStreamWaitEvent(st, e->ev_done, 0)); e->joined = true; }
+    if (e->alt.used && !e->alt.joined) { HIP_TRY(hipStreamWaitEvent(st, e->alt.ev_done, 0)); e->alt.joined = true; }
     HIP_TRY(hipGetLastError());
     e->ev_valid = true; e->last_n = n;
+    return 0;
+}
+
+// Run-on mode: see rcgpu.h.  Switching it on allocates the second bank (symbols, states, tables, coder output: about as much again as
+// the encoder holds per batch) and the three streams; switching it off waits for what is in flight.
+extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
+{
+    clear_error();
+    if (!e) return fail(1, "ffv1: null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (!on) {
+        if (e->run_on) for (hipStream_t q : { e->model_stream, e->front_stream, e->rc_stream, e->tail_stream }) if (q) HIP_TRY(hipStreamSynchronize(q));
+        e->run_on = false; e->joined = true; e->alt.joined = true;
+        return 0;
+    }
+    if (e->span_pieces) return fail(2, "ffv1: run-on mode and the split range coder (rc_span) exclude each other");
+    if (!e->alt_allocated) {
+        const uint32_t F = e->cfg.max_batch, S = e->hc.S, nseg = e->nseg;
+        const size_t nchains = size_t(F) * S, ngroups = (nchains + 63) / 64;
+        hipError_t he = hipSuccess;
+        auto dm = [&](auto** p, size_t bytes) { if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(p), bytes ? bytes : 16); };
+        rcgpu_ffv1::bank_t& b = e->alt;
+        dm(&b.d_frame_ptrs, sizeof(void*) * F); dm(&b.d_sym, size_t(F) * e->hc.samples_per_frame * 4); dm(&b.d_states, e->lds_states ? 16 : nchains * e->nkeys * 32);
+        dm(&b.d_ndec, nchains * nseg * 8); dm(&b.d_total_n, nchains * 8); dm(&b.d_seg_pieces, nchains * nseg * 4 + 8); dm(&b.d_group_off, ngroups * nseg * 8);
+        dm(&b.d_k3_resume, nchains * e->resume_stride); dm(&b.d_k4_resume, nchains * sizeof(rc_resume)); dm(&b.d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
+        dm(&b.d_out_len, nchains * 4); dm(&b.d_tot_len, nchains * 4); dm(&b.d_slice_dst, nchains * 8); dm(&b.d_err, 16); dm(&b.d_events, sizeof(uint2) * kMaxCarryEvents);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_model, hipEventDisableTiming);
+        // Five streams are busy or waiting at any time (the caller's, model, front, coder, tail) and a stream that waits holds up whatever
+        // shares its hardware queue: ROCm deals the streams of ONE priority to four hardware queues (GPU_MAX_HW_QUEUES), those of another
+        // priority to four others.  Model and tail, the background of the batch in flight, take the low priority's; measured with all five
+        // at one priority: k_resolve and k_rangecode shared a queue and ran one after the other, 820 ms per step instead of 480 (and with
+        // k_resolve at the HIGH priority its workgroups are dispatched before the coder's every time: 712 ms).
+        int lo = 0, hi = 0;
+        if (he == hipSuccess) he = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->model_stream, hipStreamNonBlocking, lo);
+        if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->tail_stream, hipStreamNonBlocking, lo);
+        e->front_stream = e->rr_stream;             // the split coder's stream, idle in this mode: no fifth stream at the normal priority
+        if (he != hipSuccess) return fail(101, "ffv1: run-on mode: cannot allocate the second bank for %u frames: %s -- lower max_batch", F, hipGetErrorString(he));
+        e->alt_allocated = true;
+    }
+    e->run_on = true;
+    return 0;
+}
+
+// Makes `hip_stream` wait for every batch issued so far (run-on mode leaves the last one unjoined).
+extern "C" int rcgpu_ffv1_join(rcgpu_ffv1* e, void* hip_stream)
+{
+    clear_error();
+    if (!e) return fail(1, "ffv1: null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (e->alt.used && !e->alt.joined) { HIP_TRY(hipStreamWaitEvent(st, e->alt.ev_done, 0)); e->alt.joined = true; }
+    if (e->used && !e->joined) { HIP_TRY(hipStreamWaitEvent(st, e->ev_done, 0)); e->joined = true; }
     return 0;
 }
 
@@ -1920,6 +2032,7 @@ extern "C" int rcgpu_ffv1_last_error_flags(rcgpu_ffv1* e, uint32_t* flags)
     if (!e->h_err) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_err), 16));
     // the batch's last kernels run on rc_stream; the caller's stream joined it at the end of the call
     HIP_TRY(hipStreamSynchronize(e->rc_stream));
+    if (e->used) HIP_TRY(hipEventSynchronize(e->ev_done));       // (run-on mode: the batch's footer runs on the tail stream)
     HIP_TRY(hipMemcpy(e->h_err, e->d_err, 16, hipMemcpyDeviceToHost));
     *flags = e->h_err[0];
     if (*flags) return fail(102, "ffv1: %s (flags %u)", ffv1_error_flags_text(*flags), *flags);

@@ -95,6 +95,63 @@ def test_many_frames_cross_sub_batches(built):
     enc.close()
 
 
+@pytest.mark.parametrize("segments", [1, 5, 32])
+@pytest.mark.parametrize("w,h,pixfmt,slices,nframes", [(200, 120, synth.PIX_RGB16_BE, 6, 5), (96, 64, synth.PIX_RGB10_FILLEDA_BE, 4, 70), (512, 270, synth.PIX_RGB16_BE, 1, 3)])
+def test_run_on_mode_is_bit_exact(built, w, h, pixfmt, slices, nframes, segments):
+    """Run-on mode (rcgpu_ffv1_set_run_on): batch k+1 is modelled and started while batch k is in flight, two banks of per-batch buffers,
+    the windows' ring running through.  Seven batches of different pictures and sizes (the last ones short), each into buffers of its own:
+    every packet equals the oracle's, whatever was in flight beside it; then back to one batch at a time with the same encoder."""
+    import torch
+    bits, nc, bpp, be = synth.PIX_INFO[pixfmt]
+    nh, nv = api.slices_to_grid(slices)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    sizes_of = [nframes, nframes, max(1, nframes // 2), nframes, 1, nframes, max(1, nframes - 1)]
+    line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, "flat", seed=0), pixfmt, True)[1]
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=segments, rc_span=1)
+    stride = (enc.max_packet + 255) & ~255
+    st = torch.cuda.Stream()
+    batches = []
+    for b, n in enumerate(sizes_of):
+        pls = [synth.pack_payload(synth.components(w, h, nc, bits, "film" if (b + i) % 3 else "noise", seed=1000 * b + i), pixfmt, True)[0] for i in range(n)]
+        batches.append((pls, [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in pls],
+                        torch.full((n * stride,), 0x5A, dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.int64, device="cuda")))
+    torch.cuda.synchronize()
+
+    def check(b):
+        pls, _, d_pk, d_sz = batches[b]
+        sz = d_sz.cpu().tolist()
+        for i, pl in enumerate(pls):
+            got = bytes(d_pk[i * stride:i * stride + sz[i]].cpu().numpy())
+            assert got == ob.encode_payload(p, pl, line_bytes), f"batch {b} frame {i}"
+
+    enc.set_run_on(True)
+    for b, (pls, d_in, d_pk, d_sz) in enumerate(batches[:5]):
+        enc.encode_device([t.data_ptr() for t in d_in], d_pk.data_ptr(), stride, d_sz.data_ptr(), st.cuda_stream)
+        if b >= 1:                      # the call for batch b has joined batch b - 1 to the stream
+            st.synchronize(); check(b - 1)
+    enc.join(st.cuda_stream); st.synchronize(); check(4)
+    assert enc.error_flags() == 0
+    enc.set_run_on(False)
+    for b in (5, 6):
+        pls, d_in, d_pk, d_sz = batches[b]
+        enc.encode_device([t.data_ptr() for t in d_in], d_pk.data_ptr(), stride, d_sz.data_ptr(), st.cuda_stream)
+        st.synchronize(); check(b)
+    enc.set_run_on(True)               # and on again: the banks and the ring carry on
+    for b in (0, 1):
+        pls, d_in, d_pk, d_sz = batches[b]
+        d_pk.fill_(0)
+        enc.encode_device([t.data_ptr() for t in d_in], d_pk.data_ptr(), stride, d_sz.data_ptr(), st.cuda_stream)
+    enc.join(st.cuda_stream); st.synchronize(); check(0); check(1)
+    enc.close()
+
+
+def test_run_on_mode_and_the_split_coder_exclude_each_other(built):
+    enc = api.Ffv1Encoder(64, 48, synth.PIX_RGB16_BE, 64 * 6, 2, 2, 1, 1, max_batch=2, rc_span=8)
+    with pytest.raises(api.RcgpuError, match="run-on"):
+        enc.set_run_on(True)
+    enc.close()
+
+
 @pytest.mark.parametrize("pixfmt,w,h,slices", [(synth.PIX_RGB16_BE, 200, 120, 6), (synth.PIX_RGB10_FILLEDA_LE, 96, 64, 4), (synth.PIX_RGBA16_BE, 64, 48, 4),
                                                 (synth.PIX_Y16_LE, 80, 40, 4), (synth.PIX_RGB8, 90, 50, 4)])
 @pytest.mark.parametrize("segments", [1, 3])
