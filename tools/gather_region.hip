@@ -1,13 +1,13 @@
 // gather_region.hip -- does the ceiling of tools/gather_peak.hip (19.7 G records/s over 4.3 GB) hold for the regions the kernels really
 // walk?  profiles/r04_gather_peak.jsonl falls from 31 G/s (128 MB) over 23 (1 GB) to 19.7 (4.3 GB) and stops there because the program
-// does.  The decoder (k_dec_slices, a lane per slice) has every slice of a batch in flight: 1600 frames x 64 slices x 484 KB of states are
-// 50 GB, 336 frames of 576 slices are 94 GB, and the 64 lanes of one load instruction are in 64 different slices' arrays.  The encoder
-// (k_resolve, a wavefront per slice) has ~2048 slices in flight whose arrays lie side by side: 1 GB, all 64 lanes in one 484 KB array.
+// does.  The decoder (k_dec_slices, a lane per slice) has every slice of a batch in flight: 1600 frames x 64 slices x 316 KB of states
+// (2 plane sets x 5063 contexts x 32 bytes) are 33 GB, 336 frames of 576 slices are 63 GB, and the 64 lanes of one load instruction are in 64 different slices' arrays.  The encoder
+// (k_resolve, a wavefront per slice) has ~2048 slices in flight whose arrays lie side by side: 0.66 GB, all 64 lanes in one 316 KB array.
 // Three patterns, each gather + a pair of lanes per record written back (gather_peak's mode 2) and gather only:
 //   flat     every lane draws from the whole region                     (gather_peak, larger regions)
 //   lane     every lane draws from its own block of B bytes             (the decoder)
 //   wave     the lanes of a wavefront draw from the wavefront's block   (the encoder)
-// Then: the encoder's pattern with its arrays 484 KB to 48 MiB apart; the same beside a copy kernel that streams 0.2 to 4 TB/s; and the
+// Then: the encoder's pattern with its arrays 316 KB to 48 MiB apart; the same beside a copy kernel that streams 0.2 to 4 TB/s; and the
 // uniform pattern from 256, 128 and 64 CUs (one workgroup of 16 wavefronts each, their CUs read back from HW_ID).
 // Output: one JSON object per line.  hipcc --offload-arch=gfx950 -O2 tools/gather_region.hip -o tools/bin/gather_region
 // Run: tools/bin/gather_region [GiB to allocate, default 100]   (with three more arguments: a fine sweep of the array distance, lo hi step in KB)
@@ -155,26 +155,26 @@ int main(int argc, char** argv)
             fflush(stdout);
         }
     }
-    // ---- lane: a block per lane (the decoder: 484 KB of states per slice), blocks side by side; waves per CU as the decoder's batch has them
-    const unsigned long long blk = 484ull * 1024 / 32;
+    // ---- lane: a block per lane (the decoder: 316 KB of states per slice), blocks side by side; waves per CU as the decoder's batch has them
+    const unsigned long long blk = 2ull * 5063;                                // records: two plane sets x 5063 contexts (324 032 bytes)
     for (uint32_t wpc : { 2u, 4u, 6u, 12u }) {
         const uint32_t waves = ncu * wpc;
         if (size_t(waves) * 64 * blk > nrec) continue;
         const uint32_t iters = uint32_t(total / (size_t(waves) * 64));
         const double t0 = run<1, false>(region, blk, blk, waves, iters, sink), t2 = run<1, true>(region, blk, blk, waves, iters, sink);
         const double recs = double(waves) * 64 * iters;
-        printf("{\"pattern\": \"lane\", \"block_kb\": 484, \"waves_per_cu\": %u, \"region_gib\": %.2f, \"gather_only_G_per_s\": %.2f, \"gather_writeback_G_per_s\": %.2f}\n",
+        printf("{\"pattern\": \"lane\", \"block_kb\": 316, \"waves_per_cu\": %u, \"region_gib\": %.2f, \"gather_only_G_per_s\": %.2f, \"gather_writeback_G_per_s\": %.2f}\n",
                wpc, double(waves) * 64 * blk * 32 / double(1ull << 30), recs / t0 * 1e-9, recs / t2 * 1e-9);
         fflush(stdout);
     }
     // ---- lane with smaller blocks (what a slice really touches, were its records packed): does the region or the page count matter?
-    for (unsigned long long kb : { 32ull, 121ull, 242ull }) {
+    for (unsigned long long kb : { 32ull, 79ull, 158ull }) {
         const uint32_t wpc = 6, waves = ncu * wpc, iters = uint32_t(total / (size_t(waves) * 64));
         const unsigned long long b = kb * 1024 / 32;
         const double t2 = run<1, true>(region, b, b, waves, iters, sink);
         const double t2s = size_t(waves) * 64 * blk <= nrec ? run<1, true>(region, b, blk, waves, iters, sink) : 0;
         const double recs = double(waves) * 64 * iters;
-        printf("{\"pattern\": \"lane\", \"block_kb\": %llu, \"waves_per_cu\": %u, \"region_gib\": %.2f, \"gather_writeback_G_per_s\": %.2f, \"same_blocks_484_kb_apart_G_per_s\": %.2f}\n",
+        printf("{\"pattern\": \"lane\", \"block_kb\": %llu, \"waves_per_cu\": %u, \"region_gib\": %.2f, \"gather_writeback_G_per_s\": %.2f, \"same_blocks_an_array_apart_G_per_s\": %.2f}\n",
                kb, wpc, double(waves) * 64 * b * 32 / double(1ull << 30), recs / t2 * 1e-9, t2s > 0 ? recs / t2s * 1e-9 : 0.0);
         fflush(stdout);
     }
@@ -186,18 +186,18 @@ int main(int argc, char** argv)
         const unsigned long long far = nrec / waves;
         const double t2f = run<2, true>(region, blk, far, waves, iters, sink);
         const double recs = double(waves) * 64 * iters;
-        printf("{\"pattern\": \"wave\", \"block_kb\": 484, \"waves_per_cu\": %u, \"region_gib\": %.2f, \"gather_only_G_per_s\": %.2f, \"gather_writeback_G_per_s\": %.2f, "
+        printf("{\"pattern\": \"wave\", \"block_kb\": 316, \"waves_per_cu\": %u, \"region_gib\": %.2f, \"gather_only_G_per_s\": %.2f, \"gather_writeback_G_per_s\": %.2f, "
                "\"blocks_spread_over_the_allocation_G_per_s\": %.2f}\n", wpc, double(waves) * blk * 32 / double(1ull << 30), recs / t0 * 1e-9, recs / t2 * 1e-9, recs / t2f * 1e-9);
         fflush(stdout);
     }
     // ---- wave: how far apart must the blocks in flight lie?  strides in KB, 8 wavefronts per CU
-    for (unsigned long long skb : { 484ull, 512ull, 726ull, 968ull, 1024ull, 1452ull, 1936ull, 2048ull, 2112ull, 3872ull, 4096ull, 5082ull, 7744ull, 15488ull, 30976ull, 49152ull }) {
+    for (unsigned long long skb : { 317ull, 512ull, 726ull, 968ull, 1024ull, 1452ull, 1936ull, 2048ull, 2112ull, 3872ull, 4096ull, 5082ull, 7744ull, 15488ull, 30976ull, 49152ull }) {
         const uint32_t wpc = 8, waves = ncu * wpc, iters = uint32_t(total / (size_t(waves) * 64));
         const unsigned long long st = skb * 1024 / 32;
         if (size_t(waves) * st > nrec) continue;
         const double t0 = run<2, false>(region, blk, st, waves, iters, sink), t2 = run<2, true>(region, blk, st, waves, iters, sink);
         const double recs = double(waves) * 64 * iters;
-        printf("{\"pattern\": \"wave\", \"block_kb\": 484, \"stride_kb\": %llu, \"waves_per_cu\": %u, \"extent_gib\": %.2f, \"gather_only_G_per_s\": %.2f, \"gather_writeback_G_per_s\": %.2f}\n",
+        printf("{\"pattern\": \"wave\", \"block_kb\": 316, \"stride_kb\": %llu, \"waves_per_cu\": %u, \"extent_gib\": %.2f, \"gather_only_G_per_s\": %.2f, \"gather_writeback_G_per_s\": %.2f}\n",
                skb, wpc, double(waves) * st * 32 / double(1ull << 30), recs / t0 * 1e-9, recs / t2 * 1e-9);
         fflush(stdout);
     }
@@ -234,12 +234,14 @@ int main(int argc, char** argv)
     }
     if (argc > 2) {                                                        // fine sweep: strides from argv[2] to argv[3] KB in steps of argv[4] KB
         const unsigned long long lo = strtoull(argv[2], nullptr, 10), hi = strtoull(argv[3], nullptr, 10), step = strtoull(argv[4], nullptr, 10);
+        const bool lane_pat = argc > 5 && argv[5][0] == 'l';                 // fifth argument "lane": the decoder's pattern, strides in BYTES
         for (unsigned long long skb = lo; skb <= hi; skb += step) {
-            const uint32_t wpc = 8, waves = ncu * wpc, iters = uint32_t((total / 4) / (size_t(waves) * 64));
-            const unsigned long long st = skb * 1024 / 32;
-            if (size_t(waves) * st > nrec) break;
-            const double t2 = run<2, true>(region, blk, st, waves, iters, sink);
-            printf("{\"sweep\": \"wave\", \"stride_kb\": %llu, \"gather_writeback_G_per_s\": %.2f}\n", skb, double(waves) * 64 * iters / t2 * 1e-9);
+            const uint32_t wpc = lane_pat ? 6 : 8, waves = ncu * wpc, iters = uint32_t((total / 4) / (size_t(waves) * 64));
+            const unsigned long long st = lane_pat ? skb / 32 : skb * 1024 / 32;
+            if (size_t(waves) * (lane_pat ? 64 : 1) * st > nrec) break;
+            const double t2 = lane_pat ? run<1, true>(region, blk, st, waves, iters, sink) : run<2, true>(region, blk, st, waves, iters, sink);
+            if (lane_pat) printf("{\"sweep\": \"lane\", \"stride_bytes\": %llu, \"gather_writeback_G_per_s\": %.2f}\n", skb, double(waves) * 64 * iters / t2 * 1e-9);
+            else printf("{\"sweep\": \"wave\", \"stride_kb\": %llu, \"gather_writeback_G_per_s\": %.2f}\n", skb, double(waves) * 64 * iters / t2 * 1e-9);
             fflush(stdout);
         }
     }
