@@ -1667,6 +1667,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     static const bool exp_serial = TIMING_ENV("RCGPU_EXP_SERIAL") != nullptr;      // timing runs: every kernel alone on the device, one after the other
     if (exp_serial) s2 = st;
     // run-on mode: this batch goes into the other bank; modelling, resolving and the batch's tail get streams of their own (see rcgpu_ffv1)
+    if (e->run_on && e->defer_gather) return fail(2, "ffv1: run-on mode and the pipeline's deferred gather exclude each other (a gather issued later would find its bank reused)");
     const bool ro = e->run_on && !exp_serial && !e->span_pieces && !e->exp_skip_rc;
     if (ro) {
 #define SW(f) std::swap(e->f, e->alt.f)
