@@ -332,6 +332,13 @@ int  rcgpu_ffv1_decoder_decode_keep(rcgpu_ffv1_decoder* dec, const uint8_t* cons
  * that has not mapped it: they are read with pread() straight into the staging buffers.  (From a mapping the bytes go up faster -- 6 GB in 0.3 s
  * against 0.35-0.7 s -- at the price of ~0.4 s when the mapping with all its pages touched is torn down, as matroska::ParseBuffer does after
  * every MiB, Matroska.cpp:394-419: about even.) */
+/* One batch AHEAD: the batch the caller will pass to its next decode_keep, started now on a thread of the library's own (packets up,
+ * decode, into slots that are neither the current ones nor under verification) while the caller hands out the current batch's frames
+ * and has them verified.  The packets must stay where they are until that decode_keep (a mapped file; not a buffer that is refilled).
+ * The next decode_keep with the same pointers and sizes adopts the result; with any other batch, or after an error, the batch is
+ * decoded as if nothing had been hinted.  rcgpu_ffv1_decoder_decode_host drops a hinted batch; decode_device must not be called
+ * while one is in flight. */
+int  rcgpu_ffv1_decoder_decode_keep_hint(rcgpu_ffv1_decoder* dec, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n);
 int  rcgpu_ffv1_decoder_decode_keep_fd(rcgpu_ffv1_decoder* dec, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n);
 int  rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* dec, uint32_t slot, uint8_t* payload);
 int  rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* dec, const rcgpu_kept_file* files, uint32_t n, rcgpu_kept_verdict* verdicts);

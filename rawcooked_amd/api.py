@@ -127,6 +127,7 @@ SYMBOLS = {
     "rcgpu_analysis_host_batch": (C.c_int, [C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, _VP, _VP, _VP, C.c_int]),
     "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_decode_keep": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32]),
+    "rcgpu_ffv1_decoder_decode_keep_hint": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32]),
     "rcgpu_ffv1_decoder_decode_keep_fd": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32]),
     "rcgpu_ffv1_decoder_kept_to_host": (C.c_int, [_VP, C.c_uint32, _VP]),
     "rcgpu_ffv1_decoder_verify_kept": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
@@ -429,13 +430,22 @@ class Ffv1Decoder:
         _check(lib().rcgpu_ffv1_decoder_decode_host(self.h, pk, sz, n, op), "rcgpu_ffv1_decoder_decode_host")
         return [o.raw for o in outs]
 
-    def decode_keep(self, packets: list[bytes]) -> None:
-        """Decodes the packets; payload i stays on the device as slot i (rcgpu_ffv1_decoder_decode_keep)."""
-        n = len(packets)
-        keep = [C.create_string_buffer(p, len(p)) for p in packets]
-        pk = (_VP * n)(*[C.cast(k, _VP) for k in keep])
-        sz = (C.c_uint64 * n)(*[len(p) for p in packets])
-        _check(lib().rcgpu_ffv1_decoder_decode_keep(self.h, pk, sz, n), "rcgpu_ffv1_decoder_decode_keep")
+    class PacketBatch:
+        """Packets at addresses that stay put (what a mapped Matroska file gives the reference): for decode_keep_hint + decode_keep."""
+        def __init__(self, packets: list[bytes]):
+            self.n = len(packets)
+            self.keep = [C.create_string_buffer(p, len(p)) for p in packets]
+            self.pk = (_VP * self.n)(*[C.cast(k, _VP) for k in self.keep])
+            self.sz = (C.c_uint64 * self.n)(*[len(p) for p in packets])
+
+    def decode_keep(self, packets) -> None:
+        """Decodes the packets (a list of bytes or a PacketBatch); payload i stays on the device as slot i (rcgpu_ffv1_decoder_decode_keep)."""
+        b = packets if isinstance(packets, Ffv1Decoder.PacketBatch) else Ffv1Decoder.PacketBatch(packets)
+        _check(lib().rcgpu_ffv1_decoder_decode_keep(self.h, b.pk, b.sz, b.n), "rcgpu_ffv1_decoder_decode_keep")
+
+    def decode_keep_hint(self, batch) -> None:
+        """Starts decoding `batch` (a PacketBatch) ahead of the decode_keep that will ask for it (rcgpu_ffv1_decoder_decode_keep_hint)."""
+        _check(lib().rcgpu_ffv1_decoder_decode_keep_hint(self.h, batch.pk, batch.sz, batch.n), "rcgpu_ffv1_decoder_decode_keep_hint")
 
     def decode_keep_fd(self, fd: int, offsets: list[int], sizes: list[int]) -> None:
         """The same with the packets at `offsets` of the open file `fd` (rcgpu_ffv1_decoder_decode_keep_fd)."""

@@ -788,20 +788,29 @@ struct rcgpu_ffv1_decoder {
         std::vector<uint32_t> img_of, cmp_of;
         struct host_part { uint64_t mine, on_disk_size, before_size, head_diff, tail_diff; };   // what the host already knows of a comparison
         std::vector<host_part> part;
-    } kept[2];
+    } kept[3];
     int kept_cur = 0;
+    // A batch decoded AHEAD of its decode_keep call (rcgpu_ffv1_decoder_decode_keep_hint): by a thread of its own, into the set of slots that
+    // is neither the current one nor under verification, from a packet buffer and staging lanes of its own.  While it runs the caller hands
+    // out the current batch's frames and has them verified; nothing else may decode with this decoder until it is joined.
+    struct hint_t {
+        std::thread th; bool active = false; int set = -1, rc = 0;
+        std::vector<const uint8_t*> packets; std::vector<uint64_t> sizes;
+    } hint;
+    uint8_t* d_kept_in2 = nullptr; size_t kept_in2_cap = 0;
     size_t kept_stride = 0;
     uint8_t* d_kept_in = nullptr; size_t kept_in_cap = 0;       // the packets of a batch
     uint8_t* d_disk = nullptr; size_t disk_cap = 0;
     hipStream_t side_stream = nullptr, md5_stream = nullptr; hipEvent_t ev_tab = nullptr, ev_side = nullptr;
     uint8_t* h_edges = nullptr; size_t edges_cap = 0;          // pinned: the bytes before and after the payloads of a batch on their way up
-    stager up;
+    stager up, up2;                                            // up2: the hinted batch's
 };
 
 extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
 {
     if (!d) return;
     (void)hipSetDevice(d->cfg.device);
+    if (d->hint.active) { d->hint.th.join(); d->hint.active = false; }
     void* bufs[] = { d->d_const, d->d_pkt_ptrs, d->d_out_ptrs, d->d_sizes, d->d_slice_start, d->d_slice_len, d->d_states, d->d_planes, d->d_err, d->d_hdr };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (d->h_ptrs) (void)hipHostFree(d->h_ptrs);
@@ -810,14 +819,15 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
     if (d->dec_stream) { (void)hipStreamSynchronize(d->dec_stream); (void)hipStreamDestroy(d->dec_stream); }
     if (d->md5_stream) (void)hipStreamSynchronize(d->md5_stream);     // a verification begun and never ended
-    for (void* b : { (void*)d->d_kept_in, (void*)d->kept[0].d, (void*)d->kept[1].d, (void*)d->d_disk, (void*)d->kept[0].d_tab, (void*)d->kept[1].d_tab }) if (b) (void)hipFree(b);
+    for (void* b : { (void*)d->d_kept_in, (void*)d->d_kept_in2, (void*)d->kept[0].d, (void*)d->kept[1].d, (void*)d->kept[2].d, (void*)d->d_disk,
+                     (void*)d->kept[0].d_tab, (void*)d->kept[1].d_tab, (void*)d->kept[2].d_tab }) if (b) (void)hipFree(b);
     for (auto& k : d->kept) if (k.h_tab) (void)hipHostFree(k.h_tab);
     if (d->h_edges) (void)hipHostFree(d->h_edges);
     if (d->side_stream) (void)hipStreamDestroy(d->side_stream);
     if (d->md5_stream) (void)hipStreamDestroy(d->md5_stream);
     if (d->ev_tab) (void)hipEventDestroy(d->ev_tab);
     if (d->ev_side) (void)hipEventDestroy(d->ev_side);
-    d->up.release();
+    d->up.release(); d->up2.release();
     delete d;
 }
 
@@ -942,11 +952,14 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     return 0;
 }
 
+static void hint_join(rcgpu_ffv1_decoder* d, bool keep);
+
 extern "C" int rcgpu_ffv1_decoder_decode_host(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n,
                                               uint8_t* const* payloads)
 {
     clear_error();
     if (!d || !packets || !packet_sizes || !payloads) return fail(1, "ffv1 decoder: null argument");
+    hint_join(d, false);                                             // a batch decoded ahead uses this decoder's buffers: it is dropped
     if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
     HIP_TRY(hipSetDevice(d->cfg.device));
     const size_t out_bytes = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
@@ -1071,27 +1084,54 @@ hipError_t grow(uint8_t*& p, size_t& cap, size_t need)
 
 }  // namespace
 
+// joins the batch decoded ahead, if any; `keep` says whether its slots are wanted
+static void hint_join(rcgpu_ffv1_decoder* d, bool keep)
+{
+    if (!d->hint.active) return;
+    d->hint.th.join();
+    d->hint.active = false;
+    if (!keep) d->kept[d->hint.set].n = 0;
+}
+
+static int decode_keep_into(rcgpu_ffv1_decoder* d, int set, uint8_t*& d_in, size_t& d_in_cap, stager& lanes,
+                            const uint8_t* const* packets, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n);
+
 static int decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n)
 {
     if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
     HIP_TRY(hipSetDevice(d->cfg.device));
-    if (d->kept[d->kept_cur].pending) {                              // its files are still being hashed: this batch goes into the other set
-        if (d->kept[d->kept_cur ^ 1].pending) return fail(2, "ffv1 decoder: two batches wait for rcgpu_ffv1_decoder_verify_kept_end");
-        d->kept_cur ^= 1;
+    if (d->hint.active) {
+        // was this the batch that is being decoded ahead?  Then its slots become the current ones; else it is dropped and decoded anew
+        const bool same = packets && d->hint.packets.size() == n && std::equal(d->hint.packets.begin(), d->hint.packets.end(), packets) &&
+                          std::equal(d->hint.sizes.begin(), d->hint.sizes.end(), packet_sizes);
+        hint_join(d, same);
+        if (same && d->hint.rc == 0) { d->kept_cur = d->hint.set; return 0; }
+        d->kept[d->hint.set].n = 0;
     }
-    rcgpu_ffv1_decoder::kept_set& K = d->kept[d->kept_cur];
+    if (d->kept[d->kept_cur].pending) {                              // its files are still being hashed: this batch goes into another set
+        int other = -1;
+        for (int k = 0; k < 3; k++) if (!d->kept[k].pending) { other = k; break; }
+        if (other < 0) return fail(2, "ffv1 decoder: three batches wait for rcgpu_ffv1_decoder_verify_kept_end");
+        d->kept_cur = other;
+    }
+    return decode_keep_into(d, d->kept_cur, d->d_kept_in, d->kept_in_cap, d->up, packets, fd, offsets, packet_sizes, n);
+}
+
+static int decode_keep_into(rcgpu_ffv1_decoder* d, int set, uint8_t*& d_in, size_t& d_in_cap, stager& lanes,
+                            const uint8_t* const* packets, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n)
+{
+    rcgpu_ffv1_decoder::kept_set& K = d->kept[set];
     K.n = 0;
     const size_t out_bytes = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
     d->kept_stride = (size_t(RCGPU_KEPT_ROOM) * 2 + out_bytes + 255) & ~size_t(255);
     uint64_t in_total = 0;
     for (uint32_t i = 0; i < n; i++) in_total += (packet_sizes[i] + 255) & ~uint64_t(255);
     kept_clock clk;
-    uint8_t*& d_in = d->d_kept_in;
     // Sized for the decoder's largest batch at the first call: a buffer that grows later is freed and allocated anew, and an allocation that
     // follows a free of tens of GB waits for the driver to wipe them (measured: 2-3 s for the 39 GB of a 744-frame batch after a 256-frame
     // one, 1.4 ms for the same bytes on memory that was never used)
     const uint32_t most = std::max(n, d->cfg.max_batch);
-    HIP_TRY(grow(d_in, d->kept_in_cap, size_t(in_total / n + 1) * most * 17 / 16 + 256));
+    HIP_TRY(grow(d_in, d_in_cap, size_t(in_total / n + 1) * most * 17 / 16 + 256));
     HIP_TRY(grow(K.d, K.cap, d->kept_stride * most));
     clk.lap("decode_keep: device buffers", n);
     std::vector<up_item> up(n);
@@ -1105,7 +1145,7 @@ static int decode_keep(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, int
         off += (packet_sizes[i] + 255) & ~uint64_t(255);
     }
     {
-        const hipError_t he = upload_side_by_side(d->up, d->cfg.device, up);
+        const hipError_t he = upload_side_by_side(lanes, d->cfg.device, up);
         if (he == hipErrorFileNotFound) return fail(20, "ffv1 decoder: the file ends before a packet does");
         HIP_TRY(he);
         clk.lap("decode_keep: packets up", n);
@@ -1131,6 +1171,25 @@ extern "C" int rcgpu_ffv1_decoder_decode_keep_fd(rcgpu_ffv1_decoder* d, int fd, 
     return decode_keep(d, nullptr, fd, offsets, packet_sizes, n);
 }
 
+// The batch the caller will pass to its NEXT rcgpu_ffv1_decoder_decode_keep, started now on a thread of its own (rcgpu.h).
+extern "C" int rcgpu_ffv1_decoder_decode_keep_hint(rcgpu_ffv1_decoder* d, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n)
+{
+    clear_error();
+    if (!d || !packets || !packet_sizes) return fail(1, "ffv1 decoder: null argument");
+    if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
+    if (d->hint.active) return 0;                                   // one batch ahead, not two
+    int set = -1;
+    for (int k = 0; k < 3; k++) if (k != d->kept_cur && !d->kept[k].pending) { set = k; break; }
+    if (set < 0) return 0;                                          // no set of slots to spare: the batch is decoded when it is asked for
+    d->hint.packets.assign(packets, packets + n); d->hint.sizes.assign(packet_sizes, packet_sizes + n);
+    d->hint.set = set; d->hint.rc = 0; d->hint.active = true;
+    d->hint.th = std::thread([d, n] {
+        (void)hipSetDevice(d->cfg.device);
+        d->hint.rc = decode_keep_into(d, d->hint.set, d->d_kept_in2, d->kept_in2_cap, d->up2, d->hint.packets.data(), -1, nullptr, d->hint.sizes.data(), n);
+    });
+    return 0;
+}
+
 extern "C" int rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* d, uint32_t slot, uint8_t* payload)
 {
     clear_error();
@@ -1152,7 +1211,7 @@ extern "C" int rcgpu_ffv1_decoder_verify_kept_begin(rcgpu_ffv1_decoder* d, const
 {
     clear_error();
     if (!d || !files || !n) return fail(1, "ffv1 decoder: null argument");
-    if (d->kept[0].pending || d->kept[1].pending) return fail(2, "ffv1 decoder: a verification is waiting for rcgpu_ffv1_decoder_verify_kept_end");
+    if (d->kept[0].pending || d->kept[1].pending || d->kept[2].pending) return fail(2, "ffv1 decoder: a verification is waiting for rcgpu_ffv1_decoder_verify_kept_end");
     HIP_TRY(hipSetDevice(d->cfg.device));
     rcgpu_ffv1_decoder::kept_set& K = d->kept[d->kept_cur];
     const size_t P = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
@@ -1300,7 +1359,7 @@ extern "C" int rcgpu_ffv1_decoder_verify_kept_end(rcgpu_ffv1_decoder* d, rcgpu_k
 {
     clear_error();
     if (!d || !verdicts) return fail(1, "ffv1 decoder: null argument");
-    rcgpu_ffv1_decoder::kept_set* Kp = d->kept[0].pending ? &d->kept[0] : d->kept[1].pending ? &d->kept[1] : nullptr;
+    rcgpu_ffv1_decoder::kept_set* Kp = d->kept[0].pending ? &d->kept[0] : d->kept[1].pending ? &d->kept[1] : d->kept[2].pending ? &d->kept[2] : nullptr;
     if (!Kp) return fail(2, "ffv1 decoder: no verification was begun");
     rcgpu_ffv1_decoder::kept_set& K = *Kp;
     HIP_TRY(hipSetDevice(d->cfg.device));

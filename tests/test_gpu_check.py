@@ -232,6 +232,50 @@ def test_check_with_the_payloads_kept_on_the_device(built):
     enc.close(); dec.close()
 
 
+def test_a_batch_decoded_ahead(built):
+    """rcgpu_ffv1_decoder_decode_keep_hint: the next batch is decoded by a thread of the library's own while the caller has the current one
+    hashed and compared; the decode_keep that asks for exactly that batch adopts its slots, any other batch (or a failed hint) is decoded
+    as if nothing had been hinted, and three sets of slots go round: under verification, current, ahead."""
+    w, h, pixfmt, nh, nv, n = 320, 180, synth.PIX_RGB16_BE, 4, 4, 12
+    srcs = []
+    for i in range(n):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 16, "film", seed=90 + i), pixfmt, True)
+        srcs.append(pl)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=n)
+    packets = enc.encode_host(srcs)
+    enc.close()
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=4)
+    B = [api.Ffv1Decoder.PacketBatch(packets[k:k + 4]) for k in (0, 4, 8)]
+    files = lambda k: [{"slot": i, "before": b"pre", "after": b"post", "on_disk": b"pre" + srcs[k + i] + b"post"} for i in range(4)]
+    want = lambda k: [(hashlib.md5(b"pre" + srcs[k + i] + b"post").digest(), -1) for i in range(4)]
+    # the steady state of route C: batch k current, k+1 ahead, k-1 under verification
+    dec.decode_keep(B[0]); dec.decode_keep_hint(B[1])
+    assert [dec.kept_to_host(i, len(srcs[i])) for i in range(4)] == srcs[0:4]           # the current batch's slots, with the next one in flight
+    dec.verify_kept(files(0), begin_only=True)
+    dec.decode_keep(B[1])                                                                # adopted
+    dec.decode_keep_hint(B[2])                                                           # third set: batch 0 is still being hashed
+    assert dec.verify_kept_end() == want(0)
+    assert [dec.kept_to_host(i, len(srcs[4 + i])) for i in range(4)] == srcs[4:8]
+    dec.verify_kept(files(4), begin_only=True)
+    dec.decode_keep(B[2])
+    assert dec.verify_kept_end() == want(4)
+    assert dec.verify_kept(files(8)) == want(8)
+    # a hint for another batch than the one asked for next is dropped; so is one for a batch with a broken packet (and the error is the asker's)
+    dec.decode_keep_hint(B[0])
+    dec.decode_keep(B[1])
+    assert [dec.kept_to_host(i, len(srcs[4 + i])) for i in range(4)] == srcs[4:8]
+    bad = api.Ffv1Decoder.PacketBatch([packets[0], packets[1][:100] + bytes([packets[1][100] ^ 8]) + packets[1][101:]])
+    dec.decode_keep_hint(bad)
+    with pytest.raises(api.RcgpuError, match="undecodable"):
+        dec.decode_keep(bad)
+    dec.decode_keep_hint(B[2])
+    assert dec.decode_host(packets[0:2], len(srcs[0])) == srcs[0:2]                                    # decode_host drops the batch in flight
+    dec.decode_keep(B[2])
+    assert [dec.kept_to_host(i, len(srcs[8 + i])) for i in range(4)] == srcs[8:12]
+    dec.decode_keep_hint(B[0])                                                           # destroyed with a batch in flight
+    dec.close()
+
+
 @pytest.mark.parametrize("name", ["dpx_rgb16be_64x48", "dpx_rgb10be_50x38", "dpx_rgba12packed_50x38", "exr_rgb16_72x40"])
 def test_corrupted_packets_never_hang_or_fault(built, name):
     """Robustness of the device decoder: random byte flips, truncations and garbage tails in reference-blessed packets.  With slice
