@@ -231,6 +231,9 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
             r = run([exe, "--check", "seq.mkv"] + extra, d, env=dict(os.environ, **env), timeout=180)
             ok = r.returncode == 0 and OKL in r.stdout
             out[name] = {"value": round(count / r.seconds, 2), "frames": count, "seconds": round(r.seconds, 2), "verdict": OKL if ok else (r.stdout + r.stderr)[-200:]}
+            if not ok:
+                out[name]["returncode"] = r.returncode
+                print("bench: %s: exit status %s\n%s" % (name, r.returncode, "\n".join(ln for ln in (r.stdout + r.stderr).replace("\r", "\n").split("\n") if ln.strip() and "Time=" not in ln and "rcgpu kept" not in ln)[-1500:]), file=sys.stderr)
             if os.environ.get("RCGPU_TRACE_KEPT"):
                 import resource
                 ru = resource.getrusage(resource.RUSAGE_CHILDREN)
@@ -349,7 +352,8 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     cpu_rec = linked_rec = None
     if cpu:
         from rawcooked_amd import synth as _synth
-        linked_rec = linked_check_record(api, _synth, record, frames, d_packets, stride, sizes, width, height, pixfmt)
+        only = set(filter(None, os.environ.get("RCGPU_LINKED_VARIANTS", "").split(","))) or None      # (measuring: some of the variants only)
+        linked_rec = linked_check_record(api, _synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, variants=only)
         cpu_rec = reference_check_baseline(api, _synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, parallel=max(1, min(8, usable_cores() // 32)))
     torch.cuda.empty_cache()
     D = max(F, check_batch or args.check_batch)

@@ -339,6 +339,12 @@ int  rcgpu_ffv1_decoder_decode_keep(rcgpu_ffv1_decoder* dec, const uint8_t* cons
  * decoded as if nothing had been hinted.  rcgpu_ffv1_decoder_decode_host drops a hinted batch; decode_device must not be called
  * while one is in flight. */
 int  rcgpu_ffv1_decoder_decode_keep_hint(rcgpu_ffv1_decoder* dec, const uint8_t* const* packets, const uint64_t* packet_sizes, uint32_t n);
+/* The same for a caller whose pointers do not last (the reference maps its Matroska file anew every megabyte, Matroska.cpp:394-408): the
+ * packets by their place in the file, which the library maps for itself; and the adoption as a call of its own -- the caller knows
+ * whether the batch it is about to ask for is the one it hinted.  An error from _adopt (nothing hinted, or the hinted batch failed)
+ * leaves the caller to decode the batch with decode_keep. */
+int  rcgpu_ffv1_decoder_decode_keep_hint_file(rcgpu_ffv1_decoder* dec, const char* path, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n);
+int  rcgpu_ffv1_decoder_decode_keep_adopt(rcgpu_ffv1_decoder* dec);
 int  rcgpu_ffv1_decoder_decode_keep_fd(rcgpu_ffv1_decoder* dec, int fd, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n);
 int  rcgpu_ffv1_decoder_kept_to_host(rcgpu_ffv1_decoder* dec, uint32_t slot, uint8_t* payload);
 int  rcgpu_ffv1_decoder_verify_kept(rcgpu_ffv1_decoder* dec, const rcgpu_kept_file* files, uint32_t n, rcgpu_kept_verdict* verdicts);

@@ -128,6 +128,8 @@ SYMBOLS = {
     "rcgpu_ffv1_decoder_decode_host": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_decode_keep": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32]),
     "rcgpu_ffv1_decoder_decode_keep_hint": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64), C.c_uint32]),
+    "rcgpu_ffv1_decoder_decode_keep_hint_file": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32]),
+    "rcgpu_ffv1_decoder_decode_keep_adopt": (C.c_int, [_VP]),
     "rcgpu_ffv1_decoder_decode_keep_fd": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32]),
     "rcgpu_ffv1_decoder_kept_to_host": (C.c_int, [_VP, C.c_uint32, _VP]),
     "rcgpu_ffv1_decoder_verify_kept": (C.c_int, [_VP, _VP, C.c_uint32, _VP]),
@@ -446,6 +448,15 @@ class Ffv1Decoder:
     def decode_keep_hint(self, batch) -> None:
         """Starts decoding `batch` (a PacketBatch) ahead of the decode_keep that will ask for it (rcgpu_ffv1_decoder_decode_keep_hint)."""
         _check(lib().rcgpu_ffv1_decoder_decode_keep_hint(self.h, batch.pk, batch.sz, batch.n), "rcgpu_ffv1_decoder_decode_keep_hint")
+
+    def decode_keep_hint_file(self, path: str, offsets: list[int], sizes: list[int]) -> None:
+        """Starts decoding the packets at `offsets` of the file `path` ahead (rcgpu_ffv1_decoder_decode_keep_hint_file)."""
+        n = len(offsets)
+        _check(lib().rcgpu_ffv1_decoder_decode_keep_hint_file(self.h, path.encode(), (C.c_uint64 * n)(*offsets), (C.c_uint64 * n)(*sizes), n), "rcgpu_ffv1_decoder_decode_keep_hint_file")
+
+    def decode_keep_adopt(self) -> None:
+        """The batch decoded ahead becomes the current one (rcgpu_ffv1_decoder_decode_keep_adopt)."""
+        _check(lib().rcgpu_ffv1_decoder_decode_keep_adopt(self.h), "rcgpu_ffv1_decoder_decode_keep_adopt")
 
     def decode_keep_fd(self, fd: int, offsets: list[int], sizes: list[int]) -> None:
         """The same with the packets at `offsets` of the open file `fd` (rcgpu_ffv1_decoder_decode_keep_fd)."""

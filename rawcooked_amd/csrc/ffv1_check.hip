@@ -27,11 +27,13 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 #include <mutex>
 #include <cerrno>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include "ffv1_host.h"
@@ -798,6 +800,9 @@ struct rcgpu_ffv1_decoder {
         std::vector<const uint8_t*> packets; std::vector<uint64_t> sizes;
     } hint;
     uint8_t* d_kept_in2 = nullptr; size_t kept_in2_cap = 0;
+    // the library's own mapping of the file a batch is hinted from (decode_keep_hint_file): the reference maps its Matroska file anew every
+    // megabyte it advances (Matroska.cpp:394-408, FileIO.cpp:258-283), so its pointers do not outlive the call they are passed in
+    std::string map_path; const uint8_t* map_base = nullptr; size_t map_size = 0;
     size_t kept_stride = 0;
     uint8_t* d_kept_in = nullptr; size_t kept_in_cap = 0;       // the packets of a batch
     uint8_t* d_disk = nullptr; size_t disk_cap = 0;
@@ -828,6 +833,7 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     if (d->ev_tab) (void)hipEventDestroy(d->ev_tab);
     if (d->ev_side) (void)hipEventDestroy(d->ev_side);
     d->up.release(); d->up2.release();
+    if (d->map_base) (void)munmap(const_cast<uint8_t*>(d->map_base), d->map_size);
     delete d;
 }
 
@@ -1187,6 +1193,44 @@ extern "C" int rcgpu_ffv1_decoder_decode_keep_hint(rcgpu_ffv1_decoder* d, const 
         (void)hipSetDevice(d->cfg.device);
         d->hint.rc = decode_keep_into(d, d->hint.set, d->d_kept_in2, d->kept_in2_cap, d->up2, d->hint.packets.data(), -1, nullptr, d->hint.sizes.data(), n);
     });
+    return 0;
+}
+
+// The same with the packets named by their place in a file, which the library maps for itself (once per file, for the decoder's life).
+extern "C" int rcgpu_ffv1_decoder_decode_keep_hint_file(rcgpu_ffv1_decoder* d, const char* path, const uint64_t* offsets, const uint64_t* packet_sizes, uint32_t n)
+{
+    clear_error();
+    if (!d || !path || !offsets || !packet_sizes) return fail(1, "ffv1 decoder: null argument");
+    if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
+    if (d->hint.active) return 0;
+    if (d->map_path != path) {
+        if (d->map_base) { (void)munmap(const_cast<uint8_t*>(d->map_base), d->map_size); d->map_base = nullptr; d->map_size = 0; d->map_path.clear(); }
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return fail(20, "ffv1 decoder: cannot open %s", path);
+        struct stat st;
+        void* m = fstat(fd, &st) == 0 && st.st_size > 0 ? mmap(nullptr, size_t(st.st_size), PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;
+        close(fd);
+        if (m == MAP_FAILED) return fail(20, "ffv1 decoder: cannot map %s", path);
+        d->map_base = static_cast<const uint8_t*>(m); d->map_size = size_t(st.st_size); d->map_path = path;
+    }
+    std::vector<const uint8_t*> pk(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i] > d->map_size || packet_sizes[i] > d->map_size - offsets[i]) return fail(20, "ffv1 decoder: the file ends before a packet does");
+        pk[i] = d->map_base + offsets[i];
+    }
+    return rcgpu_ffv1_decoder_decode_keep_hint(d, pk.data(), packet_sizes, n);
+}
+
+// The batch decoded ahead becomes the current one (the caller has made sure it is the batch it wants); an error if there is none or it failed
+// -- the caller then decodes the batch with decode_keep as if nothing had been hinted.
+extern "C" int rcgpu_ffv1_decoder_decode_keep_adopt(rcgpu_ffv1_decoder* d)
+{
+    clear_error();
+    if (!d) return fail(1, "ffv1 decoder: null argument");
+    if (!d->hint.active) return fail(2, "ffv1 decoder: no batch was decoded ahead");
+    hint_join(d, true);
+    if (d->hint.rc) { d->kept[d->hint.set].n = 0; return fail(d->hint.rc, "ffv1 decoder: the batch decoded ahead failed"); }
+    d->kept_cur = d->hint.set;
     return 0;
 }
 
