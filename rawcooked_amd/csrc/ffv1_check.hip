@@ -1228,7 +1228,9 @@ extern "C" int rcgpu_ffv1_decoder_decode_keep_adopt(rcgpu_ffv1_decoder* d)
     clear_error();
     if (!d) return fail(1, "ffv1 decoder: null argument");
     if (!d->hint.active) return fail(2, "ffv1 decoder: no batch was decoded ahead");
+    kept_clock clk;
     hint_join(d, true);
+    clk.lap("decode_keep: waited for the batch decoded ahead", uint32_t(d->hint.packets.size()));
     if (d->hint.rc) { d->kept[d->hint.set].n = 0; return fail(d->hint.rc, "ffv1 decoder: the batch decoded ahead failed"); }
     d->kept_cur = d->hint.set;
     return 0;

@@ -456,6 +456,44 @@ def test_linked_reference_checks_in_batches(built, linkedbin, refbin, tmp_path, 
     assert "f_000006" in (r.stdout + r.stderr), r.stdout + r.stderr
 
 
+def test_linked_reference_decodes_one_batch_ahead(built, linkedbin, refbin, tmp_path, monkeypatch):
+    """Route C one batch ahead: once the first frame has told the batch size, the demuxer announces the batch after the current one too and
+    ffv1_frame::Process has the decoder start on it (rcgpu_ffv1_decoder_decode_keep_hint_file, by the blocks' places in the file: frames of
+    1.8 MB make the reference map its file anew between the hint and the batch's turn, Matroska.cpp:394-408) and adopts it when its turn
+    comes.  Same verdicts as with RCGPU_CHECK_AHEAD=0, for a package that checks and for one with a broken frame in a batch that was
+    decoded ahead; the trace says that batches were adopted."""
+    work = str(tmp_path)
+    n = 14
+    make_package(work, 640, 480, synth.PIX_RGB16_BE, n, "film")
+    monkeypatch.setenv("RCGPU_CHECK_BATCH", "3")
+    r = run([linkedbin, "--no-check-padding", "--check", "--hash", "-y", "pkg"], work, timeout=120)
+    assert r.returncode == 0 and OK_LINE in r.stdout and "Error" not in (r.stdout + r.stderr), r.stdout + r.stderr
+    monkeypatch.setenv("RCGPU_TRACE_KEPT", "1")
+    r = run([linkedbin, "--check", "pkg.mkv"], work, timeout=120)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    assert r.stderr.count("waited for the batch decoded ahead") >= 2, r.stderr       # batches 3, 4 and 5 of 3 + 3 + 3 + 3 + 2
+    monkeypatch.setenv("RCGPU_CHECK_AHEAD", "0")
+    r0 = run([linkedbin, "--check", "pkg.mkv"], work, timeout=120)
+    assert r0.returncode == 0 and OK_LINE in r0.stdout and "decoded ahead" not in r0.stderr, r0.stdout + r0.stderr
+    monkeypatch.delenv("RCGPU_TRACE_KEPT")
+    # a flipped bit inside the 9th video block (third batch: decoded ahead): that frame's error, with or without the look-ahead
+    import mkv_validator
+    blocks = []
+    mkv_validator.validate(os.path.join(work, "pkg.mkv"), on_block=lambda trk, t, a, b: blocks.append((trk, a, b)))
+    video = [(a, b) for trk, a, b in blocks if trk == 1]
+    data = bytearray(open(os.path.join(work, "pkg.mkv"), "rb").read())
+    a, b = video[8]
+    data[(a + b) // 2] ^= 0x04
+    open(os.path.join(work, "pkg.mkv"), "wb").write(data)
+
+    def verdict(r):
+        return r.returncode != 0 or "Error" in (r.stdout + r.stderr), sorted(set(ln.strip() for ln in (r.stdout + r.stderr).replace("\r", "\n").split("\n") if "f_0000" in ln))
+    bad0 = verdict(run([linkedbin, "--check", "pkg.mkv"], work, timeout=120))
+    monkeypatch.delenv("RCGPU_CHECK_AHEAD")
+    bad1 = verdict(run([linkedbin, "--check", "pkg.mkv"], work, timeout=120))
+    assert bad0[0] and bad1 == bad0 and any("f_000008" in ln for ln in bad1[1]), (bad0, bad1)
+
+
 def test_linked_reference_judges_whole_batches_on_the_device(built, linkedbin, refbin, tmp_path, monkeypatch):
     """Route C with the payloads staying on the device (oracle/route_c_filewriter_cpp.patch): frame_writer::FrameCall lets every rebuilt
     file wait for the rest of its batch, and the batch is hashed and compared with the files on disk by rcgpu_ffv1_decoder_verify_kept.
