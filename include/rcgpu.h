@@ -219,6 +219,10 @@ typedef struct {
     uint8_t* (*place_packet)(void* user, uint64_t frame, size_t size);                         /* one thread, frame order; optional */
     int      (*packet_done)(void* user, uint64_t frame, const uint8_t* data, size_t size);     /* writer threads, concurrent */
     void* user;
+    /* optional, INSTEAD of read_frame (which is then NULL): the frame's payload lies in PINNED host memory already (hipHostMalloc /
+     * hipHostRegister) and stays there until its batch has been modelled; it is uploaded from where it is -- no upload slots, no reader
+     * threads, no copy.  SURVEY.md 8d's "inputs resident in pinned host memory, H2D included". */
+    const uint8_t* (*locate_frame)(void* user, uint64_t frame, size_t payload_bytes);
 } rcgpu_sequence_io;
 typedef struct {
     int device_first, device_count;     /* 0 devices = all visible */
@@ -231,6 +235,8 @@ typedef struct {
     uint32_t device_aliases;            /* test hook, 0 or 1 = off: k > 1 presents every physical device k times to device_first / device_count, so
                                            that the lane-per-device path (one encoder, ring and set of copy streams per device, one placer across
                                            them) runs on a box with a single GPU; the lanes then share its memory -- pass `batch` */
+    uint32_t frames_pinned;             /* rcgpu_ffv1_encode_sequence_memory only: 1 = frames[] point into pinned host memory: they are uploaded from
+                                           there (locate_frame instead of read_frame) */
     uint32_t numa;                      /* 0 = automatic: lanes are grouped by the NUMA node their device hangs on (hipDeviceGetPCIBusId ->
                                            /sys/bus/pci/devices/<id>/numa_node); each group has its own pinned upload slots, reader and writer threads,
                                            all bound to the node's CPUs, and every lane's download ring is allocated there -- a lane moves ~118 GB/s

@@ -29,6 +29,9 @@ struct pipe_frame { uint32_t video; uint64_t index; };     // a frame of `video`
 struct pipe_io {
     // reader threads, concurrently, any order: put the payload of `f` (payload_bytes of its video) at dst (pinned).  0 = ok.
     std::function<int(const pipe_frame& f, uint8_t* dst)> read;
+    // optional, instead of read: the payload of `f` lies in PINNED host memory already (hipHostMalloc / hipHostRegister) and stays there
+    // until its batch has been modelled -- it is uploaded from where it is: no upload slots, no reader threads, no copy.  nullptr = error.
+    std::function<const uint8_t*(const pipe_frame& f)> locate;
     // one thread, output order: where do the `size` bytes of this packet go?  nullptr = "hand them to done()"
     std::function<uint8_t*(const pipe_frame& f, size_t size)> place;
     // writer threads, concurrently: the packet is at `data` (== the place, or a pinned buffer valid during the call).  0 = ok.

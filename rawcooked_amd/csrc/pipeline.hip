@@ -396,6 +396,7 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
         G.readers = std::max<uint32_t>(1, readers * G.lanes / uint32_t(nl));
         G.writers = std::max<uint32_t>(1, writers * G.lanes / uint32_t(nl));
         G.slots_wanted = std::max<size_t>(std::min<size_t>(N, 2), slots_total * G.lanes / size_t(nl));
+        if (io.locate) { G.readers = 0; G.slots_wanted = 0; }          // the payloads are uploaded from where they lie
         G.frames.clear(); G.next_read = 0; G.jobs.clear(); G.reads_done = 0;
     }
     for (const batch_t& b : batches) { impl::group_t& G = s.groups[size_t(s.lanes[size_t(b.lane)].group)]; for (size_t k = 0; k < b.n; k++) G.frames.push_back(b.first + k); }
@@ -558,6 +559,17 @@ int pipeline::run(const std::vector<pipe_frame>& frames, const pipe_io& io, pipe
             return true;
         };
         auto upload_one = [&](const batch_t& B, const enc_staging& sg, size_t k) -> bool {
+            if (io.locate) {
+                // from the caller's pinned memory, groups of copies dealt to the copy streams in turn; the batch's last copy is followed by
+                // ev_up (transfers below), nothing is to be given back
+                const uint8_t* src = io.locate(frames[B.first + k]);
+                if (!src) { s.set_error(21, *rcgpu_last_error() ? rcgpu_last_error() : "pipeline: a frame could not be located"); return false; }
+                const auto tc = clk::now();
+                hipStream_t cs = L.cin[(k / kUploadGroup) % L.cin.size()];
+                if (!hip_ok(hipMemcpyAsync(sg.d_in + k * sg.in_stride, src, sg.payload_bytes, hipMemcpyHostToDevice, cs), "upload")) return false;
+                L.copy_calls += since(tc);
+                return true;
+            }
             uint8_t* slot = nullptr;
             size_t ugroup_max = 1;
             {
@@ -858,7 +870,7 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
 {
     using namespace rc;
     clear_error();
-    if (!cfg || !io || !io->read_frame || !io->packet_done) return fail(1, "sequence: null argument");
+    if (!cfg || !io || (!io->read_frame && !io->locate_frame) || !io->packet_done) return fail(1, "sequence: null argument");
     pipe_video v; v.cfg = *cfg; v.frames = n_frames;
     pipe_options po;
     if (opt) { po.device_first = opt->device_first; po.device_count = opt->device_count; po.readers = opt->readers; po.writers = opt->writers;
@@ -877,7 +889,8 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
     for (uint64_t i = 0; i < n_frames; i++) frames[i] = { 0, i };
     const size_t payload = size_t(payload_bytes(cfg->pixfmt, cfg->width, cfg->height, cfg->line_bytes, cfg->flags));
     pipe_io pio;
-    pio.read = [&](const pipe_frame& f, uint8_t* dst) { return io->read_frame(io->user, f.index, dst, payload); };
+    if (io->read_frame) pio.read = [&](const pipe_frame& f, uint8_t* dst) { return io->read_frame(io->user, f.index, dst, payload); };
+    if (io->locate_frame) pio.locate = [&](const pipe_frame& f) { return io->locate_frame(io->user, f.index, payload); };
     if (io->place_packet) pio.place = [&](const pipe_frame& f, size_t size) { return io->place_packet(io->user, f.index, size); };
     pio.done = [&](const pipe_frame& f, const uint8_t* data, size_t size) { return io->packet_done(io->user, f.index, data, size); };
     pipe_stats ps;
@@ -923,6 +936,11 @@ int memory_read(void* user, uint64_t frame, uint8_t* dst, size_t bytes)
     memcpy(dst, m->frames[frame % m->n_in], bytes);
     return 0;
 }
+const uint8_t* memory_locate(void* user, uint64_t frame, size_t)
+{
+    const memory_io* m = static_cast<const memory_io*>(user);
+    return m->frames[frame % m->n_in];
+}
 int memory_done(void* user, uint64_t frame, const uint8_t* data, size_t size)
 {
     const memory_io* m = static_cast<const memory_io*>(user);
@@ -941,6 +959,7 @@ extern "C" int rcgpu_ffv1_encode_sequence_memory(const rcgpu_ffv1_config* cfg, c
     rc::clear_error();
     if (!cfg || !frames || !n_in) return rc::fail(1, "sequence: null argument");
     memory_io m{ frames, n_in, out, n_out, out_cap, sizes };
-    rcgpu_sequence_io io{ memory_read, nullptr, memory_done, &m };
+    rcgpu_sequence_io io{ memory_read, nullptr, memory_done, &m, nullptr };
+    if (opt && opt->frames_pinned) { io.read_frame = nullptr; io.locate_frame = memory_locate; }
     return rcgpu_ffv1_encode_sequence(cfg, n_frames, &io, opt, stats, record, record_size);
 }

@@ -138,6 +138,28 @@ def test_sequence_memory_host_buffers_in_and_out():
         api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], 4, [a.ctypes.data for a in outs], 64, batch=2)
 
 
+@pytest.mark.parametrize("lanes,aliases", [(1, 0), (2, 0), (1, 2)])
+def test_sequence_memory_from_pinned_frames(lanes, aliases):
+    """rcgpu_sequence_options::frames_pinned (locate_frame in place of read_frame): the caller's frames are page-locked and the pipeline
+    uploads from them -- no upload slots, no reader threads ("inputs resident in pinned host memory, H2D included").
+    Same packets as from pageable frames, with one lane, two lanes on a device and a lane on each of two (aliased) devices."""
+    import numpy as np
+    import torch
+    w, h, pixfmt, n_in, n = 160, 90, synth.PIX_RGB16_BE, 7, 45
+    payloads, line_bytes = _sequence(w, h, pixfmt, n_in)
+    pins = [torch.frombuffer(bytearray(p), dtype=torch.uint8).pin_memory() for p in payloads]
+    out_cap = len(payloads[0]) * 2
+    outs = [np.zeros(out_cap, dtype=np.uint8) for _ in range(n)]
+    cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 3, 2, 1, 1, 0, 0, 0, 0, 1, 3)
+    st, sizes = api.encode_sequence_memory(cfg, [t.data_ptr() for t in pins], n, [a.ctypes.data for a in outs], out_cap, batch=6, frames_pinned=1,
+                                           lanes_per_device=lanes, device_aliases=aliases, device_count=2 if aliases else 0)
+    assert st.frames == n and st.readers == 0 and st.packet_bytes == sum(sizes)
+    p = ob.Params(w, h, pixfmt, 3, 2, 1, 1)
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
+    for i in range(n):
+        assert bytes(outs[i][:sizes[i]]) == want[i % n_in], f"packet {i}"
+
+
 @pytest.mark.parametrize("lanes,n,batch", [(2, 41, 6), (3, 50, 4), (4, 9, 8)])
 def test_several_lanes_return_packets_in_frame_order(lanes, n, batch):
     """Several encoder instances ("lanes") whose batches run staggered -- on one device here, one per device on a multi-GPU node: batch b
