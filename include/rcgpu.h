@@ -192,6 +192,7 @@ int rcgpu_ffv1_encode_device(rcgpu_ffv1* enc, const void* const* d_frames, uint3
  * read them); consecutive batches get different d_packets / d_packet_sizes if the caller reads them in between.  Costs a second set
  * of per-batch buffers (symbols, states, coder output: rcgpu_ffv1_set_run_on fails if they do not fit); same packets, byte for byte. */
 int rcgpu_ffv1_set_run_on(rcgpu_ffv1* enc, int on);
+int rcgpu_ffv1_run_on(const rcgpu_ffv1* enc);                 /* 1 when the mode is on */
 /* Makes `hip_stream` wait for every batch issued so far (the last one, in run-on mode). */
 int rcgpu_ffv1_join(rcgpu_ffv1* enc, void* hip_stream);
 
@@ -237,6 +238,8 @@ typedef struct {
                                            them) runs on a box with a single GPU; the lanes then share its memory -- pass `batch` */
     uint32_t frames_pinned;             /* rcgpu_ffv1_encode_sequence_memory only: 1 = frames[] point into pinned host memory: they are uploaded from
                                            there (locate_frame instead of read_frame) */
+    uint32_t run_on;                    /* 0 = automatic: the encoders run on from batch to batch (rcgpu_ffv1_set_run_on) where the device has room for
+                                           their second bank; 1 = one batch at a time */
     uint32_t numa;                      /* 0 = automatic: lanes are grouped by the NUMA node their device hangs on (hipDeviceGetPCIBusId ->
                                            /sys/bus/pci/devices/<id>/numa_node); each group has its own pinned upload slots, reader and writer threads,
                                            all bound to the node's CPUs, and every lane's download ring is allocated there -- a lane moves ~118 GB/s

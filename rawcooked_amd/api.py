@@ -54,7 +54,7 @@ class SequenceIo(C.Structure):
 class SequenceOptions(C.Structure):
     _fields_ = [("device_first", C.c_int), ("device_count", C.c_int), ("batch", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
                 ("in_ring_frames", C.c_uint32), ("out_ring_bytes", C.c_uint64), ("lanes_per_device", C.c_uint32),
-                ("copy_streams", C.c_uint32), ("device_aliases", C.c_uint32), ("frames_pinned", C.c_uint32), ("numa", C.c_uint32)]
+                ("copy_streams", C.c_uint32), ("device_aliases", C.c_uint32), ("frames_pinned", C.c_uint32), ("run_on", C.c_uint32), ("numa", C.c_uint32)]
 
 
 class SequenceStats(C.Structure):
@@ -359,7 +359,7 @@ def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, pla
     pd = PACKET_DONE_FN(lambda user, frame, data, n: int(packet_done(frame, data, n) or 0))
     pp = PLACE_PACKET_FN(lambda user, frame, n: place_packet(frame, n) or 0) if place_packet else PLACE_PACKET_FN()
     io = SequenceIo(rf, pp, pd, None)
-    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes, lanes_per_device, copy_streams, device_aliases, 0, numa)
+    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes, lanes_per_device, copy_streams, device_aliases, 0, 0, numa)
     st = SequenceStats()
     rec = C.create_string_buffer(8192)
     rs = _SZ(8192)
@@ -368,12 +368,12 @@ def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, pla
 
 
 def encode_sequence_memory(cfg: Ffv1Config, frame_addrs: list[int], n_frames: int, out_addrs: list[int], out_cap: int, batch=0, readers=0, writers=0,
-                           device_first=0, device_count=0, lanes_per_device=0, in_ring_frames=0, copy_streams=0, device_aliases=0, numa=0, frames_pinned=0):
+                           device_first=0, device_count=0, lanes_per_device=0, in_ring_frames=0, copy_streams=0, device_aliases=0, numa=0, frames_pinned=0, run_on=0):
     """rcgpu_ffv1_encode_sequence_memory: frame i = frame_addrs[i % len], packet i -> out_addrs[i % len].  Returns (stats, sizes)."""
     fin = (_VP * len(frame_addrs))(*frame_addrs)
     fout = (_VP * len(out_addrs))(*out_addrs) if out_addrs else None
     sizes = (C.c_uint64 * n_frames)()
-    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, 0, lanes_per_device, copy_streams, device_aliases, frames_pinned, numa)
+    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, 0, lanes_per_device, copy_streams, device_aliases, frames_pinned, run_on, numa)
     st = SequenceStats()
     _check(lib().rcgpu_ffv1_encode_sequence_memory(C.byref(cfg), fin, len(frame_addrs), n_frames, fout, len(out_addrs), out_cap, sizes, C.byref(opt), C.byref(st), None, None),
            "rcgpu_ffv1_encode_sequence_memory")

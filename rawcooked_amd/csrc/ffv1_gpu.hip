@@ -1429,7 +1429,7 @@ struct rcgpu_ffv1 {
     hipStream_t model_stream = nullptr, front_stream = nullptr, tail_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_model = nullptr;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
-    uint32_t last_n = 0;
+    uint32_t last_n = 0, prev_n = 0;
     hipEvent_t gather_wait = nullptr;              // pipeline: k_gather of the next batch waits for the previous batch's download
     bool defer_gather = false;                     // pipeline: encode_device stops after k_scan, ffv1_gather() follows later
     size_t in_stride = 0;
@@ -1667,7 +1667,6 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     static const bool exp_serial = TIMING_ENV("RCGPU_EXP_SERIAL") != nullptr;      // timing runs: every kernel alone on the device, one after the other
     if (exp_serial) s2 = st;
     // run-on mode: this batch goes into the other bank; modelling, resolving and the batch's tail get streams of their own (see rcgpu_ffv1)
-    if (e->run_on && e->defer_gather) return fail(2, "ffv1: run-on mode and the pipeline's deferred gather exclude each other (a gather issued later would find its bank reused)");
     const bool ro = e->run_on && !exp_serial && !e->span_pieces && !e->exp_skip_rc;
     if (ro) {
 #define SW(f) std::swap(e->f, e->alt.f)
@@ -1839,7 +1838,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     if (!ro) { HIP_TRY(hipStreamWaitEvent(st, e->ev_done, 0)); e->joined = true; }
     if (e->alt.used && !e->alt.joined) { HIP_TRY(hipStreamWaitEvent(st, e->alt.ev_done, 0)); e->alt.joined = true; }
     HIP_TRY(hipGetLastError());
-    e->ev_valid = true; e->last_n = n;
+    e->ev_valid = true; e->prev_n = e->last_n; e->last_n = n;
     return 0;
 }
 
@@ -1887,6 +1886,8 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
 }
 
 // Makes `hip_stream` wait for every batch issued so far (run-on mode leaves the last one unjoined).
+extern "C" int rcgpu_ffv1_run_on(const rcgpu_ffv1* e) { return e && e->run_on ? 1 : 0; }
+
 extern "C" int rcgpu_ffv1_join(rcgpu_ffv1* e, void* hip_stream)
 {
     clear_error();
@@ -1901,22 +1902,30 @@ extern "C" int rcgpu_ffv1_join(rcgpu_ffv1* e, void* hip_stream)
 namespace rc {
 void ffv1_set_defer_gather(rcgpu_ffv1* e, bool on) { if (e) e->defer_gather = on; }
 
-int ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream)
+// prev: in run-on mode, the batch BEFORE the one issued last (the pipeline issues batch k+1 while batch k is coded, then gathers batch k):
+// its buffers are the other bank's, its frame count prev_n.  The bank's next user waits for ev_done, which is therefore recorded again
+// behind the gather.
+int ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream, bool prev)
 {
     if (!e || !d_packets || !e->ev_valid) return fail(1, "ffv1: gather without a batch");
+    if (prev && !(e->run_on && e->alt.used)) return fail(1, "ffv1: gather of the previous batch without one");
     if (packet_stride < e->max_packet || (packet_stride & 3)) return fail(2, "ffv1: packet_stride must be a multiple of 4 and >= %zu", e->max_packet);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    const uint32_t nchains = e->last_n * e->hc.S;
+    const uint32_t nchains = (prev ? e->prev_n : e->last_n) * e->hc.S;
     if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(st, e->gather_wait, 0)); e->gather_wait = nullptr; }
-    const bool ev_room = e->ev_used + 2 <= e->ev.size();
+    hipEvent_t done = prev ? e->alt.ev_done : e->ev_done;
+    if (e->run_on) { HIP_TRY(hipStreamWaitEvent(st, done, 0)); (prev ? e->alt.joined : e->joined) = true; }      // footer and scan ran on the tail stream
+    const bool ev_room = !prev && e->ev_used + 2 <= e->ev.size();      // (the timing events of the previous call have been handed over to ev_prev)
     if (ev_room) HIP_TRY(hipEventRecord(e->ev[e->ev_used], st));
-    hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
-                       e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride);
+    hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, st, e->d_const, e->d_geom, prev ? e->alt.d_cbuf : e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+                       prev ? e->alt.d_tot_len : e->d_tot_len, prev ? e->alt.d_slice_dst : e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride);
     if (ev_room) { HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st)); e->ev_used += 2; e->ev_kernel.push_back(6); }
+    if (e->run_on) HIP_TRY(hipEventRecord(done, st));
     HIP_TRY(hipGetLastError());
     return 0;
 }
+uint32_t* ffv1_err_word(rcgpu_ffv1* e, bool prev) { return !e ? nullptr : prev ? e->alt.d_err : e->d_err; }
 }  // namespace rc
 
 // Sum of the device time of every launch of each kernel in the last encode call (HIP events on the launch stream).
@@ -2009,7 +2018,7 @@ int ffv1_staging(rcgpu_ffv1* e, enc_staging* out)
         e->in_stride = (e->frame_payload + 255) & ~size_t(255);
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_in), e->in_stride * F));
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_packets), e->max_packet * F));
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_psizes), 8 * F));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_psizes), 2 * 8 * F));          // two batches' worth: the pipeline alternates
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->h_psizes), 8 * F));
     }
     out->d_in = e->d_in; out->in_stride = e->in_stride; out->payload_bytes = e->frame_payload;
