@@ -1024,9 +1024,9 @@ def main():
     torch.cuda.empty_cache()
 
     if "host" in legs:
-        # the encoder above has just given some 200 GB back, which the driver wipes in the background: the leg starts on an idle device, as
-        # the product legs below do
-        time.sleep(float(os.environ.get("RCGPU_BENCH_E2E_IDLE", "4")))
+        # the encoder above has just given some 200 GB back, which the driver wipes in the background (measured: an allocation behind a free
+        # of 39 GB waits 3 s): the leg starts on an idle device, as the product legs below do
+        time.sleep(max(10.0, float(os.environ.get("RCGPU_BENCH_E2E_IDLE", "4"))))
         if os.environ.get("RCGPU_DMA_NOISE_HOST"):       # experiment: the copy pump beside the host pipeline -- do the engines have room?
             stop.clear(); moved[0] = 0; t_noise = time.perf_counter()
             noise = threading.Thread(target=pump); noise.start()
