@@ -238,8 +238,8 @@ typedef struct {
                                            them) runs on a box with a single GPU; the lanes then share its memory -- pass `batch` */
     uint32_t frames_pinned;             /* rcgpu_ffv1_encode_sequence_memory only: 1 = frames[] point into pinned host memory: they are uploaded from
                                            there (locate_frame instead of read_frame) */
-    uint32_t run_on;                    /* 0 = automatic: the encoders run on from batch to batch (rcgpu_ffv1_set_run_on) where the device has room for
-                                           their second bank; 1 = one batch at a time */
+    uint32_t run_on;                    /* 1 = the encoders run on from batch to batch (rcgpu_ffv1_set_run_on) where the device has room for their second
+                                           bank; 0 = one batch at a time (the pipeline is paced by its transfers: measured +0.5 % for 75 GB) */
     uint32_t numa;                      /* 0 = automatic: lanes are grouped by the NUMA node their device hangs on (hipDeviceGetPCIBusId ->
                                            /sys/bus/pci/devices/<id>/numa_node); each group has its own pinned upload slots, reader and writer threads,
                                            all bound to the node's CPUs, and every lane's download ring is allocated there -- a lane moves ~118 GB/s

@@ -1429,7 +1429,8 @@ struct rcgpu_ffv1 {
     hipStream_t model_stream = nullptr, front_stream = nullptr, tail_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_model = nullptr;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
-    uint32_t last_n = 0, prev_n = 0;
+    uint32_t last_n = 0;
+    hipEvent_t input_event = nullptr;              // pipeline, run-on mode: the next batch's frames are on the device when this event has happened
     hipEvent_t gather_wait = nullptr;              // pipeline: k_gather of the next batch waits for the previous batch's download
     bool defer_gather = false;                     // pipeline: encode_device stops after k_scan, ffv1_gather() follows later
     size_t in_stride = 0;
@@ -1674,12 +1675,15 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         SW(d_cbuf); SW(d_out_len); SW(d_tot_len); SW(d_slice_dst); SW(d_err); SW(d_events); SW(ev_done); SW(used); SW(joined);
 #undef SW
     }
+    if (!ro) e->input_event = nullptr;                   // (one batch at a time: everything follows the caller's stream anyway)
     hipStream_t ms = ro ? e->model_stream : st;          // k_model and the tables
     hipStream_t fr = ro ? e->front_stream : st;          // k_resolve
     hipStream_t tl = ro ? e->tail_stream : s2;           // footer, scan, gather
     if (ro) {
-        HIP_TRY(hipEventRecord(e->ev_in, st));                                       // the caller's frames are ready
-        HIP_TRY(hipStreamWaitEvent(ms, e->ev_in, 0));
+        // the caller's frames are ready: behind everything on its stream so far -- or behind the event it named (ffv1_set_input_event:
+        // the pipeline's stream carries the previous batch's gather, which must not hold this batch's modelling up)
+        if (e->input_event) { HIP_TRY(hipStreamWaitEvent(ms, e->input_event, 0)); e->input_event = nullptr; }
+        else { HIP_TRY(hipEventRecord(e->ev_in, st)); HIP_TRY(hipStreamWaitEvent(ms, e->ev_in, 0)); }
         if (e->used) HIP_TRY(hipStreamWaitEvent(ms, e->ev_done, 0));                 // the batch before the last, whose bank this is, is finished
     }
     const enc_const& c = e->hc;
@@ -1838,7 +1842,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     if (!ro) { HIP_TRY(hipStreamWaitEvent(st, e->ev_done, 0)); e->joined = true; }
     if (e->alt.used && !e->alt.joined) { HIP_TRY(hipStreamWaitEvent(st, e->alt.ev_done, 0)); e->alt.joined = true; }
     HIP_TRY(hipGetLastError());
-    e->ev_valid = true; e->prev_n = e->last_n; e->last_n = n;
+    e->ev_valid = true; e->last_n = n;
     return 0;
 }
 
@@ -1902,30 +1906,26 @@ extern "C" int rcgpu_ffv1_join(rcgpu_ffv1* e, void* hip_stream)
 namespace rc {
 void ffv1_set_defer_gather(rcgpu_ffv1* e, bool on) { if (e) e->defer_gather = on; }
 
-// prev: in run-on mode, the batch BEFORE the one issued last (the pipeline issues batch k+1 while batch k is coded, then gathers batch k):
-// its buffers are the other bank's, its frame count prev_n.  The bank's next user waits for ev_done, which is therefore recorded again
-// behind the gather.
-int ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream, bool prev)
+// In run-on mode the batch's footer and scan ran on the tail stream: the caller's stream waits for them first, and the bank's next user
+// waits for ev_done, which is therefore recorded again behind the gather.
+int ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream)
 {
     if (!e || !d_packets || !e->ev_valid) return fail(1, "ffv1: gather without a batch");
-    if (prev && !(e->run_on && e->alt.used)) return fail(1, "ffv1: gather of the previous batch without one");
     if (packet_stride < e->max_packet || (packet_stride & 3)) return fail(2, "ffv1: packet_stride must be a multiple of 4 and >= %zu", e->max_packet);
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    const uint32_t nchains = (prev ? e->prev_n : e->last_n) * e->hc.S;
+    const uint32_t nchains = e->last_n * e->hc.S;
     if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(st, e->gather_wait, 0)); e->gather_wait = nullptr; }
-    hipEvent_t done = prev ? e->alt.ev_done : e->ev_done;
-    if (e->run_on) { HIP_TRY(hipStreamWaitEvent(st, done, 0)); (prev ? e->alt.joined : e->joined) = true; }      // footer and scan ran on the tail stream
-    const bool ev_room = !prev && e->ev_used + 2 <= e->ev.size();      // (the timing events of the previous call have been handed over to ev_prev)
+    if (e->run_on) { HIP_TRY(hipStreamWaitEvent(st, e->ev_done, 0)); e->joined = true; }
+    const bool ev_room = e->ev_used + 2 <= e->ev.size();
     if (ev_room) HIP_TRY(hipEventRecord(e->ev[e->ev_used], st));
-    hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, st, e->d_const, e->d_geom, prev ? e->alt.d_cbuf : e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
-                       prev ? e->alt.d_tot_len : e->d_tot_len, prev ? e->alt.d_slice_dst : e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride);
+    hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+                       e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride);
     if (ev_room) { HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st)); e->ev_used += 2; e->ev_kernel.push_back(6); }
-    if (e->run_on) HIP_TRY(hipEventRecord(done, st));
+    if (e->run_on) HIP_TRY(hipEventRecord(e->ev_done, st));
     HIP_TRY(hipGetLastError());
     return 0;
 }
-uint32_t* ffv1_err_word(rcgpu_ffv1* e, bool prev) { return !e ? nullptr : prev ? e->alt.d_err : e->d_err; }
 }  // namespace rc
 
 // Sum of the device time of every launch of each kernel in the last encode call (HIP events on the launch stream).
@@ -2028,6 +2028,7 @@ int ffv1_staging(rcgpu_ffv1* e, enc_staging* out)
 }
 
 void ffv1_set_gather_wait(rcgpu_ffv1* e, void* hip_event) { if (e) e->gather_wait = static_cast<hipEvent_t>(hip_event); }
+void ffv1_set_input_event(rcgpu_ffv1* e, void* hip_event) { if (e) e->input_event = static_cast<hipEvent_t>(hip_event); }
 }  // namespace rc
 
 // Error word of the last batch: bit 0 a slice outgrew its byte buffer, bit 1 a slice does not fit its footer or the 24-bit size

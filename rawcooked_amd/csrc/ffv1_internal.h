@@ -28,9 +28,10 @@ void ffv1_set_gather_wait(rcgpu_ffv1* e, void* hip_event);
 // in their own buffers) and ffv1_gather() compacts them into the packets later, on the same stream.  The pipeline uses the gap to issue
 // the previous batch's downloads AFTER the next batch has been started: the device never waits for the host between two batches.
 void ffv1_set_defer_gather(rcgpu_ffv1* e, bool on);
-int  ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream, bool prev = false);
-// run-on mode (rcgpu_ffv1_set_run_on): `prev` = the batch before the one issued last, whose buffers are the encoder's other bank
-uint32_t* ffv1_err_word(rcgpu_ffv1* e, bool prev);
+int  ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_stream);
+// Run-on mode (rcgpu_ffv1_set_run_on): the next rcgpu_ffv1_encode_device models its batch as soon as this event (a hipEvent_t already
+// recorded: the frames' uploads) has happened, not behind everything the caller's stream carries -- the previous batch's gather is there.
+void ffv1_set_input_event(rcgpu_ffv1* e, void* hip_event);
 // The configuration record and the worst-case packet size of an encoder of this configuration, without a device (the container's header
 // can be written, and its file laid out, while the encoders are still being created).
 std::vector<uint8_t> ffv1_config_record_for(const rcgpu_ffv1_config& cfg);

@@ -362,10 +362,6 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         // files come through pread() out of the page cache or tmpfs at ~2 GB/s per thread (a memcpy between user buffers does 14): sixteen
         // readers per device instead of the pipeline's eight (measured on 1000 4K frames: all files read after 2.6 s instead of 3.2-4.2 s)
         po.readers = std::max(2u, std::min(std::max(2u, std::thread::hardware_concurrency()) / 2, 16u * unsigned(std::max(1, ndev))));
-        // a job runs at its output file's pace (one Matroska file: ~13 GB/s of page allocation on tmpfs), not the device's: the encoders'
-        // run-on mode would buy it nothing and cost it a second bank of device memory to allocate and to give back (measured: 8.97 instead
-        // of 8.1-8.3 s for 1000 4K frames)
-        po.run_on = 1;
         if (const char* e = getenv("RCGPU_READERS")) po.readers = uint32_t(std::max(1, atoi(e)));
         if (const char* e = getenv("RCGPU_WRITERS")) po.writers = uint32_t(std::max(1, atoi(e)));
         if (int r = pl.prepare(pvideos, po)) return bail(r);

@@ -53,7 +53,7 @@ struct pipe_options {
     uint32_t device_aliases = 0;                 // test hook: every physical device presented this many times (0, 1 = as they are)
     uint32_t copy_streams = 0;                   // copy streams per direction and lane; 0 = automatic (two)
     uint32_t numa = 0;                           // 0 = lanes grouped by their device's NUMA node, host threads and pinned memory bound to it; 1 = off; 2 = test hook
-    uint32_t run_on = 0;                         // 0 = the encoders run on from batch to batch where device memory allows (rcgpu_ffv1_set_run_on); 1 = one batch at a time
+    uint32_t run_on = 0;                         // 1 = the encoders run on from batch to batch where device memory allows (rcgpu_ffv1_set_run_on); 0 = one batch at a time
     bool trace = false;
 };
 
