@@ -138,11 +138,12 @@ def test_sequence_memory_host_buffers_in_and_out():
         api.encode_sequence_memory(cfg, [a.ctypes.data for a in src], 4, [a.ctypes.data for a in outs], 64, batch=2)
 
 
-@pytest.mark.parametrize("lanes,aliases", [(1, 0), (2, 0), (1, 2)])
-def test_sequence_memory_from_pinned_frames(lanes, aliases):
+@pytest.mark.parametrize("lanes,aliases,run_on", [(1, 0, 0), (2, 0, 0), (1, 2, 0), (1, 0, 1), (2, 0, 1), (1, 2, 1)])
+def test_sequence_memory_from_pinned_frames(lanes, aliases, run_on):
     """rcgpu_sequence_options::frames_pinned (locate_frame in place of read_frame): the caller's frames are page-locked and the pipeline
     uploads from them -- no upload slots, no reader threads ("inputs resident in pinned host memory, H2D included").
-    Same packets as from pageable frames, with one lane, two lanes on a device and a lane on each of two (aliased) devices."""
+    Same packets as from pageable frames, with one lane, two lanes on a device and a lane on each of two (aliased) devices -- and with the
+    encoders in run-on mode (rcgpu_sequence_options::run_on: batch k+1 modelled behind its uploads while batch k is coded)."""
     import numpy as np
     import torch
     w, h, pixfmt, n_in, n = 160, 90, synth.PIX_RGB16_BE, 7, 45
@@ -152,7 +153,7 @@ def test_sequence_memory_from_pinned_frames(lanes, aliases):
     outs = [np.zeros(out_cap, dtype=np.uint8) for _ in range(n)]
     cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 3, 2, 1, 1, 0, 0, 0, 0, 1, 3)
     st, sizes = api.encode_sequence_memory(cfg, [t.data_ptr() for t in pins], n, [a.ctypes.data for a in outs], out_cap, batch=6, frames_pinned=1,
-                                           lanes_per_device=lanes, device_aliases=aliases, device_count=2 if aliases else 0)
+                                           lanes_per_device=lanes, device_aliases=aliases, device_count=2 if aliases else 0, run_on=run_on)
     assert st.frames == n and st.readers == 0 and st.packet_bytes == sum(sizes)
     p = ob.Params(w, h, pixfmt, 3, 2, 1, 1)
     want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
