@@ -48,6 +48,46 @@ def test_config2_4k_16bit_64_slices(built):
     roundtrip(4096, 2160, synth.PIX_RGB16_BE, 64, 2, "film")
 
 
+def test_config2_4k_batches_run_on(built):
+    """The headline shape in the encoder's run-on mode with DIFFERENT pictures in every batch (the bench codes the same ones again and again:
+    a batch that found another batch's symbols, states or byte buffers would not show there): four batches of six 4K frames, batch k+1
+    issued while batch k is coded; every packet decodes to ITS source on the device, and equals what the same encoder produces one batch at
+    a time."""
+    w, h, pixfmt, slices, n, nb = 4096, 2160, synth.PIX_RGB16_BE, 64, 6, 4
+    nh, nv = api.slices_to_grid(slices)
+    srcs = []
+    for i in range(n * nb):
+        pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 16, "film" if i % 5 else "noise", seed=900 + i), pixfmt, True)
+        srcs.append(pl)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=n, rc_span=1)
+    dsrc = [torch.frombuffer(bytearray(p), dtype=torch.uint8).cuda() for p in srcs]
+    stride = (enc.max_packet + 255) & ~255
+    st = torch.cuda.Stream()
+
+    def run(run_on):
+        dpk = [torch.zeros(n * stride, dtype=torch.uint8, device="cuda") for _ in range(nb)]
+        dsz = [torch.zeros(n, dtype=torch.int64, device="cuda") for _ in range(nb)]
+        torch.cuda.synchronize()
+        enc.set_run_on(run_on)
+        for b in range(nb):
+            enc.encode_device([t.data_ptr() for t in dsrc[b * n:(b + 1) * n]], dpk[b].data_ptr(), stride, dsz[b].data_ptr(), st.cuda_stream)
+        enc.join(st.cuda_stream); st.synchronize()
+        assert enc.error_flags() == 0
+        return dpk, [z.cpu().tolist() for z in dsz]
+    pk1, sz1 = run(True)
+    pk0, sz0 = run(False)
+    assert sz1 == sz0
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=n)
+    dout = [torch.empty(len(srcs[0]), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    for b in range(nb):
+        for i in range(n):
+            assert torch.equal(pk1[b][i * stride:i * stride + sz1[b][i]], pk0[b][i * stride:i * stride + sz0[b][i]]), (b, i)
+        assert dec.decode_device([pk1[b].data_ptr() + i * stride for i in range(n)], sz1[b], [t.data_ptr() for t in dout]) == 0
+        for i in range(n):
+            assert api.compare_device(dout[i].data_ptr(), dsrc[b * n + i].data_ptr(), len(srcs[0])) == -1, (b, i)
+    enc.close(); dec.close()
+
+
 def test_a_4k_slice_of_the_device_decodes_by_the_rfc_alone(built):
     """One 512x270 slice of a 4K frame the device coded (config 2's shape: 64 slices, 5063 contexts, 17-bit differences), decoded by
     tests/rfc9043_validator.py -- code written from RFC 9043's text, none of this repository's codec -- gives the source's pixels: the
