@@ -624,7 +624,7 @@ def cfg1_leg(api, synth, device):
             "note": "24 frames are one short batch: the number is start-up (encoder buffers, pinned slots) plus one batch's latency, not a rate"}, ok
 
 
-def cfg4_leg(torch, api, synth, dev, device, steps=2, F=80):
+def cfg4_leg(torch, api, synth, dev, device, steps=3, F=80):
     """BASELINE config 4's shape on one device: 8192x4320 RGB 16-bit LE (the payload of a single-strip TIFF), the reference's 576 slices,
     device-resident like the headline; the dominant kernel's roofline from this run's HIP events."""
     import numpy as np
@@ -645,11 +645,16 @@ def cfg4_leg(torch, api, synth, dev, device, steps=2, F=80):
 
     def step():
         enc.encode_device(ptrs, d_packets.data_ptr(), stride, d_sizes.data_ptr(), stream)
-    step(); torch.cuda.synchronize()
+    run_on = True
+    try:
+        enc.set_run_on(True)         # the steps run on from one to the next, as the headline's do
+    except Exception:
+        run_on = False
+    step(); enc.join(stream); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    torch.cuda.synchronize()
+    enc.join(stream); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kt = enc.kernel_times(); launches = enc.kernel_launches(); flags = enc.error_flags()
     sizes = d_sizes.cpu().tolist()
@@ -661,7 +666,8 @@ def cfg4_leg(torch, api, synth, dev, device, steps=2, F=80):
     dec.close()
     payload = line_bytes * h
     packet_avg = sum(sizes) / F
-    dom = max(kt, key=lambda k: kt[k])
+    # (in run-on mode k_model's HIP events span the time it trickles through beside the previous batch at its low priority, not its work)
+    dom = max((k for k in kt if not (run_on and k == "k_model")), key=lambda k: kt[k])
     nl = max(1, launches.get(dom, 1))
     alg = F * (payload + packet_avg) / nl
     ach = alg / (kt[dom] / nl * 1e-3) / 1e9
@@ -673,7 +679,7 @@ def cfg4_leg(torch, api, synth, dev, device, steps=2, F=80):
         traffic = int(per4k * (w * h) / (W4K * H4K) * F / nl) if per4k else None
     except Exception:
         traffic = None
-    rec = {"workload": f"config 4 shape on one GPU: {w}x{h} RGB 16-bit LE (TIFF payload), slices={slices} ({nh}x{nv}), {F} frames per step resident in HBM, content=film",
+    rec = {"workload": f"config 4 shape on one GPU: {w}x{h} RGB 16-bit LE (TIFF payload), slices={slices} ({nh}x{nv}), {F} frames per step resident in HBM, content=film" + (", steps issued in run-on mode" if run_on else ""),
            "value": round(F * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "packet_bytes_avg": int(packet_avg),
            "compression_ratio": round(packet_avg / payload, 4), "device_error_flags": flags, "decodes_to_source_on_device": bool(ok),
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -940,7 +946,8 @@ def main():
 
     result = None
     if rank == 0:
-        dom = max(kt, key=lambda k: kt[k]) if kt else None
+        # (in run-on mode k_model's HIP events span the time it trickles through beside the previous batch at its low priority, not its work)
+        dom = max((k for k in kt if not (run_on and k == "k_model")), key=lambda k: kt[k]) if kt else None
         launches = enc.kernel_launches()
         roof = None
         if dom:
