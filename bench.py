@@ -994,6 +994,8 @@ def main():
                     "request_frac": req["request_frac"] if req else None, "floor_ms": req["floor_ms"] if req else None, "requests": req,
                     "algorithmic_bytes_per_launch": int(alg_bytes_launch), "launch_ms": round(launch_ms, 3), "launches_per_step": nl,
                     "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0},
+                    **({"kernel_ms_note": "run-on mode: the kernels of consecutive steps overlap (their times add up to more than a step), and k_model's figure is "
+                                          "the time it takes to trickle through beside the previous batch on its low-priority stream; alone it takes 29 ms"} if run_on else {}),
                     "note": note or "entropy coding: serial per slice and per context, bound by instruction issue rather than bytes (DESIGN.md section 5)"}
         result = {
             "metric": "4K-DCI 16-bit DPX->FFV1 frames/sec", "value": round(fps, 3), "unit": "frames/s",
