@@ -894,6 +894,8 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     // the word-stream layouts share words between neighbouring slices and keep the planes + k_pack_words route
     d->ring = c.fields == kFieldsBytes || c.fields == kFieldsExr;
     d->ring_w = (c.W + c.num_h - 1) / c.num_h + 1;
+    // a kept payload's slot: [room | payload | room] (set here once: decode_keep runs on two threads when a batch is decoded ahead)
+    d->kept_stride = (size_t(RCGPU_KEPT_ROOM) * 2 + size_t(payload_bytes(cfg->pixfmt, cfg->width, cfg->height, cfg->line_bytes, cfg->flags)) + 255) & ~size_t(255);
     DM(d->d_planes, d->ring ? (nchains + 63) / 64 * 64 * c.planes * 3 * d->ring_w * 4 : size_t(F) * c.planes * c.W * c.H * 4); DM(d->d_err, 16);      // rings: interleaved per wavefront of 64 chains
 #undef DM
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_ptrs), sizeof(void*) * F * 2);
@@ -1128,8 +1130,6 @@ static int decode_keep_into(rcgpu_ffv1_decoder* d, int set, uint8_t*& d_in, size
 {
     rcgpu_ffv1_decoder::kept_set& K = d->kept[set];
     K.n = 0;
-    const size_t out_bytes = size_t(payload_bytes(d->cfg.pixfmt, d->cfg.width, d->cfg.height, d->cfg.line_bytes, d->cfg.flags));
-    d->kept_stride = (size_t(RCGPU_KEPT_ROOM) * 2 + out_bytes + 255) & ~size_t(255);
     uint64_t in_total = 0;
     for (uint32_t i = 0; i < n; i++) in_total += (packet_sizes[i] + 255) & ~uint64_t(255);
     kept_clock clk;

@@ -115,12 +115,14 @@ def main():
                 f.write(synth.dpx_file(synth.components(w, h, 3, 16, "film", seed=i), pixfmt, frame_index=i))
         with open(os.path.join(work, "pkg", "snd.wav"), "wb") as f:
             f.write(synth.wav_file(synth.pcm_samples(16000, 2, 16, 48000), 16, 48000))
+        # RCGPU_HANG_BATCH=n: route C in batches of n frames (several batches of the 8 frames: one of them decoded ahead of its turn)
+        benv = {"RCGPU_CHECK_BATCH": os.environ["RCGPU_HANG_BATCH"]} if os.environ.get("RCGPU_HANG_BATCH") else None
         steps = [
             ("ref -d (analysis, prints the ffmpeg command)", [REF, "--hash", "--check-padding", "-d", "-y", "pkg"], None),
             ("linked -d (routes D)", [LINKED, "--hash", "--no-check-padding", "-d", "-y", "pkg"], None),
-            ("linked whole product (routes B, C, D)", [LINKED, "--no-check-padding", "--check", "--hash", "-y", "pkg"], None),
+            ("linked whole product (routes B, C, D)", [LINKED, "--no-check-padding", "--check", "--hash", "-y", "pkg"], benv),
             ("ref --check of the file", [REF, "--check", "pkg.mkv"], None),
-            ("linked --check of the file (route C)", [LINKED, "--check", "pkg.mkv"], None),
+            ("linked --check of the file (route C)", [LINKED, "--check", "pkg.mkv"], benv),
         ]
         t_all = time.time()
         for r in range(rounds):
