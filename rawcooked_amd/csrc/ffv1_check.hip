@@ -11,8 +11,12 @@
 // 64 slices per wavefront, thousands of slices in flight.  Context states live in HBM (32 bytes per context, one
 // gather + one write-back per sample into eight registers); the previous lines of a slice are kept in three-line rings
 // interleaved per wavefront; the slice's bytes come through a register window that is taken from without a look.
-// What bounds it: the memory system's rate of random 32-byte gathers + write-backs (tools/gather_peak: 19.7 G records/s;
-// 1600 4K frames in flight run at 0.8 of it) -- the same ceiling the encoder's k_resolve sits at.
+// What bounds it: the memory system's rate of random 32-byte gathers + write-backs in this pattern, every lane in a state array of
+// its own (tools/gather_region: 19.6 G records/s; 1600 4K frames in flight run at 0.99 of it alone, 0.85-0.9 with the hash of the
+// previous batch beside them -- DESIGN.md section 5).  The kernel ends with its slowest wavefront, so nothing may share a SIMD with
+// some of its wavefronts only: it raises its wave priority, and the hash runs on CUs of its own (partition_streams below).
+// Host side: a batch's payloads stay on the device in one of three sets of slots (current / under verification / decoded ahead:
+// rcgpu_ffv1_decoder_decode_keep_hint decodes the next batch on a thread of the library's own while the caller verifies this one).
 //   k_dec_split   thread / frame    walk the 24-bit slice sizes from the packet tail
 //   k_dec_crc     block  / slice    CRC-32 over the whole slice must be 0 (ec = 1)
 //   k_dec_slices  LANE   / slice    range decoder + median predictor + contexts; whole-byte layouts: inverse RCT + pack of every
