@@ -407,21 +407,20 @@ typedef struct {
 static __thread uint16_t* t_dec; static __thread size_t t_dec_cap, t_dec_n;
 static __thread uint32_t* t_sym; static __thread size_t t_sym_n;
 
-static void rc_tables(uint8_t* one, uint8_t* zero, uint32_t coder)
+static void rc_tables_from(uint8_t* one, uint8_t* zero, const uint8_t* one_src)
 {
     /* AssignStateTransitions, FFV1_RangeCoder.cpp:35-41 */
-    memcpy(one, coder == 2 ? one_state_alt : one_state_default, 256);
+    memcpy(one, one_src, 256);
     zero[0] = 0;
     for (int i = 1; i < 256; i++)
         zero[i] = (uint8_t)(256 - one[256 - i]);
 }
-static void rce_init2(rc_enc* c, uint8_t* buf, size_t cap, uint32_t coder)
+static void rce_init(rc_enc* c, uint8_t* buf, size_t cap)       /* with the default table: the record, and every slice up to its header */
 {
     c->low = 0; c->range = 0xFF00; c->outstanding_byte = -1; c->outstanding_count = 0;
     c->p = buf; c->end = buf + cap; c->overflow = 0; c->decisions = 0;
-    rc_tables(c->one_state, c->zero_state, coder);
+    rc_tables_from(c->one_state, c->zero_state, one_state_default);
 }
-static void rce_init(rc_enc* c, uint8_t* buf, size_t cap) { rce_init2(c, buf, cap, 1); }      /* the record itself: default table */
 static inline void rce_out(rc_enc* c, int v) { if (c->p < c->end) *c->p++ = (uint8_t)v; else c->overflow = 1; }
 static void rce_renorm(rc_enc* c)
 {
@@ -475,7 +474,91 @@ static void rce_symbol(rc_enc* c, uint8_t* st, int32_t v, int is_signed)
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Configuration record (inverse of parameters::Parse, FFV1_Parameters.cpp:23-183, :206-253)
+ * The stream's parameters (parameters, FFV1_Parameters.h / FFV1_Parameters.cpp:23-183): what the configuration record of a
+ * version 3 stream or the header inside every version 0 / 1 frame says.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t bps, bits, planes, set_index_count;
+    int rgb, alpha, overflow16;
+    uint32_t version, micro, intra, ec;     /* version 0, 1 or 3 */
+    uint32_t num_h, num_v;
+    int custom;                             /* coder_type 2: one_state travels in the stream */
+    uint8_t one_state[256];                 /* the transitions the slices are coded with */
+    uint32_t nsets;
+    uint32_t idx[3];                        /* quant_table_set_index this ENCODER writes for plane group 0 (Y), 1 (Cb, Cr), 2 (alpha) */
+    uint32_t idx_alt[3]; int alt;           /* ... and in the slices with odd sx + sy when alt is set */
+    quant_set qs[8];
+    const uint8_t* init[8];                 /* coded initial states of set i (context_count x 32) or NULL = all 128 */
+    uint8_t* init_own[8];                   /* the same when a parser allocated them */
+} codec_ctx;
+
+static void ctx_geometry(codec_ctx* k, uint32_t pixfmt)
+{
+    k->bps = ffv1o_bits_per_raw_sample(pixfmt);
+    k->rgb = is_rgb(pixfmt);
+    k->alpha = has_alpha(pixfmt);
+    k->planes = ffv1o_plane_count(pixfmt);
+    /* FFV1_Parameters.cpp:160-181 */
+    k->overflow16 = (!k->rgb && k->bps == 16);
+    k->bits = k->rgb ? k->bps + 1 : (k->bps <= 8 ? 8 : k->bps);
+    k->set_index_count = k->rgb ? k->planes - 1 : 2;       /* version < 4: 1 + 1 (+ alpha) */
+}
+static void ctx_free(codec_ctx* k)
+{
+    for (int i = 0; i < 8; i++) free(k->init_own[i]);
+    free(k);
+}
+/* level map (one level per |difference| 0..127) -> one table of a set; *scale is the context count so far (QuantizationTable, :222-253) */
+static void quant_from_levels(int16_t* q, const uint8_t* levels, int32_t* scale)
+{
+    for (int i = 0; i < 128; i++) q[i] = (int16_t)(*scale * levels[i]);
+    for (int i = 1; i < 128; i++) q[256 - i] = (int16_t)-q[i];
+    q[128] = (int16_t)-q[127];
+    *scale *= 2 * (levels[127] + 1) - 1;
+}
+uint32_t ffv1o_ext_context_count(const ffv1o_stream_ext* e, uint32_t set)
+{
+    int32_t scale = 1;
+    for (int j = 0; j < 5; j++) scale *= 2 * (e->levels[set][j][127] + 1) - 1;
+    return (uint32_t)((scale + 1) >> 1);
+}
+static codec_ctx* ctx_from_params(const ffv1o_params* p)
+{
+    codec_ctx* k = calloc(1, sizeof *k);
+    ctx_geometry(k, p->pixfmt);
+    k->num_h = p->num_h_slices; k->num_v = p->num_v_slices; k->ec = p->ec;
+    const ffv1o_stream_ext* e = p->ext;
+    if (!e) {
+        /* what FFmpeg's encoder sends: two table sets (version 3), the planes all on the set -context picks; version 1 carries that one set */
+        quant_set d[2];
+        build_quant_sets_c(k->bps, d, p->context_model == 2);
+        const uint32_t qidx = p->context_model ? 1 : 0;
+        k->version = p->level == 1 ? 1 : 3; k->micro = 4; k->intra = 1;
+        k->custom = p->coder == 2;
+        memcpy(k->one_state, k->custom ? one_state_alt : one_state_default, 256);
+        if (k->version == 1) { k->nsets = 1; k->qs[0] = d[qidx]; }
+        else { k->nsets = 2; k->qs[0] = d[0]; k->qs[1] = d[1]; k->idx[0] = k->idx[1] = k->idx[2] = qidx; }
+        return k;
+    }
+    k->version = e->version; k->micro = e->micro_version; k->intra = e->intra;
+    k->custom = e->custom_transitions != 0;
+    memcpy(k->one_state, k->custom ? e->one_state : one_state_default, 256);
+    k->nsets = k->version <= 1 ? 1 : e->set_count;
+    for (uint32_t i = 0; i < k->nsets; i++) {
+        int32_t scale = 1;
+        for (int j = 0; j < 5; j++) quant_from_levels(k->qs[i].q[j], e->levels[i][j], &scale);
+        k->qs[i].context_count = (uint32_t)((scale + 1) >> 1);
+        if (k->version == 3 && e->states_coded[i]) k->init[i] = e->initial_states[i];
+    }
+    for (int g = 0; g < 3; g++) k->idx[g] = k->version <= 1 ? 0 : e->set_index[g];
+    k->alt = k->version == 3 && e->alt_slices;
+    for (int g = 0; g < 3; g++) k->idx_alt[g] = e->set_index_alt[g];
+    if (k->version <= 1) { k->num_h = k->num_v = 1; k->ec = 0; }
+    return k;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Writing the parameters (inverse of parameters::Parse, FFV1_Parameters.cpp:23-183, :206-253)
  * ---------------------------------------------------------------------------------------------- */
 static void write_quant_table(rc_enc* c, const int16_t* q)
 {
@@ -485,35 +568,45 @@ static void write_quant_table(rc_enc* c, const int16_t* q)
         if (q[i] != q[i - 1]) { rce_symbol(c, st, i - last - 1, 0); last = i; }
     rce_symbol(c, st, i - last - 1, 0);
 }
+/* the fields in the order Parse reads them; `record` = out of band (version 3), else the header inside a version 0 / 1 frame */
+static void write_parameters(rc_enc* c, uint8_t* st, const codec_ctx* k, int record)
+{
+    rce_symbol(c, st, (int32_t)k->version, 0);
+    if (k->version >= 3) rce_symbol(c, st, (int32_t)k->micro, 0);      /* >= 4 required, :36-37 */
+    rce_symbol(c, st, k->custom ? 2 : 1, 0);                           /* coder_type: range coder, default or transmitted table */
+    if (k->custom)                                                     /* state_transition_delta[1..255], :41-55 */
+        for (int i = 1; i < 256; i++) rce_symbol(c, st, (int32_t)k->one_state[i] - (int32_t)one_state_default[i], 1);
+    rce_symbol(c, st, k->rgb ? 1 : 0, 0);                              /* colorspace_type */
+    if (k->version >= 1) rce_symbol(c, st, (int32_t)k->bps, 0);        /* bits_per_raw_sample; version 0 has none: 8 (:62-73) */
+    rce_put(c, st, k->rgb ? 1 : 0);                                    /* chroma_planes */
+    rce_symbol(c, st, 0, 0);                                           /* log2_h_chroma_subsample */
+    rce_symbol(c, st, 0, 0);                                           /* log2_v_chroma_subsample */
+    rce_put(c, st, k->alpha);                                          /* alpha_plane */
+    if (record) {
+        rce_symbol(c, st, (int32_t)k->num_h - 1, 0);
+        rce_symbol(c, st, (int32_t)k->num_v - 1, 0);
+        rce_symbol(c, st, (int32_t)k->nsets, 0);                       /* quant_table_set_count */
+    }
+    for (uint32_t i = 0; i < k->nsets; i++)
+        for (int j = 0; j < 5; j++)
+            write_quant_table(c, k->qs[i].q[j]);
+    if (!record) return;
+    for (uint32_t i = 0; i < k->nsets; i++) {
+        rce_put(c, st, k->init[i] != NULL);                            /* states_coded */
+        if (k->init[i])                                                /* as the reference reads them: `States[k] = E.s(States)`, :103-107 */
+            for (size_t j = 0; j < (size_t)k->qs[i].context_count * CONTEXT_SIZE; j++) rce_symbol(c, st, (int32_t)k->init[i][j], 1);
+    }
+    rce_symbol(c, st, (int32_t)k->ec, 0);                              /* ec */
+    rce_symbol(c, st, (int32_t)k->intra, 0);                           /* intra (micro_version != 0, :139-144) */
+}
 size_t ffv1o_config_record(const ffv1o_params* p, uint8_t* out, size_t cap)
 {
-    if (p->level == 1) return 0;                     /* version 1 has no out-of-band record */
-    quant_set qs[2];
-    const uint32_t bps = ffv1o_bits_per_raw_sample(p->pixfmt);
-    build_quant_sets_c(bps, qs, p->context_model == 2);
+    codec_ctx* k = ctx_from_params(p);
+    if (k->version <= 1) { ctx_free(k); return 0; }  /* version 0 / 1 have no out-of-band record */
     rc_enc c; rce_init(&c, out, cap);
     uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);
-    rce_symbol(&c, st, 3, 0);                        /* version */
-    rce_symbol(&c, st, 4, 0);                        /* micro_version (>=4 required, :37-38) */
-    rce_symbol(&c, st, p->coder == 2 ? 2 : 1, 0);    /* coder_type: range coder, default or custom table */
-    if (p->coder == 2)                               /* state_transition_delta[1..255], FFV1_Parameters.cpp:41-55 */
-        for (int i = 1; i < 256; i++) rce_symbol(&c, st, (int32_t)one_state_alt[i] - (int32_t)one_state_default[i], 1);
-    rce_symbol(&c, st, is_rgb(p->pixfmt) ? 1 : 0, 0);/* colorspace_type */
-    rce_symbol(&c, st, (int32_t)bps, 0);             /* bits_per_raw_sample */
-    rce_put(&c, st, is_rgb(p->pixfmt) ? 1 : 0);      /* chroma_planes */
-    rce_symbol(&c, st, 0, 0);                        /* log2_h_chroma_subsample */
-    rce_symbol(&c, st, 0, 0);                        /* log2_v_chroma_subsample */
-    rce_put(&c, st, has_alpha(p->pixfmt));           /* alpha_plane */
-    rce_symbol(&c, st, (int32_t)p->num_h_slices - 1, 0);
-    rce_symbol(&c, st, (int32_t)p->num_v_slices - 1, 0);
-    rce_symbol(&c, st, 2, 0);                        /* quant_table_set_count */
-    for (int i = 0; i < 2; i++)
-        for (int j = 0; j < 5; j++)
-            write_quant_table(&c, qs[i].q[j]);
-    for (int i = 0; i < 2; i++)
-        rce_put(&c, st, 0);                          /* states_coded */
-    rce_symbol(&c, st, (int32_t)p->ec, 0);           /* ec */
-    rce_symbol(&c, st, 1, 0);                        /* intra (-g 1) */
+    write_parameters(&c, st, k, 1);
+    ctx_free(k);
     size_t n = rce_terminate(&c, out, 0);
     if (c.overflow || n + 4 > cap) return 0;
     uint32_t crc = ffv1o_crc32(out, n);              /* parity: CRC over record||crc == 0, FFV1_Frame.cpp:116 */
@@ -539,32 +632,22 @@ static inline int32_t sign_extend(int32_t v, int bits)
     return (int32_t)((u ^ m) - m);
 }
 
-typedef struct {
-    uint32_t bps, bits, planes, set_index_count;
-    int rgb, overflow16;
-    uint32_t qidx;             /* quant_table_set index used by every plane = context_model */
-    quant_set qs[2];
-} codec_ctx;
-
-static void codec_ctx_init(codec_ctx* k, const ffv1o_params* p)
+/* context states of one slice: an array per plane group, copied from the set's initial states (coder_rangecoder::GOP_Init,
+ * Coder/FFV1_Coder_RangeCoder.cpp:34-57) */
+static void slice_states(const codec_ctx* k, const uint32_t idx[3], uint8_t (*states[3])[CONTEXT_SIZE])
 {
-    k->bps = ffv1o_bits_per_raw_sample(p->pixfmt);
-    k->rgb = is_rgb(p->pixfmt);
-    k->planes = ffv1o_plane_count(p->pixfmt);
-    /* FFV1_Parameters.cpp:160-181 */
-    k->overflow16 = (!k->rgb && k->bps == 16);
-    k->bits = k->rgb ? k->bps + 1 : (k->bps <= 8 ? 8 : k->bps);
-    k->set_index_count = k->rgb ? k->planes - 1 : 2;       /* version<4: 1 + 1 (+alpha) */
-    k->qidx = p->context_model ? 1 : 0;
-    build_quant_sets_c(k->bps, k->qs, p->context_model == 2);
+    for (uint32_t g = 0; g < k->set_index_count; g++) {
+        const size_t n = (size_t)k->qs[idx[g]].context_count * CONTEXT_SIZE;
+        states[g] = malloc(n);
+        if (k->init[idx[g]]) memcpy(states[g], k->init[idx[g]], n); else memset(states[g], 128, n);
+    }
 }
 
 /* One line of one plane.  cur/prev point at x=0 of buffers with 2 guard samples on the left and 1 on the
  * right (SamplesBuffer layout, FFV1_Slice.cpp:406-425).  On entry cur[] holds the line two above (TT). */
-static void encode_line(rc_enc* c, const codec_ctx* k, uint8_t (*states)[CONTEXT_SIZE], uint32_t w,
-                        int32_t* cur, int32_t* prev, const int32_t* src, uint32_t set)
+static void encode_line(rc_enc* c, const codec_ctx* k, const quant_set* qs, uint8_t (*states)[CONTEXT_SIZE], uint32_t w,
+                        int32_t* cur, int32_t* prev, const int32_t* src, uint32_t group)
 {
-    const quant_set* qs = &k->qs[k->qidx];
     const int is5 = qs->q[3][127] != 0;                       /* FFV1_Slice.cpp:453 */
     const int32_t mask = (int32_t)(((uint32_t)1 << k->bits) - 1);
     for (uint32_t x = 0; x < w; x++) {
@@ -579,19 +662,19 @@ static void encode_line(rc_enc* c, const codec_ctx* k, uint8_t (*states)[CONTEXT
         int32_t d = v - pred;
         if (ctx < 0) { ctx = -ctx; d = -d; }
         d = sign_extend(d, (int)k->bits);
-        if (t_sym) t_sym[t_sym_n++] = (set << 30) | ((uint32_t)ctx << 17) | ((uint32_t)d & 0x1FFFFu);
+        if (t_sym) t_sym[t_sym_n++] = (group << 30) | ((uint32_t)ctx << 17) | ((uint32_t)d & 0x1FFFFu);
         rce_symbol(c, states[ctx], d, 1);
         *s1 = v;
     }
 }
 
-static void slice_rect(const ffv1o_params* p, uint32_t sx, uint32_t sy, uint32_t* x, uint32_t* y, uint32_t* w, uint32_t* h)
+static void slice_rect(const ffv1o_params* p, uint32_t nh, uint32_t nv, uint32_t sx, uint32_t sy, uint32_t* x, uint32_t* y, uint32_t* w, uint32_t* h)
 {
     /* FFV1_Slice.cpp:153-156 */
-    *x = sx * p->width / p->num_h_slices;
-    *y = sy * p->height / p->num_v_slices;
-    *w = (sx + 1) * p->width / p->num_h_slices - *x;
-    *h = (sy + 1) * p->height / p->num_v_slices - *y;
+    *x = sx * p->width / nh;
+    *y = sy * p->height / nv;
+    *w = (sx + 1) * p->width / nh - *x;
+    *h = (sy + 1) * p->height / nv - *y;
 }
 
 static __thread uint64_t g_last_decisions;
@@ -601,43 +684,31 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
                            int first, uint8_t* out, size_t cap)
 {
     uint32_t x0, y0, w, h;
-    slice_rect(p, sx, sy, &x0, &y0, &w, &h);
-    const int v1 = p->level == 1;
-    rc_enc c; rce_init2(&c, out, cap, v1 ? 1 : p->coder);    /* coder_type 2: the custom table drives every slice (v1: only after the header) */
+    slice_rect(p, k->num_h, k->num_v, sx, sy, &x0, &y0, &w, &h);
+    const int inband = k->version <= 1;
+    const uint32_t* idx = k->alt && ((sx + sy) & 1) ? k->idx_alt : k->idx;
+    rc_enc c; rce_init(&c, out, cap);                         /* default transitions (FFV1_Slice.cpp:214) ... */
+    if (!inband) rc_tables_from(c.one_state, c.zero_state, k->one_state);   /* ... the stream's own from the slice header on (:254-255) */
     if (first) { uint8_t ks = 128; rce_put(&c, &ks, 1); }     /* keyframe, FFV1_Frame.cpp:148-156 */
     uint8_t hs[CONTEXT_SIZE]; memset(hs, 128, sizeof hs);
-    if (v1) {
-        /* version 1: the stream header inside the frame, parameters::Parse(E, false) (FFV1_Parameters.cpp:23-104), read with the default
-         * transitions (FFV1_Slice.cpp:214, 254-255) */
-        rce_symbol(&c, hs, 1, 0);                             /* version */
-        rce_symbol(&c, hs, p->coder == 2 ? 2 : 1, 0);         /* coder_type */
-        if (p->coder == 2)
-            for (int i = 1; i < 256; i++) rce_symbol(&c, hs, (int32_t)one_state_alt[i] - (int32_t)one_state_default[i], 1);
-        rce_symbol(&c, hs, k->rgb ? 1 : 0, 0);                /* colorspace_type */
-        rce_symbol(&c, hs, (int32_t)k->bps, 0);               /* bits_per_raw_sample (version >= 1) */
-        rce_put(&c, hs, k->rgb ? 1 : 0);                      /* chroma_planes */
-        rce_symbol(&c, hs, 0, 0); rce_symbol(&c, hs, 0, 0);   /* chroma subsampling */
-        rce_put(&c, hs, k->planes == 4);                      /* alpha_plane */
-        for (int j = 0; j < 5; j++) write_quant_table(&c, k->qs[k->qidx].q[j]);      /* the one table set (-context) */
-        rc_tables(c.one_state, c.zero_state, p->coder);
+    if (inband) {
+        /* version 0 / 1: the stream header inside the frame, parameters::Parse(E, false) (FFV1_Parameters.cpp:23-104), read with the
+         * default transitions (FFV1_Slice.cpp:214, 254-255) */
+        write_parameters(&c, hs, k, 0);
+        rc_tables_from(c.one_state, c.zero_state, k->one_state);
     } else {
     /* slice header, FFV1_Slice.cpp:113-177 */
     rce_symbol(&c, hs, (int32_t)sx, 0);
     rce_symbol(&c, hs, (int32_t)sy, 0);
     rce_symbol(&c, hs, 0, 0);                                 /* slice_width - 1 (slice units) */
     rce_symbol(&c, hs, 0, 0);
-    for (uint32_t i = 0; i < k->set_index_count; i++) rce_symbol(&c, hs, (int32_t)k->qidx, 0);
+    for (uint32_t i = 0; i < k->set_index_count; i++) rce_symbol(&c, hs, (int32_t)idx[i], 0);
     rce_symbol(&c, hs, 3, 0);                                 /* picture_structure: progressive */
     rce_symbol(&c, hs, 0, 0); rce_symbol(&c, hs, 0, 0);       /* sar 0/0 = unknown */
     }
 
-    /* context states: one array per quant_table_set_index, all 128 (states_coded = 0), GOP_Init */
-    const uint32_t nctx = k->qs[k->qidx].context_count;
-    uint8_t (*states[3])[CONTEXT_SIZE];
-    for (uint32_t i = 0; i < k->set_index_count; i++) {
-        states[i] = malloc((size_t)nctx * CONTEXT_SIZE);
-        memset(states[i], 128, (size_t)nctx * CONTEXT_SIZE);
-    }
+    uint8_t (*states[3])[CONTEXT_SIZE] = { 0, 0, 0 };
+    slice_states(k, idx, states);
     int32_t* buf = calloc((size_t)2 * k->planes * (w + 3), sizeof(int32_t));
     int32_t* sample[4][2];
     for (uint32_t pl = 0; pl < k->planes; pl++) {
@@ -651,8 +722,9 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
                 int32_t* t = sample[pl][0]; sample[pl][0] = sample[pl][1]; sample[pl][1] = t;
                 sample[pl][1][-1] = sample[pl][0][0];
                 sample[pl][0][w] = sample[pl][0][w - 1];
-                encode_line(&c, k, states[(pl + 1) >> 1], w, sample[pl][1], sample[pl][0],
-                            planes[pl] + (size_t)(y0 + y) * p->width + x0, (pl + 1) >> 1);
+                const uint32_t g = (pl + 1) >> 1;
+                encode_line(&c, k, &k->qs[idx[g]], states[g], w, sample[pl][1], sample[pl][0],
+                            planes[pl] + (size_t)(y0 + y) * p->width + x0, g);
             }
     } else {
         /* SliceContent_PlaneThenLine, FFV1_Slice.cpp:346-403 (luma only: chroma_planes = 0) */
@@ -660,7 +732,7 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
             int32_t* t = sample[0][0]; sample[0][0] = sample[0][1]; sample[0][1] = t;
             sample[0][1][-1] = sample[0][0][0];
             sample[0][0][w] = sample[0][0][w - 1];
-            encode_line(&c, k, states[0], w, sample[0][1], sample[0][0], planes[0] + (size_t)(y0 + y) * p->width + x0, 0);
+            encode_line(&c, k, &k->qs[idx[0]], states[0], w, sample[0][1], sample[0][0], planes[0] + (size_t)(y0 + y) * p->width + x0, 0);
         }
     }
     free(buf);
@@ -668,11 +740,11 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
 
     size_t n = rce_terminate(&c, out, 1);
     g_last_decisions += c.decisions;
-    if (v1) return c.overflow ? 0 : n;                        /* version 1: the frame is the coder's bytes, nothing after them */
+    if (inband) return c.overflow ? 0 : n;                    /* version 0 / 1: the frame is the coder's bytes, nothing after them */
     /* footer, FFV1_Frame.cpp:177-196, FFV1_Slice.cpp:301-314 */
     if (c.overflow || n + 8 > cap || n > 0xFFFFFF) return 0;
     out[n] = (uint8_t)(n >> 16); out[n + 1] = (uint8_t)(n >> 8); out[n + 2] = (uint8_t)n; n += 3;
-    if (p->ec) {
+    if (k->ec) {
         out[n++] = 0;                                         /* error_status */
         uint32_t crc = ffv1o_crc32(out, n);
         out[n] = (uint8_t)(crc >> 24); out[n + 1] = (uint8_t)(crc >> 16); out[n + 2] = (uint8_t)(crc >> 8); out[n + 3] = (uint8_t)crc;
@@ -683,31 +755,29 @@ static size_t encode_slice(const ffv1o_params* p, const codec_ctx* k, int32_t* c
 
 size_t ffv1o_encode_frame(const ffv1o_params* p, int32_t* const planes[4], uint8_t* out, size_t cap, uint32_t* slice_sizes)
 {
-    codec_ctx* k = malloc(sizeof *k);
-    codec_ctx_init(k, p);
+    codec_ctx* k = ctx_from_params(p);
     size_t pos = 0;
     g_last_decisions = 0;
-    for (uint32_t sy = 0; sy < p->num_v_slices; sy++)
-        for (uint32_t sx = 0; sx < p->num_h_slices; sx++) {
+    for (uint32_t sy = 0; sy < k->num_v; sy++)
+        for (uint32_t sx = 0; sx < k->num_h; sx++) {
             size_t n = encode_slice(p, k, planes, sx, sy, pos == 0, out + pos, cap - pos);
-            if (!n) { free(k); return 0; }
-            if (slice_sizes) slice_sizes[sy * p->num_h_slices + sx] = (uint32_t)n;
+            if (!n) { ctx_free(k); return 0; }
+            if (slice_sizes) slice_sizes[sy * k->num_h + sx] = (uint32_t)n;
             pos += n;
         }
-    free(k);
+    ctx_free(k);
     return pos;
 }
 
 size_t ffv1o_trace_slice(const ffv1o_params* p, int32_t* const planes[4], uint32_t sx, uint32_t sy,
                          uint32_t* sym_out, uint16_t* dec_out, size_t dec_cap, size_t* ndec, uint8_t* raw_out, size_t raw_cap)
 {
-    codec_ctx* k = malloc(sizeof *k);
-    codec_ctx_init(k, p);
+    codec_ctx* k = ctx_from_params(p);
     t_sym = sym_out; t_sym_n = 0; t_dec = dec_out; t_dec_cap = dec_cap; t_dec_n = 0;
     size_t n = encode_slice(p, k, planes, sx, sy, sx == 0 && sy == 0, raw_out, raw_cap);
     if (ndec) *ndec = t_dec_n;
     t_sym = NULL; t_dec = NULL;
-    free(k);
+    ctx_free(k);
     return n;
 }
 
@@ -724,21 +794,20 @@ size_t ffv1o_encode_payload(const ffv1o_params* p, const uint8_t* payload, size_
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Decoder: restates rangecoder (FFV1_RangeCoder.cpp:21-132), slice::Parse (FFV1_Slice.cpp:210-318),
- * ffv1_frame::Process (FFV1_Frame.cpp:134-228)
+ * Decoder: restates rangecoder (FFV1_RangeCoder.cpp:21-132), parameters::Parse (FFV1_Parameters.cpp:23-183),
+ * slice::Parse (FFV1_Slice.cpp:210-318), ffv1_frame::OutOfBand / Process (FFV1_Frame.cpp:105-228)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     uint32_t current, mask;
     const uint8_t *beg, *cur, *end;
     uint8_t one_state[256], zero_state[256];
 } rc_dec;
-static void rcd_init2(rc_dec* c, const uint8_t* buf, size_t n, uint32_t coder)
+static void rcd_init(rc_dec* c, const uint8_t* buf, size_t n)
 {
     c->beg = buf; c->cur = buf; c->end = buf + n;
     c->current = n ? *c->cur : 0; c->mask = 0xFF; c->cur++;       /* AssignBuffer, :22-33 */
-    rc_tables(c->one_state, c->zero_state, coder);
+    rc_tables_from(c->one_state, c->zero_state, one_state_default);
 }
-static void rcd_init(rc_dec* c, const uint8_t* buf, size_t n) { rcd_init2(c, buf, n, 1); }
 static int rcd_b(rc_dec* c, uint8_t* state)
 {
     if (c->mask < 0x100) {
@@ -778,31 +847,106 @@ static int32_t rcd_s(rc_dec* c, uint8_t* st)
     return rcd_b(c, st + 11 + (e < 10 ? e : 10)) ? -a : a;
 }
 
-static int decode_slice(const ffv1o_params* p, const codec_ctx* k, const uint8_t* buf, size_t size, int first, int32_t* const planes[4])
+/* parameters::Parse(E, ConfigurationRecord_IsPresent), FFV1_Parameters.cpp:23-183 with QuantizationTableSet / QuantizationTable
+ * (:206-253), line by line.  Fills what the stream says into k (geometry derived from it, not from a pixel format); 0 ok, else the
+ * step that refused. */
+static int parse_parameters(rc_dec* c, codec_ctx* k, int record)
 {
-    const size_t tail = p->ec ? 8 : 3;
-    if (size < tail) return 10;
-    if (p->ec && ffv1o_crc32(buf, size)) return 11;             /* FFV1_Slice.cpp:247-249 */
-    rc_dec c; rcd_init2(&c, buf, size - tail, p->coder);
-    if (first) { uint8_t ks = 128; rcd_b(&c, &ks); }
-    uint8_t hs[CONTEXT_SIZE]; memset(hs, 128, sizeof hs);
-    uint32_t sx = rcd_u(&c, hs), sy = rcd_u(&c, hs);
-    uint32_t sw1 = rcd_u(&c, hs), sh1 = rcd_u(&c, hs);
-    if (sx >= p->num_h_slices || sy >= p->num_v_slices || sw1 || sh1) return 12;
-    for (uint32_t i = 0; i < k->set_index_count; i++) if (rcd_u(&c, hs) != k->qidx) return 13;
-    (void)rcd_u(&c, hs); (void)rcd_u(&c, hs); (void)rcd_u(&c, hs);
-    uint32_t x0, y0, w, h;
-    slice_rect(p, sx, sy, &x0, &y0, &w, &h);
-
-    const quant_set* qs = &k->qs[k->qidx];
-    const int is5 = qs->q[3][127] != 0;
-    const int32_t mask = (int32_t)(((uint32_t)1 << k->bits) - 1);
-    const uint32_t nctx = qs->context_count;
-    uint8_t (*states[3])[CONTEXT_SIZE];
-    for (uint32_t i = 0; i < k->set_index_count; i++) {
-        states[i] = malloc((size_t)nctx * CONTEXT_SIZE);
-        memset(states[i], 128, (size_t)nctx * CONTEXT_SIZE);
+    uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);
+    k->version = rcd_u(c, st);
+    if (record && k->version <= 1) return 3;
+    if (!record && k->version > 1) return 3;
+    if (k->version == 2 || k->version > 3) return 3;
+    k->micro = 0;
+    if (k->version >= 3) k->micro = rcd_u(c, st);
+    if (k->version == 3 && k->micro < 4) return 4;
+    uint32_t coder_type = rcd_u(c, st);
+    if (coder_type > 2) return 5;
+    k->custom = 0;
+    memcpy(k->one_state, one_state_default, 256);
+    if (coder_type == 2) {
+        for (int i = 1; i < 256; i++) {
+            const int32_t v = (int32_t)one_state_default[i] + rcd_s(c, st);
+            if (v < 0 || v > 0xFF) return 5;
+            k->one_state[i] = (uint8_t)v;
+        }
+        k->custom = 1;
+        coder_type = 1;
     }
+    if (coder_type != 1) return 20;                    /* Golomb-Rice: a valid stream, outside this oracle */
+    const uint32_t colorspace = rcd_u(c, st);
+    if (colorspace > 1) return 6;
+    if (k->version) {
+        k->bps = rcd_u(c, st);
+        if (k->bps > 64) return 6;
+        if (!k->bps) k->bps = 8;
+    } else k->bps = 8;
+    const int chroma = rcd_b(c, st);
+    const uint32_t hsub = rcd_u(c, st), vsub = rcd_u(c, st);
+    k->alpha = rcd_b(c, st);
+    if (k->version > 1) {
+        k->num_h = rcd_u(c, st) + 1;
+        k->num_v = rcd_u(c, st) + 1;
+        k->nsets = rcd_u(c, st);
+        if (k->nsets > 8) return 7;
+    } else { k->num_h = k->num_v = 1; k->nsets = 1; }
+    for (uint32_t i = 0; i < k->nsets; i++) {
+        int32_t scale = 1;
+        for (int j = 0; j < 5; j++) {
+            uint8_t qst[CONTEXT_SIZE]; memset(qst, 128, sizeof qst);
+            int32_t v = 0;
+            int16_t* q = k->qs[i].q[j];
+            for (uint32_t kk = 0; kk < 128;) {
+                const uint32_t len1 = rcd_u(c, qst);
+                if (kk + len1 >= 128) return 9;
+                for (uint32_t a = 0; a <= len1; a++, kk++) q[kk] = (int16_t)(scale * v);
+                v++;
+            }
+            for (int a = 1; a < 128; a++) q[256 - a] = (int16_t)-q[a];
+            q[128] = (int16_t)-q[127];
+            scale *= 2 * v - 1;
+            if (scale > 32768) return 10;
+        }
+        k->qs[i].context_count = (uint32_t)((scale + 1) >> 1);
+    }
+    for (uint32_t i = 0; i < k->nsets; i++) {
+        int coded = 0;
+        if (k->version >= 3) coded = rcd_b(c, st);
+        if (coded) {
+            const size_t n = (size_t)k->qs[i].context_count * CONTEXT_SIZE;
+            k->init_own[i] = malloc(n);
+            for (size_t j = 0; j < n; j++) k->init_own[i][j] = (uint8_t)rcd_s(c, st);
+            k->init[i] = k->init_own[i];
+        }
+    }
+    if (k->version >= 3) {
+        k->ec = rcd_u(c, st);
+        if (k->ec > 1) return 13;
+        k->intra = 0;
+        if (k->micro) { k->intra = rcd_u(c, st); if (k->intra > 1) return 14; }
+    } else { k->ec = 0; k->intra = 0; }
+    k->rgb = colorspace == 1;
+    if (hsub || vsub || chroma != k->rgb) return 21;   /* subsampled / planar YUV: valid streams, outside this oracle */
+    k->planes = k->rgb ? (k->alpha ? 4 : 3) : (k->alpha ? 2 : 1);
+    k->overflow16 = (!k->rgb && k->bps == 16);
+    k->bits = k->rgb ? k->bps + 1 : (k->bps <= 8 ? 8 : k->bps);
+    k->set_index_count = k->rgb ? k->planes - 1 : 2 + (k->alpha ? 1 : 0);
+    return 0;
+}
+/* does the stream describe pictures of this pixel format? */
+static int ctx_matches(const codec_ctx* k, uint32_t pixfmt)
+{
+    return k->rgb == is_rgb(pixfmt) && k->alpha == has_alpha(pixfmt) && k->bps == ffv1o_bits_per_raw_sample(pixfmt) && k->planes == ffv1o_plane_count(pixfmt);
+}
+
+/* samples of one slice: SliceContent (FFV1_Slice.cpp:321-444) + Line (:447-472) with the end bit and the underrun / junk tests
+ * (:286-299, :334-345); idx = the slice's own quant_table_set_index values */
+static int decode_content(const ffv1o_params* p, const codec_ctx* k, rc_dec* c, const uint32_t idx[3], uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                          size_t coded_size, int32_t* const planes[4])
+{
+    const int32_t mask = (int32_t)(((uint32_t)1 << k->bits) - 1);
+    uint8_t (*states[3])[CONTEXT_SIZE] = { 0, 0, 0 };
+    slice_states(k, idx, states);
     int32_t* sb = calloc((size_t)2 * k->planes * (w + 3), sizeof(int32_t));
     int32_t* sample[4][2];
     for (uint32_t pl = 0; pl < k->planes; pl++) { sample[pl][0] = sb + 2 * pl * (w + 3) + 2; sample[pl][1] = sample[pl][0] + w + 3; }
@@ -811,7 +955,10 @@ static int decode_slice(const ffv1o_params* p, const codec_ctx* k, const uint8_t
             int32_t* t = sample[pl][0]; sample[pl][0] = sample[pl][1]; sample[pl][1] = t;
             sample[pl][1][-1] = sample[pl][0][0];
             sample[pl][0][w] = sample[pl][0][w - 1];
-            uint8_t (*st)[CONTEXT_SIZE] = states[k->rgb ? (pl + 1) >> 1 : 0];
+            const uint32_t g = k->rgb ? (pl + 1) >> 1 : 0;
+            uint8_t (*st)[CONTEXT_SIZE] = states[g];
+            const quant_set* qs = &k->qs[idx[g]];
+            const int is5 = qs->q[3][127] != 0;
             int32_t* dst = planes[pl] + (size_t)(y0 + y) * p->width + x0;
             /* slice::Line, FFV1_Slice.cpp:447-472 */
             for (uint32_t x = 0; x < w; x++) {
@@ -822,27 +969,62 @@ static int decode_slice(const ffv1o_params* p, const codec_ctx* k, const uint8_t
                 int32_t v;
                 if (k->overflow16) v = median3((int16_t)L, (int16_t)L + (int16_t)T - (int16_t)LT, (int16_t)T);
                 else v = median3(L, L + T - LT, T);
-                if (ctx >= 0) v += rcd_s(&c, st[ctx]); else v -= rcd_s(&c, st[-ctx]);
+                if (ctx >= 0) v += rcd_s(c, st[ctx]); else v -= rcd_s(c, st[-ctx]);
                 *s1 = v & mask;
                 dst[x] = *s1;
             }
         }
     free(sb);
     for (uint32_t i = 0; i < k->set_index_count; i++) free(states[i]);
-    { uint8_t es = 129; rcd_b(&c, &es); }                        /* FFV1_Slice.cpp:336-340 */
-    if (c.cur - (c.mask < 0x100 ? 0 : 1) > c.end) return 14;    /* IsUnderrun */
-    if (rcd_bytes_used(&c) < size - tail) return 15;             /* FFV1-SLICE-JUNK, :297-299 */
-    if (p->ec && buf[size - 5]) return 16;                       /* error_status */
+    { uint8_t es = 129; rcd_b(c, &es); }                        /* FFV1_Slice.cpp:336-340 */
+    if (c->cur - (c->mask < 0x100 ? 0 : 1) > c->end) return 14; /* IsUnderrun */
+    if (rcd_bytes_used(c) < coded_size) return 15;              /* FFV1-SLICE-JUNK, :297-299 */
     return 0;
 }
 
-int ffv1o_decode_frame(const ffv1o_params* p, const uint8_t* pkt, size_t size, int32_t* const planes[4])
+static int decode_slice(const ffv1o_params* p, const codec_ctx* k, const uint8_t* buf, size_t size, int first, int32_t* const planes[4])
 {
-    codec_ctx* k = malloc(sizeof *k);
-    codec_ctx_init(k, p);
-    const size_t tail = p->ec ? 8 : 3;
-    /* keyframe bit, FFV1_Frame.cpp:148-156 */
-    { rc_dec c; rcd_init2(&c, pkt, size, p->coder); uint8_t ks = 128; if (!rcd_b(&c, &ks)) { free(k); return 1; } }
+    const size_t tail = k->ec ? 8 : 3;
+    if (size < tail) return 10;
+    if (k->ec && ffv1o_crc32(buf, size)) return 11;             /* FFV1_Slice.cpp:247-249 */
+    rc_dec c; rcd_init(&c, buf, size - tail);
+    if (first) { uint8_t ks = 128; rcd_b(&c, &ks); }
+    rc_tables_from(c.one_state, c.zero_state, k->one_state);    /* :254-255 */
+    uint8_t hs[CONTEXT_SIZE]; memset(hs, 128, sizeof hs);
+    uint32_t sx = rcd_u(&c, hs), sy = rcd_u(&c, hs);
+    uint32_t sw1 = rcd_u(&c, hs), sh1 = rcd_u(&c, hs);
+    if (sx >= k->num_h || sy >= k->num_v || sw1 || sh1) return 12;
+    uint32_t idx[3] = { 0, 0, 0 };
+    for (uint32_t i = 0; i < k->set_index_count; i++) { idx[i] = rcd_u(&c, hs); if (idx[i] >= k->nsets) return 13; }   /* :159-168 */
+    (void)rcd_u(&c, hs); (void)rcd_u(&c, hs); (void)rcd_u(&c, hs);
+    uint32_t x0, y0, w, h;
+    slice_rect(p, k->num_h, k->num_v, sx, sy, &x0, &y0, &w, &h);
+    int r = decode_content(p, k, &c, idx, x0, y0, w, h, size - tail, planes);
+    if (r) return r;
+    if (k->ec && buf[size - 5]) return 16;                       /* error_status */
+    return 0;
+}
+
+/* ffv1_frame::Process (FFV1_Frame.cpp:134-228) for the stream k describes */
+static int decode_frame_ctx(const ffv1o_params* p, codec_ctx* k, const uint8_t* pkt, size_t size, int32_t* const planes[4])
+{
+    { rc_dec c; rcd_init(&c, pkt, size); uint8_t ks = 128; if (!rcd_b(&c, &ks)) return 1; }     /* keyframe bit, :148-156 (every frame is one: -g 1) */
+    if (k->version <= 1) {
+        /* no configuration record: one slice = the packet, its parameters in front of the samples (slice::Parse, FFV1_Slice.cpp:224-268) */
+        rc_dec c; rcd_init(&c, pkt, size);
+        { uint8_t ks = 128; rcd_b(&c, &ks); }
+        codec_ctx* s = calloc(1, sizeof *s);
+        int r = parse_parameters(&c, s, 0);
+        if (!r && !ctx_matches(s, p->pixfmt)) r = 8;
+        if (!r) {
+            rc_tables_from(c.one_state, c.zero_state, s->one_state);
+            const uint32_t idx[3] = { 0, 0, 0 };
+            r = decode_content(p, s, &c, idx, 0, 0, p->width, p->height, size, planes);
+        }
+        ctx_free(s);
+        return r;
+    }
+    const size_t tail = k->ec ? 8 : 3;
     /* split from the tail, FFV1_Frame.cpp:177-198 */
     size_t pos = size; uint32_t count = 0; int err = 0;
     while (pos && !err) {
@@ -854,8 +1036,15 @@ int ffv1o_decode_frame(const ffv1o_params* p, const uint8_t* pkt, size_t size, i
         err = decode_slice(p, k, pkt + pos, s, pos == 0, planes);
         count++;
     }
-    if (!err && count != p->num_h_slices * p->num_v_slices) err = 4;
-    free(k);
+    if (!err && count != k->num_h * k->num_v) err = 4;
+    return err;
+}
+
+int ffv1o_decode_frame(const ffv1o_params* p, const uint8_t* pkt, size_t size, int32_t* const planes[4])
+{
+    codec_ctx* k = ctx_from_params(p);
+    int err = decode_frame_ctx(p, k, pkt, size, planes);
+    ctx_free(k);
     return err;
 }
 
@@ -870,56 +1059,55 @@ int ffv1o_decode_payload(const ffv1o_params* p, const uint8_t* pkt, size_t size,
     return r;
 }
 
-/* parameters::Parse, FFV1_Parameters.cpp:23-183 (the subset of values this path emits is accepted;
- * anything else is reported as a mismatch). */
-int ffv1o_parse_config_record(const uint8_t* rec, size_t size, ffv1o_params* p)
+/* ffv1_frame::OutOfBand (FFV1_Frame.cpp:105-131): CRC, then parameters::Parse */
+static int parse_record(const uint8_t* rec, size_t size, codec_ctx* k)
 {
     if (size < 5) return 1;
     if (ffv1o_crc32(rec, size)) return 2;                          /* FFV1_Frame.cpp:116 */
     rc_dec c; rcd_init(&c, rec, size - 4);
-    uint8_t st[CONTEXT_SIZE]; memset(st, 128, sizeof st);
-    if (rcd_u(&c, st) != 3) return 3;
-    if (rcd_u(&c, st) < 4) return 4;
-    {
-        const uint32_t coder_type = rcd_u(&c, st);
-        if (coder_type != (p->coder == 2 ? 2u : 1u)) return 5;
-        if (coder_type == 2)                                             /* FFV1_Parameters.cpp:41-55 */
-            for (int i = 1; i < 256; i++)
-                if ((int32_t)one_state_default[i] + rcd_s(&c, st) != (int32_t)one_state_alt[i]) return 5;
-    }
-    uint32_t colorspace = rcd_u(&c, st);
-    uint32_t bps = rcd_u(&c, st);
-    int chroma = rcd_b(&c, st);
-    if (rcd_u(&c, st) || rcd_u(&c, st)) return 6;
-    int alpha = rcd_b(&c, st);
-    p->num_h_slices = rcd_u(&c, st) + 1;
-    p->num_v_slices = rcd_u(&c, st) + 1;
-    uint32_t nsets = rcd_u(&c, st);
-    if (nsets != 2) return 7;
-    if (colorspace != (uint32_t)is_rgb(p->pixfmt) || bps != ffv1o_bits_per_raw_sample(p->pixfmt) ||
-        chroma != is_rgb(p->pixfmt) || alpha != has_alpha(p->pixfmt)) return 8;
-    quant_set ref[2]; build_quant_sets_c(bps, ref, p->context_model == 2);
-    for (uint32_t i = 0; i < nsets; i++) {
-        int32_t scale = 1;
-        for (int j = 0; j < 5; j++) {
-            uint8_t qst[CONTEXT_SIZE]; memset(qst, 128, sizeof qst);
-            int32_t v = 0;
-            for (uint32_t kk = 0; kk < 128;) {
-                uint32_t len1 = rcd_u(&c, qst);
-                if (kk + len1 >= 128) return 9;
-                for (uint32_t a = 0; a <= len1; a++, kk++)
-                    if (ref[i].q[j][kk] != (int16_t)(scale * v)) return 10;
-                v++;
-            }
-            scale *= 2 * v - 1;
+    return parse_parameters(&c, k, 1);
+}
+
+/* The decoder as the reference runs it: everything about the stream comes from the stream -- the configuration record (rec_size > 0) or
+ * the header inside the packet (rec_size == 0) -- and only width, height, pixfmt and flags from p.  0 ok. */
+int ffv1o_decode_stream(const ffv1o_params* p, const uint8_t* rec, size_t rec_size, const uint8_t* pkt, size_t size, uint8_t* payload, size_t line_bytes)
+{
+    codec_ctx* k = calloc(1, sizeof *k);
+    int r = 0;
+    if (rec_size) { r = parse_record(rec, rec_size, k); if (!r && !ctx_matches(k, p->pixfmt)) r = 8; }
+    else k->version = 1;                                         /* (whatever the header in the packet then says: 0 or 1) */
+    size_t n = (size_t)p->width * p->height;
+    int32_t* planes[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < ffv1o_plane_count(p->pixfmt); i++) planes[i] = calloc(n, sizeof(int32_t));
+    if (!r) r = decode_frame_ctx(p, k, pkt, size, planes);
+    if (!r) ffv1o_pack(p, planes, payload, line_bytes);
+    for (int i = 0; i < 4; i++) free(planes[i]);
+    ctx_free(k);
+    return r;
+}
+
+/* The record against what this oracle's encoder would have written for p (and num_h, num_v, ec out of the record into p).  0 = same. */
+int ffv1o_parse_config_record(const uint8_t* rec, size_t size, ffv1o_params* p)
+{
+    codec_ctx* s = calloc(1, sizeof *s);
+    int r = parse_record(rec, size, s);
+    if (!r) {
+        p->num_h_slices = s->num_h; p->num_v_slices = s->num_v; p->ec = s->ec;
+        codec_ctx* k = ctx_from_params(p);
+        if (!ctx_matches(s, p->pixfmt)) r = 8;
+        else if (s->version != k->version || s->custom != k->custom || memcmp(s->one_state + 1, k->one_state + 1, 255)) r = 5;
+        else if (s->nsets != k->nsets) r = 7;
+        else if (s->intra != k->intra) r = 14;
+        for (uint32_t i = 0; !r && i < s->nsets; i++) {
+            if (memcmp(s->qs[i].q, k->qs[i].q, sizeof s->qs[i].q)) r = 10;
+            else if (s->qs[i].context_count != k->qs[i].context_count) r = 11;
+            else if ((s->init[i] != NULL) != (k->init[i] != NULL)) r = 12;
+            else if (s->init[i] && memcmp(s->init[i], k->init[i], (size_t)s->qs[i].context_count * CONTEXT_SIZE)) r = 12;
         }
-        if ((uint32_t)((scale + 1) >> 1) != ref[i].context_count) return 11;
+        ctx_free(k);
     }
-    for (uint32_t i = 0; i < nsets; i++) if (rcd_b(&c, st)) return 12;   /* states_coded */
-    p->ec = rcd_u(&c, st);
-    if (p->ec > 1) return 13;
-    if (rcd_u(&c, st) != 1) return 14;                                   /* intra */
-    return 0;
+    ctx_free(s);
+    return r;
 }
 
 int ffv1o_slices_to_grid(uint32_t n, uint32_t* num_h, uint32_t* num_v)

@@ -51,6 +51,28 @@ enum {
 #define FFV1O_FLAG_VFLIP  1u   /* picture line y is file line height-1-y (DPX orientation 2 + "-vf vflip", Main.cpp:207-211) */
 #define FFV1O_FLAG_ALTERN 2u   /* Y 10-bit only: words are filled across line ends, no line padding (DPX.cpp:363-368) */
 
+/* A stream laid out as freely as parameters::Parse reads one (FFV1_Parameters.cpp:23-183, :206-253): what FFmpeg's defaults never
+ * produce but the reference's decoder accepts -- up to 8 quantisation table sets of arbitrary level maps, a set index per plane
+ * group, any transmitted state-transition table, coded initial states, the version 0 / 1 header inside every frame.  Attached to
+ * ffv1o_params.ext; NULL there = the two FFmpeg-default sets of build_quant_sets_c. */
+typedef struct ffv1o_stream_ext {
+    uint32_t version;              /* 0 or 1: the header travels in every frame, one slice, no footer; 3: configuration record */
+    uint32_t micro_version;        /* version 3 only; the reference refuses < 4 (:36-37) */
+    uint32_t custom_transitions;   /* 1: coder_type 2, one_state[1..255] travels as deltas to the default table (:41-55) */
+    uint8_t  one_state[256];
+    uint32_t set_count;            /* quant_table_set_count, 1..8 (version 0 / 1: 1) */
+    uint8_t  levels[8][5][128];    /* level of |difference| k: 0 at k = 0, non-decreasing, steps of 1 (the record carries the run lengths, :222-253) */
+    uint32_t states_coded[8];      /* version 3: the set's initial states travel in the record */
+    const uint8_t* initial_states[8]; /* context_count x 32 states, stored the way the REFERENCE reads them: every value as it is
+                                         (`States[k] = E.s(States)`, :103-107) -- not RFC 9043's delta to the context before */
+    uint32_t set_index[3];         /* quant_table_set_index of plane group 0 (Y), 1 (Cb, Cr), 2 (alpha) in every slice header (FFV1_Slice.cpp:159-168) */
+    uint32_t intra;                /* version 3 record field; 1 = every frame is a key frame (-g 1).  (0 with key frames only is a valid stream too) */
+    uint32_t alt_slices;           /* 1: slices with odd sx + sy write set_index_alt instead -- the index is a per-SLICE field */
+    uint32_t set_index_alt[3];
+} ffv1o_stream_ext;
+/* contexts of set i of such a stream: (product over the five tables of (2 * levels - 1) + 1) / 2, FFV1_Parameters.cpp:206-219 */
+uint32_t ffv1o_ext_context_count(const ffv1o_stream_ext* e, uint32_t set);
+
 typedef struct {
     uint32_t width, height;
     uint32_t pixfmt;        /* FFV1O_* */
@@ -63,6 +85,7 @@ typedef struct {
                                then travels in the configuration record as 255 deltas (FFV1_Parameters.cpp:41-55) */
     uint32_t level;         /* -level: 0/3 = FFV1 version 3 (configuration record, slices, footers); 1 = version 1: one slice = the frame,
                                the header travels inside every frame after the keyframe bit, no footer (FFV1_Slice.cpp:224-268) */
+    const ffv1o_stream_ext* ext; /* NULL, or the stream's free-form description: then context_model, coder and level are ignored */
 } ffv1o_params;
 
 /* geometry helpers */
@@ -99,6 +122,12 @@ size_t ffv1o_encode_payload(const ffv1o_params* p, const uint8_t* payload, size_
 int ffv1o_decode_frame(const ffv1o_params* p, const uint8_t* pkt, size_t size, int32_t* const planes[4]);
 /* Convenience: decode + pack.  0 ok. */
 int ffv1o_decode_payload(const ffv1o_params* p, const uint8_t* pkt, size_t size, uint8_t* payload, size_t line_bytes);
+
+/* The decoder as the reference runs it (ffv1_frame::OutOfBand + Process): everything about the stream is read from the stream -- the
+ * configuration record, or with rec_size == 0 the header inside the packet (version 0 / 1) -- up to 8 arbitrary table sets, per-slice
+ * set indices, any transition table, coded initial states; p gives width, height, pixfmt, flags only.  0 ok, 20 / 21 = a valid stream
+ * outside this oracle (Golomb-Rice, YUV). */
+int ffv1o_decode_stream(const ffv1o_params* p, const uint8_t* rec, size_t rec_size, const uint8_t* pkt, size_t size, uint8_t* payload, size_t line_bytes);
 
 /* Parse a configuration record back into params (width/height/pixfmt are not in the record: the
  * caller supplies them; checks that the record agrees with them).  0 ok. */

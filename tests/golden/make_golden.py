@@ -74,6 +74,75 @@ FLAC = [  # name, ch, bits, rate, samples, kind
 ]
 
 
+# ---- streams FFmpeg's defaults never produce and the reference's decoder accepts (parameters::Parse, FFV1_Parameters.cpp:23-183,206-253;
+# slice::SliceHeader, FFV1_Slice.cpp:158-168): what the device `--check` decoder must take too.  Table sets as run lengths of equal levels.
+Q9 = [5, 8, 14, 29, 72]          # FFmpeg's 9-level and 5-level maps for > 8 bit, as in oracle/ffv1_oracle.c
+Q5 = [11, 53, 64]
+Q11_8 = [1, 1, 3, 7, 20, 96]
+Q5_8 = [1, 3, 124]
+ONE = [128]                      # one level: the input does not count
+SET_FFMPEG_3 = [Q9, Q9, Q9, ONE, ONE]
+SET_FFMPEG_5 = [Q9, Q9, Q5, Q5, Q5]
+SET_ODD_A = [[2, 5, 9, 30, 82], [7, 121], [1, 2, 4, 8, 16, 32, 65], ONE, ONE]           # 5 x 2 x 7 levels, three inputs
+SET_ODD_B = [[3, 125], [10, 20, 98], [40, 88], [6, 122], [1, 127]]                       # five inputs, 2-3 levels each
+SET_ODD_C = [[1, 1, 1, 1, 1, 1, 1, 121], [4, 4, 120], [128], [128], [16, 112]]           # q[3] has one level: Is5 is false although q[4] is not trivial (FFV1_Slice.cpp:453)
+SET_TINY = [[64, 64], ONE, ONE, ONE, ONE]                                                # 2 contexts
+SET_8BIT_5 = [Q11_8, Q11_8, Q5_8, Q5_8, Q5_8]
+
+
+def ext_random_transitions(seed):
+    """a transition table nobody ships: each state moves up by a random step, never to 0"""
+    import random
+    rnd = random.Random(seed)
+    one = [0] * 256
+    for i in range(1, 256):
+        one[i] = min(255, max(1, i + rnd.randint(1, 24) - (rnd.random() < 0.1) * rnd.randint(0, 12)))
+    return one
+
+
+def ext_initial_states(e, sets, seed, lo=30, hi=226):
+    import random
+    rnd = random.Random(seed)
+    out = {}
+    for i in sets:
+        n = ob.lib().ffv1o_ext_context_count(__import__("ctypes").byref(e), i) * 32
+        out[i] = bytes(rnd.randint(lo, hi) for _ in range(n))
+    return out
+
+
+def ext_cases():
+    """name, w, h, pixfmt, frames, kind, tiff, num_h, num_v, ec, ext kwargs, initial-state spec (sets, seed, lo, hi) or None"""
+    return [
+        ("ext_3sets_split_64x48", 64, 48, synth.PIX_RGB16_BE, 2, "film", False, 3, 2, 1, dict(sets=[SET_FFMPEG_3, SET_FFMPEG_5, SET_ODD_B], set_index=(2, 0, 0)), None),
+        ("ext_rgba_3groups_48x32", 48, 32, synth.PIX_RGBA16_BE, 1, "film", False, 2, 2, 1, dict(sets=[SET_ODD_A, SET_FFMPEG_3, SET_ODD_B], set_index=(1, 2, 0)), None),
+        ("ext_8sets_50x38", 50, 38, synth.PIX_RGB10_FILLEDA_BE, 1, "film", False, 3, 2, 1,
+         dict(sets=[SET_TINY, SET_ODD_A, SET_ODD_B, SET_FFMPEG_3, SET_ODD_C, SET_FFMPEG_5, SET_TINY, SET_ODD_A], set_index=(7, 4, 0)), None),
+        ("ext_one_set_tiny_40x30", 40, 30, synth.PIX_RGB16_LE, 1, "noise", True, 2, 2, 0, dict(sets=[SET_TINY], set_index=(0, 0, 0)), None),
+        ("ext_states_coded_64x48", 64, 48, synth.PIX_RGB16_BE, 2, "film", False, 2, 2, 1, dict(sets=[SET_ODD_A, SET_ODD_B], set_index=(1, 0, 0)), ([0, 1], 7, 30, 226)),
+        ("ext_states_coded_one_of_two_40x24", 40, 24, synth.PIX_Y16_BE, 1, "film", False, 2, 1, 1, dict(sets=[SET_ODD_B, SET_ODD_A], set_index=(1, 0, 0)), ([1], 9, 30, 226)),
+        ("ext_random_transitions_72x40", 72, 40, synth.PIX_RGB16_BE, 1, "film", False, 3, 2, 1,
+         dict(sets=[SET_FFMPEG_3, SET_FFMPEG_5], set_index=(1, 1, 1), one_state=ext_random_transitions(11)), None),
+        ("ext_all_at_once_48x32", 48, 32, synth.PIX_RGBA16_BE, 1, "film", False, 2, 2, 1,
+         dict(sets=[SET_ODD_C, SET_ODD_A, SET_ODD_B], set_index=(0, 2, 1), one_state=ext_random_transitions(12)), ([0, 2], 13, 40, 200)),
+        ("ext_gray_two_sets_40x24", 40, 24, synth.PIX_Y16_BE, 1, "noise", False, 2, 2, 1, dict(sets=[SET_FFMPEG_5, SET_ODD_A], set_index=(1, 0, 0)), None),
+        ("ext_v1_inband_custom_48x32", 48, 32, synth.PIX_RGB16_BE, 2, "film", False, 1, 1, 0, dict(version=1, sets=[SET_ODD_B], one_state=ext_random_transitions(14)), None),
+        ("ext_v0_rgb8_48x32", 48, 32, synth.PIX_RGB8, 1, "film", False, 1, 1, 0, dict(version=0, sets=[SET_8BIT_5]), None),
+        # valid streams the device decoder does not take: the reference decodes them, route C must fall back to the slice pool.  The set index is
+        # a per-SLICE field (the device wants one tuple per stream and finds out while decoding); intra = 0 with key frames only (refused up front)
+        ("ext_unsup_per_slice_sets_64x48", 64, 48, synth.PIX_RGB16_BE, 2, "film", False, 3, 2, 1, dict(sets=[SET_ODD_A, SET_ODD_B], set_index=(1, 0, 0), set_index_alt=(0, 1, 0)), None),
+        ("ext_unsup_intra0_64x48", 64, 48, synth.PIX_RGB16_BE, 2, "film", False, 2, 2, 1, dict(sets=[SET_FFMPEG_3, SET_FFMPEG_5], set_index=(1, 1, 1), intra=0), None),
+    ]
+
+
+def build_ext(case):
+    name, w, h, pixfmt, nframes, kind, tiff, nh, nv, ec, kw, init = case
+    e = ob.stream_ext(**kw)
+    if init:
+        sets, seed, lo, hi = init
+        e = ob.stream_ext(initial_states=ext_initial_states(e, sets, seed, lo, hi), **kw)
+    return e
+
+
 def run(cmd, cwd):
     return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=120)
 
@@ -130,6 +199,66 @@ def main():
         vectors["ffv1"].append(entry)
         shutil.rmtree(work)
         print("ffv1", name, "reference ok")
+    vectors["ffv1_ext"] = []
+    for case in ext_cases():
+        name, w, h, pixfmt, nframes, kind, tiff, nh, nv, ec, kw, init = case
+        work = tempfile.mkdtemp()
+        os.makedirs(work + "/seq")
+        bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+        files = []
+        for i in range(nframes):
+            comp = synth.components(w, h, nc, bits, kind, seed=17 * i + 3)
+            data = synth.tiff_file(comp, pixfmt, trailer=b"xyz") if tiff else synth.dpx_file(comp, pixfmt, frame_index=i)
+            fn = work + "/seq/f_%06d.%s" % (i, "tif" if tiff else "dpx")
+            open(fn, "wb").write(data)
+            files.append(fn)
+        r = run([REF, "--hash", "--no-check-padding", "--check", "-d", "-y", "seq"], work)
+        assert r.returncode == 0, r.stderr
+        first = open(files[0], "rb").read()
+        info = api.tiff_probe(first) if tiff else api.dpx_probe(first)
+        e = build_ext(case)
+        # the description, in a form tests/ rebuild it from without this script (ob.stream_ext(**ext)); initial states as files
+        ext_json = dict(kw)
+        if init:
+            ext_json["initial_states"] = {}
+            for i, buf in zip(init[0], e._keep):
+                open(os.path.join(HERE, f"ffv1_{name}.init{i}.bin"), "wb").write(buf.raw)
+                ext_json["initial_states"][str(i)] = f"ffv1_{name}.init{i}.bin"
+        p = ob.with_ext(ob.Params(w, h, pixfmt, nh, nv, ec), e)
+        rec = ob.config_record(p)
+        assert bool(rec) == (e.version == 3)
+        mux = api.MkvMuxer(work + "/seq.mkv")
+        t = mux.add_video(rec, w, h, 24, 1)
+        mux.add_attachment("RAWcooked reversibility data", open(work + "/seq.rawcooked_reversibility_data", "rb").read())
+        mux.begin()
+        entry = {"name": name, "width": w, "height": h, "pixfmt": pixfmt, "num_h": nh, "num_v": nv, "line_bytes": info.line_bytes, "ec": ec, "flags": 0,
+                 "version": e.version, "flavor": info.flavor.decode(), "config_record": "", "ext": ext_json, "frames": []}
+        if len(rec) <= 4096:
+            entry["config_record"] = rec.hex()
+        else:                                                    # coded initial states: 32 symbols per context
+            open(os.path.join(HERE, f"ffv1_{name}.record.bin"), "wb").write(rec)
+            entry["config_record_file"] = f"ffv1_{name}.record.bin"
+        for i, fn in enumerate(files):
+            b = open(fn, "rb").read()
+            payload = b[info.data_offset:info.data_offset + info.data_size]
+            pkt = ob.encode_payload(p, payload, info.line_bytes)
+            code, back = ob.decode_stream(ob.Params(w, h, pixfmt), rec, pkt, info.line_bytes)      # the oracle's own reading of what it wrote
+            assert code == 0 and back == payload, (name, code)
+            mux.write_block(t, i * 1000000000 // 24, pkt)
+            open(os.path.join(HERE, f"ffv1_{name}_{i}.payload.bin"), "wb").write(payload)
+            open(os.path.join(HERE, f"ffv1_{name}_{i}.packet.bin"), "wb").write(pkt)
+            entry["frames"].append({"payload": f"ffv1_{name}_{i}.payload.bin", "packet": f"ffv1_{name}_{i}.packet.bin",
+                                    "payload_sha256": hashlib.sha256(payload).hexdigest(), "packet_sha256": hashlib.sha256(pkt).hexdigest()})
+        mux.close()
+        r = run([REF, "--check", "seq.mkv"], work)
+        ok = r.returncode == 0 and OK in r.stdout
+        r2 = run([REF, "-y", "seq.mkv"], work)
+        same = all(open(f, "rb").read() == open(work + "/seq.mkv.RAWcooked/seq/" + os.path.basename(f), "rb").read() for f in files)
+        entry["reference_check"] = bool(ok and r2.returncode == 0 and same)
+        assert entry["reference_check"], (name, r.stdout, r.stderr)
+        vectors["ffv1_ext"].append(entry)
+        shutil.rmtree(work)
+        print("ffv1_ext", name, "reference ok", len(rec), "byte record")
     for name, ch, bits, rate, n, kind in FLAC:
         work = tempfile.mkdtemp()
         os.makedirs(work + "/aud")

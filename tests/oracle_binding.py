@@ -8,8 +8,78 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _lib = None
 
 
+class StreamExt(C.Structure):
+    """ffv1o_stream_ext: a stream laid out as freely as parameters::Parse reads one (oracle/ffv1_oracle.h)."""
+    _fields_ = [("version", C.c_uint32), ("micro_version", C.c_uint32), ("custom_transitions", C.c_uint32), ("one_state", C.c_uint8 * 256),
+                ("set_count", C.c_uint32), ("levels", C.c_uint8 * 128 * 5 * 8), ("states_coded", C.c_uint32 * 8),
+                ("initial_states", C.c_void_p * 8), ("set_index", C.c_uint32 * 3), ("intra", C.c_uint32), ("alt_slices", C.c_uint32),
+                ("set_index_alt", C.c_uint32 * 3)]
+
+
 class Params(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "pixfmt", "num_h_slices", "num_v_slices", "ec", "context_model", "flags", "coder", "level")]
+    _fields_ = [(n, C.c_uint32) for n in ("width", "height", "pixfmt", "num_h_slices", "num_v_slices", "ec", "context_model", "flags", "coder", "level")] + [("ext", C.POINTER(StreamExt))]
+
+
+def levels_from_runs(runs):
+    """run lengths of equal levels (what the record carries, FFV1_Parameters.cpp:222-253) -> the level of every |difference| 0..127"""
+    out = []
+    for level, r in enumerate(runs):
+        out += [level] * r
+    assert len(out) == 128, (runs, len(out))
+    return out
+
+
+def stream_ext(version=3, sets=None, set_index=(0, 0, 0), one_state=None, initial_states=None, micro_version=4, intra=1, set_index_alt=None):
+    """sets: list of table sets, each five lists of run lengths; initial_states: {set: bytes(context_count * 32)}.  The returned object keeps
+    the buffers it points to alive (`_keep`)."""
+    e = StreamExt()
+    e.version, e.micro_version, e.intra = version, micro_version, intra
+    if one_state is not None:
+        e.custom_transitions = 1
+        for i, v in enumerate(one_state):
+            e.one_state[i] = v
+    e.set_count = len(sets)
+    for i, st in enumerate(sets):
+        for j, runs in enumerate(st):
+            for k, lv in enumerate(levels_from_runs(runs)):
+                e.levels[i][j][k] = lv
+    for g in range(3):
+        e.set_index[g] = set_index[g]
+    if set_index_alt is not None:                     # the slices with odd sx + sy say so instead: the index is a per-slice field
+        e.alt_slices = 1
+        for g in range(3):
+            e.set_index_alt[g] = set_index_alt[g]
+    e._keep = []
+    for i, b in (initial_states or {}).items():
+        assert len(b) == lib().ffv1o_ext_context_count(C.byref(e), i) * 32
+        buf = C.create_string_buffer(bytes(b), len(b))
+        e._keep.append(buf)
+        e.states_coded[i] = 1
+        e.initial_states[i] = C.cast(buf, C.c_void_p)
+    return e
+
+
+def stream_ext_from_vector(v, golden_dir):
+    """the `ext` entry of a tests/golden/vectors.json ffv1_ext vector -> StreamExt"""
+    import os
+    kw = dict(v["ext"])
+    if "initial_states" in kw:
+        kw["initial_states"] = {int(i): open(os.path.join(golden_dir, fn), "rb").read() for i, fn in kw["initial_states"].items()}
+    return stream_ext(**kw)
+
+
+def with_ext(p: Params, e: StreamExt) -> Params:
+    q = Params(p.width, p.height, p.pixfmt, p.num_h_slices, p.num_v_slices, p.ec, p.context_model, p.flags, p.coder, p.level)
+    q.ext = C.pointer(e)
+    q._keep = e
+    return q
+
+
+def decode_stream(p: Params, record: bytes, packet: bytes, line_bytes: int):
+    """ffv1o_decode_stream: everything about the stream from the record / the packet itself.  -> (error code, payload)"""
+    out = C.create_string_buffer(lib().ffv1o_payload_bytes(C.byref(p), C.c_size_t(line_bytes)))
+    r = lib().ffv1o_decode_stream(C.byref(p), record, C.c_size_t(len(record)), packet, C.c_size_t(len(packet)), out, C.c_size_t(line_bytes))
+    return r, out.raw
 
 
 def lib():
@@ -30,8 +100,8 @@ def lib():
 
 
 def config_record(p: Params) -> bytes:
-    buf = C.create_string_buffer(8192)
-    n = lib().ffv1o_config_record(C.byref(p), buf, C.c_size_t(8192))
+    buf = C.create_string_buffer(1 << 22)                 # coded initial states: up to 32768 x 32 symbols a set
+    n = lib().ffv1o_config_record(C.byref(p), buf, C.c_size_t(len(buf)))
     return buf.raw[:n]
 
 

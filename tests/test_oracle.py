@@ -29,6 +29,34 @@ def test_ffv1_golden(built, v):
         assert ob.decode_payload(p, packet, v["line_bytes"]) == payload          # decoder restatement (FFV1_Frame/Slice.cpp)
 
 
+def ext_record(v):
+    return open(os.path.join(G, v["config_record_file"]), "rb").read() if "config_record_file" in v else bytes.fromhex(v["config_record"])
+
+
+@pytest.mark.parametrize("v", VEC["ffv1_ext"], ids=lambda v: v["name"])
+def test_ffv1_ext_golden(built, v):
+    """Streams FFmpeg's defaults never produce (up to 8 table sets of arbitrary level maps, a set per plane group or per slice, a transmitted
+    transition table, coded initial states, the version 0 / 1 header inside the frame): each one was checked and decoded by the real
+    reference (tests/golden/make_golden.py); the oracle writes these bytes from the description and reads them back knowing only the
+    picture's geometry -- parameters::Parse restated (FFV1_Parameters.cpp:23-183,206-253)."""
+    assert v["reference_check"]
+    e = ob.stream_ext_from_vector(v, G)
+    p = ob.with_ext(ob.Params(v["width"], v["height"], v["pixfmt"], v["num_h"], v["num_v"], v["ec"]), e)
+    rec = ext_record(v)
+    assert ob.config_record(p) == rec and bool(rec) == (v["version"] == 3)
+    for fr in v["frames"]:
+        payload = open(os.path.join(G, fr["payload"]), "rb").read()
+        packet = open(os.path.join(G, fr["packet"]), "rb").read()
+        assert hashlib.sha256(payload).hexdigest() == fr["payload_sha256"] and hashlib.sha256(packet).hexdigest() == fr["packet_sha256"]
+        assert ob.encode_payload(p, payload, v["line_bytes"]) == packet
+        code, back = ob.decode_stream(ob.Params(v["width"], v["height"], v["pixfmt"]), rec, packet, v["line_bytes"])
+        assert code == 0 and back == payload
+        bad = bytearray(packet)
+        bad[len(bad) // 3] ^= 0x40                      # (not the middle: with four slices of noise that is the slack at the end of a slice)
+        code, back = ob.decode_stream(ob.Params(v["width"], v["height"], v["pixfmt"]), rec, bytes(bad), v["line_bytes"])
+        assert code != 0 or back != payload
+
+
 @pytest.mark.parametrize("v", VEC["flac"], ids=lambda v: v["name"])
 def test_flac_golden(built, v):
     pcm = open(os.path.join(G, v["pcm"]), "rb").read()
