@@ -371,6 +371,35 @@ int  rcgpu_ffv1_config_from_record(const uint8_t* record, size_t size, rcgpu_ffv
 /* The same plus the one stream fact the record does not hold: which of its table sets the planes use (quant_table_set_index in every
  * slice header, FFV1_Slice.cpp:159-168), read from the first slice header of `packet` (the first frame of the track). */
 int  rcgpu_ffv1_config_from_stream(const uint8_t* record, size_t size, const uint8_t* packet, size_t packet_size, rcgpu_ffv1_config* cfg);
+/* ---- Any stream the reference's decoder takes.  The two calls above describe a stream through rcgpu_ffv1_config, which can only say
+ * what this library's ENCODER writes (FFmpeg's default table sets or the compact model, every plane on the same set, one of two known
+ * transition tables).  `--check` also meets files other encoders wrote.  rcgpu_ffv1_stream_parse reads a stream the way
+ * parameters::Parse does (Lib/CoDec/FFV1/FFV1_Parameters.cpp:23-183, tables :206-253): versions 0, 1 (no CodecPrivate: record = NULL,
+ * record_size = 0 and the header is read out of `packet`, slice::Parse FFV1_Slice.cpp:224-245) and 3, coder_type 1 and 2 with ANY
+ * transmitted transition table (:41-55), 1 to 8 quantisation table sets of arbitrary tables up to 32 768 contexts, coded initial states
+ * (states_coded, read as the reference reads them, :103-107), and from the first slice header of `packet` -- the first frame of the
+ * track -- the quant_table_set_index of every plane group (FFV1_Slice.cpp:158-168).
+ *   return 0                       parsed; *stream must be freed with rcgpu_ffv1_stream_free
+ *   return RCGPU_FFV1_UNSUPPORTED  a valid stream the device decoder does not take (Golomb-Rice; and from _create_for_stream: YUV planes,
+ *                                  inter frames, a state 0 within reach of the initial states): the caller decodes it with its own decoder --
+ *                                  ffv1_frame::Process stays on its slice pool (oracle/route_c_ffv1_frame_cpp.patch)
+ *   any other value                what the reference refuses as well (its error in rcgpu_last_error())
+ * rcgpu_ffv1_decoder_create_for_stream takes width, height, pixfmt, line_bytes, flags, max_batch and device from `files` (the stream fields
+ * of the struct are ignored) and everything else from `stream`; it fails when the stream does not describe `pixfmt` (colorspace, bit
+ * depth, alpha).  The decoder it makes is used like any other; a slice whose header names other table sets than the first slice did
+ * (they are per-slice fields) is reported as undecodable (flag 32) and left to the caller's decoder. */
+#define RCGPU_FFV1_UNSUPPORTED 20
+typedef struct rcgpu_ffv1_stream rcgpu_ffv1_stream;
+typedef struct {
+    uint32_t version, micro_version, coder_type /* 1, or 2 = transmitted transitions */, colorspace_type, bits_per_raw_sample;
+    uint32_t chroma_planes, alpha_plane, num_h_slices, num_v_slices, quant_table_set_count, ec, intra;
+    uint32_t quant_table_set_index_count, quant_table_set_index[3];   /* plane group 0 (Y), 1 (Cb, Cr), 2 (alpha) */
+    uint32_t context_count[8], states_coded[8];
+} rcgpu_ffv1_stream_info;
+int  rcgpu_ffv1_stream_parse(const uint8_t* record, size_t record_size, const uint8_t* packet, size_t packet_size, rcgpu_ffv1_stream** stream);
+void rcgpu_ffv1_stream_free(rcgpu_ffv1_stream* stream);
+int  rcgpu_ffv1_stream_get_info(const rcgpu_ffv1_stream* stream, rcgpu_ffv1_stream_info* info);
+int  rcgpu_ffv1_decoder_create_for_stream(const rcgpu_ffv1_config* files, const rcgpu_ffv1_stream* stream, rcgpu_ffv1_decoder** dec);
 int  rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* dec, float ms[3]);   /* split+crc, slices, pack */
 /* First differing byte of two device buffers; *first_diff = UINT64_MAX when they are equal (FileWriter.cpp:448-463). */
 int  rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t* first_diff, void* hip_stream);

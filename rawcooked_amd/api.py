@@ -19,7 +19,12 @@ if os.environ.get("RCGPU_LIB"):      # the measuring tools load the timing build
 
 
 class RcgpuError(RuntimeError):
-    pass
+    code = 0
+
+
+class RcgpuUnsupported(RcgpuError):
+    """RCGPU_FFV1_UNSUPPORTED: a valid stream the device decoder does not take -- the caller's own decoder does"""
+    code = 20
 
 
 class ImageInfo(C.Structure):
@@ -38,6 +43,12 @@ class Ffv1Config(C.Structure):
                 ("num_h_slices", C.c_uint32), ("num_v_slices", C.c_uint32), ("slicecrc", C.c_uint32), ("context", C.c_uint32),
                 ("max_batch", C.c_uint32), ("device", C.c_int), ("segments", C.c_uint32), ("flags", C.c_uint32), ("coder", C.c_uint32), ("level", C.c_uint32),
                 ("rc_span", C.c_uint32), ("slice_buffer_div", C.c_uint32)]
+
+
+class Ffv1StreamInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("version", "micro_version", "coder_type", "colorspace_type", "bits_per_raw_sample", "chroma_planes", "alpha_plane",
+                                          "num_h_slices", "num_v_slices", "quant_table_set_count", "ec", "intra", "quant_table_set_index_count")] + \
+               [("quant_table_set_index", C.c_uint32 * 3), ("context_count", C.c_uint32 * 8), ("states_coded", C.c_uint32 * 8)]
 
 
 READ_FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t)
@@ -140,6 +151,10 @@ SYMBOLS = {
     "rcgpu_ffv1_decoder_verify_kept_end": (C.c_int, [_VP, _VP]),
     "rcgpu_ffv1_config_from_record": (C.c_int, [_U8P, _SZ, C.POINTER(Ffv1Config)]),
     "rcgpu_ffv1_config_from_stream": (C.c_int, [_U8P, _SZ, _U8P, _SZ, C.POINTER(Ffv1Config)]),
+    "rcgpu_ffv1_stream_parse": (C.c_int, [_U8P, _SZ, _U8P, _SZ, C.POINTER(_VP)]),
+    "rcgpu_ffv1_stream_free": (None, [_VP]),
+    "rcgpu_ffv1_stream_get_info": (C.c_int, [_VP, C.POINTER(Ffv1StreamInfo)]),
+    "rcgpu_ffv1_decoder_create_for_stream": (C.c_int, [C.POINTER(Ffv1Config), _VP, C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rcgpu_compare_device": (C.c_int, [_VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     "rcgpu_compare_device_batch": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _VP, _VP]),
@@ -190,7 +205,9 @@ def last_error() -> str:
 
 def _check(rc: int, what: str) -> None:
     if rc != 0:
-        raise RcgpuError(f"{what} failed ({rc}): {last_error()}")
+        e = (RcgpuUnsupported if rc == RcgpuUnsupported.code else RcgpuError)(f"{what} failed ({rc}): {last_error()}")
+        e.code = rc
+        raise e
 
 
 def dpx_probe(data: bytes) -> ImageInfo:
@@ -392,13 +409,38 @@ class KeptVerdict(C.Structure):
     _fields_ = [("md5", C.c_uint8 * 16), ("first_diff", C.c_uint64)]
 
 
+class Ffv1Stream:
+    """rcgpu_ffv1_stream: a stream as parameters::Parse reads it (FFV1_Parameters.cpp:23-183) -- record = CodecPrivate or b"" (version 0 / 1:
+    the header is inside `packet`), packet = the first frame of the track."""
+
+    def __init__(self, record: bytes, packet: bytes):
+        self.h = _VP()
+        _check(lib().rcgpu_ffv1_stream_parse(record if record else None, len(record), packet, len(packet), C.byref(self.h)), "rcgpu_ffv1_stream_parse")
+
+    def info(self) -> Ffv1StreamInfo:
+        i = Ffv1StreamInfo()
+        _check(lib().rcgpu_ffv1_stream_get_info(self.h, C.byref(i)), "rcgpu_ffv1_stream_get_info")
+        return i
+
+    def close(self):
+        if self.h:
+            lib().rcgpu_ffv1_stream_free(self.h)
+            self.h = _VP()
+
+    __del__ = close
+
+
 class Ffv1Decoder:
     """Device FFV1 decoder + pack (the --check half).  Buffers are device pointers (ints)."""
 
-    def __init__(self, width, height, pixfmt, line_bytes, num_h, num_v, slicecrc=1, context=1, max_batch=1, device=0, flags=0, coder=1, level=3):
+    def __init__(self, width, height, pixfmt, line_bytes, num_h=0, num_v=0, slicecrc=1, context=1, max_batch=1, device=0, flags=0, coder=1, level=3, stream=None):
+        """stream = None: the stream this library's encoder writes for these fields; an Ffv1Stream: whatever it says (num_h ... level ignored)"""
         self.cfg = Ffv1Config(width, height, pixfmt, line_bytes, num_h, num_v, slicecrc, context, max_batch, device, 0, flags, coder, level)
         self.h = _VP()
-        _check(lib().rcgpu_ffv1_decoder_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_decoder_create")
+        if stream is not None:
+            _check(lib().rcgpu_ffv1_decoder_create_for_stream(C.byref(self.cfg), stream.h, C.byref(self.h)), "rcgpu_ffv1_decoder_create_for_stream")
+        else:
+            _check(lib().rcgpu_ffv1_decoder_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_decoder_create")
 
     def close(self):
         if self.h:

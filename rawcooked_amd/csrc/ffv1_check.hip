@@ -54,10 +54,13 @@ struct dec_const {
     uint32_t W, H, line_bytes, pixfmt;
     uint32_t planes, bps, bits, rgb, gb_swap, big_endian, bytes_pp, overflow16;
     uint32_t fields, fill, vflip, altern;  // payload layout of the bit-packed DPX flavors (rc_common.h kFields*), RCGPU_FLAG_*
-    uint32_t num_h, num_v, S, nctx, nsets, ec, is5, index_count, qidx;
-    uint32_t v1, hdr_n;                    // FFV1 version 1: one slice = the packet, hdr_n header decisions in front of it, no footer
+    uint32_t num_h, num_v, S, ngroups, ec, index_count;
+    // per plane group (0 = Y, 1 = Cb and Cr, 2 = alpha; Line(), FFV1_Slice.cpp:447-455): the quant_table_set_index every slice header must
+    // name, whether its table set looks at five neighbours (QuantTables[3][127] != 0, :453), its contexts and where they start in a lane's states
+    uint32_t idx[3], is5[3], nctx[3], kbase[3];
+    uint32_t v1, hdr_n;                    // FFV1 version 0 / 1: one slice = the packet, hdr_n header decisions in front of it, no footer
     uint32_t win_cap;                      // bytes a lane's window is filled up to (7; rcgpu_ffv1_decoder_debug_window makes it less, for the tests of the careful path)
-    int16_t  q[5][256];
+    int16_t  q[3][5][256];                 // the table set of each plane group (the same tables three times when the planes share a set)
     uint8_t  one_state[256], zero_state[256];
 };
 
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
 {
     __shared__ uint8_t trans[512];
     __shared__ uint16_t t16[256];
-    __shared__ int16_t q[5][256];
+    __shared__ int16_t qs[3][5][256];
     __shared__ __attribute__((aligned(16))) uint8_t slot[64 * 32];
     const int lane = threadIdx.x;
     // Every wavefront of this kernel has the same work and the kernel ends with its slowest one.  A wavefront of another kernel on the same
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     // decoder's instructions go first and the hash takes the slots the decoder leaves while it waits for memory.
     __builtin_amdgcn_s_setprio(3);
     for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; t16[i] = uint16_t(C->zero_state[i] | C->one_state[i] << 8); }
-    for (int i = lane; i < 5 * 256; i += 64) (&q[0][0])[i] = (&C->q[0][0])[i];
+    for (int i = lane; i < 3 * 5 * 256; i += 64) (&qs[0][0][0])[i] = (&C->q[0][0][0])[i];
     __syncthreads();
     const uint32_t chain = blockIdx.x * 64 + lane;
     if (chain >= nchains) return;
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     sx = rd_u(r, my, trans); sy = rd_u(r, my, trans);
     const uint32_t sw1 = rd_u(r, my, trans), sh1 = rd_u(r, my, trans);
     bad = sx >= C->num_h || sy >= C->num_v || sw1 || sh1;
-    for (uint32_t i = 0; i < C->index_count; i++) bad |= rd_u(r, my, trans) != C->qidx;
+    for (uint32_t i = 0; i < C->index_count; i++) bad |= rd_u(r, my, trans) != C->idx[i];      // per-slice fields (FFV1_Slice.cpp:158-168); one tuple per stream here
     (void)rd_u(r, my, trans); (void)rd_u(r, my, trans); (void)rd_u(r, my, trans);
     }
     if (bad) { atomicOr(err, 32u); return; }
@@ -466,16 +469,20 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     constexpr size_t xs = RING ? 64 : 1;                                         // distance between neighbouring columns, in elements
     const size_t pstride = plane_sz * xs;                                        // distance between planes
     int32_t* fp = RING ? planes + size_t(blockIdx.x) * 64 * np * plane_sz + lane : planes + size_t(f) * np * plane_sz + size_t(y0) * W + x0;
-    uint8_t* st_base = states + size_t(chain) * nkeys * 32;          // pre-set to 128 by the host (states_coded = 0)
-    const bool is5 = C->is5, ov16 = C->overflow16, rgb = C->rgb;
+    uint8_t* st_base = states + size_t(chain) * nkeys * 32;          // pre-set by the host: 128, or the set's coded initial states (k_dec_preset)
+    const bool ov16 = C->overflow16, rgb = C->rgb;
     const int32_t bitmask = int32_t((1u << C->bits) - 1);
-    const uint32_t nctx = C->nctx;
+    const uint32_t five = C->is5[0] | C->is5[1] << 1 | C->is5[2] << 2, kb0 = C->kbase[0], kb1 = C->kbase[1], kb2 = C->kbase[2];
     for (uint32_t y = 0; y < h; y++)
         for (uint32_t p = 0; p < np; p++) {
+            // the plane's group: its table set, its contexts (uniform over the wavefront -- every lane is at the same plane)
+            const uint32_t g = rgb ? (p + 1) >> 1 : 0;
+            const int16_t (*q)[256] = qs[g];
+            const bool is5 = (five >> g) & 1;
+            const uint32_t kbase = g == 0 ? kb0 : g == 1 ? kb1 : kb2;
             int32_t* cur = fp + p * pstride + size_t(RING ? y % 3 : y) * pitch * xs;
             const int32_t* prev = RING ? fp + p * pstride + size_t((y + 2) % 3) * pitch * xs : cur - W;                  // valid when y >= 1
             const int32_t* pp = RING ? fp + p * pstride + size_t((y + 1) % 3) * pitch * xs : cur - 2 * size_t(W);        // valid when y >= 2
-            const uint32_t set = rgb ? (p + 1) >> 1 : 0;
             // edge rules of SliceContent_LineThenPlane (FFV1_Slice.cpp:427-441): cur[-1] = prev[0], prev[w] = prev[w-1],
             // everything above the slice is 0, cur[-2] is 0
             int32_t L = y ? prev[0] : 0, LL = 0;
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
                 const int32_t RT = RTn, TT = TTn;
                 int32_t ctx = q[0][(L - LT) & 0xFF] + q[1][(LT - T) & 0xFF] + q[2][(T - RT) & 0xFF];
                 if (is5) ctx += q[3][(LL - L) & 0xFF] + q[4][(TT - T) & 0xFF];
-                const uint32_t key = set * nctx + uint32_t(ctx < 0 ? -ctx : ctx);
+                const uint32_t key = kbase + uint32_t(ctx < 0 ? -ctx : ctx);
                 uint4* gp = reinterpret_cast<uint4*>(st_base + size_t(key) * 32);
                 const uint4 a0 = gp[0], a1 = gp[1];
                 asm volatile("" ::: "memory");                        // the gather is issued before the loads below, not behind them
@@ -549,6 +556,14 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     if (C->ec && buf[len - 5]) atomicOr(err, 256u);                  // error_status
 }
 
+
+// states_coded = 1: every chain's context states start as the stream's initial states (coder_rangecoder::GOP_Init copies them at every key frame,
+// Coder/FFV1_Coder_RangeCoder.cpp:34-57) -- `init` holds one chain's worth (nkeys x 32 bytes = n16 uint4), written to every chain
+__global__ __launch_bounds__(256) void k_dec_preset(uint4* __restrict__ states, const uint4* __restrict__ init, uint32_t n16, unsigned long long total)
+{
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * 256)
+        states[i] = init[i % n16];
+}
 
 // k_pack for the word-stream layouts (rc_common.h kFields*): one thread per 32-bit word of the payload assembles every field that
 // touches it, so no two threads write the same word.  Restates the From() loops of Transform.cpp:214-322 (RGB 12-bit packed),
@@ -778,6 +793,7 @@ struct rcgpu_ffv1_decoder {
     const uint8_t** d_pkt_ptrs = nullptr; uint8_t** d_out_ptrs = nullptr; unsigned long long* d_sizes = nullptr;
     unsigned long long* d_slice_start = nullptr; uint32_t* d_slice_len = nullptr; uint16_t* d_hdr = nullptr;
     uint8_t* d_states = nullptr; int32_t* d_planes = nullptr; uint32_t* d_err = nullptr;
+    uint8_t* d_init = nullptr;                     // one chain's initial states when the stream codes them (states_coded), else null: all 128
     void** h_ptrs = nullptr; unsigned long long* h_sizes = nullptr;
     hipStream_t own_stream = nullptr;
     hipStream_t dec_stream = nullptr;              // k_dec_slices' stream when the hash has CUs of its own (partition_streams), else null
@@ -820,7 +836,7 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     if (!d) return;
     (void)hipSetDevice(d->cfg.device);
     if (d->hint.active) { d->hint.th.join(); d->hint.active = false; }
-    void* bufs[] = { d->d_const, d->d_pkt_ptrs, d->d_out_ptrs, d->d_sizes, d->d_slice_start, d->d_slice_len, d->d_states, d->d_planes, d->d_err, d->d_hdr };
+    void* bufs[] = { d->d_const, d->d_pkt_ptrs, d->d_out_ptrs, d->d_sizes, d->d_slice_start, d->d_slice_len, d->d_states, d->d_planes, d->d_err, d->d_hdr, d->d_init };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (d->h_ptrs) (void)hipHostFree(d->h_ptrs);
     if (d->h_sizes) (void)hipHostFree(d->h_sizes);
@@ -841,11 +857,12 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     delete d;
 }
 
-extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1_decoder** out)
+// The decoder of the stream `s` for pictures laid out as `files` says (width, height, pixfmt, line_bytes, flags; max_batch, device).
+static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_desc& s, rcgpu_ffv1_decoder** out)
 {
-    clear_error();
-    if (!cfg || !out) return fail(1, "ffv1 decoder: null argument");
-    *out = nullptr;
+    rcgpu_ffv1_config cfg_ = *files;
+    rcgpu_ffv1_config* cfg = &cfg_;
+    cfg->num_h_slices = s.num_h_slices; cfg->num_v_slices = s.num_v_slices; cfg->slicecrc = s.ec; cfg->level = s.version <= 1 ? 1 : 3; cfg->coder = s.custom_transitions ? 2 : 1;
     if (cfg->pixfmt >= RCGPU_PIX_COUNT || !cfg->width || !cfg->height || !cfg->num_h_slices || !cfg->num_v_slices || !cfg->max_batch)
         return fail(2, "ffv1 decoder: bad configuration");
     if ((unsigned long long)cfg->width * cfg->height * 4 >= (1ull << 32)) return fail(2, "ffv1 decoder: %ux%u: sample indices are 32 bit (a picture may hold 2^30 pixels)", cfg->width, cfg->height);
@@ -857,43 +874,60 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     if ((cfg->flags & RCGPU_FLAG_VFLIP) && altern) return fail(2, "ffv1 decoder: RCGPU_FLAG_VFLIP and RCGPU_FLAG_ALTERN exclude each other");
     if (!altern && cfg->line_bytes < payload_line_bytes(cfg->pixfmt, cfg->width, false)) return fail(2, "ffv1 decoder: line_bytes smaller than a line");
     if (px.fields != kFieldsBytes && px.fields != kFieldsExr && !altern && cfg->line_bytes % 4) return fail(2, "ffv1 decoder: line_bytes of a word-stream layout must be a multiple of 4");
+    // the stream against the files, and against what the device decodes
+    const bool rgb = px.planes != 1;
+    if (s.colorspace_type == 0 && s.chroma_planes) return fail(ffv1::kUnsupported, "ffv1 decoder: YCbCr planes are not decoded on the device");
+    if (s.colorspace_type != (rgb ? 1u : 0u) || s.bits_per_raw_sample != px.bits || s.chroma_planes != rgb || s.alpha_plane != (px.planes == 4))
+        return fail(5, "ffv1 decoder: stream (colorspace %u, %u bit%s) does not match the pixel format of the files", s.colorspace_type, s.bits_per_raw_sample, s.alpha_plane ? ", alpha" : "");
+    if (s.version == 3 && s.intra != 1) return fail(ffv1::kUnsupported, "ffv1 decoder: inter frames (intra = 0) are not decoded on the device");
+    if (s.version == 3 && (s.num_h_slices >= cfg->width || s.num_v_slices >= cfg->height || s.num_h_slices > 0xFFFF || s.num_v_slices > 0xFFFF))      // FFV1_Frame.cpp:161-164
+        return fail(5, "ffv1 decoder: %u x %u slices do not fit the picture (FFV1-HEADER-num_h_slices)", s.num_h_slices, s.num_v_slices);
+    const uint32_t ngroups = rgb ? (px.planes == 4 ? 3u : 2u) : 1u;
+    for (uint32_t g = 0; g < ngroups; g++) if (s.set_index[g] >= s.set_count) return fail(2, "ffv1 decoder: quant_table_set_index %u of %u sets", s.set_index[g], s.set_count);
+    if (ffv1::reaches_state_zero(s)) return fail(ffv1::kUnsupported, "ffv1 decoder: state 0 is within reach of the stream's initial states and transitions: not decoded on the device");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(3, "ffv1 decoder: no HIP device available -- there is no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(3, "ffv1 decoder: device %d out of range", cfg->device);
     HIP_TRY(hipSetDevice(cfg->device));
     rcgpu_ffv1_decoder* d = new rcgpu_ffv1_decoder;
     d->cfg = *cfg;
-    ffv1::quant_model qm[2];
-    ffv1::build_quant_models(px.bits, qm, cfg->context == 2);
-    const uint32_t qidx = cfg->context ? 1 : 0;
-    const ffv1::quant_model& Q = qm[qidx];
     dec_const& c = d->hc;
     c.W = cfg->width; c.H = cfg->height; c.line_bytes = cfg->line_bytes; c.pixfmt = cfg->pixfmt;
-    c.planes = px.planes; c.bps = px.bits; c.rgb = px.planes != 1; c.gb_swap = px.gb_swap; c.big_endian = px.big_endian; c.bytes_pp = px.bytes_pp;
+    c.planes = px.planes; c.bps = px.bits; c.rgb = rgb; c.gb_swap = px.gb_swap; c.big_endian = px.big_endian; c.bytes_pp = px.bytes_pp;
     c.fields = px.fields; c.fill = px.fill; c.vflip = (cfg->flags & RCGPU_FLAG_VFLIP) != 0; c.altern = altern;
     c.bits = c.rgb ? px.bits + 1 : (px.bits <= 8 ? 8 : px.bits);
     c.overflow16 = (!c.rgb && px.bits == 16);
-    c.num_h = cfg->num_h_slices; c.num_v = cfg->num_v_slices; c.S = c.num_h * c.num_v; c.nctx = Q.context_count;
-    c.nsets = c.rgb ? (px.planes == 4 ? 3 : 2) : 1; c.ec = cfg->slicecrc ? 1 : 0; c.is5 = Q.q[3][127] != 0;
-    c.index_count = c.rgb ? (px.planes == 4 ? 3u : 2u) : 2u; c.qidx = qidx;
-    memcpy(c.q, Q.q, sizeof c.q);
-    memcpy(c.one_state, ffv1::one_state_table(cfg->coder), 256);
-    ffv1::make_zero_state(c.zero_state, c.one_state);
-    std::vector<uint16_t> hdr;
-    if (cfg->level == 1) {
-        ffv1::stream_params sp{};
-        sp.bits_per_raw_sample = px.bits; sp.rgb = px.planes != 1; sp.alpha = px.planes == 4; sp.num_h_slices = sp.num_v_slices = 1; sp.ec = 0;
-        sp.context_model = qidx; sp.compact = cfg->context == 2; sp.coder = cfg->coder == 2 ? 2 : 1; sp.version = 1;
-        hdr = ffv1::v1_frame_header_decisions(sp);
+    c.num_h = cfg->num_h_slices; c.num_v = cfg->num_v_slices; c.S = c.num_h * c.num_v;
+    c.ngroups = ngroups; c.ec = cfg->slicecrc ? 1 : 0; c.index_count = s.index_count;
+    bool coded = false;
+    uint32_t nkeys = 0;
+    for (uint32_t g = 0; g < 3; g++) {
+        const ffv1::quant_model& Q = s.sets[g < ngroups ? s.set_index[g] : s.set_index[0]];
+        c.idx[g] = s.set_index[g]; c.nctx[g] = Q.context_count; c.kbase[g] = nkeys;
+        c.is5[g] = Q.q[3][127] != 0;                                  // FFV1_Slice.cpp:453
+        memcpy(c.q[g], Q.q, sizeof c.q[g]);
+        if (g < ngroups) { nkeys += Q.context_count; coded |= !s.initial[s.set_index[g]].empty(); }
     }
+    memcpy(c.one_state, s.one_state, 256);
+    ffv1::make_zero_state(c.zero_state, c.one_state);
+    const std::vector<uint16_t>& hdr = s.inband;
     c.v1 = cfg->level == 1; c.hdr_n = uint32_t(hdr.size()); c.win_cap = 7;
-    d->nkeys = c.nsets * c.nctx;
+    d->nkeys = nkeys;
     d->payload_bytes = size_t(cfg->line_bytes) * cfg->height;
     const uint32_t F = cfg->max_batch; const size_t nchains = size_t(F) * c.S;
     hipError_t he = hipSuccess;
 #define DM(p, b) if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&(p)), (b))
     DM(d->d_const, sizeof c); DM(d->d_pkt_ptrs, sizeof(void*) * F); DM(d->d_out_ptrs, sizeof(void*) * F); DM(d->d_sizes, 8 * F);
     DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32); DM(d->d_hdr, hdr.size() * 2 + 16);
+    std::vector<uint8_t> init;
+    if (coded) {                                                      // one chain's states as GOP_Init leaves them
+        init.assign(size_t(nkeys) * 32, 128);
+        for (uint32_t g = 0; g < ngroups; g++) {
+            const std::vector<uint8_t>& v = s.initial[s.set_index[g]];
+            if (!v.empty()) memcpy(init.data() + size_t(c.kbase[g]) * 32, v.data(), v.size());
+        }
+        DM(d->d_init, init.size());
+    }
     // whole-byte layouts (and EXR) are packed inline by the decoding lanes, which then only need three lines per plane and slice;
     // the word-stream layouts share words between neighbouring slices and keep the planes + k_pack_words route
     d->ring = c.fields == kFieldsBytes || c.fields == kFieldsExr;
@@ -909,9 +943,36 @@ extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv
     for (auto& e : d->ev) if (he == hipSuccess) he = hipEventCreate(&e);
     if (he == hipSuccess) he = hipMemcpy(d->d_const, &c, sizeof c, hipMemcpyHostToDevice);
     if (he == hipSuccess && !hdr.empty()) he = hipMemcpy(d->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
+    if (he == hipSuccess && coded) he = hipMemcpy(d->d_init, init.data(), init.size(), hipMemcpyHostToDevice);
     if (he != hipSuccess) { const int r = fail(100, "ffv1 decoder: device setup failed: %s", hipGetErrorString(he)); rcgpu_ffv1_decoder_destroy(d); return r; }
     *out = d;
     return 0;
+}
+
+// the stream this library's encoder writes for `cfg`
+extern "C" int rcgpu_ffv1_decoder_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1_decoder** out)
+{
+    clear_error();
+    if (!cfg || !out) return fail(1, "ffv1 decoder: null argument");
+    *out = nullptr;
+    if (cfg->pixfmt >= RCGPU_PIX_COUNT || !cfg->num_h_slices || !cfg->num_v_slices) return fail(2, "ffv1 decoder: bad configuration");
+    if (cfg->level == 1 && (cfg->num_h_slices * cfg->num_v_slices != 1 || cfg->slicecrc))
+        return fail(2, "ffv1 decoder: FFV1 version 1 (-level 1) has one slice and no slice CRC");
+    const pix_desc& px = pix(cfg->pixfmt);
+    ffv1::stream_params sp{};
+    sp.bits_per_raw_sample = px.bits; sp.rgb = px.planes != 1; sp.alpha = px.planes == 4; sp.num_h_slices = cfg->num_h_slices; sp.num_v_slices = cfg->num_v_slices;
+    sp.ec = cfg->slicecrc ? 1 : 0; sp.context_model = cfg->context ? 1 : 0; sp.compact = cfg->context == 2; sp.coder = cfg->coder == 2 ? 2 : 1; sp.version = cfg->level == 1 ? 1 : 3;
+    ffv1::stream_desc s;
+    ffv1::stream_of_encoder(sp, s);
+    return decoder_create(cfg, s, out);
+}
+
+extern "C" int rcgpu_ffv1_decoder_create_for_stream(const rcgpu_ffv1_config* files, const rcgpu_ffv1_stream* stream, rcgpu_ffv1_decoder** out)
+{
+    clear_error();
+    if (!files || !stream || !out) return fail(1, "ffv1 decoder: null argument");
+    *out = nullptr;
+    return decoder_create(files, stream->d, out);
 }
 
 // Decode n packets (device memory) into n payload buffers (device memory, data_size bytes each).  Asynchronous on the
@@ -931,7 +992,12 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     HIP_TRY(hipMemcpyAsync(d->d_out_ptrs, d->h_ptrs + d->cfg.max_batch, sizeof(void*) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d->d_sizes, d->h_sizes, 8 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d->d_err, 0, 16, st));
-    HIP_TRY(hipMemsetAsync(d->d_states, 128, size_t(nchains) * d->nkeys * 32, st));          // states_coded = 0: every state starts at 128
+    if (d->d_init) {                                                                          // states_coded = 1: the stream's own initial states
+        const unsigned long long total = (unsigned long long)nchains * d->nkeys * 2;
+        hipLaunchKernelGGL(k_dec_preset, dim3(uint32_t(std::min<unsigned long long>((total + 255) / 256, 65536))), dim3(256), 0, st,
+                           reinterpret_cast<uint4*>(d->d_states), reinterpret_cast<const uint4*>(d->d_init), d->nkeys * 2, total);
+    }
+    else HIP_TRY(hipMemsetAsync(d->d_states, 128, size_t(nchains) * d->nkeys * 32, st));     // states_coded = 0: every state starts at 128
     HIP_TRY(hipEventRecord(d->ev[0], st));
     hipLaunchKernelGGL(k_dec_split, dim3((n + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_sizes, n, d->d_slice_start, d->d_slice_len, d->d_err);
     if (c.ec) hipLaunchKernelGGL(k_dec_crc, dim3(nchains), dim3(256), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, d->d_err);

@@ -199,17 +199,23 @@ std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx
 
 }}  // namespace rc::ffv1
 
-// ---- configuration record reader (parameters::Parse, FFV1_Parameters.cpp:23-183): a scalar range decoder over a few hundred bytes
+// ---- the decode side's reader (parameters::Parse, FFV1_Parameters.cpp:23-183; slice::SliceHeader, FFV1_Slice.cpp:113-177): a scalar range
+// decoder over a few hundred bytes -- or, with coded initial states, up to a million symbols once per stream
 namespace {
 struct host_rd {
     const uint8_t* cur; const uint8_t* end; uint32_t current, mask; uint8_t zero[256]; const uint8_t* one = rc::ffv1::kOneState;
+    std::vector<uint16_t>* trace = nullptr;          // every decision as state | bit << 8
     host_rd(const uint8_t* p, size_t n) : cur(p), end(p + n) { current = n ? *cur : 0; mask = 0xFF; cur++; rc::ffv1::make_zero_state(zero); }
+    void transitions(const uint8_t* t) { one = t; rc::ffv1::make_zero_state(zero, t); }          // AssignStateTransitions, FFV1_RangeCoder.cpp:35-41
+    bool underrun() const { return cur - (mask < 0x100 ? 0 : 1) > end; }                           // IsUnderrun, :62-65
     bool bit(uint8_t& st)
     {
         if (mask < 0x100) { current <<= 8; if (cur < end) current |= *cur; mask <<= 8; cur++; }
         const uint32_t m2 = (mask * st) >> 8;
         mask -= m2;
-        if (current < mask) { st = zero[st]; return false; }
+        const bool b = current >= mask;
+        if (trace) trace->push_back(uint16_t(st | (b ? 0x100 : 0)));
+        if (!b) { st = zero[st]; return false; }
         current -= mask; mask = m2; st = one[st];
         return true;
     }
@@ -232,7 +238,212 @@ struct host_rd {
         return bit(st[11 + (e < 10 ? e : 10)]) ? -a : a;
     }
 };
+
+// parameters::Parse(E, ConfigurationRecord_IsPresent) with QuantizationTableSet / QuantizationTable (:206-253), field for field.  The
+// errors are the reference's (its message in the text); rc::ffv1::kUnsupported marks what the reference decodes and the device does not.
+int parse_parameters(host_rd& r, rc::ffv1::stream_desc& s, bool record)
+{
+    using namespace rc; using namespace rc::ffv1;
+    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
+    s.version = r.u(st);
+    if (record ? s.version <= 1 : s.version > 1) return fail(4, "ffv1 stream: version %u %s a configuration record (FFV1-HEADER-version-OUTOFBAND)", s.version, record ? "with" : "without");
+    if (s.version == 2 || s.version > 3) return fail(4, "ffv1 stream: version %u (FFV1_Parameters.cpp:33-34)", s.version);
+    s.micro_version = s.version >= 3 ? r.u(st) : 0;
+    if (s.version == 3 && s.micro_version < 4) return fail(4, "ffv1 stream: micro_version %u < 4 (FFV1_Parameters.cpp:36-37)", s.micro_version);
+    uint32_t coder_type = r.u(st);
+    if (coder_type > 2) return fail(4, "ffv1 stream: coder_type %u (FFV1_Parameters.cpp:39-40)", coder_type);
+    s.custom_transitions = false;
+    memcpy(s.one_state, kOneState, 256);
+    if (coder_type == 2) {                                   // state_transition_delta[1..255], :41-55
+        for (int i = 1; i < 256; i++) {
+            const int32_t v = int32_t(kOneState[i]) + r.s(st);
+            if (v < 0 || v > 0xFF) return fail(4, "ffv1 stream: state_transition_delta out of range (FFV1_Parameters.cpp:49-50)");
+            s.one_state[i] = uint8_t(v);
+        }
+        s.custom_transitions = true;
+        coder_type = 1;
+    }
+    if (coder_type != 1) return fail(kUnsupported, "ffv1 stream: Golomb-Rice coded (coder_type 0): not decoded on the device");
+    s.colorspace_type = r.u(st);
+    if (s.colorspace_type > 1) return fail(4, "ffv1 stream: colorspace_type %u (FFV1_Parameters.cpp:59-60)", s.colorspace_type);
+    if (s.version) {
+        s.bits_per_raw_sample = r.u(st);
+        if (s.bits_per_raw_sample > 64) return fail(4, "ffv1 stream: bits_per_raw_sample %u (FFV1_Parameters.cpp:64-65)", s.bits_per_raw_sample);
+        if (!s.bits_per_raw_sample) s.bits_per_raw_sample = 8;
+    } else s.bits_per_raw_sample = 8;
+    s.chroma_planes = r.bit(st[0]);
+    s.log2_h_chroma_subsample = r.u(st); s.log2_v_chroma_subsample = r.u(st);
+    s.alpha_plane = r.bit(st[0]);
+    if (s.version > 1) {
+        s.num_h_slices = r.u(st) + 1; s.num_v_slices = r.u(st) + 1;
+        s.set_count = r.u(st);
+        if (s.set_count > 8) return fail(6, "ffv1 stream: %u quantisation table sets (FFV1_Parameters.cpp:84-85)", s.set_count);
+    } else { s.num_h_slices = s.num_v_slices = 1; s.set_count = 1; }
+    for (uint32_t i = 0; i < s.set_count; i++) {
+        int64_t scale = 1;                                   // contexts so far; the reference stops at 32768
+        memset(&s.sets[i], 0, sizeof s.sets[i]);
+        for (int j = 0; j < 5; j++) {
+            uint8_t qst[kContextSize]; memset(qst, 128, sizeof qst);
+            int16_t* q = s.sets[i].q[j];
+            int32_t v = 0;
+            for (uint32_t k = 0; k < 128;) {
+                const uint32_t len1 = r.u(qst);
+                if (k + len1 >= 128) return fail(6, "ffv1 stream: bad quantisation table (FFV1_Parameters.cpp:231-232)");
+                for (uint32_t a = 0; a <= len1; a++, k++) q[k] = int16_t(scale * v);
+                v++;
+            }
+            for (int k = 1; k < 128; k++) q[256 - k] = int16_t(-q[k]);
+            q[128] = int16_t(-q[127]);
+            scale *= 2 * v - 1;
+            if (scale > 32768) return fail(6, "ffv1 stream: more than 32768 contexts (FFV1_Parameters.cpp:247-248)");
+        }
+        s.sets[i].context_count = uint32_t((scale + 1) >> 1);
+    }
+    for (uint32_t i = 0; i < s.set_count; i++) {
+        s.initial[i].clear();
+        if (s.version >= 3 && r.bit(st[0])) {                // states_coded: `States[k] = E.s(States)` (:103-107), every value as it stands
+            s.initial[i].resize(size_t(s.sets[i].context_count) * kContextSize);
+            for (uint8_t& v : s.initial[i]) v = uint8_t(r.s(st));
+        }
+    }
+    if (s.version >= 3) {
+        s.ec = r.u(st);
+        if (s.ec > 1) return fail(7, "ffv1 stream: ec %u (FFV1_Parameters.cpp:137)", s.ec);
+        s.intra = 0;
+        if (s.micro_version) { s.intra = r.u(st); if (s.intra > 1) return fail(7, "ffv1 stream: intra %u (FFV1_Parameters.cpp:142-143)", s.intra); }
+    } else { s.ec = 0; s.intra = 0; }
+    if (r.underrun()) return fail(3, "ffv1 stream: the parameters end before they are complete");
+    // quant_table_set_index_count, :164-178
+    s.index_count = s.colorspace_type == 1 ? (s.alpha_plane ? 3u : 2u) : 2u + (s.alpha_plane ? 1u : 0u);
+    return 0;
+}
 }  // namespace
+
+namespace rc { namespace ffv1 {
+
+int parse_stream(const uint8_t* rec, size_t rec_size, const uint8_t* packet, size_t packet_size, stream_desc& s)
+{
+    if (rec_size) {                                          // ffv1_frame::OutOfBand, FFV1_Frame.cpp:105-131
+        if (!rec) return fail(1, "ffv1 stream: null argument");
+        if (rec_size < 5 || rcgpu_crc32_ffv1(rec, rec_size)) return fail(3, "ffv1 record: CRC mismatch (FFV1_Frame.cpp:116)");
+        host_rd r(rec, rec_size - 4);
+        if (int e = parse_parameters(r, s, true)) return e;
+    }
+    if (!packet || packet_size < (rec_size ? 8u : 2u)) return fail(8, "ffv1 stream: the first packet of the track is needed (the %s)", rec_size ? "quantisation table set of every plane stands in its slice headers" : "stream's header travels inside it");
+    host_rd r(packet, packet_size);
+    s.inband.clear();
+    if (!rec_size) r.trace = &s.inband;
+    { uint8_t ks = 128; if (!r.bit(ks)) return fail(8, "ffv1 stream: the first frame is not a key frame (FFV1-FRAME-key_frame-NOINFIRSTFRAME)"); }
+    if (!rec_size) {                                         // slice::Parse without a record, FFV1_Slice.cpp:224-245: the parameters, then the samples
+        if (int e = parse_parameters(r, s, false)) return e;
+        r.trace = nullptr;
+        s.set_index[0] = s.set_index[1] = s.set_index[2] = 0;
+        return 0;
+    }
+    if (s.custom_transitions) r.transitions(s.one_state);    // FFV1_Slice.cpp:254-255
+    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
+    const uint32_t sx = r.u(st), sy = r.u(st), sw1 = r.u(st), sh1 = r.u(st);
+    if (sx >= s.num_h_slices || sy >= s.num_v_slices || sx + sw1 >= s.num_h_slices || sy + sh1 >= s.num_v_slices)
+        return fail(8, "ffv1 stream: slice geometry of the first slice header (FFV1-SLICE-slice_xywh)");
+    for (uint32_t i = 0; i < s.index_count; i++) {
+        s.set_index[i] = r.u(st);
+        if (s.set_index[i] >= s.set_count) return fail(8, "ffv1 stream: quant_table_set_index %u of %u sets (FFV1_Slice.cpp:162-167)", s.set_index[i], s.set_count);
+    }
+    if (r.underrun()) return fail(8, "ffv1 stream: the first packet ends inside its first slice header");
+    return 0;
+}
+
+void stream_of_encoder(const stream_params& p, stream_desc& s)
+{
+    quant_model m[2];
+    build_quant_models(p.bits_per_raw_sample, m, p.compact);
+    s = stream_desc();
+    s.version = p.version == 1 ? 1 : 3; s.micro_version = s.version == 3 ? 4 : 0;
+    s.custom_transitions = p.coder == 2;
+    memcpy(s.one_state, one_state_table(p.coder), 256);
+    s.colorspace_type = p.rgb ? 1 : 0; s.bits_per_raw_sample = p.bits_per_raw_sample; s.chroma_planes = p.rgb; s.alpha_plane = p.alpha;
+    s.num_h_slices = p.num_h_slices; s.num_v_slices = p.num_v_slices; s.ec = p.ec; s.intra = s.version == 3 ? 1 : 0;
+    s.index_count = p.rgb ? (p.alpha ? 3u : 2u) : 2u;
+    if (s.version == 1) { s.set_count = 1; s.sets[0] = m[p.context_model]; s.inband = v1_frame_header_decisions(p); }
+    else { s.set_count = 2; s.sets[0] = m[0]; s.sets[1] = m[1]; s.set_index[0] = s.set_index[1] = s.set_index[2] = p.context_model; }
+}
+
+bool reaches_state_zero(const stream_desc& s)
+{
+    uint8_t zero[256];
+    make_zero_state(zero, s.one_state);
+    bool seen[256] = {};
+    std::vector<uint8_t> todo;
+    auto visit = [&](uint8_t v) { if (!seen[v]) { seen[v] = true; todo.push_back(v); } };
+    visit(128);
+    const uint32_t groups = s.colorspace_type == 1 ? s.index_count : 1u;           // gray: only the luma group has samples
+    for (uint32_t g = 0; g < groups; g++) for (uint8_t v : s.initial[s.set_index[g]]) visit(v);
+    while (!todo.empty()) { const uint8_t v = todo.back(); todo.pop_back(); if (!v) return true; visit(s.one_state[v]); visit(zero[v]); }
+    return false;
+}
+
+}}  // namespace rc::ffv1
+
+extern "C" int rcgpu_ffv1_stream_parse(const uint8_t* record, size_t record_size, const uint8_t* packet, size_t packet_size, rcgpu_ffv1_stream** out)
+{
+    using namespace rc;
+    clear_error();
+    if (!out) return fail(1, "ffv1 stream: null argument");
+    *out = nullptr;
+    rcgpu_ffv1_stream* s = new rcgpu_ffv1_stream;
+    if (const int e = ffv1::parse_stream(record, record_size, packet, packet_size, s->d)) { delete s; return e; }
+    *out = s;
+    return 0;
+}
+
+extern "C" void rcgpu_ffv1_stream_free(rcgpu_ffv1_stream* s) { delete s; }
+
+extern "C" int rcgpu_ffv1_stream_get_info(const rcgpu_ffv1_stream* s, rcgpu_ffv1_stream_info* info)
+{
+    using namespace rc;
+    clear_error();
+    if (!s || !info) return fail(1, "ffv1 stream: null argument");
+    const ffv1::stream_desc& d = s->d;
+    memset(info, 0, sizeof *info);
+    info->version = d.version; info->micro_version = d.micro_version; info->coder_type = d.custom_transitions ? 2 : 1;
+    info->colorspace_type = d.colorspace_type; info->bits_per_raw_sample = d.bits_per_raw_sample;
+    info->chroma_planes = d.chroma_planes; info->alpha_plane = d.alpha_plane;
+    info->num_h_slices = d.num_h_slices; info->num_v_slices = d.num_v_slices; info->quant_table_set_count = d.set_count;
+    info->ec = d.ec; info->intra = d.intra; info->quant_table_set_index_count = d.index_count;
+    for (int g = 0; g < 3; g++) info->quant_table_set_index[g] = d.set_index[g];
+    for (uint32_t i = 0; i < d.set_count; i++) { info->context_count[i] = d.sets[i].context_count; info->states_coded[i] = !d.initial[i].empty(); }
+    return 0;
+}
+
+// The older, narrower form: the stream must be one this library's encoder writes (FFmpeg's two default table sets or the compact
+// model, all planes on one of them, one of the two known transition tables), and `cfg` then describes it to rcgpu_ffv1_decoder_create.
+// Anything else parameters::Parse accepts goes through rcgpu_ffv1_stream_parse + rcgpu_ffv1_decoder_create_for_stream.
+static int config_from_desc(const rc::ffv1::stream_desc& s, rcgpu_ffv1_config* cfg)
+{
+    using namespace rc; using namespace rc::ffv1;
+    const pix_desc& d = pix(cfg->pixfmt);
+    const bool rgb = d.planes != 1;
+    if (s.version != 3) return fail(4, "ffv1 record: only version 3 is described by a configuration (rcgpu_ffv1_stream_parse takes the others)");
+    if (s.colorspace_type != (rgb ? 1u : 0u) || s.bits_per_raw_sample != d.bits || s.chroma_planes != rgb || s.log2_h_chroma_subsample || s.log2_v_chroma_subsample || s.alpha_plane != (d.planes == 4))
+        return fail(5, "ffv1 record: stream (colorspace %u, %u bit%s) does not match the pixel format of the files", s.colorspace_type, s.bits_per_raw_sample, s.alpha_plane ? ", alpha" : "");
+    if (s.num_h_slices > cfg->width || s.num_v_slices > cfg->height || s.num_h_slices > 0x10000 || s.num_v_slices > 0x10000)
+        return fail(5, "ffv1 record: %u x %u slices do not fit the picture", s.num_h_slices, s.num_v_slices);
+    if (s.custom_transitions && memcmp(s.one_state + 1, kOneStateAlt + 1, 255)) return fail(kUnsupported, "ffv1 record: a transition table of the stream's own (rcgpu_ffv1_stream_parse takes it)");
+    if (s.set_count != 2) return fail(kUnsupported, "ffv1 record: %u quantisation table sets (rcgpu_ffv1_stream_parse takes them)", s.set_count);
+    quant_model ref[2], compact[2];
+    build_quant_models(d.bits, ref, false); build_quant_models(d.bits, compact, true);
+    const bool is_ref = !memcmp(s.sets[0].q, ref[0].q, sizeof ref[0].q) && !memcmp(s.sets[1].q, ref[1].q, sizeof ref[1].q);
+    const bool is_compact = !memcmp(s.sets[0].q, compact[0].q, sizeof ref[0].q) && !memcmp(s.sets[1].q, compact[1].q, sizeof ref[1].q);
+    if (!is_ref && !is_compact) return fail(kUnsupported, "ffv1 record: quantisation tables other than this encoder's two models (rcgpu_ffv1_stream_parse takes them)");
+    if (!s.initial[0].empty() || !s.initial[1].empty()) return fail(kUnsupported, "ffv1 record: coded initial states (rcgpu_ffv1_stream_parse takes them)");
+    if (s.intra != 1) return fail(kUnsupported, "ffv1 record: inter frames (intra = 0) are not decoded on the device");
+    cfg->num_h_slices = s.num_h_slices; cfg->num_v_slices = s.num_v_slices; cfg->slicecrc = s.ec; cfg->coder = s.custom_transitions ? 2 : 1;
+    // which of the two table sets the planes use is a per-slice field; this encoder always picks set 1 for -context 1 / compact,
+    // set 0 for -context 0 -- the caller keeps what it asked for unless the tables say "compact"
+    if (is_compact && !is_ref) cfg->context = 2;
+    else if (cfg->context == 2) cfg->context = 1;
+    return 0;
+}
 
 extern "C" int rcgpu_ffv1_config_from_record(const uint8_t* rec, size_t size, rcgpu_ffv1_config* cfg)
 {
@@ -241,82 +452,26 @@ extern "C" int rcgpu_ffv1_config_from_record(const uint8_t* rec, size_t size, rc
     if (!rec || !cfg) return fail(1, "ffv1 record: null argument");
     if (cfg->pixfmt >= RCGPU_PIX_COUNT) return fail(2, "ffv1 record: unknown pixel format %u", cfg->pixfmt);
     if (size < 5 || rcgpu_crc32_ffv1(rec, size)) return fail(3, "ffv1 record: CRC mismatch (FFV1_Frame.cpp:116)");
-    const pix_desc& d = pix(cfg->pixfmt);
+    stream_desc s;
     host_rd r(rec, size - 4);
-    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
-    if (r.u(st) != 3) return fail(4, "ffv1 record: only version 3 is supported");
-    if (r.u(st) < 4) return fail(4, "ffv1 record: micro_version < 4 (FFV1_Parameters.cpp:36-37)");
-    const uint32_t coder = r.u(st);
-    if (coder != 1 && coder != 2) return fail(4, "ffv1 record: coder_type %u is not supported (range coder only)", coder);
-    if (coder == 2)
-        for (int i = 1; i < 256; i++)
-            if (int32_t(kOneState[i]) + r.s(st) != int32_t(kOneStateAlt[i])) return fail(4, "ffv1 record: unknown custom state-transition table");
-    const uint32_t colorspace = r.u(st), bps = r.u(st);
-    const bool chroma = r.bit(st[0]);
-    const uint32_t hs = r.u(st), vs = r.u(st);
-    const bool alpha = r.bit(st[0]);
-    const bool rgb = d.planes != 1;
-    if (colorspace != (rgb ? 1u : 0u) || bps != d.bits || chroma != rgb || hs || vs || alpha != (d.planes == 4))
-        return fail(5, "ffv1 record: stream (colorspace %u, %u bit%s) does not match the pixel format of the files", colorspace, bps, alpha ? ", alpha" : "");
-    const uint32_t nh1 = r.u(st), nv1 = r.u(st);
-    if (nh1 >= cfg->width || nv1 >= cfg->height || nh1 > 0xFFFF || nv1 > 0xFFFF) return fail(5, "ffv1 record: %u x %u slices do not fit the picture", nh1 + 1, nv1 + 1);
-    cfg->num_h_slices = nh1 + 1; cfg->num_v_slices = nv1 + 1;
-    if (r.u(st) != 2) return fail(6, "ffv1 record: expected two quantisation table sets");
-    quant_model ref[2], compact[2];
-    build_quant_models(d.bits, ref, false); build_quant_models(d.bits, compact, true);
-    bool is_ref = true, is_compact = true;
-    for (int i = 0; i < 2; i++) {
-        int64_t scale = 1;                                             // context_count so far; FFmpeg and the reference stop at 32768
-        for (int j = 0; j < 5; j++) {
-            uint8_t qst[kContextSize]; memset(qst, 128, sizeof qst);
-            int32_t v = 0;
-            for (uint32_t k = 0; k < 128;) {
-                const uint32_t len1 = r.u(qst);
-                if (k + len1 >= 128) return fail(6, "ffv1 record: bad quantisation table (FFV1_Parameters.cpp:222-253)");
-                for (uint32_t a = 0; a <= len1; a++, k++) {
-                    is_ref &= int64_t(ref[i].q[j][k]) == scale * v;
-                    is_compact &= int64_t(compact[i].q[j][k]) == scale * v;
-                }
-                v++;
-            }
-            scale *= 2 * v - 1;
-            if (scale > 32768) return fail(6, "ffv1 record: more than 32768 contexts (FFV1_Parameters.cpp:222-253)");
-        }
-    }
-    if (!is_ref && !is_compact) return fail(6, "ffv1 record: quantisation tables other than this encoder's two models");
-    for (int i = 0; i < 2; i++) if (r.bit(st[0])) return fail(7, "ffv1 record: coded initial states are not supported");
-    cfg->slicecrc = r.u(st);
-    if (cfg->slicecrc > 1) return fail(7, "ffv1 record: ec %u", cfg->slicecrc);
-    if (r.u(st) != 1) return fail(7, "ffv1 record: inter frames (intra = 0) are not supported");
-    // which of the two table sets the planes use is a per-slice field; this encoder always picks set 1 for -context 1 / compact,
-    // set 0 for -context 0 -- the caller keeps what it asked for unless the tables say "compact"
-    cfg->coder = coder;
-    if (is_compact && !is_ref) cfg->context = 2;
-    else if (cfg->context == 2) cfg->context = 1;
-    return 0;
+    if (const int e = parse_parameters(r, s, true)) return e;
+    return config_from_desc(s, cfg);
 }
 
 // The record says which table sets exist; which one the planes USE stands in every slice header (quant_table_set_index,
-// FFV1_Slice.cpp:159-168).  A decoder-side caller that holds the first packet of the stream settles it here: the header of the slice
-// at the packet's start is read with the default transitions' sibling of the record's coder (the header states are fresh).
+// FFV1_Slice.cpp:159-168).  A decoder-side caller that holds the first packet of the stream settles it here.
 extern "C" int rcgpu_ffv1_config_from_stream(const uint8_t* rec, size_t size, const uint8_t* packet, size_t packet_size, rcgpu_ffv1_config* cfg)
 {
     using namespace rc; using namespace rc::ffv1;
-    if (int r = rcgpu_ffv1_config_from_record(rec, size, cfg)) return r;
-    if (!packet || packet_size < 8) return fail(8, "ffv1 stream: packet too small for a slice header");
-    host_rd r(packet, packet_size);
-    if (cfg->coder == 2) { make_zero_state(r.zero, kOneStateAlt); r.one = kOneStateAlt; }
-    uint8_t st[kContextSize]; memset(st, 128, sizeof st);
-    if (!r.bit(st[0])) return fail(8, "ffv1 stream: the first frame is not a key frame");
-    memset(st, 128, sizeof st);
-    const uint32_t sx = r.u(st), sy = r.u(st), sw1 = r.u(st), sh1 = r.u(st);
-    if (sx >= cfg->num_h_slices || sy >= cfg->num_v_slices || sw1 || sh1) return fail(8, "ffv1 stream: unexpected slice geometry in the first slice header");
-    const pix_desc& d = pix(cfg->pixfmt);
-    const uint32_t count = d.planes == 1 ? 2 : d.planes - 1;                      // FFV1_Parameters.cpp:170,175
-    uint32_t idx = r.u(st);
-    for (uint32_t i = 1; i < count; i++) if (r.u(st) != idx) return fail(8, "ffv1 stream: planes with different quantisation table sets are not supported");
-    if (idx > 1) return fail(8, "ffv1 stream: quant_table_set_index %u", idx);
-    if (idx == 0) cfg->context = 0;
+    clear_error();
+    if (!rec || !cfg) return fail(1, "ffv1 record: null argument");
+    if (cfg->pixfmt >= RCGPU_PIX_COUNT) return fail(2, "ffv1 record: unknown pixel format %u", cfg->pixfmt);
+    stream_desc s;
+    if (const int e = parse_stream(rec, size, packet, packet_size, s)) return e;
+    if (const int e = config_from_desc(s, cfg)) return e;
+    const uint32_t groups = s.colorspace_type == 1 ? s.index_count : 2u;
+    for (uint32_t i = 1; i < groups; i++) if (s.set_index[i] != s.set_index[0]) return fail(kUnsupported, "ffv1 stream: planes with different quantisation table sets (rcgpu_ffv1_stream_parse takes them)");
+    if (s.set_index[0] == 0) cfg->context = 0;
     else if (cfg->context != 2) cfg->context = 1;
     return 0;
 }

@@ -1,6 +1,7 @@
 // ffv1_host.h -- host-side FFV1 pieces of the encoder: bitstream constants, the configuration record,
 // and the per-slice header decisions that are prepended to each slice's decision stream on the device.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -49,4 +50,33 @@ std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx
 // read with the default transitions, FFV1_Slice.cpp:214) -- there is no slice header.
 std::vector<uint16_t> v1_frame_header_decisions(const stream_params& p);
 
+// ---- the decode side: what a stream says about itself.  parameters (FFV1_Parameters.h; parameters::Parse, FFV1_Parameters.cpp:23-183)
+// plus the one fact that stands in the slice headers, the quant_table_set_index tuple (FFV1_Slice.cpp:158-168) -- read from the first
+// slice of the first packet; the device insists on it in every slice.
+struct stream_desc {
+    uint32_t version = 3, micro_version = 4;        // 0 / 1: the header travels inside every frame, one slice, no footer; 3: configuration record
+    bool     custom_transitions = false;            // coder_type 2
+    uint8_t  one_state[256];                        // the transitions the slices are coded with
+    uint32_t colorspace_type = 0, bits_per_raw_sample = 8;
+    bool     chroma_planes = false, alpha_plane = false;
+    uint32_t log2_h_chroma_subsample = 0, log2_v_chroma_subsample = 0;
+    uint32_t num_h_slices = 1, num_v_slices = 1, ec = 0, intra = 0;
+    uint32_t set_count = 0;                         // quant_table_set_count, 1..8
+    quant_model sets[8];
+    std::vector<uint8_t> initial[8];                // states_coded: context_count x 32 states as the reference reads them (:103-107); empty = all 128
+    uint32_t index_count = 0, set_index[3] = { 0, 0, 0 };   // plane group 0 (Y), 1 (Cb, Cr), 2 (alpha)
+    std::vector<uint16_t> inband;                   // version 0 / 1: keyframe bit + header of a frame as (state | bit << 8) decisions
+};
+// rec_size == 0: no configuration record, the packet carries the header (version 0 / 1).  0 ok; else rc::fail()'s code with its text set:
+// kUnsupported = a valid stream outside the device decoder (the caller's own decoder takes it), anything else = what the reference refuses too.
+constexpr int kUnsupported = 20;
+int parse_stream(const uint8_t* rec, size_t rec_size, const uint8_t* packet, size_t packet_size, stream_desc& out);
+// the stream this library's encoder writes for a configuration (two table sets, all planes on one of them)
+void stream_of_encoder(const stream_params& p, stream_desc& out);
+// can state 0 be reached from the initial states of the sets in use?  (one_state[0] of a transmitted table is never set in the reference,
+// FFV1_Parameters.cpp:43-53: what such a stream decodes to is not defined there)
+bool reaches_state_zero(const stream_desc& s);
+
 }}  // namespace rc::ffv1
+
+struct rcgpu_ffv1_stream { rc::ffv1::stream_desc d; };

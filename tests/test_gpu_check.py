@@ -35,6 +35,63 @@ def test_decode_golden_packets(built, v):
     dec.close()
 
 
+def _ext_record(v):
+    return open(os.path.join(G, v["config_record_file"]), "rb").read() if "config_record_file" in v else bytes.fromhex(v.get("config_record", ""))
+
+
+@pytest.mark.parametrize("v", [v for v in VEC["ffv1_ext"] if "unsup" not in v["name"]], ids=lambda v: v["name"])
+def test_decode_streams_other_encoders_could_write(built, v):
+    """What parameters::Parse accepts and FFmpeg's defaults never produce (FFV1_Parameters.cpp:23-183,206-253; FFV1_Slice.cpp:158-168): 1 to 8
+    table sets of arbitrary tables, a set of its own per plane group, a transmitted transition table nobody ships, coded initial states, the
+    version 0 / 1 header inside the frame.  Each stream was checked and decoded by the real reference (tests/golden/make_golden.py); the device
+    decoder knows the picture's geometry and reads everything else from CodecPrivate and the first packet -- to the same payload bytes, with
+    the full window and with samples forced down the careful path."""
+    n = len(v["frames"])
+    payloads = [open(os.path.join(G, f["payload"]), "rb").read() for f in v["frames"]]
+    packets = [open(os.path.join(G, f["packet"]), "rb").read() for f in v["frames"]]
+    stream = api.Ffv1Stream(_ext_record(v), packets[0])
+    dec = api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], max_batch=n + 1, stream=stream)
+    stream.close()                                              # the decoder keeps what it needs
+    dpk = [dev(p) for p in packets]
+    for cap in (7, 2):
+        dec.debug_window(cap)
+        dout = [torch.full((len(p),), 0xAA, dtype=torch.uint8, device="cuda") for p in payloads]
+        assert dec.decode_device([t.data_ptr() for t in dpk], [len(p) for p in packets], [t.data_ptr() for t in dout]) == 0
+        for i in range(n):
+            assert bytes(dout[i].cpu().numpy()) == payloads[i], f"window {cap}: frame {i}"
+    assert dec.decode_host(packets[::-1], len(payloads[0])) == payloads[::-1]            # a second batch: the states are set anew for every batch
+    bad = bytearray(packets[0])
+    bad[len(bad) // 3] ^= 0x08
+    if v["ec"]:
+        with pytest.raises(api.RcgpuError, match="undecodable"):
+            dec.decode_host([bytes(bad)], len(payloads[0]))
+    else:                                                       # no slice CRC: the decoder may run to the end, but not to the same picture
+        try:
+            assert dec.decode_host([bytes(bad)], len(payloads[0])) != [payloads[0]]
+        except api.RcgpuError:
+            pass
+    dec.close()
+
+
+def test_streams_the_device_does_not_take_are_told_apart_from_broken_ones(built):
+    """Two valid streams (the real reference decodes both, tests/golden/make_golden.py) outside the device decoder: intra = 0 is refused when
+    the decoder is made (RCGPU_FFV1_UNSUPPORTED); slices that name other table sets than the first slice did -- quant_table_set_index is a
+    per-slice field, FFV1_Slice.cpp:158-168 -- are found while decoding and reported like any undecodable frame (header flag 32).  Either
+    way a binding hands the frames to its own decoder (route C: test_gpu_e2e.py)."""
+    by = {v["name"]: v for v in VEC["ffv1_ext"]}
+    v = by["ext_unsup_intra0_64x48"]
+    pk = open(os.path.join(G, v["frames"][0]["packet"]), "rb").read()
+    s = api.Ffv1Stream(_ext_record(v), pk)
+    with pytest.raises(api.RcgpuUnsupported):
+        api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], max_batch=1, stream=s)
+    v = by["ext_unsup_per_slice_sets_64x48"]
+    pk = open(os.path.join(G, v["frames"][0]["packet"]), "rb").read()
+    dec = api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], max_batch=1, stream=api.Ffv1Stream(_ext_record(v), pk))
+    with pytest.raises(api.RcgpuError, match="undecodable.*0x20"):
+        dec.decode_host([pk], len(open(os.path.join(G, v["frames"][0]["payload"]), "rb").read()))
+    dec.close()
+
+
 @pytest.mark.parametrize("window", [1, 2, 3, 5])
 @pytest.mark.parametrize("v", [v for v in VEC["ffv1"] if v["name"] in ("dpx_rgb16be_64x48", "dpx_rgb10be_50x38", "dpx_rgba12packed_50x38", "dpx_y16be_40x24", "tiff_rgb8_40x30",
                                                                        "exr_rgb16_72x40", "dpx_rgb16be_coder2_72x40")], ids=lambda v: v["name"])

@@ -413,3 +413,98 @@ def test_config_from_stream_reads_the_table_set_from_the_first_slice_header(buil
         assert (cfg.context, cfg.coder, cfg.num_h_slices, cfg.num_v_slices, cfg.slicecrc) == (context, coder, 3, 2, 1)
     cfg = api.Ffv1Config(w, h, pixfmt, line_bytes, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0)
     assert api.lib().rcgpu_ffv1_config_from_stream(rec, len(rec), pk[:4], 4, ctypes.byref(cfg)) != 0
+
+
+_VEC = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))
+_G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _ext_record(v):
+    return open(os.path.join(_G, v["config_record_file"]), "rb").read() if "config_record_file" in v else bytes.fromhex(v.get("config_record", ""))
+
+
+@pytest.mark.parametrize("v", _VEC["ffv1"] + _VEC["ffv1_ext"], ids=lambda v: v["name"])
+def test_stream_parse_reads_what_the_reference_reads(built, v):
+    """rcgpu_ffv1_stream_parse = parameters::Parse (FFV1_Parameters.cpp:23-183, tables :206-253) + the first slice header's
+    quant_table_set_index values (FFV1_Slice.cpp:158-168), for every golden stream the real reference checked: the defaults FFmpeg writes,
+    and 1-8 table sets of arbitrary tables, a set per plane group, transmitted transitions, coded initial states, version 0 / 1 headers."""
+    import oracle_binding as ob
+    import ctypes
+    rec = _ext_record(v)
+    pk = open(os.path.join(_G, v["frames"][0]["packet"]), "rb").read()
+    s = api.Ffv1Stream(rec, pk)
+    i = s.info()
+    ext = v.get("ext")
+    bits, nc, _, _ = synth.PIX_INFO[v["pixfmt"]]
+    assert (i.colorspace_type, i.bits_per_raw_sample, i.chroma_planes, i.alpha_plane) == (int(nc != 1), bits, int(nc != 1), int(nc == 4))
+    assert i.quant_table_set_index_count == (nc - 1 if nc != 1 else 2)
+    if ext is None:
+        assert (i.version, i.micro_version, i.coder_type, i.num_h_slices, i.num_v_slices, i.quant_table_set_count, i.ec, i.intra) == (3, 4, v["coder"], v["num_h"], v["num_v"], 2, 1, 1)
+        assert list(i.quant_table_set_index)[:i.quant_table_set_index_count] == [1] * i.quant_table_set_index_count and list(i.states_coded) == [0] * 8
+        assert list(i.context_count)[:2] == ([666, 7563] if bits <= 8 else [365, 5063])
+    else:
+        e = ob.stream_ext_from_vector(v, _G)
+        version = ext.get("version", 3)
+        assert (i.version, i.coder_type, i.quant_table_set_count, i.ec) == (version, 2 if "one_state" in ext else 1, len(ext["sets"]), v["ec"])
+        assert (i.num_h_slices, i.num_v_slices) == (v["num_h"], v["num_v"])
+        assert i.intra == (ext.get("intra", 1) if version == 3 else 0)
+        want_idx = list(ext.get("set_index", (0, 0, 0))) if version == 3 else [0, 0, 0]
+        assert list(i.quant_table_set_index)[:i.quant_table_set_index_count] == want_idx[:i.quant_table_set_index_count]
+        assert list(i.context_count)[:len(ext["sets"])] == [ob.lib().ffv1o_ext_context_count(ctypes.byref(e), k) for k in range(len(ext["sets"]))]
+        assert [k for k in range(8) if i.states_coded[k]] == sorted(int(k) for k in ext.get("initial_states", {}))
+    s.close()
+    if rec:
+        bad = bytearray(rec); bad[len(rec) // 2] ^= 0x10
+        with pytest.raises(api.RcgpuError, match="CRC"):
+            api.Ffv1Stream(bytes(bad), pk)
+        with pytest.raises(api.RcgpuError):
+            api.Ffv1Stream(rec, b"")                                                     # the first packet is part of the description
+    else:
+        with pytest.raises(api.RcgpuError):
+            api.Ffv1Stream(b"", pk[:3])
+
+
+def test_stream_parse_survives_hostile_input(built):
+    """Mutated records (re-sealed with a valid CRC) and mutated first packets, incl. the version 0 / 1 headers inside the packet and records
+    with a million coded initial states cut short: an error or a description whose numbers are in range.  (tools/fuzz/ runs the long version.)"""
+    rng = np.random.default_rng(11)
+    for v in _VEC["ffv1_ext"]:
+        rec = _ext_record(v)
+        pk = open(os.path.join(_G, v["frames"][0]["packet"]), "rb").read()
+        for k in range(120 if len(rec) > 4096 else 600):
+            r, q = bytearray(rec), bytearray(pk[:256])
+            tgt = r if (rec and k % 3) else q
+            for _ in range(int(rng.integers(1, 5))):
+                tgt[int(rng.integers(0, max(1, len(tgt) - 4)))] = int(rng.integers(0, 256))
+            if rec and rng.integers(0, 4) == 0:
+                r = r[:int(rng.integers(5, len(r)))]
+            if rec:
+                r[-4:] = api.lib().rcgpu_crc32_ffv1(bytes(r[:-4]), len(r) - 4).to_bytes(4, "big")
+            try:
+                s = api.Ffv1Stream(bytes(r), bytes(q))
+            except api.RcgpuError:
+                continue
+            i = s.info()
+            assert i.version in (0, 1, 3) and 1 <= i.quant_table_set_count <= 8 and i.ec <= 1 and i.intra <= 1 and i.coder_type in (1, 2)
+            assert all(1 <= c <= 16384 for c in list(i.context_count)[:i.quant_table_set_count])
+            assert all(x < i.quant_table_set_count for x in list(i.quant_table_set_index)[:i.quant_table_set_index_count])
+            s.close()
+
+
+def test_decoder_for_stream_says_unsupported_before_it_looks_for_a_device(built):
+    """What the reference decodes and the device does not is told apart from what is broken: RCGPU_FFV1_UNSUPPORTED (20), so that a binding
+    leaves the stream to its own decoder (route C: ffv1_frame::Process stays on the slice pool).  intra = 0 is such a stream; a stream that
+    does not describe the files' pixel format is an error; a fine stream on a box without a device fails for that reason only."""
+    v = [x for x in _VEC["ffv1_ext"] if x["name"] == "ext_unsup_intra0_64x48"][0]
+    s = api.Ffv1Stream(_ext_record(v), open(os.path.join(_G, v["frames"][0]["packet"]), "rb").read())
+    assert s.info().intra == 0
+    with pytest.raises(api.RcgpuUnsupported, match="intra = 0"):
+        api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], max_batch=1, stream=s)
+    with pytest.raises(api.RcgpuError, match="does not match the pixel format") as ei:
+        api.Ffv1Decoder(v["width"], v["height"], synth.PIX_Y16_BE, v["width"] * 2, max_batch=1, stream=s)
+    assert not isinstance(ei.value, api.RcgpuUnsupported)
+    if api.lib().rcgpu_device_count() < 1:
+        v = [x for x in _VEC["ffv1_ext"] if x["name"] == "ext_8sets_50x38"][0]
+        s2 = api.Ffv1Stream(_ext_record(v), open(os.path.join(_G, v["frames"][0]["packet"]), "rb").read())
+        with pytest.raises(api.RcgpuError, match="no HIP device"):
+            api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], max_batch=1, stream=s2)

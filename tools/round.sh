@@ -1,0 +1,48 @@
+#!/bin/bash
+# One script for the GPU-box runs of a round (replaces the per-round one-offs).  Run through gpurun from the repo root:
+#   gpurun --timeout 1500 -- 'bash tools/round.sh <what> [tag] [args...]'
+# Everything it writes goes to gpurun_out/$ROUND/ (scratch; copy what is to be judged into profiles/).
+#   tests [tag] [pytest args]     the GPU suite (or the files / -k expression given)
+#   check_ab [tag]                the check tests, then the check half at 64 and at 576 slices (decoder A/B between builds)
+#   bench [tag] [bench args]      one bench.py line -> bench_<tag>.json
+#   line [tag]                    the driver's default line (python bench.py)
+#   stats [tag] [bench args]      rocprofv3 --kernel-trace --stats of a bench run -> stats_<tag>/
+#   pmc [tag] [bench args]        the PMC passes of tools/profile_pmc.sh over a bench run
+ROUND=${ROUND:-r05}
+WHAT=${1:-tests}; TAG=${2:-x}; shift 2 2>/dev/null
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+OUT=gpurun_out/$ROUND; mkdir -p $OUT
+export TMPDIR=/tmp
+show() { python - "$@" <<'PY'
+import json, sys
+for f in sys.argv[1:]:
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e:
+        print(f, "unreadable:", e); continue
+    r = d.get("roofline") or {}
+    print(f, d.get("metric"), d.get("value"), d.get("unit"), "ms/step", d.get("ms_per_step"), "kernel_ms", r.get("kernel_ms"), "frac", r.get("frac"),
+          "identical", (d.get("config") or {}).get("all_frames_identical_to_source"))
+PY
+}
+case $WHAT in
+tests)
+    timeout 2400 python -m pytest ${@:-tests} -x -q -m gpu 2>&1 | tail -15 | tee $OUT/tests_$TAG.log ;;
+check_ab)
+    timeout 900 python -m pytest tests/test_gpu_check.py tests/test_gpu_stages.py -x -q -m gpu 2>&1 | tail -5 | tee $OUT/tests_$TAG.log
+    timeout 600 python bench.py --mode check --steps 2 --warmup 1 --legs "" > $OUT/check_$TAG.json 2> $OUT/check_$TAG.err || tail -3 $OUT/check_$TAG.err
+    timeout 600 python bench.py --mode check --steps 2 --warmup 1 --legs "" --slices 576 --check-batch 256 > $OUT/check576_$TAG.json 2> $OUT/check576_$TAG.err || tail -3 $OUT/check576_$TAG.err
+    show $OUT/check_$TAG.json $OUT/check576_$TAG.json ;;
+bench)
+    timeout 1500 python bench.py "$@" > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err || tail -5 $OUT/bench_$TAG.err
+    show $OUT/bench_$TAG.json ;;
+line)
+    timeout 1500 python bench.py > $OUT/line_$TAG.json 2> $OUT/line_$TAG.err || tail -5 $OUT/line_$TAG.err
+    show $OUT/line_$TAG.json ;;
+stats)
+    cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/stats_$TAG" -o s -- python "$OLDPWD/bench.py" "$@" > "$OLDPWD/$OUT/stats_$TAG.json" 2> "$OLDPWD/$OUT/stats_$TAG.err"; cd "$OLDPWD"
+    python tools/rocprof_summary.py $OUT/stats_$TAG 2>/dev/null | head -30 ;;
+pmc)
+    bash tools/profile_pmc.sh $OUT/pmc_$TAG "$@" ;;
+*)  echo "round.sh: unknown '$WHAT'"; exit 2 ;;
+esac
