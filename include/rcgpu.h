@@ -216,16 +216,20 @@ int rcgpu_ffv1_encode_host(rcgpu_ffv1* enc, const uint8_t* const* frames, uint32
  * else cfg->max_batch when that is above 1, else sized from the device's free memory and the sequence length.  All callbacks return 0
  * for success; a failure ends the job with that code. */
 typedef struct {
+    uint32_t struct_size;               /* sizeof(rcgpu_sequence_io) as the caller was compiled: a caller built against another rcgpu.h is refused
+                                           instead of having a slot it never set called */
     int      (*read_frame)(void* user, uint64_t frame, uint8_t* dst, size_t payload_bytes);     /* reader threads, concurrent */
     uint8_t* (*place_packet)(void* user, uint64_t frame, size_t size);                         /* one thread, frame order; optional */
     int      (*packet_done)(void* user, uint64_t frame, const uint8_t* data, size_t size);     /* writer threads, concurrent */
     void* user;
-    /* optional, INSTEAD of read_frame (which is then NULL): the frame's payload lies in PINNED host memory already (hipHostMalloc /
-     * hipHostRegister) and stays there until its batch has been modelled; it is uploaded from where it is -- no upload slots, no reader
-     * threads, no copy.  SURVEY.md 8d's "inputs resident in pinned host memory, H2D included". */
+    /* optional, INSTEAD of read_frame (exactly one of the two is set; both is refused): the frame's payload lies in PINNED host memory already
+     * (hipHostMalloc / hipHostRegister) and stays there until its batch has been modelled; it is uploaded from where it is -- no upload slots,
+     * no reader threads, no copy.  SURVEY.md 8d's "inputs resident in pinned host memory, H2D included".  Called from the LANE threads (one per
+     * device and lane), concurrently, in no order across lanes, and with run-on encoders while the lane's previous batch is still in flight. */
     const uint8_t* (*locate_frame)(void* user, uint64_t frame, size_t payload_bytes);
 } rcgpu_sequence_io;
 typedef struct {
+    uint32_t struct_size;               /* sizeof(rcgpu_sequence_options) as the caller was compiled (see rcgpu_sequence_io) */
     int device_first, device_count;     /* 0 devices = all visible */
     uint32_t batch;                     /* frames per batch and device; 0 = automatic */
     uint32_t readers, writers;          /* host threads; 0 = automatic */
@@ -266,10 +270,14 @@ int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t n_frames, 
                                const rcgpu_sequence_options* options, rcgpu_sequence_stats* stats, uint8_t* record, size_t* record_size);
 
 /* The sharding rcgpu_ffv1_encode_sequence follows, without a device: frames are coded in batches of `batch` consecutive frames, batch b on
- * lane b mod lanes (a lane = one device of the selection; SURVEY.md 8e: frames shard with no exchange because every frame is a key frame and
- * every slice resets its contexts, CLI/Global.cpp:959-960).  lane_of_frame / batch_of_frame: n_frames entries each, either may be NULL.  For
- * callers that want their input staged next to the device that will read it. */
+ * lane b mod L (frames shard with no exchange because every frame is a key frame and every slice resets its contexts,
+ * CLI/Global.cpp:959-960).  `lanes` = the devices of the selection (x lanes_per_device); L = the lanes the job really gets -- a short job
+ * uses no more devices than it has batches of 8 frames for, exactly as the pipeline decides it: rcgpu_sequence_plan_lanes(n_frames, devices,
+ * lanes_per_device) says how many (20 frames on 8 devices: 3).  It matches the pipeline when `batch` is the batch the pipeline uses
+ * (options.batch passed explicitly; an automatic batch comes from the device's free memory).  lane_of_frame / batch_of_frame: n_frames
+ * entries each, either may be NULL.  For callers that want their input staged next to the device that will read it. */
 int rcgpu_sequence_plan(uint64_t n_frames, uint32_t batch, uint32_t lanes, uint32_t* lane_of_frame, uint32_t* batch_of_frame);
+uint32_t rcgpu_sequence_plan_lanes(uint64_t n_frames, uint32_t devices, uint32_t lanes_per_device);
 
 /* The same with host memory on both ends: frame i = frames[i % n_in], packet i -> out[i % n_out] (out_cap bytes each, may be NULL to
  * drop the bytes) and sizes[i] (n_frames entries, may be NULL).  n_in == n_out == n_frames: rcgpu_ffv1_encode_host for a whole

@@ -58,12 +58,12 @@ LOCATE_FRAME_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64, C.c_size_t)
 
 
 class SequenceIo(C.Structure):
-    _fields_ = [("read_frame", READ_FRAME_FN), ("place_packet", PLACE_PACKET_FN), ("packet_done", PACKET_DONE_FN), ("user", C.c_void_p),
+    _fields_ = [("struct_size", C.c_uint32), ("read_frame", READ_FRAME_FN), ("place_packet", PLACE_PACKET_FN), ("packet_done", PACKET_DONE_FN), ("user", C.c_void_p),
                 ("locate_frame", LOCATE_FRAME_FN)]
 
 
 class SequenceOptions(C.Structure):
-    _fields_ = [("device_first", C.c_int), ("device_count", C.c_int), ("batch", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("device_first", C.c_int), ("device_count", C.c_int), ("batch", C.c_uint32), ("readers", C.c_uint32), ("writers", C.c_uint32),
                 ("in_ring_frames", C.c_uint32), ("out_ring_bytes", C.c_uint64), ("lanes_per_device", C.c_uint32),
                 ("copy_streams", C.c_uint32), ("device_aliases", C.c_uint32), ("frames_pinned", C.c_uint32), ("run_on", C.c_uint32), ("numa", C.c_uint32)]
 
@@ -123,6 +123,7 @@ SYMBOLS = {
     "rcgpu_ffv1_join": (C.c_int, [_VP, _VP]),
     "rcgpu_ffv1_run_on": (C.c_int, [_VP]),
     "rcgpu_sequence_plan": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rcgpu_sequence_plan_lanes": (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32]),
     "rcgpu_ffv1_encode_sequence": (C.c_int, [C.POINTER(Ffv1Config), C.c_uint64, C.POINTER(SequenceIo), C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
     "rcgpu_ffv1_encode_sequence_memory": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP), C.c_uint64, C.c_uint64, C.POINTER(_VP), C.c_uint64, _SZ, C.POINTER(C.c_uint64),
                                           C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
@@ -368,6 +369,11 @@ def sequence_plan(n_frames: int, batch: int, lanes: int) -> tuple[list[int], lis
     return list(lane[:n_frames]), list(bat[:n_frames])
 
 
+def sequence_plan_lanes(n_frames: int, devices: int, lanes_per_device: int = 1) -> int:
+    """rcgpu_sequence_plan_lanes: the lanes a job of n_frames really gets (a device per 8 frames at most) -- the pipeline's own decision."""
+    return int(lib().rcgpu_sequence_plan_lanes(n_frames, devices, lanes_per_device))
+
+
 def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, place_packet=None, batch=0, readers=0, writers=0,
                     in_ring_frames=0, out_ring_bytes=0, device_first=0, device_count=0, lanes_per_device=0, copy_streams=0, device_aliases=0, numa=0):
     """rcgpu_ffv1_encode_sequence: `read_frame(frame, dst_address, nbytes) -> int` fills a pinned upload slot, `packet_done(frame,
@@ -376,8 +382,8 @@ def encode_sequence(cfg: Ffv1Config, n_frames: int, read_frame, packet_done, pla
     rf = READ_FRAME_FN(lambda user, frame, dst, n: int(read_frame(frame, dst, n) or 0))
     pd = PACKET_DONE_FN(lambda user, frame, data, n: int(packet_done(frame, data, n) or 0))
     pp = PLACE_PACKET_FN(lambda user, frame, n: place_packet(frame, n) or 0) if place_packet else PLACE_PACKET_FN()
-    io = SequenceIo(rf, pp, pd, None)
-    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes, lanes_per_device, copy_streams, device_aliases, 0, 0, numa)
+    io = SequenceIo(C.sizeof(SequenceIo), rf, pp, pd, None)
+    opt = SequenceOptions(C.sizeof(SequenceOptions), device_first, device_count, batch, readers, writers, in_ring_frames, out_ring_bytes, lanes_per_device, copy_streams, device_aliases, 0, 0, numa)
     st = SequenceStats()
     rec = C.create_string_buffer(8192)
     rs = _SZ(8192)
@@ -391,7 +397,7 @@ def encode_sequence_memory(cfg: Ffv1Config, frame_addrs: list[int], n_frames: in
     fin = (_VP * len(frame_addrs))(*frame_addrs)
     fout = (_VP * len(out_addrs))(*out_addrs) if out_addrs else None
     sizes = (C.c_uint64 * n_frames)()
-    opt = SequenceOptions(device_first, device_count, batch, readers, writers, in_ring_frames, 0, lanes_per_device, copy_streams, device_aliases, frames_pinned, run_on, numa)
+    opt = SequenceOptions(C.sizeof(SequenceOptions), device_first, device_count, batch, readers, writers, in_ring_frames, 0, lanes_per_device, copy_streams, device_aliases, frames_pinned, run_on, numa)
     st = SequenceStats()
     _check(lib().rcgpu_ffv1_encode_sequence_memory(C.byref(cfg), fin, len(frame_addrs), n_frames, fout, len(out_addrs), out_cap, sizes, C.byref(opt), C.byref(st), None, None),
            "rcgpu_ffv1_encode_sequence_memory")

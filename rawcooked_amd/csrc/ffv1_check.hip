@@ -817,12 +817,14 @@ struct rcgpu_ffv1_decoder {
     // out the current batch's frames and has them verified; nothing else may decode with this decoder until it is joined.
     struct hint_t {
         std::thread th; bool active = false; int set = -1, rc = 0;
+        std::string error;                          // rcgpu_last_error() of the hint thread (the text is thread-local: the adopting call reports it)
         std::vector<const uint8_t*> packets; std::vector<uint64_t> sizes;
     } hint;
     uint8_t* d_kept_in2 = nullptr; size_t kept_in2_cap = 0;
     // the library's own mapping of the file a batch is hinted from (decode_keep_hint_file): the reference maps its Matroska file anew every
     // megabyte it advances (Matroska.cpp:394-408, FileIO.cpp:258-283), so its pointers do not outlive the call they are passed in
     std::string map_path; const uint8_t* map_base = nullptr; size_t map_size = 0;
+    dev_t map_dev = 0; ino_t map_ino = 0; struct timespec map_mtime = {};     // what was mapped: a file rewritten or replaced under the same name is mapped anew
     size_t kept_stride = 0;
     uint8_t* d_kept_in = nullptr; size_t kept_in_cap = 0;       // the packets of a batch
     uint8_t* d_disk = nullptr; size_t disk_cap = 0;
@@ -1222,7 +1224,7 @@ static int decode_keep_into(rcgpu_ffv1_decoder* d, int set, uint8_t*& d_in, size
     }
     {
         const hipError_t he = upload_side_by_side(lanes, d->cfg.device, up);
-        if (he == hipErrorFileNotFound) return fail(20, "ffv1 decoder: the file ends before a packet does");
+        if (he == hipErrorFileNotFound) return fail(21, "ffv1 decoder: the file ends before a packet does");
         HIP_TRY(he);
         clk.lap("decode_keep: packets up", n);
     }
@@ -1262,6 +1264,7 @@ extern "C" int rcgpu_ffv1_decoder_decode_keep_hint(rcgpu_ffv1_decoder* d, const 
     d->hint.th = std::thread([d, n] {
         (void)hipSetDevice(d->cfg.device);
         d->hint.rc = decode_keep_into(d, d->hint.set, d->d_kept_in2, d->kept_in2_cap, d->up2, d->hint.packets.data(), -1, nullptr, d->hint.sizes.data(), n);
+        d->hint.error = d->hint.rc ? rcgpu_last_error() : "";
     });
     return 0;
 }
@@ -1273,19 +1276,25 @@ extern "C" int rcgpu_ffv1_decoder_decode_keep_hint_file(rcgpu_ffv1_decoder* d, c
     if (!d || !path || !offsets || !packet_sizes) return fail(1, "ffv1 decoder: null argument");
     if (!n || n > d->cfg.max_batch) return fail(2, "ffv1 decoder: batch of %u frames (max_batch %u)", n, d->cfg.max_batch);
     if (d->hint.active) return 0;
-    if (d->map_path != path) {
+    // the mapping is kept for the decoder's life, but only while it is still THAT file: same name, device, inode, size and modification time
+    struct stat now;
+    const bool have = stat(path, &now) == 0;
+    const bool same = have && d->map_base && d->map_path == path && now.st_dev == d->map_dev && now.st_ino == d->map_ino && size_t(now.st_size) == d->map_size &&
+                      now.st_mtim.tv_sec == d->map_mtime.tv_sec && now.st_mtim.tv_nsec == d->map_mtime.tv_nsec;
+    if (!same) {
         if (d->map_base) { (void)munmap(const_cast<uint8_t*>(d->map_base), d->map_size); d->map_base = nullptr; d->map_size = 0; d->map_path.clear(); }
         const int fd = open(path, O_RDONLY);
-        if (fd < 0) return fail(20, "ffv1 decoder: cannot open %s", path);
+        if (fd < 0) return fail(21, "ffv1 decoder: cannot open %s", path);
         struct stat st;
         void* m = fstat(fd, &st) == 0 && st.st_size > 0 ? mmap(nullptr, size_t(st.st_size), PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;
         close(fd);
-        if (m == MAP_FAILED) return fail(20, "ffv1 decoder: cannot map %s", path);
+        if (m == MAP_FAILED) return fail(21, "ffv1 decoder: cannot map %s", path);
         d->map_base = static_cast<const uint8_t*>(m); d->map_size = size_t(st.st_size); d->map_path = path;
+        d->map_dev = st.st_dev; d->map_ino = st.st_ino; d->map_mtime = st.st_mtim;
     }
     std::vector<const uint8_t*> pk(n);
     for (uint32_t i = 0; i < n; i++) {
-        if (offsets[i] > d->map_size || packet_sizes[i] > d->map_size - offsets[i]) return fail(20, "ffv1 decoder: the file ends before a packet does");
+        if (offsets[i] > d->map_size || packet_sizes[i] > d->map_size - offsets[i]) return fail(21, "ffv1 decoder: the file ends before a packet does");
         pk[i] = d->map_base + offsets[i];
     }
     return rcgpu_ffv1_decoder_decode_keep_hint(d, pk.data(), packet_sizes, n);
@@ -1301,7 +1310,7 @@ extern "C" int rcgpu_ffv1_decoder_decode_keep_adopt(rcgpu_ffv1_decoder* d)
     kept_clock clk;
     hint_join(d, true);
     clk.lap("decode_keep: waited for the batch decoded ahead", uint32_t(d->hint.packets.size()));
-    if (d->hint.rc) { d->kept[d->hint.set].n = 0; return fail(d->hint.rc, "ffv1 decoder: the batch decoded ahead failed"); }
+    if (d->hint.rc) { d->kept[d->hint.set].n = 0; return fail(d->hint.rc, "ffv1 decoder: the batch decoded ahead failed: %s", d->hint.error.c_str()); }
     d->kept_cur = d->hint.set;
     return 0;
 }

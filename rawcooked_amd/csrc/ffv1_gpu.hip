@@ -1882,7 +1882,21 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
         if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->model_stream, hipStreamNonBlocking, lo);
         if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->tail_stream, hipStreamNonBlocking, lo);
         e->front_stream = e->rr_stream;             // the split coder's stream, idle in this mode: no fifth stream at the normal priority
-        if (he != hipSuccess) return fail(101, "ffv1: run-on mode: cannot allocate the second bank for %u frames: %s -- lower max_batch", F, hipGetErrorString(he));
+        if (he != hipSuccess) {
+            // nothing of a half-made bank stays behind: the memory it holds is what the first batch's windows need, and a second attempt
+            // would overwrite (leak) the pointers
+            void* abufs[] = { b.d_frame_ptrs, b.d_sym, b.d_states, b.d_ndec, b.d_total_n, b.d_seg_pieces, b.d_group_off, b.d_k3_resume, b.d_k4_resume, b.d_cbuf,
+                              b.d_out_len, b.d_tot_len, b.d_slice_dst, b.d_err, b.d_events };
+            for (void* q : abufs) if (q) (void)hipFree(q);
+            b.d_frame_ptrs = nullptr; b.d_sym = nullptr; b.d_states = nullptr; b.d_ndec = nullptr; b.d_total_n = nullptr; b.d_seg_pieces = nullptr; b.d_group_off = nullptr;
+            b.d_k3_resume = nullptr; b.d_k4_resume = nullptr; b.d_cbuf = nullptr; b.d_out_len = nullptr; b.d_tot_len = nullptr; b.d_slice_dst = nullptr; b.d_err = nullptr; b.d_events = nullptr;
+            for (hipEvent_t* q : { &b.ev_done, &e->ev_in, &e->ev_model }) if (*q) { (void)hipEventDestroy(*q); *q = nullptr; }
+            for (hipStream_t* q : { &e->model_stream, &e->tail_stream }) if (*q) { (void)hipStreamDestroy(*q); *q = nullptr; }
+            e->front_stream = nullptr;
+            e->run_on = false;
+            (void)hipGetLastError();
+            return fail(101, "ffv1: run-on mode: cannot allocate the second bank for %u frames: %s -- lower max_batch", F, hipGetErrorString(he));
+        }
         e->alt_allocated = true;
     }
     e->run_on = true;
@@ -2066,6 +2080,7 @@ extern "C" int rcgpu_ffv1_encode_host(rcgpu_ffv1* e, const uint8_t* const* frame
         ptrs[i] = sg.d_in + i * sg.in_stride;
     }
     if (int r = rcgpu_ffv1_encode_device(e, ptrs.data(), n, e->d_packets, e->max_packet, reinterpret_cast<uint64_t*>(e->d_psizes), st)) return r;
+    if (e->run_on) if (int r = rcgpu_ffv1_join(e, st)) return r;      // run-on mode leaves the batch unjoined: its coder, footer, scan and gather are still on their streams
     uint32_t err = 0;
     HIP_TRY(hipMemcpyAsync(e->h_psizes, e->d_psizes, 8 * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&err, e->d_err, 4, hipMemcpyDeviceToHost, st));
@@ -2096,6 +2111,7 @@ extern "C" int rcgpu_ffv1_framemd5_last(rcgpu_ffv1* e, uint32_t n, uint8_t* out_
     const uint64_t bytes = uint64_t(c.samples_per_frame) * (c.bps == 8 ? 1 : 2);
     const size_t stride = size_t(c.samples_per_frame) * 4;
     hipStream_t st = e->own_stream;
+    if (e->run_on) if (int r = rcgpu_ffv1_join(e, st)) return r;      // the rawvideo bytes go into the bank's symbol buffer: not while its k_resolve may still be reading it
     hipLaunchKernelGGL(k_rawvideo, dim3((c.W * c.H + 255) / 256, n), dim3(256), 0, st, e->d_const, e->d_frame_ptrs, reinterpret_cast<uint8_t*>(e->d_sym), stride);
     HIP_TRY(hipGetLastError());
     std::vector<const void*> bufs(n); std::vector<uint64_t> sizes(n, bytes);

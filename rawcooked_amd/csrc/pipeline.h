@@ -88,6 +88,6 @@ private:
 
 // Device memory one frame in flight needs inside an encoder of this configuration (symbols, states, stream windows, slice and
 // packet buffers, payload), without creating one.
-uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& cfg);
+uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& cfg, bool run_on = false);   // run_on: with the encoder's second bank
 
 }  // namespace rc

@@ -198,7 +198,17 @@ pipeline::~pipeline() {}
 rcgpu_ffv1* pipeline::encoder(uint32_t video) const { return p->lanes.empty() || video >= p->lanes[0].enc.size() ? nullptr : p->lanes[0].enc[video]; }
 uint32_t pipeline::batch_frames(uint32_t video) const { return video < p->F.size() ? p->F[video] : 0; }
 
-uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& c)
+// devices and lanes a job of `longest` frames gets out of `devices` devices: a device per 8 frames at most, lanes_per_device (<= 4) lanes on each
+static int effective_lanes(uint64_t longest, uint32_t devices, uint32_t lanes_per_device, int* devices_used)
+{
+    const uint64_t min_batch = 8, chunks = (longest + min_batch - 1) / min_batch;
+    const int ndev_used = int(std::max<uint64_t>(1, std::min<uint64_t>(devices, chunks)));
+    const int per_dev = int(std::max(1u, std::min(4u, lanes_per_device)));
+    if (devices_used) *devices_used = ndev_used;
+    return int(std::max<uint64_t>(ndev_used, std::min<uint64_t>(uint64_t(ndev_used) * per_dev, chunks)));
+}
+
+uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& c, bool run_on)
 {
     if (c.pixfmt >= RCGPU_PIX_COUNT) return 0;
     const pix_desc& d = pix(c.pixfmt);
@@ -213,7 +223,9 @@ uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& c)
     const uint64_t windows = samples * 35 * 8 / 7 * (nseg > 1 ? 3 : 1) / nseg;              // worst case: 35 decisions per sample, 64 bytes per 56 of them; three windows (split coder)
     const uint64_t ckpt = samples * 35 / 56 / 8 + S * nseg * 8;                              // split coder: 8 bytes per span of >= 8 pieces and slice
     const uint64_t cbuf = raw * 3 / 2 + S * ((256u << 10) + 4096 + 32);
-    return samples * 4 + states + windows + ckpt + 2 * cbuf + raw + (1u << 20);
+    // run-on mode: the encoder's second bank (rcgpu_ffv1_set_run_on) -- symbols, context states, slice byte buffers once more
+    const uint64_t second_bank = run_on ? samples * 4 + states + cbuf + S * 64 : 0;
+    return samples * 4 + states + windows + ckpt + 2 * cbuf + raw + (1u << 20) + second_bank;
 }
 
 int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options& opt)
@@ -236,11 +248,9 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
     cnt = std::min(cnt, ndev - dev0);
     uint64_t longest = 0;
     for (const pipe_video& v : videos) longest = std::max(longest, v.frames);
-    // no more lanes than there is work for: a short job on an 8-GPU node uses the devices it can fill
-    const uint64_t min_batch = 8;
-    const int ndev_used = int(std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cnt), (longest + min_batch - 1) / min_batch)));
-    const int per_dev = int(std::max(1u, std::min(4u, opt.lanes_per_device)));
-    cnt = int(std::max<uint64_t>(ndev_used, std::min<uint64_t>(uint64_t(ndev_used) * per_dev, (longest + min_batch - 1) / min_batch)));
+    // no more lanes than there is work for: a short job on an 8-GPU node uses the devices it can fill (effective_lanes: also behind rcgpu_sequence_plan)
+    int ndev_used = 1;
+    cnt = effective_lanes(longest, uint32_t(cnt), opt.lanes_per_device, &ndev_used);
     s.lanes.resize(size_t(cnt));
     s.F.assign(videos.size(), 1); s.payload.assign(videos.size(), 0); s.max_packet.assign(videos.size(), 0);
     for (int li = 0; li < cnt; li++) {
@@ -259,7 +269,7 @@ int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options&
                 // which does not --, and evened out over the batches of the sequence.  The bound is in CHAINS: the 576
                 // slices RAWcooked asks for at 4K (DPX.cpp:428-458) fill the device with 40 frames (571 frames/s; 546 with 256, whose 71 GB of
                 // context states alone take 4.3 s to allocate).
-                const uint64_t per = std::max<uint64_t>(1, ffv1_device_bytes_per_frame(c));
+                const uint64_t per = std::max<uint64_t>(1, ffv1_device_bytes_per_frame(c, opt.run_on == 1));
                 const uint64_t share = videos.size() * uint64_t((cnt + ndev_used - 1) / ndev_used);      // encoders that will live on this device
                 const uint64_t slices = std::max<uint64_t>(1, uint64_t(c.num_h_slices) * c.num_v_slices);
                 const uint64_t by_chains = std::min<uint64_t>(336, std::max<uint64_t>(8, (336 * 64 + slices - 1) / slices));
@@ -876,7 +886,12 @@ extern "C" int rcgpu_ffv1_encode_sequence(const rcgpu_ffv1_config* cfg, uint64_t
 {
     using namespace rc;
     clear_error();
-    if (!cfg || !io || (!io->read_frame && !io->locate_frame) || !io->packet_done) return fail(1, "sequence: null argument");
+    if (!cfg || !io) return fail(1, "sequence: null argument");
+    if (io->struct_size != sizeof(rcgpu_sequence_io) || (opt && opt->struct_size != sizeof(rcgpu_sequence_options)))
+        return fail(1, "sequence: struct_size %u / %u, this library's structs have %zu / %zu bytes -- the caller was built against another rcgpu.h",
+                    io->struct_size, opt ? opt->struct_size : 0u, sizeof(rcgpu_sequence_io), sizeof(rcgpu_sequence_options));
+    if ((!io->read_frame && !io->locate_frame) || !io->packet_done) return fail(1, "sequence: null argument");
+    if (io->read_frame && io->locate_frame) return fail(1, "sequence: read_frame and locate_frame are alternatives -- set one");
     pipe_video v; v.cfg = *cfg; v.frames = n_frames;
     pipe_options po;
     if (opt) { po.device_first = opt->device_first; po.device_count = opt->device_count; po.readers = opt->readers; po.writers = opt->writers;
@@ -923,12 +938,17 @@ extern "C" int rcgpu_sequence_plan(uint64_t n_frames, uint32_t batch, uint32_t l
     if (!batch || !lanes) return rc::fail(1, "sequence plan: batch and lanes must be at least 1");
     std::vector<uint32_t> video_of(size_t(n_frames), 0), batch_of;
     std::vector<rc::batch_t> batches;
-    rc::plan_batches(video_of, { batch }, { n_frames }, int(lanes), false, batches, batch_of);
+    rc::plan_batches(video_of, { batch }, { n_frames }, rc::effective_lanes(n_frames, lanes, 1, nullptr), false, batches, batch_of);
     for (uint64_t i = 0; i < n_frames; i++) {
         if (lane_of_frame) lane_of_frame[i] = uint32_t(batches[batch_of[size_t(i)]].lane);
         if (batch_of_frame) batch_of_frame[i] = batch_of[size_t(i)];
     }
     return 0;
+}
+
+extern "C" uint32_t rcgpu_sequence_plan_lanes(uint64_t n_frames, uint32_t devices, uint32_t lanes_per_device)
+{
+    return devices ? uint32_t(rc::effective_lanes(n_frames, devices, lanes_per_device, nullptr)) : 0u;
 }
 
 // Host memory in, host memory out: frame i is frames[i % n_in], packet i lands in out[i % n_out] (out_cap bytes each) and sizes[i].
@@ -965,7 +985,8 @@ extern "C" int rcgpu_ffv1_encode_sequence_memory(const rcgpu_ffv1_config* cfg, c
     rc::clear_error();
     if (!cfg || !frames || !n_in) return rc::fail(1, "sequence: null argument");
     memory_io m{ frames, n_in, out, n_out, out_cap, sizes };
-    rcgpu_sequence_io io{ memory_read, nullptr, memory_done, &m, nullptr };
+    if (opt && opt->struct_size != sizeof(rcgpu_sequence_options)) return rc::fail(1, "sequence: options.struct_size %u, this library's struct has %zu bytes", opt->struct_size, sizeof(rcgpu_sequence_options));
+    rcgpu_sequence_io io{ uint32_t(sizeof(rcgpu_sequence_io)), memory_read, nullptr, memory_done, &m, nullptr };
     if (opt && opt->frames_pinned) { io.read_frame = nullptr; io.locate_frame = memory_locate; }
     return rcgpu_ffv1_encode_sequence(cfg, n_frames, &io, opt, stats, record, record_size);
 }

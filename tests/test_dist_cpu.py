@@ -17,9 +17,14 @@ def test_the_products_shard_plan_covers_every_frame_once_in_order():
         for lanes in (1, 2, 3, 8):
             for batch in (1, 5, 336):
                 lane, bat = api.sequence_plan(n, batch, lanes)
-                assert len(lane) == n and all(0 <= x < lanes for x in lane)
+                # the lanes the job really gets: a device per 8 frames at most (pipeline::prepare's own rule -- 20 frames on 8 devices run on 3)
+                L = api.sequence_plan_lanes(n, lanes)
+                assert L == max(1, min(lanes, (n + 7) // 8))
+                assert len(lane) == n and all(0 <= x < L for x in lane)
                 assert bat == [i // batch for i in range(n)]                     # batches are runs of consecutive frames ...
-                assert lane == [(i // batch) % lanes for i in range(n)]         # ... dealt to the lanes in turn (batch b -> lane b mod lanes)
+                assert lane == [(i // batch) % L for i in range(n)]             # ... dealt to the lanes in turn (batch b -> lane b mod L)
+    assert api.sequence_plan_lanes(20, 8) == 3 and api.sequence_plan_lanes(20, 8, 2) == 3 and api.sequence_plan_lanes(2000, 8, 2) == 16
+    assert set(api.sequence_plan(20, 4, 8)[0]) == {0, 1, 2}
     lane, _ = api.sequence_plan(10, 2, 2)
     assert [i for i in range(10) if lane[i] == 0] == [0, 1, 4, 5, 8, 9] and [i for i in range(10) if lane[i] == 1] == [2, 3, 6, 7]
     # BASELINE config 4: 2000 frames over 8 GPUs in batches of 80 -> 25 batches, lanes 0..7 then 0 again; no lane idles while another has two more

@@ -145,6 +145,33 @@ def test_run_on_mode_is_bit_exact(built, w, h, pixfmt, slices, nframes, segments
     enc.close()
 
 
+def test_run_on_mode_and_the_host_conveniences(built):
+    """rcgpu_ffv1_encode_host and rcgpu_ffv1_framemd5_last with a run-on encoder: encode_device leaves the batch unjoined in that mode (its
+    coder, footer, scan and gather are still on their streams), so both join it before they read sizes and packets / before the rawvideo
+    bytes go into the bank's symbol buffer.  Several batches back to back, packets against the oracle, frame sums against run-on off."""
+    w, h, pixfmt, nh, nv, n = 200, 120, synth.PIX_RGB16_BE, 3, 2, 6
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    batches = []
+    for b in range(4):
+        pls = [synth.pack_payload(synth.components(w, h, nc, bits, "film" if (b + i) % 2 else "noise", seed=50 * b + i), pixfmt, True) for i in range(n - b)]
+        batches.append([x[0] for x in pls])
+        line_bytes = pls[0][1]
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=n, rc_span=1)
+    want_sums = []
+    for pls in batches:
+        enc.encode_host(pls)
+        want_sums.append(enc.framemd5_last(len(pls)))
+    enc.set_run_on(True)
+    for b, pls in enumerate(batches):
+        got = enc.encode_host(pls)
+        for i, pl in enumerate(pls):
+            assert got[i] == ob.encode_payload(p, pl, line_bytes), f"batch {b} frame {i}"
+        assert enc.framemd5_last(len(pls)) == want_sums[b]
+        assert enc.error_flags() == 0
+    enc.close()
+
+
 def test_run_on_mode_and_the_split_coder_exclude_each_other(built):
     enc = api.Ffv1Encoder(64, 48, synth.PIX_RGB16_BE, 64 * 6, 2, 2, 1, 1, max_batch=2, rc_span=8)
     with pytest.raises(api.RcgpuError, match="run-on"):

@@ -508,3 +508,21 @@ def test_decoder_for_stream_says_unsupported_before_it_looks_for_a_device(built)
         s2 = api.Ffv1Stream(_ext_record(v), open(os.path.join(_G, v["frames"][0]["packet"]), "rb").read())
         with pytest.raises(api.RcgpuError, match="no HIP device"):
             api.Ffv1Decoder(v["width"], v["height"], v["pixfmt"], v["line_bytes"], max_batch=1, stream=s2)
+
+
+def test_sequence_structs_carry_their_size_and_one_input_callback(built):
+    """rcgpu_sequence_io / rcgpu_sequence_options begin with struct_size: a caller compiled against another rcgpu.h is refused before any of its
+    slots is called; read_frame and locate_frame are alternatives."""
+    import ctypes as C
+    cfg = api.Ffv1Config(64, 48, synth.PIX_RGB16_BE, 384, 2, 2, 1, 1, 2, 0, 0, 0, 1, 3)
+    rf = api.READ_FRAME_FN(lambda user, frame, dst, n: 0)
+    pd = api.PACKET_DONE_FN(lambda user, frame, data, n: 0)
+    lf = api.LOCATE_FRAME_FN(lambda user, frame, n: 0)
+    call = lambda io, opt: api.lib().rcgpu_ffv1_encode_sequence(C.byref(cfg), 4, C.byref(io), C.byref(opt) if opt is not None else None, None, None, None)
+    good_opt = api.SequenceOptions(C.sizeof(api.SequenceOptions))
+    assert call(api.SequenceIo(0, rf, api.PLACE_PACKET_FN(), pd, None), good_opt) == 1 and "another rcgpu.h" in api.last_error()
+    assert call(api.SequenceIo(C.sizeof(api.SequenceIo) - 8, rf, api.PLACE_PACKET_FN(), pd, None), good_opt) == 1
+    assert call(api.SequenceIo(C.sizeof(api.SequenceIo), rf, api.PLACE_PACKET_FN(), pd, None), api.SequenceOptions(4)) == 1 and "another rcgpu.h" in api.last_error()
+    assert call(api.SequenceIo(C.sizeof(api.SequenceIo), rf, api.PLACE_PACKET_FN(), pd, None, lf), good_opt) == 1 and "alternatives" in api.last_error()
+    if api.lib().rcgpu_device_count() < 1:                       # well-formed: gets as far as looking for a device
+        assert call(api.SequenceIo(C.sizeof(api.SequenceIo), rf, api.PLACE_PACKET_FN(), pd, None), good_opt) == 4 and "no HIP device" in api.last_error()
