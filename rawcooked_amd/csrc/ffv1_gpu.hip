@@ -47,6 +47,7 @@ struct enc_const {
     uint32_t num_h, num_v, S, nctx, nsets, ec, is5;
     uint32_t samples_per_frame;            // W*H*planes
     uint32_t nseg;                         // segments a slice is cut into for the k_resolve -> k_rangecode hand-over
+    uint32_t rc_prio;                      // the whole-slice coder's wave priority (3; the timing build's RCGPU_RC_PRIO measures the others)
     int16_t  q[5][256];
     uint8_t  one_state[256], zero_state[256];
 };
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
     constexpr int kDrain = SPAN ? kDrainSpan : kDrainWhole, kRows = ring_rows(kDrain);
     __shared__ uint32_t obuf[kRows * 64];
     // The whole-slice coder is latency-bound and shares SIMDs with throughput-bound k_resolve wavefronts: take issue priority.
-    if (!SPAN) __builtin_amdgcn_s_setprio(3);
+    if (!SPAN) { const uint32_t pr = C->rc_prio; if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); }
     const int lane = threadIdx.x;
     const uint32_t chain = blockIdx.x * 64 + lane;
     const bool active = chain < nchains;
@@ -1571,6 +1572,8 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         }
     e->nseg = cfg->segments ? cfg->segments : std::max(1u, std::min(32u, min_nsamp / 1024));
     c.nseg = e->nseg;
+    c.rc_prio = 3;
+    if (const char* x = TIMING_ENV("RCGPU_RC_PRIO")) c.rc_prio = uint32_t(atoi(x));                          // for measuring
     // the split coder keeps a window until its spans are coded, two kernels behind k_resolve: a third window keeps k_resolve from waiting
     // (4096x2160, 168 frames per step: 476 frames/s with two windows, 565 with three or four)
     e->nwin = e->span_pieces ? kWindows + 1 : kWindows;
@@ -1620,8 +1623,21 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
 #undef DM
 #undef HM
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->rc_stream, hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->rr_stream, hipStreamNonBlocking);
+    // Timing build, RCGPU_EXP_PARTITION=k[,shared]: the range coder's kernels on k CUs of every XCD, k_resolve (in run-on mode: the front stream)
+    // on the other 32 - k -- or, with ",shared", on all of them.  Bit i of a CU mask is a CU of XCD i % 8 and a mask that leaves an XCD empty is
+    // ignored whole (tools/cu_mask_probe.hip).  Same bytes; the shipped library makes plain streams (profiles/r05_partition.jsonl says why).
+    if (const char* x = TIMING_ENV("RCGPU_EXP_PARTITION")) {
+        const int k = std::max(1, std::min(31, atoi(x)));
+        const bool shared = strstr(x, "shared") != nullptr;
+        uint32_t mrc[8], mrs[8];
+        for (int w = 0; w < 8; w++) { mrc[w] = 0; mrs[w] = 0; }
+        for (int i = 0; i < 256; i++) { if (i < 8 * k) mrc[i >> 5] |= 1u << (i & 31); else mrs[i >> 5] |= 1u << (i & 31); }
+        if (shared) for (int w = 0; w < 8; w++) mrs[w] = ~0u;
+        if (he == hipSuccess) he = hipExtStreamCreateWithCUMask(&e->rc_stream, 8, mrc);
+        if (he == hipSuccess) he = hipExtStreamCreateWithCUMask(&e->rr_stream, 8, mrs);
+    }
+    if (he == hipSuccess && !e->rc_stream) he = hipStreamCreateWithFlags(&e->rc_stream, hipStreamNonBlocking);
+    if (he == hipSuccess && !e->rr_stream) he = hipStreamCreateWithFlags(&e->rr_stream, hipStreamNonBlocking);
     e->ev.resize(2 * (7 + 3 * nseg));              // timing events: k_model, tails, footer, scan, gather + up to three kernels per segment
     for (auto& ev : e->ev) if (he == hipSuccess) he = hipEventCreate(&ev);
     e->ev_prev.resize(e->ev.size());
@@ -1811,7 +1827,10 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
                                                           (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, ck, e->span_pieces); }));
         } else {
             HIP_TRY(hipStreamWaitEvent(s2, k3, 0));
-            HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<false>, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
+            // timing build, RCGPU_EXP_RC_LDS=bytes: dynamic LDS nobody uses, so that a CU takes at most 160 KB / bytes of the coder's workgroups
+            // (40960: four, one per SIMD) -- the dispatcher otherwise packs a masked stream's wavefronts onto few SIMDs (profiles/r05_partition.jsonl)
+            static const uint32_t exp_rc_lds = TIMING_ENV("RCGPU_EXP_RC_LDS") ? uint32_t(atoi(TIMING_ENV("RCGPU_EXP_RC_LDS"))) : 0u;
+            HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<false>, dim3(ngroups), dim3(64), exp_rc_lds, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
                                                           j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
                                                           (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, static_cast<rc_ckpt*>(nullptr), 0u); }));
         }

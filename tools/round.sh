@@ -8,6 +8,7 @@
 #   line [tag]                    the driver's default line (python bench.py)
 #   stats [tag] [bench args]      rocprofv3 --kernel-trace --stats of a bench run -> stats_<tag>/
 #   pmc [tag] [bench args]        the PMC passes of tools/profile_pmc.sh over a bench run
+#   sweep [tag] "ENV=.." ...       one bench line per environment setting with the TIMING build -> sweep_<tag>.jsonl
 ROUND=${ROUND:-r05}
 WHAT=${1:-tests}; TAG=${2:-x}; shift 2 2>/dev/null
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
@@ -44,5 +45,24 @@ stats)
     python tools/rocprof_summary.py $OUT/stats_$TAG 2>/dev/null | head -30 ;;
 pmc)
     bash tools/profile_pmc.sh $OUT/pmc_$TAG "$@" ;;
+sweep)
+    # A/B over environment settings with the TIMING build (the shipped library reads no measuring switch): one bench line per argument
+    # ("A=1 B=2" "A=3" ...; "" = no setting) -> $OUT/sweep_<tag>.jsonl.  SWEEP_ARGS = extra bench.py arguments.
+    : > $OUT/sweep_$TAG.jsonl
+    for cfg in "$@"; do
+        env RCGPU_LIB=rawcooked_amd/librcgpu_timing.so RCGPU_BENCH_TIMING_BUILD=1 $cfg timeout 400 python bench.py --steps ${SWEEP_STEPS:-3} --warmup 1 --legs "" ${SWEEP_ARGS:-} > /tmp/line.json 2>/tmp/line.err || tail -3 /tmp/line.err
+        python - "$cfg" /tmp/line.json >> $OUT/sweep_$TAG.jsonl <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+    c, r = d["config"], d["roofline"]
+    print(json.dumps({"env": sys.argv[1], "frames_per_s": d["value"], "ms_per_step": d["ms_per_step"], "frames_per_step": c.get("frames_per_step_per_gpu"),
+                      "kernel_ms_per_step": {k: round(v, 1) for k, v in r.get("kernel_ms_per_step", {}).items()},
+                      "verified_vs_oracle": c.get("verified_vs_oracle"), "device_error_flags": c.get("device_error_flags"), "run_on": c.get("run_on")}))
+except Exception as e:
+    print(json.dumps({"env": sys.argv[1], "error": str(e)}))
+PY
+        tail -1 $OUT/sweep_$TAG.jsonl
+    done ;;
 *)  echo "round.sh: unknown '$WHAT'"; exit 2 ;;
 esac
