@@ -263,6 +263,105 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
         shutil.rmtree(work, ignore_errors=True)
 
 
+def long_sequence_leg(synth, host_ring, width, height, n_frames, pixfmt):
+    """The product on a sequence long enough to show its steady state (real sequences are 7 000 frames and more, Doc/Case_study.md:234-238;
+    the 1000-frame legs are three or four batches, mostly fill and drain): n_frames DPX files on tmpfs (the ring's distinct pictures,
+    hard-linked), then two processes of the REAL reference with this library linked in (oracle/Makefile.ref `linked`), each timed from
+    start to exit:  `rawcooked_linked --hash --no-check -y seq` -- analysis with the MD5 of every source (route D), FFV1 encoding at the reference's own
+    slice count into one Matroska file (route B) -- and `rawcooked_linked --check seq.mkv` (route C: the device decoder in batches, the
+    rebuilt files hashed on the device).  Steady rates from the processes' own traces: batches after the first / the time between the
+    first and the last batch's completion."""
+    import re
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    import numpy as np
+    exe = os.path.join(ROOT, "oracle", "_ref", "rawcooked_linked")
+    if not os.path.exists(exe):
+        return {"skipped": "oracle/_ref/rawcooked_linked is not here"}, True
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    R = len(host_ring)
+    payload = host_ring[0].nbytes
+    if not base or shutil.disk_usage(base).free < 1.2 * (n_frames * payload + R * payload) + (8 << 30):
+        return {"skipped": "no tmpfs with room for a %d-frame Matroska file" % n_frames}, True
+    work = tempfile.mkdtemp(prefix="rcgpu_long_", dir=base)
+    OKL = "Reversibility was checked, no issue detected."
+    try:
+        os.makedirs(os.path.join(work, "uniq")); os.makedirs(os.path.join(work, "seq"))
+        hdr = synth.dpx_file(np.zeros((1, 1, 3), dtype=np.uint16), pixfmt)[:2048]
+        for i in range(R):
+            h = bytearray(hdr)
+            struct.pack_into(">I", h, 772, width); struct.pack_into(">I", h, 776, height); struct.pack_into(">I", h, 16, 2048 + payload)
+            with open(os.path.join(work, "uniq", "u_%03d.dpx" % i), "wb") as f:
+                f.write(h); f.write(memoryview(host_ring[i]))
+        for i in range(n_frames):
+            os.link(os.path.join(work, "uniq", "u_%03d.dpx" % (i % R)), os.path.join(work, "seq", "f_%06d.dpx" % i))
+        env = dict(os.environ, RCGPU_TRACE="1", RCGPU_TRACE_KEPT="1", RCGPU_CHECK="1")
+        out = {"frames": n_frames, "unit": "frames/s", "distinct_pictures": R}
+
+        def run(cmd, timeout):
+            # stderr is read as it comes, every line with its arrival time: the processes' own traces say WHERE a long run spends its time
+            import threading
+            for attempt in range(2):      # one retry: the lost shutdown wake-up of the reference's thread pool (profiles/r04_hang_stacks.txt)
+                t0 = time.perf_counter()
+                pr = subprocess.Popen(cmd, cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE, stdin=subprocess.DEVNULL, text=True, env=env)
+                lines, outbuf = [], []
+
+                def pump_err():
+                    for ln in pr.stderr:
+                        for part in ln.replace("\r", "\n").split("\n"):
+                            if part.strip():
+                                lines.append((round(time.perf_counter() - t0, 2), part.rstrip()))
+                th = threading.Thread(target=pump_err); th.start()
+                th2 = threading.Thread(target=lambda: outbuf.append(pr.stdout.read())); th2.start()
+                try:
+                    pr.wait(timeout=timeout)
+                except subprocess.TimeoutExpired:
+                    pr.kill(); pr.wait()
+                    if attempt == 1:
+                        raise
+                    continue
+                th.join(); th2.join()
+                class R_: pass
+                r_ = R_()
+                r_.returncode = pr.returncode; r_.stdout = outbuf[0] if outbuf else ""; r_.stderr = "\n".join(l for _, l in lines); r_.seconds = time.perf_counter() - t0
+                r_.timeline = ["%7.2f s  %s" % (t, l[:160]) for t, l in lines if "rcgpu" in l and "rcgpu kept" not in l]
+                return r_
+        time.sleep(float(os.environ.get("RCGPU_BENCH_E2E_IDLE", "4")))
+        # --no-check: without it the reference parses the file it has just written once more and, because of --hash, MD5s the whole Matroska file on
+        # one core (input_base::Parse -> Hash, Lib/Utils/FileIO/Input_Base.cpp:38-81: 129 s for the 119 GB of 2000 frames); the check is the second process
+        r = run([exe, "--hash", "--no-check-padding", "--no-check", "-y", "seq"], 600)
+        ok_e = r.returncode == 0 and os.path.exists(os.path.join(work, "seq.mkv"))
+        slices = re.search(r"-slices (\d+)", r.stdout + r.stderr)
+        pl = [ln for ln in r.stderr.splitlines() if "pipeline:" in ln and "frames in" in ln]
+        steady = re.search(r"frames/s; ([0-9.]+) between the first and the last batch", pl[-1]) if pl else None
+        out["analysis_and_encode"] = {"value": round(n_frames / r.seconds, 2), "seconds": round(r.seconds, 2), "slices": int(slices.group(1)) if slices else None,
+                                      "mkv_bytes": os.path.getsize(os.path.join(work, "seq.mkv")) if ok_e else 0,
+                                      "encode_steady_frames_per_second": float(steady.group(1)) if steady else None,
+                                      "trace": pl[-1].split("pipeline: ", 1)[1][:400] if pl else None, "timeline": r.timeline[:12] + (["..."] if len(r.timeline) > 40 else []) + r.timeline[12:][-28:],
+                                      **({} if ok_e else {"error": (r.stdout + r.stderr)[-300:]})}
+        ok_c = False
+        if ok_e:
+            time.sleep(float(os.environ.get("RCGPU_BENCH_E2E_IDLE", "4")))
+            r = run([exe, "--check", "seq.mkv"], 600)
+            ok_c = r.returncode == 0 and OKL in r.stdout
+            done = [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"verify_kept: md5 done\s+(\d+) files\s+[0-9.]+ ms\s+\(at ([0-9.]+) s\)", r.stderr)]
+            steady_c = None
+            if len(done) >= 3 and done[-1][1] > done[0][1]:
+                steady_c = round(sum(n for n, _ in done[1:]) / (done[-1][1] - done[0][1]), 2)
+            out["linked_check"] = {"value": round(n_frames / r.seconds, 2), "seconds": round(r.seconds, 2), "verdict": OKL if ok_c else (r.stdout + r.stderr)[-200:],
+                                   "batches": len(done), "steady_frames_per_second": steady_c,
+                                   "first_batch_verified_at_s": done[0][1] if done else None, "last_batch_verified_at_s": done[-1][1] if done else None}
+        out["what"] = (f"{n_frames} x {width}x{height} RGB16 DPX on tmpfs ({R} distinct, hard-linked); rawcooked_linked --hash --no-check -y (analysis + encoding at the reference's own slice count, one MKV) "
+                       f"and rawcooked_linked --check of that file, each process start to exit; steady = batches after the first over the time between the first and the last batch's completion")
+        return out, ok_e and ok_c
+    except Exception as e:
+        return {"error": str(e)[-300:]}, False
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def reference_check_baseline(api, synth, record, frames, d_packets, stride, sizes, width, height, pixfmt, nframes=16, parallel=1):
     """cpu_baseline of the check path, kind "reference": the REAL reference binary (oracle/_ref/rawcooked, built from the reference's
     own sources by oracle/Makefile.ref) decodes and verifies an MKV holding `nframes` of this run's packets, on the host's cores."""
@@ -328,6 +427,36 @@ def reference_check_baseline(api, synth, record, frames, d_packets, stride, size
         return None
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+_TRAFFIC = None
+
+
+def traffic_json():
+    """profiles/traffic.json, and whether it still describes the code: it records the sha256 of the kernel sources the PMC passes ran on
+    (tools/update_traffic.py); when ffv1_gpu.hip / ffv1_check.hip have changed since, the byte counts are withheld (`traffic: null,
+    traffic_stale: true`) instead of being printed beside kernels they were not measured on."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        import hashlib
+        d, stale = {}, {}
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            for name, want in d.get("sources", {}).items():
+                got = hashlib.sha256(open(os.path.join(ROOT, name), "rb").read()).hexdigest()
+                stale[os.path.basename(name)] = got != want
+        except Exception:
+            d = {}
+        _TRAFFIC = (d, stale)
+    return _TRAFFIC
+
+
+def traffic_of(kernel, source):
+    """(HBM bytes per 4K frame of `kernel` from the PMC passes or None, stale?) -- source = the file the kernel lives in"""
+    d, stale = traffic_json()
+    if not d.get("sources") or stale.get(source, True):
+        return None, True
+    return d.get(kernel, {}).get("per_frame_bytes"), False
 
 
 def request_roofline(records_per_second):
@@ -428,14 +557,8 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     packet_avg = sum(sizes) / len(sizes)
     dom = "k_dec_slices"
     achieved = D * (packet_avg + 2 * payload) / (kt[dom] * 1e-3) / 1e9          # packet in + payload out + the source again for the compare
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj):
-        try:
-            per_frame = json.load(open(tj)).get(dom, {}).get("per_frame_bytes")
-            traffic = int(per_frame * D) if per_frame else None
-        except Exception:
-            traffic = None
+    per_frame, traffic_stale = traffic_of(dom, "ffv1_check.hip")
+    traffic = int(per_frame * D * (width * height) / (W4K * H4K)) if per_frame else None
     rec = {
         "metric": "4K-DCI 16-bit FFV1->DPX check frames/sec", "value": round(D * steps / dt, 3), "unit": "frames/s", "n_gpus": 1,
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -444,7 +567,7 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
                    "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "md5_inside_timed_region": state["hashed"],
                    "compared_inside_timed_region": state["compared"], "verify_seconds_last_batch": round(t_verify, 3)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": traffic, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}, **request_roofline(width * height * 3 * D / (kt[dom] * 1e-3) if dom in kt and kt[dom] else 0)},
+                     "traffic": traffic, "traffic_stale": traffic_stale, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}, **request_roofline(width * height * 3 * D / (kt[dom] * 1e-3) if dom in kt and kt[dom] else 0)},
         **({"cpu_baseline": cpu_rec} if cpu_rec else {}), **({"linked_check": linked_rec} if linked_rec else {})}
     dec.close()
     del outs
@@ -624,17 +747,17 @@ def cfg1_leg(api, synth, device):
             "note": "24 frames are one short batch: the number is start-up (encoder buffers, pinned slots) plus one batch's latency, not a rate"}, ok
 
 
-def cfg4_leg(torch, api, synth, dev, device, steps=3, F=80):
-    """BASELINE config 4's shape on one device: 8192x4320 RGB 16-bit LE (the payload of a single-strip TIFF), the reference's 576 slices,
-    device-resident like the headline; the dominant kernel's roofline from this run's HIP events."""
-    import numpy as np
-    w, h, pixfmt = 8192, 4320, synth.PIX_RGB16_LE
+def encode_leg(torch, api, synth, dev, device, label, w, h, pixfmt, slices, kind, F, steps=3, little_endian=False, seed=77):
+    """One more encode configuration, device-resident and timed like the headline (run-on steps, a device-wide synchronisation at the end),
+    with the dominant kernel's roofline from this run's own HIP events and a parity check on the device (the decoder, itself pinned by the
+    oracle and the reference in tests/, rebuilds the first 8 payloads)."""
     line_bytes = w * 6
-    slices = api.lib().rcgpu_reference_slices(w, h, 16, 1)
     nh, nv = api.slices_to_grid(slices)
-    base = make_frames(torch, 8, w, h, "film", 77, dev)                   # 8 distinct 212 MB pictures (big endian as generated) ...
-    base = base.view(8, -1, 2).flip(-1).reshape(8, -1).contiguous()     # ... byte-swapped: little endian, as TIFF stores them
-    frames = base.repeat((F + 7) // 8, 1)[:F].contiguous()
+    D = min(8, F)
+    base = make_frames(torch, D, w, h, kind, seed, dev)                   # D distinct pictures (big endian as generated) ...
+    if little_endian:
+        base = base.view(D, -1, 2).flip(-1).reshape(D, -1).contiguous()   # ... byte-swapped: little endian, as TIFF stores them
+    frames = base.repeat((F + D - 1) // D, 1)[:F].contiguous()
     del base
     enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=F, device=device)
     stride = (enc.max_packet + 255) & ~255
@@ -658,11 +781,10 @@ def cfg4_leg(torch, api, synth, dev, device, steps=3, F=80):
     dt = time.perf_counter() - t0
     kt = enc.kernel_times(); launches = enc.kernel_launches(); flags = enc.error_flags()
     sizes = d_sizes.cpu().tolist()
-    # parity at this shape: the device decoder (itself checked against the oracle and the reference in tests/) rebuilds the first 8 payloads
-    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=8, device=device)
-    outs = torch.empty((8, line_bytes * h), dtype=torch.uint8, device=dev)
-    dec.decode_device([d_packets.data_ptr() + i * stride for i in range(8)], sizes[:8], [outs[i].data_ptr() for i in range(8)], stream)
-    ok = api.compare_device_batch([outs[i].data_ptr() for i in range(8)], ptrs[:8], [line_bytes * h] * 8, stream) == [-1] * 8
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=D, device=device)
+    outs = torch.empty((D, line_bytes * h), dtype=torch.uint8, device=dev)
+    dec.decode_device([d_packets.data_ptr() + i * stride for i in range(D)], sizes[:D], [outs[i].data_ptr() for i in range(D)], stream)
+    ok = api.compare_device_batch([outs[i].data_ptr() for i in range(D)], ptrs[:D], [line_bytes * h] * D, stream) == [-1] * D
     dec.close()
     payload = line_bytes * h
     packet_avg = sum(sizes) / F
@@ -671,25 +793,38 @@ def cfg4_leg(torch, api, synth, dev, device, steps=3, F=80):
     nl = max(1, launches.get(dom, 1))
     alg = F * (payload + packet_avg) / nl
     ach = alg / (kt[dom] / nl * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel: the PMC passes were taken at 4K (profiles/traffic.json); state gathers, write-backs and stream bytes
-    # are per sample, so an 8K frame moves four times a 4K frame's bytes
-    traffic = None
-    try:
-        per4k = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(dom, {}).get("per_frame_bytes")
-        traffic = int(per4k * (w * h) / (W4K * H4K) * F / nl) if per4k else None
-    except Exception:
-        traffic = None
-    rec = {"workload": f"config 4 shape on one GPU: {w}x{h} RGB 16-bit LE (TIFF payload), slices={slices} ({nh}x{nv}), {F} frames per step resident in HBM, content=film" + (", steps issued in run-on mode" if run_on else ""),
+    # HBM traffic of the dominant kernel: the PMC passes were taken at 4K film content, 64 slices (profiles/traffic.json); state gathers, write-backs
+    # and stream bytes are per sample, so a frame of another size moves its samples' share -- for film content only
+    per4k, stale = traffic_of(dom, "ffv1_gpu.hip")
+    traffic = int(per4k * (w * h) / (W4K * H4K) * F / nl) if per4k and kind == "film" else None
+    rec = {"workload": f"{label}: {w}x{h} RGB 16-bit {'LE' if little_endian else 'BE'}, slices={slices} ({nh}x{nv}), {F} frames per step resident in HBM, content={kind}" + (", steps issued in run-on mode" if run_on else ""),
            "value": round(F * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "packet_bytes_avg": int(packet_avg),
            "compression_ratio": round(packet_avg / payload, 4), "device_error_flags": flags, "decodes_to_source_on_device": bool(ok),
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
-                        "traffic_note": "scaled by samples per frame from the 4K PMC passes (profiles/traffic.json)",
+                        "traffic_stale": stale, "traffic_note": "scaled by samples per frame from the 4K film PMC passes (profiles/traffic.json); null for other content",
                         "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(kt[dom] / nl, 3), "launches_per_step": nl,
                         "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0}}}
     enc.close()
     del frames, d_packets, outs
     torch.cuda.empty_cache()
     return rec, bool(ok) and flags == 0
+
+
+def cfg4_leg(torch, api, synth, dev, device, steps=3, F=80):
+    """BASELINE config 4's shape on one device: 8192x4320 RGB 16-bit LE (the payload of a single-strip TIFF), the reference's 576 slices."""
+    w, h = 8192, 4320
+    return encode_leg(torch, api, synth, dev, device, "config 4 shape on one GPU (TIFF payload)", w, h, synth.PIX_RGB16_LE, api.lib().rcgpu_reference_slices(w, h, 16, 1), "film", F, steps, little_endian=True)
+
+
+def encode576_leg(torch, api, synth, dev, device, width, height):
+    """The encode half at the slice count the reference itself picks for 4K 16-bit (slice_x = slice_y = 24 -> `-slices 576`,
+    Lib/Uncompressed/DPX/DPX.cpp:428-441): nine times the chains per frame, so 40 frames fill the device (the pipeline's own choice, by chains)."""
+    return encode_leg(torch, api, synth, dev, device, "config 2 at the reference's own slice count", width, height, synth.PIX_RGB16_BE, api.lib().rcgpu_reference_slices(width, height, 16, 1), "film", 40, 6, seed=9)
+
+
+def flat_leg(torch, api, synth, dev, device, width, height, slices, F):
+    """SURVEY.md 8d's second content class: "flat" (constant colour per frame, the best case) at the headline's geometry."""
+    return encode_leg(torch, api, synth, dev, device, "config 2, content class (ii) flat", width, height, synth.PIX_RGB16_BE, slices, "flat", F, 3, seed=1000)
 
 
 def check576_leg(args, torch, api, synth, dev, device, width, height):
@@ -750,20 +885,25 @@ def main():
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--legs", default="host,e2e,check,cpu,configs",
-                    help="comma list of the extra records: host (host_pipeline), e2e (config 3), check (config 5), cpu (cpu_baseline), configs (config 1 and 4 shapes, check at 576 slices); '' = none")
+    ap.add_argument("--legs", default="host,e2e,check,cpu,configs,long",
+                    help="comma list of the extra records: host (host_pipeline), e2e (config 3), check (config 5), cpu (cpu_baseline), configs (config 1 and 4 shapes, 576 slices, flat content), "
+                         "long (the linked reference on a 5000-frame sequence); '' = none")
     ap.add_argument("--host-frames", type=int, default=3840, help="host_pipeline: frames per GPU")
     ap.add_argument("--host-lanes", type=int, default=1, help="host_pipeline: encoder instances per GPU, batches staggered")
     ap.add_argument("--host-readers", type=int, default=0)
     ap.add_argument("--host-writers", type=int, default=0)
     ap.add_argument("--host-slots", type=int, default=0)
     ap.add_argument("--e2e-frames", type=int, default=1000, help="e2e: frames of the sequence (BASELINE config 2: 1000)")
+    ap.add_argument("--long-frames", type=int, default=5000, help="long: frames of the long-sequence product leg (0 = off)")
+    ap.add_argument("--time-budget", type=float, default=float(os.environ.get("RCGPU_BENCH_BUDGET", "420")),
+                    help="seconds after which the legs that are not part of the contract's line (long, flat, encode_576_slices) are skipped and say so")
     ap.add_argument("--dma-noise", action="store_true", help="experiment: pinned H2D + D2H copies at full rate on two side streams during the timed steps")
     ap.add_argument("--context-model", default="ffmpeg", choices=["ffmpeg", "compact"],
                     help="level maps of the 5-input context model: FFmpeg's (5063 contexts, states in HBM) or compact (338 contexts, states in LDS)")
     ap.add_argument("--mode", default="encode", choices=["encode", "check"],
                     help="check: BASELINE config 5 alone -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
+    t_bench = time.perf_counter()
     if os.environ.get("RCGPU_NUMA_NODE"):
         bind_to_numa_node(int(os.environ["RCGPU_NUMA_NODE"]))
     legs = {x for x in args.legs.split(",") if x}
@@ -956,17 +1096,10 @@ def main():
             alg_bytes_launch = F * (payload_bytes + packet_avg) / nl
             launch_ms = kt[dom] / nl
             achieved = alg_bytes_launch / (launch_ms * 1e-3) / 1e9
-            traffic = note = None
-            tjd = {}
-            tj = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tj):
-                try:
-                    tjd = json.load(open(tj))
-                    per_frame = tjd.get(dom, {}).get("per_frame_bytes")
-                    traffic = int(per_frame * F / nl) if per_frame else None      # PMC-measured HBM bytes per launch (scales with the batch)
-                    note = tjd.get("note")
-                except Exception:
-                    traffic = None
+            tjd = traffic_json()[0]
+            per_frame, traffic_stale = traffic_of(dom, "ffv1_gpu.hip")
+            traffic = int(per_frame * F / nl) if per_frame else None      # PMC-measured HBM bytes per launch (scales with the batch)
+            note = tjd.get("note")
             issue = None
             try:      # VALU wave-instructions per frame (SQ_INSTS_VALU, profiles/) against the issue rates tools/valu_peak measured on this chip
                 v = tjd.get("valu", {})
@@ -990,7 +1123,8 @@ def main():
             except Exception:
                 req = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "issue_frac": issue,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_stale": traffic_stale,
+                    "traffic_measured_on": tjd.get("measured_on"), "issue_frac": issue,
                     "request_frac": req["request_frac"] if req else None, "floor_ms": req["floor_ms"] if req else None, "requests": req,
                     "algorithmic_bytes_per_launch": int(alg_bytes_launch), "launch_ms": round(launch_ms, 3), "launches_per_step": nl,
                     "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0},
@@ -1018,7 +1152,7 @@ def main():
 
     # ---- the extra legs.  What they need of the headline run is kept on the host; the encoder's 170 GB go back first.
     record = enc.config_record()
-    host_ring = [frames[i].cpu().numpy() for i in range(R)] if (legs & {"host", "e2e", "cpu"}) else []
+    host_ring = [frames[i].cpu().numpy() for i in range(R)] if (legs & {"host", "e2e", "cpu", "long"}) else []
     expect = [bytes(d_packets[i * stride:i * stride + sizes[i]].cpu().numpy()) for i in range(R)] if (legs & {"host", "e2e", "cpu"}) else []
     src0 = bytes(frames[0].cpu().numpy()) if "cpu" in legs and not host_ring else None
     cfg = api.Ffv1Config(width, height, pixfmt, line_bytes, nh, nv, 1, ctx, 0, local_rank, args.segments, 0, 1, 3)
@@ -1064,6 +1198,14 @@ def main():
             hq["value"] = round(world * n_q / dt_q, 2); hq["unit"] = "frames/s"; hq["n_gpus"] = world
             hq["fraction_of_device_resident"] = round(hq["value"] / fps, 3)
             result["host_pipeline_pinned_inputs"] = hq
+        # ... and on BASELINE config 2's own 1000 frames (three batches: mostly the pipeline's fill and drain)
+        time.sleep(float(os.environ.get("RCGPU_BENCH_E2E_IDLE", "4")))
+        h1, ok = host_pipeline_leg(api, cfg, host_ring, 1000, F, expect, barrier, reduce_max, args.host_lanes, args.host_readers, args.host_writers, args.host_slots, pinned=True)
+        ok_all &= ok
+        n_1, _, dt_1 = h1.pop("_local")
+        if result is not None:
+            h1["value"] = round(world * n_1 / dt_1, 2); h1["unit"] = "frames/s"; h1["n_gpus"] = world
+            result["host_pipeline_pinned_inputs_1000_frames"] = h1
         if result is not None and "host_pipeline" in result:
             hp = result["host_pipeline"]
             result["kernel_metric"] = {"value": hq["value"], "unit": "frames/s", "h2d_included": True, "from_pageable_inputs": hp["value"],
@@ -1114,7 +1256,12 @@ def main():
         if "configs" in legs:
             cfgs = {}
             for name, fn in (("cfg1", lambda: cfg1_leg(api, synth, local_rank)), ("cfg4", lambda: cfg4_leg(torch, api, synth, dev, local_rank)),
+                             ("encode_576_slices", lambda: encode576_leg(torch, api, synth, dev, local_rank, width, height)),
+                             ("flat", lambda: flat_leg(torch, api, synth, dev, local_rank, width, height, args.slices, F)),
                              ("check_576_slices", lambda: check576_leg(args, torch, api, synth, dev, local_rank, width, height))):
+                if name in ("encode_576_slices", "flat") and time.perf_counter() - t_bench > args.time_budget:
+                    cfgs[name] = {"skipped": "time budget of %.0f s used up (--time-budget)" % args.time_budget}
+                    continue
                 try:
                     cfgs[name], ok = fn()
                     ok_all &= ok
@@ -1127,6 +1274,47 @@ def main():
             cb, ok = cpu_baseline([a.tobytes() for a in host_ring] if host_ring else [src0], line_bytes, width, height, [hashlib.md5(e).hexdigest() for e in expect] if expect else [])
             ok_all &= ok
             result["cpu_baseline"] = cb
+    if rank == 0 and world == 1 and "long" in legs and args.long_frames > 0 and host_ring:
+        if time.perf_counter() - t_bench > args.time_budget:
+            result["long_sequence"] = {"skipped": "time budget of %.0f s used up (--time-budget)" % args.time_budget}
+        else:
+            result["long_sequence"], ok = long_sequence_leg(synth, host_ring, width, height, args.long_frames, pixfmt)
+            ok_all &= ok
+    if rank == 0 and result is not None:
+        # The contract's numbers where the driver keeps them: flat numeric keys inside `config` (the records they come from follow in the line)
+        def num(*path):
+            d = result
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d if isinstance(d, (int, float)) and not isinstance(d, bool) else None
+        c = result["config"]
+        c["h2d_inclusive_fps"] = num("kernel_metric", "value")                                   # inputs in pinned host memory, H2D included; 3840 frames
+        c["h2d_inclusive_fps_frames"] = args.host_frames if c["h2d_inclusive_fps"] is not None else None
+        c["h2d_inclusive_fps_from_pageable"] = num("host_pipeline", "value")
+        c["h2d_inclusive_fps_1000_frames"] = num("host_pipeline_pinned_inputs_1000_frames", "value")   # ... on config 2's own 1000 frames
+        c["h2d_inclusive_steady_fps"] = num("host_pipeline_pinned_inputs", "steady_frames_per_second")
+        c["e2e_fps"] = num("e2e", "value")                                                        # config 3: files + WAV -> MKV, process start to exit
+        c["check_fps"] = num("check", "value")                                                    # config 5, device-resident, 64 slices
+        c["check_roofline_frac"] = num("check", "roofline", "frac")
+        c["check_request_frac"] = num("check", "roofline", "request_frac")
+        c["check_576_slices_fps"] = num("configs", "check_576_slices", "value")
+        c["linked_check_fps"] = num("check", "linked_check", "device_decoder", "value")           # the real reference + the device decoder, 1000 frames
+        c["linked_check_576_slices_fps"] = num("configs", "check_576_slices", "linked_check", "device_decoder", "value")
+        c["linked_check_cpu_pool_fps"] = num("check", "linked_check", "reference_cpu_pool", "value")
+        c["whole_product_fps"] = num("check", "linked_check", "whole_product", "value")
+        c["encode_576_slices_fps"] = num("configs", "encode_576_slices", "value")                 # config 2 at the reference's own slice count
+        c["encode_576_slices_roofline_frac"] = num("configs", "encode_576_slices", "roofline", "frac")
+        c["flat_fps"] = num("configs", "flat", "value")                                           # SURVEY 8d content class (ii)
+        c["flat_roofline_frac"] = num("configs", "flat", "roofline", "frac")
+        c["cfg4_8k_fps"] = num("configs", "cfg4", "value")
+        c["cfg4_8k_roofline_frac"] = num("configs", "cfg4", "roofline", "frac")
+        c["long_frames"] = num("long_sequence", "frames")
+        c["long_encode_product_fps"] = num("long_sequence", "analysis_and_encode", "value")
+        c["long_encode_steady_fps"] = num("long_sequence", "analysis_and_encode", "encode_steady_frames_per_second")
+        c["long_linked_check_fps"] = num("long_sequence", "linked_check", "value")
+        c["long_linked_check_steady_fps"] = num("long_sequence", "linked_check", "steady_frames_per_second")
+        c["cpu_baseline_fps"] = num("cpu_baseline", "value")
+        c["bench_wall_seconds"] = round(time.perf_counter() - t_bench, 1)
     if rank == 0:
         print(json.dumps(result))
     rdist.finish(dist)
