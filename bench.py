@@ -511,23 +511,31 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
     main = torch.cuda.Stream()
     stream = main.cuda_stream
     state = {"k": 0, "bad": 0, "hashed": 0, "compared": 0, "differing": 0, "ev": None}
+    spans = {"decode": [], "compare": [], "md5": []}          # HIP events around every launch: (begin, end) on the stream it was issued to
 
-    def verify(prev, st):
+    def verify(prev, st, ts):
         # frame_writer's two checks (FileWriter.cpp:448-463 byte compare with the source, :596-727 MD5), on the device
+        a0, a1, a2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        a0.record(ts)
         diffs = api.compare_device_batch(prev, ptrs, [payload_bytes] * D, st)
+        a1.record(ts)
         state["differing"] += sum(d != -1 for d in diffs); state["compared"] += D
         got = api.md5_device(prev, [payload_bytes] * D, st)
+        a2.record(ts)
+        spans["compare"].append((a0, a1)); spans["md5"].append((a1, a2))
         state["bad"] += sum(got[i] != want[i % F] for i in range(D) if (i % F) in want); state["hashed"] += D
 
     def step():
         k = state["k"]; cur = k & 1 if pipelined else 0
+        e0 = torch.cuda.Event(enable_timing=True); e0.record(main)
         dec.decode_device(pk, sizes, ops[cur], stream, check=False)
-        ev = torch.cuda.Event(); ev.record(main)
+        ev = torch.cuda.Event(enable_timing=True); ev.record(main)
+        spans["decode"].append((e0, ev))
         if pipelined and state["ev"] is not None:         # batch k-1 is verified on the side stream while batch k is decoded
             side.wait_event(state["ev"])
-            verify(ops[cur ^ 1], side.cuda_stream)
+            verify(ops[cur ^ 1], side.cuda_stream, side)
         elif not pipelined:
-            verify(ops[0], stream)
+            verify(ops[0], stream, main)
         state["ev"] = ev; state["k"] = k + 1
 
     # untimed warm-up steps until two in a row take the same time (3 %; four more at most): the legs before this one end by giving back
@@ -541,11 +549,16 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
             break
         last = tw
     torch.cuda.synchronize()
+    for v_ in spans.values():
+        v_.clear()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # every launch of the timed steps by its own HIP events, in the configuration that was timed (the hash on CUs of its own: rocprofv3's
+    # kernel trace cannot look at that, tools/rocprof_cumask_repro.hip) -- decode = k_dec_split + k_dec_crc + k_dec_slices of one batch
+    per_launch = {k_: [round(a.elapsed_time(b), 2) for a, b in v_] for k_, v_ in spans.items()}
     op = ops[(state["k"] - 1) & 1 if pipelined else 0]                                     # the batch decoded last: verified below
     kt = dec.kernel_times()
     t1 = time.perf_counter()
@@ -567,8 +580,39 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
                    "all_frames_identical_to_source": bool(same), "md5_matches_hashlib": bool(ok_md5), "md5_inside_timed_region": state["hashed"],
                    "compared_inside_timed_region": state["compared"], "verify_seconds_last_batch": round(t_verify, 3)},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": traffic, "traffic_stale": traffic_stale, "kernel_ms": {k: round(v, 3) for k, v in kt.items()}, **request_roofline(width * height * 3 * D / (kt[dom] * 1e-3) if dom in kt and kt[dom] else 0)},
+                     "traffic": traffic, "traffic_stale": traffic_stale, "kernel_ms": {k: round(v, 3) for k, v in kt.items()},
+                     "per_launch_ms": per_launch, "hash_on_cus_of_its_own": not os.environ.get("RCGPU_NO_CU_PARTITION"), **request_roofline(width * height * 3 * D / (kt[dom] * 1e-3) if dom in kt and kt[dom] else 0)},
         **({"cpu_baseline": cpu_rec} if cpu_rec else {}), **({"linked_check": linked_rec} if linked_rec else {})}
+    if getattr(args, "check_offsets", ""):
+        # One allocation, several base addresses (rcgpu_ffv1_decoder_debug_states_offset): does k_dec_slices' time depend on where its states lie?
+        # Every offset in turn, three rounds, the kernel alone on the device (no hash beside it), its own HIP events.
+        offs = [int(x) for x in args.check_offsets.split(",") if x.strip()]
+        table = {str(o): [] for o in offs}
+        for _ in range(3):
+            for o in offs:
+                dec.debug_states_offset(o)
+                torch.cuda.synchronize()
+                dec.decode_device(pk, sizes, ops[0], stream, check=False)
+                torch.cuda.synchronize()
+                table[str(o)].append(round(dec.kernel_times()["k_dec_slices"], 1))
+        dec.debug_states_offset(0)
+        rec["roofline"]["k_dec_slices_ms_by_states_offset"] = table
+        # ... and on where the ALLOCATION lies: the decoder made anew three times in this process, another buffer allocated in between each time
+        # (an offset moves virtual addresses inside one mapping; a new allocation gets other physical pages)
+        alloc = []
+        for gb in (0, 3, 11):
+            dec.close()
+            pad = torch.empty(gb << 30, dtype=torch.uint8, device=frames.device) if gb else None
+            dec = api.Ffv1Decoder(width, height, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=D, device=device)
+            ms = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                dec.decode_device(pk, sizes, ops[0], stream, check=False)
+                torch.cuda.synchronize()
+                ms.append(round(dec.kernel_times()["k_dec_slices"], 1))
+            alloc.append({"buffer_allocated_before_the_decoder_gb": gb, "k_dec_slices_ms": ms})
+            del pad
+        rec["roofline"]["k_dec_slices_ms_by_allocation"] = alloc
     dec.close()
     del outs
     torch.cuda.empty_cache()
@@ -900,6 +944,9 @@ def main():
     ap.add_argument("--dma-noise", action="store_true", help="experiment: pinned H2D + D2H copies at full rate on two side streams during the timed steps")
     ap.add_argument("--context-model", default="ffmpeg", choices=["ffmpeg", "compact"],
                     help="level maps of the 5-input context model: FFmpeg's (5063 contexts, states in HBM) or compact (338 contexts, states in LDS)")
+    ap.add_argument("--check-offsets", default="", help="--mode check: comma list of byte offsets (multiples of 256, <= 64 MiB) at which the decoder's state arrays are placed in turn; "
+                                                         "k_dec_slices' time at each is recorded (does the time depend on the addresses?)")
+    ap.add_argument("--check-profile-out", default="", help="--mode check: write the per-launch HIP-event timings to this file (profiles/r05_check_partitioned.json)")
     ap.add_argument("--mode", default="encode", choices=["encode", "check"],
                     help="check: BASELINE config 5 alone -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
@@ -972,7 +1019,18 @@ def main():
         sizes = d_sizes.cpu().tolist(); record = enc.config_record(); enc.close()
         rec, ok = check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, local_rank,
                             args.steps, args.warmup, cpu="cpu" in legs)
+        if args.check_profile_out:
+            r_ = rec["roofline"]
+            json.dump({"what": "bench.py --mode check: HIP-event time of every launch of the timed steps, in the configuration the line times (the hash on eight CUs of its own, "
+                               "the decoder on the other 248: CU-masked streams, ffv1_check.hip partition_streams); decode = k_dec_split + k_dec_crc + k_dec_slices of one batch of "
+                               "frames_per_step frames, md5 = k_md5 of the batch before (beside the decoder), compare = k_compare_batch",
+                       "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "frames_per_step": rec["config"]["frames_per_step_per_gpu"], "slices": nh * nv,
+                       "per_launch_ms": r_["per_launch_ms"], "last_launch_kernel_ms": r_["kernel_ms"], "hash_on_cus_of_its_own": r_["hash_on_cus_of_its_own"],
+                       **({"k_dec_slices_ms_by_states_offset": r_["k_dec_slices_ms_by_states_offset"], "k_dec_slices_ms_by_allocation": r_.get("k_dec_slices_ms_by_allocation")}
+                          if "k_dec_slices_ms_by_states_offset" in r_ else {}),
+                       "all_frames_identical_to_source": rec["config"]["all_frames_identical_to_source"]}, open(args.check_profile_out, "w"), indent=1)
         print(json.dumps(rec))
+        api.lib().rcgpu_release_device_streams()      # a CU-masked stream alive at exit takes rocprofv3's trace with it (profiles/r05_rocprof_cumask.txt)
         sys.exit(0 if ok else 2)
 
     noise = None
@@ -1317,6 +1375,7 @@ def main():
         c["bench_wall_seconds"] = round(time.perf_counter() - t_bench, 1)
     if rank == 0:
         print(json.dumps(result))
+    api.lib().rcgpu_release_device_streams()          # (see --mode check above)
     rdist.finish(dist)
     if not ok_all:
         sys.exit(2)

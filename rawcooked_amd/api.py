@@ -124,6 +124,7 @@ SYMBOLS = {
     "rcgpu_ffv1_run_on": (C.c_int, [_VP]),
     "rcgpu_sequence_plan": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rcgpu_sequence_plan_lanes": (C.c_uint32, [C.c_uint64, C.c_uint32, C.c_uint32]),
+    "rcgpu_release_device_streams": (None, []),
     "rcgpu_ffv1_encode_sequence": (C.c_int, [C.POINTER(Ffv1Config), C.c_uint64, C.POINTER(SequenceIo), C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
     "rcgpu_ffv1_encode_sequence_memory": (C.c_int, [C.POINTER(Ffv1Config), C.POINTER(_VP), C.c_uint64, C.c_uint64, C.POINTER(_VP), C.c_uint64, _SZ, C.POINTER(C.c_uint64),
                                           C.POINTER(SequenceOptions), C.POINTER(SequenceStats), _VP, C.POINTER(_SZ)]),
@@ -196,6 +197,7 @@ def lib() -> C.CDLL:
         dbg.restype, dbg.argtypes = C.c_longlong, [_VP, C.c_int, C.c_uint32, _VP, _SZ]
         L.rcgpu_ffv1_decoder_debug_window.restype, L.rcgpu_ffv1_decoder_debug_window.argtypes = C.c_int, [_VP, C.c_uint32]
         L.rcgpu_ffv1_decoder_debug_careful.restype, L.rcgpu_ffv1_decoder_debug_careful.argtypes = C.c_longlong, [_VP]
+        L.rcgpu_ffv1_decoder_debug_states_offset.restype, L.rcgpu_ffv1_decoder_debug_states_offset.argtypes = C.c_int, [_VP, C.c_uint64]
         _lib = L
     return _lib
 
@@ -459,6 +461,11 @@ class Ffv1Decoder:
         """Test hook: the sample decoder's byte window is filled to `nbytes` (1..7) instead of 7, so that samples outrun it and go through the careful path."""
         if lib().rcgpu_ffv1_decoder_debug_window(self.h, nbytes) != 0:
             raise RcgpuError("rcgpu_ffv1_decoder_debug_window failed")
+
+    def debug_states_offset(self, nbytes: int) -> None:
+        """Test hook: the context-state arrays begin `nbytes` (multiple of 256, <= 64 MiB) into their allocation from the next batch on."""
+        if lib().rcgpu_ffv1_decoder_debug_states_offset(self.h, nbytes) != 0:
+            raise RcgpuError("rcgpu_ffv1_decoder_debug_states_offset failed")
 
     def debug_careful(self) -> int:
         """Samples (per wavefront) of the last batch that were decoded a second time, carefully."""

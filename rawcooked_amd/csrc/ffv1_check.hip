@@ -759,13 +759,21 @@ static bool partition_streams(int device, hipStream_t* decode, hipStream_t* hash
     return true;
 }
 // the hash stream of the free-standing rcgpu_md5_device, one per device, made on first use and kept
+static std::mutex g_hash_mu; static hipStream_t g_hash_st[16]; static bool g_hash_tried[16];
 static hipStream_t device_hash_stream(int device)
 {
-    static std::mutex mu; static hipStream_t st[16]; static bool tried[16];
-    std::lock_guard<std::mutex> g(mu);
+    std::lock_guard<std::mutex> g(g_hash_mu);
     const int k = device & 15;
-    if (!tried[k]) { tried[k] = true; st[k] = nullptr; if (!partition_streams(device, nullptr, &st[k])) st[k] = nullptr; }
-    return st[k];
+    if (!g_hash_tried[k]) { g_hash_tried[k] = true; g_hash_st[k] = nullptr; if (!partition_streams(device, nullptr, &g_hash_st[k])) g_hash_st[k] = nullptr; }
+    return g_hash_st[k];
+}
+// The per-device hash streams live as long as the library; a caller that wants them gone before the process ends (a profiler's finalisation
+// after this library's streams, say) gives them back itself.
+extern "C" void rcgpu_release_device_streams(void)
+{
+    std::lock_guard<std::mutex> g(g_hash_mu);
+    for (int k = 0; k < 16; k++)
+        if (g_hash_st[k]) { (void)hipStreamSynchronize(g_hash_st[k]); (void)hipStreamDestroy(g_hash_st[k]); g_hash_st[k] = nullptr; g_hash_tried[k] = false; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -794,6 +802,7 @@ struct rcgpu_ffv1_decoder {
     unsigned long long* d_slice_start = nullptr; uint32_t* d_slice_len = nullptr; uint16_t* d_hdr = nullptr;
     uint8_t* d_states = nullptr; int32_t* d_planes = nullptr; uint32_t* d_err = nullptr;
     uint8_t* d_init = nullptr;                     // one chain's initial states when the stream codes them (states_coded), else null: all 128
+    size_t states_off = 0;                         // test hook (rcgpu_ffv1_decoder_debug_states_offset): the state arrays begin this far into their allocation
     void** h_ptrs = nullptr; unsigned long long* h_sizes = nullptr;
     hipStream_t own_stream = nullptr;
     hipStream_t dec_stream = nullptr;              // k_dec_slices' stream when the hash has CUs of its own (partition_streams), else null
@@ -859,6 +868,8 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     delete d;
 }
 
+constexpr size_t kStatesSlack = size_t(64) << 20;      // room behind the state arrays for rcgpu_ffv1_decoder_debug_states_offset
+
 // The decoder of the stream `s` for pictures laid out as `files` says (width, height, pixfmt, line_bytes, flags; max_batch, device).
 static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_desc& s, rcgpu_ffv1_decoder** out)
 {
@@ -920,7 +931,7 @@ static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_des
     hipError_t he = hipSuccess;
 #define DM(p, b) if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&(p)), (b))
     DM(d->d_const, sizeof c); DM(d->d_pkt_ptrs, sizeof(void*) * F); DM(d->d_out_ptrs, sizeof(void*) * F); DM(d->d_sizes, 8 * F);
-    DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32); DM(d->d_hdr, hdr.size() * 2 + 16);
+    DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32 + kStatesSlack); DM(d->d_hdr, hdr.size() * 2 + 16);
     std::vector<uint8_t> init;
     if (coded) {                                                      // one chain's states as GOP_Init leaves them
         init.assign(size_t(nkeys) * 32, 128);
@@ -997,9 +1008,9 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     if (d->d_init) {                                                                          // states_coded = 1: the stream's own initial states
         const unsigned long long total = (unsigned long long)nchains * d->nkeys * 2;
         hipLaunchKernelGGL(k_dec_preset, dim3(uint32_t(std::min<unsigned long long>((total + 255) / 256, 65536))), dim3(256), 0, st,
-                           reinterpret_cast<uint4*>(d->d_states), reinterpret_cast<const uint4*>(d->d_init), d->nkeys * 2, total);
+                           reinterpret_cast<uint4*>(d->d_states + d->states_off), reinterpret_cast<const uint4*>(d->d_init), d->nkeys * 2, total);
     }
-    else HIP_TRY(hipMemsetAsync(d->d_states, 128, size_t(nchains) * d->nkeys * 32, st));     // states_coded = 0: every state starts at 128
+    else HIP_TRY(hipMemsetAsync(d->d_states + d->states_off, 128, size_t(nchains) * d->nkeys * 32, st));     // states_coded = 0: every state starts at 128
     HIP_TRY(hipEventRecord(d->ev[0], st));
     hipLaunchKernelGGL(k_dec_split, dim3((n + 63) / 64), dim3(64), 0, st, d->d_const, d->d_pkt_ptrs, d->d_sizes, n, d->d_slice_start, d->d_slice_len, d->d_err);
     if (c.ec) hipLaunchKernelGGL(k_dec_crc, dim3(nchains), dim3(256), 0, st, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, d->d_err);
@@ -1010,10 +1021,10 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     if (ks != st) HIP_TRY(hipStreamWaitEvent(ks, d->ev[1], 0));
     if (d->ring)
         hipLaunchKernelGGL(k_dec_slices<true>, dim3((nchains + 63) / 64), dim3(64), 0, ks, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
-                           d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, d->ring_w, d->d_err, d->d_hdr);
+                           d->d_states + d->states_off, d->nkeys, d->d_planes, d->d_out_ptrs, d->ring_w, d->d_err, d->d_hdr);
     else
         hipLaunchKernelGGL(k_dec_slices<false>, dim3((nchains + 63) / 64), dim3(64), 0, ks, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
-                           d->d_states, d->nkeys, d->d_planes, d->d_out_ptrs, 0u, d->d_err, d->d_hdr);
+                           d->d_states + d->states_off, d->nkeys, d->d_planes, d->d_out_ptrs, 0u, d->d_err, d->d_hdr);
     HIP_TRY(hipEventRecord(d->ev[2], ks));
     if (ks != st) HIP_TRY(hipStreamWaitEvent(st, d->ev[2], 0));
     if (d->ring) { /* packed inline */ }
@@ -1527,6 +1538,15 @@ extern "C" int rcgpu_ffv1_decoder_debug_window(rcgpu_ffv1_decoder* d, uint32_t b
     d->hc.win_cap = bytes;
     return hipMemcpy(d->d_const, &d->hc, sizeof d->hc, hipMemcpyHostToDevice) == hipSuccess ? 0 : 2;
 }
+// Test hook: the decoder's context-state arrays begin `bytes` (a multiple of 256, at most 64 MiB) into their allocation from the next batch on --
+// one allocation, two base addresses: does the decoder's time depend on WHERE its 33 GB of states lie?  (tools/check_offsets.py)
+extern "C" int rcgpu_ffv1_decoder_debug_states_offset(rcgpu_ffv1_decoder* d, uint64_t bytes)
+{
+    if (!d || (bytes & 255) || bytes > kStatesSlack) return 1;
+    d->states_off = size_t(bytes);
+    return 0;
+}
+
 extern "C" long long rcgpu_ffv1_decoder_debug_careful(rcgpu_ffv1_decoder* d)
 {
     if (!d || hipSetDevice(d->cfg.device) != hipSuccess) return -1;

@@ -1,7 +1,8 @@
 # rocprofv3 of the check half (config 5): --stats, then the two PMC passes that give k_dec_slices its HBM bytes.  GPU box: bash tools/profile_check.sh <tag>
 TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
-export RCGPU_NO_CU_PARTITION=1      # rocprofv3 of ROCm 7.2 crashes in a process with CU-masked streams (the hash then shares the CUs again)
+# (until round 5 this script set RCGPU_NO_CU_PARTITION=1: rocprofv3 lost its trace at exit in a process that still held a CU-masked stream.  bench.py now
+# gives the library's hash streams back before it ends -- rcgpu_release_device_streams, tools/rocprof_cumask_repro.py -- and the profile is of the configuration the line times)
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/pc gpurun_out/summary
 timeout ${PASS_TIMEOUT:-420} rocprofv3 --kernel-trace --stats -d gpurun_out/pc -o chk -- python bench.py --mode check --steps 2 --warmup 1 --legs "" > gpurun_out/pc/log 2>&1
 python tools/rocprof_summary.py stats $(find gpurun_out/pc -name "*.db" | head -1) > gpurun_out/summary/${TAG}_check_kernel_stats.csv

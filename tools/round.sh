@@ -8,6 +8,9 @@
 #   line [tag]                    the driver's default line (python bench.py)
 #   stats [tag] [bench args]      rocprofv3 --kernel-trace --stats of a bench run -> stats_<tag>/
 #   pmc [tag] [bench args]        the PMC passes of tools/profile_pmc.sh over a bench run
+#   cumask                         rocprofv3 modes against a process with a CU-masked stream (tools/rocprof_cumask_repro.hip)
+#   checkprof [tag]                check half: per-launch HIP events as timed (partitioned), then rocprofv3 --stats + FETCH/WRITE_SIZE passes unpartitioned
+#   encprof [tag]                  encode half: rocprofv3 --stats, FETCH/WRITE_SIZE passes, SQ instruction counters at batch 336
 #   sweep [tag] "ENV=.." ...       one bench line per environment setting with the TIMING build -> sweep_<tag>.jsonl
 ROUND=${ROUND:-r05}
 WHAT=${1:-tests}; TAG=${2:-x}; shift 2 2>/dev/null
@@ -45,6 +48,43 @@ stats)
     python tools/rocprof_summary.py $OUT/stats_$TAG 2>/dev/null | head -30 ;;
 pmc)
     bash tools/profile_pmc.sh $OUT/pmc_$TAG "$@" ;;
+cumask)
+    # which rocprofv3 modes survive a process that has made a CU-masked stream (tools/rocprof_cumask_repro.hip)
+    B=$PWD/tools/bin/rocprof_cumask_repro; R=$PWD/$OUT/rocprof_cumask.txt; : > $R
+    [ -x $B ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/rocprof_cumask_repro.hip -o $B
+    cd /tmp
+    for masked in 1 2 0; do
+        echo "== second stream $([ $masked = 1 ] && echo CU-masked || ([ $masked = 2 ] && echo 'CU-masked and alive at exit' || echo plain))" >> $R
+        echo "alone: $($B $masked 2>&1 | tail -1) (exit $?)" >> $R
+        for mode in "--kernel-trace" "--kernel-trace --stats" "--pmc GRBM_GUI_ACTIVE" "--kernel-trace --pmc GRBM_GUI_ACTIVE" "--memory-copy-trace"; do
+            rm -rf /tmp/rp_cm; timeout 120 rocprofv3 $mode -d /tmp/rp_cm -o x -- $B $masked > /tmp/rp_cm.log 2>&1; rc=$?
+            echo "rocprofv3 $mode: exit $rc$([ $rc = 139 ] && echo ' (SIGSEGV)'); $(grep -c . /tmp/rp_cm.log) lines of output; last: $(grep -v '^$' /tmp/rp_cm.log | tail -1 | cut -c1-160)" >> $R
+        done
+    done
+    rocprofv3 --version 2>&1 | head -3 >> $R
+    cat $R ;;
+cumaskpy)
+    R=$PWD/$OUT/rocprof_cumask_py.txt; : > $R; P=$PWD/tools/rocprof_cumask_repro.py
+    cd /tmp
+    for v in lib lib+free torch torch+lib torch+lib+free torch+mask; do
+        rm -rf /tmp/rp_py; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/rp_py -o x -- python $P $v > /tmp/rp_py.log 2>&1; rc=$?
+        echo "rocprofv3 --kernel-trace --stats -- python tools/rocprof_cumask_repro.py $v: exit $rc$([ $rc = 139 ] && echo ' (SIGSEGV)'); said: $(grep '^ok' /tmp/rp_py.log | tail -1); trace written: $(find /tmp/rp_py -name '*.db' 2>/dev/null | wc -l) database(s); $(grep -c __cxa_finalize /tmp/rp_py.log) x __cxa_finalize in the stack" >> $R
+    done
+    cat $R ;;
+checkprof)
+    # the check half as the driver times it (hash on CUs of its own): HIP events per launch -> profiles-ready JSON; then the same under rocprofv3 --stats
+    # with RCGPU_NO_CU_PARTITION=1 (the only way its kernel trace survives), and the PMC passes for k_dec_slices' HBM bytes
+    timeout 600 python bench.py --mode check --steps 3 --warmup 1 --legs "" --check-offsets 0,4096,2097152,1052672,0,33554432,16781312 --check-profile-out $OUT/check_partitioned_$TAG.json > $OUT/checkprof_$TAG.json 2> $OUT/checkprof_$TAG.err || tail -3 $OUT/checkprof_$TAG.err
+    timeout 600 python bench.py --mode check --steps 3 --warmup 1 --legs "" --slices 576 --check-batch 512 --check-profile-out $OUT/check576_partitioned_$TAG.json > $OUT/checkprof576_$TAG.json 2> $OUT/checkprof576_$TAG.err || tail -3 $OUT/checkprof576_$TAG.err
+    show $OUT/checkprof_$TAG.json $OUT/checkprof576_$TAG.json
+    PASS_TIMEOUT=500 bash tools/profile_check.sh ${ROUND}${TAG} > $OUT/profile_check_$TAG.log 2>&1; tail -12 $OUT/profile_check_$TAG.log | cut -c1-220
+    cp gpurun_out/summary/${ROUND}${TAG}_check_* $OUT/ 2>/dev/null ;;
+encprof)
+    # the encode half: rocprofv3 --kernel-trace --stats, then FETCH_SIZE / WRITE_SIZE passes (tools/profile_r03.sh), then the SQ instruction counters at batch 336
+    PASS_TIMEOUT=500 bash tools/profile_r03.sh ${ROUND}${TAG} > $OUT/profile_enc_$TAG.log 2>&1; tail -25 $OUT/profile_enc_$TAG.log | cut -c1-220
+    cp gpurun_out/prof/${ROUND}${TAG}_* $OUT/ 2>/dev/null
+    RCGPU_BENCH_BATCH=336 PMC_GROUPS="3" PMC_PASS_TIMEOUT=500 bash tools/profile_pmc.sh ${ROUND}${TAG}_sq > $OUT/profile_sq_$TAG.log 2>&1; tail -12 $OUT/profile_sq_$TAG.log | cut -c1-200
+    cp gpurun_out/pmc/${ROUND}${TAG}_sq.csv $OUT/ 2>/dev/null ;;
 sweep)
     # A/B over environment settings with the TIMING build (the shipped library reads no measuring switch): one bench line per argument
     # ("A=1 B=2" "A=3" ...; "" = no setting) -> $OUT/sweep_<tag>.jsonl.  SWEEP_ARGS = extra bench.py arguments.
