@@ -675,7 +675,7 @@ def host_pipeline_leg(api, cfg, host_ring, n_frames, batch, expect_packets, barr
             "source": f"ring of {R} distinct frames in {'pinned' if pinned else 'pageable'} host memory, reused", "_local": (n_frames, st.seconds, dt)}, (not bad)
 
 
-def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packets, with_audio=True):
+def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packets, with_audio=True, device=None, tag="", batch=0):
     """Files on tmpfs -> `rcgpu-ffmpeg` with the argv grammar the reference assembles (Source/CLI/Output.cpp:81-310) -> MKV on tmpfs:
     the disk is out of the number, everything else (process start, device init, buffers, readers, muxer) is in it."""
     import shutil
@@ -683,7 +683,7 @@ def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packets, w
     import subprocess
     import numpy as np
     base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
-    work = os.path.join(base, "rcgpu_e2e_%d" % os.getpid())
+    work = os.path.join(base, "rcgpu_e2e_%d%s" % (os.getpid(), tag))
     shutil.rmtree(work, ignore_errors=True)
     try:
         os.makedirs(os.path.join(work, "uniq"))
@@ -712,13 +712,16 @@ def e2e_leg(synth, host_ring, width, height, n_frames, slices, expect_packets, w
             argv += ["-i", "snd.wav", "-map", "0", "-map", "1", "-c:a", "flac"]
             audio_note = f" + snd.wav (6 ch / 24 bit / 48 kHz, {nsamp} samples per channel) -> FLAC"
         argv += ["-c:v", "ffv1", "-coder", "1", "-context", "1", "-f", "matroska", "-g", "1", "-level", "3",
-                 "-slicecrc", "1", "-slices", str(slices), "-y", "-f", "matroska", "out.mkv"]
+                 "-slicecrc", "1", "-slices", str(slices), "-y"] + (["-rcgpu_batch", str(batch)] if batch else []) + ["-f", "matroska", "out.mkv"]
+        env = dict(os.environ, RCGPU_TRACE="1")
+        if device is not None:
+            env["RCGPU_DEVICES"] = "%d,1" % device          # this job's GPU (the shim's device selection; default: all visible)
         # The legs before this one have just given ~140 GB of device memory back, which the driver wipes in the background: a hipMalloc that
         # comes within ~3 s waits for the wipe (measured: encoder creation 3.2 s instead of 0.1 s).  A job does not follow another one's exit
         # by milliseconds, so the wipe is allowed to finish before the clock starts.
         time.sleep(float(os.environ.get("RCGPU_BENCH_E2E_IDLE", "4")))
         t0 = time.perf_counter()
-        r = subprocess.run(argv, cwd=work, capture_output=True, text=True, env=dict(os.environ, RCGPU_TRACE="1"), timeout=600)
+        r = subprocess.run(argv, cwd=work, capture_output=True, text=True, env=env, timeout=600)
         dt = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": (r.stderr or r.stdout)[-400:]}, False
@@ -1270,6 +1273,42 @@ def main():
                                        "what": "SURVEY.md 8d 'kernel-only fps (inputs resident in pinned host memory, H2D included)': payloads start in pinned host memory and "
                                                "packets end in pageable host memory, uploads / coding / downloads overlapped (the host_pipeline_pinned_inputs record); "
                                                "from_pageable_inputs: the payloads start in pageable memory and reader threads copy them into pinned slots first (host_pipeline)"}
+    if (world > 1 or alias_n > 1) and "e2e" in legs:
+        # ---- N JOBS SIDE BY SIDE, N Matroska files: the way a node pays off under the single-file ceiling (one job writes one file at ~13 GB/s whatever
+        # the GPU count), and the reference's own way to use one (GNU parallel, Doc/Case_study.md:81): every rank -- or, on a one-GPU box, every alias --
+        # runs its own `rcgpu-ffmpeg` on its own device, files to MKV, all started together; every block of every file against the N = 1 run's packets.
+        nj = alias_n if alias_n > 1 else world
+        n_job = max(64, args.e2e_frames // (2 if alias_n > 1 else 1))
+        barrier()
+        t0 = time.perf_counter()
+        if alias_n > 1:          # one GPU: the jobs share it (device 0) and its memory -- each takes a batch that fits beside the others
+            import threading as _th
+            recs = [None] * nj
+
+            def one(j):
+                recs[j] = e2e_leg(synth, host_ring, width, height, n_job, args.slices, expect, with_audio=False, device=0, tag="_job%d" % j, batch=max(8, F // (2 * nj)))
+            ths = [_th.Thread(target=one, args=(j,)) for j in range(nj)]
+            [t.start() for t in ths]; [t.join() for t in ths]
+            rows = [[j, r_[0].get("frames", 0), r_[0].get("seconds", 0.0), 1.0 if r_[0].get("all_blocks_identical_to_device_resident_run") else 0.0] for j, r_ in enumerate(recs)]
+            errs = [r_[0].get("error") or r_[0].get("skipped") for r_ in recs]
+        else:
+            rec_, ok_ = e2e_leg(synth, host_ring, width, height, n_job, args.slices, expect, with_audio=False, device=local_rank, tag="_rank%d" % rank)
+            rows = rdist.gather_floats(dist, [rank, rec_.get("frames", 0), rec_.get("seconds", 0.0), 1.0 if rec_.get("all_blocks_identical_to_device_resident_run") else 0.0], dev)
+            errs = [rec_.get("error") or rec_.get("skipped")]
+        wall = reduce_max(time.perf_counter() - t0)
+        if result is not None:
+            jobs = [{"job": int(v[0]), "device": 0 if alias_n > 1 else int(v[0]), "frames": int(v[1]), "seconds": round(v[2], 3), "frames_per_second": round(v[1] / v[2], 2) if v[2] else None,
+                     "all_blocks_identical_to_the_n1_runs_packets": bool(v[3])} for v in rows]
+            slowest = max((j["seconds"] for j in jobs), default=0.0)
+            ok_jobs = all(j["all_blocks_identical_to_the_n1_runs_packets"] for j in jobs) and len(jobs) == nj
+            ok_all &= ok_jobs
+            result["jobs_side_by_side"] = {
+                "value": round(sum(j["frames"] for j in jobs) / slowest, 2) if slowest else None, "unit": "frames/s", "jobs": nj, "frames_per_job": n_job, "slowest_job_seconds": slowest,
+                "wall_seconds_with_setup": round(wall, 2), "per_job": jobs, "errors": [e for e in errs if e] or None,
+                "what": (f"{nj} rcgpu-ffmpeg processes started together, each {n_job} x {width}x{height} RGB16 DPX on tmpfs -> FFV1 slices={args.slices} -> its own MKV on tmpfs, "
+                         + ("all on the ONE GPU of this box (RCGPU_DEVICES=0,1; they share its memory and its time: this checks the path, the number is not a scaling figure)" if alias_n > 1
+                            else "job r on GPU r (RCGPU_DEVICES=r,1)") + "; value = all frames / the slowest job's process start to exit")}
+        barrier()
     if (world > 1 or alias_n > 1) and "host" in legs:
         # ---- the PRODUCT's sharding: one process, one sequence, a lane per device (frame i -> GPU by batch, one placer in frame
         # order; rawcooked_amd/csrc/pipeline.hip), next to the per-rank rows above, which are N independent jobs (the reference's own way to
@@ -1284,6 +1323,9 @@ def main():
                 ok_all &= ok
                 n_loc, dt_loc, _ = sp.pop("_local")
                 sp["value"] = round(n_loc / dt_loc, 2); sp["unit"] = "frames/s"; sp["devices"] = ndv
+                # every lane's pinned download ring on the NUMA node its device hangs on (-1 = the kernel did not say)
+                sp["pinned_rings_on_their_devices_nodes"] = all(l["pinned_ring_on_node"] == l["numa_node"] or l["numa_node"] < 0 or l["pinned_ring_on_node"] < 0 for l in sp.get("lanes", []))
+                sp["lanes_per_device_seen"] = sorted({l["device"] for l in sp.get("lanes", [])})
                 sp["what"] = (f"ONE process, ONE sequence of {n_seq} frames, a lane per device over {ndv} " + ("aliases of the one GPU of this box (the lanes share its memory and its kernels' time: "
                               "this checks the path, the number is not a scaling figure)" if alias_n > 1 else "GPUs") + ": batches dealt to the lanes in turn, no collective, packets placed in frame order "
                               "and compared with the N = 1 run's; lanes grouped by their device's NUMA node")
@@ -1292,6 +1334,14 @@ def main():
             if result is not None:
                 result["single_process_sharding"] = sp
         barrier()
+    if world > 1:
+        # the process group is RCCL (torch's "nccl" backend on ROCm) and every rank is in it: an all-reduce of ones over the ranks' devices
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        if result is not None:
+            result["rccl"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_counted_by_all_reduce": int(ones.item()),
+                              "saw_every_rank": int(ones.item()) == world == dist.get_world_size(), "used_for": "barriers and the max-over-ranks of the timings only: the encode path has no collective"}
+            ok_all &= result["rccl"]["saw_every_rank"]
     if rank == 0 and world > 1 and result is not None:
         result["single_job_note"] = ("frames shard over the GPUs with no collective; a single JOB, though, writes ONE Matroska file, whose page allocation runs at "
                                      "~13 GB/s = ~265 4K frames/s whatever the GPU count (e2e record at N = 1): N GPUs pay off for N jobs side by side or for a caller that keeps packets in memory")
@@ -1371,6 +1421,9 @@ def main():
         c["long_encode_steady_fps"] = num("long_sequence", "analysis_and_encode", "encode_steady_frames_per_second")
         c["long_linked_check_fps"] = num("long_sequence", "linked_check", "value")
         c["long_linked_check_steady_fps"] = num("long_sequence", "linked_check", "steady_frames_per_second")
+        c["jobs_side_by_side_fps"] = num("jobs_side_by_side", "value")
+        c["single_process_sharding_fps"] = num("single_process_sharding", "value")
+        c["rccl_ranks"] = num("rccl", "ranks_counted_by_all_reduce")
         c["cpu_baseline_fps"] = num("cpu_baseline", "value")
         c["bench_wall_seconds"] = round(time.perf_counter() - t_bench, 1)
     if rank == 0:

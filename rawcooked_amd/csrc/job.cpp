@@ -191,11 +191,15 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     // Every coded byte comes from the device; the only job that needs none is one that codes nothing (PCM tracks copied as they are)
     bool codes_something = !audio_copy;
     for (size_t si = 0; si < job->n_streams && !codes_something; si++) codes_something = job->streams[si].slices != 0;
-    int ndev_visible = rcgpu_device_count();
-    if (ndev_visible <= 0 && codes_something) return bail(fail(4, "no HIP device available -- rcgpu has no CPU encode path"));
+    // `-rcgpu_plan_only 1` (an option like every other; the shim's command line or rcgpu_job::options): analyse the inputs -- sequences enumerated, files
+    // probed, slice grids and frame rates settled, the flavor checks made -- print the plan and stop.  Needs no device and writes nothing: what a caller
+    // runs to see what a job would do, and what tools/fuzz/fuzz_argv.cpp drives with hostile command lines and file lists.
+    const bool plan_only = opt.num("rcgpu_plan_only", 0) != 0;
+    int ndev_visible = plan_only ? 0 : rcgpu_device_count();
+    if (ndev_visible <= 0 && codes_something && !plan_only) return bail(fail(4, "no HIP device available -- rcgpu has no CPU encode path"));
     const int dev0 = std::max(0, job->device_first);
     int ndev = job->device_count > 0 ? job->device_count : ndev_visible - dev0;
-    if (codes_something) {
+    if (codes_something && !plan_only) {
         if (dev0 >= ndev_visible || ndev <= 0) return bail(fail(4, "device selection %d+%d is outside the %d visible devices", dev0, job->device_count, ndev_visible));
         ndev = std::min(ndev, ndev_visible - dev0);
     } else
@@ -259,6 +263,20 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     std::vector<uint8_t> framemd5_sums(want_framemd5 ? videos[md5_video].files.size() * 16 : 0);
     std::atomic<uint64_t> framemd5_frame_bytes{ 0 };
     mark("streams analysed");
+    if (plan_only) {
+        for (const auto& o : order) {
+            if (o.first) {
+                const video_plan& v = videos[o.second];
+                printf("rcgpu plan: video %zu frames %ux%u %s slices %ux%u fps %u/%u%s first %s\n", v.files.size(), v.info.width, v.info.height, v.info.flavor, v.num_h, v.num_v,
+                       v.fps.num, v.fps.den, v.vflip ? " vflip" : "", v.files[0].c_str());
+            } else {
+                const audio_plan& a = audios[o.second];
+                printf("rcgpu plan: audio %s %u ch %u Hz %u bit%s\n", a.info.flavor, a.info.channels, a.info.sample_rate, a.info.bits_per_sample, audio_copy ? " (copied)" : " -> FLAC");
+            }
+        }
+        printf("rcgpu plan: output %s%s, %zu attachment(s)%s\n", job->output_path, want_framemd5 ? " + framemd5" : "", job->n_attachments, job->reversibility_path ? " + reversibility data" : "");
+        return 0;
+    }
     // ---- audio first: A_FLAC CodecPrivate (STREAMINFO) must be final before the header is written
     for (audio_plan& a : audios) {
         if (audio_copy) {
@@ -543,6 +561,7 @@ extern "C" int rcgpu_main_ffmpeg_argv(int argc, const char* const* argv)
                 while (p < text.size()) {
                     size_t e = text.find('\n', p); if (e == std::string::npos) e = text.size();
                     std::string line = text.substr(p, e - p); p = e + 1;
+                    while (!line.empty() && (line.back() == '\r' || line.back() == ' ' || line.back() == '\t')) line.pop_back();     // a list that went through a CR LF system
                     if (line.compare(0, 6, "file '") == 0 && line.size() > 7 && line.back() == '\'') { if (!list.empty()) list += '\n'; list += line.substr(6, line.size() - 7); }
                     // at exactly 25 frames per second the reference skips its own rewriting and the list holds bare paths (Output.cpp:162-163)
                     else if (!line.empty() && line.compare(0, 9, "duration ") != 0 && line.compare(0, 5, "file ") != 0 && line[0] != '#' && line.compare(0, 8, "ffconcat") != 0)

@@ -316,3 +316,23 @@ def test_hd_sequence_with_real_transfers_equals_the_oracle(copy_streams, lanes, 
     want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
     for i in range(n):
         assert got[i] == want[i % distinct], f"packet {i} differs from the oracle's"
+
+
+def test_bench_gpus_2_on_one_gpu_prints_both_multi_gpu_records(built):
+    """`bench.py --gpus 2` on a box with one GPU (what the driver's N > 1 command turns into here): the headline on the device, then the two multi-GPU
+    records over ALIASES of it -- `jobs_side_by_side` (N rcgpu-ffmpeg processes, N Matroska files: how a node pays off under the single-file
+    ceiling) and `single_process_sharding` (one sequence, a lane per device, one placer) -- every packet equal to the N = 1 run's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--width", "512", "--height", "270", "--slices", "4", "--batch", "32",
+                        "--host-frames", "128", "--e2e-frames", "128", "--legs", "host,e2e", "--no-verify"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    j = d["jobs_side_by_side"]
+    assert j["jobs"] == 2 and len(j["per_job"]) == 2 and all(x["all_blocks_identical_to_the_n1_runs_packets"] and x["frames"] == j["frames_per_job"] for x in j["per_job"]), j
+    s = d["single_process_sharding"]
+    assert s["devices"] == 2 and s["packets_identical_to_device_resident_run"] and len(s["lanes"]) == 2 and s["pinned_rings_on_their_devices_nodes"], s
+    assert d["config"]["jobs_side_by_side_fps"] == j["value"] and d["config"]["single_process_sharding_fps"] == s["value"]

@@ -526,3 +526,44 @@ def test_sequence_structs_carry_their_size_and_one_input_callback(built):
     assert call(api.SequenceIo(C.sizeof(api.SequenceIo), rf, api.PLACE_PACKET_FN(), pd, None, lf), good_opt) == 1 and "alternatives" in api.last_error()
     if api.lib().rcgpu_device_count() < 1:                       # well-formed: gets as far as looking for a device
         assert call(api.SequenceIo(C.sizeof(api.SequenceIo), rf, api.PLACE_PACKET_FN(), pd, None), good_opt) == 4 and "no HIP device" in api.last_error()
+
+
+def test_traffic_json_describes_this_code():
+    """profiles/traffic.json holds the HBM bytes the PMC passes measured -- and the sha256 of the kernel sources they ran on (tools/update_traffic.py).
+    A kernel source that has changed since makes bench.py withhold the figure (`traffic: null, traffic_stale: true`); at the end of a round the
+    passes are taken again and this holds."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert set(d["sources"]) == {"rawcooked_amd/csrc/ffv1_gpu.hip", "rawcooked_amd/csrc/ffv1_check.hip"}
+    for name, want in d["sources"].items():
+        assert hashlib.sha256(open(os.path.join(root, name), "rb").read()).hexdigest() == want, f"{name} changed since the PMC passes of {d.get('measured_on')}: bash tools/round.sh encprof / checkprof, then python tools/update_traffic.py"
+    for k in ("k_resolve", "k_rangecode", "k_dec_slices"):
+        assert d[k]["per_frame_bytes"] > 0 and d[k]["source"] in ("ffv1_gpu.hip", "ffv1_check.hip")
+
+
+def test_plan_only_analyses_a_job_without_a_device(built, tmp_path):
+    """`-rcgpu_plan_only 1` (an output option like the others, rcgpu_job::options): rcgpu_encode enumerates the sequence the way image2 does (stops at the first
+    gap, CLI/Input.cpp:123-317), reads the ffconcat list the reference writes for gapped sequences (CLI/Output.cpp:138-251), probes the files, settles slice
+    grid and frame rate -- and stops: nothing is written and no device is looked for.  This is the part of the front end tools/fuzz/fuzz_argv.cpp drives."""
+    shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+    os.makedirs(tmp_path / "seq")
+    for i in list(range(5)) + [7]:                                                          # a gap after f_000004
+        (tmp_path / "seq" / ("f_%06d.dpx" % i)).write_bytes(synth.dpx_file(synth.components(64, 48, 3, 16, "film", seed=i), synth.PIX_RGB16_BE, frame_index=i))
+    (tmp_path / "a.wav").write_bytes(synth.wav_file(synth.pcm_samples(4800, 2, 16), 16, 48000))
+    common = ["-c:a", "flac", "-c:v", "ffv1", "-coder", "1", "-context", "1", "-f", "matroska", "-g", "1", "-level", "3", "-slicecrc", "1", "-slices", "6", "-y", "-rcgpu_plan_only", "1",
+              "-f", "matroska", "out.mkv"]
+    r = subprocess.run([shim, "-xerror", "-framerate", "24000/1001", "-r", "24000/1001", "-f", "image2", "-c:v", "dpx", "-start_number", "000000", "-i", "seq/f_%06d.dpx", "-i", "a.wav",
+                        "-map", "0", "-map", "1"] + common, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rcgpu plan: video 5 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 3x2 fps 24000/1001 first seq/f_000000.dpx" in r.stdout
+    assert "rcgpu plan: audio WAV/PCM/48kHz/16bit/2ch/S/LE 2 ch 48000 Hz 16 bit -> FLAC" in r.stdout and "rcgpu plan: output out.mkv" in r.stdout
+    assert not os.path.exists(tmp_path / "out.mkv")
+    (tmp_path / "list.txt").write_text("ffconcat version 1.0\n" + "".join("file 'seq/f_%06d.dpx'\r\nduration 0.041667\n" % i for i in (0, 1, 2, 3, 4, 7)))
+    r = subprocess.run([shim, "-framerate", "24", "-r", "24", "-f", "concat", "-safe", "0", "-c:v", "dpx", "-i", "list.txt"] + common, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "rcgpu plan: video 6 frames 64x48" in r.stdout, r.stdout + r.stderr
+    (tmp_path / "list.txt").write_text("file 'seq/f_000000.dpx'\nfile 'seq/nothing.dpx'\n")
+    r = subprocess.run([shim, "-f", "concat", "-safe", "0", "-c:v", "dpx", "-i", "list.txt"] + common, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0                                                                 # (the plan stops before the files behind the first are opened)
+    r = subprocess.run([shim, "-f", "concat", "-safe", "0", "-c:v", "dpx", "-i", "missing.txt"] + common, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0 and "Error: cannot open file list" in r.stderr
