@@ -27,6 +27,21 @@ int main(int argc, char** argv)
                 ok += rcgpu_ffv1_config_from_stream(buf, n, buf, n, &cfg) == 0; n_all++;
                 ok += rcgpu_ffv1_config_from_stream(seed.data(), seed.size(), buf, n, &cfg) == 0; n_all++;
             }
+            // ... and the reader of everything parameters::Parse accepts (rcgpu_ffv1_stream_parse): the bytes as a record with themselves as the first
+            // packet, as a record-less (version 0 / 1) packet, and as a mutated packet behind the good record
+            for (int mode = 0; mode < 3; mode++) {
+                rcgpu_ffv1_stream* st = nullptr;
+                const int r = mode == 0 ? rcgpu_ffv1_stream_parse(buf, n, buf, n, &st) : mode == 1 ? rcgpu_ffv1_stream_parse(nullptr, 0, buf, n, &st)
+                                                                                                     : rcgpu_ffv1_stream_parse(seed.data(), seed.size(), buf, n, &st);
+                n_all++;
+                if (r == 0) {
+                    ok++;
+                    rcgpu_ffv1_stream_info info;
+                    if (rcgpu_ffv1_stream_get_info(st, &info) != 0 || info.quant_table_set_count < 1 || info.quant_table_set_count > 8 || info.version > 3) abort();
+                    for (uint32_t g = 0; g < info.quant_table_set_index_count && g < 3; g++) if (info.quant_table_set_index[g] >= info.quant_table_set_count) abort();
+                    rcgpu_ffv1_stream_free(st);
+                } else if (st) abort();
+            }
             free(buf);
         }
     }

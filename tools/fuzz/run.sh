@@ -33,6 +33,13 @@ for k in range(6):
     w("job/seq/f_%06d.dpx" % k, synth.dpx_file(synth.components(32, 16, 3, 16, "film", seed=k), synth.PIX_RGB16_BE, frame_index=k))
 w("job/a.dpx", synth.dpx_file(comp, synth.PIX_RGB16_BE)); w("job/b.dpx", synth.dpx_file(synth.components(33, 7, 3, 10, "film", seed=2), synth.PIX_RGB10_FILLEDA_BE))
 w("job/a.tif", synth.tiff_file(comp, synth.PIX_RGB16_LE, trailer=b"xx")); w("job/a.exr", synth.exr_file(comp)); w("job/a.wav", synth.wav_file(s, 16)); w("job/rev", b"\x1a\x45\xdf\xa3" + bytes(60))
+import json
+V = json.load(open("tests/golden/vectors.json"))["ffv1_ext"]                     # records of 1-8 arbitrary table sets, transmitted transitions, coded initial states ...
+for v in V:
+    if v["name"] in ("ext_8sets_50x38", "ext_random_transitions_72x40", "ext_states_coded_one_of_two_40x24", "ext_rgba_3groups_48x32"):
+        w("rec/%s.bin" % v["name"], open("tests/golden/" + v["config_record_file"], "rb").read() if "config_record_file" in v else bytes.fromhex(v["config_record"]))
+    if v["name"] in ("ext_v1_inband_custom_48x32", "ext_v0_rgb8_48x32"):            # ... and packets with the version 0 / 1 header inside (first 600 bytes)
+        w("rec/%s.bin" % v["name"], open("tests/golden/" + v["frames"][0]["packet"], "rb").read()[:600])
 for i, (pixfmt, ctx, coder) in enumerate([(synth.PIX_RGB16_BE, 1, 1), (synth.PIX_RGB10_FILLEDA_BE, 0, 2), (synth.PIX_Y8, 1, 1), (synth.PIX_RGBA16_LE, 2, 2)]):
     w("rec/rec%d.bin" % i, ob.config_record(ob.Params(64, 48, pixfmt, 2, 2, 1, ctx, 0, coder, 3)))
 PY

@@ -1,6 +1,6 @@
-# Round-3 profile set for profiles/: per-kernel times (rocprofv3 --kernel-trace --stats over the headline workload) and HBM bytes per kernel
+# The encode half's profile set for profiles/ (bash tools/round.sh encprof): per-kernel times (rocprofv3 --kernel-trace --stats over the headline workload) and HBM bytes per kernel
 # (FETCH_SIZE and WRITE_SIZE in separate --pmc passes, never combined with other trace domains).  Every pass is bounded and summarised at
-# once; the databases are deleted (they exceed what gpurun copies back).  Usage on the GPU box: bash tools/profile_r03.sh [label]
+# once; the databases are deleted (they exceed what gpurun copies back).  Usage on the GPU box: bash tools/profile_enc.sh [label]
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

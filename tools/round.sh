@@ -11,7 +11,9 @@
 #   cumask                         rocprofv3 modes against a process with a CU-masked stream (tools/rocprof_cumask_repro.hip)
 #   checkprof [tag]                check half: per-launch HIP events as timed (partitioned), then rocprofv3 --stats + FETCH/WRITE_SIZE passes unpartitioned
 #   encprof [tag]                  encode half: rocprofv3 --stats, FETCH/WRITE_SIZE passes, SQ instruction counters at batch 336
-#   sweep [tag] "ENV=.." ...       one bench line per environment setting with the TIMING build -> sweep_<tag>.jsonl
+#   trace [tag] [bench args]       rocprofv3 --kernel-trace as a timeline: where k_resolve / k_rangecode stand still (TRACE_MODE=check: the check half's launches)
+#   sweep [tag] "ENV=.." ...       one bench line per environment setting with the TIMING build -> sweep_<tag>.jsonl, e.g. the floor of round 4:
+#                                  sweep floor "" RCGPU_EXP_SKIP_RC=1 "RCGPU_EXP_SKIP_RC=1 RCGPU_EXP_STATES_L2=1" RCGPU_EXP_STATES_L2=1 RCGPU_RC_SPAN=64
 ROUND=${ROUND:-r05}
 WHAT=${1:-tests}; TAG=${2:-x}; shift 2 2>/dev/null
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
@@ -80,11 +82,15 @@ checkprof)
     PASS_TIMEOUT=500 bash tools/profile_check.sh ${ROUND}${TAG} > $OUT/profile_check_$TAG.log 2>&1; tail -12 $OUT/profile_check_$TAG.log | cut -c1-220
     cp gpurun_out/summary/${ROUND}${TAG}_check_* $OUT/ 2>/dev/null ;;
 encprof)
-    # the encode half: rocprofv3 --kernel-trace --stats, then FETCH_SIZE / WRITE_SIZE passes (tools/profile_r03.sh), then the SQ instruction counters at batch 336
-    PASS_TIMEOUT=500 bash tools/profile_r03.sh ${ROUND}${TAG} > $OUT/profile_enc_$TAG.log 2>&1; tail -25 $OUT/profile_enc_$TAG.log | cut -c1-220
+    # the encode half: rocprofv3 --kernel-trace --stats, then FETCH_SIZE / WRITE_SIZE passes (tools/profile_enc.sh), then the SQ instruction counters at batch 336
+    PASS_TIMEOUT=500 bash tools/profile_enc.sh ${ROUND}${TAG} > $OUT/profile_enc_$TAG.log 2>&1; tail -25 $OUT/profile_enc_$TAG.log | cut -c1-220
     cp gpurun_out/prof/${ROUND}${TAG}_* $OUT/ 2>/dev/null
     RCGPU_BENCH_BATCH=336 PMC_GROUPS="3" PMC_PASS_TIMEOUT=500 bash tools/profile_pmc.sh ${ROUND}${TAG}_sq > $OUT/profile_sq_$TAG.log 2>&1; tail -12 $OUT/profile_sq_$TAG.log | cut -c1-200
     cp gpurun_out/pmc/${ROUND}${TAG}_sq.csv $OUT/ 2>/dev/null ;;
+trace)
+    # rocprofv3 --kernel-trace of a bench run as a timeline (tools/kernel_trace.py): TRACE_MODE=check for the check half
+    cd /tmp; rm -rf /tmp/rp_tr; timeout 600 rocprofv3 --kernel-trace -d /tmp/rp_tr -o t -- python "$OLDPWD/bench.py" ${@:---steps 4 --warmup 1 --legs "" --no-verify} > "$OLDPWD/$OUT/trace_$TAG.log" 2>&1; cd "$OLDPWD"
+    python tools/kernel_trace.py "$(find /tmp/rp_tr -name '*.db' | head -1)" ${TRACE_MODE:-encode} | tee $OUT/trace_$TAG.txt | tail -40 ;;
 sweep)
     # A/B over environment settings with the TIMING build (the shipped library reads no measuring switch): one bench line per argument
     # ("A=1 B=2" "A=3" ...; "" = no setting) -> $OUT/sweep_<tag>.jsonl.  SWEEP_ARGS = extra bench.py arguments.
