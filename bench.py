@@ -1286,13 +1286,17 @@ def main():
             recs = [None] * nj
 
             def one(j):
+                recs[j] = ({"error": "did not run"}, False)
                 recs[j] = e2e_leg(synth, host_ring, width, height, n_job, args.slices, expect, with_audio=False, device=0, tag="_job%d" % j, batch=max(8, F // (2 * nj)))
             ths = [_th.Thread(target=one, args=(j,)) for j in range(nj)]
             [t.start() for t in ths]; [t.join() for t in ths]
             rows = [[j, r_[0].get("frames", 0), r_[0].get("seconds", 0.0), 1.0 if r_[0].get("all_blocks_identical_to_device_resident_run") else 0.0] for j, r_ in enumerate(recs)]
             errs = [r_[0].get("error") or r_[0].get("skipped") for r_ in recs]
         else:
-            rec_, ok_ = e2e_leg(synth, host_ring, width, height, n_job, args.slices, expect, with_audio=False, device=local_rank, tag="_rank%d" % rank)
+            try:         # whatever goes wrong in one rank's job is a row of zeros and an error text, not a rank that leaves the others waiting at the gather
+                rec_, ok_ = e2e_leg(synth, host_ring, width, height, n_job, args.slices, expect, with_audio=False, device=local_rank, tag="_rank%d" % rank)
+            except Exception as e:
+                rec_ = {"error": str(e)[-300:]}
             rows = rdist.gather_floats(dist, [rank, rec_.get("frames", 0), rec_.get("seconds", 0.0), 1.0 if rec_.get("all_blocks_identical_to_device_resident_run") else 0.0], dev)
             errs = [rec_.get("error") or rec_.get("skipped")]
         wall = reduce_max(time.perf_counter() - t0)
@@ -1351,9 +1355,20 @@ def main():
             ok_all &= ok
             result["e2e"] = rec
         if "check" in legs:
+            # (The device-resident part before the product-level records.  Running it FIRST among the extra legs was tried in round 5 -- k_dec_slices' time
+            # depends on where its allocation lands, profiles/r05_check_allocations.json -- and undone: the host pipeline that then follows the decoder's 240 GB
+            # free runs at 365 instead of 600 frames/s, its transfers at 19 instead of 35 GB/s, whatever the pause between them.)
             rec, ok = check_leg(args, torch, api, record, frames, keep_pk, sizes, ptrs, stride, stream, F, width, height, line_bytes, nh, nv, pixfmt, local_rank,
-                                steps=2, warmup=1, cpu="cpu" in legs)
+                                steps=2, warmup=1, cpu=False)
             ok_all &= ok
+            if "cpu" in legs:
+                only = set(filter(None, os.environ.get("RCGPU_LINKED_VARIANTS", "").split(","))) or None      # (measuring: some of the variants only)
+                lr = linked_check_record(api, synth, record, frames, keep_pk, stride, sizes, width, height, pixfmt, variants=only)
+                cr = reference_check_baseline(api, synth, record, frames, keep_pk, stride, sizes, width, height, pixfmt, parallel=max(1, min(8, usable_cores() // 32)))
+                if lr:
+                    rec["linked_check"] = lr
+                if cr:
+                    rec["cpu_baseline"] = cr
             result["check"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline", "linked_check") if k in rec}
             if result["check"].get("config", {}).get("all_frames_identical_to_source"):
                 result["config"]["packets_verified"] = (f"all {F} packets of the last timed step decode to their sources on the device (check record: byte compare + MD5); "
