@@ -222,7 +222,9 @@ def linked_check_record(api, synth, record, frames, d_packets, stride, sizes, wi
                 ("reference_cpu_pool", {"RCGPU_CHECK": "0"}, small, m, []),
                 ("reference_cpu_pool_and_sources", {"RCGPU_CHECK": "0"}, small, m, ["-o", "."]))
         for name, env, d, count, extra in todo:
-            if (variants and name not in variants) or (not variants and name == "reference_cpu_pool_and_sources"):
+            # by default: the device decoder and the reference's own pool; the other variants (sources compared too, payloads back to the host) on request
+            # (RCGPU_LINKED_VARIANTS=device_decoder,device_decoder_and_sources,...): they were the subject of rounds 3-4 and cost the line 20 s
+            if (variants and name not in variants) or (not variants and name not in ("device_decoder", "reference_cpu_pool")):
                 continue
             # the process before this one has just given tens of GB of device memory back, which the driver wipes in the background: an allocation
             # that follows within ~3 s waits for the wipe (measured: 3 s for 39 GB that take 0.1 s on an idle device).  A job does not follow another
@@ -954,6 +956,10 @@ def main():
                     help="check: BASELINE config 5 alone -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
     t_bench = time.perf_counter()
+    marks = []
+
+    def mark(name):
+        marks.append((name, round(time.perf_counter() - t_bench, 1)))
     if os.environ.get("RCGPU_NUMA_NODE"):
         bind_to_numa_node(int(os.environ["RCGPU_NUMA_NODE"]))
     legs = {x for x in args.legs.split(",") if x}
@@ -1110,6 +1116,7 @@ def main():
     if noise is not None:
         stop.set(); noise.join()
         print("bench: dma noise moved %.0f GB during warm-up and timed steps = %.1f GB/s beside the kernels" % (moved[0] / 1e9, moved[0] / 1e9 / max(1e-9, time.perf_counter() - t_noise)), file=sys.stderr)
+    mark("headline steps")
     kt = enc.kernel_times()          # HIP events of the last timed step, recorded on the launch streams
     try:
         flags = enc.error_flags()    # the device-pointer API only enqueues: this is where an overflow would show (raises)
@@ -1250,6 +1257,7 @@ def main():
             hp["value"] = round(world * n_loc / dt_all, 2); hp["unit"] = "frames/s"; hp["n_gpus"] = world
             hp["fraction_of_device_resident"] = round(hp["value"] / fps, 3)
             result["host_pipeline"] = hp
+            mark("host_pipeline (pageable)")
         # the same with the ring page-locked by the caller: SURVEY.md 8d's own wording
         time.sleep(float(os.environ.get("RCGPU_BENCH_E2E_IDLE", "4")))
         hq, ok = host_pipeline_leg(api, cfg, host_ring, args.host_frames, F, expect, barrier, reduce_max, args.host_lanes, args.host_readers, args.host_writers, args.host_slots, pinned=True)
@@ -1354,6 +1362,7 @@ def main():
             rec, ok = e2e_leg(synth, host_ring, width, height, args.e2e_frames, args.slices, expect)
             ok_all &= ok
             result["e2e"] = rec
+            mark("e2e")
         if "check" in legs:
             # (The device-resident part before the product-level records.  Running it FIRST among the extra legs was tried in round 5 -- k_dec_slices' time
             # depends on where its allocation lands, profiles/r05_check_allocations.json -- and undone: the host pipeline that then follows the decoder's 240 GB
@@ -1370,6 +1379,7 @@ def main():
                 if cr:
                     rec["cpu_baseline"] = cr
             result["check"] = {k: rec[k] for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline", "linked_check") if k in rec}
+            mark("check + linked_check + reference check")
             if result["check"].get("config", {}).get("all_frames_identical_to_source"):
                 result["config"]["packets_verified"] = (f"all {F} packets of the last timed step decode to their sources on the device (check record: byte compare + MD5); "
                                                         "the first ones also through the oracle and the reference binary (verified_vs_oracle, verified_by_reference), "
@@ -1392,17 +1402,20 @@ def main():
                     cfgs[name] = {"error": str(e)[-300:]}
                     ok_all = False
             result["configs"] = cfgs
+            mark("configs")
         if "cpu" in legs:
             import hashlib
             cb, ok = cpu_baseline([a.tobytes() for a in host_ring] if host_ring else [src0], line_bytes, width, height, [hashlib.md5(e).hexdigest() for e in expect] if expect else [])
             ok_all &= ok
             result["cpu_baseline"] = cb
+            mark("cpu_baseline")
     if rank == 0 and world == 1 and "long" in legs and args.long_frames > 0 and host_ring:
         if time.perf_counter() - t_bench > args.time_budget:
             result["long_sequence"] = {"skipped": "time budget of %.0f s used up (--time-budget)" % args.time_budget}
         else:
             result["long_sequence"], ok = long_sequence_leg(synth, host_ring, width, height, args.long_frames, pixfmt)
             ok_all &= ok
+            mark("long_sequence")
     if rank == 0 and result is not None:
         # The contract's numbers where the driver keeps them: flat numeric keys inside `config` (the records they come from follow in the line)
         def num(*path):
@@ -1441,6 +1454,7 @@ def main():
         c["rccl_ranks"] = num("rccl", "ranks_counted_by_all_reduce")
         c["cpu_baseline_fps"] = num("cpu_baseline", "value")
         c["bench_wall_seconds"] = round(time.perf_counter() - t_bench, 1)
+        result["legs_done_at_seconds"] = {k: v for k, v in marks}
     if rank == 0:
         print(json.dumps(result))
     api.lib().rcgpu_release_device_streams()          # (see --mode check above)

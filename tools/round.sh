@@ -75,7 +75,7 @@ cumaskpy)
     cat $R ;;
 checkprof)
     # the check half as the driver times it (hash on CUs of its own): HIP events per launch -> profiles-ready JSON; then the same under rocprofv3 --stats
-    # with RCGPU_NO_CU_PARTITION=1 (the only way its kernel trace survives), and the PMC passes for k_dec_slices' HBM bytes
+    # (its trace survives since bench.py gives the CU-masked hash streams back before it ends), and the PMC passes for k_dec_slices' HBM bytes
     timeout 600 python bench.py --mode check --steps 3 --warmup 1 --legs "" --check-offsets 0,4096,2097152,1052672,0,33554432,16781312 --check-profile-out $OUT/check_partitioned_$TAG.json > $OUT/checkprof_$TAG.json 2> $OUT/checkprof_$TAG.err || tail -3 $OUT/checkprof_$TAG.err
     timeout 600 python bench.py --mode check --steps 3 --warmup 1 --legs "" --slices 576 --check-batch 512 --check-profile-out $OUT/check576_partitioned_$TAG.json > $OUT/checkprof576_$TAG.json 2> $OUT/checkprof576_$TAG.err || tail -3 $OUT/checkprof576_$TAG.err
     show $OUT/checkprof_$TAG.json $OUT/checkprof576_$TAG.json
