@@ -1,4 +1,5 @@
-/* ffv1_oracle.c -- CPU oracle for the FFV1 v3 intra path.  TEST INFRASTRUCTURE ONLY (see ffv1_oracle.h).
+/* ffv1_oracle.c -- CPU oracle for the FFV1 intra path (version 3 as FFmpeg writes it for RAWcooked; versions 0 / 1 and everything else
+ * parameters::Parse accepts through ffv1o_stream_ext).  TEST INFRASTRUCTURE ONLY (see ffv1_oracle.h).
  *
  * Every function cites the reference lines (under /root/reference/Source/Lib) it restates or inverts.
  * The encoder half has no in-tree counterpart (the reference runs FFmpeg, CLI/Output.cpp:356); it is
