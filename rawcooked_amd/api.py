@@ -197,6 +197,10 @@ def lib() -> C.CDLL:
         dbg.restype, dbg.argtypes = C.c_longlong, [_VP, C.c_int, C.c_uint32, _VP, _SZ]
         L.rcgpu_ffv1_decoder_debug_window.restype, L.rcgpu_ffv1_decoder_debug_window.argtypes = C.c_int, [_VP, C.c_uint32]
         L.rcgpu_ffv1_decoder_debug_careful.restype, L.rcgpu_ffv1_decoder_debug_careful.argtypes = C.c_longlong, [_VP]
+        # the library's per-device hash streams are CU-masked; they are given back while the HIP runtime is certainly still there, not in the
+        # middle of the interpreter's and the runtime's teardown (profiles/r05_rocprof_cumask.txt: what a profiler makes of the other order)
+        import atexit
+        atexit.register(L.rcgpu_release_device_streams)
         L.rcgpu_ffv1_decoder_debug_states_offset.restype, L.rcgpu_ffv1_decoder_debug_states_offset.argtypes = C.c_int, [_VP, C.c_uint64]
         _lib = L
     return _lib

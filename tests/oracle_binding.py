@@ -106,7 +106,7 @@ def config_record(p: Params) -> bytes:
 
 
 def encode_payload(p: Params, payload: bytes, line_bytes: int) -> bytes:
-    cap = len(payload) * 2 + (1 << 16)
+    cap = len(payload) * (2 if not p.ext else 6) + (1 << 16)      # (a stream with adverse initial states or transitions can expand a flat picture several times)
     out = C.create_string_buffer(cap)
     n = lib().ffv1o_encode_payload(C.byref(p), payload, C.c_size_t(line_bytes), out, C.c_size_t(cap), None)
     assert n > 0, "oracle encoder overflow"
