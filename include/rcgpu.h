@@ -414,8 +414,10 @@ int  rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t
 /* The same for n pairs of device buffers in one launch: first_diff[i] (host) for pair i.  Ordered on hip_stream alone, like rcgpu_md5_device:
  * a --check binding compares batch k-1 on a side stream while batch k is decoded. */
 int  rcgpu_compare_device_batch(const void* const* d_a, const void* const* d_b, const uint64_t* sizes, uint32_t n, uint64_t* first_diff, void* hip_stream);
-/* rcgpu_md5_device and rcgpu_analysis_host_batch keep one CU-masked hash stream per device for the library's life (made on first use); this
- * gives them back early (they are made again on the next use).  Not needed for correctness. */
+/* The library's CU-masked streams -- one hash stream per device for rcgpu_md5_device / rcgpu_analysis_host_batch, and the (decode, hash) pairs its
+ * decoders borrow from a pool -- live as long as the library (they are pooled, not destroyed with a decoder: the HIP runtime of ROCm 7.0 cannot
+ * survive an out-of-memory hipMalloc once such a stream has been destroyed).  This call destroys the ones not in use; they are made again on the
+ * next use.  Meant for the end of a process (a profiler's finalisation after this library's streams); not needed for correctness. */
 void rcgpu_release_device_streams(void);
 /* MD5 of n device buffers, one lane per buffer; out_md5 = n x 16 bytes on the host (FileWriter.cpp:596-727). */
 int  rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, void* hip_stream);

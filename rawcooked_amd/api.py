@@ -301,7 +301,11 @@ class Ffv1Encoder:
             lib().rcgpu_ffv1_destroy(self.h)
             self.h = _VP()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # at interpreter shutdown the module's globals may be gone already
+            pass
 
     def config_record(self) -> bytes:
         buf = C.create_string_buffer(8192)
@@ -439,7 +443,11 @@ class Ffv1Stream:
             lib().rcgpu_ffv1_stream_free(self.h)
             self.h = _VP()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # at interpreter shutdown the module's globals may be gone already
+            pass
 
 
 class Ffv1Decoder:
@@ -459,7 +467,11 @@ class Ffv1Decoder:
             lib().rcgpu_ffv1_decoder_destroy(self.h)
             self.h = _VP()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # at interpreter shutdown the module's globals may be gone already
+            pass
 
     def debug_window(self, nbytes: int) -> None:
         """Test hook: the sample decoder's byte window is filled to `nbytes` (1..7) instead of 7, so that samples outrun it and go through the careful path."""
@@ -613,7 +625,11 @@ class FlacEncoder:
             lib().rcgpu_flac_destroy(self.h)
             self.h = _VP()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # at interpreter shutdown the module's globals may be gone already
+            pass
 
     def encode(self, pcm: bytes) -> tuple[list[bytes], bytes]:
         """Returns (FLAC frames, CodecPrivate = 'fLaC' + STREAMINFO)."""

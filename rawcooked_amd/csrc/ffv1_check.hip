@@ -759,6 +759,28 @@ static bool partition_streams(int device, hipStream_t* decode, hipStream_t* hash
     return true;
 }
 // the hash stream of the free-standing rcgpu_md5_device, one per device, made on first use and kept
+// CU-masked streams are POOLED, never destroyed while the library is in use: a decoder borrows a (decode, hash) pair and hands it back.  The HIP
+// runtime torch 2.10 bundles (ROCm 7.0.5) dies of a segmentation fault in an out-of-memory hipMalloc once such a stream has been DESTROYED in
+// the process (alive: fine; ROCm 7.2's own runtime: fine either way -- tools/oom_after_decoder.py, tools/oom_after_decoder.cpp), and callers rely on
+// that error code (route C halves its batch on it, rcgpu_ffv1_set_run_on falls back to one batch at a time).
+struct masked_pair { hipStream_t decode, hash; };
+static std::mutex g_pool_mu; static std::vector<masked_pair> g_pool[16];
+static bool acquire_masked_pair(int device, hipStream_t* decode, hipStream_t* hash)
+{
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        std::vector<masked_pair>& P = g_pool[device & 15];
+        if (!P.empty()) { *decode = P.back().decode; *hash = P.back().hash; P.pop_back(); return true; }
+    }
+    return partition_streams(device, decode, hash);
+}
+static void release_masked_pair(int device, hipStream_t decode, hipStream_t hash)
+{
+    if (!decode || !hash) return;
+    (void)hipStreamSynchronize(decode); (void)hipStreamSynchronize(hash);
+    std::lock_guard<std::mutex> g(g_pool_mu);
+    g_pool[device & 15].push_back({ decode, hash });
+}
 static std::mutex g_hash_mu; static hipStream_t g_hash_st[16]; static bool g_hash_tried[16];
 static hipStream_t device_hash_stream(int device)
 {
@@ -771,9 +793,13 @@ static hipStream_t device_hash_stream(int device)
 // after this library's streams, say) gives them back itself.
 extern "C" void rcgpu_release_device_streams(void)
 {
-    std::lock_guard<std::mutex> g(g_hash_mu);
-    for (int k = 0; k < 16; k++)
-        if (g_hash_st[k]) { (void)hipStreamSynchronize(g_hash_st[k]); (void)hipStreamDestroy(g_hash_st[k]); g_hash_st[k] = nullptr; g_hash_tried[k] = false; }
+    {
+        std::lock_guard<std::mutex> g(g_hash_mu);
+        for (int k = 0; k < 16; k++)
+            if (g_hash_st[k]) { (void)hipStreamSynchronize(g_hash_st[k]); (void)hipStreamDestroy(g_hash_st[k]); g_hash_st[k] = nullptr; g_hash_tried[k] = false; }
+    }
+    std::lock_guard<std::mutex> g(g_pool_mu);                 // the pairs no decoder holds at the moment
+    for (auto& P : g_pool) { for (masked_pair& m : P) { (void)hipStreamDestroy(m.decode); (void)hipStreamDestroy(m.hash); } P.clear(); }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -853,14 +879,14 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     if (d->h_sizes) (void)hipHostFree(d->h_sizes);
     for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
     if (d->own_stream) (void)hipStreamDestroy(d->own_stream);
-    if (d->dec_stream) { (void)hipStreamSynchronize(d->dec_stream); (void)hipStreamDestroy(d->dec_stream); }
+    if (d->dec_stream) (void)hipStreamSynchronize(d->dec_stream);
     if (d->md5_stream) (void)hipStreamSynchronize(d->md5_stream);     // a verification begun and never ended
     for (void* b : { (void*)d->d_kept_in, (void*)d->d_kept_in2, (void*)d->kept[0].d, (void*)d->kept[1].d, (void*)d->kept[2].d, (void*)d->d_disk,
                      (void*)d->kept[0].d_tab, (void*)d->kept[1].d_tab, (void*)d->kept[2].d_tab }) if (b) (void)hipFree(b);
     for (auto& k : d->kept) if (k.h_tab) (void)hipHostFree(k.h_tab);
     if (d->h_edges) (void)hipHostFree(d->h_edges);
     if (d->side_stream) (void)hipStreamDestroy(d->side_stream);
-    if (d->md5_stream) (void)hipStreamDestroy(d->md5_stream);
+    release_masked_pair(d->cfg.device, d->dec_stream, d->md5_stream);       // back into the pool, not destroyed (see acquire_masked_pair)
     if (d->ev_tab) (void)hipEventDestroy(d->ev_tab);
     if (d->ev_side) (void)hipEventDestroy(d->ev_side);
     d->up.release(); d->up2.release();
@@ -952,7 +978,7 @@ static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_des
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_ptrs), sizeof(void*) * F * 2);
     if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&d->h_sizes), 8 * F);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking);
-    if (he == hipSuccess && !partition_streams(cfg->device, &d->dec_stream, &d->md5_stream)) d->dec_stream = d->md5_stream = nullptr;
+    if (he == hipSuccess && !acquire_masked_pair(cfg->device, &d->dec_stream, &d->md5_stream)) d->dec_stream = d->md5_stream = nullptr;
     for (auto& e : d->ev) if (he == hipSuccess) he = hipEventCreate(&e);
     if (he == hipSuccess) he = hipMemcpy(d->d_const, &c, sizeof c, hipMemcpyHostToDevice);
     if (he == hipSuccess && !hdr.empty()) he = hipMemcpy(d->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);

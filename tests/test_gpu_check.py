@@ -554,3 +554,43 @@ def test_random_streams_of_the_general_syntax(built, seed):
         dec.debug_window(cap)
         assert dec.decode_host(pks, len(pls[0])) == pls, f"window {cap}"
     dec.close()
+
+
+def test_a_hinted_file_that_changed_is_mapped_anew(built, tmp_path):
+    """rcgpu_ffv1_decoder_decode_keep_hint_file maps the Matroska file for itself and keeps the mapping -- while it is still THAT file: a file
+    rewritten under the same name (other size, other bytes, another inode) is mapped again instead of being read through the stale mapping;
+    and a hinted batch that fails says why when it is adopted."""
+    w, h, pixfmt, nh, nv = 192, 96, synth.PIX_RGB16_BE, 2, 2
+    sets = []
+    for k in range(2):
+        srcs = [synth.pack_payload(synth.components(w, h, 3, 16, "film", seed=300 + 10 * k + i), pixfmt, True) for i in range(3)]
+        line_bytes = srcs[0][1]
+        sets.append([s_[0] for s_ in srcs])
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=3)
+    packets = [enc.encode_host(s_) for s_ in sets]
+    enc.close()
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=3)
+    path = str(tmp_path / "blocks.bin")
+
+    def write(pk, pad):
+        offs, pos, blob = [], pad, bytearray(pad)
+        for p_ in pk:
+            offs.append(pos); blob += p_ + b"\0" * 7; pos += len(p_) + 7
+        tmp = path + ".new"
+        open(tmp, "wb").write(blob)
+        os.replace(tmp, path)                                                                 # another inode under the same name
+        return offs
+    offs = write(packets[0], 11)
+    dec.decode_keep_hint_file(path, offs, [len(p_) for p_ in packets[0]])
+    dec.decode_keep_adopt()
+    assert [dec.kept_to_host(i, len(sets[0][i])) for i in range(3)] == sets[0]
+    offs = write(packets[1], 4099)                                                              # other bytes at other places, another size
+    dec.decode_keep_hint_file(path, offs, [len(p_) for p_ in packets[1]])
+    dec.decode_keep_adopt()
+    assert [dec.kept_to_host(i, len(sets[1][i])) for i in range(3)] == sets[1]
+    with pytest.raises(api.RcgpuError, match="ends before a packet"):
+        dec.decode_keep_hint_file(path, [offs[0], os.path.getsize(path) - 5, offs[2]], [len(p_) for p_ in packets[1]])
+    dec.decode_keep_hint_file(path, [offs[0] + 3, offs[1], offs[2]], [len(p_) for p_ in packets[1]])       # a batch that cannot be decoded
+    with pytest.raises(api.RcgpuError, match="decoded ahead failed: .*undecodable"):
+        dec.decode_keep_adopt()
+    dec.close()

@@ -414,3 +414,33 @@ def test_level3_without_slicecrc_and_with_the_3_input_model(built, pixfmt, w, h,
     for f in range(3):
         assert bytes(dout[f].cpu().numpy()) == payloads[f]
     enc.close(); dec.close()
+
+
+def test_a_second_bank_that_does_not_fit_leaves_nothing_behind(built):
+    """rcgpu_ffv1_set_run_on allocates a second bank of per-batch buffers.  When the device has no room for it the call fails, everything it had
+    allocated is given back (the memory is what the first batch's windows need), the encoder keeps coding one batch at a time, and a later
+    attempt -- with room -- succeeds."""
+    import torch
+    w, h, pixfmt, nh, nv, n = 1024, 540, synth.PIX_RGB16_BE, 2, 2, 48
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    pls = [synth.pack_payload(synth.components(w, h, nc, bits, "film", seed=700 + i), pixfmt, True) for i in range(2)]
+    line_bytes = pls[0][1]
+    srcs = [pls[i % 2][0] for i in range(n)]
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    want = [ob.encode_payload(p, pls[i][0], line_bytes) for i in range(2)]
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=n, rc_span=1)
+    assert enc.encode_host(srcs[:4]) == [want[i % 2] for i in range(4)]                          # staging areas and windows exist now
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    filler = torch.empty(max(0, free0 - (96 << 20)), dtype=torch.uint8, device="cuda")         # the bank of 48 such frames is ~0.7 GB: no room
+    with pytest.raises(api.RcgpuError, match="second bank"):
+        enc.set_run_on(True)
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free1 - (free0 - filler.numel())) < (64 << 20), (free0, free1)                  # nothing of the half-made bank is held
+    assert enc.encode_host(srcs[:6]) == [want[i % 2] for i in range(6)]                          # one batch at a time, as before
+    del filler
+    torch.cuda.empty_cache()
+    enc.set_run_on(True)                                                                        # with room: the mode is there
+    assert enc.encode_host(srcs) == [want[i % 2] for i in range(n)]
+    assert enc.error_flags() == 0
+    enc.close()

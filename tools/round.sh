@@ -33,7 +33,8 @@ PY
 }
 case $WHAT in
 tests)
-    timeout 2400 python -m pytest ${@:-tests} -x -q -m gpu 2>&1 | tail -15 | tee $OUT/tests_$TAG.log ;;
+    [ $# -gt 0 ] || set -- tests
+    timeout 2400 python -m pytest "$@" -x -q -m gpu 2>&1 | tail -15 | tee $OUT/tests_$TAG.log ;;
 check_ab)
     timeout 900 python -m pytest tests/test_gpu_check.py tests/test_gpu_stages.py -x -q -m gpu 2>&1 | tail -5 | tee $OUT/tests_$TAG.log
     timeout 600 python bench.py --mode check --steps 2 --warmup 1 --legs "" > $OUT/check_$TAG.json 2> $OUT/check_$TAG.err || tail -3 $OUT/check_$TAG.err
@@ -65,6 +66,9 @@ cumask)
     done
     rocprofv3 --version 2>&1 | head -3 >> $R
     cat $R ;;
+oomrepro)
+    B=$PWD/tools/bin/oom_cumask_repro; [ -x $B ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/oom_cumask_repro.hip -o $B
+    for m in 0 1 2; do $B $m 2>&1 | grep -v amdgpu.ids | tail -1; echo "  mode $m -> exit ${PIPESTATUS[0]}"; done | tee $OUT/oom_cumask.txt ;;
 cumaskpy)
     R=$PWD/$OUT/rocprof_cumask_py.txt; : > $R; P=$PWD/tools/rocprof_cumask_repro.py
     cd /tmp
