@@ -436,7 +436,7 @@ def test_a_second_bank_that_does_not_fit_leaves_nothing_behind(built):
     with pytest.raises(api.RcgpuError, match="second bank"):
         enc.set_run_on(True)
     free1 = torch.cuda.mem_get_info()[0]
-    assert abs(free1 - (free0 - filler.numel())) < (64 << 20), (free0, free1)                  # nothing of the half-made bank is held
+    assert free1 >= free0 - filler.numel() - (64 << 20), (free0, free1)                        # nothing of the half-made bank is held
     assert enc.encode_host(srcs[:6]) == [want[i % 2] for i in range(6)]                          # one batch at a time, as before
     del filler
     torch.cuda.empty_cache()
