@@ -594,3 +594,28 @@ def test_a_hinted_file_that_changed_is_mapped_anew(built, tmp_path):
     with pytest.raises(api.RcgpuError, match="decoded ahead failed: .*undecodable"):
         dec.decode_keep_adopt()
     dec.close()
+
+
+def test_a_device_without_room_is_an_error_not_a_crash(built):
+    """Out of device memory is an ordinary error of rcgpu_ffv1_decoder_create / rcgpu_ffv1_create (100 / "device setup failed"): route C halves its
+    batch on it (oracle/route_c_ffv1_frame_cpp.patch), the pipeline sizes by free memory.  Also after decoders have come and gone in the
+    process -- the order in which the HIP runtime of ROCm 7.0 used to die (CU-masked streams are pooled since, ffv1_check.hip)."""
+    w, h, pixfmt = 1024, 540, synth.PIX_RGB16_BE
+    line_bytes = w * 6
+    for _ in range(2):
+        d = api.Ffv1Decoder(w, h, pixfmt, line_bytes, 4, 4, 1, 1, max_batch=2)
+        d.close()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    filler = torch.empty(free0 - (256 << 20), dtype=torch.uint8, device="cuda")
+    with pytest.raises(api.RcgpuError, match="device setup failed") as ei:
+        api.Ffv1Decoder(w, h, pixfmt, line_bytes, 4, 4, 1, 1, max_batch=512)                 # 512 x 16 chains x 10126 contexts x 32 bytes = 2.6 GB of states
+    assert ei.value.code == 100
+    with pytest.raises(api.RcgpuError):
+        api.Ffv1Encoder(w, h, pixfmt, line_bytes, 4, 4, 1, 1, max_batch=512)
+    small = api.Ffv1Decoder(w, h, pixfmt, line_bytes, 4, 4, 1, 1, max_batch=1)              # what a halving caller arrives at
+    small.close()
+    del filler
+    torch.cuda.empty_cache()
+    big = api.Ffv1Decoder(w, h, pixfmt, line_bytes, 4, 4, 1, 1, max_batch=512)
+    big.close()
