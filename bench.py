@@ -845,12 +845,14 @@ def encode_leg(torch, api, synth, dev, device, label, w, h, pixfmt, slices, kind
     # HBM traffic of the dominant kernel: the PMC passes were taken at 4K film content, 64 slices (profiles/traffic.json); state gathers, write-backs
     # and stream bytes are per sample, so a frame of another size moves its samples' share -- for film content only
     per4k, stale = traffic_of(dom, "ffv1_gpu.hip")
-    traffic = int(per4k * (w * h) / (W4K * H4K) * F / nl) if per4k and kind == "film" else None
+    own = None if stale else traffic_json()[0].get("configs", {}).get("%dx%d/%d" % (w, h, slices), {}).get(dom, {}).get("per_frame_bytes")      # PMC passes of this very configuration
+    traffic = None if kind != "film" else int(own * F / nl) if own else int(per4k * (w * h) / (W4K * H4K) * F / nl) if per4k else None
     rec = {"workload": f"{label}: {w}x{h} RGB 16-bit {'LE' if little_endian else 'BE'}, slices={slices} ({nh}x{nv}), {F} frames per step resident in HBM, content={kind}" + (", steps issued in run-on mode" if run_on else ""),
            "value": round(F * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "packet_bytes_avg": int(packet_avg),
            "compression_ratio": round(packet_avg / payload, 4), "device_error_flags": flags, "decodes_to_source_on_device": bool(ok),
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": traffic,
-                        "traffic_stale": stale, "traffic_note": "scaled by samples per frame from the 4K film PMC passes (profiles/traffic.json); null for other content",
+                        "traffic_stale": stale, "traffic_note": ("PMC passes of this configuration (profiles/traffic.json: configs)" if own else
+                                                                 "scaled by samples per frame from the 4K film PMC passes (profiles/traffic.json); null for other content"),
                         "algorithmic_bytes_per_launch": int(alg), "launch_ms": round(kt[dom] / nl, 3), "launches_per_step": nl,
                         "kernel_ms_per_step": {k: round(v, 3) for k, v in kt.items() if v > 0}}}
     enc.close()

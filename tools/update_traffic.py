@@ -74,6 +74,17 @@ def main():
                                  f"k_rangecode {v['k_rangecode'] * nl / enc_batch / 1e6:.1f} M (whole-slice coder), k_model {v.get('k_model', 0) / enc_batch / 1e6:.1f} M; "
                                  "wave_instr_per_frame_split and the peaks are round 3's (profiles/r03_sq_counters.csv, profiles/r03_valu_peak.txt): a SIMD issues 1.05 G wave64 instructions/s of "
                                  "add/sub/logic/right-shift/mov but 0.58 G/s of everything else, a single wavefront never more than one per 4.7 cycles (8.1 when dependent)")
+    # the dominant kernel at the other encode configurations of the bench, from passes of their own (tools/profile_enc.sh <tag>_576 --slices 576 --batch 40,
+    # <tag>_8k --width 8192 --height 4320 --slices 576 --batch 80): bytes per frame OF THAT SIZE
+    d["configs"] = {}
+    for cfgtag, key, batch in (("576", "4096x2160/576", 40), ("8k", "8192x4320/576", 80)):
+        f = table(os.path.join(P, f"{tag}_{cfgtag}_pmc_fetch_size.csv"), "FETCH_SIZE_sum_KB")
+        w = table(os.path.join(P, f"{tag}_{cfgtag}_pmc_write_size.csv"), "WRITE_SIZE_sum_KB")
+        if "k_resolve" in f and "k_resolve" in w and "k_model" in f:
+            steps = f["k_model"][0]
+            d["configs"][key] = {"k_resolve": {"per_frame_bytes": int((f["k_resolve"][1] + w["k_resolve"][1]) / steps / batch), "measured_at_batch": batch,
+                                                "launches_per_step": round(f["k_resolve"][0] / steps),
+                                                "method": f"profiles/{tag}_{cfgtag}_pmc_*.csv, as the 4K / 64-slice passes"}}
     d["sources"] = {s: hashlib.sha256(open(os.path.join(ROOT, s), "rb").read()).hexdigest() for s in SOURCES}
     d["measured_on"] = f"{tag}: the tree whose kernel sources have the sha256 under `sources`"
     json.dump(d, open(tj, "w"), indent=1)
