@@ -843,9 +843,9 @@ static int32_t rcd_s(rc_dec* c, uint8_t* st)
     if (rcd_b(c, st)) return 0;
     int e = 0;
     while (rcd_b(c, st + 1 + (e < 9 ? e : 9))) { if (++e > 31) return 0; }
-    int32_t a = 1;
-    for (int i = e - 1; i >= 0; i--) a = (a << 1) | rcd_b(c, st + 22 + (i < 9 ? i : 9));
-    return rcd_b(c, st + 11 + (e < 10 ? e : 10)) ? -a : a;
+    uint32_t a = 1;                     /* (unsigned: a corrupted stream reaches e = 31, and a signed shift there is undefined in C; the value is the reference's) */
+    for (int i = e - 1; i >= 0; i--) a = (a << 1) | (uint32_t)rcd_b(c, st + 22 + (i < 9 ? i : 9));
+    return rcd_b(c, st + 11 + (e < 10 ? e : 10)) ? (int32_t)(0u - a) : (int32_t)a;
 }
 
 /* parameters::Parse(E, ConfigurationRecord_IsPresent), FFV1_Parameters.cpp:23-183 with QuantizationTableSet / QuantizationTable

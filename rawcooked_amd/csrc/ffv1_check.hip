@@ -48,7 +48,9 @@ using namespace rc;
 
 namespace {
 
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+// (a failed call also leaves the runtime's sticky "last error" behind, which the NEXT user of the runtime in this thread -- torch, say -- would take for
+// its own: it is read out here, the error travels in the return code)
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
 
 struct dec_const {
     uint32_t W, H, line_bytes, pixfmt;
@@ -983,7 +985,7 @@ static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_des
     if (he == hipSuccess) he = hipMemcpy(d->d_const, &c, sizeof c, hipMemcpyHostToDevice);
     if (he == hipSuccess && !hdr.empty()) he = hipMemcpy(d->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
     if (he == hipSuccess && coded) he = hipMemcpy(d->d_init, init.data(), init.size(), hipMemcpyHostToDevice);
-    if (he != hipSuccess) { const int r = fail(100, "ffv1 decoder: device setup failed: %s", hipGetErrorString(he)); rcgpu_ffv1_decoder_destroy(d); return r; }
+    if (he != hipSuccess) { (void)hipGetLastError(); const int r = fail(100, "ffv1 decoder: device setup failed: %s", hipGetErrorString(he)); rcgpu_ffv1_decoder_destroy(d); return r; }
     *out = d;
     return 0;
 }

@@ -78,7 +78,9 @@ constexpr int kCandBytes = 512;                  // k_resolve: which lane of the
 constexpr int kResolveFixedLds = kStageEntries + kStageBitDwords * 4 + kStageMaxPieces * 16 + 64 * 32 + 512 + 2 * 256 + kCandBytes;   // k_resolve: stage bytes | stage bits | piece tails | slots | transitions | powers | candidates
 
 
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+// (a failed call also leaves the runtime's sticky "last error" behind, which the NEXT user of the runtime in this thread -- torch, say -- would take for
+// its own: it is read out here, the error travels in the return code)
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
 
 // ---------------------------------------------------------------------------------------------------------
 // K1: unpack + forward RCT.  One thread per pixel; 10-bit words and 8/16-bit triplets are read with the widest
@@ -1654,6 +1656,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     if (he == hipSuccess) he = hipMemcpy(e->d_hdr, hdr.data(), hdr.size() * 2, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipFuncSetAttribute(reinterpret_cast<const void*>(e->lds_states ? k_resolve<true> : k_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(e->resolve_lds));
     if (he != hipSuccess) {
+        (void)hipGetLastError();                  // (the sticky error goes with this report: see HIP_TRY)
         const int r = fail(100, "ffv1: device setup failed: %s", hipGetErrorString(he));
         rcgpu_ffv1_destroy(e);
         return r;
@@ -1770,7 +1773,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
             if (e->d_ckpt) HIP_TRY(hipFree(e->d_ckpt));
             e->d_ckpt = nullptr; e->ckpt_cap = 0;
             const size_t want = need + need / 8 + (1u << 20);
-            if (hipMalloc(reinterpret_cast<void**>(&e->d_ckpt), want) != hipSuccess) return fail(101, "ffv1: cannot allocate %zu bytes of range-coder checkpoints for %u frames -- lower max_batch", want, n);
+            if (hipMalloc(reinterpret_cast<void**>(&e->d_ckpt), want) != hipSuccess) { (void)hipGetLastError(); return fail(101, "ffv1: cannot allocate %zu bytes of range-coder checkpoints for %u frames -- lower max_batch", want, n); }
             e->ckpt_cap = want;
         }
     }
@@ -1781,7 +1784,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         const size_t want = window_need + window_need / 8 + (1u << 20);
         for (uint32_t k = 0; k < (nseg > 1 ? e->nwin : 1u); k++) {
             hipError_t he = hipMalloc(reinterpret_cast<void**>(&e->d_window[k]), want);
-            if (he != hipSuccess) return fail(101, "ffv1: cannot allocate %zu bytes for a decision-stream window of %u frames: %s -- lower max_batch", want, n, hipGetErrorString(he));
+            if (he != hipSuccess) { (void)hipGetLastError(); return fail(101, "ffv1: cannot allocate %zu bytes for a decision-stream window of %u frames: %s -- lower max_batch", want, n, hipGetErrorString(he)); }
         }
         e->window_cap = want;
     }

@@ -28,7 +28,9 @@ constexpr int kQlpPrecision = 15;
 constexpr int kMaxPartOrder = 8;
 constexpr int kMaxParts = 1 << kMaxPartOrder;
 
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+// (a failed call also leaves the runtime's sticky "last error" behind, which the NEXT user of the runtime in this thread -- torch, say -- would take for
+// its own: it is read out here, the error travels in the return code)
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); return fail(100, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
 
 struct flac_const {
     uint32_t channels, sample_rate, bps, block_size, max_order;
@@ -510,7 +512,7 @@ extern "C" int rcgpu_flac_encode_host(rcgpu_flac* e, const uint8_t* pcm, uint64_
     if (he == hipSuccess) he = hipMemcpy(d_c, &hc, sizeof hc, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(d_pcm, pcm, pcm_bytes, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemset(d_work, 0, slots + 16);
-    if (he != hipSuccess) { cleanup(); return fail(100, "flac: device setup failed: %s", hipGetErrorString(he)); }
+    if (he != hipSuccess) { (void)hipGetLastError(); cleanup(); return fail(100, "flac: device setup failed: %s", hipGetErrorString(he)); }
     const size_t lds = size_t(B) * 4 * 2 + kMaxParts * 8 + size_t(B) * 8 + 2 * kMaxParts;
     he = hipFuncSetAttribute(reinterpret_cast<const void*>(k_flac_plan), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (he == hipSuccess) {

@@ -18,4 +18,4 @@ trap 'cp $T/librcgpu.orig rawcooked_amd/librcgpu.so; cp $T/liboracle.orig oracle
 cp $T/librcgpu.so rawcooked_amd/librcgpu.so; cp $T/liboracle.so oracle/liboracle.so
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
-  python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider
+  python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider ${ASAN_PYTEST_ARGS:-}
