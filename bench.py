@@ -870,7 +870,7 @@ def cfg4_leg(torch, api, synth, dev, device, steps=3, F=80):
 def encode576_leg(torch, api, synth, dev, device, width, height):
     """The encode half at the slice count the reference itself picks for 4K 16-bit (slice_x = slice_y = 24 -> `-slices 576`,
     Lib/Uncompressed/DPX/DPX.cpp:428-441): nine times the chains per frame, so 40 frames fill the device (the pipeline's own choice, by chains)."""
-    return encode_leg(torch, api, synth, dev, device, "config 2 at the reference's own slice count", width, height, synth.PIX_RGB16_BE, api.lib().rcgpu_reference_slices(width, height, 16, 1), "film", 40, 6, seed=9)
+    return encode_leg(torch, api, synth, dev, device, "config 2 at the reference's own slice count", width, height, synth.PIX_RGB16_BE, api.lib().rcgpu_reference_slices(width, height, 16, 1), "film", 40, 24, seed=9)      # 24 steps: 1.5 s inside the clock
 
 
 def flat_leg(torch, api, synth, dev, device, width, height, slices, F):
