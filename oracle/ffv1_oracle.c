@@ -833,7 +833,7 @@ static uint32_t rcd_u(rc_dec* c, uint8_t* st)
 {
     if (rcd_b(c, st)) return 0;
     int e = 0;
-    while (rcd_b(c, st + 1 + (e < 9 ? e : 9))) { if (++e > 31) return 0; }
+    while (rcd_b(c, st + 1 + (e < 9 ? e : 9))) { if (++e > 31) { c->mask = 0; c->cur = c->end + 1; return 0; } }    /* ForceUnderrun, :308-312 */
     uint32_t a = 1;
     for (int i = e - 1; i >= 0; i--) a = (a << 1) | (uint32_t)rcd_b(c, st + 22 + (i < 9 ? i : 9));
     return a;
@@ -842,7 +842,7 @@ static int32_t rcd_s(rc_dec* c, uint8_t* st)
 {
     if (rcd_b(c, st)) return 0;
     int e = 0;
-    while (rcd_b(c, st + 1 + (e < 9 ? e : 9))) { if (++e > 31) return 0; }
+    while (rcd_b(c, st + 1 + (e < 9 ? e : 9))) { if (++e > 31) { c->mask = 0; c->cur = c->end + 1; return 0; } }    /* ForceUnderrun, :308-312 */
     uint32_t a = 1;                     /* (unsigned: a corrupted stream reaches e = 31, and a signed shift there is undefined in C; the value is the reference's) */
     for (int i = e - 1; i >= 0; i--) a = (a << 1) | (uint32_t)rcd_b(c, st + 22 + (i < 9 ? i : 9));
     return rcd_b(c, st + 11 + (e < 10 ? e : 10)) ? (int32_t)(0u - a) : (int32_t)a;
@@ -897,7 +897,7 @@ static int parse_parameters(rc_dec* c, codec_ctx* k, int record)
             uint8_t qst[CONTEXT_SIZE]; memset(qst, 128, sizeof qst);
             int32_t v = 0;
             int16_t* q = k->qs[i].q[j];
-            for (uint32_t kk = 0; kk < 128;) {
+            for (uint64_t kk = 0; kk < 128;) {      /* size_t in the reference: len_minus1 reaches 2^32 - 1 and must not wrap */
                 const uint32_t len1 = rcd_u(c, qst);
                 if (kk + len1 >= 128) return 9;
                 for (uint32_t a = 0; a <= len1; a++, kk++) q[kk] = (int16_t)(scale * v);

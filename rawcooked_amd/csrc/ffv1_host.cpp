@@ -203,14 +203,20 @@ std::vector<uint16_t> slice_header_decisions(const stream_params& p, uint32_t sx
 // decoder over a few hundred bytes -- or, with coded initial states, up to a million symbols once per stream
 namespace {
 struct host_rd {
-    const uint8_t* cur; const uint8_t* end; uint32_t current, mask; uint8_t zero[256]; const uint8_t* one = rc::ffv1::kOneState;
+    const uint8_t* buf; size_t pos, size; uint32_t current, mask; uint8_t zero[256]; const uint8_t* one = rc::ffv1::kOneState;
     std::vector<uint16_t>* trace = nullptr;          // every decision as state | bit << 8
-    host_rd(const uint8_t* p, size_t n) : cur(p), end(p + n) { current = n ? *cur : 0; mask = 0xFF; cur++; rc::ffv1::make_zero_state(zero); }
+    host_rd(const uint8_t* p, size_t n) : buf(p), pos(1), size(n) { current = n ? p[0] : 0; mask = 0xFF; rc::ffv1::make_zero_state(zero); }
     void transitions(const uint8_t* t) { one = t; rc::ffv1::make_zero_state(zero, t); }          // AssignStateTransitions, FFV1_RangeCoder.cpp:35-41
-    bool underrun() const { return cur - (mask < 0x100 ? 0 : 1) > end; }                           // IsUnderrun, :62-65
+    bool underrun() const { return pos - (mask < 0x100 ? 0 : 1) > size; }                          // IsUnderrun, :59-62
+    void force_underrun() { mask = 0; pos = size + 1; }                                            // ForceUnderrun, :308-312: an exponent beyond 31 condemns the stream
     bool bit(uint8_t& st)
     {
-        if (mask < 0x100) { current <<= 8; if (cur < end) current |= *cur; mask <<= 8; cur++; }
+        if (mask < 0x100) {                                                                        // :74-88: past the end every decision is 0 and nothing moves
+            current <<= 8;
+            if (pos > size) return false;
+            if (pos < size) current |= buf[pos];
+            mask <<= 8; pos++;
+        }
         const uint32_t m2 = (mask * st) >> 8;
         mask -= m2;
         const bool b = current >= mask;
@@ -223,7 +229,7 @@ struct host_rd {
     {
         if (bit(st[0])) return 0;
         int e = 0;
-        while (bit(st[1 + (e < 9 ? e : 9)])) if (++e > 31) return 0;
+        while (bit(st[1 + (e < 9 ? e : 9)])) if (++e > 31) { force_underrun(); return 0; }
         uint32_t a = 1;
         for (int i = e - 1; i >= 0; i--) a = (a << 1) | uint32_t(bit(st[22 + (i < 9 ? i : 9)]));
         return a;
@@ -232,7 +238,7 @@ struct host_rd {
     {
         if (bit(st[0])) return 0;
         int e = 0;
-        while (bit(st[1 + (e < 9 ? e : 9)])) if (++e > 31) return 0;
+        while (bit(st[1 + (e < 9 ? e : 9)])) if (++e > 31) { force_underrun(); return 0; }
         int32_t a = 1;
         for (int i = e - 1; i >= 0; i--) a = (a << 1) | int32_t(bit(st[22 + (i < 9 ? i : 9)]));
         return bit(st[11 + (e < 10 ? e : 10)]) ? -a : a;
@@ -286,7 +292,7 @@ int parse_parameters(host_rd& r, rc::ffv1::stream_desc& s, bool record)
             uint8_t qst[kContextSize]; memset(qst, 128, sizeof qst);
             int16_t* q = s.sets[i].q[j];
             int32_t v = 0;
-            for (uint32_t k = 0; k < 128;) {
+            for (uint64_t k = 0; k < 128;) {                 // 64 bits as in the reference (size_t): len_minus1 reaches 2^32 - 1
                 const uint32_t len1 = r.u(qst);
                 if (k + len1 >= 128) return fail(6, "ffv1 stream: bad quantisation table (FFV1_Parameters.cpp:231-232)");
                 for (uint32_t a = 0; a <= len1; a++, k++) q[k] = int16_t(scale * v);
@@ -303,7 +309,11 @@ int parse_parameters(host_rd& r, rc::ffv1::stream_desc& s, bool record)
         s.initial[i].clear();
         if (s.version >= 3 && r.bit(st[0])) {                // states_coded: `States[k] = E.s(States)` (:103-107), every value as it stands
             s.initial[i].resize(size_t(s.sets[i].context_count) * kContextSize);
-            for (uint8_t& v : s.initial[i]) v = uint8_t(r.s(st));
+            size_t n = 0;
+            for (uint8_t& v : s.initial[i]) {
+                v = uint8_t(r.s(st));
+                if (!(++n & 1023) && r.underrun()) return fail(3, "ffv1 stream: the parameters end inside the coded initial states");
+            }
         }
     }
     if (s.version >= 3) {
@@ -343,7 +353,7 @@ int parse_stream(const uint8_t* rec, size_t rec_size, const uint8_t* packet, siz
     if (s.custom_transitions) r.transitions(s.one_state);    // FFV1_Slice.cpp:254-255
     uint8_t st[kContextSize]; memset(st, 128, sizeof st);
     const uint32_t sx = r.u(st), sy = r.u(st), sw1 = r.u(st), sh1 = r.u(st);
-    if (sx >= s.num_h_slices || sy >= s.num_v_slices || sx + sw1 >= s.num_h_slices || sy + sh1 >= s.num_v_slices)
+    if (sx >= s.num_h_slices || sy >= s.num_v_slices || uint64_t(sx) + sw1 >= s.num_h_slices || uint64_t(sy) + sh1 >= s.num_v_slices)
         return fail(8, "ffv1 stream: slice geometry of the first slice header (FFV1-SLICE-slice_xywh)");
     for (uint32_t i = 0; i < s.index_count; i++) {
         s.set_index[i] = r.u(st);

@@ -491,6 +491,88 @@ def test_stream_parse_survives_hostile_input(built):
             s.close()
 
 
+class _RangeEncoder:
+    """RFC 9043 3.8.1 the other way round (what FFmpeg's rangecoder.c writes), for records no encoder would make."""
+    def __init__(self):
+        from rfc9043_validator import default_state_transition
+        self.one = default_state_transition()
+        self.zero = [0] * 256
+        for i in range(1, 256):
+            self.zero[i] = (256 - self.one[256 - i]) & 0xFF
+        self.low, self.range, self.out, self.pending, self.pending_ff = 0, 0xFF00, bytearray(), -1, 0
+
+    def _renorm(self):
+        while self.range < 0x100:
+            if self.pending < 0:
+                self.pending = self.low >> 8
+            elif self.low <= 0xFF00:
+                self.out.append(self.pending); self.out += b"\xff" * self.pending_ff; self.pending_ff = 0; self.pending = self.low >> 8
+            elif self.low >= 0x10000:
+                self.out.append(self.pending + 1); self.out += b"\x00" * self.pending_ff; self.pending_ff = 0; self.pending = (self.low >> 8) & 0xFF
+            else:
+                self.pending_ff += 1
+            self.low = (self.low & 0xFF) << 8
+            self.range <<= 8
+
+    def bit(self, st, i, b):
+        r1 = (self.range * st[i]) >> 8
+        if b:
+            self.low += self.range - r1; self.range = r1; st[i] = self.one[st[i]]
+        else:
+            self.range -= r1; st[i] = self.zero[st[i]]
+        self._renorm()
+
+    def u(self, st, v):
+        self.bit(st, 0, v == 0)
+        if v == 0:
+            return
+        e = v.bit_length() - 1
+        for k in range(e):
+            self.bit(st, 1 + min(k, 9), 1)
+        if e < 32:                                  # (a value of 2^32 and more: 32 ones and no terminator -- the exponent the reference condemns)
+            self.bit(st, 1 + min(e, 9), 0)
+        for k in range(min(e, 31) - 1, -1, -1):
+            self.bit(st, 22 + min(k, 9), (v >> k) & 1)
+
+    def done(self):
+        self.range = 0xFF; self.low += 0xFF; self._renorm(); self.range = 0xFF; self._renorm()
+        return bytes(self.out)
+
+
+def _record_with_run(run_minus1: int, tail=b"") -> bytes:
+    """A version 3 record (RGB, 16 bit, 1 x 1 slices, one table set) whose first table starts with one entry and goes on with `run_minus1`."""
+    e, st = _RangeEncoder(), [128] * 32
+    for v in (3, 4, 1, 1, 16):                      # version, micro_version, coder_type, colorspace_type, bits_per_raw_sample
+        e.u(st, v)
+    e.bit(st, 0, 1); e.u(st, 0); e.u(st, 0); e.bit(st, 0, 0)        # chroma_planes, subsampling, alpha_plane
+    e.u(st, 0); e.u(st, 0); e.u(st, 1)              # 1 x 1 slices, one quantisation table set
+    q = [128] * 32
+    e.u(q, 0); e.u(q, run_minus1)
+    body = e.done() + tail
+    return body + api.lib().rcgpu_crc32_ffv1(body, len(body)).to_bytes(4, "big")
+
+
+def test_stream_parse_does_its_sums_in_the_reference_s_width(built):
+    """`k + len_minus1 >= 128` is a size_t sum in parameters::QuantizationTable (FFV1_Parameters.cpp:231): a run of 2^32 - 1 after the
+    first entry must not wrap to 0 and then be written; and an exponent beyond 31 condemns the stream (ForceUnderrun, FFV1_RangeCoder.cpp:
+    114-118) rather than reading as 0."""
+    from rfc9043_validator import RangeDecoder, default_state_transition
+    rec = _record_with_run(0xFFFFFFFF, b"\0" * 64)
+    rd, st, q = RangeDecoder(rec[:-4], default_state_transition()), [128] * 32, [128] * 32          # the writer above against the validator's reader
+    assert [rd.symbol(st, False) for _ in range(5)] == [3, 4, 1, 1, 16] and rd.bit(st, 0) == 1
+    assert [rd.symbol(st, False) for _ in range(2)] == [0, 0] and rd.bit(st, 0) == 0 and [rd.symbol(st, False) for _ in range(3)] == [0, 0, 1]
+    assert [rd.symbol(q, False) for _ in range(2)] == [0, 0xFFFFFFFF]
+    for run in (126, 0xFFFFFF80, 5):
+        try:
+            api.Ffv1Stream(_record_with_run(run, b"\0" * 64), bytes(16)).close()               # parsed or refused; the table after it is zeros' doing
+        except api.RcgpuError:
+            pass
+    with pytest.raises(api.RcgpuError, match="bad quantisation table"):
+        api.Ffv1Stream(_record_with_run(0xFFFFFFFF, b"\0" * 64), bytes(16))
+    with pytest.raises(api.RcgpuError):
+        api.Ffv1Stream(_record_with_run(1 << 32, b"\0" * 64), bytes(16))
+
+
 def test_decoder_for_stream_says_unsupported_before_it_looks_for_a_device(built):
     """What the reference decodes and the device does not is told apart from what is broken: RCGPU_FFV1_UNSUPPORTED (20), so that a binding
     leaves the stream to its own decoder (route C: ffv1_frame::Process stays on the slice pool).  intra = 0 is such a stream; a stream that
