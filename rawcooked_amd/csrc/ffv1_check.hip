@@ -913,6 +913,7 @@ static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_des
     const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
     if (altern && px.fields != kFieldsLow) return fail(2, "ffv1 decoder: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only");
     if ((cfg->flags & RCGPU_FLAG_VFLIP) && altern) return fail(2, "ffv1 decoder: RCGPU_FLAG_VFLIP and RCGPU_FLAG_ALTERN exclude each other");
+    if (!payload_line_bytes(cfg->pixfmt, cfg->width, true)) return fail(2, "ffv1 decoder: a line of %u pixels does not fit 32 bits", cfg->width);
     if (!altern && cfg->line_bytes < payload_line_bytes(cfg->pixfmt, cfg->width, false)) return fail(2, "ffv1 decoder: line_bytes smaller than a line");
     if (px.fields != kFieldsBytes && px.fields != kFieldsExr && !altern && cfg->line_bytes % 4) return fail(2, "ffv1 decoder: line_bytes of a word-stream layout must be a multiple of 4");
     // the stream against the files, and against what the device decodes
@@ -1609,6 +1610,7 @@ static int make_pad_scan(uint32_t pixfmt, uint32_t W, uint32_t H, uint32_t flags
     const bool altern = (flags & RCGPU_FLAG_ALTERN) != 0;
     pad_scan s{};
     const uint32_t line = payload_line_bytes(pixfmt, W, true);
+    if (!W || !H || !line) return fail(2, "padding scan: %u x %u pixels", W, H);
     s.total = payload_bytes(pixfmt, W, H, line, flags);
     s.line = line;
     const bool y10 = pixfmt == RCGPU_PIX_Y10_FILLEDA_BE || pixfmt == RCGPU_PIX_Y10_FILLEDB_BE;

@@ -1504,6 +1504,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     const bool altern = (cfg->flags & RCGPU_FLAG_ALTERN) != 0;
     if (altern && d.fields != kFieldsLow) return fail(2, "ffv1: RCGPU_FLAG_ALTERN is a layout of the Y 10-bit flavors only (DPX.cpp:363-368)");
     if ((cfg->flags & RCGPU_FLAG_VFLIP) && altern) return fail(2, "ffv1: RCGPU_FLAG_VFLIP and RCGPU_FLAG_ALTERN exclude each other");
+    if (!payload_line_bytes(cfg->pixfmt, cfg->width, true)) return fail(2, "ffv1: a line of %u pixels does not fit 32 bits", cfg->width);
     if (!altern && cfg->line_bytes < payload_line_bytes(cfg->pixfmt, cfg->width, false)) return fail(2, "ffv1: line_bytes smaller than a line");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

@@ -106,6 +106,7 @@ extern "C" int rcgpu_dpx_probe(const uint8_t* f, size_t size, rcgpu_image_info* 
     out->flags = (orientation == 2 ? RCGPU_FLAG_VFLIP : 0) | (altern ? RCGPU_FLAG_ALTERN : 0);
     out->width = width; out->height = height; out->pixfmt = uint32_t(pf); out->bits_per_sample = d.bits;
     out->line_bytes = altern ? 0 : payload_line_bytes(uint32_t(pf), width, true);
+    if (!altern && !out->line_bytes) return fail(13, "dpx: a line of %u pixels does not fit 32 bits", width);
     out->data_offset = offset_to_data;
     out->data_size = payload_bytes(uint32_t(pf), width, height, out->line_bytes, out->flags);
     if (out->data_offset + out->data_size > size) return fail(15, "dpx: truncated image data");
@@ -213,7 +214,8 @@ extern "C" int rcgpu_tiff_probe(const uint8_t* f, size_t size, rcgpu_image_info*
     }
     const pix_desc& d = pix(uint32_t(pf));
     out->width = width; out->height = height; out->pixfmt = uint32_t(pf); out->bits_per_sample = d.bits;
-    out->line_bytes = width * d.bytes_pp;
+    out->line_bytes = payload_line_bytes(uint32_t(pf), width, false);
+    if (!out->line_bytes) return fail(13, "tiff: a line of %u pixels does not fit 32 bits", width);
     out->data_offset = offs[0];
     out->data_size = uint64_t(out->line_bytes) * height;
     if (out->data_offset + out->data_size != last) return fail(16, "tiff: strip sizes do not match the image size");
@@ -305,6 +307,7 @@ extern "C" int rcgpu_exr_probe(const uint8_t* f, size_t size, rcgpu_image_info* 
     width++; height++;
     out->width = width; out->height = height; out->pixfmt = RCGPU_PIX_EXR_RGB16; out->bits_per_sample = 16;
     out->line_bytes = payload_line_bytes(RCGPU_PIX_EXR_RGB16, width, false);
+    if (!out->line_bytes) return fail(13, "exr: a line of %u pixels does not fit 32 bits", width);
     out->data_offset = o + 8ull * height;                                                                   // line offset table, EXR.cpp:597-598
     out->data_size = uint64_t(out->line_bytes) * height;
     if (out->data_offset + out->data_size > size) return fail(15, "exr: truncated image data");

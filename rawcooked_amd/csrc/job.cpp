@@ -75,7 +75,7 @@ bool expand_template(const std::string& tpl, unsigned long long n, std::string& 
     if (pc == std::string::npos) return false;
     size_t i = pc + 1; int width = 0; bool zero = false;
     if (i < tpl.size() && tpl[i] == '0') { zero = true; i++; }
-    while (i < tpl.size() && isdigit(uint8_t(tpl[i]))) width = width * 10 + (tpl[i++] - '0');
+    while (i < tpl.size() && isdigit(uint8_t(tpl[i]))) { width = width * 10 + (tpl[i++] - '0'); if (width > 20) return false; }     // (a frame number has 20 digits at most; `num` below holds them)
     if (i >= tpl.size() || tpl[i] != 'd') return false;
     char num[32];
     snprintf(num, sizeof num, zero ? "%0*llu" : "%*llu", width, n);

@@ -42,15 +42,17 @@ static const pix_desc k_pix[RCGPU_PIX_COUNT] = {
 };
 const pix_desc& pix(uint32_t pixfmt) { return k_pix[pixfmt < RCGPU_PIX_COUNT ? pixfmt : 0]; }
 
+// 0: the line does not fit 32 bits (a width only a hostile header names; every caller refuses it)
 uint32_t payload_line_bytes(uint32_t pixfmt, uint32_t width, bool dpx_padding)
 {
     const pix_desc& d = pix(pixfmt);
     const uint64_t nfields = uint64_t(width) * d.planes;
-    if (d.fields == kFieldsExr) return uint32_t(8 + 6 * uint64_t(width));           // EXR.cpp:601-606
-    if (d.fields == kFieldsPacked) return uint32_t((nfields * 12 + 31) / 32 * 4);
-    if (d.fields != kFieldsBytes) return uint32_t((nfields + 2) / 3 * 4);
-    const uint64_t n = uint64_t(width) * d.bytes_pp;
-    return uint32_t(dpx_padding ? (n + 3) / 4 * 4 : n);
+    uint64_t n;
+    if (d.fields == kFieldsExr) n = 8 + 6 * uint64_t(width);                          // EXR.cpp:601-606
+    else if (d.fields == kFieldsPacked) n = (nfields * 12 + 31) / 32 * 4;
+    else if (d.fields != kFieldsBytes) n = (nfields + 2) / 3 * 4;
+    else { n = uint64_t(width) * d.bytes_pp; if (dpx_padding) n = (n + 3) / 4 * 4; }
+    return n > 0xFFFFFFFFull ? 0u : uint32_t(n);
 }
 uint64_t payload_bytes(uint32_t pixfmt, uint32_t width, uint32_t height, uint32_t line_bytes, uint32_t flags)
 {

@@ -184,6 +184,19 @@ def test_hostile_records_and_files_are_refused_not_trusted(built):
                     pass
 
 
+def test_a_line_that_does_not_fit_32_bits_is_refused(built):
+    """width x bytes per pixel is a 64-bit product everywhere: a DPX header naming 2^29 RGBA16 pixels on one line (4 GiB a line: the 32-bit
+    product is 0, and `offset + 0 <= size` holds) is refused by the probe, and by the encoder and the decoder before any device is looked for."""
+    d = bytearray(synth.dpx_file(synth.components(8, 2, 4, 16, "film", seed=3), synth.PIX_RGBA16_BE))
+    assert api.dpx_probe(bytes(d)).width == 8
+    d[772:776] = (1 << 29).to_bytes(4, "big"); d[776:780] = (1).to_bytes(4, "big")
+    with pytest.raises(RuntimeError, match="does not fit 32 bits"):
+        api.dpx_probe(bytes(d))
+    for make in (lambda: api.Ffv1Encoder(1 << 29, 1, synth.PIX_RGBA16_BE, 0, 1, 1), lambda: api.Ffv1Decoder(1 << 29, 1, synth.PIX_RGBA16_BE, 0, 1, 1, 1, 1)):
+        with pytest.raises(RuntimeError, match="does not fit 32 bits|2\\^30 pixels"):
+            make()
+
+
 def test_exr_probe(built):
     v = [v for v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))["ffv1"] if v["name"].startswith("exr")][0]
     d = synth.exr_file(synth.components(v["width"], v["height"], 3, 16, "film", seed=1), trailer=b"tail")

@@ -12,6 +12,7 @@
 #   checkprof [tag]                check half: per-launch HIP events as timed (partitioned), then rocprofv3 --stats + FETCH/WRITE_SIZE passes unpartitioned
 #   encprof [tag]                  encode half: rocprofv3 --stats, FETCH/WRITE_SIZE passes, SQ instruction counters at batch 336
 #   trace [tag] [bench args]       rocprofv3 --kernel-trace as a timeline: where k_resolve / k_rangecode stand still (TRACE_MODE=check: the check half's launches)
+#   refresh [tag]                  tests + encprof + checkprof + the 576-slice and 8K passes + the driver's line, on one box (then tools/adopt_profiles.sh)
 #   sweep [tag] "ENV=.." ...       one bench line per environment setting with the TIMING build -> sweep_<tag>.jsonl, e.g. the floor of round 4:
 #                                  sweep floor "" RCGPU_EXP_SKIP_RC=1 "RCGPU_EXP_SKIP_RC=1 RCGPU_EXP_STATES_L2=1" RCGPU_EXP_STATES_L2=1 RCGPU_RC_SPAN=64
 ROUND=${ROUND:-r05}
@@ -114,5 +115,15 @@ except Exception as e:
 PY
         tail -1 $OUT/sweep_$TAG.jsonl
     done ;;
+refresh)
+    # the end-of-round set on the final tree, one box: GPU suite, every pass profiles/traffic.json is made from (64 slices, 576, 8K, the check half),
+    # the driver's line.  Then, at home: bash tools/adopt_profiles.sh $TAG
+    bash $0 tests $TAG; grep -q "passed" $OUT/tests_$TAG.log && ! grep -q "failed\|error" $OUT/tests_$TAG.log || { echo "round.sh refresh: the suite is not green, nothing else is run"; exit 1; }
+    bash $0 encprof $TAG; bash $0 checkprof $TAG
+    PASS_TIMEOUT=500 bash tools/profile_enc.sh ${ROUND}${TAG}_576 --slices 576 --batch 40 > $OUT/profile_enc576_$TAG.log 2>&1; tail -8 $OUT/profile_enc576_$TAG.log | cut -c1-200
+    PASS_TIMEOUT=500 bash tools/profile_enc.sh ${ROUND}${TAG}_8k --width 8192 --height 4320 --slices 576 --batch 80 > $OUT/profile_enc8k_$TAG.log 2>&1; tail -8 $OUT/profile_enc8k_$TAG.log | cut -c1-200
+    cp gpurun_out/prof/${ROUND}${TAG}_* $OUT/ 2>/dev/null
+    bash tools/adopt_profiles.sh $TAG $ROUND | tail -6      # profiles/traffic.json of THIS tree, here on the box, so that the line below carries it
+    bash $0 bench $TAG --gpus 1 --steps 20 --warmup 5 ;;
 *)  echo "round.sh: unknown '$WHAT'"; exit 2 ;;
 esac
