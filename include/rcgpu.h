@@ -407,6 +407,13 @@ typedef struct {
 int  rcgpu_ffv1_stream_parse(const uint8_t* record, size_t record_size, const uint8_t* packet, size_t packet_size, rcgpu_ffv1_stream** stream);
 void rcgpu_ffv1_stream_free(rcgpu_ffv1_stream* stream);
 int  rcgpu_ffv1_stream_get_info(const rcgpu_ffv1_stream* stream, rcgpu_ffv1_stream_info* info);
+/* What the description holds beyond the numbers, for a caller that wants to look (tests/test_host.py compares it with what the reference's
+ * own parameters::Parse made of the same bytes): the state transition table in force (256 bytes, one_state; may be NULL), and of table set
+ * `set` the five quantisation tables (5 x 256 values as parameters::QuantizationTable leaves them, FFV1_Parameters.cpp:222-253; may be NULL)
+ * and the coded initial states (context_count x 32 bytes into initial_states when it is not NULL and the capacity suffices;
+ * *initial_size = their size, 0 when the set's states start at 128). */
+int  rcgpu_ffv1_stream_get_tables(const rcgpu_ffv1_stream* stream, uint32_t set, uint8_t* state_transitions, int16_t* quant_tables,
+                                  uint8_t* initial_states, uint64_t initial_capacity, uint64_t* initial_size);
 int  rcgpu_ffv1_decoder_create_for_stream(const rcgpu_ffv1_config* files, const rcgpu_ffv1_stream* stream, rcgpu_ffv1_decoder** dec);
 int  rcgpu_ffv1_decoder_last_kernel_times(const rcgpu_ffv1_decoder* dec, float ms[3]);   /* split+crc, slices, pack */
 /* First differing byte of two device buffers; *first_diff = UINT64_MAX when they are equal (FileWriter.cpp:448-463). */

@@ -156,6 +156,7 @@ SYMBOLS = {
     "rcgpu_ffv1_stream_parse": (C.c_int, [_U8P, _SZ, _U8P, _SZ, C.POINTER(_VP)]),
     "rcgpu_ffv1_stream_free": (None, [_VP]),
     "rcgpu_ffv1_stream_get_info": (C.c_int, [_VP, C.POINTER(Ffv1StreamInfo)]),
+    "rcgpu_ffv1_stream_get_tables": (C.c_int, [_VP, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "rcgpu_ffv1_decoder_create_for_stream": (C.c_int, [C.POINTER(Ffv1Config), _VP, C.POINTER(_VP)]),
     "rcgpu_ffv1_decoder_last_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_float)]),
     "rcgpu_compare_device": (C.c_int, [_VP, _VP, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
@@ -437,6 +438,16 @@ class Ffv1Stream:
         i = Ffv1StreamInfo()
         _check(lib().rcgpu_ffv1_stream_get_info(self.h, C.byref(i)), "rcgpu_ffv1_stream_get_info")
         return i
+
+    def tables(self, set_index: int):
+        """(state transitions: 256 bytes, quantisation tables: int16 [5][256], coded initial states: bytes, b"" when the set starts at 128)."""
+        import numpy as np
+        one = (C.c_uint8 * 256)(); q = np.zeros((5, 256), dtype=np.int16); n = C.c_uint64(0)
+        _check(lib().rcgpu_ffv1_stream_get_tables(self.h, set_index, one, q.ctypes.data, None, 0, C.byref(n)), "rcgpu_ffv1_stream_get_tables")
+        init = (C.c_uint8 * max(1, n.value))()
+        if n.value:
+            _check(lib().rcgpu_ffv1_stream_get_tables(self.h, set_index, None, None, init, n.value, None), "rcgpu_ffv1_stream_get_tables")
+        return bytes(one), q, bytes(init)[:n.value]
 
     def close(self):
         if self.h:

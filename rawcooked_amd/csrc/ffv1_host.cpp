@@ -350,11 +350,23 @@ int parse_stream(const uint8_t* rec, size_t rec_size, const uint8_t* packet, siz
         s.set_index[0] = s.set_index[1] = s.set_index[2] = 0;
         return 0;
     }
+    // The reference compares slice_y with num_h_slices (FFV1_Slice.cpp:125): in a stream with more slice rows than columns it reports
+    // FFV1-SLICE-slice_xywh for every slice below row num_h_slices and decodes it where the slice before it lay.  No encoder RAWcooked drives
+    // writes such a grid (FFmpeg picks columns >= rows); one that has it keeps the reference's decoder and the reference's verdict.
+    if (s.num_v_slices > s.num_h_slices) return fail(kUnsupported, "ffv1 stream: %u x %u slices: more rows than columns, which the reference itself misreads (FFV1_Slice.cpp:125): left to it", s.num_h_slices, s.num_v_slices);
     if (s.custom_transitions) r.transitions(s.one_state);    // FFV1_Slice.cpp:254-255
     uint8_t st[kContextSize]; memset(st, 128, sizeof st);
-    const uint32_t sx = r.u(st), sy = r.u(st), sw1 = r.u(st), sh1 = r.u(st);
-    if (sx >= s.num_h_slices || sy >= s.num_v_slices || uint64_t(sx) + sw1 >= s.num_h_slices || uint64_t(sy) + sh1 >= s.num_v_slices)
-        return fail(8, "ffv1 stream: slice geometry of the first slice header (FFV1-SLICE-slice_xywh)");
+    // slice::SliceHeader's tests, in its order and its arithmetic (FFV1_Slice.cpp:117-147): 32-bit sums that may wrap, and slice_y against
+    // num_H_slices.  What gets through here and is still nonsense meets the device's own comparison of every slice header with its place.
+    const uint32_t sx = r.u(st);
+    bool bad = sx >= s.num_h_slices;
+    const uint32_t sy = bad ? 0 : r.u(st);
+    bad = bad || sy >= s.num_h_slices;
+    const uint32_t sw1 = bad ? 0 : r.u(st);
+    bad = bad || uint32_t(sx + sw1 + 1) > s.num_h_slices;
+    const uint32_t sh1 = bad ? 0 : r.u(st);
+    bad = bad || uint32_t(sy + sh1 + 1) > s.num_v_slices;
+    if (bad) return fail(8, "ffv1 stream: slice geometry of the first slice header (FFV1-SLICE-slice_xywh)");
     for (uint32_t i = 0; i < s.index_count; i++) {
         s.set_index[i] = r.u(st);
         if (s.set_index[i] >= s.set_count) return fail(8, "ffv1 stream: quant_table_set_index %u of %u sets (FFV1_Slice.cpp:162-167)", s.set_index[i], s.set_count);
@@ -422,6 +434,24 @@ extern "C" int rcgpu_ffv1_stream_get_info(const rcgpu_ffv1_stream* s, rcgpu_ffv1
     info->ec = d.ec; info->intra = d.intra; info->quant_table_set_index_count = d.index_count;
     for (int g = 0; g < 3; g++) info->quant_table_set_index[g] = d.set_index[g];
     for (uint32_t i = 0; i < d.set_count; i++) { info->context_count[i] = d.sets[i].context_count; info->states_coded[i] = !d.initial[i].empty(); }
+    return 0;
+}
+
+extern "C" int rcgpu_ffv1_stream_get_tables(const rcgpu_ffv1_stream* s, uint32_t set, uint8_t* state_transitions, int16_t* quant_tables,
+                                            uint8_t* initial_states, uint64_t initial_capacity, uint64_t* initial_size)
+{
+    using namespace rc;
+    clear_error();
+    if (!s) return fail(1, "ffv1 stream: null argument");
+    const ffv1::stream_desc& d = s->d;
+    if (set >= d.set_count) return fail(2, "ffv1 stream: table set %u of %u", set, d.set_count);
+    if (state_transitions) memcpy(state_transitions, d.one_state, 256);
+    if (quant_tables) memcpy(quant_tables, d.sets[set].q, sizeof d.sets[set].q);
+    if (initial_size) *initial_size = d.initial[set].size();
+    if (initial_states && !d.initial[set].empty()) {
+        if (initial_capacity < d.initial[set].size()) return fail(2, "ffv1 stream: %zu bytes of initial states, room for %llu", d.initial[set].size(), (unsigned long long)initial_capacity);
+        memcpy(initial_states, d.initial[set].data(), d.initial[set].size());
+    }
     return 0;
 }
 

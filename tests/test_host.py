@@ -504,52 +504,7 @@ def test_stream_parse_survives_hostile_input(built):
             s.close()
 
 
-class _RangeEncoder:
-    """RFC 9043 3.8.1 the other way round (what FFmpeg's rangecoder.c writes), for records no encoder would make."""
-    def __init__(self):
-        from rfc9043_validator import default_state_transition
-        self.one = default_state_transition()
-        self.zero = [0] * 256
-        for i in range(1, 256):
-            self.zero[i] = (256 - self.one[256 - i]) & 0xFF
-        self.low, self.range, self.out, self.pending, self.pending_ff = 0, 0xFF00, bytearray(), -1, 0
-
-    def _renorm(self):
-        while self.range < 0x100:
-            if self.pending < 0:
-                self.pending = self.low >> 8
-            elif self.low <= 0xFF00:
-                self.out.append(self.pending); self.out += b"\xff" * self.pending_ff; self.pending_ff = 0; self.pending = self.low >> 8
-            elif self.low >= 0x10000:
-                self.out.append(self.pending + 1); self.out += b"\x00" * self.pending_ff; self.pending_ff = 0; self.pending = (self.low >> 8) & 0xFF
-            else:
-                self.pending_ff += 1
-            self.low = (self.low & 0xFF) << 8
-            self.range <<= 8
-
-    def bit(self, st, i, b):
-        r1 = (self.range * st[i]) >> 8
-        if b:
-            self.low += self.range - r1; self.range = r1; st[i] = self.one[st[i]]
-        else:
-            self.range -= r1; st[i] = self.zero[st[i]]
-        self._renorm()
-
-    def u(self, st, v):
-        self.bit(st, 0, v == 0)
-        if v == 0:
-            return
-        e = v.bit_length() - 1
-        for k in range(e):
-            self.bit(st, 1 + min(k, 9), 1)
-        if e < 32:                                  # (a value of 2^32 and more: 32 ones and no terminator -- the exponent the reference condemns)
-            self.bit(st, 1 + min(e, 9), 0)
-        for k in range(min(e, 31) - 1, -1, -1):
-            self.bit(st, 22 + min(k, 9), (v >> k) & 1)
-
-    def done(self):
-        self.range = 0xFF; self.low += 0xFF; self._renorm(); self.range = 0xFF; self._renorm()
-        return bytes(self.out)
+from range_writer import RangeEncoder as _RangeEncoder
 
 
 def _record_with_run(run_minus1: int, tail=b"") -> bytes:
@@ -584,6 +539,139 @@ def test_stream_parse_does_its_sums_in_the_reference_s_width(built):
         api.Ffv1Stream(_record_with_run(0xFFFFFFFF, b"\0" * 64), bytes(16))
     with pytest.raises(api.RcgpuError):
         api.Ffv1Stream(_record_with_run(1 << 32, b"\0" * 64), bytes(16))
+
+
+_FNV0 = 0xcbf29ce484222325
+
+
+def _fnv(h, data):
+    for x in data:
+        h = ((h ^ x) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _parse_cases():
+    blob = open(os.path.join(_G, "parse_cases.bin"), "rb").read()
+    lines = open(os.path.join(_G, "parse_cases.txt")).read().splitlines()
+    cases, o = [], 0
+    while o < len(blob):
+        a, b = struct.unpack_from("<II", blob, o)
+        cases.append((blob[o + 8:o + 8 + a], blob[o + 8 + a:o + 8 + a + b]))
+        o += 8 + a + b
+    assert len(cases) == len(lines)
+    return cases, lines
+
+
+def _reference_said(line):
+    """A line of oracle/ref_ffv1_parse.cpp: None when the reference refused, else (fields, transitions hash, [(tables hash, contexts, states hash)],
+    underrun, (key, header ok, indexes, underrun, message) or None)."""
+    w = line.split()
+    if w[0] == "ERR":
+        return None
+    f = [int(x) for x in w[1:18]]     # version micro coder colorspace bits chroma log2h log2v alpha num_h num_v sets ec intra index_count custom underrun
+    rest, sets, k = w[18:], [], 1
+    while k < len(rest) and rest[k][0] == "Q":
+        sets.append((int(rest[k][1:], 16), int(rest[k + 1][1:]), int(rest[k + 2][1:], 16)))
+        k += 3
+    hdr = None
+    if k < len(rest):
+        hdr = (int(rest[k][1:]), int(rest[k + 1][1:]), [int(x) for x in rest[k + 2][1:].split(",") if x], int(rest[k + 3][1:]), rest[k + 4][1:])
+    return [f[0], f[1], f[2], f[3], f[4], f[5], f[8], f[9], f[10], f[11], f[12], f[13], f[14], f[15]], int(rest[0][1:], 16), sets, f[16], hdr
+
+
+def _library_says(rec, pk):
+    s = api.Ffv1Stream(rec, pk)
+    i = s.info()
+    fields = [i.version, i.micro_version, 1, i.colorspace_type, i.bits_per_raw_sample, i.chroma_planes, i.alpha_plane, i.num_h_slices, i.num_v_slices,
+              i.quant_table_set_count, i.ec, i.intra, i.quant_table_set_index_count, int(i.coder_type == 2)]
+    t, sets = None, []
+    for k in range(i.quant_table_set_count):
+        one, q, init = s.tables(k)
+        t = _fnv(_FNV0, one[1:])
+        sets.append((_fnv(_FNV0, q.astype("<i4").tobytes()), i.context_count[k], _fnv(_FNV0, init if init else bytes([128]) * (i.context_count[k] * 32))))
+    idx = list(i.quant_table_set_index)[:i.quant_table_set_index_count]
+    s.close()
+    return fields, t, sets, idx
+
+
+def _hold_to_the_reference(cases, lines):
+    both = 0
+    for n, ((rec, pk), line) in enumerate(zip(cases, lines)):
+        ref = _reference_said(line)
+        try:
+            mine = _library_says(rec, pk)
+        except api.RcgpuError as ex:
+            if ref is None:
+                continue
+            fields, _, _, underrun, hdr = ref
+            # the library may refuse what the reference reads, never the other way round -- and only for these reasons: the record ran out of
+            # bytes (the reference reads zeros on), a stream the device does not decode, or a first frame that is no key frame / whose first slice
+            # header the reference itself flags / that ends inside it / that is shorter than any frame
+            assert (ex.code == 3 and underrun) or ex.code == 20 or (ex.code == 8 and hdr and (not hdr[0] or not hdr[1] or hdr[3] or len(pk) < 8)), (n, str(ex), line)
+            continue
+        assert ref is not None, f"case {n}: the reference refuses ({line}) what the library reads"
+        fields, t, sets, underrun, hdr = ref
+        assert mine[0] == fields and mine[1] == t and mine[2] == sets, (n, mine, line)
+        if hdr is not None:
+            assert hdr[0] == 1 and hdr[1] == 1 and mine[3] == hdr[2], (n, mine[3], line)
+        both += 1
+    return both
+
+
+def test_stream_parse_agrees_with_the_reference_s_reader(built):
+    """3165 records and first frames -- the golden ones, ones written field by field on and beyond every limit (tests/range_writer.py), and seeded
+    mutations of both -- with what the REAL reference's ffv1_frame::OutOfBand, parameters::Parse and slice::SliceHeader made of each
+    (oracle/ref_ffv1_parse.cpp drives them; tests/golden/make_parse_golden.py): whatever the reference refuses the library refuses; whatever both
+    read they read alike -- every field, every table value, every initial state, the table set of every plane group."""
+    cases, lines = _parse_cases()
+    assert len(cases) >= 3000
+    assert _hold_to_the_reference(cases, lines) >= 500
+    for v in _VEC["ffv1_ext"] + _VEC["ffv1"]:                                             # and the golden streams as they are: read by both
+        rec = _ext_record(v) if "config_record_file" in v else bytes.fromhex(v.get("config_record", ""))
+        if rec and len(rec) <= 700:
+            k = cases.index((rec, open(os.path.join(_G, v["frames"][0]["packet"]), "rb").read()[:48]))
+            assert _reference_said(lines[k]) is not None and _library_says(*cases[k])
+
+
+def test_more_slice_rows_than_columns_stay_with_the_reference(built):
+    """slice::SliceHeader compares slice_y with num_H_slices (FFV1_Slice.cpp:125): with 3 columns and 6 rows the reference reports
+    FFV1-SLICE-slice_xywh for every slice from row 3 on (parse_cases.txt holds its verdict on such headers).  A device decoder that read them
+    right would pass a file the reference fails: the stream is told apart (RCGPU_FFV1_UNSUPPORTED) and keeps the reference's decoder."""
+    import range_writer as rw
+    with pytest.raises(api.RcgpuUnsupported, match="more rows than columns"):
+        api.Ffv1Stream(rw.record(h1=2, v1=5), rw.first_slice((0, 0)))
+    api.Ffv1Stream(rw.record(h1=5, v1=2), rw.first_slice((0, 0))).close()
+    api.Ffv1Stream(rw.record(h1=5, v1=5), rw.first_slice((0, 0))).close()
+
+
+def test_stream_parse_agrees_with_the_reference_s_reader_on_fresh_mutations(built, tmp_path):
+    """The same against the reference's reader itself (oracle/_ref/ref_ffv1_parse, where it was built), on mutations nobody has seen: a new seed
+    every run, printed on failure."""
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_ffv1_parse")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_ffv1_parse not built (needs /root/reference)")
+    import range_writer as rw
+    seed = int.from_bytes(os.urandom(4), "little")
+    rng = np.random.default_rng(seed)
+    base, _ = _parse_cases()
+    base = [c for c in base[:150] if len(c[0]) + len(c[1]) > 0]
+    cases = []
+    for _ in range(4000):
+        rec, pk = base[int(rng.integers(0, len(base)))]
+        r, q = bytearray(rec), bytearray(pk)
+        for _ in range(int(rng.integers(1, 5))):
+            tgt = r if (len(r) > 4 and rng.integers(0, 3)) else q
+            if len(tgt):
+                tgt[int(rng.integers(0, max(1, len(tgt) - (4 if tgt is r else 0))))] = int(rng.integers(0, 256))
+        cases.append((rw.sealed(bytes(r[:-4])) if len(r) > 4 else bytes(r), bytes(q)))
+    f = tmp_path / "cases.bin"
+    f.write_bytes(b"".join(struct.pack("<II", len(r), len(p)) + r + p for r, p in cases))
+    lines = subprocess.run([exe, str(f)], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(lines) == len(cases), f"seed {seed}"
+    try:
+        _hold_to_the_reference(cases, lines)
+    except AssertionError as e:
+        raise AssertionError(f"seed {seed}: {e}")
 
 
 def test_decoder_for_stream_says_unsupported_before_it_looks_for_a_device(built):
