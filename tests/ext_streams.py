@@ -1,0 +1,79 @@
+"""Random FFV1 streams of the general syntax -- what parameters::Parse accepts and FFmpeg's defaults never produce -- written by the oracle
+(whose writer of this syntax is pinned by the reference-blessed ext vectors, and stream by stream by oracle/_ref/ref_ffv1_decode where it
+exists).  Shared by the CPU test (oracle writer against the real reference's decoder) and the GPU test (device decoder)."""
+import ctypes
+
+import numpy as np
+
+import oracle_binding as ob
+from rawcooked_amd import api, synth
+
+
+def random_ext(rng, bits):
+    """a random stream description within what parameters::Parse accepts: 1..8 table sets, each five random level maps whose context count
+    stays small enough for a test, a random set per plane group, now and then a transition table of its own and coded initial states"""
+    def table(max_levels):
+        L = int(rng.integers(1, max_levels + 1))
+        if L == 1:
+            return [128]
+        cuts = sorted(rng.choice(np.arange(1, 128), size=L - 1, replace=False).tolist())
+        return [b - a for a, b in zip([0] + cuts, cuts + [128])]
+    sets = []
+    for _ in range(int(rng.integers(1, 9))):
+        while True:
+            t = [table(6), table(5), table(4), table(3) if rng.random() < 0.6 else [128], table(3) if rng.random() < 0.6 else [128]]
+            n = 1
+            for r in t:
+                n *= 2 * len(r) - 1
+            if n <= 6000:
+                break
+        sets.append(t)
+    kw = dict(sets=sets, set_index=tuple(int(rng.integers(0, len(sets))) for _ in range(3)))
+    custom = rng.random() < 0.5
+    if custom:
+        kw["one_state"] = [0] + [int(min(255, max(1, i + rng.integers(1, 20) - (rng.random() < 0.1) * rng.integers(0, 10)))) for i in range(1, 256)]
+    return kw, custom
+
+
+
+def random_stream(seed, n=3):
+    """(width, height, pixfmt, line_bytes, record, packets, payloads, flavor string, flags) of seed's stream: geometry, pixel layout, table
+    sets, transitions, coded initial states, version 1 or 3 all drawn from it."""
+    rng = np.random.default_rng(9000 + seed)
+    pixfmt = [synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_LE, synth.PIX_RGBA16_LE, synth.PIX_Y16_BE, synth.PIX_RGB8, synth.PIX_RGB12_PACKED_BE][seed % 6]
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    w, h = int(rng.integers(40, 120)), int(rng.integers(24, 72))
+    if pixfmt == synth.PIX_RGB12_PACKED_BE:
+        w = 96                                               # (a geometry the reference's word merging handles, tests/golden/make_golden.py)
+    nh = int(rng.integers(1, 5)); nv = int(rng.integers(1, nh + 1))
+    kw, custom = random_ext(rng, bits)
+    version = 1 if seed % 5 == 4 else 3
+    if version == 1:
+        kw = dict(version=1, sets=kw["sets"][:1], **({"one_state": kw["one_state"]} if custom else {}))
+        nh = nv = 1
+    e = ob.stream_ext(**kw)
+    if version == 3 and rng.random() < 0.5:                    # coded initial states for the sets in use: values from which state 0 is out of reach
+        lo, hi = (1, 255) if custom else (30, 226)
+        used = sorted(set(kw["set_index"][:(nc - 1 if nc != 1 else 1)]))
+        init = {i: bytes(rng.integers(lo, hi + 1, size=ob.lib().ffv1o_ext_context_count(ctypes.byref(e), i) * 32, dtype=np.int64).astype(np.uint8)) for i in used}
+        e = ob.stream_ext(initial_states=init, **kw)
+    ec = int(rng.integers(0, 2)) if version == 3 else 0
+    p = ob.with_ext(ob.Params(w, h, pixfmt, nh, nv, ec), e)
+    pls, tight = [], []
+    for i in range(n):
+        comp = synth.components(w, h, nc, bits, ["film", "noise", "flat"][(seed + i) % 3], seed=seed * 10 + i)
+        pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
+        pls.append(pl)
+        tight.append(synth.pack_payload(comp, pixfmt, False)[0])
+    rec = ob.config_record(p)
+    pks = [ob.encode_payload(p, pl, line_bytes) for pl in pls]
+    flavor = api.dpx_probe(synth.dpx_file(comp, pixfmt)).flavor.decode()
+    return w, h, pixfmt, line_bytes, rec, pks, pls, flavor, 0, tight
+
+
+def reference_decodes_to(frames, tight):
+    """What oracle/_ref/ref_ffv1_decode returned for a stream against its source pictures.  The reference's decoder lays the lines of the 8 and
+    16 bit DPX flavors out one behind the other (raw_frame::DPX_Create, RawFrame.cpp:89-113: no room at a line's end, the whole plane rounded up
+    to 32 bits) -- its PARSER expects every line rounded up to 32 bits (DPX.cpp:476-482), which is what `payloads` are; `tight` is the same
+    picture without that room.  Route C takes line_bytes from the reference's plane, so the device writes what the reference would have."""
+    return len(frames) == len(tight) and all(v == 0 and len(got) - len(t) in (0, 1, 2, 3) and got[:len(t)] == t for (v, got), t in zip(frames, tight))

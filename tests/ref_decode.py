@@ -1,0 +1,40 @@
+"""tests -> oracle/_ref/ref_ffv1_decode (oracle/ref_ffv1_decode.cpp): the REAL reference's FFV1 decoder on a track's record and frames, no
+Matroska file around them.  Present where oracle/Makefile.ref was run (this container; the binary travels to the GPU box)."""
+import os
+import struct
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "ref_ffv1_decode")
+
+
+def available() -> bool:
+    return os.path.exists(EXE)
+
+
+def decode(cases):
+    """cases: [(flavor string, flags (1 VFlip | 2 Altern), width, height, record, [packets])] -> per case [(verdict, payload bytes)] per frame
+    and the driver's line (the reference's first complaint at its end)."""
+    blob = bytearray()
+    for flavor, flags, w, h, rec, pks in cases:
+        fl = flavor.encode()
+        blob += struct.pack("<I", len(fl)) + fl + struct.pack("<IIII", flags, w, h, len(rec)) + rec + struct.pack("<I", len(pks))
+        for p in pks:
+            blob += struct.pack("<I", len(p)) + p
+    with tempfile.TemporaryDirectory() as t:
+        a, b = os.path.join(t, "cases.bin"), os.path.join(t, "out.bin")
+        open(a, "wb").write(blob)
+        r = subprocess.run([EXE, a, b], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+        out = open(b, "rb").read()
+    lines, res, o = r.stdout.splitlines(), [], 0
+    assert len(lines) == len(cases), r.stdout[-400:]
+    for _, _, _, _, _, pks in cases:
+        frames = []
+        for _ in pks:
+            v, n = struct.unpack_from("<II", out, o)
+            frames.append((v, out[o + 8:o + 8 + n]))
+            o += 8 + n
+        res.append(frames)
+    return res, lines

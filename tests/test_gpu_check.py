@@ -487,69 +487,22 @@ def test_padding_scan_matches_the_reference_parser(built):
     assert checked == len(vs) > 600
 
 
-def _random_ext(rng, bits):
-    """a random stream description within what parameters::Parse accepts: 1..8 table sets, each five random level maps whose context count
-    stays small enough for a test, a random set per plane group, now and then a transition table of its own and coded initial states"""
-    def table(max_levels):
-        L = int(rng.integers(1, max_levels + 1))
-        if L == 1:
-            return [128]
-        cuts = sorted(rng.choice(np.arange(1, 128), size=L - 1, replace=False).tolist())
-        return [b - a for a, b in zip([0] + cuts, cuts + [128])]
-    sets = []
-    for _ in range(int(rng.integers(1, 9))):
-        while True:
-            t = [table(6), table(5), table(4), table(3) if rng.random() < 0.6 else [128], table(3) if rng.random() < 0.6 else [128]]
-            n = 1
-            for r in t:
-                n *= 2 * len(r) - 1
-            if n <= 6000:
-                break
-        sets.append(t)
-    kw = dict(sets=sets, set_index=tuple(int(rng.integers(0, len(sets))) for _ in range(3)))
-    custom = rng.random() < 0.5
-    if custom:
-        kw["one_state"] = [0] + [int(min(255, max(1, i + rng.integers(1, 20) - (rng.random() < 0.1) * rng.integers(0, 10)))) for i in range(1, 256)]
-    return kw, custom
-
-
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RCGPU_SOAK_EXT", "24"))))
 def test_random_streams_of_the_general_syntax(built, seed):
-    """Random stream descriptions (table sets, set per plane group, transitions, coded initial states, version 1 headers) written by the oracle
-    -- whose writer and reader of this syntax are pinned by the 13 reference-blessed ext vectors -- and decoded by the device knowing only the
-    geometry: the payload bytes, with the full window and with samples forced down the careful path.  RCGPU_SOAK_EXT=N runs N seeds."""
-    import ctypes
-    rng = np.random.default_rng(9000 + seed)
-    pixfmt = [synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_LE, synth.PIX_RGBA16_LE, synth.PIX_Y16_BE, synth.PIX_RGB8, synth.PIX_RGB12_PACKED_BE][seed % 6]
-    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
-    w, h = int(rng.integers(40, 120)), int(rng.integers(24, 72))
-    if pixfmt == synth.PIX_RGB12_PACKED_BE:
-        w = 96                                               # (a geometry the reference's word merging handles, tests/golden/make_golden.py)
-    nh = int(rng.integers(1, 5)); nv = int(rng.integers(1, nh + 1))
-    kw, custom = _random_ext(rng, bits)
-    version = 1 if seed % 5 == 4 else 3
-    if version == 1:
-        kw = dict(version=1, sets=kw["sets"][:1], **({"one_state": kw["one_state"]} if custom else {}))
-        nh = nv = 1
-    e = ob.stream_ext(**kw)
-    if version == 3 and rng.random() < 0.5:                    # coded initial states for the sets in use: values from which state 0 is out of reach
-        lo, hi = (1, 255) if custom else (30, 226)
-        used = sorted(set(kw["set_index"][:(nc - 1 if nc != 1 else 1)]))
-        init = {i: bytes(rng.integers(lo, hi + 1, size=ob.lib().ffv1o_ext_context_count(ctypes.byref(e), i) * 32, dtype=np.int64).astype(np.uint8)) for i in used}
-        e = ob.stream_ext(initial_states=init, **kw)
-    ec = int(rng.integers(0, 2)) if version == 3 else 0
-    p = ob.with_ext(ob.Params(w, h, pixfmt, nh, nv, ec), e)
-    n = 3
-    pls = []
-    for i in range(n):
-        pl, line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, ["film", "noise", "flat"][(seed + i) % 3], seed=seed * 10 + i), pixfmt, True)
-        pls.append(pl)
-    rec = ob.config_record(p)
-    pks = [ob.encode_payload(p, pl, line_bytes) for pl in pls]
+    """Random stream descriptions (table sets, set per plane group, transitions, coded initial states, version 1 headers; tests/ext_streams.py)
+    written by the oracle and decoded by the device knowing only the geometry: the payload bytes, with the full window and with samples forced
+    down the careful path -- and by the REAL reference's decoder too where its driver was built (oracle/_ref/ref_ffv1_decode: the same bytes
+    from ffv1_frame::Process), so that every one of these streams is a stream the reference reads the same way.  RCGPU_SOAK_EXT=N runs N seeds."""
+    import ext_streams
+    import ref_decode
+    w, h, pixfmt, line_bytes, rec, pks, pls, flavor, flags, tight = ext_streams.random_stream(seed)
     code, back = ob.decode_stream(ob.Params(w, h, pixfmt), rec, pks[0], line_bytes)
     assert code == 0 and back == pls[0]
+    if ref_decode.available():
+        (frames,), lines = ref_decode.decode([(flavor, flags, w, h, rec, pks)])
+        assert ext_streams.reference_decodes_to(frames, tight), lines
     stream = api.Ffv1Stream(rec, pks[0])
-    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, max_batch=n, stream=stream)
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, max_batch=len(pks), stream=stream)
     for cap in (7, 1 + seed % 3):
         dec.debug_window(cap)
         assert dec.decode_host(pks, len(pls[0])) == pls, f"window {cap}"

@@ -57,6 +57,30 @@ def test_ffv1_ext_golden(built, v):
         assert code != 0 or back != payload
 
 
+def test_random_streams_of_the_general_syntax_are_what_the_reference_decodes(built):
+    """The oracle's WRITER of the general syntax, stream by stream against the real reference's decoder: 150 random descriptions (tests/
+    ext_streams.py: 1 to 8 random table sets, a set per plane group, transition tables, coded initial states, version 1 headers, six pixel
+    layouts, random geometry and slices), three pictures each, handed to ffv1_frame::OutOfBand / ::Process by oracle/ref_ffv1_decode.cpp --
+    every one decodes to its source without a complaint, and the oracle's own reader agrees.  (Where the driver was not built -- no
+    /root/reference -- the thirteen blessed vectors above carry the claim alone; the GPU test of the same streams checks the device.)"""
+    import ext_streams
+    import ref_decode
+    if not ref_decode.available():
+        pytest.skip("oracle/_ref/ref_ffv1_decode not built (needs /root/reference)")
+    n = int(os.environ.get("RCGPU_SOAK_EXT_CPU", "150"))
+    streams = [ext_streams.random_stream(seed) for seed in range(n)]
+    res, lines = ref_decode.decode([(fl, flags, w, h, rec, pks) for w, h, _, _, rec, pks, _, fl, flags, _ in streams])
+    for (w, h, pixfmt, line_bytes, rec, pks, pls, _, _, tight), frames, line in zip(streams, res, lines):
+        assert ext_streams.reference_decodes_to(frames, tight), line
+        code, back = ob.decode_stream(ob.Params(w, h, pixfmt), rec, pks[-1], line_bytes)
+        assert code == 0 and back == pls[-1], line
+    # and the reference's complaint when a stream is NOT what it says: a flipped bit in the middle of a frame
+    w, h, _, _, rec, pks, _, fl, flags, tight = streams[0]
+    bad = bytearray(pks[0]); bad[len(bad) // 3] ^= 0x10
+    (frames,), _ = ref_decode.decode([(fl, flags, w, h, rec, [bytes(bad)])])
+    assert frames[0][0] != 0 or frames[0][1][:len(tight[0])] != tight[0]
+
+
 @pytest.mark.parametrize("v", VEC["flac"], ids=lambda v: v["name"])
 def test_flac_golden(built, v):
     pcm = open(os.path.join(G, v["pcm"]), "rb").read()
