@@ -56,7 +56,8 @@ extern "C" int rcgpu_dpx_probe(const uint8_t* f, size_t size, rcgpu_image_info* 
     const uint32_t width = rd32(f + 772, be), height = rd32(f + 776, be);
     if (rd32(f + 780, be) != 0) return fail(7, "dpx: signed data");
     const uint8_t descriptor = f[800], bitdepth = f[803];
-    const uint16_t packing = rd16(f + 804, be), encoding = rd16(f + 806, be);
+    // (the reference keeps the packing field in an 8-bit enum, `Info.Packing = (packing)Get_X2()`, DPX.cpp:134,348: only its low byte counts)
+    const uint16_t packing = rd16(f + 804, be) & 0xFF, encoding = rd16(f + 806, be);
     if (encoding) return fail(8, "dpx: RLE encoding");
     uint32_t offset_to_data = rd32(f + 808, be);
     if (offset_to_data) {
@@ -65,7 +66,8 @@ extern "C" int rcgpu_dpx_probe(const uint8_t* f, size_t size, rcgpu_image_info* 
     } else
         offset_to_data = offset_to_image;                                                     // DPX.cpp:352-361
     if (rd32(f + 812, be) != 0) return fail(11, "dpx: end-of-line padding");
-    if (orientation != 0 && orientation != 2) return fail(12, "dpx: orientation %u is not supported", orientation);
+    // orientation: only 2 (bottom to top) means anything to the reference, and only for the flavors it flags VFlip (DPX.cpp:411-412,495); any
+    // other value is a field of the header like the others -- the picture is coded as its lines lie in the file
     if (!width || !height) return fail(13, "dpx: empty image");
 
     // flavor table, DPX.cpp:184-231 (Tested + Also rows reachable with the layouts this encoder implements)
@@ -357,7 +359,8 @@ extern "C" int rcgpu_wav_probe(const uint8_t* f, size_t size, rcgpu_audio_info* 
             if (out->bits_per_sample != 8 && out->bits_per_sample != 16 && out->bits_per_sample != 24 && out->bits_per_sample != 32)
                 return fail(14, "wav: %u-bit PCM is not supported", out->bits_per_sample);
             if (!out->block_align || !out->sample_rate) return fail(7, "wav: BlockAlign or SamplesPerSec is zero");
-            if (uint64_t(avg) * 8 != uint64_t(out->channels) * out->bits_per_sample * out->sample_rate) return fail(7, "wav: incoherent AvgBytesPerSec");
+            // (both sides in 32 bits, as the reference has them, WAV.cpp:476: a field whose top bits wrap away is coherent to it)
+            if (uint32_t(avg * 8u) != uint32_t(uint32_t(out->channels) * out->bits_per_sample * out->sample_rate)) return fail(7, "wav: incoherent AvgBytesPerSec");
             if (out->block_align * 8u != out->channels * out->bits_per_sample) return fail(7, "wav: incoherent BlockAlign");
             if (tag == 0xFFFE) {
                 if (csize != 40 || rd16(f + pos + 16, false) != 22) return fail(8, "wav: bad WAVE_FORMAT_EXTENSIBLE chunk");

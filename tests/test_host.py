@@ -541,6 +541,46 @@ def test_stream_parse_does_its_sums_in_the_reference_s_width(built):
         api.Ffv1Stream(_record_with_run(1 << 32, b"\0" * 64), bytes(16))
 
 
+def test_probes_agree_with_the_reference_s_parsers(built):
+    """2011 small files -- DPX of eight flavors, TIFF, EXR, WAV and seeded mutations of their headers (tests/golden/make_probe_golden.py makes them
+    again here) -- with what the REAL reference's wav, dpx, tiff and exr parsers said of each (oracle/ref_probe.cpp drives them in the CLI's
+    order; tests/golden/probe_cases.txt): whatever the reference would hand to its encoder the shim's probes take, from the same parser, as
+    the same flavor, with the same -slices.  (The other way round is not asked for: the shim is only ever called for what the reference
+    supports.)  One class apart: a TIFF whose Compression tag is not 1 -- the reference only tests that the tag is there (TIFF.cpp:465,557),
+    FFmpeg would try to decompress; the probe refuses -- as it refuses a TIFF whose strips are not the picture's size or whose line does not
+    fit 32 bits, which the reference's 32-bit sums let through on hostile headers."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_probe_golden", os.path.join(_G, "make_probe_golden.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    cases = mod.cases()
+    lines = open(os.path.join(_G, "probe_cases.txt")).read().splitlines()
+    blob = b"".join(struct.pack("<I", len(c)) + c for c in cases)
+    assert lines[0] == "sha256 " + hashlib.sha256(blob).hexdigest(), "the generator no longer makes the files the reference was shown: run tests/golden/make_probe_golden.py"
+    lines = lines[1:]
+    assert len(lines) == len(cases) > 2000
+    probes = {"wav": api.wav_probe, "dpx": api.dpx_probe, "tiff": api.tiff_probe, "exr": api.exr_probe}
+    supported = stricter = 0
+    for n, (data, line) in enumerate(zip(cases, lines)):
+        w = line.split()
+        if w[1] != "supported=1":
+            continue
+        supported += 1
+        try:
+            i = probes[w[0]](data)
+        except RuntimeError as ex:
+            # (what FFmpeg, whose place the shim takes, would not have encoded either)
+            assert w[0] == "tiff" and any(t in str(ex) for t in ("compressed content", "strip sizes do not match", "does not fit 32 bits")), (n, line, str(ex))
+            stricter += 1
+            continue
+        assert i.flavor.decode() == w[2][len("flavor="):] and getattr(i, "slices", 0) == int(w[3][len("slices="):]), (n, line, i.flavor, getattr(i, "slices", 0))
+        for other in ("wav", "dpx", "tiff", "exr"):                         # and no earlier parser of the CLI's order claims the file
+            if other == w[0]:
+                break
+            with pytest.raises(RuntimeError):
+                probes[other](data)
+    assert supported > 1400 and stricter <= 3
+
+
 _FNV0 = 0xcbf29ce484222325
 
 
