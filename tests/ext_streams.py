@@ -77,3 +77,62 @@ def reference_decodes_to(frames, tight):
     to 32 bits) -- its PARSER expects every line rounded up to 32 bits (DPX.cpp:476-482), which is what `payloads` are; `tight` is the same
     picture without that room.  Route C takes line_bytes from the reference's plane, so the device writes what the reference would have."""
     return len(frames) == len(tight) and all(v == 0 and len(got) - len(t) in (0, 1, 2, 3) and got[:len(t)] == t for (v, got), t in zip(frames, tight))
+
+
+_FLAVOR = {}
+
+
+def flavor_of(pixfmt):
+    """the reference's name of a pixel layout (the string its --info prints and its reversibility data carries), via the DPX probe"""
+    if pixfmt not in _FLAVOR:
+        bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+        _FLAVOR[pixfmt] = api.dpx_probe(synth.dpx_file(synth.components(96, 8, nc, bits, "flat", seed=1), pixfmt)).flavor.decode()
+    return _FLAVOR[pixfmt]
+
+
+def mixed_content_stream(seed):
+    """The pictures of tests/test_gpu_stages.py::test_random_geometries_mixed_content: flat patches, ramps and noise at random sizes, slice grids,
+    segment counts and range-coder mappings, three per seed, in twelve pixel layouts.  Returns a dict; `reference_takes_it` says whether the
+    real reference's decoder can be asked about this geometry: with several pixels to a block (the bit-packed flavors) its parser refuses
+    pictures whose slices would start inside a block (DPX.cpp:443-456), and its decoder, shown one all the same, writes out of bounds --
+    there the oracle and the device decoder stand alone."""
+    rng = np.random.default_rng(1000 + seed)
+    pixfmt = [synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGB8, synth.PIX_Y16_LE, synth.PIX_RGBA16_LE, synth.PIX_Y8,
+              synth.PIX_RGB12_PACKED_BE, synth.PIX_Y10_FILLEDA_BE, synth.PIX_RGBA10_FILLEDA_LE, synth.PIX_RGBA12_PACKED_BE, synth.PIX_Y12_PACKED_BE,
+              synth.PIX_RGB12_FILLEDA_LE][seed % 12]
+    bits, nc, bpp, _ = synth.PIX_INFO[pixfmt]
+    w, h = int(rng.integers(24, 200)), int(rng.integers(10, 120))
+    slices = [1, 4, 6, 9, 12][int(rng.integers(0, 5))]
+    nh, nv = api.slices_to_grid(slices)
+    if nh >= w or nv >= h:
+        nh = nv = 1
+    segments = [0, 1, 3, 7][int(rng.integers(0, 4))]
+    rc_span = [0, 1, 8, 9, 31, 64][int(rng.integers(0, 6))]      # range-coder mapping: automatic, whole slices, split into spans of N pieces
+    maxv = (1 << bits) - 1
+    payloads, tight = [], []
+    for f in range(3):
+        comp = np.zeros((h, w, nc), dtype=np.uint16)
+        for _ in range(12):                                   # random patches
+            y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
+            y1, x1 = int(rng.integers(y0, h)) + 1, int(rng.integers(x0, w)) + 1
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                comp[y0:y1, x0:x1] = rng.integers(0, maxv + 1, size=nc)
+            elif kind == 1:
+                ramp = (np.arange(x1 - x0)[None, :, None] * int(rng.integers(1, 4)) + np.arange(y1 - y0)[:, None, None] + int(rng.integers(0, maxv // 2))) & maxv
+                comp[y0:y1, x0:x1] = ramp
+            else:
+                comp[y0:y1, x0:x1] = rng.integers(0, maxv + 1, size=(y1 - y0, x1 - x0, nc))
+        pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
+        payloads.append(pl)
+        tight.append(synth.pack_payload(comp, pixfmt, False)[0])
+    takes = True
+    if bpp == 0:
+        takes = nh == 1
+        if takes:
+            try:
+                api.dpx_probe(synth.dpx_file(comp, pixfmt))
+            except RuntimeError:
+                takes = False
+    return dict(w=w, h=h, pixfmt=pixfmt, nh=nh, nv=nv, segments=segments, rc_span=rc_span, payloads=payloads, tight=tight, line_bytes=line_bytes,
+                flavor=flavor_of(pixfmt), reference_takes_it=takes)

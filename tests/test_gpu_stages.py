@@ -263,37 +263,13 @@ def test_bit_packed_flavors(built, pixfmt, flags, w, h, slices):
 def test_random_geometries_mixed_content(built, seed):
     """Stress for k_resolve's chunk pipeline: pictures made of flat patches (runs of zero residuals in one context), smooth ramps
     (many lanes per context -> rounds, forwarding between chunks) and noise, at random sizes / slice grids / segment counts, so that
-    slices end in partial chunks of every length."""
-    import torch
-    rng = np.random.default_rng(1000 + seed)
-    pixfmt = [synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGB8, synth.PIX_Y16_LE, synth.PIX_RGBA16_LE, synth.PIX_Y8,
-              synth.PIX_RGB12_PACKED_BE, synth.PIX_Y10_FILLEDA_BE, synth.PIX_RGBA10_FILLEDA_LE, synth.PIX_RGBA12_PACKED_BE, synth.PIX_Y12_PACKED_BE,
-              synth.PIX_RGB12_FILLEDA_LE][seed % 12]
-    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
-    w, h = int(rng.integers(24, 200)), int(rng.integers(10, 120))
-    slices = [1, 4, 6, 9, 12][int(rng.integers(0, 5))]
-    nh, nv = api.slices_to_grid(slices)
-    if nh >= w or nv >= h:
-        nh = nv = 1
-    segments = [0, 1, 3, 7][int(rng.integers(0, 4))]
-    rc_span = [0, 1, 8, 9, 31, 64][int(rng.integers(0, 6))]      # range-coder mapping: automatic, whole slices, split into spans of N pieces
-    maxv = (1 << bits) - 1
-    payloads = []
-    for f in range(3):
-        comp = np.zeros((h, w, nc), dtype=np.uint16)
-        for _ in range(12):                                   # random patches
-            y0, x0 = int(rng.integers(0, h)), int(rng.integers(0, w))
-            y1, x1 = int(rng.integers(y0, h)) + 1, int(rng.integers(x0, w)) + 1
-            kind = int(rng.integers(0, 3))
-            if kind == 0:
-                comp[y0:y1, x0:x1] = rng.integers(0, maxv + 1, size=nc)
-            elif kind == 1:
-                ramp = (np.arange(x1 - x0)[None, :, None] * int(rng.integers(1, 4)) + np.arange(y1 - y0)[:, None, None] + int(rng.integers(0, maxv // 2))) & maxv
-                comp[y0:y1, x0:x1] = ramp
-            else:
-                comp[y0:y1, x0:x1] = rng.integers(0, maxv + 1, size=(y1 - y0, x1 - x0, nc))
-        pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
-        payloads.append(pl)
+    slices end in partial chunks of every length.  The packets are the oracle's byte for byte, decode to the pictures in the device decoder
+    -- and in the REAL reference's (oracle/_ref/ref_ffv1_decode: ffv1_frame::Process itself, where its driver was built and the geometry is
+    one its parser admits)."""
+    import ext_streams
+    import ref_decode
+    m = ext_streams.mixed_content_stream(seed)
+    w, h, pixfmt, nh, nv, segments, rc_span, payloads, line_bytes = m["w"], m["h"], m["pixfmt"], m["nh"], m["nv"], m["segments"], m["rc_span"], m["payloads"], m["line_bytes"]
     for ctx in (1, 2):
         p = ob.Params(w, h, pixfmt, nh, nv, 1, ctx)
         enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=3, segments=segments, rc_span=rc_span)
@@ -301,6 +277,9 @@ def test_random_geometries_mixed_content(built, seed):
         for f in range(3):
             assert packets[f] == ob.encode_payload(p, payloads[f], line_bytes), f"context model {ctx}, frame {f}, {w}x{h} {nh}x{nv} segments {segments} rc_span {rc_span}"
         enc.close()
+        if ref_decode.available() and m["reference_takes_it"]:                               # the REAL reference's decoder on the device's packets
+            (frames,), lines = ref_decode.decode([(m["flavor"], 0, w, h, ob.config_record(p), packets)])
+            assert ext_streams.reference_decodes_to(frames, m["tight"]), (lines, f"context model {ctx}, {w}x{h} {nh}x{nv}")
         dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=3)        # and back through the device decoder
         assert dec.decode_host(packets, len(payloads[0])) == [bytes(x) for x in payloads], f"decoder, context model {ctx}, {w}x{h} {nh}x{nv}"
         dec.close()

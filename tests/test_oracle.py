@@ -81,6 +81,30 @@ def test_random_streams_of_the_general_syntax_are_what_the_reference_decodes(bui
     assert frames[0][0] != 0 or frames[0][1][:len(tight[0])] != tight[0]
 
 
+def test_default_streams_of_random_geometry_are_what_the_reference_decodes(built):
+    """The oracle's ENCODER -- whose bytes the device encoder must equal -- against the real reference's decoder, beyond the 33 blessed vectors:
+    the pictures of the GPU soak (tests/ext_streams.py::mixed_content_stream: flat patches, ramps, noise; random sizes and slice grids; twelve
+    pixel layouts), both context models, handed to ffv1_frame::OutOfBand / ::Process by oracle/ref_ffv1_decode.cpp: every frame decodes to
+    its picture without a complaint."""
+    import ext_streams
+    import ref_decode
+    if not ref_decode.available():
+        pytest.skip("oracle/_ref/ref_ffv1_decode not built (needs /root/reference)")
+    cases, want = [], []
+    for seed in range(int(os.environ.get("RCGPU_SOAK_SEEDS_CPU", "72"))):
+        m = ext_streams.mixed_content_stream(seed)
+        if not m["reference_takes_it"]:
+            continue
+        for ctx in (1, 2):
+            p = ob.Params(m["w"], m["h"], m["pixfmt"], m["nh"], m["nv"], 1, ctx)
+            cases.append((m["flavor"], 0, m["w"], m["h"], ob.config_record(p), [ob.encode_payload(p, pl, m["line_bytes"]) for pl in m["payloads"]]))
+            want.append(m["tight"])
+    assert len(cases) >= 80
+    res, lines = ref_decode.decode(cases)
+    for frames, tight, line in zip(res, want, lines):
+        assert ext_streams.reference_decodes_to(frames, tight), line
+
+
 @pytest.mark.parametrize("v", VEC["flac"], ids=lambda v: v["name"])
 def test_flac_golden(built, v):
     pcm = open(os.path.join(G, v["pcm"]), "rb").read()
