@@ -136,3 +136,34 @@ def mixed_content_stream(seed):
                 takes = False
     return dict(w=w, h=h, pixfmt=pixfmt, nh=nh, nv=nv, segments=segments, rc_span=rc_span, payloads=payloads, tight=tight, line_bytes=line_bytes,
                 flavor=flavor_of(pixfmt), reference_takes_it=takes)
+
+
+def flac_signal(seed):
+    """(channels, bits, rate, samples, WAV-style PCM bytes) of tests/test_gpu_flac.py's random signals: tones + dither at random levels, steps,
+    bursts of full-scale noise, silence; now and then a correlated stereo pair."""
+    rng = np.random.default_rng(4000 + seed)
+    ch = int([1, 2, 2, 4, 6, 8][int(rng.integers(0, 6))]); bits = int([8, 16, 16, 24, 24][int(rng.integers(0, 5))]); rate = int([44100, 48000, 96000][int(rng.integers(0, 3))])
+    n = int(rng.integers(1, 3 * 4608 + 50))
+    full = (1 << (bits - 1)) - 1
+    t = np.arange(n) / rate
+    pcm_i = np.zeros((n, ch), dtype=np.int64)
+    for c in range(ch):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            sig = np.zeros(n)
+        elif kind == 1:
+            sig = rng.uniform(0.001, 1.0) * np.sin(2 * np.pi * rng.uniform(20, 15000) * t + rng.uniform(0, 6)) + rng.uniform(0, 0.05) * (rng.random(n) - 0.5)
+        elif kind == 2:
+            sig = rng.uniform(-1, 1, size=n) * rng.uniform(0.0, 1.0)
+        elif kind == 3:
+            sig = np.repeat(rng.uniform(-1, 1, size=n // 97 + 1), 97)[:n]                     # steps
+        else:
+            sig = 0.3 * np.sin(2 * np.pi * 440 * t); a = int(rng.integers(0, n)); sig[a:a + int(rng.integers(1, 600))] = rng.uniform(-1, 1)
+        pcm_i[:, c] = np.clip(np.round(sig * full), -full - 1, full)
+    if ch == 2 and seed % 2:           # a correlated pair: the stereo assignments (left/side, side/right, mid/side) get their turn
+        w = rng.uniform(0.0, 0.2)
+        pcm_i[:, 1] = np.clip(pcm_i[:, 0] * rng.choice([1.0, -1.0, 0.5]) + np.round(w * pcm_i[:, 1]), -full - 1, full)
+    wav = synth.wav_file(pcm_i.astype(np.int32), bits, rate)
+    info = api.wav_probe(wav)
+    pcm = wav[info.data_offset:info.data_offset + info.data_size]
+    return ch, bits, rate, n, pcm

@@ -38,3 +38,32 @@ def decode(cases):
             o += 8 + n
         res.append(frames)
     return res, lines
+
+
+FLAC_EXE = os.path.join(ROOT, "oracle", "_ref", "ref_flac_decode")
+
+
+def flac_available() -> bool:
+    return os.path.exists(FLAC_EXE)
+
+
+def flac_decode(cases):
+    """cases: [(bits of the WAV, CodecPrivate, [FLAC frames])] -> [(complaints, PCM bytes)]: the reference's own FLAC wrapper and the libFLAC
+    it ships (oracle/ref_flac_decode.cpp)."""
+    blob = bytearray()
+    for bits, cp, frames in cases:
+        blob += struct.pack("<II", bits, len(cp)) + cp + struct.pack("<I", len(frames))
+        for fr in frames:
+            blob += struct.pack("<I", len(fr)) + fr
+    with tempfile.TemporaryDirectory() as t:
+        a, b = os.path.join(t, "cases.bin"), os.path.join(t, "out.bin")
+        open(a, "wb").write(blob)
+        r = subprocess.run([FLAC_EXE, a, b], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+        out = open(b, "rb").read()
+    res, o = [], 0
+    for _ in cases:
+        v, n = struct.unpack_from("<II", out, o)
+        res.append((v, out[o + 8:o + 8 + n]))
+        o += 8 + n
+    return res

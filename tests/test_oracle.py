@@ -105,6 +105,23 @@ def test_default_streams_of_random_geometry_are_what_the_reference_decodes(built
         assert ext_streams.reference_decodes_to(frames, tight), line
 
 
+def test_flac_of_random_signals_is_what_the_reference_decodes(built):
+    """The oracle's FLAC ENCODER -- whose frames the device encoder must equal -- against the reference's own FLAC path (its wrapper around the
+    libFLAC it ships, fed CodecPrivate and blocks the way track_info feeds them; oracle/ref_flac_decode.cpp), beyond the 7 blessed streams:
+    the random signals of the GPU soak (tests/ext_streams.py::flac_signal: 1 to 8 channels, 8 / 16 / 24 bit, three rates, 1 to 13 874
+    samples) decode to their PCM bytes without a complaint."""
+    import ext_streams
+    import ref_decode
+    if not ref_decode.flac_available():
+        pytest.skip("oracle/_ref/ref_flac_decode not built (needs /root/reference)")
+    cases, want = [], []
+    for seed in range(int(os.environ.get("RCGPU_SOAK_FLAC_CPU", "40"))):
+        ch, bits, rate, n, pcm = ext_streams.flac_signal(seed)
+        frames, cp = ob.flac_encode(ch, rate, bits, pcm, 0, 8)
+        cases.append((bits, cp, frames)); want.append(pcm)
+    assert ref_decode.flac_decode(cases) == [(0, p) for p in want]
+
+
 @pytest.mark.parametrize("v", VEC["flac"], ids=lambda v: v["name"])
 def test_flac_golden(built, v):
     pcm = open(os.path.join(G, v["pcm"]), "rb").read()
