@@ -379,6 +379,59 @@ def test_corrupted_packets_never_hang_or_fault(built, name):
     dec.close()
 
 
+@pytest.mark.parametrize("pixfmt,ctx", [(synth.PIX_RGB16_BE, 1), (synth.PIX_RGB10_FILLEDA_BE, 1), (synth.PIX_RGBA16_LE, 2), (synth.PIX_Y16_BE, 1), (synth.PIX_RGB8, 1)])
+def test_damaged_streams_without_slice_crc_decode_like_the_reference(built, pixfmt, ctx):
+    """Without slice CRCs (ec = 0) most damage is invisible to a decoder: it decodes SOMETHING.  Whatever the device decodes without a
+    complaint must be what the REAL reference's decoder makes of the same bytes (oracle/_ref/ref_ffv1_decode: ffv1_frame::Process) -- the
+    byte compare with the source file that follows in --check then says the same in both.  Flipped bytes, truncations and garbage tails;
+    RCGPU_SOAK_CORRUPT scales the number of variants."""
+    import ext_streams
+    import ref_decode
+    if not ref_decode.available():
+        pytest.skip("oracle/_ref/ref_ffv1_decode not built (needs /root/reference)")
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    w, h, nh, nv = 64, 48, 2, 2
+    comp = synth.components(w, h, nc, bits, "film", seed=77)
+    payload, line_bytes = synth.pack_payload(comp, pixfmt, True)
+    tight = synth.pack_payload(comp, pixfmt, False)[0]
+    p = ob.Params(w, h, pixfmt, nh, nv, 0, ctx)
+    good, rec = ob.encode_payload(p, payload, line_bytes), ob.config_record(p)
+    rng = np.random.default_rng(6 + pixfmt)
+    variants = [good]
+    for k in range(48 * int(os.environ.get("RCGPU_SOAK_CORRUPT", "1"))):
+        b = bytearray(good)
+        kind = k % 4
+        if kind in (0, 1):
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(0, len(b) - 3))] ^= int(rng.integers(1, 256))          # (the last three bytes: the last slice's size)
+        elif kind == 2:
+            at = int(rng.integers(len(b) // 2, len(b) - 3))
+            b[at:-3] = bytes(rng.integers(0, 256, size=len(b) - 3 - at, dtype=np.uint8))
+        else:
+            b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+        variants.append(bytes(b))
+    res, lines = ref_decode.decode([(ext_streams.flavor_of(pixfmt), 0, w, h, rec, [pk]) for pk in variants])       # (a decoder each: its first complaint stays with it)
+    frames = [r[0] for r in res]
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 0, ctx, max_batch=1)
+    quiet = same = 0
+    for i, pk in enumerate(variants):
+        try:
+            got = dec.decode_host([pk], len(payload))[0]
+        except RuntimeError:
+            continue                                             # a complaint: the frame is the reference's own decoder's (INTEGRATION.md, route C)
+        quiet += 1
+        verdict, ref_bytes = frames[i]
+        # the device's lines carry the DPX room at their end, the reference's plane does not (ext_streams.reference_decodes_to): line by line
+        tl = len(tight) // h
+        got_tight = b"".join(got[y * line_bytes:y * line_bytes + tl] for y in range(h))
+        assert verdict == 0 and ref_bytes[:len(tight)] == got_tight, f"variant {i}: the device decoded it without a complaint, the reference {'complains' if verdict else 'decodes other bytes'}"
+        same += 1
+    # (the reference's end-of-slice tests -- bytes left over, bytes missing: FFV1-SLICE-JUNK, FFV1-SLICE-SliceContent -- catch nearly all damage even
+    # without a CRC, and so do the device's: the quiet set is small, the undamaged packet always in it)
+    assert quiet >= 1 and same == quiet and frames[0][0] == 0 and frames[0][1][:len(tight)] == tight
+    dec.close()
+
+
 @pytest.mark.parametrize("name", ["dpx_rgb16be_64x48", "dpx_rgb12packed_56x38", "dpx_rgb10be_coder2_50x38", "tiff_rgba16le_40x30"])
 def test_decode_host_from_codec_private(built, name):
     """The caller of the --check half holds Matroska blocks and a CodecPrivate in host memory (ffv1_wrapper::Process/OutOfBand,
