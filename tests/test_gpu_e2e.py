@@ -456,6 +456,43 @@ def test_linked_reference_checks_in_batches(built, linkedbin, refbin, tmp_path, 
     assert "f_000006" in (r.stdout + r.stderr), r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("damaged", [1, 4])
+def test_linked_reference_lists_the_files_the_reference_lists(built, linkedbin, refbin, tmp_path, monkeypatch, damaged):
+    """A complaint about a slice stays with the reference's decoder for the rest of the track (parameters::error_message is set once,
+    ffv1_frame::Process ends in `return P.Error() ? true : false`, FFV1_Frame.cpp:227): after one damaged frame the unmodified reference
+    lists EVERY later frame of the track under "undecodable frame", though their bytes compare equal.  What the user reads from the linked
+    binary must be that list, file for file -- and the list of files that differ from their sources, which is the damaged one alone."""
+    work = str(tmp_path)
+    n = 8
+    make_package(work, 96, 64, synth.PIX_RGB16_BE, n, "film")
+    monkeypatch.setenv("RCGPU_CHECK_BATCH", "3")
+    r = run([linkedbin, "--no-check-padding", "--check", "--hash", "-y", "pkg"], work, timeout=60)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    import mkv_validator
+    blocks = []
+    mkv_validator.validate(os.path.join(work, "pkg.mkv"), on_block=lambda trk, t, a, b: blocks.append((trk, a, b)))
+    video = [(a, b) for trk, a, b in blocks if trk == 1]
+    data = bytearray(open(os.path.join(work, "pkg.mkv"), "rb").read())
+    a, b = video[damaged]
+    data[(a + b) // 2] ^= 0x04
+    open(os.path.join(work, "pkg.mkv"), "wb").write(data)
+
+    def lists(r):
+        out, cur = {}, None
+        for ln in (r.stdout + r.stderr).replace("\r", "\n").split("\n"):
+            if ln.startswith("Error:"):
+                cur = ln.strip(); out[cur] = []
+            elif cur and ln.startswith("       "):
+                out[cur].append(ln.strip())
+            elif ln.strip():
+                cur = None
+        return r.returncode != 0, out
+    want = lists(run([refbin, "--check", "pkg.mkv"], work, timeout=120))
+    got = lists(run([linkedbin, "--check", "pkg.mkv"], work, timeout=120))
+    assert want[0] and got == want, (got, want)
+    assert any(len(v) == n - damaged for v in want[1].values()) and any(v == ["pkg/img/f_%06d.dpx" % damaged] for v in want[1].values()), want
+
+
 def test_linked_reference_decodes_one_batch_ahead(built, linkedbin, refbin, tmp_path, monkeypatch):
     """Route C one batch ahead: once the first frame has told the batch size, the demuxer announces the batch after the current one too and
     ffv1_frame::Process has the decoder start on it (rcgpu_ffv1_decoder_decode_keep_hint_file, by the blocks' places in the file: frames of
