@@ -8,6 +8,7 @@ import shutil
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from rawcooked_amd import synth
@@ -491,6 +492,70 @@ def test_linked_reference_lists_the_files_the_reference_lists(built, linkedbin, 
     got = lists(run([linkedbin, "--check", "pkg.mkv"], work, timeout=120))
     assert want[0] and got == want, (got, want)
     assert any(len(v) == n - damaged for v in want[1].values()) and any(v == ["pkg/img/f_%06d.dpx" % damaged] for v in want[1].values()), want
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RCGPU_SOAK_DAMAGE", "3"))))      # soak: RCGPU_SOAK_DAMAGE=40
+def test_linked_reference_says_what_the_reference_says_about_damaged_files(built, linkedbin, refbin, tmp_path, monkeypatch, seed):
+    """Route C under damage of every kind, held to the unmodified reference: a Matroska file with 10 video frames and audio, then eight
+    damaged copies per seed -- a bit flipped inside a frame, in a frame's last bytes (slice sizes, CRCs), in the bytes in front of a frame
+    (EBML heads: the look-ahead of oracle/route_c_matroska_cpp.patch walks them), anywhere in the file, a run of zeros inside a frame, two
+    damaged frames -- and `--check` by both binaries: the same exit code and the same files under the same complaints.  (A copy the
+    unmodified reference itself does not survive -- killed by a signal or out of time -- is not held against anybody.)"""
+    work = str(tmp_path)
+    n = 10
+    make_package(work, 96, 64, [synth.PIX_RGB16_BE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGBA16_LE][seed % 3], n, "film", audio=(2, 16, 48000, 20000))
+    monkeypatch.setenv("RCGPU_CHECK_BATCH", ["3", "4", "16"][seed % 3])
+    r = run([linkedbin, "--no-check-padding", "--check", "--hash", "-y", "pkg"], work, timeout=60)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    import mkv_validator
+    blocks = []
+    mkv_validator.validate(os.path.join(work, "pkg.mkv"), on_block=lambda trk, t, a, b: blocks.append((trk, a, b)))
+    video = [(a, b) for trk, a, b in blocks if trk == 1]
+    good = open(os.path.join(work, "pkg.mkv"), "rb").read()
+    rng = np.random.default_rng(700 + seed)
+
+    def lists(r):
+        out, cur = {}, None
+        for ln in (r.stdout + r.stderr).replace("\r", "\n").split("\n"):
+            if ln.startswith("Error:") or ln.startswith("Warning:"):
+                cur = ln.strip(); out.setdefault(cur, [])
+            elif cur and ln.startswith("       "):
+                out[cur].append(ln.strip())
+            elif ln.strip():
+                cur = None
+        return r.returncode, OK_LINE in r.stdout, out
+    compared = 0
+    for kind in range(8):
+        d = bytearray(good)
+        a, b = video[int(rng.integers(0, n))]
+        if kind == 0:
+            d[int(rng.integers(a, b))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            d[b - 1 - int(rng.integers(0, 8))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 2:
+            d[a - 1 - int(rng.integers(0, 12))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 3:
+            d[int(rng.integers(0, len(d)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 4:
+            at = int(rng.integers(a, b - 16)); d[at:at + 16] = bytes(16)
+        elif kind == 5:
+            a2, b2 = video[int(rng.integers(0, n))]
+            d[(a + b) // 2] ^= 4; d[(a2 + b2) // 3] ^= 16
+        elif kind == 6:
+            d[a + int(rng.integers(0, 4))] ^= 1 << int(rng.integers(0, 8))          # the key frame bit and the first slice header
+        else:
+            d[int(rng.integers(video[0][0] - 200, video[0][0]))] ^= 1 << int(rng.integers(0, 8))      # CodecPrivate, track entries, the first cluster's head
+        open(os.path.join(work, "pkg.mkv"), "wb").write(d)
+        try:
+            ref = run([refbin, "--check", "pkg.mkv"], work, timeout=60)
+        except subprocess.TimeoutExpired:
+            continue
+        if ref.returncode < 0:
+            continue
+        got = run([linkedbin, "--check", "pkg.mkv"], work, timeout=120)
+        assert lists(got) == lists(ref), (seed, kind, lists(got), lists(ref), got.stderr[-300:])
+        compared += 1
+    assert compared >= 5
 
 
 def test_linked_reference_decodes_one_batch_ahead(built, linkedbin, refbin, tmp_path, monkeypatch):
