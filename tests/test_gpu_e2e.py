@@ -494,7 +494,7 @@ def test_linked_reference_lists_the_files_the_reference_lists(built, linkedbin, 
     assert any(len(v) == n - damaged for v in want[1].values()) and any(v == ["pkg/img/f_%06d.dpx" % damaged] for v in want[1].values()), want
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RCGPU_SOAK_DAMAGE", "3"))))      # soak: RCGPU_SOAK_DAMAGE=40
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RCGPU_SOAK_DAMAGE_FROM", "0")), int(os.environ.get("RCGPU_SOAK_DAMAGE", "1"))))      # soak: RCGPU_SOAK_DAMAGE=40 (50 s a seed)
 def test_linked_reference_says_what_the_reference_says_about_damaged_files(built, linkedbin, refbin, tmp_path, monkeypatch, seed):
     """Route C under damage of every kind, held to the unmodified reference: a Matroska file with 10 video frames and audio, then eight
     damaged copies per seed -- a bit flipped inside a frame, in a frame's last bytes (slice sizes, CRCs), in the bytes in front of a frame
