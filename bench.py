@@ -444,9 +444,13 @@ def traffic_json():
         d, stale = {}, {}
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            # ... or, the sources having changed, the sha256 of the library's DEVICE code (rawcooked_amd/devcode.py): host code edited inside a
+            # .hip file leaves the kernels what they were
+            from rawcooked_amd import devcode
+            same_kernels = bool(d.get("device_code_sha256")) and devcode.fatbin_sha256(os.path.join(ROOT, "rawcooked_amd", "librcgpu.so")) == d["device_code_sha256"]
             for name, want in d.get("sources", {}).items():
                 got = hashlib.sha256(open(os.path.join(ROOT, name), "rb").read()).hexdigest()
-                stale[os.path.basename(name)] = got != want
+                stale[os.path.basename(name)] = got != want and not same_kernels
         except Exception:
             d = {}
         _TRAFFIC = (d, stale)

@@ -86,7 +86,10 @@ def main():
                                                 "launches_per_step": round(f["k_resolve"][0] / steps),
                                                 "method": f"profiles/{tag}_{cfgtag}_pmc_*.csv, as the 4K / 64-slice passes"}}
     d["sources"] = {s: hashlib.sha256(open(os.path.join(ROOT, s), "rb").read()).hexdigest() for s in SOURCES}
-    d["measured_on"] = f"{tag}: the tree whose kernel sources have the sha256 under `sources`"
+    sys.path.insert(0, ROOT)
+    from rawcooked_amd import devcode
+    d["device_code_sha256"] = devcode.fatbin_sha256(os.path.join(ROOT, "rawcooked_amd", "librcgpu.so"))      # the kernels themselves, as built from those sources
+    d["measured_on"] = f"{tag}: the tree whose kernel sources have the sha256 under `sources` (built: device code `device_code_sha256`)"
     json.dump(d, open(tj, "w"), indent=1)
     for k in ("k_resolve", "k_rangecode", "k_model", "k_dec_slices"):
         if k in d:
