@@ -553,7 +553,10 @@ def test_linked_reference_says_what_the_reference_says_about_damaged_files(built
         if ref.returncode < 0:
             continue
         got = run([linkedbin, "--check", "pkg.mkv"], work, timeout=120)
-        assert lists(got) == lists(ref), (seed, kind, lists(got), lists(ref), got.stderr[-300:])
+        if lists(got) != lists(ref) and os.environ.get("RCGPU_DAMAGE_DUMP"):            # (a box without a debugger: what both said, and the damaged file)
+            open(os.environ["RCGPU_DAMAGE_DUMP"] + "_%d_%d.txt" % (seed, kind), "w").write("LINKED rc %d\n%s\n%s\nREFERENCE rc %d\n%s\n%s\n" % (got.returncode, got.stdout, got.stderr, ref.returncode, ref.stdout, ref.stderr))
+            open(os.environ["RCGPU_DAMAGE_DUMP"] + "_%d_%d.diff" % (seed, kind), "w").write(repr([(i, good[i], d[i]) for i in range(len(d)) if d[i] != good[i]]) + " blocks " + repr(video))
+        assert lists(got) == lists(ref), (seed, kind, lists(got), lists(ref), got.stderr[-4000:])
         compared += 1
     assert compared >= 5
 
