@@ -9,6 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "oracle", "_ref", "ref_ffv1_decode")
 
 
+def clean_env():
+    """the environment for a driver: this process's without LD_PRELOAD (tools/asan_cpu.sh preloads the sanitizer runtime into the suite; the
+    drivers are the reference's code, bound their own address space, and are not what is being sanitized)"""
+    return {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")}
+
+
 def available() -> bool:
     return os.path.exists(EXE)
 
@@ -25,7 +31,7 @@ def decode(cases):
     with tempfile.TemporaryDirectory() as t:
         a, b = os.path.join(t, "cases.bin"), os.path.join(t, "out.bin")
         open(a, "wb").write(blob)
-        r = subprocess.run([EXE, a, b], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([EXE, a, b], capture_output=True, text=True, timeout=600, env=clean_env())
         assert r.returncode == 0, (r.returncode, r.stderr[-400:])
         out = open(b, "rb").read()
     lines, res, o = r.stdout.splitlines(), [], 0
@@ -58,7 +64,7 @@ def flac_decode(cases):
     with tempfile.TemporaryDirectory() as t:
         a, b = os.path.join(t, "cases.bin"), os.path.join(t, "out.bin")
         open(a, "wb").write(blob)
-        r = subprocess.run([FLAC_EXE, a, b], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([FLAC_EXE, a, b], capture_output=True, text=True, timeout=600, env=clean_env())
         assert r.returncode == 0, (r.returncode, r.stderr[-400:])
         out = open(b, "rb").read()
     res, o = [], 0

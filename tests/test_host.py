@@ -706,7 +706,8 @@ def test_stream_parse_agrees_with_the_reference_s_reader_on_fresh_mutations(buil
         cases.append((rw.sealed(bytes(r[:-4])) if len(r) > 4 else bytes(r), bytes(q)))
     f = tmp_path / "cases.bin"
     f.write_bytes(b"".join(struct.pack("<II", len(r), len(p)) + r + p for r, p in cases))
-    lines = subprocess.run([exe, str(f)], capture_output=True, text=True, check=True).stdout.splitlines()
+    import ref_decode
+    lines = subprocess.run([exe, str(f)], capture_output=True, text=True, check=True, env=ref_decode.clean_env()).stdout.splitlines()
     assert len(lines) == len(cases), f"seed {seed}"
     try:
         _hold_to_the_reference(cases, lines)
