@@ -105,6 +105,46 @@ def test_default_streams_of_random_geometry_are_what_the_reference_decodes(built
         assert ext_streams.reference_decodes_to(frames, tight), line
 
 
+def test_verdicts_on_damaged_frames_are_the_reference_s(built):
+    """The oracle's decoder is what the GPU tests hold the device's complaints to ("flagged, or the source's bytes").  Here it is held to the
+    real reference's decoder itself on damaged frames -- one flipped bit anywhere in a frame, a third of them in its last 40 bytes (slice
+    sizes, CRCs), with and without slice CRCs, four pixel layouts: the same frames draw a complaint from both, and the frames both decode
+    quietly decode to the same bytes (oracle/_ref/ref_ffv1_decode, a decoder per frame: its first complaint stays with it)."""
+    import ext_streams
+    import ref_decode
+    from rawcooked_amd import synth
+    if not ref_decode.available():
+        pytest.skip("oracle/_ref/ref_ffv1_decode not built (needs /root/reference)")
+    quiet = loud = 0
+    for pixfmt, ctx, ec in [(synth.PIX_RGB16_BE, 1, 0), (synth.PIX_RGB16_BE, 1, 1), (synth.PIX_RGB10_FILLEDA_BE, 1, 0), (synth.PIX_Y16_BE, 2, 0), (synth.PIX_RGBA16_LE, 1, 1)]:
+        bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+        w, h, nh, nv = 48, 32, 2, 2
+        comp = synth.components(w, h, nc, bits, "film", seed=9)
+        payload, line_bytes = synth.pack_payload(comp, pixfmt, True)
+        tight = synth.pack_payload(comp, pixfmt, False)[0]
+        tl = len(tight) // h
+        p = ob.Params(w, h, pixfmt, nh, nv, ec, ctx)
+        good, rec = ob.encode_payload(p, payload, line_bytes), ob.config_record(p)
+        rng = np.random.default_rng(3)
+        variants = []
+        for k in range(int(os.environ.get("RCGPU_SOAK_VERDICTS", "120"))):
+            b = bytearray(good)
+            at = int(rng.integers(0, len(b))) if k % 3 else len(b) - 1 - int(rng.integers(0, 40))
+            b[at] ^= 1 << int(rng.integers(0, 8))
+            variants.append(bytes(b))
+        res, _ = ref_decode.decode([(ext_streams.flavor_of(pixfmt), 0, w, h, rec, [pk]) for pk in variants])
+        for (frame,), pk in zip(res, variants):
+            verdict, ref_bytes = frame
+            code, back = ob.decode_stream(ob.Params(w, h, pixfmt), rec, pk, line_bytes)
+            assert (verdict == 0) == (code == 0), (pixfmt, ec, verdict, code)
+            if code == 0:
+                assert ref_bytes[:len(tight)] == b"".join(back[y * line_bytes:y * line_bytes + tl] for y in range(h))
+                quiet += 1
+            else:
+                loud += 1
+    assert loud > 500 and quiet >= 1
+
+
 def test_flac_of_random_signals_is_what_the_reference_decodes(built):
     """The oracle's FLAC ENCODER -- whose frames the device encoder must equal -- against the reference's own FLAC path (its wrapper around the
     libFLAC it ships, fed CodecPrivate and blocks the way track_info feeds them; oracle/ref_flac_decode.cpp), beyond the 7 blessed streams:
