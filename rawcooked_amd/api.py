@@ -201,10 +201,26 @@ def lib() -> C.CDLL:
         # the library's per-device hash streams are CU-masked; they are given back while the HIP runtime is certainly still there, not in the
         # middle of the interpreter's and the runtime's teardown (profiles/r05_rocprof_cumask.txt: what a profiler makes of the other order)
         import atexit
-        atexit.register(L.rcgpu_release_device_streams)
+        atexit.register(_at_exit)
         L.rcgpu_ffv1_decoder_debug_states_offset.restype, L.rcgpu_ffv1_decoder_debug_states_offset.argtypes = C.c_int, [_VP, C.c_uint64]
         _lib = L
     return _lib
+
+
+_live_decoders = None
+
+
+def _at_exit():
+    """Before the interpreter and the HIP runtime go: decoders still alive are closed (one may have a batch decoded AHEAD on a thread of the
+    library's -- a thread inside the runtime while it is torn down is a segmentation fault at exit, as route C's damage soak showed for the
+    linked binary), then the library's CU-masked streams are given back."""
+    for d in list(_live_decoders or ()):
+        try:
+            d.close()
+        except Exception:
+            pass
+    if _lib is not None:
+        _lib.rcgpu_release_device_streams()
 
 
 def last_error() -> str:
@@ -472,6 +488,11 @@ class Ffv1Decoder:
             _check(lib().rcgpu_ffv1_decoder_create_for_stream(C.byref(self.cfg), stream.h, C.byref(self.h)), "rcgpu_ffv1_decoder_create_for_stream")
         else:
             _check(lib().rcgpu_ffv1_decoder_create(C.byref(self.cfg), C.byref(self.h)), "rcgpu_ffv1_decoder_create")
+        global _live_decoders
+        if _live_decoders is None:
+            import weakref
+            _live_decoders = weakref.WeakSet()
+        _live_decoders.add(self)
 
     def close(self):
         if self.h:
