@@ -145,6 +145,84 @@ def test_verdicts_on_damaged_frames_are_the_reference_s(built):
     assert loud > 500 and quiet >= 1
 
 
+def _muxed_package_checks(refbin, name, w, h, pixfmt, n, fps, audio=None, attach=(), kind="film"):
+    """A package (DPX sequence, optional WAV, optional attachments) analysed by the real reference (`-d`: its reversibility data, its -slices),
+    encoded by the oracle, muxed by the PRODUCT's Matroska writer (api.MkvMuxer, host code: no device), checked by the real reference."""
+    import shutil
+    import subprocess
+    import tempfile
+    from rawcooked_amd import api, synth
+
+    def run(cmd, cwd):
+        return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=600)
+    work = tempfile.mkdtemp()
+    try:
+        os.makedirs(work + "/pkg/img")
+        bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+        comps = [synth.components(w, h, nc, bits, kind, seed=s) for s in range(min(n, 7))]
+        files = []
+        for i in range(n):
+            fn = work + "/pkg/img/f_%06d.dpx" % i
+            open(fn, "wb").write(synth.dpx_file(comps[i % len(comps)], pixfmt, frame_index=i))
+            files.append(fn)
+        if audio:
+            ch, abits, rate, ns = audio
+            wav = synth.wav_file(np.random.default_rng(5).integers(-2000, 2000, size=(ns, ch)).astype(np.int32), abits, rate)
+            open(work + "/pkg/snd.wav", "wb").write(wav)
+        for an, ad in attach:
+            open(work + "/pkg/" + an, "wb").write(ad)
+        r = run([refbin, "--hash", "--no-check-padding", "--check", "-d", "-y", "-framerate", "%d/%d" % fps if fps[1] != 1 else str(fps[0]), "pkg"], work)
+        assert r.returncode == 0, (name, r.stdout[-500:], r.stderr[-500:])
+        info = api.dpx_probe(open(files[0], "rb").read())
+        nh, nv = api.slices_to_grid(int(r.stdout.split("-slices ")[1].split()[0]))
+        p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+        mux = api.MkvMuxer(work + "/pkg.mkv")
+        tv = mux.add_video(ob.config_record(p), w, h, fps[0], fps[1])
+        blocks, cache = [], {}
+        for i, fn in enumerate(files):
+            k = i % len(comps)
+            if k not in cache:
+                b = open(fn, "rb").read()
+                cache[k] = ob.encode_payload(p, b[info.data_offset:info.data_offset + info.data_size], info.line_bytes)
+            blocks.append((i * 1000000000 * fps[1] // fps[0], 0, tv, cache[k]))
+        if audio:
+            winfo = api.wav_probe(wav)
+            frames, cp = ob.flac_encode(ch, rate, abits, wav[winfo.data_offset:winfo.data_offset + winfo.data_size], 0, 8)
+            ta = mux.add_audio(cp, ch, rate, abits)
+            for k, fr in enumerate(frames):
+                blocks.append((k * 4608 * 1000000000 // rate, 1, ta, fr))
+        for fn in sorted(os.listdir(work + "/pkg")):
+            if fn not in ("img", "snd.wav"):
+                mux.add_attachment("pkg/" + fn, open(work + "/pkg/" + fn, "rb").read())
+        mux.add_attachment("RAWcooked reversibility data", open(work + "/pkg.rawcooked_reversibility_data", "rb").read())
+        mux.begin()
+        for pts, _, trk, data in sorted(blocks, key=lambda x: (x[0], x[1])):
+            mux.write_block(trk, pts, data)
+        mux.close()
+        r = run([refbin, "--check", "pkg.mkv"], work)
+        assert r.returncode == 0 and "Reversibility was checked, no issue detected." in r.stdout, (name, r.stdout[-800:], r.stderr[-800:])
+    finally:
+        shutil.rmtree(work)
+
+
+@pytest.mark.parametrize("name,args", [
+    ("long: 2500 frames, 104 s of timestamps, many clusters", dict(w=16, h=8, pixfmt=0, n=2500, fps=(24, 1))),
+    ("24000/1001", dict(w=32, h=16, pixfmt=5, n=120, fps=(24000, 1001))),
+    ("one frame per second", dict(w=32, h=16, pixfmt=1, n=40, fps=(1, 1))),
+    ("60 fps beside 6 channels of 24-bit FLAC", dict(w=48, h=32, pixfmt=5, n=90, fps=(60, 1), audio=(6, 24, 48000, 72000))),
+    ("audio outlasting the pictures", dict(w=32, h=16, pixfmt=11, n=10, fps=(24, 1), audio=(2, 16, 44100, 200000))),
+    ("attachments: text, 300 KB, empty", dict(w=32, h=16, pixfmt=9, n=12, fps=(25, 1), attach=[("notes.txt", b"hello"), ("big.bin", bytes(range(256)) * 1200), ("empty.dat", b"")])),
+    ("frames of 19 MB: four-byte EBML sizes", dict(w=2048, h=1556, pixfmt=5, n=2, fps=(24, 1), kind="noise")),
+], ids=lambda x: x if isinstance(x, str) else "")
+def test_reference_checks_what_the_muxer_writes(built, refbin, name, args):
+    """The product's Matroska writer (mkv_mux.cpp) beyond the shapes the GPU end-to-end tests give it, judged by the real reference's demuxer
+    and --check on the CPU: long timestamp ranges, rational and slow frame rates, audio interleaved and outlasting the video, attachments
+    of every size, blocks beyond 16 MB."""
+    from rawcooked_amd import synth
+    pf = {0: synth.PIX_RGB8, 1: synth.PIX_RGB10_FILLEDA_BE, 5: synth.PIX_RGB16_BE, 9: synth.PIX_RGBA16_LE, 11: synth.PIX_Y16_BE}[args.pop("pixfmt")]
+    _muxed_package_checks(refbin, name, pixfmt=pf, **args)
+
+
 def test_flac_of_random_signals_is_what_the_reference_decodes(built):
     """The oracle's FLAC ENCODER -- whose frames the device encoder must equal -- against the reference's own FLAC path (its wrapper around the
     libFLAC it ships, fed CodecPrivate and blocks the way track_info feeds them; oracle/ref_flac_decode.cpp), beyond the 7 blessed streams:
