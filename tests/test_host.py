@@ -752,6 +752,58 @@ def test_sequence_structs_carry_their_size_and_one_input_callback(built):
         assert call(api.SequenceIo(C.sizeof(api.SequenceIo), rf, api.PLACE_PACKET_FN(), pd, None), good_opt) == 4 and "no HIP device" in api.last_error()
 
 
+def _reference_command_line(refbin, work, seqs, wavs=(), opts=()):
+    """A package on disk and the ffmpeg command line the REAL reference writes for it (`-d`: display, do not run; CLI/Output.cpp:81-332)."""
+    import shlex
+    for name, (w, h, pixfmt, idx, kind) in seqs.items():
+        os.makedirs(os.path.join(work, "pkg", name), exist_ok=True)
+        bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+        for i in idx:
+            comp = synth.components(w, h, nc, bits, "film", seed=i % 5)
+            data = synth.tiff_file(comp, pixfmt) if kind == "tif" else synth.exr_file(comp) if kind == "exr" else synth.dpx_file(comp, pixfmt, frame_index=i)
+            open(os.path.join(work, "pkg", name, "f_%06d.%s" % (i, kind)), "wb").write(data)
+    for wn, (ch, bits, rate, ns) in dict(wavs).items():
+        open(os.path.join(work, "pkg", wn), "wb").write(synth.wav_file(np.random.default_rng(1).integers(-1000, 1000, size=(ns, ch)).astype(np.int32), bits, rate))
+    r = subprocess.run([refbin, "--no-check-padding", "--check", "-d", "-y"] + list(opts) + ["pkg"], cwd=work, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cmds = [ln for ln in r.stdout.splitlines() if ln.startswith("ffmpeg ")]
+    assert len(cmds) == 1, r.stdout
+    return shlex.split(cmds[0])
+
+
+@pytest.mark.parametrize("name,seqs,wavs,opts,want", [
+    ("plain", {"img": (64, 48, synth.PIX_RGB16_BE, range(6), "dpx")}, {}, [], ["video 6 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 6x6 fps 24/1 first pkg/img/f_000000.dpx"]),
+    ("gapped: the reference's own file list", {"img": (64, 48, synth.PIX_RGB16_BE, [0, 1, 2, 5, 6, 9], "dpx")}, {}, [], ["video 6 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 6x6 fps 24/1 first "]),
+    ("start number 86400", {"img": (64, 48, synth.PIX_RGB10_FILLEDA_BE, range(86400, 86405), "dpx")}, {}, [], ["video 5 frames 64x48 DPX/Raw/RGB/10bit/U/BE/FilledA slices 4x4 fps 24/1 first pkg/img/f_086400.dpx"]),
+    ("tiff", {"img": (64, 48, synth.PIX_RGB16_LE, range(4), "tif")}, {}, [], ["video 4 frames 64x48 TIFF/Raw/RGB/16bit/U/LE slices 6x6 fps 24/1 first pkg/img/f_000000.tif"]),
+    ("exr", {"img": (64, 48, synth.PIX_EXR_RGB16, range(4), "exr")}, {}, [], ["video 4 frames 64x48 EXR/Raw/RGB/16bit/F/BE slices 6x6 fps 24/1 first pkg/img/f_000000.exr"]),
+    ("two sequences and two WAVs", {"a": (64, 48, synth.PIX_RGB16_BE, range(4), "dpx"), "b": (32, 16, synth.PIX_Y16_BE, range(8), "dpx")}, {"x.wav": (2, 16, 48000, 8000), "y.wav": (6, 24, 48000, 8000)}, [],
+     ["video 4 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 6x6 fps 24/1 first pkg/a/f_000000.dpx", "video 8 frames 32x16 DPX/Raw/Y/16bit/U/BE slices 6x6 fps 24/1 first pkg/b/f_000000.dpx",
+      "audio WAV/PCM/48kHz/16bit/2ch/S/LE 2 ch 48000 Hz 16 bit -> FLAC", "audio WAV/PCM/48kHz/24bit/6ch/S/LE 6 ch 48000 Hz 24 bit -> FLAC"]),
+    ("-framerate 24000/1001", {"img": (64, 48, synth.PIX_RGB16_BE, range(6), "dpx")}, {}, ["-framerate", "24000/1001"], ["video 6 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 6x6 fps 24000/1001 first "]),
+    ("-coder 2 -slices 16", {"img": (64, 48, synth.PIX_RGB16_BE, range(3), "dpx")}, {}, ["-coder", "2", "-slices", "16"], ["video 3 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 4x4 fps 24/1 first "]),
+    ("Y 10 bit", {"img": (50, 38, synth.PIX_Y10_FILLEDA_BE, range(3), "dpx")}, {}, [], ["video 3 frames 50x38 DPX/Raw/Y/10bit/U/BE/FilledA slices 4x4 fps 24/1 first "]),
+    ("RGBA 12 bit packed", {"img": (48, 32, synth.PIX_RGBA12_PACKED_BE, range(3), "dpx")}, {}, [], ["video 3 frames 48x32 DPX/Raw/RGBA/12bit/U/BE/Packed slices 6x6 fps 24/1 first "]),
+], ids=lambda x: x if isinstance(x, str) else "")
+def test_shim_plans_what_the_reference_asks_for(built, refbin, tmp_path, name, seqs, wavs, opts, want):
+    """The argv front end on the command lines the REAL reference writes (not on ones written from reading CLI/Output.cpp): the package is
+    analysed by `rawcooked -d`, its ffmpeg command line -- quoting, option order, the file list it writes for a gapped sequence and all --
+    goes to the shim with `-rcgpu_plan_only 1` (no device), and the plan is the package: every track, its frames, size, flavor, the slice
+    grid of the reference's -slices, the frame rate."""
+    work = str(tmp_path)
+    argv = _reference_command_line(refbin, work, seqs, wavs, opts)
+    shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
+    r = subprocess.run([shim] + argv[1:-1] + ["-rcgpu_plan_only", "1", argv[-1]], cwd=work, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    plan = [ln[len("rcgpu plan: "):] for ln in r.stdout.splitlines() if ln.startswith("rcgpu plan: ")]
+    assert len(plan) == len(want) + 1 and plan[-1] == "output pkg.mkv, 0 attachment(s) + reversibility data", plan
+    for got, w in zip(plan, want):
+        assert got.startswith(w), (got, w)
+    slices = int(argv[argv.index("-slices") + 1])
+    nh, nv = api.slices_to_grid(slices)
+    assert all(("slices %dx%d " % (nh, nv)) in ln for ln in plan if ln.startswith("video"))
+
+
 def test_integration_patches_only_add_lines_and_hold_no_reference_source():
     """oracle/route_*.patch and linked_threadpool_h.patch are what a maintainer would add: every hunk adds lines and removes
     none (`diff -U0`: no context lines either, so no line of the reference's source is kept in this repository), and what the FFV1 / Matroska /
