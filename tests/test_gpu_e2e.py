@@ -561,6 +561,29 @@ def test_linked_reference_says_what_the_reference_says_about_damaged_files(built
     assert compared >= 5
 
 
+def test_linked_reference_fails_what_the_reference_fails_to_rebuild(built, linkedbin, refbin, tmp_path, monkeypatch):
+    """146 pixels of 12-bit packed RGB in the 6 slice columns the reference itself chooses: its first slice ends on a block of 8 pixels, the
+    others do not, and the unmodified reference rebuilds the picture wrongly (Lib/Transform/Transform.cpp:176-177 registers the merging of
+    shared blocks only from a first slice that needs it) -- `--check` of a file it agreed to encode says the files are not the sources.  The
+    device decoder would rebuild them right; what the user reads from the linked binary must be the reference's verdict all the same (the
+    archive will be decoded by whatever RAWcooked there is): the track is left to the pool (RCGPU_TRACE_KEPT says so).  96 pixels wide,
+    where every slice ends on a block, both binaries pass."""
+    for width, passes in ((146, False), (96, True)):
+        work = str(tmp_path / str(width))
+        os.makedirs(work)
+        make_package(work, width, 45, synth.PIX_RGB12_PACKED_BE, 4, "film")
+        r = run([linkedbin, "--no-check-padding", "--hash", "--no-check", "-y", "pkg"], work, timeout=60)      # encoded on the device (route B)
+        assert r.returncode == 0, r.stdout + r.stderr
+        want = run([refbin, "--check", "pkg.mkv"], work, timeout=120)
+        monkeypatch.setenv("RCGPU_TRACE_KEPT", "1")
+        got = run([linkedbin, "--check", "pkg.mkv"], work, timeout=120)
+        monkeypatch.delenv("RCGPU_TRACE_KEPT")
+        assert (want.returncode == 0 and OK_LINE in want.stdout) == passes, want.stdout + want.stderr
+        assert got.returncode == want.returncode and (OK_LINE in got.stdout) == passes, got.stdout + got.stderr
+        assert ("not same as files from source" in got.stdout + got.stderr) == (not passes)
+        assert ("rebuilds wrongly" in got.stderr) == (not passes), got.stderr
+
+
 def test_linked_reference_decodes_one_batch_ahead(built, linkedbin, refbin, tmp_path, monkeypatch):
     """Route C one batch ahead: once the first frame has told the batch size, the demuxer announces the batch after the current one too and
     ffv1_frame::Process has the decoder start on it (rcgpu_ffv1_decoder_decode_keep_hint_file, by the blocks' places in the file: frames of

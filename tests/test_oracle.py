@@ -223,6 +223,71 @@ def test_reference_checks_what_the_muxer_writes(built, refbin, name, args):
     _muxed_package_checks(refbin, name, pixfmt=pf, **args)
 
 
+def reference_misdecodes(width, num_h, pixels_per_block):
+    """The rule of oracle/route_c_ffv1_frame_cpp.patch (RefMisdecodes), restated: the reference's decoder merges the blocks two slices share
+    only when slice (0,0) itself ends inside a block (Lib/Transform/Transform.cpp:176-177,733-734,871-872) and only two slices to a block."""
+    if num_h <= 1 or pixels_per_block <= 1:
+        return False
+    edge = [i * width // num_h for i in range(num_h + 1)]
+    other = any(edge[i] % pixels_per_block for i in range(2, num_h))
+    narrow = any(edge[i + 1] - edge[i] < pixels_per_block and (edge[i] % pixels_per_block or edge[i + 1] % pixels_per_block) for i in range(num_h))
+    return other and (edge[1] % pixels_per_block == 0 or narrow)
+
+
+def test_the_geometries_the_reference_rebuilds_wrongly_are_the_ones_route_c_leaves_to_it(built):
+    """12-bit packed RGB / Y and 10-bit filled Y pack several pixels into a block, and slices may start inside one.  The unmodified reference
+    rebuilds such a picture wrongly when its first slice ends ON a block and others do not (146 pixels in 6 columns: its own --check of a
+    file it agreed to encode fails) -- the device decoder rebuilds it right, and route C must not pass what the reference fails.  The rule
+    the hook uses is held to the reference's decoder here: wherever the rule says "the reference is right" the reference's decoder returns
+    the source's bytes (never the other way round), and the textbook case of the rule really is rebuilt wrongly."""
+    import ref_decode
+    from rawcooked_amd import api, synth
+    if not ref_decode.available():
+        pytest.skip("oracle/_ref/ref_ffv1_decode not built (needs /root/reference)")
+    ppb = {synth.PIX_RGB12_PACKED_BE: 8, synth.PIX_Y10_FILLEDA_BE: 3, synth.PIX_Y10_FILLEDB_BE: 3, synth.PIX_Y12_PACKED_BE: 8}
+    right = wrong = 0
+    for seed in range(int(os.environ.get("RCGPU_SOAK_SPAN", "160"))):
+        rng = np.random.default_rng(900 + seed)
+        pixfmt = list(ppb)[seed % 4]
+        flags = [0, 1][seed % 2] if ppb[pixfmt] == 8 else 0
+        bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+        w, h = int(rng.integers(16, 200)), int(rng.integers(6, 40))
+        try:
+            f = synth.dpx_file(synth.components(w, h, nc, bits, "noise", seed=seed), pixfmt, flags=flags)
+            info = api.dpx_probe(f)
+        except RuntimeError:
+            continue
+        nh, nv = api.slices_to_grid(info.slices if seed % 5 else [4, 6, 9, 12, 16][seed % 5])
+        if nh >= w or nv >= h:
+            continue
+        payload = f[info.data_offset:info.data_offset + info.data_size]
+        p = ob.Params(w, h, pixfmt, nh, nv, 1, 1, flags)
+        try:
+            (frames,), _ = ref_decode.decode([(info.flavor.decode(), flags, w, h, ob.config_record(p), [ob.encode_payload(p, payload, info.line_bytes)])])
+            ok = frames[0][0] == 0 and frames[0][1][:len(payload)] == payload
+        except AssertionError:
+            ok = False                                       # (the reference's decoder did not survive the geometry)
+        if not reference_misdecodes(w, nh, ppb[pixfmt]):
+            assert ok, (seed, w, h, nh, nv, pixfmt, flags)
+            right += 1
+        elif not ok:
+            wrong += 1
+    assert right > 80 and wrong >= 5
+    (frames,), _ = ref_decode.decode([_span_case(146, 45, synth.PIX_RGB12_PACKED_BE)])
+    assert reference_misdecodes(146, 6, 8) and frames[0][0] == 0 and frames[0][1] != _span_case.payload
+
+
+def _span_case(w, h, pixfmt):
+    from rawcooked_amd import api, synth
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    f = synth.dpx_file(synth.components(w, h, nc, bits, "film", seed=0), pixfmt)
+    info = api.dpx_probe(f)
+    nh, nv = api.slices_to_grid(info.slices)
+    _span_case.payload = f[info.data_offset:info.data_offset + info.data_size]
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    return info.flavor.decode(), 0, w, h, ob.config_record(p), [ob.encode_payload(p, _span_case.payload, info.line_bytes)]
+
+
 def test_flac_of_random_signals_is_what_the_reference_decodes(built):
     """The oracle's FLAC ENCODER -- whose frames the device encoder must equal -- against the reference's own FLAC path (its wrapper around the
     libFLAC it ships, fed CodecPrivate and blocks the way track_info feeds them; oracle/ref_flac_decode.cpp), beyond the 7 blessed streams:
