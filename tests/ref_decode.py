@@ -73,3 +73,17 @@ def flac_decode(cases):
         res.append((v, out[o + 8:o + 8 + n]))
         o += 8 + n
     return res
+
+
+def run_reference(cmd, cwd, timeout=60, attempts=3):
+    """Start the real reference binary (or the linked one).  Retried on a timeout, for one known cause in unpatched reference code: the lost
+    wake-up of its third-party thread pool at shutdown (Lib/ThirdParty/thread-pool/include/ThreadPool.h:27-33,66-68; tests/test_gpu_e2e.py::run
+    has the whole story) -- about one run in a hundred on a loaded box never returns.  Every step the tests make is idempotent."""
+    import sys
+    for attempt in range(attempts):
+        try:
+            return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=timeout, env=clean_env())
+        except subprocess.TimeoutExpired:
+            sys.stderr.write("reference step timed out after %d s (attempt %d): %s\n" % (timeout, attempt + 1, " ".join(cmd[:5])))
+            if attempt + 1 == attempts:
+                raise

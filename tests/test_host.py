@@ -764,7 +764,8 @@ def _reference_command_line(refbin, work, seqs, wavs=(), opts=()):
             open(os.path.join(work, "pkg", name, "f_%06d.%s" % (i, kind)), "wb").write(data)
     for wn, (ch, bits, rate, ns) in dict(wavs).items():
         open(os.path.join(work, "pkg", wn), "wb").write(synth.wav_file(np.random.default_rng(1).integers(-1000, 1000, size=(ns, ch)).astype(np.int32), bits, rate))
-    r = subprocess.run([refbin, "--no-check-padding", "--check", "-d", "-y"] + list(opts) + ["pkg"], cwd=work, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=120)
+    from ref_decode import run_reference
+    r = run_reference([refbin, "--no-check-padding", "--check", "-d", "-y"] + list(opts) + ["pkg"], work)
     assert r.returncode == 0, r.stdout + r.stderr
     cmds = [ln for ln in r.stdout.splitlines() if ln.startswith("ffmpeg ")]
     assert len(cmds) == 1, r.stdout

@@ -153,8 +153,7 @@ def _muxed_package_checks(refbin, name, w, h, pixfmt, n, fps, audio=None, attach
     import tempfile
     from rawcooked_amd import api, synth
 
-    def run(cmd, cwd):
-        return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=600)
+    from ref_decode import run_reference as run          # (retried: the reference's thread pool loses a wake-up at shutdown now and then)
     work = tempfile.mkdtemp()
     try:
         os.makedirs(work + "/pkg/img")
