@@ -8,7 +8,7 @@ their headers (bytes overwritten, bits flipped, files cut short).  oracle/_ref/r
 parsers in the order CLI/Main.cpp tries them and prints which one recognised it, whether it supports it, the flavor string and slice_x *
 slice_y; tests/test_host.py::test_probes_agree_with_the_reference_s_parsers holds rcgpu_*_probe to those lines: what the reference would hand
 to its encoder, the shim must take, as the same flavor, with the same slice count.  Deterministic: only the reference's lines are kept (the
-first one is the sha256 of all the cases' bytes); the test makes the same 3357 files again with cases() below.
+first one is the sha256 of all the cases' bytes); the test makes the same 3601 files again with cases() below.
 """
 import hashlib
 import os
@@ -51,6 +51,10 @@ def cases():
         more.append(synth.tiff_file(synth.components(32, 8, nc, bits, "film", seed=1), pf))
     more.append(synth.wav_file(s[:, :1], 8))
     more.append(synth.wav_file(np.tile(s, (1, 4)), 16, 96000))
+    more.append(synth.wav_file(s, 32))                                    # what only `-c:a copy` can carry (CLI/Main.cpp:300-317): 32-bit integer
+    more.append(synth.wav_file(s, 32, float32=True))                      # ... and 32-bit float
+    more.append(synth.wav_file(np.tile(s, (1, 2)), 32, 44100, extensible=True, float32=True))
+    more.append(synth.wav_file(s[:, :1], 24, 44100, trailer_chunk=b"LIST" + (4).to_bytes(4, "little") + b"abcd"))
     out = list(seeds)
     for d in seeds:
         for k in range(150):

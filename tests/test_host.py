@@ -542,7 +542,7 @@ def test_stream_parse_does_its_sums_in_the_reference_s_width(built):
 
 
 def test_probes_agree_with_the_reference_s_parsers(built):
-    """3357 small files -- DPX of all 22 flavors, TIFF of eight, EXR, WAV of four, and seeded mutations of their headers (tests/golden/make_probe_golden.py makes them
+    """3601 small files -- DPX of all 22 flavors, TIFF of eight, EXR, WAV of eight (32-bit integer and float among them), and seeded mutations of their headers (tests/golden/make_probe_golden.py makes them
     again here) -- with what the REAL reference's wav, dpx, tiff and exr parsers said of each (oracle/ref_probe.cpp drives them in the CLI's
     order; tests/golden/probe_cases.txt): whatever the reference would hand to its encoder the shim's probes take, from the same parser, as
     the same flavor, with the same -slices.  (The other way round is not asked for: the shim is only ever called for what the reference
@@ -557,7 +557,7 @@ def test_probes_agree_with_the_reference_s_parsers(built):
     blob = b"".join(struct.pack("<I", len(c)) + c for c in cases)
     assert lines[0] == "sha256 " + hashlib.sha256(blob).hexdigest(), "the generator no longer makes the files the reference was shown: run tests/golden/make_probe_golden.py"
     lines = lines[1:]
-    assert len(lines) == len(cases) > 3300
+    assert len(lines) == len(cases) > 3500
     probes = {"wav": api.wav_probe, "dpx": api.dpx_probe, "tiff": api.tiff_probe, "exr": api.exr_probe}
     supported = stricter = 0
     for n, (data, line) in enumerate(zip(cases, lines)):
