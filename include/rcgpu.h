@@ -388,10 +388,13 @@ int  rcgpu_ffv1_config_from_stream(const uint8_t* record, size_t size, const uin
  * (states_coded, read as the reference reads them, :103-107), and from the first slice header of `packet` -- the first frame of the
  * track -- the quant_table_set_index of every plane group (FFV1_Slice.cpp:158-168).
  *   return 0                       parsed; *stream must be freed with rcgpu_ffv1_stream_free
- *   return RCGPU_FFV1_UNSUPPORTED  a valid stream the device decoder does not take (Golomb-Rice; and from _create_for_stream: YUV planes,
+ *   return RCGPU_FFV1_UNSUPPORTED  a valid stream the device decoder does not take (Golomb-Rice; more slice rows than columns -- which the
+ *                                  reference itself misreads, FFV1_Slice.cpp:125, so that its verdict must stay its own; and from _create_for_stream: YUV planes,
  *                                  inter frames, a state 0 within reach of the initial states): the caller decodes it with its own decoder --
  *                                  ffv1_frame::Process stays on its slice pool (oracle/route_c_ffv1_frame_cpp.patch)
- *   any other value                what the reference refuses as well (its error in rcgpu_last_error())
+ *   any other value                what the reference refuses as well (its error in rcgpu_last_error()), a record that ends before its fields do,
+ *                                  or a first frame that is no key frame / whose first slice header the reference flags.  The reader is held to
+ *                                  the reference's own (tests/golden/parse_cases.*): what the reference refuses it refuses, what both read they read alike.
  * rcgpu_ffv1_decoder_create_for_stream takes width, height, pixfmt, line_bytes, flags, max_batch and device from `files` (the stream fields
  * of the struct are ignored) and everything else from `stream`; it fails when the stream does not describe `pixfmt` (colorspace, bit
  * depth, alpha).  The decoder it makes is used like any other; a slice whose header names other table sets than the first slice did
