@@ -12,6 +12,7 @@
 #   checkprof [tag]                check half: per-launch HIP events as timed (partitioned), then rocprofv3 --stats + FETCH/WRITE_SIZE passes unpartitioned
 #   encprof [tag]                  encode half: rocprofv3 --stats, FETCH/WRITE_SIZE passes, SQ instruction counters at batch 336
 #   trace [tag] [bench args]       rocprofv3 --kernel-trace as a timeline: where k_resolve / k_rangecode stand still (TRACE_MODE=check: the check half's launches)
+#   damage [tag] [from] [to]       the damage soak of route C: both binaries' verdicts on damaged files, seeds from..to-1
 #   refresh [tag]                  tests + encprof + checkprof + the 576-slice and 8K passes + the driver's line, on one box (then tools/adopt_profiles.sh)
 #   sweep [tag] "ENV=.." ...       one bench line per environment setting with the TIMING build -> sweep_<tag>.jsonl, e.g. the floor of round 4:
 #                                  sweep floor "" RCGPU_EXP_SKIP_RC=1 "RCGPU_EXP_SKIP_RC=1 RCGPU_EXP_STATES_L2=1" RCGPU_EXP_STATES_L2=1 RCGPU_RC_SPAN=64
@@ -115,6 +116,10 @@ except Exception as e:
 PY
         tail -1 $OUT/sweep_$TAG.jsonl
     done ;;
+damage)
+    # the linked binary's verdict against the unmodified reference's on damaged Matroska files (tests/test_gpu_e2e.py, ~65 s a seed, eight damaged
+    # copies each): damage [tag] [first seed] [one past the last]; what both binaries said goes to $OUT/damage_<seed>_<kind>.txt on a mismatch
+    RCGPU_DAMAGE_DUMP=$PWD/$OUT/damage RCGPU_SOAK_DAMAGE_FROM=${1:-0} RCGPU_SOAK_DAMAGE=${2:-8} timeout 2400 python -m pytest tests/test_gpu_e2e.py -k "says_what_the_reference_says" -x -q -m gpu 2>&1 | tail -15 | tee $OUT/damage_$TAG.log ;;
 refresh)
     # the end-of-round set on the final tree, one box: GPU suite, every pass profiles/traffic.json is made from (64 slices, 576, 8K, the check half),
     # the driver's line.  Then, at home: bash tools/adopt_profiles.sh $TAG
