@@ -35,6 +35,55 @@ W4K, H4K = 4096, 2160
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+LINE_LIMIT = 4096             # the driver keeps the last 8 KB of stdout: the line it parses stays under half of that
+DETAIL_FILE = "bench_detail.json"
+
+
+def compact_line(result: dict, step_ms=None, detail_file: str = DETAIL_FILE) -> str:
+    """The ONE line the driver parses: the contract's keys, `config` as a one-sentence workload plus flat numbers, `roofline` and
+    `cpu_baseline` as numbers, the per-step times.  Everything else bench.py measures (per-leg records, traces, prose) stays in
+    `result`, which main() writes to bench_detail.json (stderr gets one summary line: the driver's record joins the tails of both
+    streams).  Never longer than LINE_LIMIT bytes: what does not fit is
+    dropped from the END of `config` (the contract's keys come first)."""
+    def scalar(v):
+        return v is None or isinstance(v, (bool, int, float)) or (isinstance(v, str) and len(v) <= 48)
+    src_cfg = result.get("config") or {}
+    cfg = {"workload": str(src_cfg.get("workload", "")).split(";")[0][:200]}
+    for k, v in src_cfg.items():
+        if k != "workload" and scalar(v) and v is not None:
+            cfg[k] = v
+    r = result.get("roofline") or {}
+    roof = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "request_frac", "floor_ms", "launch_ms",
+                                  "launches_per_step", "algorithmic_bytes_per_launch")} if r else None
+    if r and isinstance(r.get("kernel_ms_per_step"), dict):
+        roof["kernel_ms_per_step"] = {k: round(v, 1) for k, v in r["kernel_ms_per_step"].items()}
+    cb = result.get("cpu_baseline")
+    cpu = None
+    if isinstance(cb, dict) and "value" in cb:
+        cpu = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")}
+        cpu["sample"] = str(cb.get("sample", "")).split(";")[0].split("(")[0].strip()[:120]
+    line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                       "dtype", "data", "h2d_included")}
+    km = result.get("kernel_metric")
+    if isinstance(km, dict) and "value" in km:      # SURVEY.md 8d: inputs in pinned host memory, H2D included
+        line["kernel_metric"] = {"value": km["value"], "unit": km.get("unit", "frames/s"), "h2d_included": True, "frames": km.get("frames")}
+    line["config"] = cfg
+    line["roofline"] = roof
+    line["cpu_baseline"] = cpu
+    if step_ms:
+        line["step_ms"] = [round(float(x), 1) for x in step_ms]
+    line["detail"] = detail_file
+    s = json.dumps(line, separators=(",", ":"))
+    keys = [k for k in cfg if k != "workload"]
+    while len(s) >= LINE_LIMIT and keys:
+        cfg.pop(keys.pop())
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= LINE_LIMIT:      # (cannot happen with the keys above: a hundred step times would do it)
+        line.pop("step_ms", None)
+        s = json.dumps(line, separators=(",", ":"))
+    return s
+
+
 def make_frames(torch, n, width, height, kind, seed, device):
     """n synthetic RGB16-BE payloads on the device, uint8 [n, height*width*6]; generated 8 frames at a time."""
     g = torch.Generator(device=device)
@@ -940,9 +989,9 @@ def main():
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--legs", default="host,e2e,check,cpu,configs,long",
+    ap.add_argument("--legs", default="host,e2e,check,cpu,configs",
                     help="comma list of the extra records: host (host_pipeline), e2e (config 3), check (config 5), cpu (cpu_baseline), configs (config 1 and 4 shapes, 576 slices, flat content), "
-                         "long (the linked reference on a 5000-frame sequence); '' = none")
+                         "long (the linked reference on a 5000-frame sequence, ~100 s: not in the default set, which has to fit the driver's run); '' = none")
     ap.add_argument("--host-frames", type=int, default=3840, help="host_pipeline: frames per GPU")
     ap.add_argument("--host-lanes", type=int, default=1, help="host_pipeline: encoder instances per GPU, batches staggered")
     ap.add_argument("--host-readers", type=int, default=0)
@@ -958,6 +1007,7 @@ def main():
     ap.add_argument("--check-offsets", default="", help="--mode check: comma list of byte offsets (multiples of 256, <= 64 MiB) at which the decoder's state arrays are placed in turn; "
                                                          "k_dec_slices' time at each is recorded (does the time depend on the addresses?)")
     ap.add_argument("--check-profile-out", default="", help="--mode check: write the per-launch HIP-event timings to this file (profiles/r05_check_partitioned.json)")
+    ap.add_argument("--detail-out", default=DETAIL_FILE, help="file (beside this script unless absolute) that receives everything measured; the stdout line is the compact one")
     ap.add_argument("--mode", default="encode", choices=["encode", "check"],
                     help="check: BASELINE config 5 alone -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
@@ -1116,9 +1166,22 @@ def main():
         mode_probe = {"run_on_ms_per_step": round(probe(True) * 1e3, 1), "one_batch_at_a_time_ms_per_step": round(probe(False) * 1e3, 1)}
         run_on = mode_probe["run_on_ms_per_step"] <= mode_probe["one_batch_at_a_time_ms_per_step"]
         enc.set_run_on(run_on)
-    dt = rdist.timed_steps(dist, dev, step, args.steps, args.warmup, torch.cuda.synchronize)
+    # per-step times for the line's `step_ms`: a device event behind every timed step.  In run-on mode a batch ends on the encoder's own
+    # streams and the caller's stream must NOT be made to wait for it (the next batch's modelling follows the caller's stream): a side
+    # stream joins the batches issued so far and carries the events.
+    side = torch.cuda.Stream(device=dev)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+
+    def mark_step(k):
+        if run_on:
+            enc.join(side.cuda_stream)
+            step_ev[k + 1].record(side)
+        else:
+            step_ev[k + 1].record(torch.cuda.current_stream())
+    dt = rdist.timed_steps(dist, dev, step, args.steps, args.warmup, torch.cuda.synchronize, mark=mark_step)
     if run_on:
         enc.join(stream); torch.cuda.synchronize()
+    step_ms = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps)]
     if noise is not None:
         stop.set(); noise.join()
         print("bench: dma noise moved %.0f GB during warm-up and timed steps = %.1f GB/s beside the kernels" % (moved[0] / 1e9, moved[0] / 1e9 / max(1e-9, time.perf_counter() - t_noise)), file=sys.stderr)
@@ -1283,9 +1346,11 @@ def main():
             result["host_pipeline_pinned_inputs_1000_frames"] = h1
         if result is not None and "host_pipeline" in result:
             hp = result["host_pipeline"]
-            result["kernel_metric"] = {"value": hq["value"], "unit": "frames/s", "h2d_included": True, "from_pageable_inputs": hp["value"],
-                                       "what": "SURVEY.md 8d 'kernel-only fps (inputs resident in pinned host memory, H2D included)': payloads start in pinned host memory and "
-                                               "packets end in pageable host memory, uploads / coding / downloads overlapped (the host_pipeline_pinned_inputs record); "
+            result["kernel_metric"] = {"value": h1["value"], "unit": "frames/s", "h2d_included": True, "frames": 1000, "long_run_value": hq["value"], "long_run_frames": args.host_frames,
+                                       "from_pageable_inputs": hp["value"],
+                                       "what": "SURVEY.md 8d 'kernel-only fps (inputs resident in pinned host memory, H2D included)' on BASELINE config 2's own 1000 frames: payloads start in "
+                                               "pinned host memory and packets end in pageable host memory, uploads / coding / downloads overlapped (host_pipeline_pinned_inputs_1000_frames; "
+                                               "long_run_value: the same on --host-frames frames, host_pipeline_pinned_inputs); "
                                                "from_pageable_inputs: the payloads start in pageable memory and reader threads copy them into pinned slots first (host_pipeline)"}
     if (world > 1 or alias_n > 1) and "e2e" in legs:
         # ---- N JOBS SIDE BY SIDE, N Matroska files: the way a node pays off under the single-file ceiling (one job writes one file at ~13 GB/s whatever
@@ -1430,7 +1495,7 @@ def main():
                 d = d.get(k) if isinstance(d, dict) else None
             return d if isinstance(d, (int, float)) and not isinstance(d, bool) else None
         c = result["config"]
-        c["h2d_inclusive_fps"] = num("kernel_metric", "value")                                   # inputs in pinned host memory, H2D included; 3840 frames
+        c["h2d_inclusive_fps"] = num("kernel_metric", "long_run_value")                          # inputs in pinned host memory, H2D included; 3840 frames
         c["h2d_inclusive_fps_frames"] = args.host_frames if c["h2d_inclusive_fps"] is not None else None
         c["h2d_inclusive_fps_from_pageable"] = num("host_pipeline", "value")
         c["h2d_inclusive_fps_1000_frames"] = num("host_pipeline_pinned_inputs_1000_frames", "value")   # ... on config 2's own 1000 frames
@@ -1462,7 +1527,25 @@ def main():
         c["bench_wall_seconds"] = round(time.perf_counter() - t_bench, 1)
         result["legs_done_at_seconds"] = {k: v for k, v in marks}
     if rank == 0:
-        print(json.dumps(result))
+        # The driver parses the LAST line of stdout and keeps 8 KB of it: one compact object there; everything measured goes to
+        # bench_detail.json beside this script (and gpurun_out/, which travels back from the GPU box) and to stderr.
+        result["step_ms"] = [round(x, 2) for x in step_ms]
+        detail = json.dumps(result, indent=1)
+        outs = [args.detail_out if os.path.isabs(args.detail_out) else os.path.join(ROOT, args.detail_out)]
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            outs.append(os.path.join(ROOT, "gpurun_out", os.path.basename(args.detail_out)))
+        for path in outs:
+            try:
+                with open(path, "w") as fh:
+                    fh.write(detail + "\n")
+            except OSError as ex:
+                print("bench: cannot write %s: %s" % (path, ex), file=sys.stderr)
+        # (stderr stays short as well: the driver's record joins the tails of both streams)
+        print("bench: %s %s %s, %s ms per step; detail record: %d bytes in %s" % (result["metric"], result["value"], result["unit"], result["ms_per_step"], len(detail), ", ".join(outs)),
+              file=sys.stderr)
+        sys.stderr.flush()
+        print(compact_line(result, step_ms, os.path.basename(args.detail_out)))
+        sys.stdout.flush()
     api.lib().rcgpu_release_device_streams()          # (see --mode check above)
     rdist.finish(dist)
     if not ok_all:

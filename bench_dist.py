@@ -46,9 +46,10 @@ def gather_floats(dist, values, device):
     return [[float(x) for x in o.tolist()] for o in out]
 
 
-def timed_steps(dist, device, step, steps: int, warmup: int, synchronize) -> float:
+def timed_steps(dist, device, step, steps: int, warmup: int, synchronize, mark=None) -> float:
     """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by barrier + device synchronize on
-    both sides; the result is the slowest rank's wall time."""
+    both sides; the result is the slowest rank's wall time.  `mark(k)`, if given, is called with -1 when the clock starts and with k
+    after timed step k has been issued (bench.py records a device event there: the per-step times of the line's `step_ms`)."""
     import time
     for _ in range(max(0, warmup)):
         step()
@@ -56,8 +57,12 @@ def timed_steps(dist, device, step, steps: int, warmup: int, synchronize) -> flo
     barrier(dist)
     synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if mark:
+        mark(-1)
+    for k in range(steps):
         step()
+        if mark:
+            mark(k)
     synchronize()
     barrier(dist)
     dt = time.perf_counter() - t0

@@ -7,6 +7,8 @@ import subprocess
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -75,3 +77,67 @@ def test_bench_command_line_is_the_contract():
     assert r.returncode == 0, r.stderr
     for opt in ("--gpus", "--steps", "--warmup", "--legs", "--mode"):
         assert opt in r.stdout, opt
+
+
+def _canned_result(n_gpus):
+    """What bench.py's main() holds at the end of a run, with the prose and the per-leg records a real run carries (and more)."""
+    prose = "a paragraph of explanation that belongs in bench_detail.json and not in the line the driver parses; " * 12
+    r = {"metric": "4K-DCI 16-bit DPX->FFV1 frames/sec", "value": 701.5 * n_gpus, "unit": "frames/s", "n_gpus": n_gpus, "steps": 20, "warmup": 5, "ms_per_step": 479.0,
+         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic", "h2d_included": False,
+         "config": {"workload": "BASELINE config 2: 4096x2160 RGB 16-bit BE DPX payload -> FFV1 v3 intra, slices=64 (8x8), coder=1 context=1 (ffmpeg level maps) slicecrc=1, content=film; " + prose,
+                    "range_coder": "one lane per slice", "frames_per_step_per_gpu": 336, "parallelism": "frame-sharded x%d, no collective" % n_gpus, "steps_issued": prose,
+                    "steps_issued_probe": {"run_on_ms_per_step": 502.3, "one_batch_at_a_time_ms_per_step": 512.3}, "packet_bytes_avg": 48847621, "compression_ratio": 0.9202,
+                    "decisions_per_frame": 552785634, "verified_vs_oracle": True, "verified_by_reference": True, "device_error_flags": 0, "hbm_in_use_gb": 218.2, "packets_verified": prose,
+                    **{"some_leg_%d_fps" % i: 100.0 + i for i in range(40)}},
+         "roofline": {"bound": "hbm", "kernel": "k_resolve", "achieved": 73.992, "peak": 8000.0, "unit": "GB/s", "frac": 0.009249, "traffic": 31939375818, "traffic_stale": False,
+                      "request_frac": 0.7201, "floor_ms": 8.916, "algorithmic_bytes_per_launch": 1070283707, "launch_ms": 14.465, "launches_per_step": 32,
+                      "kernel_ms_per_step": {"k_model": 329.966, "k_resolve": 462.878, "k_rangecode": 437.875, "k_footer": 4.586, "k_scan": 0.007, "k_gather": 8.85},
+                      "note": prose, "requests": {"ceiling_what": prose, "floor_what": prose}, "issue_frac": {"note": prose}},
+         "cpu_baseline": {"value": 5.478, "unit": "frames/s", "cores": 16, "cores_busy": 16, "kind": "port", "sample": "16 processes x 2 frames of the same 4096x2160 RGB16 workload (32 distinct frames); " + prose},
+         "kernel_metric": {"value": 610.0, "unit": "frames/s", "h2d_included": True, "frames": 1000, "what": prose},
+         "host_pipeline": {"trace": prose, "per_rank": [{"rank": r_, "frames": 3840, "seconds": 6.5} for r_ in range(n_gpus)]},
+         "e2e": {"timeline": [prose] * 40}, "check": {"roofline": {"note": prose}}, "configs": {"cfg4": {"what": prose}}, "long_sequence": {"timeline": [prose] * 60}}
+    if n_gpus > 1:
+        r["rccl"] = {"backend": "nccl", "world_size": n_gpus, "ranks_counted_by_all_reduce": n_gpus, "saw_every_rank": True, "used_for": prose}
+        r["jobs_side_by_side"] = {"value": 1400.0, "jobs": n_gpus, "per_job": [{"job": j, "frames": 1000, "seconds": 5.0 + j} for j in range(n_gpus)], "what": prose}
+        r["single_process_sharding"] = {"value": 260.0, "lanes": [{"device": j} for j in range(n_gpus)], "what": prose}
+        r["config"].update(jobs_side_by_side_fps=1400.0, single_process_sharding_fps=260.0, rccl_ranks=n_gpus)
+    return r
+
+
+@pytest.mark.parametrize("n_gpus", [1, 8])
+def test_bench_line_is_compact_and_carries_the_contract(n_gpus):
+    """The driver keeps the last 8 KB of stdout and parses the last line (round 5's 26 KB line left `parsed: null`): whatever a run
+    measured, the line is one JSON object under 4 KB with the contract's keys, `roofline` and `cpu_baseline` as numbers and the
+    per-step times; the prose and the per-leg records stay in the detail file."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    res = _canned_result(n_gpus)
+    assert len(json.dumps(res)) > 30000                      # the record is far larger than the driver keeps
+    steps = [479.0 + 0.37 * k for k in range(20)]
+    line = bench.compact_line(res, steps)
+    assert "\n" not in line and len(line.encode()) < 4096 == bench.LINE_LIMIT, len(line)
+    d = json.loads(line)
+    assert json.loads(json.dumps(d)) == d
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == res["value"] and d["n_gpus"] == n_gpus and d["ms_per_step"] == 479.0 and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("BASELINE config 2") and len(d["config"]["workload"]) <= 200 and "model" not in d["config"]
+    assert all(not isinstance(v, (dict, list)) for v in d["config"].values())                    # flat: the driver keeps config values it can print
+    assert d["config"]["frames_per_step_per_gpu"] == 336 and d["config"]["verified_vs_oracle"] is True
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] == "k_resolve" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 and rf["traffic"] == 31939375818 and rf["launches_per_step"] == 32
+    assert all(not isinstance(v, str) or k in ("bound", "kernel", "unit") for k, v in rf.items())   # numbers only
+    cb = d["cpu_baseline"]
+    assert cb["value"] == 5.478 and cb["cores"] == 16 and cb["kind"] == "port" and cb["unit"] == "frames/s" and 0 < len(cb["sample"]) <= 120
+    assert d["step_ms"] == [round(x, 1) for x in steps] and d["detail"] == bench.DETAIL_FILE
+    assert d["kernel_metric"] == {"value": 610.0, "unit": "frames/s", "h2d_included": True, "frames": 1000}
+    if n_gpus > 1:
+        assert d["config"]["rccl_ranks"] == n_gpus and d["config"]["jobs_side_by_side_fps"] == 1400.0
+    # a real record of the last round (26.5 KB as printed then) comes out under the limit too
+    real = os.path.join(ROOT, "profiles", "r05_bench_default.json")
+    if os.path.exists(real):
+        line = bench.compact_line(json.load(open(real)), steps)
+        assert len(line) < 4096 and json.loads(line)["roofline"]["kernel"] == "k_resolve"

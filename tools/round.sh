@@ -16,7 +16,7 @@
 #   refresh [tag]                  tests + encprof + checkprof + the 576-slice and 8K passes + the driver's line, on one box (then tools/adopt_profiles.sh)
 #   sweep [tag] "ENV=.." ...       one bench line per environment setting with the TIMING build -> sweep_<tag>.jsonl, e.g. the floor of round 4:
 #                                  sweep floor "" RCGPU_EXP_SKIP_RC=1 "RCGPU_EXP_SKIP_RC=1 RCGPU_EXP_STATES_L2=1" RCGPU_EXP_STATES_L2=1 RCGPU_RC_SPAN=64
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 WHAT=${1:-tests}; TAG=${2:-x}; shift 2 2>/dev/null
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 OUT=gpurun_out/$ROUND; mkdir -p $OUT
