@@ -51,9 +51,12 @@ typedef struct {
     const char* output_path;              /* Global.OutputFileName (Output.cpp:292-305) */
     const char* framemd5_path;            /* optional (Output.cpp:312-332); NULL = none */
     const char* const* options;           /* key,value,key,value... = Global.OutputOptions (Output.cpp:273-278):           */
-    size_t      n_options;                /*   coder, context, g, level, slicecrc, slices, threads, c:a, c:v, y, n, loglevel */
+    size_t      n_options;                /*   coder, context, g, level, slicecrc, slices, threads, c:a, c:v, y, n, loglevel, */
+                                          /*   and the reference's GPU selection (CLI/Global.cpp:367-378): c:v = ffv1_vulkan,  */
+                                          /*   init_hw_device = vulkan=vk:N, vf = hwupload -> ffv1 on HIP device N             */
     int device_first;                     /* first HIP device to use */
-    int device_count;                     /* number of devices (frames shard i mod device_count); 0 = all visible */
+    int device_count;                     /* number of devices (frames shard i mod device_count); 0 = all visible -- or, with  */
+                                          /*   device_first 0 and an init_hw_device option, the one device that option names   */
 } rcgpu_job;
 
 /* 0 ok; >0 error (becomes the process exit code the reference propagates, Output.cpp:356-374).

@@ -160,7 +160,28 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     for (size_t i = 0; i + 1 < job->n_options; i += 2)
         if (job->options[i]) opt.kv[job->options[i]] = job->options[i + 1] ? job->options[i + 1] : "";
     // What this encoder implements of the option surface (defaults: CLI/Global.cpp:938-989)
-    if (const char* cv = opt.get("c:v")) if (strcmp(cv, "ffv1") != 0) return bail(fail(2, "video codec %s is not supported by rcgpu (only ffv1)", cv));
+    // `rawcooked -c:v ffv1_vulkan[:N]` is the reference's one GPU-selection surface: it puts `-init_hw_device "vulkan=vk:N" -vf hwupload -c:v
+    // ffv1_vulkan` on the command line (CLI/Global.cpp:367-378; test/vulkan.sh:48-56 adds `,debug=0`).  Here that reads "ffv1 on device N":
+    // the codec is this encoder either way, `hwupload` is what the pipeline does anyway, and N picks the HIP device -- unless the caller chose
+    // devices itself (rcgpu_job::device_count, the shim's RCGPU_DEVICES), which stands above the command line.
+    const char* cv = opt.get("c:v");
+    if (cv && strcmp(cv, "ffv1") != 0 && strcmp(cv, "ffv1_vulkan") != 0) return bail(fail(2, "video codec %s is not supported by rcgpu (ffv1, or ffv1_vulkan = ffv1 on the device -init_hw_device names)", cv));
+    int hw_device = -1;
+    if (const char* hw = opt.get("init_hw_device")) {
+        // FFmpeg's syntax: type[=name][:device[,key=value...]]; the reference only ever writes vulkan=vk:N
+        const char* q = hw;
+        if (strncmp(q, "vulkan", 6) != 0 || (q[6] && q[6] != '=' && q[6] != ':' && q[6] != ',')) return bail(fail(2, "-init_hw_device %s is not supported by rcgpu (vulkan[=name][:N]: HIP device N)", hw));
+        q += 6;
+        if (*q == '=') { q++; while (*q && *q != ':' && *q != ',') q++; }
+        hw_device = 0;
+        if (*q == ':') {
+            char* end = nullptr;
+            const long n = strtol(q + 1, &end, 10);
+            if (end == q + 1 || n < 0 || n > 1023 || (*end && *end != ',')) return bail(fail(2, "-init_hw_device %s: the device is a number (vulkan=vk:N)", hw));
+            hw_device = int(n);
+        }
+    } else if (cv && !strcmp(cv, "ffv1_vulkan"))
+        hw_device = 0;                                                  // ffmpeg would pick the first Vulkan device
     // -c:a copy: what the reference asks for above 24 bits (CLI/Main.cpp:300-317) and what test/pcm.sh asks for by hand
     bool audio_copy = false;
     if (const char* ca = opt.get("c:a")) {
@@ -176,8 +197,18 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     // the latter unless `-an` stands in front of it (--framemd5-an)
     const bool want_framemd5 = job->framemd5_path && *job->framemd5_path;
     // the only filter the reference ever asks for is `-vf vflip`, for DPX stored bottom-up (CLI/Main.cpp:207-211)
-    if (const char* vf = opt.get("vf")) if (strcmp(vf, "vflip") != 0) return bail(fail(2, "-vf %s is not supported by rcgpu (only vflip)", vf));
-    const bool vflip_all = opt.has("vf");
+    // ... and `-vf hwupload` beside ffv1_vulkan (CLI/Global.cpp:374), which means nothing here: every frame is uploaded
+    bool vflip_all = false;
+    if (const char* vf = opt.get("vf")) {
+        std::string rest = vf;
+        while (!rest.empty()) {
+            const size_t c = rest.find(',');
+            const std::string one = rest.substr(0, c);
+            rest = c == std::string::npos ? std::string() : rest.substr(c + 1);
+            if (one == "vflip") vflip_all = true;
+            else if (one != "hwupload") return bail(fail(2, "-vf %s is not supported by rcgpu (vflip, hwupload)", vf));
+        }
+    }
     uint32_t context = uint32_t(opt.num("context", 0));
     const uint32_t slicecrc = uint32_t(opt.num("slicecrc", 1));
     // -context 1 uses FFmpeg's level maps unless the compact 5-input model is asked for (the option rcgpu_context_model=compact; on the
@@ -197,8 +228,9 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
     const bool plan_only = opt.num("rcgpu_plan_only", 0) != 0;
     int ndev_visible = plan_only ? 0 : rcgpu_device_count();
     if (ndev_visible <= 0 && codes_something && !plan_only) return bail(fail(4, "no HIP device available -- rcgpu has no CPU encode path"));
-    const int dev0 = std::max(0, job->device_first);
-    int ndev = job->device_count > 0 ? job->device_count : ndev_visible - dev0;
+    const bool hw_chooses = hw_device >= 0 && job->device_count <= 0 && job->device_first <= 0;       // the caller named no devices: the command line does
+    const int dev0 = hw_chooses ? hw_device : std::max(0, job->device_first);
+    int ndev = hw_chooses ? 1 : job->device_count > 0 ? job->device_count : ndev_visible - dev0;
     if (codes_something && !plan_only) {
         if (dev0 >= ndev_visible || ndev <= 0) return bail(fail(4, "device selection %d+%d is outside the %d visible devices", dev0, job->device_count, ndev_visible));
         ndev = std::min(ndev, ndev_visible - dev0);
@@ -274,6 +306,7 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
                 printf("rcgpu plan: audio %s %u ch %u Hz %u bit%s\n", a.info.flavor, a.info.channels, a.info.sample_rate, a.info.bits_per_sample, audio_copy ? " (copied)" : " -> FLAC");
             }
         }
+        if (hw_device >= 0) printf("rcgpu plan: device %d%s\n", dev0, hw_chooses ? " (-init_hw_device)" : " (the caller's choice stands above -init_hw_device)");
         printf("rcgpu plan: output %s%s, %zu attachment(s)%s\n", job->output_path, want_framemd5 ? " + framemd5" : "", job->n_attachments, job->reversibility_path ? " + reversibility data" : "");
         return 0;
     }

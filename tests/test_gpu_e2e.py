@@ -119,6 +119,29 @@ def test_unmodified_rawcooked_drives_the_shim(built, refbin, tmp_path):
     assert os.path.exists(os.path.join(work, "pkg.mkv"))
 
 
+def test_unmodified_rawcooked_selects_the_gpu_the_reference_s_way(built, refbin, tmp_path):
+    """`rawcooked -c:v ffv1_vulkan[:N]` is the reference's own GPU-selection surface (CLI/Global.cpp:367-378: -init_hw_device "vulkan=vk:N" -vf hwupload
+    -c:v ffv1_vulkan): a site that runs it with --bin-name gets this encoder on HIP device N.  Mirrors test/vulkan.sh:48-80 -- encode, decode, byte
+    compare -- and a device that is not there is an Error: line and a failed job, never another device."""
+    import torch
+    work = str(tmp_path)
+    make_package(work, 64, 48, synth.PIX_RGB16_BE, 3, "film", audio=(2, 16, 48000, 6000))
+    r = run([refbin, "--bin-name", SHIM, "-c:v", "ffv1_vulkan:0", "--check", "--hash", "-y", "pkg"], work)
+    assert r.returncode == 0 and OK_LINE in r.stdout, r.stdout + r.stderr
+    r = run([refbin, "-y", "pkg.mkv"], work)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for dirpath, _, files in os.walk(os.path.join(work, "pkg")):
+        for fn in files:
+            src = os.path.join(dirpath, fn)
+            assert open(src, "rb").read() == open(os.path.join(work, "pkg.mkv.RAWcooked", os.path.relpath(src, work)), "rb").read(), fn
+    # the stream is what `-c:v ffv1_vulkan` means to FFmpeg without -context: the small context model (test/vulkan.sh:54 takes -context 1 out)
+    n = torch.cuda.device_count()
+    os.remove(os.path.join(work, "pkg.mkv"))
+    r = run([refbin, "--bin-name", SHIM, "-c:v", "ffv1_vulkan:%d" % n, "--check", "--hash", "-y", "pkg"], work)
+    assert r.returncode != 0 and "outside the %d visible devices" % n in (r.stdout + r.stderr), r.stdout + r.stderr
+    assert not os.path.exists(os.path.join(work, "pkg.mkv")) or os.path.getsize(os.path.join(work, "pkg.mkv")) == 0
+
+
 def test_output_version_2_appends_to_our_mkv(built, refbin, tmp_path):
     """--output-version 2 (Main.cpp:905-929): the encoder gets no reversibility attachment; rawcooked appends its own EBML document
     behind our Segment afterwards -- which only works because the Segment's size is exact -- and then reads the file back."""

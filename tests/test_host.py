@@ -325,7 +325,8 @@ def test_argv_front_end_rejects_what_it_cannot_do(built, tmp_path):
     assert r.returncode == 0 and r.stdout.startswith("rcgpu version")                       # Main.cpp:751-774 parses "<name> version <x>"
     p = tmp_path / "a.dpx"
     p.write_bytes(synth.dpx_file(synth.components(16, 16, 3, 16), synth.PIX_RGB16_BE))
-    for extra in (["-coder", "0"], ["-level", "0"], ["-level", "1", "-slices", "4"], ["-c:v", "ffv1_vulkan"], ["-g", "2"]):
+    for extra in (["-coder", "0"], ["-level", "0"], ["-level", "1", "-slices", "4"], ["-c:v", "ffv1_nvenc"], ["-g", "2"], ["-vf", "scale=8:8"], ["-vf", "hwupload,transpose"],
+                  ["-init_hw_device", "cuda=cu:0"], ["-init_hw_device", "vulkan=vk:x"], ["-init_hw_device", "vulkanize"]):
         r = subprocess.run([shim, "-i", str(p), "-c:v", "ffv1", "-coder", "1", "-level", "3", "-g", "1"] + extra + ["-f", "matroska", str(tmp_path / "o.mkv")],
                            capture_output=True, text=True)
         assert r.returncode != 0 and "Error: " in r.stderr                                  # helpers.sh:81 greps for "Error:"
@@ -784,6 +785,10 @@ def _reference_command_line(refbin, work, seqs, wavs=(), opts=()):
       "audio WAV/PCM/48kHz/16bit/2ch/S/LE 2 ch 48000 Hz 16 bit -> FLAC", "audio WAV/PCM/48kHz/24bit/6ch/S/LE 6 ch 48000 Hz 24 bit -> FLAC"]),
     ("-framerate 24000/1001", {"img": (64, 48, synth.PIX_RGB16_BE, range(6), "dpx")}, {}, ["-framerate", "24000/1001"], ["video 6 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 6x6 fps 24000/1001 first "]),
     ("-coder 2 -slices 16", {"img": (64, 48, synth.PIX_RGB16_BE, range(3), "dpx")}, {}, ["-coder", "2", "-slices", "16"], ["video 3 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 4x4 fps 24/1 first "]),
+    ("-c:v ffv1_vulkan:1 = ffv1 on device 1", {"img": (64, 48, synth.PIX_RGB16_BE, range(3), "dpx")}, {}, ["-c:v", "ffv1_vulkan:1"],
+     ["video 3 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 6x6 fps 24/1 first ", "device 1 (-init_hw_device)"]),
+    ("-c:v ffv1_vulkan", {"img": (64, 48, synth.PIX_RGB16_BE, range(3), "dpx")}, {}, ["-c:v", "ffv1_vulkan"],
+     ["video 3 frames 64x48 DPX/Raw/RGB/16bit/U/BE slices 6x6 fps 24/1 first ", "device 0 (-init_hw_device)"]),
     ("Y 10 bit", {"img": (50, 38, synth.PIX_Y10_FILLEDA_BE, range(3), "dpx")}, {}, [], ["video 3 frames 50x38 DPX/Raw/Y/10bit/U/BE/FilledA slices 4x4 fps 24/1 first "]),
     ("RGBA 12 bit packed", {"img": (48, 32, synth.PIX_RGBA12_PACKED_BE, range(3), "dpx")}, {}, [], ["video 3 frames 48x32 DPX/Raw/RGBA/12bit/U/BE/Packed slices 6x6 fps 24/1 first "]),
 ], ids=lambda x: x if isinstance(x, str) else "")
@@ -794,6 +799,8 @@ def test_shim_plans_what_the_reference_asks_for(built, refbin, tmp_path, name, s
     grid of the reference's -slices, the frame rate."""
     work = str(tmp_path)
     argv = _reference_command_line(refbin, work, seqs, wavs, opts)
+    if "ffv1_vulkan:1" in opts:          # the reference's GPU-selection surface as it writes it (CLI/Global.cpp:367-378, test/vulkan.sh:48-56)
+        assert argv[argv.index("-init_hw_device") + 1] == "vulkan=vk:1" and argv[argv.index("-vf") + 1] == "hwupload" and argv[argv.index("-c:v", argv.index("-i")) + 1] == "ffv1_vulkan"
     shim = os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")
     r = subprocess.run([shim] + argv[1:-1] + ["-rcgpu_plan_only", "1", argv[-1]], cwd=work, capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -864,3 +871,13 @@ def test_plan_only_analyses_a_job_without_a_device(built, tmp_path):
     assert r.returncode == 0                                                                 # (the plan stops before the files behind the first are opened)
     r = subprocess.run([shim, "-f", "concat", "-safe", "0", "-c:v", "dpx", "-i", "missing.txt"] + common, cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0 and "Error: cannot open file list" in r.stderr
+    # the command line test/vulkan.sh:48-56 puts together by hand: -init_hw_device vulkan=vk:N,debug=0 in front, -hwaccel options before the input,
+    # -vf hwupload -c:v ffv1_vulkan in place of -c:v ffv1 and no -context: ffv1 on HIP device N; a caller that named devices itself keeps its choice
+    vk = [shim, "-xerror", "-init_hw_device", "vulkan=vk:2,debug=0", "-hwaccel", "vulkan", "-hwaccel_output_format", "vulkan", "-framerate", "24", "-f", "image2", "-c:v", "dpx",
+          "-start_number", "000000", "-i", "seq/f_%06d.dpx", "-c:a", "flac", "-vf", "hwupload", "-c:v", "ffv1_vulkan", "-coder", "1", "-f", "matroska", "-g", "1", "-level", "3",
+          "-slicecrc", "1", "-slices", "6", "-y", "-rcgpu_plan_only", "1", "-f", "matroska", "out.mkv"]
+    r = subprocess.run(vk, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0 and "rcgpu plan: device 2 (-init_hw_device)" in r.stdout and "rcgpu plan: video 5 frames" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run(vk, cwd=tmp_path, capture_output=True, text=True, env=dict(os.environ, RCGPU_DEVICES="1,1"))
+    assert r.returncode == 0 and "rcgpu plan: device 1 (the caller's choice stands above -init_hw_device)" in r.stdout, r.stdout + r.stderr
+    assert not os.path.exists(tmp_path / "out.mkv")

@@ -10,7 +10,8 @@
 // Then: the encoder's pattern with its arrays 316 KB to 48 MiB apart; the same beside a copy kernel that streams 0.2 to 4 TB/s; and the
 // uniform pattern from 256, 128 and 64 CUs (one workgroup of 16 wavefronts each, their CUs read back from HW_ID).
 // Output: one JSON object per line.  hipcc --offload-arch=gfx950 -O2 tools/gather_region.hip -o tools/bin/gather_region
-// Run: tools/bin/gather_region [GiB to allocate, default 100]   (with three more arguments: a fine sweep of the array distance, lo hi step in KB)
+// Run: tools/bin/gather_region [GiB to allocate, default 100]   (with three more arguments: a fine sweep of the array distance, lo hi step in KB;
+//      with the one word "rec": the record-size rows of round 6 -- 32 / 64 / 128-byte records gathered and written back whole)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +64,99 @@ __global__ __launch_bounds__(64) void k_walk(uint4* __restrict__ region, unsigne
     }
     acc += a.y ^ b.z;
     if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// Round 6: the record size as a template parameter.  REC = 32 is k_walk's wave pattern again; REC = 64 / 128 put every record in a
+// sector pair / a whole 128-byte line of its own (aligned), gathered whole by its lane (REC / 16 loads of 16 bytes, all in one line) and
+// written back whole by REC / 16 neighbouring lanes in ONE store instruction -- no partial sector, no partial line ever leaves the CU.
+// The question ("what's weak" 1 i): the 32-byte write-back costs half the gather-only rate; does a whole-sector or
+// whole-line write-back cost less?  If the ceiling rose by a quarter, the encoder's state records would be laid out that way.
+// PAT 2 (wave: the encoder, all lanes in the wavefront's block) or 0 (flat).
+template <int REC, int PAT, bool WB>
+__global__ __launch_bounds__(64) void k_walk_rec(uint4* __restrict__ region, unsigned long long span, unsigned long long stride, uint32_t iters, uint32_t seed,
+                                                 unsigned long long* __restrict__ sink)
+{
+    constexpr int V = REC / 16;                      // 16-byte vectors per record = lanes that share a write-back
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    const unsigned long long base = PAT == 0 ? 0ull : size_t(wave) * stride;
+    uint32_t s = mix(seed + wave * 64u + lane);
+    auto draw = [&]() -> unsigned long long {
+        s = mix(s + 0x9e3779b9u);
+        if (PAT == 0) { const uint32_t t = mix(s ^ 0x51ed270bu); return __umul64hi((static_cast<unsigned long long>(t) << 32) | s, span); }
+        return __umulhi(s, uint32_t(span));
+    };
+    unsigned long long at = base + draw();
+    uint4 r[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) r[k] = region[at * V + k];
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; it++) {
+        uint4 v[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) { v[k] = r[k]; acc += v[k].x ^ v[k].w; v[k].x += 1; }
+        const unsigned long long was = at;
+        at = base + draw();
+#pragma unroll
+        for (int k = 0; k < V; k++) r[k] = region[at * V + k];
+        if (WB) {
+            // store instruction h writes the records of lanes h * (64 / V) .. : V lanes side by side cover one record
+            uint4 mine = v[0];
+#pragma unroll
+            for (int k = 1; k < V; k++) mine = (lane % V) == uint32_t(k) ? v[k] : mine;
+#pragma unroll
+            for (int h = 0; h < V; h++) {
+                const int srcl = h * (64 / V) + int(lane / V);
+                const uint32_t lo = uint32_t(__shfl(int(uint32_t(was)), srcl));
+                const uint32_t hi = uint32_t(__shfl(int(uint32_t(was >> 32)), srcl));
+                const unsigned long long rec = (static_cast<unsigned long long>(hi) << 32) | lo;
+                region[rec * V + (lane % V)] = mine;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; k++) acc += r[k].y ^ r[k].z;
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int REC, int PAT, bool WB>
+static double run_rec(uint4* region, unsigned long long span, unsigned long long stride, uint32_t waves, uint32_t iters, unsigned long long* sink)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_walk_rec<REC, PAT, WB>), dim3(waves), dim3(64), 0, nullptr, region, span, stride, iters / 8, 1u, sink);
+    CHECK(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL((k_walk_rec<REC, PAT, WB>), dim3(waves), dim3(64), 0, nullptr, region, span, stride, iters, 7u, sink);
+    CHECK(hipEventRecord(e1, nullptr));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+    return double(ms) * 1e-3;
+}
+
+template <int REC>
+static void record_rows(uint4* region, unsigned long long nbytes, uint32_t ncu, unsigned long long* sink)
+{
+    const unsigned long long total = 1ull << 30;                               // records per run
+    const unsigned long long blk = 2ull * 5063;                                // records per wavefront's array: two plane sets x 5063 contexts
+    for (uint32_t wpc : { 8u, 10u, 12u }) {
+        const uint32_t waves = ncu * wpc, iters = uint32_t(total / (size_t(waves) * 64));
+        if (size_t(waves) * blk * REC > nbytes) continue;
+        const double t0 = run_rec<REC, 2, false>(region, blk, blk, waves, iters, sink), t2 = run_rec<REC, 2, true>(region, blk, blk, waves, iters, sink);
+        const double recs = double(waves) * 64 * iters;
+        printf("{\"pattern\": \"wave\", \"record_bytes\": %d, \"lanes_per_write_back\": %d, \"block_kb\": %.0f, \"waves_per_cu\": %u, \"region_gib\": %.2f, "
+               "\"gather_only_G_per_s\": %.2f, \"gather_writeback_G_per_s\": %.2f}\n", REC, REC / 16, double(blk) * REC / 1024, wpc, double(waves) * blk * REC / double(1ull << 30),
+               recs / t0 * 1e-9, recs / t2 * 1e-9);
+        fflush(stdout);
+    }
+    for (double r : { 0.125, 4.0, 64.0 }) {                                    // flat: is it the pattern or the memory?
+        const unsigned long long span = static_cast<unsigned long long>(r * double(1ull << 30)) / REC;
+        if (span * REC > nbytes) continue;
+        const uint32_t waves = ncu * 8, iters = uint32_t(total / (size_t(waves) * 64));
+        const double t0 = run_rec<REC, 0, false>(region, span, 0, waves, iters, sink), t2 = run_rec<REC, 0, true>(region, span, 0, waves, iters, sink);
+        const double recs = double(waves) * 64 * iters;
+        printf("{\"pattern\": \"flat\", \"record_bytes\": %d, \"lanes_per_write_back\": %d, \"region_gib\": %.3f, \"waves_per_cu\": 8, "
+               "\"gather_only_G_per_s\": %.2f, \"gather_writeback_G_per_s\": %.2f}\n", REC, REC / 16, r, recs / t0 * 1e-9, recs / t2 * 1e-9);
+        fflush(stdout);
+    }
 }
 
 // A stream beside the gathers: `groups` workgroups of 256 copy `bytes_each` bytes each, 16 bytes per lane and turn, `turns` times over
@@ -141,6 +235,12 @@ int main(int argc, char** argv)
     CHECK(hipMemset(region, 0x80, nrec * 32));
     CHECK(hipDeviceSynchronize());
     printf("{\"cus\": %u, \"allocated_gib\": %.1f}\n", ncu, double(nrec) * 32 / double(1ull << 30));
+    if (argc > 2 && argv[2][0] == 'r') {                                        // tools/bin/gather_region <GiB> rec: the record-size rows of round 6 only
+        record_rows<32>(region, nrec * 32, ncu, sink);
+        record_rows<64>(region, nrec * 32, ncu, sink);
+        record_rows<128>(region, nrec * 32, ncu, sink);
+        return 0;
+    }
     const unsigned long long total = 1ull << 31;                              // records per run
     // ---- flat: the whole chip draws from one region of R GiB
     for (double r : { 0.125, 1.0, 4.0, 8.0, 16.0, 32.0, 64.0, 96.0 }) {
