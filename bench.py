@@ -639,7 +639,8 @@ def check_leg(args, torch, api, record, frames, d_packets, sizes, ptrs, stride, 
                      "per_launch_ms": per_launch, "hash_on_cus_of_its_own": not os.environ.get("RCGPU_NO_CU_PARTITION"), **request_roofline(width * height * 3 * D / (kt[dom] * 1e-3) if dom in kt and kt[dom] else 0)},
         **({"cpu_baseline": cpu_rec} if cpu_rec else {}), **({"linked_check": linked_rec} if linked_rec else {})}
     if getattr(args, "check_offsets", ""):
-        # One allocation, several base addresses (rcgpu_ffv1_decoder_debug_states_offset): does k_dec_slices' time depend on where its states lie?
+        # One allocation, several base addresses (rcgpu_ffv1_decoder_debug_states_offset; the decoder leaves room for them when RCGPU_DEC_STATES_SLACK=1
+        # is set before it is made -- main() does for --check-offsets): does k_dec_slices' time depend on where its states lie?
         # Every offset in turn, three rounds, the kernel alone on the device (no hash beside it), its own HIP events.
         offs = [int(x) for x in args.check_offsets.split(",") if x.strip()]
         table = {str(o): [] for o in offs}
@@ -981,6 +982,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("RCGPU_BENCH_BATCH", "336")), help="frames in flight per GPU per step")
     ap.add_argument("--segments", type=int, default=0, help="hand-over windows per slice between k_resolve and k_rangecode (0 = library default)")
+    ap.add_argument("--rc-span", type=int, default=0, help="range coder mapping: 0 = the library's choice (whole slices from 300 wavefronts of chains), 1 = whole slices, >= 8 = split coder with spans of that many pieces")
     ap.add_argument("--run-on", type=int, default=1, help="1: the timed steps in the encoder's run-on mode (batch k+1 started while batch k is coded); 0: one batch at a time")
     ap.add_argument("--check-batch", type=int, default=1600, help="check leg: frames decoded per step (>= --batch)")
     ap.add_argument("--kind", default="film", choices=["film", "flat", "noise"])
@@ -1011,6 +1013,8 @@ def main():
     ap.add_argument("--mode", default="encode", choices=["encode", "check"],
                     help="check: BASELINE config 5 alone -- device FFV1 decode + inverse transform + byte compare + MD5 of the encoder's packets")
     args = ap.parse_args()
+    if args.check_offsets:
+        os.environ["RCGPU_DEC_STATES_SLACK"] = "1"
     t_bench = time.perf_counter()
     marks = []
 
@@ -1064,7 +1068,7 @@ def main():
     nh, nv = api.slices_to_grid(args.slices)
     frames = make_frames(torch, F, width, height, args.kind, rank, dev)
     ctx = 2 if args.context_model == "compact" else 1
-    enc = api.Ffv1Encoder(width, height, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=F, device=local_rank, segments=args.segments)
+    enc = api.Ffv1Encoder(width, height, pixfmt, line_bytes, nh, nv, 1, ctx, max_batch=F, device=local_rank, segments=args.segments, rc_span=args.rc_span)
     stride = (enc.max_packet + 255) & ~255
     d_packets = torch.empty(F * stride, dtype=torch.uint8, device=dev)
     d_sizes = torch.zeros(F, dtype=torch.int64, device=dev)

@@ -193,7 +193,8 @@ int rcgpu_ffv1_encode_device(rcgpu_ffv1* enc, const void* const* d_frames, uint3
  * makes `hip_stream` wait for batch k only: packets and sizes of the batch passed to a call are complete, in stream order, after the
  * NEXT call or after rcgpu_ffv1_join().  A batch's frames may be reused as soon as its call has returned, as before (k_model has
  * read them); consecutive batches get different d_packets / d_packet_sizes if the caller reads them in between.  Costs a second set
- * of per-batch buffers (symbols, states, coder output: rcgpu_ffv1_set_run_on fails if they do not fit); same packets, byte for byte. */
+ * of per-batch buffers (symbols, states, coder output: rcgpu_ffv1_set_run_on fails if they do not fit); same packets, byte for byte.
+ * Works with either mapping of the range coder (rc_span): the split coder's checkpoints are kept per bank as well. */
 int rcgpu_ffv1_set_run_on(rcgpu_ffv1* enc, int on);
 int rcgpu_ffv1_run_on(const rcgpu_ffv1* enc);                 /* 1 when the mode is on */
 /* Makes `hip_stream` wait for every batch issued so far (the last one, in run-on mode). */
@@ -393,11 +394,13 @@ int  rcgpu_ffv1_config_from_stream(const uint8_t* record, size_t size, const uin
  *   return 0                       parsed; *stream must be freed with rcgpu_ffv1_stream_free
  *   return RCGPU_FFV1_UNSUPPORTED  a valid stream the device decoder does not take (Golomb-Rice; more slice rows than columns -- which the
  *                                  reference itself misreads, FFV1_Slice.cpp:125, so that its verdict must stay its own; and from _create_for_stream: YUV planes,
- *                                  inter frames, a state 0 within reach of the initial states): the caller decodes it with its own decoder --
+ *                                  gray with an alpha plane, inter frames, a state 0 within reach of the initial states): the caller decodes it with its own decoder --
  *                                  ffv1_frame::Process stays on its slice pool (oracle/route_c_ffv1_frame_cpp.patch)
  *   any other value                what the reference refuses as well (its error in rcgpu_last_error()), a record that ends before its fields do,
  *                                  or a first frame that is no key frame / whose first slice header the reference flags.  The reader is held to
  *                                  the reference's own (tests/golden/parse_cases.*): what the reference refuses it refuses, what both read they read alike.
+ *   from _create_for_stream also 5 a valid stream that describes OTHER files than `files` (RGB against gray, another bit depth, alpha against none;
+ *                                  with colorspace_type 1 chroma_planes is ignored, as the reference ignores it, FFV1_Parameters.cpp:174)
  * rcgpu_ffv1_decoder_create_for_stream takes width, height, pixfmt, line_bytes, flags, max_batch and device from `files` (the stream fields
  * of the struct are ignored) and everything else from `stream`; it fails when the stream does not describe `pixfmt` (colorspace, bit
  * depth, alpha).  The decoder it makes is used like any other; a slice whose header names other table sets than the first slice did
@@ -429,8 +432,11 @@ int  rcgpu_compare_device(const void* d_a, const void* d_b, uint64_t n, uint64_t
 int  rcgpu_compare_device_batch(const void* const* d_a, const void* const* d_b, const uint64_t* sizes, uint32_t n, uint64_t* first_diff, void* hip_stream);
 /* The library's CU-masked streams -- one hash stream per device for rcgpu_md5_device / rcgpu_analysis_host_batch, and the (decode, hash) pairs its
  * decoders borrow from a pool -- live as long as the library (they are pooled, not destroyed with a decoder: the HIP runtime of ROCm 7.0 cannot
- * survive an out-of-memory hipMalloc once such a stream has been destroyed).  This call destroys the ones not in use; they are made again on the
- * next use.  Meant for the end of a process (a profiler's finalisation after this library's streams); not needed for correctness. */
+ * survive an out-of-memory hipMalloc once such a stream has been destroyed).  This call is for the END OF A PROCESS only (a profiler's
+ * finalisation after this library's streams; not needed for correctness): it destroys the ones not in use and latches -- from then on the library
+ * makes and hands out plain streams only (same results; the hash shares CUs with the decoder), a decoder still alive gives its pair back to
+ * be destroyed, and an rcgpu_md5_device that is in flight on another thread must have returned before the call.  On ROCm 7.0 an out-of-memory
+ * hipMalloc AFTER this call may crash the process (the runtime's defect above): do not rely on allocation errors behind it. */
 void rcgpu_release_device_streams(void);
 /* MD5 of n device buffers, one lane per buffer; out_md5 = n x 16 bytes on the host (FileWriter.cpp:596-727). */
 int  rcgpu_md5_device(const void* const* d_bufs, const uint64_t* sizes, uint32_t n, uint8_t* out_md5, void* hip_stream);

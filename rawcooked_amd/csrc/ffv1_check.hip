@@ -767,8 +767,12 @@ static bool partition_streams(int device, hipStream_t* decode, hipStream_t* hash
 // that error code (route C halves its batch on it, rcgpu_ffv1_set_run_on falls back to one batch at a time).
 struct masked_pair { hipStream_t decode, hash; };
 static std::mutex g_pool_mu; static std::vector<masked_pair> g_pool[16];
+// set by rcgpu_release_device_streams: from then on nothing CU-masked is made or handed out (plain streams: same bytes, the hash beside the decoder
+// on shared CUs) -- a masked stream made after the release would be destroyed by nobody, and one handed out across it by somebody else
+static std::atomic<bool> g_streams_released{ false };
 static bool acquire_masked_pair(int device, hipStream_t* decode, hipStream_t* hash)
 {
+    if (g_streams_released.load()) return false;
     {
         std::lock_guard<std::mutex> g(g_pool_mu);
         std::vector<masked_pair>& P = g_pool[device & 15];
@@ -781,6 +785,7 @@ static void release_masked_pair(int device, hipStream_t decode, hipStream_t hash
     if (!decode || !hash) return;
     (void)hipStreamSynchronize(decode); (void)hipStreamSynchronize(hash);
     std::lock_guard<std::mutex> g(g_pool_mu);
+    if (g_streams_released.load()) { (void)hipStreamDestroy(decode); (void)hipStreamDestroy(hash); return; }      // a decoder that outlived the release
     g_pool[device & 15].push_back({ decode, hash });
 }
 static std::mutex g_hash_mu; static hipStream_t g_hash_st[16]; static bool g_hash_tried[16];
@@ -788,6 +793,7 @@ static hipStream_t device_hash_stream(int device)
 {
     std::lock_guard<std::mutex> g(g_hash_mu);
     const int k = device & 15;
+    if (g_streams_released.load()) return nullptr;
     if (!g_hash_tried[k]) { g_hash_tried[k] = true; g_hash_st[k] = nullptr; if (!partition_streams(device, nullptr, &g_hash_st[k])) g_hash_st[k] = nullptr; }
     return g_hash_st[k];
 }
@@ -795,6 +801,7 @@ static hipStream_t device_hash_stream(int device)
 // after this library's streams, say) gives them back itself.
 extern "C" void rcgpu_release_device_streams(void)
 {
+    g_streams_released.store(true);
     {
         std::lock_guard<std::mutex> g(g_hash_mu);
         for (int k = 0; k < 16; k++)
@@ -830,7 +837,7 @@ struct rcgpu_ffv1_decoder {
     unsigned long long* d_slice_start = nullptr; uint32_t* d_slice_len = nullptr; uint16_t* d_hdr = nullptr;
     uint8_t* d_states = nullptr; int32_t* d_planes = nullptr; uint32_t* d_err = nullptr;
     uint8_t* d_init = nullptr;                     // one chain's initial states when the stream codes them (states_coded), else null: all 128
-    size_t states_off = 0;                         // test hook (rcgpu_ffv1_decoder_debug_states_offset): the state arrays begin this far into their allocation
+    size_t states_off = 0, states_slack = 0;       // test hook (rcgpu_ffv1_decoder_debug_states_offset): the state arrays begin this far into their allocation
     void** h_ptrs = nullptr; unsigned long long* h_sizes = nullptr;
     hipStream_t own_stream = nullptr;
     hipStream_t dec_stream = nullptr;              // k_dec_slices' stream when the hash has CUs of its own (partition_streams), else null
@@ -896,7 +903,9 @@ extern "C" void rcgpu_ffv1_decoder_destroy(rcgpu_ffv1_decoder* d)
     delete d;
 }
 
-constexpr size_t kStatesSlack = size_t(64) << 20;      // room behind the state arrays for rcgpu_ffv1_decoder_debug_states_offset
+// room behind the state arrays for rcgpu_ffv1_decoder_debug_states_offset -- only in a process that asks for the hook (RCGPU_DEC_STATES_SLACK=1,
+// bench.py --check-offsets): a production decoder allocates what it uses
+constexpr size_t kStatesSlack = size_t(64) << 20;
 
 // The decoder of the stream `s` for pictures laid out as `files` says (width, height, pixfmt, line_bytes, flags; max_batch, device).
 static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_desc& s, rcgpu_ffv1_decoder** out)
@@ -918,8 +927,12 @@ static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_des
     if (px.fields != kFieldsBytes && px.fields != kFieldsExr && !altern && cfg->line_bytes % 4) return fail(2, "ffv1 decoder: line_bytes of a word-stream layout must be a multiple of 4");
     // the stream against the files, and against what the device decodes
     const bool rgb = px.planes != 1;
+    // Valid streams no pixel format here describes are the CALLER's decoder's (kUnsupported), a stream that describes other files than these is an
+    // error (5).  With colorspace_type 1 the reference counts 3 or 4 planes whatever chroma_planes says (FFV1_Parameters.cpp:174); gray with an alpha
+    // plane (:169: two planes) it decodes as well.
     if (s.colorspace_type == 0 && s.chroma_planes) return fail(ffv1::kUnsupported, "ffv1 decoder: YCbCr planes are not decoded on the device");
-    if (s.colorspace_type != (rgb ? 1u : 0u) || s.bits_per_raw_sample != px.bits || s.chroma_planes != rgb || s.alpha_plane != (px.planes == 4))
+    if (s.colorspace_type == 0 && s.alpha_plane) return fail(ffv1::kUnsupported, "ffv1 decoder: gray with an alpha plane is not decoded on the device");
+    if (s.colorspace_type != (rgb ? 1u : 0u) || s.bits_per_raw_sample != px.bits || (rgb && s.alpha_plane != (px.planes == 4)))
         return fail(5, "ffv1 decoder: stream (colorspace %u, %u bit%s) does not match the pixel format of the files", s.colorspace_type, s.bits_per_raw_sample, s.alpha_plane ? ", alpha" : "");
     if (s.version == 3 && s.intra != 1) return fail(ffv1::kUnsupported, "ffv1 decoder: inter frames (intra = 0) are not decoded on the device");
     if (s.version == 3 && (s.num_h_slices >= cfg->width || s.num_v_slices >= cfg->height || s.num_h_slices > 0xFFFF || s.num_v_slices > 0xFFFF))      // FFV1_Frame.cpp:161-164
@@ -957,10 +970,11 @@ static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_des
     d->nkeys = nkeys;
     d->payload_bytes = size_t(cfg->line_bytes) * cfg->height;
     const uint32_t F = cfg->max_batch; const size_t nchains = size_t(F) * c.S;
+    if (const char* e = getenv("RCGPU_DEC_STATES_SLACK")) if (*e && *e != '0') d->states_slack = kStatesSlack;
     hipError_t he = hipSuccess;
 #define DM(p, b) if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&(p)), (b))
     DM(d->d_const, sizeof c); DM(d->d_pkt_ptrs, sizeof(void*) * F); DM(d->d_out_ptrs, sizeof(void*) * F); DM(d->d_sizes, 8 * F);
-    DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32 + kStatesSlack); DM(d->d_hdr, hdr.size() * 2 + 16);
+    DM(d->d_slice_start, nchains * 8); DM(d->d_slice_len, nchains * 4); DM(d->d_states, nchains * d->nkeys * 32 + d->states_slack); DM(d->d_hdr, hdr.size() * 2 + 16);
     std::vector<uint8_t> init;
     if (coded) {                                                      // one chain's states as GOP_Init leaves them
         init.assign(size_t(nkeys) * 32, 128);
@@ -1571,7 +1585,7 @@ extern "C" int rcgpu_ffv1_decoder_debug_window(rcgpu_ffv1_decoder* d, uint32_t b
 // one allocation, two base addresses: does the decoder's time depend on WHERE its 33 GB of states lie?  (tools/check_offsets.py)
 extern "C" int rcgpu_ffv1_decoder_debug_states_offset(rcgpu_ffv1_decoder* d, uint64_t bytes)
 {
-    if (!d || (bytes & 255) || bytes > kStatesSlack) return 1;
+    if (!d || (bytes & 255) || bytes > d->states_slack) return 1;
     d->states_off = size_t(bytes);
     return 0;
 }

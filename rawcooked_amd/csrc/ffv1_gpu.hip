@@ -1424,13 +1424,15 @@ struct rcgpu_ffv1 {
         unsigned long long* d_ndec = nullptr; unsigned long long* d_total_n = nullptr; uint32_t* d_seg_pieces = nullptr; unsigned long long* d_group_off = nullptr;
         uint8_t* d_k3_resume = nullptr; rc_resume* d_k4_resume = nullptr; uint8_t* d_cbuf = nullptr; uint32_t* d_out_len = nullptr; uint32_t* d_tot_len = nullptr;
         unsigned long long* d_slice_dst = nullptr; uint32_t* d_err = nullptr; uint2* d_events = nullptr;
+        rc_ckpt* d_ckpt = nullptr; size_t ckpt_cap = 0;       // split coder: a batch's checkpoints are read until its k_rc_tails has run
         hipEvent_t ev_done = nullptr;              // behind the last kernel of the bank's batch
         bool used = false, joined = true;          // a batch has run in it; a caller's stream has been made to wait for it
     } alt;
     hipEvent_t ev_done = nullptr; bool used = false, joined = true;       // the current bank's
     bool run_on = false, alt_allocated = false;
     hipStream_t model_stream = nullptr, front_stream = nullptr, tail_stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_model = nullptr;
+    hipStream_t front_own = nullptr, chain_stream = nullptr;     // run-on mode with the split coder: k_resolve's own stream, k_rc_range's (high priority)
+    hipEvent_t ev_in = nullptr, ev_model = nullptr, ev_tails = nullptr;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
     uint32_t last_n = 0;
     hipEvent_t input_event = nullptr;              // pipeline, run-on mode: the next batch's frames are on the device when this event has happened
@@ -1456,13 +1458,14 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
     void* bufs[] = { e->d_const, e->d_geom, e->d_hdr, e->d_frame_ptrs, e->d_planes, e->d_sym, e->d_states, e->d_ndec, e->d_total_n, e->d_seg_pieces,
                      e->d_group_off, e->d_k3_resume, e->d_k4_resume, e->d_cbuf, e->d_out_len, e->d_tot_len,
                      e->d_slice_dst, e->d_err, e->d_events, e->d_in, e->d_packets, e->d_psizes, e->d_ckpt };
-    for (hipStream_t q : { e->model_stream, e->front_stream, e->tail_stream, e->rc_stream }) if (q) (void)hipStreamSynchronize(q);
+    for (hipStream_t q : { e->model_stream, e->front_stream, e->tail_stream, e->rc_stream, e->rr_stream, e->chain_stream }) if (q) (void)hipStreamSynchronize(q);
     for (void* b : bufs) if (b) (void)hipFree(b);
     void* abufs[] = { e->alt.d_frame_ptrs, e->alt.d_sym, e->alt.d_states, e->alt.d_ndec, e->alt.d_total_n, e->alt.d_seg_pieces, e->alt.d_group_off, e->alt.d_k3_resume,
                       e->alt.d_k4_resume, e->alt.d_cbuf, e->alt.d_out_len, e->alt.d_tot_len, e->alt.d_slice_dst, e->alt.d_err, e->alt.d_events };
     for (void* b : abufs) if (b) (void)hipFree(b);
-    for (hipEvent_t q : { e->ev_done, e->alt.ev_done, e->ev_in, e->ev_model }) if (q) (void)hipEventDestroy(q);
-    for (hipStream_t q : { e->model_stream, e->tail_stream }) if (q) (void)hipStreamDestroy(q);       // (front_stream is rr_stream)
+    if (e->alt.d_ckpt) (void)hipFree(e->alt.d_ckpt);
+    for (hipEvent_t q : { e->ev_done, e->alt.ev_done, e->ev_in, e->ev_model, e->ev_tails }) if (q) (void)hipEventDestroy(q);
+    for (hipStream_t q : { e->model_stream, e->tail_stream, e->front_own, e->chain_stream }) if (q) (void)hipStreamDestroy(q);       // (front_stream is rr_stream or front_own)
     for (uint8_t* w : e->d_window) if (w) (void)hipFree(w);
     void* hosts[] = { e->h_psizes, e->h_ndec_pinned, e->h_frame_ptrs, e->h_total_n, e->h_seg_pieces, e->h_group_off, e->h_err };
     for (void* h : hosts) if (h) (void)hipHostFree(h);
@@ -1688,11 +1691,11 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     static const bool exp_serial = TIMING_ENV("RCGPU_EXP_SERIAL") != nullptr;      // timing runs: every kernel alone on the device, one after the other
     if (exp_serial) s2 = st;
     // run-on mode: this batch goes into the other bank; modelling, resolving and the batch's tail get streams of their own (see rcgpu_ffv1)
-    const bool ro = e->run_on && !exp_serial && !e->span_pieces && !e->exp_skip_rc;
+    const bool ro = e->run_on && !exp_serial && !e->exp_skip_rc;
     if (ro) {
 #define SW(f) std::swap(e->f, e->alt.f)
         SW(d_frame_ptrs); SW(d_sym); SW(d_states); SW(d_ndec); SW(d_total_n); SW(d_seg_pieces); SW(d_group_off); SW(d_k3_resume); SW(d_k4_resume);
-        SW(d_cbuf); SW(d_out_len); SW(d_tot_len); SW(d_slice_dst); SW(d_err); SW(d_events); SW(ev_done); SW(used); SW(joined);
+        SW(d_cbuf); SW(d_out_len); SW(d_tot_len); SW(d_slice_dst); SW(d_err); SW(d_events); SW(d_ckpt); SW(ckpt_cap); SW(ev_done); SW(used); SW(joined);
 #undef SW
     }
     if (!ro) e->input_event = nullptr;                   // (one batch at a time: everything follows the caller's stream anyway)
@@ -1771,6 +1774,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
         }
         const size_t need = size_t(total_spans) * nchains * sizeof(rc_ckpt);
         if (need > e->ckpt_cap) {
+            // (run-on mode: this bank's checkpoints; its last batch has run -- the model stream waited for it above and the host for the model stream)
             if (e->d_ckpt) HIP_TRY(hipFree(e->d_ckpt));
             e->d_ckpt = nullptr; e->ckpt_cap = 0;
             const size_t want = need + need / 8 + (1u << 20);
@@ -1796,7 +1800,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     // k_resolve(seg j) on the caller's stream, k_rangecode(seg j) on rc_stream; window j % nwin is reused once k_rangecode(j - nwin) is done.
     // Split coder: k_rc_range(seg j) on rr_stream between the two -- it follows k_resolve(j) and its own previous segment, the spans of
     // segment j follow it and nothing else.
-    hipStream_t s3 = exp_serial ? st : e->rr_stream;
+    hipStream_t s3 = exp_serial ? st : (ro && e->chain_stream) ? e->chain_stream : e->rr_stream;
     HIP_TRY(hipEventRecord(e->ev_fork, fr));
     HIP_TRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
     if (e->span_pieces) HIP_TRY(hipStreamWaitEvent(s3, e->ev_fork, 0));
@@ -1847,7 +1851,10 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
                                                       e->d_cbuf, (unsigned long long)e->cbuf_frame_stride); }));
     // footer / scan / gather follow the last range-coder segment -- on its stream, or in run-on mode on the tail stream, beside the next
     // batch's first coder segments; then the caller's stream joins: this batch, or in run-on mode the batch before it
-    if (tl != s2) HIP_TRY(hipStreamWaitEvent(tl, k4_last, 0));
+    if (tl != s2) {
+        if (e->span_pieces && !e->exp_skip_rc) { HIP_TRY(hipEventRecord(e->ev_tails, s2)); HIP_TRY(hipStreamWaitEvent(tl, e->ev_tails, 0)); }    // (behind k_rc_tails, which follows the last span)
+        else HIP_TRY(hipStreamWaitEvent(tl, k4_last, 0));
+    }
     HIP_TRY(timed(4, tl, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, tl, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));
     HIP_TRY(timed(5, tl, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, tl, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
@@ -1877,11 +1884,10 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
     if (!e) return fail(1, "ffv1: null argument");
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (!on) {
-        if (e->run_on) for (hipStream_t q : { e->model_stream, e->front_stream, e->rc_stream, e->tail_stream }) if (q) HIP_TRY(hipStreamSynchronize(q));
+        if (e->run_on) for (hipStream_t q : { e->model_stream, e->front_stream, e->rc_stream, e->tail_stream, e->chain_stream }) if (q) HIP_TRY(hipStreamSynchronize(q));
         e->run_on = false; e->joined = true; e->alt.joined = true;
         return 0;
     }
-    if (e->span_pieces) return fail(2, "ffv1: run-on mode and the split range coder (rc_span) exclude each other");
     if (!e->alt_allocated) {
         const uint32_t F = e->cfg.max_batch, S = e->hc.S, nseg = e->nseg;
         const size_t nchains = size_t(F) * S, ngroups = (nchains + 63) / 64;
@@ -1895,6 +1901,7 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
         if (he == hipSuccess) he = hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_model, hipEventDisableTiming);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_tails, hipEventDisableTiming);
         // Five streams are busy or waiting at any time (the caller's, model, front, coder, tail) and a stream that waits holds up whatever
         // shares its hardware queue: ROCm deals the streams of ONE priority to four hardware queues (GPU_MAX_HW_QUEUES), those of another
         // priority to four others.  Model and tail, the background of the batch in flight, take the low priority's; measured with all five
@@ -1905,6 +1912,14 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
         if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->model_stream, hipStreamNonBlocking, lo);
         if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->tail_stream, hipStreamNonBlocking, lo);
         e->front_stream = e->rr_stream;             // the split coder's stream, idle in this mode: no fifth stream at the normal priority
+        if (e->span_pieces) {
+            // The split coder in run-on mode (round 6) keeps SIX streams busy: k_rc_range -- the one serial chain left, nine dependent instructions
+            // per decision -- gets a stream at the HIGH priority (hardware queues of its own, and its few wavefronts are dispatched first), k_resolve a
+            // stream of its own at the normal priority beside the spans' (rc_stream) and the caller's.
+            if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->chain_stream, hipStreamNonBlocking, hi);
+            if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->front_own, hipStreamNonBlocking, 0);
+            e->front_stream = e->front_own;
+        }
         if (he != hipSuccess) {
             // nothing of a half-made bank stays behind: the memory it holds is what the first batch's windows need, and a second attempt
             // would overwrite (leak) the pointers
@@ -1913,8 +1928,8 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
             for (void* q : abufs) if (q) (void)hipFree(q);
             b.d_frame_ptrs = nullptr; b.d_sym = nullptr; b.d_states = nullptr; b.d_ndec = nullptr; b.d_total_n = nullptr; b.d_seg_pieces = nullptr; b.d_group_off = nullptr;
             b.d_k3_resume = nullptr; b.d_k4_resume = nullptr; b.d_cbuf = nullptr; b.d_out_len = nullptr; b.d_tot_len = nullptr; b.d_slice_dst = nullptr; b.d_err = nullptr; b.d_events = nullptr;
-            for (hipEvent_t* q : { &b.ev_done, &e->ev_in, &e->ev_model }) if (*q) { (void)hipEventDestroy(*q); *q = nullptr; }
-            for (hipStream_t* q : { &e->model_stream, &e->tail_stream }) if (*q) { (void)hipStreamDestroy(*q); *q = nullptr; }
+            for (hipEvent_t* q : { &b.ev_done, &e->ev_in, &e->ev_model, &e->ev_tails }) if (*q) { (void)hipEventDestroy(*q); *q = nullptr; }
+            for (hipStream_t* q : { &e->model_stream, &e->tail_stream, &e->front_own, &e->chain_stream }) if (*q) { (void)hipStreamDestroy(*q); *q = nullptr; }
             e->front_stream = nullptr;
             e->run_on = false;
             (void)hipGetLastError();

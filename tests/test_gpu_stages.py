@@ -95,19 +95,22 @@ def test_many_frames_cross_sub_batches(built):
     enc.close()
 
 
+@pytest.mark.parametrize("rc_span", [1, 8, 64], ids=["whole-slice coder", "split coder, spans of 8 pieces", "split coder, spans of 64"])
 @pytest.mark.parametrize("segments", [1, 5, 32])
 @pytest.mark.parametrize("w,h,pixfmt,slices,nframes", [(200, 120, synth.PIX_RGB16_BE, 6, 5), (96, 64, synth.PIX_RGB10_FILLEDA_BE, 4, 70), (512, 270, synth.PIX_RGB16_BE, 1, 3)])
-def test_run_on_mode_is_bit_exact(built, w, h, pixfmt, slices, nframes, segments):
+def test_run_on_mode_is_bit_exact(built, w, h, pixfmt, slices, nframes, segments, rc_span):
     """Run-on mode (rcgpu_ffv1_set_run_on): batch k+1 is modelled and started while batch k is in flight, two banks of per-batch buffers,
     the windows' ring running through.  Seven batches of different pictures and sizes (the last ones short), each into buffers of its own:
-    every packet equals the oracle's, whatever was in flight beside it; then back to one batch at a time with the same encoder."""
+    every packet equals the oracle's, whatever was in flight beside it; then back to one batch at a time with the same encoder.
+    With either mapping of the range coder (round 6: the split coder -- k_rc_range's nine-instruction chain, spans, tails -- runs on as well:
+    checkpoints per bank, k_resolve and the chain on streams of their own, the tail behind k_rc_tails)."""
     import torch
     bits, nc, bpp, be = synth.PIX_INFO[pixfmt]
     nh, nv = api.slices_to_grid(slices)
     p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
     sizes_of = [nframes, nframes, max(1, nframes // 2), nframes, 1, nframes, max(1, nframes - 1)]
     line_bytes = synth.pack_payload(synth.components(w, h, nc, bits, "flat", seed=0), pixfmt, True)[1]
-    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=segments, rc_span=1)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=nframes, segments=segments, rc_span=rc_span)
     stride = (enc.max_packet + 255) & ~255
     st = torch.cuda.Stream()
     batches = []
@@ -169,13 +172,6 @@ def test_run_on_mode_and_the_host_conveniences(built):
             assert got[i] == ob.encode_payload(p, pl, line_bytes), f"batch {b} frame {i}"
         assert enc.framemd5_last(len(pls)) == want_sums[b]
         assert enc.error_flags() == 0
-    enc.close()
-
-
-def test_run_on_mode_and_the_split_coder_exclude_each_other(built):
-    enc = api.Ffv1Encoder(64, 48, synth.PIX_RGB16_BE, 64 * 6, 2, 2, 1, 1, max_batch=2, rc_span=8)
-    with pytest.raises(api.RcgpuError, match="run-on"):
-        enc.set_run_on(True)
     enc.close()
 
 
