@@ -49,7 +49,7 @@ def gather_floats(dist, values, device):
 def timed_steps(dist, device, step, steps: int, warmup: int, synchronize, mark=None) -> float:
     """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by barrier + device synchronize on
     both sides; the result is the slowest rank's wall time.  `mark(k)`, if given, is called with -1 when the clock starts and with k
-    after timed step k has been issued (bench.py records a device event there: the per-step times of the line's `step_ms`)."""
+    after timed step k has been issued (bench.py reads the host clock there: the per-step times of the line's `step_ms`)."""
     import time
     for _ in range(max(0, warmup)):
         step()

@@ -93,6 +93,12 @@ enum {   /* pixel layouts; names follow the reference flavors (DPX.cpp:184-231, 
 #define RCGPU_FLAG_VFLIP  1u   /* orientation 2: lines stored bottom to top; the reference then adds "-vf vflip" (Main.cpp:207-211),
                                   picture line y = file line height-1-y (Transform.cpp:181-185).  12-bit Packed flavors only (DPX.cpp:189,204) */
 #define RCGPU_FLAG_ALTERN 2u   /* Y 10-bit from some scanners: words are filled across line ends, no line padding (DPX.cpp:363-368,465-469) */
+/* encoder only (rcgpu_ffv1_config::flags), nothing a header announces: */
+#define RCGPU_FLAG_OWN_SLICE_BUFFERS 0x100u   /* Where every slice is large enough the encoder keeps a slice's coded bytes in the slice's own area of the
+                                  symbol buffer -- the coder writes at most 3.4 bytes where a 4-byte symbol lay that k_resolve has read already -- and
+                                  allocates no slice byte buffers (96 MB per 4K frame in flight, twice that in run-on mode).  A slice whose FIRST
+                                  segments code to more than 4 bytes per sample (16-bit noise with untrained states: 3.4) is then reported as
+                                  overflowing although it may fit 1.5 x raw in the end.  This flag gives the slices buffers of their own again. */
 
 typedef struct {
     uint32_t width, height;
@@ -149,7 +155,7 @@ typedef struct {
     int      device;          /* HIP device ordinal */
     uint32_t segments;        /* hand-over granularity between state resolution and range coding: each slice's decision
                                  stream is produced/consumed in this many windows (0 = automatic, 1 = whole slice) */
-    uint32_t flags;           /* RCGPU_FLAG_VFLIP | RCGPU_FLAG_ALTERN: how the payload is laid out (line_bytes is ignored for ALTERN) */
+    uint32_t flags;           /* RCGPU_FLAG_VFLIP | RCGPU_FLAG_ALTERN: how the payload is laid out (line_bytes is ignored for ALTERN); RCGPU_FLAG_OWN_SLICE_BUFFERS */
     uint32_t coder;           /* -coder: 0 or 1 = range coder with the default state transitions; 2 = range coder whose transition
                                  table travels in the configuration record (FFV1_Parameters.cpp:41-55) */
     uint32_t level;           /* -level: 0 or 3 = FFV1 version 3; 1 = version 1, what the reference asks for with -slices 1
@@ -168,6 +174,10 @@ typedef struct {
 typedef struct rcgpu_ffv1 rcgpu_ffv1;
 
 int    rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** enc);
+/* Device memory ONE frame in flight costs an encoder of this configuration, the caller's payload and packet buffers included (symbols, context
+ * states, decision windows, checkpoints, slice byte buffers where they are not overlaid; run_on != 0: with the second bank of run-on mode).
+ * 4096x2160 RGB16, 64 slices: 348 MB, 454 MB in run-on mode.  Needs no device: what a caller sizes max_batch with (the job level does). */
+uint64_t rcgpu_ffv1_device_bytes_per_frame(const rcgpu_ffv1_config* cfg, int run_on);
 void   rcgpu_ffv1_destroy(rcgpu_ffv1* enc);
 /* FFV1 configuration record incl. CRC = Matroska CodecPrivate (parsed at FFV1_Parameters.cpp:23-183). */
 size_t rcgpu_ffv1_config_record(const rcgpu_ffv1* enc, uint8_t* out, size_t cap);

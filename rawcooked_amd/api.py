@@ -116,6 +116,7 @@ SYMBOLS = {
     "rcgpu_ffv1_destroy": (None, [_VP]),
     "rcgpu_ffv1_config_record": (_SZ, [_VP, _VP, _SZ]),
     "rcgpu_ffv1_max_packet_bytes": (_SZ, [_VP]),
+    "rcgpu_ffv1_device_bytes_per_frame": (C.c_uint64, [_VP, C.c_int]),
     "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rcgpu_ffv1_last_error_flags": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),

@@ -48,6 +48,8 @@ struct enc_const {
     uint32_t samples_per_frame;            // W*H*planes
     uint32_t nseg;                         // segments a slice is cut into for the k_resolve -> k_rangecode hand-over
     uint32_t rc_prio;                      // the whole-slice coder's wave priority (3; the timing build's RCGPU_RC_PRIO measures the others)
+    uint32_t overlay;                      // != 0: the slice byte buffers lie inside the slices' own symbol areas (see rcgpu_ffv1::overlay); the value divides
+                                           // the per-segment limit (1; rcgpu_ffv1_config::slice_buffer_div in the tests of the overflow report)
     int16_t  q[5][256];
     uint8_t  one_state[256], zero_state[256];
 };
@@ -991,6 +993,12 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
     else if (seg) { const rc_resume v = resume[cc]; r.range = v.range; r.low = v.low; r.nb = v.nb; r.pd = v.pd; r.pos = v.pos; }   // nb in bits
     r.out = cbuf + size_t(f) * cbuf_frame_stride + (size_t(G.cbuf_off_hi) << 32 | G.cbuf_off_lo);
     r.cap = int(G.cbuf_cap);
+    // Overlay: the slice's bytes go where its symbols lay.  While segment `seg` is coded k_resolve may be reading the symbols of segment
+    // seg + 1 onwards, which begin 4 * seg_q * (seg + 1) bytes into the area (16 of them in front of the byte buffer): the bytes must stay below
+    // that.  A symbol is four bytes and codes to 3.4 at the very worst (16-bit noise, untrained states), so they do; a slice that does not
+    // is reported as overflowing, like one that outgrows its buffer.
+    const bool seg_limited = C->overlay && !last_seg;
+    if (seg_limited) { const unsigned long long lim = 4ull * G.seg_q * (seg + 1) / C->overlay - 48; if (lim < (unsigned long long)r.cap) r.cap = int(lim); }
 
     unsigned long long maxp = npieces;
     for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_xor(maxp, o); maxp = t > maxp ? t : maxp; }
@@ -1036,6 +1044,7 @@ __global__ __launch_bounds__(64) __attribute__((aligned(4096))) void k_rangecode
     }
     }
     rc_drain<kRows, SPAN, true>(r);
+    if (seg_limited && active && r.pos > r.cap) atomicOr(err, 1u);       // the bytes ran into symbols not read yet: their stores were held back, the batch is void
     if (!SPAN && active && !last_seg) { rc_resume v; v.range = r.range; v.low = r.low; v.nb = r.nb; v.pd = r.pd; v.pos = r.pos; v.pad = 0; resume[cc] = v; }
     if (SPAN && active && !ends_chain) {
         // End of a span: the second stage and the finished bytes leave one by one (the next span's first byte follows directly), the 16
@@ -1324,7 +1333,26 @@ static size_t slice_buffer_bytes(const pix_desc& d, uint32_t w, uint32_t h, uint
     return cap;
 }
 
+// Do the slice byte buffers of this configuration lie inside the slices' symbol areas (rcgpu_ffv1::overlay)?  nseg as the encoder chooses it.
+static bool overlay_fits(const rcgpu_ffv1_config& cfg)
+{
+    if (cfg.pixfmt >= RCGPU_PIX_COUNT || !cfg.num_h_slices || !cfg.num_v_slices || cfg.level == 1 || (cfg.flags & RCGPU_FLAG_OWN_SLICE_BUFFERS)) return false;
+    const pix_desc& d = pix(cfg.pixfmt);
+    uint32_t min_nsamp = ~0u;
+    for (uint32_t sy = 0; sy < cfg.num_v_slices; sy++)
+        for (uint32_t sx = 0; sx < cfg.num_h_slices; sx++) {
+            const uint32_t w = uint32_t(uint64_t(sx + 1) * cfg.width / cfg.num_h_slices) - uint32_t(uint64_t(sx) * cfg.width / cfg.num_h_slices);
+            const uint32_t h = uint32_t(uint64_t(sy + 1) * cfg.height / cfg.num_v_slices) - uint32_t(uint64_t(sy) * cfg.height / cfg.num_v_slices);
+            const size_t nsamp = size_t(w) * h * d.planes;
+            if (size_t(16) + slice_buffer_bytes(d, w, h, 3, cfg.slice_buffer_div) + 16 > nsamp * 4) return false;
+            min_nsamp = std::min<uint32_t>(min_nsamp, uint32_t(nsamp));
+        }
+    const uint32_t nseg = cfg.segments ? cfg.segments : std::max(1u, std::min(32u, min_nsamp / 1024));
+    return (((size_t(min_nsamp) + nseg - 1) / nseg + 63) & ~size_t(63)) * 4 / std::max(1u, cfg.slice_buffer_div) > 4096;      // a segment's symbols: room for the per-segment limit to mean something
+}
+
 namespace rc {
+bool ffv1_overlays_slice_buffers(const rcgpu_ffv1_config& cfg) { return overlay_fits(cfg); }
 std::vector<uint8_t> ffv1_config_record_for(const rcgpu_ffv1_config& cfg)
 {
     if (cfg.pixfmt >= RCGPU_PIX_COUNT || !cfg.num_h_slices || !cfg.num_v_slices) return {};
@@ -1379,6 +1407,12 @@ struct rcgpu_ffv1 {
     bool lds_states = false;            // compact context model: k_resolve keeps the slice's states in LDS
     size_t resolve_lds = 0;
     size_t frame_payload = 0, cbuf_frame_stride = 0, max_packet = 0;
+    // OVERLAY (round 6): a slice's byte buffer lies inside its own symbol area.  The coder consumes segment j's decisions after k_resolve has read
+    // segment j's symbols, and it writes at most 3.4 bytes where four bytes of symbol lay: the 96 MB of slice buffers per 4K frame (and per bank
+    // in run-on mode) are the symbol buffer's dead front.  On when every slice's buffer fits its symbol area (large slices; small ones keep
+    // buffers of their own: their caps are dominated by the constant room for untrained contexts).
+    bool overlay = false;
+    uint8_t* cbuf_base() const { return overlay ? reinterpret_cast<uint8_t*>(d_sym) : d_cbuf; }
     hipStream_t own_stream = nullptr, rc_stream = nullptr;      // rc_stream: k_rangecode runs beside k_resolve
     hipStream_t rr_stream = nullptr;                            // split coder: k_rc_range's stream (the spans are coded on rc_stream)
     uint32_t span_pieces = 0;                                   // split coder: pieces per span; 0 = one lane codes a whole slice
@@ -1608,6 +1642,15 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         }
     e->cbuf_frame_stride = cb;
     e->max_packet = (cb + 15) & ~size_t(15);
+    {   // the overlay: every slice's 16 + cap bytes inside its nsamp * 4 bytes of symbols, and room for the per-segment limit to mean something
+        const bool fits = overlay_fits(*cfg) && !TIMING_ENV("RCGPU_NO_OVERLAY");
+        e->overlay = fits;
+        if (fits) {
+            for (slice_geom& g : e->geom) { const uint64_t off = uint64_t(g.sym_off) * 4 + 16; g.cbuf_off_lo = uint32_t(off); g.cbuf_off_hi = uint32_t(off >> 32); }
+            e->cbuf_frame_stride = size_t(c.samples_per_frame) * 4;
+        }
+        c.overlay = fits ? std::max(1u, cfg->slice_buffer_div) : 0u;
+    }
 
     const uint32_t F = cfg->max_batch;
     const size_t nchains = size_t(F) * S, ngroups = (nchains + 63) / 64;
@@ -1622,7 +1665,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
     DM(e->d_states, e->lds_states ? 16 : nchains * e->nkeys * 32);
     DM(e->d_ndec, nchains * nseg * 8); DM(e->d_total_n, nchains * 8); DM(e->d_seg_pieces, nchains * nseg * 4 + 8); DM(e->d_group_off, ngroups * nseg * 8);
     DM(e->d_k3_resume, nchains * e->resume_stride); DM(e->d_k4_resume, nchains * sizeof(rc_resume));
-    DM(e->d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
+    if (!e->overlay) DM(e->d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
     DM(e->d_out_len, nchains * 4); DM(e->d_tot_len, nchains * 4); DM(e->d_slice_dst, nchains * 8); DM(e->d_err, 16); DM(e->d_events, sizeof(uint2) * kMaxCarryEvents);
     HM(e->h_ndec_pinned, nchains * nseg * 8); HM(e->h_frame_ptrs, sizeof(void*) * F); HM(e->h_total_n, nchains * 8);
     HM(e->h_seg_pieces, nchains * nseg * 4 + 8); HM(e->h_group_off, ngroups * nseg * 8);
@@ -1831,7 +1874,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
             static const bool exp_skip_b = TIMING_ENV("RCGPU_EXP_SKIP_B") != nullptr;        // timing runs: no span coder (no valid output)
             if (!exp_skip_b)
             HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<true>, dim3(ngroups, nsp), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
-                                                          j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
+                                                          j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->cbuf_base(),
                                                           (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, ck, e->span_pieces); }));
         } else {
             HIP_TRY(hipStreamWaitEvent(s2, k3, 0));
@@ -1839,7 +1882,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
             // (40960: four, one per SIMD) -- the dispatcher otherwise packs a masked stream's wavefronts onto few SIMDs (profiles/r05_partition.jsonl)
             static const uint32_t exp_rc_lds = TIMING_ENV("RCGPU_EXP_RC_LDS") ? uint32_t(atoi(TIMING_ENV("RCGPU_EXP_RC_LDS"))) : 0u;
             HIP_TRY(timed(3, s2, [&] { hipLaunchKernelGGL(k_rangecode<false>, dim3(ngroups), dim3(64), exp_rc_lds, s2, e->d_const, e->d_geom, e->d_total_n, e->d_seg_pieces + size_t(j) * nchains,
-                                                          j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->d_cbuf,
+                                                          j, e->d_k4_resume, e->d_group_off + size_t(j) * ngroups, win, e->cbuf_base(),
                                                           (unsigned long long)e->cbuf_frame_stride, nchains, e->d_out_len, e->d_err, e->d_events, static_cast<rc_ckpt*>(nullptr), 0u); }));
         }
         HIP_TRY(hipEventRecord(k4, s2));
@@ -1848,19 +1891,19 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     e->gseg += nseg;
     if (e->span_pieces && !e->exp_skip_rc)
         HIP_TRY(timed(8, s2, [&] { hipLaunchKernelGGL(k_rc_tails, dim3(ngroups), dim3(64), 0, s2, e->d_const, e->d_geom, e->d_ckpt, total_spans, nchains,
-                                                      e->d_cbuf, (unsigned long long)e->cbuf_frame_stride); }));
+                                                      e->cbuf_base(), (unsigned long long)e->cbuf_frame_stride); }));
     // footer / scan / gather follow the last range-coder segment -- on its stream, or in run-on mode on the tail stream, beside the next
     // batch's first coder segments; then the caller's stream joins: this batch, or in run-on mode the batch before it
     if (tl != s2) {
         if (e->span_pieces && !e->exp_skip_rc) { HIP_TRY(hipEventRecord(e->ev_tails, s2)); HIP_TRY(hipStreamWaitEvent(tl, e->ev_tails, 0)); }    // (behind k_rc_tails, which follows the last span)
         else HIP_TRY(hipStreamWaitEvent(tl, k4_last, 0));
     }
-    HIP_TRY(timed(4, tl, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, tl, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+    HIP_TRY(timed(4, tl, [&] { hipLaunchKernelGGL(k_footer, dim3(nchains), dim3(256), 0, tl, e->d_const, e->d_geom, e->cbuf_base(), (unsigned long long)e->cbuf_frame_stride,
                                                   e->d_out_len, e->d_tot_len, e->d_err, e->d_events); }));
     HIP_TRY(timed(5, tl, [&] { hipLaunchKernelGGL(k_scan, dim3(n), dim3(64), 0, tl, e->d_const, e->d_tot_len, e->d_slice_dst, reinterpret_cast<unsigned long long*>(d_packet_sizes)); }));
     if (!e->defer_gather) {
         if (e->gather_wait) { HIP_TRY(hipStreamWaitEvent(tl, e->gather_wait, 0)); e->gather_wait = nullptr; }
-        HIP_TRY(timed(6, tl, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, tl, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+        HIP_TRY(timed(6, tl, [&] { hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, tl, e->d_const, e->d_geom, e->cbuf_base(), (unsigned long long)e->cbuf_frame_stride,
                                                       e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride); }));
     }
 #ifdef RCGPU_TIMING_BUILD
@@ -1896,7 +1939,7 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
         rcgpu_ffv1::bank_t& b = e->alt;
         dm(&b.d_frame_ptrs, sizeof(void*) * F); dm(&b.d_sym, size_t(F) * e->hc.samples_per_frame * 4); dm(&b.d_states, e->lds_states ? 16 : nchains * e->nkeys * 32);
         dm(&b.d_ndec, nchains * nseg * 8); dm(&b.d_total_n, nchains * 8); dm(&b.d_seg_pieces, nchains * nseg * 4 + 8); dm(&b.d_group_off, ngroups * nseg * 8);
-        dm(&b.d_k3_resume, nchains * e->resume_stride); dm(&b.d_k4_resume, nchains * sizeof(rc_resume)); dm(&b.d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
+        dm(&b.d_k3_resume, nchains * e->resume_stride); dm(&b.d_k4_resume, nchains * sizeof(rc_resume)); if (!e->overlay) dm(&b.d_cbuf, size_t(F) * e->cbuf_frame_stride + 64);
         dm(&b.d_out_len, nchains * 4); dm(&b.d_tot_len, nchains * 4); dm(&b.d_slice_dst, nchains * 8); dm(&b.d_err, 16); dm(&b.d_events, sizeof(uint2) * kMaxCarryEvents);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
@@ -1907,9 +1950,16 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
         // priority to four others.  Model and tail, the background of the batch in flight, take the low priority's; measured with all five
         // at one priority: k_resolve and k_rangecode shared a queue and ran one after the other, 820 ms per step instead of 480 (and with
         // k_resolve at the HIGH priority its workgroups are dispatched before the coder's every time: 712 ms).
+        // Round 6: k_model at the HIGH priority.  At the low one its blocks were dispatched only where the batch in flight left a slot -- the launch
+        // boundaries of its segments -- and the 29 ms of work trickled through in 440, ending with the batch: the next batch's first k_resolve
+        // then stood 26 ms behind the host's round trip (counts back, window layout, tables up) with nothing else left to run
+        // (profiles/r06_trace_run_on.txt).  At the high priority (hardware queues nobody else uses) it runs when it is issued, early in the batch
+        // in flight, and the round trip hides behind that batch.
         int lo = 0, hi = 0;
         if (he == hipSuccess) he = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->model_stream, hipStreamNonBlocking, lo);
+        int model_prio = hi;
+        if (const char* x = TIMING_ENV("RCGPU_MODEL_PRIO")) model_prio = atoi(x) < 0 ? hi : atoi(x) > 0 ? lo : 0;      // for measuring: -1 high, 0 normal, 1 low
+        if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->model_stream, hipStreamNonBlocking, model_prio);
         if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->tail_stream, hipStreamNonBlocking, lo);
         e->front_stream = e->rr_stream;             // the split coder's stream, idle in this mode: no fifth stream at the normal priority
         if (e->span_pieces) {
@@ -1971,7 +2021,7 @@ int ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_
     if (e->run_on) { HIP_TRY(hipStreamWaitEvent(st, e->ev_done, 0)); e->joined = true; }
     const bool ev_room = e->ev_used + 2 <= e->ev.size();
     if (ev_room) HIP_TRY(hipEventRecord(e->ev[e->ev_used], st));
-    hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, st, e->d_const, e->d_geom, e->d_cbuf, (unsigned long long)e->cbuf_frame_stride,
+    hipLaunchKernelGGL(k_gather, dim3(nchains, 8), dim3(256), 0, st, e->d_const, e->d_geom, e->cbuf_base(), (unsigned long long)e->cbuf_frame_stride,
                        e->d_tot_len, e->d_slice_dst, static_cast<uint8_t*>(d_packets), (unsigned long long)packet_stride);
     if (ev_room) { HIP_TRY(hipEventRecord(e->ev[e->ev_used + 1], st)); e->ev_used += 2; e->ev_kernel.push_back(6); }
     if (e->run_on) HIP_TRY(hipEventRecord(e->ev_done, st));
@@ -2054,7 +2104,7 @@ namespace rc {
 const char* ffv1_error_flags_text(uint32_t flags)
 {
     if (!flags) return "";
-    if (flags & 1u) return "a slice outgrew its byte buffer (content expands beyond 1.5x raw)";
+    if (flags & 1u) return "a slice outgrew its byte buffer (content expands beyond 1.5x raw -- or, where the slices' bytes share the symbol buffer, beyond 4 bytes per sample early in a slice: RCGPU_FLAG_OWN_SLICE_BUFFERS)";
     if (flags & 2u) return "a slice does not fit its footer / the 24-bit slice size field";
     if (flags & 4u) return "more late carries than the event table holds";
     if (flags & 8u) return "timing build: a coder was switched off, the packets are not FFV1";
@@ -2182,7 +2232,21 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
         (void)hipFree(planes);
         return r;
     }
-    case 1: return d2h(e->d_sym, size_t(e->last_n) * c.samples_per_frame * 4);
+    case 1: {
+        if (!e->overlay) return d2h(e->d_sym, size_t(e->last_n) * c.samples_per_frame * 4);
+        // the slices' bytes have taken the symbols' place: the batch is modelled again into a buffer of its own (the caller's frames must still be there)
+        uint32_t* sym = nullptr; unsigned long long* nd = nullptr;
+        const uint32_t nchains = e->last_n * S;
+        if (hipMalloc(reinterpret_cast<void**>(&sym), size_t(e->last_n) * c.samples_per_frame * 4) != hipSuccess) return -3;
+        if (hipMalloc(reinterpret_cast<void**>(&nd), size_t(nchains) * e->nseg * 8) != hipSuccess) { (void)hipFree(sym); return -3; }
+        (void)hipMemset(nd, 0, size_t(nchains) * e->nseg * 8);
+        uint32_t max_tiles = 0;
+        for (const slice_geom& g : e->geom) max_tiles = std::max(max_tiles, ((g.w + kTileW - 1) / kTileW) * ((g.h + kTileR - 1) / kTileR));
+        hipLaunchKernelGGL(k_model, dim3(max_tiles, nchains), dim3(256), size_t(c.planes) * kTileRows * kTileCols * 4, nullptr, e->d_const, e->d_geom, e->d_frame_ptrs, sym, nd);
+        const long long r = hipDeviceSynchronize() == hipSuccess ? d2h(sym, size_t(e->last_n) * c.samples_per_frame * 4) : -3;
+        (void)hipFree(sym); (void)hipFree(nd);
+        return r;
+    }
     case 2: return d2h(e->d_total_n, size_t(e->last_n) * S * 8);
     case 3: {
         if (chain >= e->last_n * S) return -4;
@@ -2208,7 +2272,7 @@ extern "C" long long rcgpu_ffv1_debug_fetch(rcgpu_ffv1* e, int what, uint32_t ch
         uint32_t len = 0;
         if (hipMemcpy(&len, e->d_out_len + chain, 4, hipMemcpyDeviceToHost) != hipSuccess) return -3;
         const slice_geom& g = e->geom[chain % S];
-        const uint8_t* src = e->d_cbuf + size_t(chain / S) * e->cbuf_frame_stride + (size_t(g.cbuf_off_hi) << 32 | g.cbuf_off_lo);
+        const uint8_t* src = e->cbuf_base() + size_t(chain / S) * e->cbuf_frame_stride + (size_t(g.cbuf_off_hi) << 32 | g.cbuf_off_lo);
         return d2h(src, len);
     }
     case 5: return d2h(e->d_err, 16);      // [0] error flags, [1] carries k_rangecode handed to k_footer (events) in the last call

@@ -36,6 +36,8 @@ void ffv1_set_input_event(rcgpu_ffv1* e, void* hip_event);
 // can be written, and its file laid out, while the encoders are still being created).
 std::vector<uint8_t> ffv1_config_record_for(const rcgpu_ffv1_config& cfg);
 size_t ffv1_max_packet_bytes_for(const rcgpu_ffv1_config& cfg);
+// true: an encoder of this configuration keeps its slice byte buffers inside the symbol buffer (no memory of their own)
+bool ffv1_overlays_slice_buffers(const rcgpu_ffv1_config& cfg);
 // Per-kernel device time of the call before the last one (see rcgpu_ffv1_last_kernel_times).
 int  ffv1_prev_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap);
 int  ffv1_prev_timeline(const rcgpu_ffv1* e, float* t6);      // see ffv1_gpu.hip; for RCGPU_TRACE

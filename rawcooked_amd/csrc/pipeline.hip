@@ -223,10 +223,15 @@ uint64_t ffv1_device_bytes_per_frame(const rcgpu_ffv1_config& c, bool run_on)
     const uint64_t windows = samples * 35 * 8 / 7 * (nseg > 1 ? 3 : 1) / nseg;              // worst case: 35 decisions per sample, 64 bytes per 56 of them; three windows (split coder)
     const uint64_t ckpt = samples * 35 / 56 / 8 + S * nseg * 8;                              // split coder: 8 bytes per span of >= 8 pieces and slice
     const uint64_t cbuf = raw * 3 / 2 + S * ((256u << 10) + 4096 + 32);
+    const uint64_t own_cbuf = ffv1_overlays_slice_buffers(c) ? 0 : cbuf;                    // large slices: the byte buffers lie inside the symbol buffer
     // run-on mode: the encoder's second bank (rcgpu_ffv1_set_run_on) -- symbols, context states, slice byte buffers once more
-    const uint64_t second_bank = run_on ? samples * 4 + states + cbuf + S * 64 : 0;
-    return samples * 4 + states + windows + ckpt + 2 * cbuf + raw + (1u << 20) + second_bank;
+    const uint64_t second_bank = run_on ? samples * 4 + states + own_cbuf + S * 64 : 0;
+    return samples * 4 + states + windows + ckpt + own_cbuf + cbuf /* packets */ + raw + (1u << 20) + second_bank;
 }
+
+}  // namespace rc
+extern "C" uint64_t rcgpu_ffv1_device_bytes_per_frame(const rcgpu_ffv1_config* cfg, int run_on) { return cfg ? rc::ffv1_device_bytes_per_frame(*cfg, run_on != 0) : 0; }
+namespace rc {
 
 int pipeline::prepare(const std::vector<pipe_video>& videos, const pipe_options& opt)
 {

@@ -318,7 +318,7 @@ def test_hd_sequence_with_real_transfers_equals_the_oracle(copy_streams, lanes, 
         assert got[i] == want[i % distinct], f"packet {i} differs from the oracle's"
 
 
-def test_bench_gpus_2_on_one_gpu_prints_both_multi_gpu_records(built):
+def test_bench_gpus_2_on_one_gpu_prints_both_multi_gpu_records(built, tmp_path):
     """`bench.py --gpus 2` on a box with one GPU (what the driver's N > 1 command turns into here): the headline on the device, then the two multi-GPU
     records over ALIASES of it -- `jobs_side_by_side` (N rcgpu-ffmpeg processes, N Matroska files: how a node pays off under the single-file
     ceiling) and `single_process_sharding` (one sequence, a lane per device, one placer) -- every packet equal to the N = 1 run's."""
@@ -328,9 +328,15 @@ def test_bench_gpus_2_on_one_gpu_prints_both_multi_gpu_records(built):
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--width", "512", "--height", "270", "--slices", "4", "--batch", "32",
-                        "--host-frames", "128", "--e2e-frames", "128", "--legs", "host,e2e", "--no-verify"], capture_output=True, text=True, timeout=900)
+                        "--host-frames", "128", "--e2e-frames", "128", "--legs", "host,e2e", "--no-verify", "--detail-out", str(tmp_path / "detail.json")],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    # the line the driver parses is compact (one object under 4 KB: the contract's keys and the flat numbers); the records are in the detail file
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert len(last) < 4096 and line["roofline"]["kernel"] and line["detail"] == "detail.json" and len(line["step_ms"]) == 1
+    d = json.load(open(tmp_path / "detail.json"))
+    assert line["config"]["jobs_side_by_side_fps"] == d["jobs_side_by_side"]["value"] and line["config"]["single_process_sharding_fps"] == d["single_process_sharding"]["value"]
     j = d["jobs_side_by_side"]
     assert j["jobs"] == 2 and len(j["per_job"]) == 2 and all(x["all_blocks_identical_to_the_n1_runs_packets"] and x["frames"] == j["frames_per_job"] for x in j["per_job"]), j
     s = d["single_process_sharding"]

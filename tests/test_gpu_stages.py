@@ -16,6 +16,7 @@ CASES = [
     (130, 67, synth.PIX_RGB16_LE, 9, "noise", 3),
     (96, 64, synth.PIX_RGB16_BE, 4, "flat", 1),
     (257, 131, synth.PIX_RGB8, 16, "film", 2),
+    (600, 200, synth.PIX_RGB16_BE, 1, "noise", 2),           # a slice large enough for its coded bytes to lie inside its symbol area (round 6)
 ]
 
 
@@ -419,3 +420,69 @@ def test_a_second_bank_that_does_not_fit_leaves_nothing_behind(built):
     assert enc.encode_host(srcs) == [want[i % 2] for i in range(n)]
     assert enc.error_flags() == 0
     enc.close()
+
+
+OWN = 0x100          # RCGPU_FLAG_OWN_SLICE_BUFFERS
+
+
+@pytest.mark.parametrize("rc_span", [1, 8], ids=["whole-slice coder", "split coder"])
+@pytest.mark.parametrize("segments", [1, 5, 32])
+@pytest.mark.parametrize("w,h,pixfmt,slices", [(600, 200, synth.PIX_RGB16_BE, 1), (1024, 540, synth.PIX_RGB16_BE, 4), (900, 400, synth.PIX_RGB10_FILLEDA_BE, 2), (1100, 600, synth.PIX_RGBA16_BE, 2)])
+def test_slice_bytes_inside_the_symbol_buffer(built, w, h, pixfmt, slices, segments, rc_span):
+    """Round 6: where every slice is large enough its coded bytes lie in its own area of the symbol buffer (the coder writes at most 3.4
+    bytes where a 4-byte symbol lay that k_resolve has read), no slice byte buffers are allocated.  Same packets as with buffers of their
+    own (RCGPU_FLAG_OWN_SLICE_BUFFERS) and as the oracle's, on noise -- the content that comes closest to the symbols -- and film, one
+    batch at a time and in run-on mode; the estimate callers size batches with says what the overlay saves."""
+    import ctypes as C
+    import torch
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    nh, nv = api.slices_to_grid(slices)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    pls = [synth.pack_payload(synth.components(w, h, nc, bits, ["noise", "film", "noise"][i], seed=300 + i), pixfmt, True) for i in range(3)]
+    line_bytes = pls[0][1]
+    pls = [x[0] for x in pls]
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in pls]
+    L = api.lib()
+    L.rcgpu_ffv1_device_bytes_per_frame.restype, L.rcgpu_ffv1_device_bytes_per_frame.argtypes = C.c_uint64, [C.c_void_p, C.c_int]
+    per = {}
+    for flags in (0, OWN):
+        enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=3, segments=segments, rc_span=rc_span, flags=flags)
+        per[flags] = [L.rcgpu_ffv1_device_bytes_per_frame(C.byref(enc.cfg), r) for r in (0, 1)]
+        assert enc.encode_host(pls) == want, f"flags {flags:#x}"
+        assert enc.error_flags() == 0
+        enc.set_run_on(True)
+        for _ in range(3):
+            assert enc.encode_host(pls[::-1]) == want[::-1], f"flags {flags:#x}, run-on"
+        assert enc.error_flags() == 0
+        enc.close()
+    raw = len(pls[0])
+    assert per[OWN][0] - per[0][0] >= raw * 3 // 2 and per[OWN][1] - per[0][1] >= 2 * (raw * 3 // 2)      # one set of slice buffers, two in run-on mode
+
+
+def test_bytes_that_reach_unread_symbols_are_reported(built):
+    """The overlay's own limit: while segment j is coded the bytes must stay below the symbols of segment j + 1, four bytes per sample from the
+    slice's start.  Real content cannot get there (16-bit noise with untrained states codes to 3.4 bytes per sample), so the limit is halved
+    (slice_buffer_div = 2): a picture whose first lines are noise and whose rest is flat fits its buffer many times over in the end, yet its
+    first segment runs past the halved limit -- reported (the error word, never silently wrong bytes); with buffers of their own the same
+    configuration codes it, and so does the overlay with the true limit."""
+    import torch
+    w, h, pixfmt = 600, 200, synth.PIX_RGB16_BE
+    comp = synth.components(w, h, 3, 16, "flat", seed=3).copy()
+    comp[:6] = synth.components(w, h, 3, 16, "noise", seed=4)[:6]            # the first of 32 segments (200 / 32 lines) and no more
+    pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
+    p = ob.Params(w, h, pixfmt, 1, 1, 1, 1)
+    want = ob.encode_payload(p, pl, line_bytes)
+    assert len(want) < len(pl) // 8
+    d = torch.frombuffer(bytearray(pl), dtype=torch.uint8).cuda()
+    for flags, div, ok in ((0, 0, True), (OWN, 2, True), (0, 2, False)):
+        enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 1, 1, 1, 1, max_batch=1, segments=32, flags=flags, slice_buffer_div=div)
+        pk = torch.zeros(enc.max_packet, dtype=torch.uint8, device="cuda")
+        sz = torch.zeros(1, dtype=torch.int64, device="cuda")
+        enc.encode_device([d.data_ptr()], pk.data_ptr(), enc.max_packet, sz.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if ok:
+            assert enc.error_flags() == 0 and bytes(pk[:int(sz[0])].cpu().numpy()) == want, (flags, div)
+        else:
+            with pytest.raises(api.RcgpuError, match="outgrew"):
+                enc.error_flags()
+        enc.close()

@@ -31,6 +31,23 @@ def test_library_exports_every_declared_symbol(built):
     assert b"rcgpu version" in L.rcgpu_version()
 
 
+def test_device_bytes_per_frame_needs_no_device(built):
+    """rcgpu_ffv1_device_bytes_per_frame: what one frame in flight costs on the device, for callers that size max_batch (the job level does).
+    BASELINE config 2 (4096x2160 RGB16, 64 slices) in run-on mode: 506 MB at the worst-case decision count (35 per sample; film content: ~460),
+    against 700 before round 6 laid the slices' coded bytes into the dead front of the symbol buffer; RCGPU_FLAG_OWN_SLICE_BUFFERS and
+    slices too small for that (576 slices at 4K) pay for their byte buffers."""
+    import ctypes as C
+    L = api.lib()
+    def per(w, h, nh, nv, flags=0, run_on=1):
+        cfg = api.Ffv1Config(w, h, synth.PIX_RGB16_BE, w * 6, nh, nv, 1, 1, 336, 0, 0, flags, 1, 3, 0, 0)
+        return L.rcgpu_ffv1_device_bytes_per_frame(C.byref(cfg), run_on)
+    raw = 4096 * 2160 * 6
+    a, b = per(4096, 2160, 8, 8), per(4096, 2160, 8, 8, 0x100)
+    assert 440e6 < a < 520e6 and b - a >= 2 * (raw * 3 // 2) and per(4096, 2160, 8, 8, run_on=0) < a - 100e6
+    assert per(4096, 2160, 32, 18) == per(4096, 2160, 32, 18, 0x100)            # 128 x 120 slices: buffers of their own either way
+    assert L.rcgpu_ffv1_device_bytes_per_frame(None, 1) == 0
+
+
 def test_product_does_not_link_the_oracle(built):
     ldd = subprocess.run(["ldd", api.LIB_PATH], capture_output=True, text=True).stdout
     assert "liboracle" not in ldd
@@ -45,7 +62,7 @@ def test_shipped_library_has_no_switch_that_changes_bytes(built):
     reference's only such switches are its command line's (CLI/Global.cpp:938-989)."""
     csrc = os.path.join(ROOT, "rawcooked_amd", "csrc")
     allowed = {"RCGPU_BATCH", "RCGPU_DEVICES", "RCGPU_LANES", "RCGPU_MKV_MMAP", "RCGPU_MKV_NO_MMAP", "RCGPU_READERS", "RCGPU_WRITERS",
-               "RCGPU_NO_CU_PARTITION", "RCGPU_RELEASE_AT_EXIT", "RCGPU_TRACE", "RCGPU_TRACE_KEPT", "RCGPU_UPLOAD_THREADS"}      # sizing and tracing: same bytes
+               "RCGPU_NO_CU_PARTITION", "RCGPU_RELEASE_AT_EXIT", "RCGPU_TRACE", "RCGPU_TRACE_KEPT", "RCGPU_UPLOAD_THREADS", "RCGPU_DEC_STATES_SLACK"}      # sizing and tracing: same bytes
     for path in (api.LIB_PATH, os.path.join(ROOT, "rawcooked_amd", "rcgpu-ffmpeg")):
         names = set(re.findall(rb"RCGPU_[A-Z0-9_]+", open(path, "rb").read()))
         names = {n.decode() for n in names if not n.startswith((b"RCGPU_PIX_", b"RCGPU_FLAG_", b"RCGPU_RC_WHOLE", b"RCGPU_KEPT_"))}

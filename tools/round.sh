@@ -95,7 +95,7 @@ encprof)
     cp gpurun_out/pmc/${ROUND}${TAG}_sq.csv $OUT/ 2>/dev/null ;;
 trace)
     # rocprofv3 --kernel-trace of a bench run as a timeline (tools/kernel_trace.py): TRACE_MODE=check for the check half
-    cd /tmp; rm -rf /tmp/rp_tr; timeout 600 rocprofv3 --kernel-trace -d /tmp/rp_tr -o t -- python "$OLDPWD/bench.py" ${@:---steps 4 --warmup 1 --legs "" --no-verify} > "$OLDPWD/$OUT/trace_$TAG.log" 2>&1; cd "$OLDPWD"
+    cd /tmp; rm -rf /tmp/rp_tr; timeout 600 rocprofv3 --kernel-trace -d /tmp/rp_tr -o t -- python "$OLDPWD/bench.py" ${@:---steps 4 --warmup 1 --legs= --no-verify} > "$OLDPWD/$OUT/trace_$TAG.log" 2>&1; cd "$OLDPWD"
     python tools/kernel_trace.py "$(find /tmp/rp_tr -name '*.db' | head -1)" ${TRACE_MODE:-encode} | tee $OUT/trace_$TAG.txt | tail -40 ;;
 sweep)
     # A/B over environment settings with the TIMING build (the shipped library reads no measuring switch): one bench line per argument
