@@ -427,7 +427,7 @@ OWN = 0x100          # RCGPU_FLAG_OWN_SLICE_BUFFERS
 
 @pytest.mark.parametrize("rc_span", [1, 8], ids=["whole-slice coder", "split coder"])
 @pytest.mark.parametrize("segments", [1, 5, 32])
-@pytest.mark.parametrize("w,h,pixfmt,slices", [(600, 200, synth.PIX_RGB16_BE, 1), (1024, 540, synth.PIX_RGB16_BE, 4), (900, 400, synth.PIX_RGB10_FILLEDA_BE, 2), (1100, 600, synth.PIX_RGBA16_BE, 2)])
+@pytest.mark.parametrize("w,h,pixfmt,slices", [(600, 200, synth.PIX_RGB16_BE, 1), (1024, 540, synth.PIX_RGB16_BE, 4), (900, 400, synth.PIX_RGB10_FILLEDA_BE, 4), (1100, 600, synth.PIX_RGBA16_BE, 4)])
 def test_slice_bytes_inside_the_symbol_buffer(built, w, h, pixfmt, slices, segments, rc_span):
     """Round 6: where every slice is large enough its coded bytes lie in its own area of the symbol buffer (the coder writes at most 3.4
     bytes where a 4-byte symbol lay that k_resolve has read), no slice byte buffers are allocated.  Same packets as with buffers of their
