@@ -94,7 +94,7 @@ enum {   /* pixel layouts; names follow the reference flavors (DPX.cpp:184-231, 
                                   picture line y = file line height-1-y (Transform.cpp:181-185).  12-bit Packed flavors only (DPX.cpp:189,204) */
 #define RCGPU_FLAG_ALTERN 2u   /* Y 10-bit from some scanners: words are filled across line ends, no line padding (DPX.cpp:363-368,465-469) */
 /* encoder only (rcgpu_ffv1_config::flags), nothing a header announces: */
-#define RCGPU_FLAG_OWN_SLICE_BUFFERS 0x100u   /* Where every slice is large enough the encoder keeps a slice's coded bytes in the slice's own area of the
+#define RCGPU_FLAG_OWN_SLICE_BUFFERS 0x100u   /* Where every slice holds >= 64 K samples the encoder keeps a slice's coded bytes in the slice's own area of the
                                   symbol buffer -- the coder writes at most 3.4 bytes where a 4-byte symbol lay that k_resolve has read already -- and
                                   allocates no slice byte buffers (96 MB per 4K frame in flight, twice that in run-on mode).  A slice whose FIRST
                                   segments code to more than 4 bytes per sample (16-bit noise with untrained states: 3.4) is then reported as

@@ -1334,6 +1334,8 @@ static size_t slice_buffer_bytes(const pix_desc& d, uint32_t w, uint32_t h, uint
 }
 
 // Do the slice byte buffers of this configuration lie inside the slices' symbol areas (rcgpu_ffv1::overlay)?  nseg as the encoder chooses it.
+constexpr size_t kOverlayMinSamples = size_t(64) << 10;
+static size_t overlay_cap(size_t cap, size_t nsamp) { return std::min(cap, (nsamp * 4 - 48) & ~size_t(15)); }      // 16 bytes in front, 16 behind, inside nsamp * 4
 static bool overlay_fits(const rcgpu_ffv1_config& cfg)
 {
     if (cfg.pixfmt >= RCGPU_PIX_COUNT || !cfg.num_h_slices || !cfg.num_v_slices || cfg.level == 1 || (cfg.flags & RCGPU_FLAG_OWN_SLICE_BUFFERS)) return false;
@@ -1344,7 +1346,9 @@ static bool overlay_fits(const rcgpu_ffv1_config& cfg)
             const uint32_t w = uint32_t(uint64_t(sx + 1) * cfg.width / cfg.num_h_slices) - uint32_t(uint64_t(sx) * cfg.width / cfg.num_h_slices);
             const uint32_t h = uint32_t(uint64_t(sy + 1) * cfg.height / cfg.num_v_slices) - uint32_t(uint64_t(sy) * cfg.height / cfg.num_v_slices);
             const size_t nsamp = size_t(w) * h * d.planes;
-            if (size_t(16) + slice_buffer_bytes(d, w, h, 3, cfg.slice_buffer_div) + 16 > nsamp * 4) return false;
+            // a slice of 64 K samples and more: 16-bit noise codes to 3.1 bytes per sample there (3.4 at 12 K, 3.9 in the first hundreds, where
+            // every context is untrained: small slices keep buffers of their own); its cap inside the overlay is its symbol area (kOverlayCap)
+            if (nsamp < kOverlayMinSamples) return false;
             min_nsamp = std::min<uint32_t>(min_nsamp, uint32_t(nsamp));
         }
     const uint32_t nseg = cfg.segments ? cfg.segments : std::max(1u, std::min(32u, min_nsamp / 1024));
@@ -1646,7 +1650,10 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         const bool fits = overlay_fits(*cfg) && !TIMING_ENV("RCGPU_NO_OVERLAY");
         e->overlay = fits;
         if (fits) {
-            for (slice_geom& g : e->geom) { const uint64_t off = uint64_t(g.sym_off) * 4 + 16; g.cbuf_off_lo = uint32_t(off); g.cbuf_off_hi = uint32_t(off >> 32); }
+            for (slice_geom& g : e->geom) {
+                const uint64_t off = uint64_t(g.sym_off) * 4 + 16; g.cbuf_off_lo = uint32_t(off); g.cbuf_off_hi = uint32_t(off >> 32);
+                g.cbuf_cap = uint32_t(overlay_cap(g.cbuf_cap, g.nsamp));       // (the packet stride callers allocate, max_packet, keeps the caps of buffers of their own)
+            }
             e->cbuf_frame_stride = size_t(c.samples_per_frame) * 4;
         }
         c.overlay = fits ? std::max(1u, cfg->slice_buffer_div) : 0u;

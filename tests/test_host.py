@@ -44,7 +44,8 @@ def test_device_bytes_per_frame_needs_no_device(built):
     raw = 4096 * 2160 * 6
     a, b = per(4096, 2160, 8, 8), per(4096, 2160, 8, 8, 0x100)
     assert 440e6 < a < 520e6 and b - a >= 2 * (raw * 3 // 2) and per(4096, 2160, 8, 8, run_on=0) < a - 100e6
-    assert per(4096, 2160, 32, 18) == per(4096, 2160, 32, 18, 0x100)            # 128 x 120 slices: buffers of their own either way
+    assert per(4096, 2160, 32, 18) == per(4096, 2160, 32, 18, 0x100)            # 128 x 120 slices (46 K samples): buffers of their own either way
+    assert per(8192, 4320, 32, 18) < per(8192, 4320, 32, 18, 0x100) - 900e6     # config 4's shape: 256 x 240 slices, the overlay saves two sets of 468 MB
     assert L.rcgpu_ffv1_device_bytes_per_frame(None, 1) == 0
 
 
