@@ -1957,14 +1957,12 @@ extern "C" int rcgpu_ffv1_set_run_on(rcgpu_ffv1* e, int on)
         // priority to four others.  Model and tail, the background of the batch in flight, take the low priority's; measured with all five
         // at one priority: k_resolve and k_rangecode shared a queue and ran one after the other, 820 ms per step instead of 480 (and with
         // k_resolve at the HIGH priority its workgroups are dispatched before the coder's every time: 712 ms).
-        // Round 6: k_model at the HIGH priority.  At the low one its blocks were dispatched only where the batch in flight left a slot -- the launch
-        // boundaries of its segments -- and the 29 ms of work trickled through in 440, ending with the batch: the next batch's first k_resolve
-        // then stood 26 ms behind the host's round trip (counts back, window layout, tables up) with nothing else left to run
-        // (profiles/r06_trace_run_on.txt).  At the high priority (hardware queues nobody else uses) it runs when it is issued, early in the batch
-        // in flight, and the round trip hides behind that batch.
+        // (Round 6 measured k_model's stream at the other priorities, profiles/r06_model_priority.jsonl: at the normal one its 29 ms of work take 45 ms,
+        // at the low or the high one they trickle through in 375-450 ms beside the batch in flight -- and the step is the same 470-480 ms either
+        // way: the round trip that follows k_model hides behind the batch in flight as long as k_model ends before that batch does.)
         int lo = 0, hi = 0;
         if (he == hipSuccess) he = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        int model_prio = hi;
+        int model_prio = lo;
         if (const char* x = TIMING_ENV("RCGPU_MODEL_PRIO")) model_prio = atoi(x) < 0 ? hi : atoi(x) > 0 ? lo : 0;      // for measuring: -1 high, 0 normal, 1 low
         if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->model_stream, hipStreamNonBlocking, model_prio);
         if (he == hipSuccess) he = hipStreamCreateWithPriority(&e->tail_stream, hipStreamNonBlocking, lo);
@@ -2111,7 +2109,7 @@ namespace rc {
 const char* ffv1_error_flags_text(uint32_t flags)
 {
     if (!flags) return "";
-    if (flags & 1u) return "a slice outgrew its byte buffer (content expands beyond 1.5x raw -- or, where the slices' bytes share the symbol buffer, beyond 4 bytes per sample early in a slice: RCGPU_FLAG_OWN_SLICE_BUFFERS)";
+    if (flags & 1u) return "a slice outgrew its byte buffer (content expands beyond 1.5x raw -- or, where the slices' bytes share the symbol buffer, beyond 4 bytes per sample early in a slice: RCGPU_FLAG_OWN_SLICE_BUFFERS, the shim's -rcgpu_own_slice_buffers 1)";
     if (flags & 2u) return "a slice does not fit its footer / the 24-bit slice size field";
     if (flags & 4u) return "more late carries than the event table holds";
     if (flags & 8u) return "timing build: a coder was switched off, the packets are not FFV1";

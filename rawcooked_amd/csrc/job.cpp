@@ -362,6 +362,8 @@ extern "C" int rcgpu_encode(const rcgpu_job* job)
         rcgpu_ffv1_config& c = pv.cfg;
         c.width = v.info.width; c.height = v.info.height; c.pixfmt = v.info.pixfmt; c.line_bytes = v.info.line_bytes;
         c.flags = (v.info.flags & RCGPU_FLAG_ALTERN) | (v.vflip ? RCGPU_FLAG_VFLIP : 0);
+        // `-rcgpu_own_slice_buffers 1`: for content that the overflow report names (a slice that codes to more than 4 bytes per sample early on)
+        if (opt.num("rcgpu_own_slice_buffers", 0)) c.flags |= RCGPU_FLAG_OWN_SLICE_BUFFERS;
         c.num_h_slices = v.num_h; c.num_v_slices = v.num_v; c.slicecrc = slicecrc; c.context = context; c.coder = uint32_t(coder); c.level = uint32_t(level);
         if (level == 1) { if (v.num_h * v.num_v != 1) return bail(fail(2, "-level 1 (FFV1 version 1) has no slices: use -slices 1")); c.slicecrc = 0; }
         pvideos.push_back(pv);

@@ -408,16 +408,18 @@ def test_a_second_bank_that_does_not_fit_leaves_nothing_behind(built):
     enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=n, rc_span=1)
     assert enc.encode_host(srcs[:4]) == [want[i % 2] for i in range(4)]                          # staging areas and windows exist now
     torch.cuda.synchronize()
-    # the bank of 48 such frames is ~0.4 GB (0.7 before the slices' bytes moved into the symbol buffer): the device is filled up to 96 MB.  Memory
-    # other tests freed comes back late (the driver wipes it in the background), so the filling is repeated until the free figure stands
-    fillers = []
-    for _ in range(8):
-        torch.cuda.synchronize()
-        free0 = torch.cuda.mem_get_info()[0]
-        if free0 <= (128 << 20):
-            break
-        fillers.append(torch.empty(free0 - (96 << 20), dtype=torch.uint8, device="cuda"))
-        time.sleep(0.5)
+    # the bank of 48 such frames is ~0.4 GB (0.7 before the slices' bytes moved into the symbol buffer).  The device is filled until an allocation
+    # FAILS -- the free figure the runtime reports runs behind what it can still hand out when other tests have just freed memory -- and
+    # one 64 MB block is given back
+    fillers = [torch.empty(max(0, torch.cuda.mem_get_info()[0] - (1 << 30)), dtype=torch.uint8, device="cuda")]
+    try:
+        for _ in range(4096):
+            fillers.append(torch.empty(64 << 20, dtype=torch.uint8, device="cuda"))
+    except torch.OutOfMemoryError:
+        pass
+    fillers.pop()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
     with pytest.raises(api.RcgpuError, match="second bank"):
         enc.set_run_on(True)
