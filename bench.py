@@ -1170,21 +1170,16 @@ def main():
         mode_probe = {"run_on_ms_per_step": round(probe(True) * 1e3, 1), "one_batch_at_a_time_ms_per_step": round(probe(False) * 1e3, 1)}
         run_on = mode_probe["run_on_ms_per_step"] <= mode_probe["one_batch_at_a_time_ms_per_step"]
         enc.set_run_on(run_on)
-    # Per-step times for the line's `step_ms`: the HOST clock when each step's call returns.  A call returns once its batch is modelled, which
-    # waits for the batch before the last (run-on mode) or the last (one at a time) to be finished: the returns are paced by the device, one
-    # step behind.  Nothing is recorded on the device: round 6's first attempt joined every batch on a side stream to carry an event, and that
-    # stream's barrier packets shared a hardware queue with k_resolve's stream -- the next batch's first segment then waited for the whole
-    # previous batch, 22 ms per step (profiles/r06_trace_run_on.txt).  The last entry runs to the end of the timed region, so the entries add up to it.
-    step_t = [0.0] * (args.steps + 1)
-
-    def mark_step(k):
-        step_t[k + 1] = time.perf_counter()
-    dt = rdist.timed_steps(dist, dev, step, args.steps, args.warmup, torch.cuda.synchronize, mark=mark_step)
-    t_end = time.perf_counter()
+    # Per-step times for the line's `step_ms`: the device time from the end of one batch to the end of the next, from events the library
+    # records behind each batch's last kernel on the stream it ran on (rcgpu_ffv1_batch_intervals).  Nothing of the bench's own stands
+    # between the batches: round 6's first attempt joined every batch on a side stream to carry an event, and that stream's barrier
+    # packets shared a hardware queue with k_resolve's stream -- the next batch's first segment then waited for the whole previous batch,
+    # 22 ms per step (profiles/r06_trace_run_on.txt).  The first entry's interval begins at the end of the last warm-up batch, which is
+    # before the clock starts: the entries add up to a little more than the timed region.
+    dt = rdist.timed_steps(dist, dev, step, args.steps, args.warmup, torch.cuda.synchronize)
     if run_on:
         enc.join(stream); torch.cuda.synchronize()
-    step_ms = [(step_t[k + 1] - step_t[k]) * 1e3 for k in range(args.steps)]
-    step_ms[-1] = (t_end - step_t[args.steps - 1]) * 1e3
+    step_ms = enc.batch_intervals(min(args.steps, 63))          # (fewer entries than steps when no batch at all went before the first timed one)
     if noise is not None:
         stop.set(); noise.join()
         print("bench: dma noise moved %.0f GB during warm-up and timed steps = %.1f GB/s beside the kernels" % (moved[0] / 1e9, moved[0] / 1e9 / max(1e-9, time.perf_counter() - t_noise)), file=sys.stderr)

@@ -309,6 +309,11 @@ int  rcgpu_ffv1_framemd5_last(rcgpu_ffv1* enc, uint32_t n, uint8_t* out_md5, uin
  * on the stream the kernels were launched on.  names[i] is a static string. Returns the number of entries written. */
 int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* enc, const char** names, float* ms, int cap);
 int rcgpu_ffv1_last_kernel_launches(const rcgpu_ffv1* enc, int index);   /* launches of kernel `index` in the last call */
+/* Device time from the end of one batch to the end of the next for the last n <= min(cap, 63) pairs of batches issued through
+ * rcgpu_ffv1_encode_device (HIP events behind each batch's last kernel, on the stream it ran on; the call waits for the newest): ms[0] is the
+ * oldest interval.  In run-on mode these are the step times of a caller that issues batch after batch -- a stream of the caller's own that waited
+ * for the batches to time them would share a hardware queue with the encoder's and hold the next batch back.  Returns n. */
+int rcgpu_ffv1_batch_intervals(const rcgpu_ffv1* enc, float* ms, int cap);
 /* Totals of the last batch (valid after the stream is synchronised): binary range-coder decisions and packet bytes. */
 int rcgpu_ffv1_last_stats(const rcgpu_ffv1* enc, uint64_t* decisions, uint64_t* packet_bytes);
 

@@ -117,6 +117,7 @@ SYMBOLS = {
     "rcgpu_ffv1_config_record": (_SZ, [_VP, _VP, _SZ]),
     "rcgpu_ffv1_max_packet_bytes": (_SZ, [_VP]),
     "rcgpu_ffv1_device_bytes_per_frame": (C.c_uint64, [_VP, C.c_int]),
+    "rcgpu_ffv1_batch_intervals": (C.c_int, [_VP, C.POINTER(C.c_float), C.c_int]),
     "rcgpu_ffv1_encode_device": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, _VP, _SZ, _VP, _VP]),
     "rcgpu_ffv1_encode_host": (C.c_int, [_VP, C.POINTER(_VP), C.c_uint32, C.POINTER(_VP), C.POINTER(_SZ)]),
     "rcgpu_ffv1_last_error_flags": (C.c_int, [_VP, C.POINTER(C.c_uint32)]),
@@ -366,6 +367,12 @@ class Ffv1Encoder:
         _check(lib().rcgpu_ffv1_last_error_flags(self.h, C.byref(f)), "rcgpu_ffv1_last_error_flags")
         return f.value
 
+    def batch_intervals(self, n: int = 63) -> list[float]:
+        """ms from the end of one batch to the end of the next, for the last n pairs of batches (oldest first)."""
+        buf = (C.c_float * max(1, n))()
+        k = lib().rcgpu_ffv1_batch_intervals(self.h, buf, n)
+        return [float(buf[i]) for i in range(k)]
+
     def kernel_times(self) -> dict[str, float]:
         names = (C.c_char_p * 16)()
         ms = (C.c_float * 16)()
@@ -609,6 +616,12 @@ class Ffv1Decoder:
         _check(lib().rcgpu_ffv1_decoder_verify_kept_end(self.h, out), "rcgpu_ffv1_decoder_verify_kept_end")
         self._begun = 0
         return [(bytes(bytearray(o.md5)), -1 if o.first_diff == 0xFFFFFFFFFFFFFFFF else o.first_diff) for o in out]
+
+    def batch_intervals(self, n: int = 63) -> list[float]:
+        """ms from the end of one batch to the end of the next, for the last n pairs of batches (oldest first)."""
+        buf = (C.c_float * max(1, n))()
+        k = lib().rcgpu_ffv1_batch_intervals(self.h, buf, n)
+        return [float(buf[i]) for i in range(k)]
 
     def kernel_times(self) -> dict[str, float]:
         ms = (C.c_float * 3)()

@@ -1471,6 +1471,8 @@ struct rcgpu_ffv1 {
     hipStream_t model_stream = nullptr, front_stream = nullptr, tail_stream = nullptr;
     hipStream_t front_own = nullptr, chain_stream = nullptr;     // run-on mode with the split coder: k_resolve's own stream, k_rc_range's (high priority)
     hipEvent_t ev_in = nullptr, ev_model = nullptr, ev_tails = nullptr;
+    static constexpr int kBatchEvents = 64;        // a timing event behind every batch's last kernel, on the stream that kernel ran on: rcgpu_ffv1_batch_intervals
+    hipEvent_t ev_batch[kBatchEvents] = {}; unsigned long long nbatch = 0;
     uint64_t last_decisions = 0, last_packet_bytes = 0;
     uint32_t last_n = 0;
     hipEvent_t input_event = nullptr;              // pipeline, run-on mode: the next batch's frames are on the device when this event has happened
@@ -1513,6 +1515,7 @@ extern "C" void rcgpu_ffv1_destroy(rcgpu_ffv1* e)
     for (auto& ev : e->ev_k4) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_rr) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (auto& ev : e->ev_batch) if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     if (e->rc_stream) (void)hipStreamDestroy(e->rc_stream);
     if (e->rr_stream) (void)hipStreamDestroy(e->rr_stream);
@@ -1704,6 +1707,7 @@ extern "C" int rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** out)
         if (he == hipSuccess && j < nseg) he = hipEventCreateWithFlags(&e->ev_rr[j], hipEventDisableTiming);
     }
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    for (auto& ev : e->ev_batch) if (he == hipSuccess) he = hipEventCreate(&ev);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming);
     if (he == hipSuccess) he = hipMemcpy(e->d_const, &e->hc, sizeof(enc_const), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(e->d_geom, e->geom.data(), sizeof(slice_geom) * S, hipMemcpyHostToDevice);
@@ -1918,6 +1922,7 @@ extern "C" int rcgpu_ffv1_encode_device(rcgpu_ffv1* e, const void* const* d_fram
     if (e->exp_skip_rc || TIMING_ENV("RCGPU_EXP_SKIP_B") || TIMING_ENV("RCGPU_EXP_STATES_L2")) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->d_err), 8, 1, tl));
 #endif
     HIP_TRY(hipEventRecord(e->ev_done, tl));
+    HIP_TRY(hipEventRecord(e->ev_batch[e->nbatch % rcgpu_ffv1::kBatchEvents], tl)); e->nbatch++;
     e->used = true; e->joined = false;
     if (!ro) { HIP_TRY(hipStreamWaitEvent(st, e->ev_done, 0)); e->joined = true; }
     if (e->alt.used && !e->alt.joined) { HIP_TRY(hipStreamWaitEvent(st, e->alt.ev_done, 0)); e->alt.joined = true; }
@@ -2034,6 +2039,24 @@ int ffv1_gather(rcgpu_ffv1* e, void* d_packets, size_t packet_stride, void* hip_
     return 0;
 }
 }  // namespace rc
+
+// Device time from the end of one batch to the end of the next, for the last batches issued (their events are waited for): what a caller that issues
+// batch after batch reads a step's duration from without putting anything of its own between the batches.  ms[0] is the oldest interval.
+extern "C" int rcgpu_ffv1_batch_intervals(const rcgpu_ffv1* e, float* ms, int cap)
+{
+    if (!e || !ms || cap <= 0 || e->nbatch < 2) return 0;
+    (void)hipSetDevice(e->cfg.device);
+    const unsigned long long have = std::min<unsigned long long>(e->nbatch, rcgpu_ffv1::kBatchEvents);
+    const int n = int(std::min<unsigned long long>(have - 1, (unsigned long long)cap));
+    if (hipEventSynchronize(e->ev_batch[(e->nbatch - 1) % rcgpu_ffv1::kBatchEvents]) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    for (int i = 0; i < n; i++) {
+        const unsigned long long b = e->nbatch - 1 - (unsigned long long)(n - 1 - i);       // the batch whose end closes interval i
+        float t = 0;
+        if (hipEventElapsedTime(&t, e->ev_batch[(b - 1) % rcgpu_ffv1::kBatchEvents], e->ev_batch[b % rcgpu_ffv1::kBatchEvents]) != hipSuccess) { (void)hipGetLastError(); return i; }
+        ms[i] = t;
+    }
+    return n;
+}
 
 // Sum of the device time of every launch of each kernel in the last encode call (HIP events on the launch stream).
 extern "C" int rcgpu_ffv1_last_kernel_times(const rcgpu_ffv1* e, const char** names, float* ms, int cap)

@@ -498,3 +498,33 @@ def test_bytes_that_reach_unread_symbols_are_reported(built):
             with pytest.raises(api.RcgpuError, match="outgrew"):
                 enc.error_flags()
         enc.close()
+
+
+def test_batch_intervals_time_the_steps_of_a_run_on_caller(built):
+    """rcgpu_ffv1_batch_intervals: the device time between the ends of consecutive batches, from events the library records behind each batch's
+    last kernel -- what bench.py's `step_ms` is made of.  Five batches in run-on mode: four intervals, oldest first, all positive, and together no
+    longer than the wall clock around the five calls and the join."""
+    import time
+    import torch
+    w, h, pixfmt = 512, 270, synth.PIX_RGB16_BE
+    pl, line_bytes = synth.pack_payload(synth.components(w, h, 3, 16, "film", seed=9), pixfmt, True)
+    n = 8
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, 1, 1, 1, 1, max_batch=n)
+    assert enc.batch_intervals() == []
+    d = [torch.frombuffer(bytearray(pl), dtype=torch.uint8).cuda() for _ in range(n)]
+    stride = (enc.max_packet + 255) & ~255
+    pk = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
+    sz = torch.zeros(n, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    enc.set_run_on(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        enc.encode_device([t.data_ptr() for t in d], pk.data_ptr(), stride, sz.data_ptr(), st)
+    enc.join(st); torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    iv = enc.batch_intervals()
+    assert len(iv) == 4 and all(x > 0 for x in iv) and sum(iv) <= wall, (iv, wall)
+    assert enc.batch_intervals(2) == iv[-2:]
+    assert enc.error_flags() == 0
+    enc.close()

@@ -64,13 +64,20 @@ int main(int argc, char** argv)
           "-metadata:s:3", "mimetype=application/octet-stream", "-metadata:s:3", "filename=RAWcooked reversibility data", "-f", "matroska", "out.mkv", "-an", "-f", "framemd5", "out.framemd5" },
         { "ffmpeg", "-xerror", "-framerate", "24", "-r", "24", "-f", "concat", "-safe", "0", "-c:v", "dpx", "-i", "list.txt", "-c:v", "ffv1", "-g", "1", "-slices", "4", "-vf", "vflip", "-y", "-f", "matroska", "out.mkv" },
         { "ffmpeg", "-i", "a.wav", "-c:a", "copy", "-y", "-f", "matroska", "out.mkv" },
+        // rawcooked -c:v ffv1_vulkan:1 (CLI/Global.cpp:367-378) and test/vulkan.sh's hand-made form
+        { "ffmpeg", "-xerror", "-framerate", "24.000000", "-r", "24.000000", "-f", "image2", "-c:v", "dpx", "-start_number", "000000", "-i", "seq/f_%06d.dpx", "-c:a", "flac", "-c:v", "ffv1_vulkan",
+          "-f", "matroska", "-init_hw_device", "vulkan=vk:1", "-slices", "4", "-vf", "hwupload", "-y", "-f", "matroska", "out.mkv" },
+        { "ffmpeg", "-xerror", "-init_hw_device", "vulkan=vk:0,debug=0", "-hwaccel", "vulkan", "-hwaccel_output_format", "vulkan", "-framerate", "24", "-f", "image2", "-c:v", "dpx", "-start_number", "0",
+          "-i", "seq/f_%06d.dpx", "-vf", "hwupload", "-c:v", "ffv1_vulkan", "-coder", "1", "-g", "1", "-level", "3", "-slices", "4", "-rcgpu_own_slice_buffers", "1", "-y", "-f", "matroska", "out.mkv" },
         { "ffmpeg", "-version" },
     };
     static const char* const words[] = { "-i", "-f", "concat", "image2", "matroska", "framemd5", "-attach", "-metadata:s:1", "-metadata:s:v", "filename=RAWcooked reversibility data", "filename=", "-map", "-an",
                                          "-y", "-n", "-slices", "-coder", "-context", "-level", "-g", "-slicecrc", "-vf", "vflip", "-c:v", "-c:a", "ffv1", "flac", "copy", "dpx", "tiff", "exr", "-start_number",
                                          "-framerate", "-r", "-safe", "-rcgpu_context_model", "compact", "-rcgpu_plan_only", "0", "1", "2", "3", "576", "4294967295", "-1", "99999999999999999999", "0/0", "1/0",
                                          "24000/1001", "1e309", "nan", "", "%", "seq/f_%06d.dpx", "seq/f_%09d.dpx", "seq/f_%d.dpx", "seq/f_%s.dpx", "seq/f_%06d%06d.dpx", "a.dpx", "b.dpx", "a.tif", "a.exr", "a.wav",
-                                         "list.txt", "missing.dpx", ".", "/", "/dev/null", "seq", "rev", "-xerror", "-version" };
+                                         "list.txt", "missing.dpx", ".", "/", "/dev/null", "seq", "rev", "-xerror", "-version",
+                                         "-init_hw_device", "vulkan", "vulkan=vk", "vulkan=vk:1", "vulkan=vk:99999999999", "vulkan=:", "vulkan:2,x=y", "vulkanx", "cuda=cu:0", "ffv1_vulkan", "hwupload",
+                                         "vflip,hwupload", "hwupload,,vflip", ",", "-hwaccel", "-rcgpu_own_slice_buffers" };
     const size_t nwords = sizeof words / sizeof words[0];
     size_t accepted = 0, refused = 0;
     FILE* devnull = fopen("/dev/null", "w");
