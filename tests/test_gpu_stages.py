@@ -528,3 +528,54 @@ def test_batch_intervals_time_the_steps_of_a_run_on_caller(built):
     assert enc.batch_intervals(2) == iv[-2:]
     assert enc.error_flags() == 0
     enc.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RCGPU_SOAK_OVERLAY", "6"))))      # soak: RCGPU_SOAK_OVERLAY=60
+def test_overlay_random_geometries(built, seed):
+    """The overlay at random: pictures whose slices all hold 64 K samples or more (so that their coded bytes lie inside the symbol buffer), random
+    size, pixel layout, slice grid, segment count and coder mapping, every frame a patchwork of noise, film and flat areas -- noise in a slice's
+    first lines is what brings the bytes closest to the symbols not read yet.  One batch at a time and in run-on mode: the oracle's packets."""
+    rng = np.random.default_rng(9000 + seed)
+    pixfmt = [synth.PIX_RGB16_BE, synth.PIX_RGB16_LE, synth.PIX_RGB10_FILLEDA_BE, synth.PIX_RGBA16_BE, synth.PIX_Y16_BE, synth.PIX_RGB8, synth.PIX_RGB12_PACKED_BE][int(rng.integers(0, 7))]
+    bits, nc, _, _ = synth.PIX_INFO[pixfmt]
+    slices = [1, 4, 6, 9][int(rng.integers(0, 4))]
+    nh, nv = api.slices_to_grid(slices)
+    need = 66000 // nc + 1                                   # pixels per slice
+    for _ in range(100):
+        w, h = int(rng.integers(260, 1500)), int(rng.integers(160, 900))
+        if (w // nh) * (h // nv) >= need and w * h * nc <= 2_400_000:
+            break
+    else:
+        pytest.skip("no geometry drawn")
+    segments = int([1, 3, 7, 32, 0][int(rng.integers(0, 5))])
+    rc_span = int([1, 8, 64][int(rng.integers(0, 3))])
+    payloads = []
+    for f in range(3):
+        comp = synth.components(w, h, nc, bits, "film", seed=seed * 10 + f).copy()
+        for _ in range(int(rng.integers(1, 6))):
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            x1, y1 = min(w, x0 + int(rng.integers(8, w))), min(h, y0 + int(rng.integers(2, h)))
+            kind = ["noise", "flat", "noise"][int(rng.integers(0, 3))]
+            comp[y0:y1, x0:x1] = synth.components(w, h, nc, bits, kind, seed=seed * 100 + f)[y0:y1, x0:x1]
+        if f == 0:
+            comp[:max(1, h // (8 * nv))] = synth.components(w, h, nc, bits, "noise", seed=seed + 77)[:max(1, h // (8 * nv))]      # noise at the top of the first slice row
+        pl, line_bytes = synth.pack_payload(comp, pixfmt, True)
+        payloads.append(pl)
+    p = ob.Params(w, h, pixfmt, nh, nv, 1, 1)
+    want = [ob.encode_payload(p, pl, line_bytes) for pl in payloads]
+    what = f"{w}x{h} pixfmt {pixfmt} {nh}x{nv} segments {segments} rc_span {rc_span}"
+    L = api.lib()
+    import ctypes as C
+    probe = lambda fl: L.rcgpu_ffv1_device_bytes_per_frame(C.byref(api.Ffv1Config(w, h, pixfmt, line_bytes, nh, nv, 1, 1, 3, 0, segments, fl, 1, 3, rc_span, 0)), 0)
+    assert probe(0) < probe(OWN), "the overlay is off for " + what
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=3, segments=segments, rc_span=rc_span)
+    assert enc.encode_host(payloads) == want, what
+    enc.set_run_on(True)
+    for k in range(3):
+        order = [(k + i) % 3 for i in range(3)]
+        assert enc.encode_host([payloads[i] for i in order]) == [want[i] for i in order], what + " run-on"
+    assert enc.error_flags() == 0
+    enc.close()
+    dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=3)
+    assert dec.decode_host(want, len(payloads[0])) == [bytes(x) for x in payloads], what
+    dec.close()

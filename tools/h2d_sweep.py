@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--slices", type=int, default=64)
     ap.add_argument("--settings", default="336x1,336x1r,250x1,168x2,168x2r,112x3,125x2,84x4,200x1r")
+    ap.add_argument("--rc-span", type=int, default=0, help="rcgpu_ffv1_config::rc_span of the encoders (0 automatic, 1 whole slices, >= 8 split coder)")
     ap.add_argument("--idle", type=float, default=4.0, help="seconds between two settings (the driver wipes freed memory in the background)")
     args = ap.parse_args()
     import numpy as np
@@ -42,7 +43,7 @@ def main():
     for s in args.settings.split(","):
         run_on = s.endswith("r")
         b, l = (int(x) for x in s.rstrip("r").split("x"))
-        cfg = api.Ffv1Config(W, H, synth.PIX_RGB16_BE, W * 6, nh, nv, 1, 1, 0, 0, 0, 0, 1, 3)
+        cfg = api.Ffv1Config(W, H, synth.PIX_RGB16_BE, W * 6, nh, nv, 1, 1, 0, 0, 0, 0, 1, 3, args.rc_span, 0)
         time.sleep(args.idle)
         t0 = time.perf_counter()
         try:
@@ -55,7 +56,7 @@ def main():
         sig = (sizes, [hashlib.md5(bytes(outs[f % nout][:sizes[f]])).hexdigest() for f in range(args.frames - 8, args.frames)])
         if want is None:
             want = sig
-        print(json.dumps({"setting": s, "frames": args.frames, "batch": b, "lanes_per_device": l, "run_on": run_on, "frames_per_second": round(args.frames / st.seconds, 1),
+        print(json.dumps({"setting": s, "rc_span": args.rc_span, "ramp": bool(os.environ.get("RCGPU_RAMP")), "frames": args.frames, "batch": b, "lanes_per_device": l, "run_on": run_on, "frames_per_second": round(args.frames / st.seconds, 1),
                           "seconds": round(st.seconds, 3), "call_seconds": round(wall, 3), "prepare_seconds": round(st.prepare_seconds, 3), "first_packet_seconds": round(st.first_packet_seconds, 3),
                           "last_batch_seconds": round(st.last_batch_seconds, 3), "steady_frames_per_second": round(st.steady_frames_per_second, 1), "batches": st.batches,
                           "batch_frames": st.batch_frames, "packets_equal_to_first_setting": sig == want}))
