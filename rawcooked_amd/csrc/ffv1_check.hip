@@ -62,7 +62,9 @@ struct dec_const {
     uint32_t idx[3], is5[3], nctx[3], kbase[3];
     uint32_t v1, hdr_n;                    // FFV1 version 0 / 1: one slice = the packet, hdr_n header decisions in front of it, no footer
     uint32_t win_cap;                      // bytes a lane's window is filled up to (7; rcgpu_ffv1_decoder_debug_window makes it less, for the tests of the careful path)
-    int16_t  q[3][5][256];                 // the table set of each plane group (the same tables three times when the planes share a set)
+    uint32_t qslot[3], nqslots;            // the DISTINCT table sets of the plane groups, q[0 .. nqslots), and which of them each group uses: the kernel
+                                           // stages only those in LDS (2.5 KB each; one for every stream this encoder writes)
+    int16_t  q[3][5][256];
     uint8_t  one_state[256], zero_state[256];
 };
 
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
 {
     __shared__ uint8_t trans[512];
     __shared__ uint16_t t16[256];
-    __shared__ int16_t qs[3][5][256];
+    extern __shared__ __attribute__((aligned(16))) int16_t qs_dyn[];          // [nqslots][5][256]
     __shared__ __attribute__((aligned(16))) uint8_t slot[64 * 32];
     const int lane = threadIdx.x;
     // Every wavefront of this kernel has the same work and the kernel ends with its slowest one.  A wavefront of another kernel on the same
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     // decoder's instructions go first and the hash takes the slots the decoder leaves while it waits for memory.
     __builtin_amdgcn_s_setprio(3);
     for (int i = lane; i < 256; i += 64) { trans[i] = C->zero_state[i]; trans[256 + i] = C->one_state[i]; t16[i] = uint16_t(C->zero_state[i] | C->one_state[i] << 8); }
-    for (int i = lane; i < 3 * 5 * 256; i += 64) (&qs[0][0][0])[i] = (&C->q[0][0][0])[i];
+    for (int i = lane; i < int(C->nqslots) * 5 * 256; i += 64) qs_dyn[i] = (&C->q[0][0][0])[i];
     __syncthreads();
     const uint32_t chain = blockIdx.x * 64 + lane;
     if (chain >= nchains) return;
@@ -475,11 +477,12 @@ __global__ __launch_bounds__(64) void k_dec_slices(const dec_const* __restrict__
     const bool ov16 = C->overflow16, rgb = C->rgb;
     const int32_t bitmask = int32_t((1u << C->bits) - 1);
     const uint32_t five = C->is5[0] | C->is5[1] << 1 | C->is5[2] << 2, kb0 = C->kbase[0], kb1 = C->kbase[1], kb2 = C->kbase[2];
+    const uint32_t qs0 = C->qslot[0] * 1280, qs1 = C->qslot[1] * 1280, qs2 = C->qslot[2] * 1280;
     for (uint32_t y = 0; y < h; y++)
         for (uint32_t p = 0; p < np; p++) {
             // the plane's group: its table set, its contexts (uniform over the wavefront -- every lane is at the same plane)
             const uint32_t g = rgb ? (p + 1) >> 1 : 0;
-            const int16_t (*q)[256] = qs[g];
+            const int16_t (*q)[256] = reinterpret_cast<const int16_t (*)[256]>(qs_dyn + (g == 0 ? qs0 : g == 1 ? qs1 : qs2));
             const bool is5 = (five >> g) & 1;
             const uint32_t kbase = g == 0 ? kb0 : g == 1 ? kb1 : kb2;
             int32_t* cur = fp + p * pstride + size_t(RING ? y % 3 : y) * pitch * xs;
@@ -960,7 +963,13 @@ static int decoder_create(const rcgpu_ffv1_config* files, const ffv1::stream_des
         const ffv1::quant_model& Q = s.sets[g < ngroups ? s.set_index[g] : s.set_index[0]];
         c.idx[g] = s.set_index[g]; c.nctx[g] = Q.context_count; c.kbase[g] = nkeys;
         c.is5[g] = Q.q[3][127] != 0;                                  // FFV1_Slice.cpp:453
-        memcpy(c.q[g], Q.q, sizeof c.q[g]);
+        {   // the group's table set: a slot of its own unless a group before it uses the same set
+            auto eff = [&](uint32_t x) { return x < ngroups ? s.set_index[x] : s.set_index[0]; };      // (a group the picture does not have reads group 0's)
+            uint32_t k = 0;
+            while (k < g && eff(k) != eff(g)) k++;
+            if (k < g) c.qslot[g] = c.qslot[k];
+            else { c.qslot[g] = c.nqslots; memcpy(c.q[c.nqslots], Q.q, sizeof c.q[0]); c.nqslots++; }
+        }
         if (g < ngroups) { nkeys += Q.context_count; coded |= !s.initial[s.set_index[g]].empty(); }
     }
     memcpy(c.one_state, s.one_state, 256);
@@ -1063,10 +1072,10 @@ extern "C" int rcgpu_ffv1_decoder_decode_device(rcgpu_ffv1_decoder* d, const voi
     hipStream_t ks = d->dec_stream ? d->dec_stream : st;
     if (ks != st) HIP_TRY(hipStreamWaitEvent(ks, d->ev[1], 0));
     if (d->ring)
-        hipLaunchKernelGGL(k_dec_slices<true>, dim3((nchains + 63) / 64), dim3(64), 0, ks, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
+        hipLaunchKernelGGL(k_dec_slices<true>, dim3((nchains + 63) / 64), dim3(64), size_t(c.nqslots) * 2560, ks, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
                            d->d_states + d->states_off, d->nkeys, d->d_planes, d->d_out_ptrs, d->ring_w, d->d_err, d->d_hdr);
     else
-        hipLaunchKernelGGL(k_dec_slices<false>, dim3((nchains + 63) / 64), dim3(64), 0, ks, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
+        hipLaunchKernelGGL(k_dec_slices<false>, dim3((nchains + 63) / 64), dim3(64), size_t(c.nqslots) * 2560, ks, d->d_const, d->d_pkt_ptrs, d->d_slice_start, d->d_slice_len, nchains,
                            d->d_states + d->states_off, d->nkeys, d->d_planes, d->d_out_ptrs, 0u, d->d_err, d->d_hdr);
     HIP_TRY(hipEventRecord(d->ev[2], ks));
     if (ks != st) HIP_TRY(hipStreamWaitEvent(st, d->ev[2], 0));
