@@ -176,7 +176,8 @@ typedef struct rcgpu_ffv1 rcgpu_ffv1;
 int    rcgpu_ffv1_create(const rcgpu_ffv1_config* cfg, rcgpu_ffv1** enc);
 /* Device memory ONE frame in flight costs an encoder of this configuration, the caller's payload and packet buffers included (symbols, context
  * states, decision windows, checkpoints, slice byte buffers where they are not overlaid; run_on != 0: with the second bank of run-on mode).
- * 4096x2160 RGB16, 64 slices: 348 MB, 454 MB in run-on mode.  Needs no device: what a caller sizes max_batch with (the job level does). */
+ * 4096x2160 RGB16, 64 slices: 379 MB, 506 MB in run-on mode -- with decision windows for the worst case of 35 decisions per sample; film content
+ * measures ~330 / ~460.  Needs no device: what a caller sizes max_batch with (the job level does). */
 uint64_t rcgpu_ffv1_device_bytes_per_frame(const rcgpu_ffv1_config* cfg, int run_on);
 void   rcgpu_ffv1_destroy(rcgpu_ffv1* enc);
 /* FFV1 configuration record incl. CRC = Matroska CodecPrivate (parsed at FFV1_Parameters.cpp:23-183). */
