@@ -579,3 +579,9 @@ def test_overlay_random_geometries(built, seed):
     dec = api.Ffv1Decoder(w, h, pixfmt, line_bytes, nh, nv, 1, 1, max_batch=3)
     assert dec.decode_host(want, len(payloads[0])) == [bytes(x) for x in payloads], what
     dec.close()
+    # ... and with the compact context model (states in LDS, k_resolve<true>): the same overlay under the other kernel
+    p2 = ob.Params(w, h, pixfmt, nh, nv, 1, 2)
+    enc = api.Ffv1Encoder(w, h, pixfmt, line_bytes, nh, nv, 1, 2, max_batch=3, segments=segments, rc_span=rc_span)
+    assert enc.encode_host(payloads[:2]) == [ob.encode_payload(p2, pl, line_bytes) for pl in payloads[:2]], what + " compact model"
+    assert enc.error_flags() == 0
+    enc.close()
